@@ -1,0 +1,171 @@
+"""Deterministic synthetic weights / conditioning / noise for the RAG denoising path.
+
+Everything is drawn from ``numpy.random.Generator(PCG64(seed))`` so that this
+container (where golden fixtures are generated from the imported reference) and
+the GPU box (where the HIP path is checked) regenerate bit-identical inputs; only
+the *outputs* are committed as fixtures.
+
+Shapes / key names follow the reference's state-dict contract:
+``scripts/model/RAG.py:56-77`` (TED), ``scripts_beat/model/RAG.py:56-77`` (BEAT),
+``scripts/model/mlp_module.py:37-100``, ``scripts/model/audio_enc.py:9-20``.
+
+Weights are re-drawn with non-degenerate scale on purpose: the reference's own
+init (``mlp_module.py:63-65`` xavier gain 1e-8, ``RAG.py:67`` constant 1e-6) makes
+92 % of the FLOPs numerically invisible and would hide kernel bugs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+SEED_WEIGHTS = 7
+SEED_COND = 3
+SEED_NOISE = 99
+
+
+@dataclass(frozen=True)
+class PathConfig:
+    """Static shape of one dataset variant of the path."""
+    name: str
+    njoints: int
+    nfeats: int
+    nframes: int = 34
+    n_prefix_tokens: int = 1      # style (TED) / style+emotion (BEAT)
+    n_pre_seq: int = 4            # RAG.py:70
+    audio_len: int = 36267
+    latent_dim: int = 512
+    layers: int = 8
+    n_speakers: int = 1400        # RAG.py:65
+    n_emotions: int = 0
+    audio_feat: int = 256
+
+    @property
+    def jf(self) -> int:
+        return self.njoints * self.nfeats
+
+    @property
+    def seq_len(self) -> int:
+        return self.nframes + self.n_prefix_tokens
+
+    @property
+    def in_feats(self) -> int:     # input_mapping fan-in, RAG.py:62
+        return 2 * self.jf + 1 + self.audio_feat
+
+
+TED = PathConfig("ted", njoints=9, nfeats=3, n_prefix_tokens=1, audio_len=36267)
+BEAT = PathConfig("beat", njoints=47, nfeats=6, n_prefix_tokens=2, audio_len=36266,
+                  n_emotions=8)
+CONFIGS = {"ted": TED, "beat": BEAT}
+
+AUDIO_CONV = [(1, 32, 5, 1600), (32, 64, 6, 0), (64, 128, 6, 0), (128, 256, 6, 0)]  # (cin,cout,stride,pad), k=15
+AUDIO_KERNEL = 15
+
+
+def audio_lengths(n: int):
+    """Conv output lengths, audio_enc.py:9-20 (36267 -> 7891 -> 1313 -> 217 -> 34)."""
+    out = []
+    for (_, _, s, p) in AUDIO_CONV:
+        n = (n + 2 * p - AUDIO_KERNEL) // s + 1
+        out.append(n)
+    return out
+
+
+def _rng(seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def make_state_dict(cfg: PathConfig, seed: int = SEED_WEIGHTS) -> dict:
+    """Non-degenerate weights under the reference's state-dict key names."""
+    g = _rng(seed)
+    D, S, L = cfg.latent_dim, cfg.seq_len, cfg.layers
+    sd = {}
+
+    def uni(shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return _f32(g.uniform(-b, b, size=shape))
+
+    for i in range(L):
+        p = f"backbone.mlps.{i}."
+        sd[p + "block1.0.alpha"] = _f32(1.0 + 0.1 * g.standard_normal((1, 1, D)))
+        sd[p + "block1.0.beta"] = _f32(0.05 * g.standard_normal((1, 1, D)))
+        sd[p + "block1.1.weight"] = _f32(g.standard_normal((S, S, 1)) * (0.6 / np.sqrt(S)))
+        sd[p + "block1.1.bias"] = _f32(0.05 * g.standard_normal((S,)))
+        sd[p + "block2.0.alpha"] = _f32(1.0 + 0.1 * g.standard_normal((1, 1, D)))
+        sd[p + "block2.0.beta"] = _f32(0.05 * g.standard_normal((1, 1, D)))
+        sd[p + "block2.1.weight"] = _f32(g.standard_normal((D, D)) * (0.6 / np.sqrt(D)))
+        sd[p + "block2.1.bias"] = _f32(0.05 * g.standard_normal((D,)))
+    for j in (0, 2):
+        sd[f"backbone.embed_timestep.time_embed.{j}.weight"] = uni((D, D), D)
+        sd[f"backbone.embed_timestep.time_embed.{j}.bias"] = uni((D,), D)
+    sd["input_mapping.weight"] = uni((D, cfg.in_feats), cfg.in_feats)
+    sd["input_mapping.bias"] = uni((D,), cfg.in_feats)
+    sd["speaker_embedding.weight"] = _f32(0.5 * g.standard_normal((cfg.n_speakers, 256)))
+    sd["speaker_mu.weight"] = uni((D, 256), 256)
+    sd["speaker_mu.bias"] = uni((D,), 256)
+    sd["speaker_logvar.weight"] = _f32(0.3 * g.uniform(-1, 1, size=(D, 256)) / 16.0)
+    sd["speaker_logvar.bias"] = _f32(-2.0 + 0.1 * g.standard_normal((D,)))
+    for idx, (cin, cout, _, _) in zip((0, 3, 6, 9), AUDIO_CONV):
+        fan = cin * AUDIO_KERNEL
+        sd[f"audio_encoder.feat_extractor.{idx}.weight"] = uni((cout, cin, AUDIO_KERNEL), fan)
+        sd[f"audio_encoder.feat_extractor.{idx}.bias"] = uni((cout,), fan)
+    sd["output_process.poseFinal.weight"] = uni((cfg.jf, D), D)
+    sd["output_process.poseFinal.bias"] = uni((cfg.jf,), D)
+    if cfg.n_emotions:
+        sd["emotion_embedding.weight"] = _f32(0.3 * g.standard_normal((cfg.n_emotions, D)))
+    return sd
+
+
+def make_cond(cfg: PathConfig, batch: int, seed: int = SEED_COND, scale: float = 1.5,
+              first_sample: int = 0, total: int | None = None) -> dict:
+    """Synthetic conditioning. Drawn for ``total`` samples and sliced
+    ``[first_sample, first_sample+batch)`` so shards of a larger job see the same data."""
+    total = batch if total is None else total
+    g = _rng(seed)
+    audio = _f32(0.1 * g.standard_normal((total, cfg.audio_len)))
+    origin_x = _f32(0.3 * g.standard_normal((total, cfg.njoints, cfg.nfeats, cfg.nframes)))
+    n_vid = 1370 if cfg.name == "ted" else 30
+    vid = g.integers(0, n_vid, size=(total,)).astype(np.int64)
+    sl = slice(first_sample, first_sample + batch)
+    y = {"audio_input": audio[sl].copy(), "origin_x": origin_x[sl].copy(),
+         "vid_indices": vid[sl].copy(),
+         "scale": np.full((batch,), scale, dtype=np.float32)}
+    if cfg.n_emotions:
+        emo = g.integers(0, cfg.n_emotions, size=(total, 1)).astype(np.int64)
+        y["emo"] = np.repeat(emo, cfg.nframes, axis=1)[sl].copy()
+    return y
+
+
+def make_init_image(cfg: PathConfig, batch: int, seed: int = SEED_COND + 1000) -> np.ndarray:
+    """Stand-in for the SAG decoder output (config 3 until the SAG row is built)."""
+    g = _rng(seed)
+    return _f32(0.3 * g.standard_normal((batch, cfg.njoints, cfg.nfeats, cfg.nframes)))
+
+
+class NoiseTape:
+    """Pre-drawn N(0,1) tape consumed in the reference's draw order:
+    ``randn(B,J,F,T)`` once, then per step ``randn_like(B,1,512)`` (cond pass),
+    ``randn_like(B,1,512)`` (uncond pass), ``randn_like(B,J,F,T)`` (step noise).
+    RAG.py:120, cfg_sampler.py:29-30, gaussian_diffusion.py:543/787, :704/:975."""
+
+    def __init__(self, cfg: PathConfig, batch: int, n_steps: int, seed: int = SEED_NOISE):
+        g = _rng(seed)
+        shp = (batch, cfg.njoints, cfg.nfeats, cfg.nframes)
+        self.x_init = _f32(g.standard_normal(shp))
+        self.eps = _f32(g.standard_normal((n_steps, 2, batch, cfg.latent_dim)))
+        self.noise = _f32(g.standard_normal((n_steps,) + shp))
+        self.n_steps = n_steps
+        self.shape = shp
+
+    def draws(self):
+        """Flat list of arrays in consumption order."""
+        out = [self.x_init]
+        for i in range(self.n_steps):
+            out.append(self.eps[i, 0][:, None, :])
+            out.append(self.eps[i, 1][:, None, :])
+            out.append(self.noise[i])
+        return out
