@@ -1,0 +1,184 @@
+/*
+ * ls_hip.h -- C-ABI of the MI355X-native RAG denoising / diffusion-sampling engine.
+ *
+ * The reference (zyhbili/LivelySpeaker) is pure Python/PyTorch: it has no FFI, plugin registry
+ * or operator API for this path.  Its "operator interface" is the pair
+ *     model(x, timesteps, y=dict)                      scripts/model/RAG.py:98-133
+ *     diffusion.p_sample_loop / ddim_sample_loop(...)  scripts/diffusion/gaussian_diffusion.py:608-671, 895-943
+ * The entry points below are what a ctypes binding on the reference side would call to replace
+ * those two; each cites the reference code it stands in for.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * LS_E* code and never throws across the ABI; ls_last_error() gives the message.  One handle owns
+ * one GPU (one HIP stream, its captured hipGraphs, all device buffers); a handle is not
+ * thread-safe, distinct handles are independent.  Pointers in ls_cond / ls_sample_args /
+ * ls_forward_args are host pointers unless the struct's on_device flag is set, in which case they
+ * are device pointers on the handle's GPU.  The library never frees or retains caller memory.
+ * All tensors are fp32, C-contiguous, in the reference's layouts ([B, njoints, nfeats, nframes]).
+ */
+#ifndef LS_HIP_H
+#define LS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS_ABI_VERSION 1
+
+enum {
+    LS_OK = 0,
+    LS_EINVAL = -1,   /* bad argument / shape / unknown key            */
+    LS_ESTATE = -2,   /* call order (weights / schedule / prepare missing) */
+    LS_EHIP = -3,     /* a HIP runtime call failed                     */
+    LS_ENOMEM = -4,
+    LS_EUNSUPPORTED = -5
+};
+
+enum { LS_SAMPLER_DDPM = 0, LS_SAMPLER_DDIM = 1 };
+enum { LS_NOISE_TAPE = 0, LS_NOISE_PHILOX = 1 };
+
+typedef struct ls_handle ls_handle;
+
+/* Static shape of the denoiser: RAG.__init__ (scripts/model/RAG.py:17-77; BEAT variant
+ * scripts_beat/model/RAG.py:56,72-74) + get_model_args (scripts/mdm_utils/model_util.py:20-37). */
+typedef struct ls_config {
+    int32_t njoints;          /* 9 (TED) | 47 (BEAT)                               */
+    int32_t nfeats;           /* 3 | 6                                             */
+    int32_t nframes;          /* 34 (the token-mixing conv fixes it)               */
+    int32_t n_prefix_tokens;  /* 1 = [style] | 2 = [style, emotion]                */
+    int32_t n_pre_seq;        /* 4 prefix poses (RAG.py:70)                        */
+    int32_t latent_dim;       /* 512                                               */
+    int32_t layers;           /* 8                                                 */
+    int32_t audio_len;        /* 36267 | 36266 raw samples -> 34 audio frames      */
+    int32_t n_speakers;       /* 1400 (RAG.py:65)                                  */
+    int32_t n_emotions;       /* 0 | 8                                             */
+    int32_t device;           /* HIP device ordinal                                */
+    int32_t reserved;
+} ls_config;
+
+/* GaussianDiffusion.__init__ tables after SpacedDiffusion (gaussian_diffusion.py:168-204,
+ * respace.py:74-88), fp64 as the reference keeps them; cast to fp32 per step exactly like
+ * _extract_into_tensor (gaussian_diffusion.py:1651-1664).  Each array has n_steps entries. */
+typedef struct ls_schedule {
+    int32_t n_steps;
+    int32_t reserved;
+    const int64_t* timestep_map;                 /* _WrappedModel, respace.py:125-130 */
+    const double* sqrt_alphas_cumprod;           /* q_sample, :240-258               */
+    const double* sqrt_one_minus_alphas_cumprod;
+    const double* posterior_mean_coef1;          /* q_posterior_mean_variance :260-282 */
+    const double* posterior_mean_coef2;
+    const double* posterior_log_variance_clipped;/* p_sample :507-558 (FIXED_SMALL)  */
+    const double* alphas_cumprod;                /* ddim_sample :745-798             */
+    const double* alphas_cumprod_prev;
+    const double* sqrt_recip_alphas_cumprod;     /* _predict_eps_from_xstart :418-422 */
+    const double* sqrt_recipm1_alphas_cumprod;
+} ls_schedule;
+
+/* model_kwargs['y'] of the callers (scripts/test_RAG_ted.py:64-70): only the keys RAG.forward
+ * reads.  origin_x is NOT mutated here (the Python shim reproduces RAG.py:110's in-place zeroing). */
+typedef struct ls_cond {
+    int32_t batch;
+    int32_t on_device;
+    const float* audio_input;   /* [B, audio_len]                                  */
+    const float* origin_x;      /* [B, J, F, T]; frames >= n_pre_seq are ignored   */
+    const int64_t* vid_indices; /* [B] < n_speakers                                */
+    const int64_t* emo;         /* [B] emotion id of frame 0, or NULL (TED)        */
+    const float* scale;         /* [B] guidance scale (cfg_sampler.py:31)          */
+} ls_cond;
+
+/* One call of p_sample_loop / ddim_sample_loop with ClassifierFreeSampleModel as the model. */
+typedef struct ls_sample_args {
+    int32_t sampler;            /* LS_SAMPLER_*                                     */
+    int32_t noise_mode;         /* LS_NOISE_*                                       */
+    int32_t skip_timesteps;     /* gaussian_diffusion.py:712 / :982                 */
+    int32_t const_noise;        /* :545-546 / :706-707 (TAPE mode only)             */
+    int32_t on_device;
+    int32_t use_graph;          /* 1: capture the step loop in a hipGraph and replay */
+    int32_t clip_denoised;      /* clamp pred_xstart to [-1,1] (callers pass False)  */
+    int32_t reserved;
+    float eta;                  /* DDIM eta (callers never pass it: 0)              */
+    int32_t n_dump;             /* dump_steps (DDPM only, :660-671)                 */
+    const int32_t* dump_steps;  /* executed-step counters (0 = first executed step), host memory */
+    float* dump_out;            /* [n_dump, B, J, F, T] pred_xstart                 */
+    const float* x_init;        /* [B,J,F,T] x_T = the loop's first randn; NULL only with PHILOX */
+    const float* init_image;    /* [B,J,F,T] or NULL (zeros when skip_timesteps>0)  */
+    const float* eps_tape;      /* TAPE: [n_exec, 2, B, latent_dim] style eps (cond, uncond) */
+    const float* noise_tape;    /* TAPE: [n_exec, B, J, F, T] per-step randn_like(x) */
+    uint64_t seed;              /* PHILOX key                                       */
+    uint64_t sample_offset;     /* PHILOX: global index of sample 0 (shard-invariant streams) */
+    float* out;                 /* [B, J, F, T]                                     */
+} ls_sample_args;
+
+/* One RAG.forward pair (cond / uncond) and optionally the CFG combination, for model(x,t,y)
+ * parity (RAG.py:98-133, cfg_sampler.py:24-31). Any of the three outputs may be NULL. */
+typedef struct ls_forward_args {
+    int32_t on_device;
+    int32_t reserved;
+    const float* x;             /* [B,J,F,T]                                        */
+    const int64_t* timesteps;   /* [B] model-scale t in [0, 5000)                   */
+    const float* eps_cond;      /* [B, latent_dim] randn_like of reparameterize (RAG.py:12) */
+    const float* eps_uncond;    /* [B, latent_dim]                                  */
+    float* out_cond;            /* [B,J,F,T]                                        */
+    float* out_uncond;
+    float* out_cfg;             /* out_u + scale*(out_c - out_u)                    */
+    float* trace;               /* debug: [B, layers+1, 2*S, latent_dim] residual stream, or NULL */
+} ls_forward_args;
+
+/* One p_sample / ddim_sample step (gaussian_diffusion.py:507-558, 745-798) at schedule index i. */
+typedef struct ls_step_args {
+    int32_t sampler;
+    int32_t index;              /* schedule index i (model sees timestep_map[i])    */
+    int32_t on_device;
+    float eta;
+    int32_t clip_denoised;
+    int32_t reserved;
+    const float* x;             /* [B,J,F,T]                                        */
+    const float* eps_cond;
+    const float* eps_uncond;
+    const float* noise;         /* [B,J,F,T]                                        */
+    float* sample;              /* [B,J,F,T]                                        */
+    float* pred_xstart;         /* [B,J,F,T] or NULL                                */
+} ls_step_args;
+
+typedef struct ls_timing {
+    float prepare_ms;           /* last ls_prepare, GPU time (HIP events on the handle's stream) */
+    float loop_ms;              /* last ls_sample: first step launch .. last step done */
+    float total_ms;             /* last ls_sample incl. layout conversion and copies */
+    int32_t n_step_launches;
+    int32_t graph_replayed;     /* 1 if the loop ran as a hipGraph replay           */
+} ls_timing;
+
+int ls_abi_version(void);
+int ls_create(const ls_config* cfg, ls_handle** out);
+void ls_destroy(ls_handle* h);
+const char* ls_last_error(const ls_handle* h);   /* h may be NULL: error of the last failed ls_create */
+
+/* load_state_dict (scripts/mdm_utils/model_util.py:5-10): key = reference state-dict key, data =
+ * fp32 host array of n elements.  '*.pe' buffers are accepted and ignored (recomputed).
+ * ls_commit_weights builds the MFMA-ordered device images; it fails if a required key is missing. */
+int ls_set_weight(ls_handle* h, const char* key, const float* data, size_t n);
+int ls_commit_weights(ls_handle* h);
+
+int ls_set_schedule(ls_handle* h, const ls_schedule* s);
+int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */
+int ls_sample(ls_handle* h, const ls_sample_args* a);
+int ls_forward(ls_handle* h, const ls_forward_args* a);
+int ls_step(ls_handle* h, const ls_step_args* a);
+/* elementwise q_sample (gaussian_diffusion.py:240-258) at schedule index i; pointers per on_device */
+int ls_q_sample(ls_handle* h, int index, int on_device, size_t n, const float* x_start,
+                const float* noise, float* out);
+
+/* Read back a prepared intermediate into host memory (parity tests of the once-per-call stages):
+ * "audio_feat" [B,T,256], "static_c"/"static_u" [B,T,D], "z_mu"/"z_logvar"/"z_std" [B,D],
+ * "temb" [n_steps,D].  Returns the element count, or a negative error. */
+long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capacity);
+int ls_get_timing(const ls_handle* h, ls_timing* out);
+int ls_synchronize(ls_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LS_HIP_H */

@@ -1,0 +1,292 @@
+"""ctypes binding of ``include/ls_hip.h`` (the C-ABI of the gfx950 engine).
+
+There is deliberately NO fallback: if ``libls_hip.so`` is missing or fails to load, importing the
+engine raises; nothing in the product path ever routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+
+LS_SAMPLER_DDPM, LS_SAMPLER_DDIM = 0, 1
+LS_NOISE_TAPE, LS_NOISE_PHILOX = 0, 1
+
+
+class LsConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("njoints", "nfeats", "nframes", "n_prefix_tokens", "n_pre_seq",
+                                         "latent_dim", "layers", "audio_len", "n_speakers", "n_emotions",
+                                         "device", "reserved")]
+
+
+class LsSchedule(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("reserved", C.c_int32), ("timestep_map", c_i64p)] + [
+        (n, c_f64p) for n in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_mean_coef1",
+                              "posterior_mean_coef2", "posterior_log_variance_clipped", "alphas_cumprod",
+                              "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")]
+
+
+class LsCond(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("on_device", C.c_int32), ("audio_input", C.c_void_p),
+                ("origin_x", C.c_void_p), ("vid_indices", C.c_void_p), ("emo", C.c_void_p), ("scale", C.c_void_p)]
+
+
+class LsSampleArgs(C.Structure):
+    _fields_ = [("sampler", C.c_int32), ("noise_mode", C.c_int32), ("skip_timesteps", C.c_int32),
+                ("const_noise", C.c_int32), ("on_device", C.c_int32), ("use_graph", C.c_int32),
+                ("clip_denoised", C.c_int32), ("reserved", C.c_int32), ("eta", C.c_float), ("n_dump", C.c_int32), ("dump_steps", c_i32p), ("dump_out", C.c_void_p),
+                ("x_init", C.c_void_p), ("init_image", C.c_void_p), ("eps_tape", C.c_void_p),
+                ("noise_tape", C.c_void_p), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
+                ("out", C.c_void_p)]
+
+
+class LsForwardArgs(C.Structure):
+    _fields_ = [("on_device", C.c_int32), ("reserved", C.c_int32), ("x", C.c_void_p), ("timesteps", C.c_void_p),
+                ("eps_cond", C.c_void_p), ("eps_uncond", C.c_void_p), ("out_cond", C.c_void_p),
+                ("out_uncond", C.c_void_p), ("out_cfg", C.c_void_p), ("trace", C.c_void_p)]
+
+
+class LsStepArgs(C.Structure):
+    _fields_ = [("sampler", C.c_int32), ("index", C.c_int32), ("on_device", C.c_int32), ("eta", C.c_float),
+                ("clip_denoised", C.c_int32), ("reserved", C.c_int32), ("x", C.c_void_p), ("eps_cond", C.c_void_p), ("eps_uncond", C.c_void_p), ("noise", C.c_void_p),
+                ("sample", C.c_void_p), ("pred_xstart", C.c_void_p)]
+
+
+class LsTiming(C.Structure):
+    _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32)]
+
+
+EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
+           "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
+           "ls_get_timing", "ls_synchronize")
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load_library(build_if_missing: bool = True):
+    """dlopen libls_hip.so (building it in-tree first if it is missing or stale and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if build_if_missing and _build.is_stale():
+        try:
+            _build.build_library()
+        except Exception as e:      # no hipcc on this box: fall through to whatever .so travelled here
+            if not os.path.exists(path):
+                raise EngineError(f"libls_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise EngineError(f"{path} not found: run `python -m livelyspeaker_amd.build` (no CPU fallback exists)")
+    lib = C.CDLL(path)
+    lib.ls_abi_version.restype = C.c_int
+    lib.ls_create.argtypes = [C.POINTER(LsConfig), C.POINTER(C.c_void_p)]
+    lib.ls_destroy.argtypes = [C.c_void_p]
+    lib.ls_destroy.restype = None
+    lib.ls_last_error.argtypes = [C.c_void_p]
+    lib.ls_last_error.restype = C.c_char_p
+    lib.ls_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_commit_weights.argtypes = [C.c_void_p]
+    lib.ls_set_schedule.argtypes = [C.c_void_p, C.POINTER(LsSchedule)]
+    lib.ls_prepare.argtypes = [C.c_void_p, C.POINTER(LsCond)]
+    lib.ls_sample.argtypes = [C.c_void_p, C.POINTER(LsSampleArgs)]
+    lib.ls_forward.argtypes = [C.c_void_p, C.POINTER(LsForwardArgs)]
+    lib.ls_step.argtypes = [C.c_void_p, C.POINTER(LsStepArgs)]
+    lib.ls_q_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ls_read.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_read.restype = C.c_longlong
+    lib.ls_get_timing.argtypes = [C.c_void_p, C.POINTER(LsTiming)]
+    lib.ls_synchronize.argtypes = [C.c_void_p]
+    if lib.ls_abi_version() != 1:
+        raise EngineError("libls_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _np32(a) -> np.ndarray:
+    """Host fp32 C-contiguous view/copy of a numpy array or CPU torch tensor."""
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _np64i(a) -> np.ndarray:
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One handle = one GPU. Thin, typed wrapper over the C-ABI; all arrays in/out are host numpy
+    (torch CUDA tensors on the same device may be passed to ``sample``/``prepare`` via ``*_device``)."""
+
+    def __init__(self, njoints, nfeats, n_prefix_tokens, audio_len, n_emotions=0, nframes=34, n_pre_seq=4,
+                 latent_dim=512, layers=8, n_speakers=1400, device=0):
+        self.lib = load_library()
+        self.cfg = LsConfig(njoints, nfeats, nframes, n_prefix_tokens, n_pre_seq, latent_dim, layers, audio_len,
+                            n_speakers, n_emotions, device, 0)
+        self.h = C.c_void_p()
+        rc = self.lib.ls_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise EngineError(f"ls_create failed ({rc}): {self.lib.ls_last_error(None).decode()}")
+        self.J, self.F, self.T, self.D = njoints, nfeats, nframes, latent_dim
+        self.S = nframes + n_prefix_tokens
+        self.layers = layers
+        self.device = device
+        self.batch = 0
+        self.n_steps = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.ls_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.ls_last_error(self.h).decode()}")
+        return rc
+
+    # ---- weights / schedule --------------------------------------------------------------------
+    def load_state_dict(self, sd: dict):
+        for k, v in sd.items():
+            a = _np32(v)
+            self._check(self.lib.ls_set_weight(self.h, k.encode(), a.ctypes.data_as(c_f32p), a.size), f"ls_set_weight({k})")
+        self._check(self.lib.ls_commit_weights(self.h), "ls_commit_weights")
+
+    def set_schedule(self, sched):
+        """sched: object with the GaussianDiffusion table attributes + timestep_map."""
+        tabs = {}
+        s = LsSchedule()
+        s.n_steps = int(sched.num_timesteps)
+        tmap = np.ascontiguousarray(np.asarray(sched.timestep_map), dtype=np.int64)
+        s.timestep_map = tmap.ctypes.data_as(c_i64p)
+        for name, _ in LsSchedule._fields_[3:]:
+            tabs[name] = np.ascontiguousarray(getattr(sched, name), dtype=np.float64)
+            assert tabs[name].shape == (s.n_steps,), name
+            setattr(s, name, tabs[name].ctypes.data_as(c_f64p))
+        self._check(self.lib.ls_set_schedule(self.h, C.byref(s)), "ls_set_schedule")
+        self.n_steps = s.n_steps
+
+    # ---- per call --------------------------------------------------------------------------------
+    def prepare(self, y: dict):
+        audio = _np32(y["audio_input"])
+        ox = _np32(y["origin_x"])
+        vid = _np64i(y["vid_indices"])
+        scale = _np32(y["scale"])
+        B = audio.shape[0]
+        assert ox.shape == (B, self.J, self.F, self.T), ox.shape
+        c = LsCond(B, 0, _ptr(audio), _ptr(ox), _ptr(vid), None, _ptr(scale))
+        if self.cfg.n_prefix_tokens == 2:
+            emo = _np64i(y["emo"])
+            emo0 = np.ascontiguousarray(emo[:, 0] if emo.ndim == 2 else emo)
+            c.emo = _ptr(emo0)
+        self._check(self.lib.ls_prepare(self.h, C.byref(c)), "ls_prepare")
+        self.batch = B
+
+    def _xshape(self):
+        return (self.batch, self.J, self.F, self.T)
+
+    def forward(self, x, t, eps_c, eps_u, trace=False):
+        x, eps_c, eps_u, t = _np32(x), _np32(eps_c).reshape(self.batch, self.D), _np32(eps_u).reshape(self.batch, self.D), _np64i(t)
+        assert x.shape == self._xshape(), (x.shape, self._xshape())
+        oc, ou, og = (np.empty(self._xshape(), np.float32) for _ in range(3))
+        tr = np.empty((self.batch, self.layers + 1, 2 * self.S, self.D), np.float32) if trace else None
+        a = LsForwardArgs(0, 0, _ptr(x), _ptr(t), _ptr(eps_c), _ptr(eps_u), _ptr(oc), _ptr(ou), _ptr(og),
+                          _ptr(tr) if trace else None)
+        self._check(self.lib.ls_forward(self.h, C.byref(a)), "ls_forward")
+        return (oc, ou, og, tr) if trace else (oc, ou, og)
+
+    def step(self, sampler, index, x, eps_c, eps_u, noise, eta=0.0, clip_denoised=False):
+        x, noise = _np32(x), _np32(noise)
+        eps_c, eps_u = _np32(eps_c).reshape(self.batch, self.D), _np32(eps_u).reshape(self.batch, self.D)
+        out, x0 = np.empty(self._xshape(), np.float32), np.empty(self._xshape(), np.float32)
+        a = LsStepArgs(sampler, index, 0, eta, int(clip_denoised), 0, _ptr(x), _ptr(eps_c), _ptr(eps_u), _ptr(noise), _ptr(out), _ptr(x0))
+        self._check(self.lib.ls_step(self.h, C.byref(a)), "ls_step")
+        return out, x0
+
+    def q_sample(self, index, x_start, noise):
+        x_start, noise = _np32(x_start), _np32(noise)
+        out = np.empty_like(x_start)
+        self._check(self.lib.ls_q_sample(self.h, index, 0, x_start.size, _ptr(x_start), _ptr(noise), _ptr(out)), "ls_q_sample")
+        return out
+
+    def sample(self, sampler=LS_SAMPLER_DDPM, x_init=None, eps_tape=None, noise_tape=None, init_image=None,
+               skip_timesteps=0, eta=0.0, const_noise=False, dump_steps=None, philox_seed=None, sample_offset=0,
+               use_graph=True, clip_denoised=False):
+        """Run the whole loop. TAPE mode when tapes are given, PHILOX mode when ``philox_seed`` is."""
+        a = LsSampleArgs()
+        a.sampler, a.skip_timesteps, a.const_noise, a.on_device = sampler, skip_timesteps, int(const_noise), 0
+        a.use_graph, a.eta, a.clip_denoised = int(use_graph), eta, int(clip_denoised)
+        keep = []
+        if philox_seed is None:
+            a.noise_mode = LS_NOISE_TAPE
+            n_exec = self.n_steps - skip_timesteps
+            e, n = _np32(eps_tape), _np32(noise_tape)
+            assert e.shape == (n_exec, 2, self.batch, self.D), e.shape
+            assert n.shape == (n_exec,) + self._xshape(), n.shape
+            a.eps_tape, a.noise_tape = _ptr(e), _ptr(n)
+            keep += [e, n]
+        else:
+            a.noise_mode = LS_NOISE_PHILOX
+            a.seed, a.sample_offset = int(philox_seed), int(sample_offset)
+        if x_init is not None:
+            xi = _np32(x_init)
+            assert xi.shape == self._xshape()
+            a.x_init = _ptr(xi)
+            keep.append(xi)
+        if init_image is not None:
+            ii = _np32(init_image)
+            assert ii.shape == self._xshape()
+            a.init_image = _ptr(ii)
+            keep.append(ii)
+        out = np.empty(self._xshape(), np.float32)
+        a.out = _ptr(out)
+        dumps = None
+        if dump_steps:
+            ds = np.ascontiguousarray(dump_steps, dtype=np.int32)
+            dumps = np.empty((len(ds),) + self._xshape(), np.float32)
+            a.n_dump, a.dump_steps, a.dump_out = len(ds), ds.ctypes.data_as(c_i32p), _ptr(dumps)
+            keep.append(ds)
+        self._check(self.lib.ls_sample(self.h, C.byref(a)), "ls_sample")
+        return (out, dumps) if dump_steps else out
+
+    def read(self, name: str) -> np.ndarray:
+        shapes = {"audio_feat": (self.batch, self.T, 256), "static_c": (self.batch, self.T, self.D),
+                  "static_u": (self.batch, self.T, self.D), "z_mu": (self.batch, self.D),
+                  "z_logvar": (self.batch, self.D), "z_std": (self.batch, self.D), "temb": (self.n_steps, self.D)}
+        out = np.empty(shapes[name], np.float32)
+        n = self._check(self.lib.ls_read(self.h, name.encode(), out.ctypes.data_as(c_f32p), out.size), f"ls_read({name})")
+        assert n == out.size
+        return out
+
+    def timing(self) -> dict:
+        t = LsTiming()
+        self.lib.ls_get_timing(self.h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in LsTiming._fields_}

@@ -1,0 +1,28 @@
+"""``ClassifierFreeSampleModel`` drop-in (scripts/model/cfg_sampler.py:8-31).
+
+The reference deep-copies ``y`` (cloning the [B, 36267] audio tensor) and runs two full RAG forwards per
+call.  Here both passes are rows of the same workgroup inside one launch of the fused step kernel and the
+lerp ``out_u + scale * (out_c - out_u)`` is applied in its epilogue."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+class ClassifierFreeSampleModel(nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+        self.translation = self.model.translation
+        self.njoints = self.model.njoints
+        self.nfeats = self.model.nfeats
+        self.data_rep = self.model.data_rep
+        self.cond_mode = self.model.cond_mode
+
+    def forward(self, x, timesteps, y=None):
+        if self.model.cond_mask_prob > 0:
+            # draw order of the reference: cond pass eps, then uncond pass eps (RAG.py:120 via cfg_sampler.py:29-30)
+            out = self.model._forward_engine(x, timesteps, y, want="cfg")
+            return out
+        # cond_mask_prob == 0: the reference has no else branch and returns None (cfg_sampler.py:24-31)
+        return None

@@ -1,0 +1,786 @@
+// Host side of the C-ABI declared in include/ls_hip.h: handle, weight images in MFMA operand order,
+// once-per-call preparation, the diffusion loop (stream launches or a captured hipGraph) and read-back.
+// No torch types here; the Python shim (livelyspeaker_amd/_lib.py) binds these symbols with ctypes.
+#include "ls_hip.h"
+#include "ls_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ls;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    float* f() const { return static_cast<float*>(p); }
+};
+
+const int kConvCin[4] = {1, 32, 64, 128};
+const int kConvCout[4] = {32, 64, 128, 256};
+const int kConvStride[4] = {5, 6, 6, 6};
+const int kConvPad[4] = {1600, 0, 0, 0};
+const int kConvKey[4] = {0, 3, 6, 9};
+
+}  // namespace
+
+struct ls_handle {
+    ls_config cfg{};
+    Variant var = kTED;
+    int JF = 0, S = 0, R = 0, NOB = 0, KXQ = 0, MK = 0, KIN = 0, KF = 0;
+    int convL[5] = {0, 0, 0, 0, 0};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+
+    std::map<std::string, std::vector<float>> w;   // host copies under the reference's state-dict keys
+    bool committed = false;
+    unsigned weights_version = 0;
+
+    // device weights
+    DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, bout, devw;
+    DevBuf conv_w[4], conv_b[4], win_full, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
+    DevBuf te_w0, te_b0, te_w2, te_b2, pe;
+
+    // schedule
+    bool have_sched = false;
+    unsigned sched_version = 0;
+    int n_steps = 0;
+    std::vector<long long> tmap;
+    std::vector<double> t_sac, t_s1mac, t_c1, t_c2, t_plv, t_ac, t_acp, t_srac, t_srm1ac;
+    DevBuf temb, temb_tmp, tmap_dev;
+    bool temb_valid = false;
+
+    // per-call state
+    int B = 0;              // prepared batch
+    bool prepared = false;
+    DevBuf audio, origin_x, vid, emo, scale;
+    DevBuf c1, c2, c3, c4, st1, st2, st3, feat_c, feat_u, static_c, static_u, z, z_mu, z_logvar, z_std, emo_tok;
+    DevBuf audio_feat;
+    DevBuf xa, xb, xtmp, xio, fwd_c, fwd_u, fwd_cfg, eps, noise, tfwd, tfwd_tmp, tidx, dump, trace, callp;
+    DevBuf eps_tape, noise_tape;
+
+    // cached graph of the step loop
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::string graph_key;
+
+    ls_timing timing{};
+    CallParams call_host{0, 0};
+};
+
+namespace {
+
+int fail(ls_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail((h), LS_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+int upload(ls_handle* h, DevBuf& d, const void* src, size_t bytes) {
+    HIPCHK(h, d.ensure(bytes ? bytes : 4));
+    if (bytes) {
+        HIPCHK(h, hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));     // src is usually a temporary: finish before it dies
+    }
+    return LS_OK;
+}
+
+// copy a caller buffer (host or device) into an internal device buffer
+int ingest(ls_handle* h, DevBuf& d, const void* src, size_t bytes, int on_device) {
+    HIPCHK(h, d.ensure(bytes ? bytes : 4));
+    HIPCHK(h, hipMemcpyAsync(d.p, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    return LS_OK;
+}
+int egress(ls_handle* h, void* dst, const void* src, size_t bytes, int on_device) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    return LS_OK;
+}
+
+const std::vector<float>* find_w(ls_handle* h, const std::string& key, size_t want) {
+    auto it = h->w.find(key);
+    if (it == h->w.end()) { fail(h, LS_ESTATE, "missing weight '%s'", key.c_str()); return nullptr; }
+    if (it->second.size() != want) {
+        fail(h, LS_EINVAL, "weight '%s' has %zu elements, expected %zu", key.c_str(), it->second.size(), want);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+void free_graph(ls_handle* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr;
+    h->graph = nullptr;
+    h->graph_key.clear();
+}
+
+// Build the device images whose element order is the per-lane MFMA operand order of ls_step.hip.
+int build_images(ls_handle* h) {
+    const int L = h->cfg.layers, S = h->S, R = h->R, JF = h->JF, D = kD;
+    const int MK = h->MK, KXQ = h->KXQ, NOB = h->NOB, KIN = h->KIN;
+    std::vector<float> wch((size_t)L * D * D), bch((size_t)L * D), l1a((size_t)L * D), l1b((size_t)L * D),
+        l2a((size_t)L * D), l2b((size_t)L * D), ww((size_t)L * kNT * MK * 64), bt((size_t)L * 80, 0.f);
+    char key[160];
+    for (int l = 0; l < L; ++l) {
+        auto K = [&](const char* suffix) { snprintf(key, sizeof key, "backbone.mlps.%d.%s", l, suffix); return std::string(key); };
+        const auto* W = find_w(h, K("block2.1.weight"), (size_t)D * D);        // Linear(512,512) [out][in], mlp_module.py:58-60
+        const auto* b2 = find_w(h, K("block2.1.bias"), D);
+        const auto* Wt = find_w(h, K("block1.1.weight"), (size_t)S * S);       // Conv1d(S,S,1) [out tok][in tok][1], :51-55
+        const auto* b1 = find_w(h, K("block1.1.bias"), S);
+        const auto* a1 = find_w(h, K("block1.0.alpha"), D);
+        const auto* be1 = find_w(h, K("block1.0.beta"), D);
+        const auto* a2 = find_w(h, K("block2.0.alpha"), D);
+        const auto* be2 = find_w(h, K("block2.0.beta"), D);
+        if (!W || !b2 || !Wt || !b1 || !a1 || !be1 || !a2 || !be2) return LS_ESTATE;
+        // wch_img[l][w][p][q][c2][lane][j] = W[n = 64w + 16(2p+c2) + (lane&15)][k = 16q + 4(lane>>4) + j]
+        size_t o = (size_t)l * D * D;
+        for (int w = 0; w < kWaves; ++w)
+            for (int p = 0; p < 2; ++p)
+                for (int q = 0; q < 32; ++q)
+                    for (int c2 = 0; c2 < 2; ++c2)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = 64 * w + 16 * (2 * p + c2) + (lane & 15);
+                                const int k = 16 * q + 4 * (lane >> 4) + j;
+                                wch[o++] = (*W)[(size_t)n * D + k];
+                            }
+        memcpy(&bch[(size_t)l * D], b2->data(), D * sizeof(float));
+        memcpy(&l1a[(size_t)l * D], a1->data(), D * sizeof(float));
+        memcpy(&l1b[(size_t)l * D], be1->data(), D * sizeof(float));
+        memcpy(&l2a[(size_t)l * D], a2->data(), D * sizeof(float));
+        memcpy(&l2b[(size_t)l * D], be2->data(), D * sizeof(float));
+        // ww_img[l][t][m][lane] = WW[r = 16t + (lane&15)][r' = 4m + (lane>>4)], WW = blockdiag(Wt, Wt) on packed rows
+        for (int t = 0; t < kNT; ++t)
+            for (int m = 0; m < MK; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = 16 * t + (lane & 15), rp = 4 * m + (lane >> 4);
+                    float v = 0.f;
+                    if (r < R && rp < R && r / S == rp / S) v = (*Wt)[(size_t)(r % S) * S + (rp % S)];
+                    ww[(((size_t)l * kNT + t) * MK + m) * 64 + lane] = v;
+                }
+        for (int r = 0; r < R; ++r) bt[(size_t)l * 80 + r] = (*b1)[r % S];
+    }
+    const auto* Win = find_w(h, "input_mapping.weight", (size_t)D * KIN);        // RAG.py:62
+    const auto* bin = find_w(h, "input_mapping.bias", D);
+    const auto* Wout = find_w(h, "output_process.poseFinal.weight", (size_t)JF * D);   // RAG.py:203
+    const auto* bo = find_w(h, "output_process.poseFinal.bias", JF);
+    if (!Win || !bin || !Wout || !bo) return LS_ESTATE;
+    std::vector<float> winx((size_t)kWaves * 2 * KXQ * 2 * 64 * 4), wout((size_t)NOB * 32 * 64 * 4), bout((size_t)NOB * 16, 0.f);
+    {
+        size_t o = 0;
+        for (int w = 0; w < kWaves; ++w)
+            for (int p = 0; p < 2; ++p)
+                for (int q = 0; q < KXQ; ++q)
+                    for (int c2 = 0; c2 < 2; ++c2)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = 64 * w + 16 * (2 * p + c2) + (lane & 15);
+                                const int k = 16 * q + 4 * (lane >> 4) + j;
+                                winx[o++] = k < JF ? (*Win)[(size_t)n * KIN + k] : 0.f;
+                            }
+        o = 0;
+        for (int ob = 0; ob < NOB; ++ob)
+            for (int q = 0; q < 32; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 16 * ob + (lane & 15);
+                        const int k = 16 * q + 4 * (lane >> 4) + j;
+                        wout[o++] = c < JF ? (*Wout)[(size_t)c * D + k] : 0.f;
+                    }
+        for (int c = 0; c < JF; ++c) bout[c] = (*bo)[c];
+    }
+    int rc;
+#define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
+    UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
+    UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(bout, bout);
+    UP(win_full, *Win); UP(win_bias, *bin);
+    // raw weights used by the once-per-call kernels
+    for (int i = 0; i < 4; ++i) {
+        snprintf(key, sizeof key, "audio_encoder.feat_extractor.%d.weight", kConvKey[i]);
+        const auto* cw = find_w(h, key, (size_t)kConvCout[i] * kConvCin[i] * 15);   // audio_enc.py:9-20
+        snprintf(key, sizeof key, "audio_encoder.feat_extractor.%d.bias", kConvKey[i]);
+        const auto* cb = find_w(h, key, kConvCout[i]);
+        if (!cw || !cb) return LS_ESTATE;
+        UP(conv_w[i], *cw); UP(conv_b[i], *cb);
+    }
+    const auto* se = find_w(h, "speaker_embedding.weight", (size_t)h->cfg.n_speakers * 256);   // RAG.py:65-69
+    const auto* mw = find_w(h, "speaker_mu.weight", (size_t)D * 256);
+    const auto* mb = find_w(h, "speaker_mu.bias", D);
+    const auto* lw = find_w(h, "speaker_logvar.weight", (size_t)D * 256);
+    const auto* lb = find_w(h, "speaker_logvar.bias", D);
+    const auto* t0w = find_w(h, "backbone.embed_timestep.time_embed.0.weight", (size_t)D * D);   // mlp_module.py:129-133
+    const auto* t0b = find_w(h, "backbone.embed_timestep.time_embed.0.bias", D);
+    const auto* t2w = find_w(h, "backbone.embed_timestep.time_embed.2.weight", (size_t)D * D);
+    const auto* t2b = find_w(h, "backbone.embed_timestep.time_embed.2.bias", D);
+    if (!se || !mw || !mb || !lw || !lb || !t0w || !t0b || !t2w || !t2b) return LS_ESTATE;
+    UP(spk_emb, *se); UP(mu_w, *mw); UP(mu_b, *mb); UP(lv_w, *lw); UP(lv_b, *lb);
+    UP(te_w0, *t0w); UP(te_b0, *t0b); UP(te_w2, *t2w); UP(te_b2, *t2b);
+    if (h->cfg.n_emotions > 0) {
+        const auto* ee = find_w(h, "emotion_embedding.weight", (size_t)h->cfg.n_emotions * D);   // scripts_beat/model/RAG.py:72
+        if (!ee) return LS_ESTATE;
+        UP(emo_emb, *ee);
+    }
+#undef UP
+    // PositionalEncoding buffer (mlp_module.py:104-116), fp32 like the torch buffer
+    {
+        std::vector<float> pe((size_t)kPeRows * D);
+        const float cexp = (float)(-std::log(10000.0) / D);
+        for (int i = 0; i < D / 2; ++i) {
+            const float div = expf((float)(2 * i) * cexp);
+            for (int p = 0; p < kPeRows; ++p) {
+                pe[(size_t)p * D + 2 * i] = sinf((float)p * div);
+                pe[(size_t)p * D + 2 * i + 1] = cosf((float)p * div);
+            }
+        }
+        if ((rc = upload(h, h->pe, pe.data(), pe.size() * sizeof(float))) != LS_OK) return rc;
+    }
+    DevWeights dw{};
+    dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
+    dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
+    dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
+    dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.bout = h->bout.f();
+    if ((rc = upload(h, h->devw, &dw, sizeof dw)) != LS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LS_OK;
+}
+
+// temb[i] = time_embed(pe[timestep_map[i]])  (TimestepEmbedder, mlp_module.py:123-136), one row per schedule index
+int build_temb_rows(ls_handle* h, const long long* idx_dev, int n, DevBuf& tmp, DevBuf& out) {
+    HIPCHK(h, tmp.ensure((size_t)2 * n * kD * sizeof(float)));
+    HIPCHK(h, out.ensure((size_t)n * kD * sizeof(float)));
+    float* rows = tmp.f();
+    float* hid = tmp.f() + (size_t)n * kD;
+    HIPCHK(h, launch_gather_rows(h->pe.f(), reinterpret_cast<const int64_t*>(idx_dev), rows, n, kD, kPeRows, h->stream));
+    HIPCHK(h, launch_linear(rows, kD, h->te_w0.f(), kD, h->te_b0.f(), hid, kD, n, kD, kD, 1, h->stream));
+    HIPCHK(h, launch_linear(hid, kD, h->te_w2.f(), kD, h->te_b2.f(), out.f(), kD, n, kD, kD, 0, h->stream));
+    return LS_OK;
+}
+
+int ensure_temb_table(ls_handle* h) {
+    if (h->temb_valid) return LS_OK;
+    int rc = upload(h, h->tmap_dev, h->tmap.data(), h->tmap.size() * sizeof(long long));
+    if (rc != LS_OK) return rc;
+    rc = build_temb_rows(h, static_cast<const long long*>(h->tmap_dev.p), h->n_steps, h->temb_tmp, h->temb);
+    if (rc != LS_OK) return rc;
+    h->temb_valid = true;
+    return LS_OK;
+}
+
+void fill_common(ls_handle* h, StepArgs& a) {
+    memset(&a, 0, sizeof a);
+    a.static_c = h->static_c.f(); a.static_u = h->static_u.f();
+    a.z_mu = h->z_mu.f(); a.z_std = h->z_std.f();
+    a.emo_tok = h->cfg.n_prefix_tokens == 2 ? h->emo_tok.f() : nullptr;
+    a.scale = h->scale.f();
+    a.call = static_cast<const CallParams*>(h->callp.p);
+    a.W = static_cast<const DevWeights*>(h->devw.p);
+    a.layers = h->cfg.layers;
+    a.sampler = kNone;
+}
+
+// per-step scalars, cast fp64 -> fp32 exactly like _extract_into_tensor (gaussian_diffusion.py:1651-1664)
+void fill_sampler(ls_handle* h, StepArgs& a, int sampler, int i, float eta) {
+    a.t_nonzero = i != 0;
+    if (sampler == LS_SAMPLER_DDPM) {
+        a.sampler = kDDPM;
+        a.c0 = (float)h->t_c1[i];                                  // posterior_mean_coef1 (:268-271)
+        a.c1 = (float)h->t_c2[i];
+        a.c2 = expf(0.5f * (float)h->t_plv[i]);                    // exp(0.5*log_variance) (:556)
+    } else {
+        a.sampler = kDDIM;
+        const float ab = (float)h->t_ac[i], abp = (float)h->t_acp[i];
+        a.c0 = (float)h->t_srac[i];                                // _predict_eps_from_xstart (:418-422)
+        a.c1 = (float)h->t_srm1ac[i];
+        const float sigma = eta * sqrtf((1.0f - abp) / (1.0f - ab)) * sqrtf(1.0f - ab / abp);   // (:781-785), fp32
+        a.c2 = sqrtf(abp);                                         // (:790-793)
+        a.c3 = sqrtf(1.0f - abp - sigma * sigma);
+        a.c4 = sigma;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ls_abi_version(void) { return LS_ABI_VERSION; }
+
+const char* ls_last_error(const ls_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ls_create(const ls_config* cfg, ls_handle** out) {
+    if (!cfg || !out) return fail(nullptr, LS_EINVAL, "ls_create: null argument");
+    *out = nullptr;
+    if (cfg->latent_dim != kD) return fail(nullptr, LS_EUNSUPPORTED, "latent_dim must be %d", kD);
+    if (cfg->nframes != kT) return fail(nullptr, LS_EUNSUPPORTED, "nframes must be %d", kT);
+    const int JF = cfg->njoints * cfg->nfeats;
+    Variant var;
+    if (JF == 27 && cfg->n_prefix_tokens == 1) var = kTED;
+    else if (JF == 282 && cfg->n_prefix_tokens == 2) var = kBEAT;
+    else return fail(nullptr, LS_EUNSUPPORTED, "unsupported shape: J*F=%d with %d prefix tokens (built: 27/1 TED, 282/2 BEAT)",
+                     JF, cfg->n_prefix_tokens);
+    if (cfg->layers < 1 || cfg->layers > 64) return fail(nullptr, LS_EINVAL, "layers out of range");
+    if (cfg->n_prefix_tokens == 2 && cfg->n_emotions <= 0) return fail(nullptr, LS_EINVAL, "BEAT variant needs n_emotions > 0");
+    int L = cfg->audio_len;
+    int convL[5];
+    convL[0] = L;
+    for (int i = 0; i < 4; ++i) {
+        L = (L + 2 * kConvPad[i] - 15) / kConvStride[i] + 1;
+        convL[i + 1] = L;
+    }
+    if (L != kT) return fail(nullptr, LS_EINVAL, "audio_len %d yields %d audio frames, need %d", cfg->audio_len, L, kT);
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail(nullptr, LS_EHIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
+    ls_handle* h = new ls_handle();
+    h->cfg = *cfg;
+    h->var = var;
+    h->JF = JF;
+    h->S = kT + cfg->n_prefix_tokens;
+    h->R = 2 * h->S;
+    h->NOB = (JF + 15) / 16;
+    h->KXQ = (JF + 15) / 16;
+    h->MK = (h->R + 3) / 4;
+    h->KIN = 2 * JF + 1 + kAudioFeat;
+    h->KF = JF + 1 + kAudioFeat;
+    memcpy(h->convL, convL, sizeof convL);
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    for (auto& ev : h->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    }
+    e = init_step_kernels();
+    if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
+    CallParams cp{0, 0};
+    if (upload(h, h->callp, &cp, sizeof cp) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
+    *out = h;
+    return LS_OK;
+}
+
+void ls_destroy(ls_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_graph(h);
+    DevBuf* all[] = {&h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
+                     &h->wout_img, &h->bout, &h->devw, &h->win_full, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
+                     &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
+                     &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
+                     &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
+                     &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
+                     &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
+                     &h->callp, &h->eps_tape, &h->noise_tape};
+    for (DevBuf* d : all) d->release();
+    for (int i = 0; i < 4; ++i) { h->conv_w[i].release(); h->conv_b[i].release(); }
+    for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ls_set_weight(ls_handle* h, const char* key, const float* data, size_t n) {
+    if (!h || !key || (!data && n)) return fail(h, LS_EINVAL, "ls_set_weight: null argument");
+    const std::string k(key);
+    if (k.size() >= 3 && k.compare(k.size() - 3, 3, ".pe") == 0) return LS_OK;   // buffers, recomputed (mlp_module.py:104-116)
+    h->w[k].assign(data, data + n);
+    h->committed = false;
+    return LS_OK;
+}
+
+int ls_commit_weights(ls_handle* h) {
+    if (!h) return LS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = build_images(h);
+    if (rc != LS_OK) return rc;
+    h->committed = true;
+    h->weights_version++;
+    h->temb_valid = false;
+    h->prepared = false;
+    free_graph(h);
+    return LS_OK;
+}
+
+int ls_set_schedule(ls_handle* h, const ls_schedule* s) {
+    if (!h || !s) return fail(h, LS_EINVAL, "ls_set_schedule: null argument");
+    if (s->n_steps < 1) return fail(h, LS_EINVAL, "n_steps must be >= 1");
+    const double* tabs[] = {s->sqrt_alphas_cumprod, s->sqrt_one_minus_alphas_cumprod, s->posterior_mean_coef1,
+                            s->posterior_mean_coef2, s->posterior_log_variance_clipped, s->alphas_cumprod,
+                            s->alphas_cumprod_prev, s->sqrt_recip_alphas_cumprod, s->sqrt_recipm1_alphas_cumprod};
+    for (const double* t : tabs) if (!t) return fail(h, LS_EINVAL, "ls_set_schedule: null table");
+    if (!s->timestep_map) return fail(h, LS_EINVAL, "ls_set_schedule: null timestep_map");
+    const int n = s->n_steps;
+    for (int i = 0; i < n; ++i)
+        if (s->timestep_map[i] < 0 || s->timestep_map[i] >= kPeRows)
+            return fail(h, LS_EINVAL, "timestep_map[%d]=%lld outside [0,%d)", i, (long long)s->timestep_map[i], kPeRows);
+    h->n_steps = n;
+    h->tmap.assign(s->timestep_map, s->timestep_map + n);
+    std::vector<double>* dst[] = {&h->t_sac, &h->t_s1mac, &h->t_c1, &h->t_c2, &h->t_plv, &h->t_ac, &h->t_acp, &h->t_srac, &h->t_srm1ac};
+    for (int k = 0; k < 9; ++k) dst[k]->assign(tabs[k], tabs[k] + n);
+    h->have_sched = true;
+    h->sched_version++;
+    h->temb_valid = false;
+    free_graph(h);
+    return LS_OK;
+}
+
+int ls_prepare(ls_handle* h, const ls_cond* c) {
+    if (!h || !c) return fail(h, LS_EINVAL, "ls_prepare: null argument");
+    if (!h->committed) return fail(h, LS_ESTATE, "ls_prepare before ls_commit_weights");
+    if (c->batch < 1) return fail(h, LS_EINVAL, "batch must be >= 1");
+    if (!c->audio_input || !c->origin_x || !c->vid_indices || !c->scale) return fail(h, LS_EINVAL, "ls_prepare: null conditioning pointer");
+    if (h->cfg.n_prefix_tokens == 2 && !c->emo) return fail(h, LS_EINVAL, "BEAT variant needs emo ids");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = c->batch, JF = h->JF, AL = h->cfg.audio_len;
+    const int od = c->on_device;
+    hipStream_t st = h->stream;
+    int rc;
+    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    if ((rc = ingest(h, h->audio, c->audio_input, (size_t)B * AL * sizeof(float), od)) != LS_OK) return rc;
+    if ((rc = ingest(h, h->origin_x, c->origin_x, (size_t)B * JF * kT * sizeof(float), od)) != LS_OK) return rc;
+    if ((rc = ingest(h, h->vid, c->vid_indices, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
+    if ((rc = ingest(h, h->scale, c->scale, (size_t)B * sizeof(float), od)) != LS_OK) return rc;
+    if (c->emo && (rc = ingest(h, h->emo, c->emo, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
+
+    // ---- WavEncoder (audio_enc.py:6-25): conv -> [IN + LReLU fused into the next conv's staging] x3 -> conv
+    const int* Lc = h->convL;
+    DevBuf* outs[4] = {&h->c1, &h->c2, &h->c3, &h->c4};
+    DevBuf* stats[3] = {&h->st1, &h->st2, &h->st3};
+    const float* in = h->audio.f();
+    const float* in_stats = nullptr;
+    for (int i = 0; i < 4; ++i) {
+        HIPCHK(h, outs[i]->ensure((size_t)B * kConvCout[i] * Lc[i + 1] * sizeof(float)));
+        HIPCHK(h, launch_conv1d(in, in_stats, h->conv_w[i].f(), h->conv_b[i].f(), outs[i]->f(), B, kConvCin[i], kConvCout[i],
+                                Lc[i], Lc[i + 1], kConvStride[i], kConvPad[i], st));
+        if (i < 3) {
+            HIPCHK(h, stats[i]->ensure((size_t)B * kConvCout[i] * 2 * sizeof(float)));
+            HIPCHK(h, launch_instnorm_stats(outs[i]->f(), stats[i]->f(), B * kConvCout[i], Lc[i + 1], st));
+            in_stats = stats[i]->f();
+        }
+        in = outs[i]->f();
+    }
+    // ---- static part of input_mapping (RAG.py:110-114): columns JF.. of W_in act on [prefix poses | bit | audio]
+    const int KF = h->KF, KIN = h->KIN;
+    HIPCHK(h, h->feat_c.ensure((size_t)B * kT * KF * sizeof(float)));
+    HIPCHK(h, h->feat_u.ensure((size_t)B * kT * KF * sizeof(float)));
+    HIPCHK(h, h->static_c.ensure((size_t)B * kT * kD * sizeof(float)));
+    HIPCHK(h, h->static_u.ensure((size_t)B * kT * kD * sizeof(float)));
+    HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_c.f(), h->feat_u.f(), B, JF, h->cfg.n_pre_seq, st));
+    HIPCHK(h, launch_linear(h->feat_c.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), h->static_c.f(), kD, B * kT, kD, KF, 0, st));
+    HIPCHK(h, launch_linear(h->feat_u.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), h->static_u.f(), kD, B * kT, kD, KF, 0, st));
+    // ---- speaker style (RAG.py:116-119): z = Embedding[vid]; mu, logvar = Linear(z); std = exp(0.5*logvar)
+    HIPCHK(h, h->z.ensure((size_t)B * 256 * sizeof(float)));
+    HIPCHK(h, h->z_mu.ensure((size_t)B * kD * sizeof(float)));
+    HIPCHK(h, h->z_logvar.ensure((size_t)B * kD * sizeof(float)));
+    HIPCHK(h, h->z_std.ensure((size_t)B * kD * sizeof(float)));
+    HIPCHK(h, launch_gather_rows(h->spk_emb.f(), static_cast<const int64_t*>(h->vid.p), h->z.f(), B, 256, h->cfg.n_speakers, st));
+    HIPCHK(h, launch_linear(h->z.f(), 256, h->mu_w.f(), 256, h->mu_b.f(), h->z_mu.f(), kD, B, kD, 256, 0, st));
+    HIPCHK(h, launch_linear(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), h->z_logvar.f(), kD, B, kD, 256, 0, st));
+    HIPCHK(h, launch_linear(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), h->z_std.f(), kD, B, kD, 256, 2, st));
+    if (h->cfg.n_prefix_tokens == 2) {   // scripts_beat/model/RAG.py:125
+        HIPCHK(h, h->emo_tok.ensure((size_t)B * kD * sizeof(float)));
+        HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st));
+    }
+    HIPCHK(h, hipEventRecord(h->ev[1], st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipEventElapsedTime(&h->timing.prepare_ms, h->ev[0], h->ev[1]));
+    if (h->B != B) free_graph(h);
+    h->B = B;
+    h->prepared = true;
+    return LS_OK;
+}
+
+int ls_forward(ls_handle* h, const ls_forward_args* a) {
+    if (!h || !a) return fail(h, LS_EINVAL, "ls_forward: null argument");
+    if (!h->prepared) return fail(h, LS_ESTATE, "ls_forward before ls_prepare");
+    if (!a->x || !a->timesteps || !a->eps_cond || !a->eps_uncond) return fail(h, LS_EINVAL, "ls_forward: null input");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, JF = h->JF, od = a->on_device;
+    const size_t nx = (size_t)B * JF * kT * sizeof(float);
+    hipStream_t st = h->stream;
+    int rc;
+    if ((rc = ingest(h, h->xio, a->x, nx, od)) != LS_OK) return rc;
+    HIPCHK(h, h->xa.ensure(nx));
+    HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st));
+    HIPCHK(h, h->eps.ensure((size_t)2 * B * kD * sizeof(float)));
+    HIPCHK(h, hipMemcpyAsync(h->eps.f(), a->eps_cond, (size_t)B * kD * sizeof(float), od ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->eps.f() + (size_t)B * kD, a->eps_uncond, (size_t)B * kD * sizeof(float), od ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if ((rc = ingest(h, h->tidx, a->timesteps, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
+    if ((rc = build_temb_rows(h, static_cast<const long long*>(h->tidx.p), B, h->tfwd_tmp, h->tfwd)) != LS_OK) return rc;
+    HIPCHK(h, h->fwd_c.ensure(nx)); HIPCHK(h, h->fwd_u.ensure(nx)); HIPCHK(h, h->fwd_cfg.ensure(nx));
+    StepArgs s;
+    fill_common(h, s);
+    s.x_in = h->xa.f();
+    s.fwd_c = h->fwd_c.f(); s.fwd_u = h->fwd_u.f(); s.x0_out = h->fwd_cfg.f();
+    s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
+    s.temb = h->tfwd.f(); s.temb_stride = kD;
+    if (a->trace) {
+        HIPCHK(h, h->trace.ensure((size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float)));
+        s.trace = h->trace.f();
+    }
+    HIPCHK(h, launch_step(h->var, s, B, st));
+    float* outs[3] = {a->out_cond, a->out_uncond, a->out_cfg};
+    const float* srcs[3] = {h->fwd_c.f(), h->fwd_u.f(), h->fwd_cfg.f()};
+    for (int i = 0; i < 3; ++i) {
+        if (!outs[i]) continue;
+        HIPCHK(h, launch_from_internal(srcs[i], h->xio.f(), B, JF, st));
+        if ((rc = egress(h, outs[i], h->xio.f(), nx, od)) != LS_OK) return rc;
+    }
+    if (a->trace && (rc = egress(h, a->trace, h->trace.f(), (size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float), od)) != LS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(st));
+    return LS_OK;
+}
+
+int ls_step(ls_handle* h, const ls_step_args* a) {
+    if (!h || !a) return fail(h, LS_EINVAL, "ls_step: null argument");
+    if (!h->prepared) return fail(h, LS_ESTATE, "ls_step before ls_prepare");
+    if (!h->have_sched) return fail(h, LS_ESTATE, "ls_step before ls_set_schedule");
+    if (a->index < 0 || a->index >= h->n_steps) return fail(h, LS_EINVAL, "step index %d outside [0,%d)", a->index, h->n_steps);
+    if (!a->x || !a->eps_cond || !a->eps_uncond || !a->noise || !a->sample) return fail(h, LS_EINVAL, "ls_step: null pointer");
+    if (a->sampler != LS_SAMPLER_DDPM && a->sampler != LS_SAMPLER_DDIM) return fail(h, LS_EINVAL, "bad sampler");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, JF = h->JF, od = a->on_device;
+    const size_t nx = (size_t)B * JF * kT * sizeof(float);
+    hipStream_t st = h->stream;
+    int rc;
+    if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
+    if ((rc = ingest(h, h->xio, a->x, nx, od)) != LS_OK) return rc;
+    HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->fwd_cfg.ensure(nx));
+    HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st));
+    HIPCHK(h, h->eps.ensure((size_t)2 * B * kD * sizeof(float)));
+    const hipMemcpyKind kind = od ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPCHK(h, hipMemcpyAsync(h->eps.f(), a->eps_cond, (size_t)B * kD * sizeof(float), kind, st));
+    HIPCHK(h, hipMemcpyAsync(h->eps.f() + (size_t)B * kD, a->eps_uncond, (size_t)B * kD * sizeof(float), kind, st));
+    if ((rc = ingest(h, h->noise, a->noise, nx, od)) != LS_OK) return rc;
+    StepArgs s;
+    fill_common(h, s);
+    fill_sampler(h, s, a->sampler, a->index, a->eta);
+    s.clip_denoised = a->clip_denoised;
+    s.x_in = h->xa.f(); s.x_out = h->xb.f(); s.x0_out = h->fwd_cfg.f();
+    s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
+    s.noise = h->noise.f();
+    s.temb = h->temb.f() + (size_t)a->index * kD; s.temb_stride = 0;
+    HIPCHK(h, launch_step(h->var, s, B, st));
+    HIPCHK(h, launch_from_internal(h->xb.f(), h->xio.f(), B, JF, st));
+    if ((rc = egress(h, a->sample, h->xio.f(), nx, od)) != LS_OK) return rc;
+    if (a->pred_xstart) {
+        HIPCHK(h, launch_from_internal(h->fwd_cfg.f(), h->xio.f(), B, JF, st));
+        if ((rc = egress(h, a->pred_xstart, h->xio.f(), nx, od)) != LS_OK) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    return LS_OK;
+}
+
+int ls_q_sample(ls_handle* h, int index, int on_device, size_t n, const float* x_start, const float* noise, float* out) {
+    if (!h || !x_start || !noise || !out) return fail(h, LS_EINVAL, "ls_q_sample: null argument");
+    if (!h->have_sched) return fail(h, LS_ESTATE, "ls_q_sample before ls_set_schedule");
+    if (index < 0 || index >= h->n_steps) return fail(h, LS_EINVAL, "index out of range");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const float a = (float)h->t_sac[index], b = (float)h->t_s1mac[index];
+    hipStream_t st = h->stream;
+    if (on_device) {
+        HIPCHK(h, launch_q_sample(x_start, noise, out, n, a, b, st));
+    } else {
+        int rc;
+        if ((rc = ingest(h, h->xio, x_start, n * sizeof(float), 0)) != LS_OK) return rc;
+        if ((rc = ingest(h, h->xtmp, noise, n * sizeof(float), 0)) != LS_OK) return rc;
+        HIPCHK(h, launch_q_sample(h->xio.f(), h->xtmp.f(), h->xio.f(), n, a, b, st));
+        if ((rc = egress(h, out, h->xio.f(), n * sizeof(float), 0)) != LS_OK) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    return LS_OK;
+}
+
+int ls_sample(ls_handle* h, const ls_sample_args* a) {
+    if (!h || !a) return fail(h, LS_EINVAL, "ls_sample: null argument");
+    if (!h->prepared) return fail(h, LS_ESTATE, "ls_sample before ls_prepare");
+    if (!h->have_sched) return fail(h, LS_ESTATE, "ls_sample before ls_set_schedule");
+    if (a->sampler != LS_SAMPLER_DDPM && a->sampler != LS_SAMPLER_DDIM) return fail(h, LS_EINVAL, "bad sampler");
+    if (a->noise_mode != LS_NOISE_TAPE && a->noise_mode != LS_NOISE_PHILOX) return fail(h, LS_EINVAL, "bad noise_mode");
+    if (a->skip_timesteps < 0 || a->skip_timesteps >= h->n_steps) return fail(h, LS_EINVAL, "skip_timesteps out of range");
+    if (!a->out) return fail(h, LS_EINVAL, "ls_sample: null out");
+    const bool tape = a->noise_mode == LS_NOISE_TAPE;
+    if (tape && (!a->x_init || !a->eps_tape || !a->noise_tape)) return fail(h, LS_EINVAL, "TAPE mode needs x_init, eps_tape and noise_tape");
+    if (!tape && a->const_noise) return fail(h, LS_EUNSUPPORTED, "const_noise is supported in TAPE mode only");
+    if (a->n_dump > 0 && (a->sampler != LS_SAMPLER_DDPM || !a->dump_steps || !a->dump_out))
+        return fail(h, LS_EINVAL, "dump_steps: DDPM only (ddim_sample_loop raises NotImplementedError, gaussian_diffusion.py:919-920)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, JF = h->JF, od = a->on_device;
+    const int n_exec = h->n_steps - a->skip_timesteps;
+    const size_t nelem = (size_t)B * JF * kT;
+    const size_t nx = nelem * sizeof(float);
+    hipStream_t st = h->stream;
+    int rc;
+    if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->xtmp.ensure(nx)); HIPCHK(h, h->xio.ensure(nx));
+    h->call_host = CallParams{a->seed, a->sample_offset};
+    HIPCHK(h, hipMemcpyAsync(h->callp.p, &h->call_host, sizeof(CallParams), hipMemcpyHostToDevice, st));
+
+    // x_T (gaussian_diffusion.py:700-707 / :972-977)
+    if (a->x_init) {
+        if ((rc = ingest(h, h->xio, a->x_init, nx, od)) != LS_OK) return rc;
+        HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st));
+    } else {
+        HIPCHK(h, launch_randn_fill(h->xa.f(), B, JF, static_cast<const CallParams*>(h->callp.p), 0u, st));
+    }
+    // init_image -> q_sample at the first executed index (:709-716 / :979-986)
+    const int first_index = n_exec - 1;
+    if (a->init_image || a->skip_timesteps > 0) {
+        if (a->init_image) {
+            if ((rc = ingest(h, h->xio, a->init_image, nx, od)) != LS_OK) return rc;
+            HIPCHK(h, launch_to_internal(h->xio.f(), h->xtmp.f(), B, JF, st));
+        } else {
+            HIPCHK(h, hipMemsetAsync(h->xtmp.p, 0, nx, st));
+        }
+        HIPCHK(h, launch_q_sample(h->xtmp.f(), h->xa.f(), h->xa.f(), nelem, (float)h->t_sac[first_index], (float)h->t_s1mac[first_index], st));
+    }
+    if (tape) {
+        const void* old_e = h->eps_tape.p; const void* old_n = h->noise_tape.p;
+        if ((rc = ingest(h, h->eps_tape, a->eps_tape, (size_t)n_exec * 2 * B * kD * sizeof(float), od)) != LS_OK) return rc;
+        if ((rc = ingest(h, h->noise_tape, a->noise_tape, (size_t)n_exec * nx, od)) != LS_OK) return rc;
+        if (old_e != h->eps_tape.p || old_n != h->noise_tape.p) free_graph(h);
+    }
+    if (a->n_dump > 0) {
+        const void* old = h->dump.p;
+        HIPCHK(h, h->dump.ensure((size_t)a->n_dump * nx));
+        if (old != h->dump.p) free_graph(h);
+    }
+
+    // ---- the loop: for i = T-1-skip ... 0 (gaussian_diffusion.py:724-743 / :994-1014) ----------------
+    char keybuf[256];
+    {
+        int off = snprintf(keybuf, sizeof keybuf, "B%d s%d e%a k%d n%d c%d cl%d w%u v%u d%d", B, a->sampler, (double)a->eta,
+                           a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, a->n_dump);
+        for (int d = 0; d < a->n_dump && off < (int)sizeof keybuf - 12; ++d) off += snprintf(keybuf + off, sizeof keybuf - off, ",%d", a->dump_steps[d]);
+    }
+    auto enqueue_loop = [&]() -> int {
+        for (int k = 0; k < n_exec; ++k) {
+            const int i = n_exec - 1 - k;
+            StepArgs s;
+            fill_common(h, s);
+            fill_sampler(h, s, a->sampler, i, a->eta);
+            s.clip_denoised = a->clip_denoised;
+            s.x_in = (k & 1) ? h->xb.f() : h->xa.f();
+            s.x_out = (k & 1) ? h->xa.f() : h->xb.f();
+            s.temb = h->temb.f() + (size_t)i * kD; s.temb_stride = 0;
+            s.step_id = (unsigned)k;
+            if (tape) {
+                s.eps_c = h->eps_tape.f() + ((size_t)k * 2 + 0) * B * kD;
+                s.eps_u = h->eps_tape.f() + ((size_t)k * 2 + 1) * B * kD;
+                s.noise = h->noise_tape.f() + (size_t)k * nelem;
+                s.const_noise = a->const_noise;
+            }
+            for (int d = 0; d < a->n_dump; ++d)
+                if (a->dump_steps[d] == k) s.x0_out = h->dump.f() + (size_t)d * nelem;
+            HIPCHK(h, launch_step(h->var, s, B, st));
+        }
+        return LS_OK;
+    };
+    h->timing.graph_replayed = 0;
+    HIPCHK(h, hipEventRecord(h->ev[1], st));
+    if (a->use_graph) {
+        if (!h->graph_exec || h->graph_key != keybuf) {
+            free_graph(h);
+            HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_loop();
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc != LS_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(h, LS_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            h->graph = g;
+            HIPCHK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+            h->graph_key = keybuf;
+            HIPCHK(h, hipEventRecord(h->ev[1], st));    // exclude capture/instantiate from loop_ms
+        } else {
+            h->timing.graph_replayed = 1;
+        }
+        HIPCHK(h, hipGraphLaunch(h->graph_exec, st));
+    } else {
+        if ((rc = enqueue_loop()) != LS_OK) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[2], st));
+    const float* final_x = (n_exec & 1) ? h->xb.f() : h->xa.f();
+    HIPCHK(h, launch_from_internal(final_x, h->xio.f(), B, JF, st));
+    if ((rc = egress(h, a->out, h->xio.f(), nx, od)) != LS_OK) return rc;
+    for (int d = 0; d < a->n_dump; ++d) {
+        HIPCHK(h, launch_from_internal(h->dump.f() + (size_t)d * nelem, h->xio.f(), B, JF, st));
+        if ((rc = egress(h, a->dump_out + (size_t)d * nelem, h->xio.f(), nx, od)) != LS_OK) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[3], st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
+    h->timing.n_step_launches = n_exec;
+    return LS_OK;
+}
+
+long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capacity) {
+    if (!h || !name || !host_out) return fail(h, LS_EINVAL, "ls_read: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const std::string n(name);
+    const float* src = nullptr;
+    size_t cnt = 0;
+    const size_t B = (size_t)h->B;
+    if (n == "temb") {
+        if (!h->have_sched || !h->committed) return fail(h, LS_ESTATE, "temb needs weights and schedule");
+        int rc = ensure_temb_table(h);
+        if (rc != LS_OK) return rc;
+        src = h->temb.f(); cnt = (size_t)h->n_steps * kD;
+    } else {
+        if (!h->prepared) return fail(h, LS_ESTATE, "ls_read('%s') before ls_prepare", name);
+        if (n == "audio_feat") {
+            HIPCHK(h, h->audio_feat.ensure(B * kT * kAudioFeat * sizeof(float)));
+            HIPCHK(h, launch_transpose_feat(h->c4.f(), h->audio_feat.f(), (int)B, h->stream));
+            src = h->audio_feat.f(); cnt = B * kT * kAudioFeat;
+        } else if (n == "static_c") { src = h->static_c.f(); cnt = B * kT * kD; }
+        else if (n == "static_u") { src = h->static_u.f(); cnt = B * kT * kD; }
+        else if (n == "z_mu") { src = h->z_mu.f(); cnt = B * kD; }
+        else if (n == "z_logvar") { src = h->z_logvar.f(); cnt = B * kD; }
+        else if (n == "z_std") { src = h->z_std.f(); cnt = B * kD; }
+        else return fail(h, LS_EINVAL, "ls_read: unknown buffer '%s'", name);
+    }
+    if (cnt > capacity) return fail(h, LS_EINVAL, "ls_read('%s'): need %zu floats, capacity %zu", name, cnt, capacity);
+    HIPCHK(h, hipMemcpyAsync(host_out, src, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return (long long)cnt;
+}
+
+int ls_get_timing(const ls_handle* h, ls_timing* out) {
+    if (!h || !out) return LS_EINVAL;
+    *out = h->timing;
+    return LS_OK;
+}
+
+int ls_synchronize(ls_handle* h) {
+    if (!h) return LS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Internal declarations shared by the host side (ls_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ls {
+
+constexpr int kD = 512;        // latent_dim (RAG.py:38; parser default 512)
+constexpr int kWaves = 8;      // waves per workgroup of the step kernel
+constexpr int kCB = 4;         // 16-channel blocks owned by one wave  (8 waves * 4 * 16 = 512)
+constexpr int kNT = 5;         // 16-row token tiles per workgroup     (2*S = 70|72 rows -> 80)
+constexpr int kUStride = 520;  // LDS row stride (floats) of the staged GEMM operand: conflict-free ds_read_b128
+constexpr int kT = 34;         // frames
+constexpr int kAudioFeat = 256;
+constexpr int kPeRows = 5000;  // PositionalEncoding max_len (mlp_module.py:105)
+
+enum SamplerKind { kDDPM = 0, kDDIM = 1, kNone = 2 };
+
+// Per-call values that may change between replays of a captured graph live in device memory.
+struct CallParams {
+    unsigned long long seed;
+    unsigned long long sample_offset;
+};
+
+// Weight images in MFMA operand order (built by ls_api.cpp build_images); lives in device memory so
+// the kernel fetches each pointer with one s_load where it is used instead of pinning ~22 SGPR pairs.
+struct DevWeights {
+    const float* wch_img;    // [L][8][2 passes][32 q][2 cb][64 lanes][4]   channel-mix Linear(512,512)
+    const float* bch;        // [L][512]
+    const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
+    const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
+    const float* btok_rows;  // [L][80]
+    const float* winx_img;   // [8][2 passes][KXQ][2 cb][64][4]   x_t columns of input_mapping
+    const float* wout_img;   // [NOB][32][64][4]   poseFinal
+    const float* bout;       // [NOB*16]
+};
+
+// Arguments of one launch of the fused step kernel (one workgroup = one sample = cond+uncond rows).
+struct StepArgs {
+    // activations (internal layout [B][T][JF])
+    const float* x_in;
+    float* x_out;        // x_{t-1}                       (sampler != kNone)
+    float* x0_out;       // pred_xstart (CFG-combined)    (nullable)
+    float* fwd_c;        // raw cond / uncond model outputs (nullable)
+    float* fwd_u;
+    // prepared conditioning
+    const float* static_c;   // [B][T][512]  W_in[:,JF:] . [prefix poses | bit | audio] + b
+    const float* static_u;   // same with the audio term masked
+    const float* z_mu;       // [B][512]
+    const float* z_std;      // [B][512] exp(0.5*logvar)
+    const float* emo_tok;    // [B][512] or null
+    const float* scale;      // [B]
+    const float* temb;       // timestep embedding row(s)
+    int temb_stride;         // floats between samples (0: one row shared by the batch)
+    // noise
+    const float* eps_c;      // [B][512] or null -> Philox
+    const float* eps_u;
+    const float* noise;      // [B][JF][T] (reference layout) or null -> Philox
+    int const_noise;
+    const CallParams* call;  // Philox key / sample offset
+    unsigned step_id;        // Philox stream selector
+    const struct DevWeights* W;   // weight images (device memory, constant per model)
+    int layers;
+    // sampler update
+    int sampler;             // SamplerKind
+    int t_nonzero;           // 1[t != 0]
+    int clip_denoised;       // clamp pred_xstart to [-1,1] (process_xstart, gaussian_diffusion.py:365-371)
+    float c0, c1, c2, c3, c4;
+    // DDPM: x' = c0*x0 + c1*x_t + nz*c2*noise
+    // DDIM: eps = (c0*x_t - x0)/c1 ; x' = x0*c2 + c3*eps + nz*c4*noise
+    float* trace;            // [B][L+1][2S][512] or null
+};
+
+// dataset variant of the compiled kernel
+enum Variant { kTED = 0, kBEAT = 1 };
+
+hipError_t launch_step(Variant v, const StepArgs& a, int batch, hipStream_t st);
+size_t step_lds_bytes(Variant v);
+hipError_t init_step_kernels();
+
+// ---- once-per-call kernels (ls_prepare.hip) ------------------------------------------------
+hipError_t launch_conv1d(const float* in, const float* stats, const float* w, const float* bias, float* out,
+                         int B, int Cin, int Cout, int Lin, int Lout, int stride, int pad, hipStream_t st);
+hipError_t launch_instnorm_stats(const float* x, float* stats, int rows, int L, hipStream_t st);
+// y[M][N] = act(x[M][K] . W[N][ldw]^T + b);  act: 0 none, 1 SiLU, 2 exp(0.5*y)
+hipError_t launch_linear(const float* x, int ldx, const float* w, int ldw, const float* b, float* y, int ldy,
+                         int M, int N, int K, int act, hipStream_t st);
+hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int rows, int width,
+                              int table_rows, hipStream_t st);
+hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
+                              int B, int JF, int n_pre_seq, hipStream_t st);
+hipError_t launch_to_internal(const float* src_bjft, float* dst_btc, int B, int JF, hipStream_t st);
+hipError_t launch_from_internal(const float* src_btc, float* dst_bjft, int B, int JF, hipStream_t st);
+hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size_t n, float a, float b,
+                           hipStream_t st);
+hipError_t launch_randn_fill(float* out_btc, int B, int JF, const CallParams* call, unsigned stream_id,
+                             hipStream_t st);
+hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipStream_t st);
+
+}  // namespace ls

@@ -1,0 +1,452 @@
+// Fused diffusion-step kernel for gfx950 (MI355X): ONE launch = one p_sample / ddim_sample step of the
+// CFG-wrapped RAG denoiser for the whole batch.  Replaces, per step, the ~230 eager aten ops of
+//   ClassifierFreeSampleModel.forward   scripts/model/cfg_sampler.py:24-31
+//   RAG.forward                         scripts/model/RAG.py:98-133
+//   TransMLP / MLPblock / LN_spatial    scripts/model/mlp_module.py:21-91
+//   OutputProcess                       scripts/model/RAG.py:205-211
+//   p_mean_variance / p_sample / ddim_sample   scripts/diffusion/gaussian_diffusion.py:284-399, 507-558, 745-798
+//
+// Mapping:
+//   * one workgroup (8 waves, 512 threads) owns ONE sample: the cond and uncond passes are packed as
+//     R = 2*S rows (70 TED / 72 BEAT) -> 5 token tiles of 16, so the CFG lerp and the sampler update fuse
+//     into the same launch and nothing but x_t (3.7 KB) round-trips through HBM between steps.
+//   * every contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32; bf16/fp16 inputs fail the 1e-3
+//     parity budget) in the TRANSPOSED form D[channel][token]: channels on the
+//     MFMA M axis, tokens on N.  The MFMA C/D layout (lane&15 = token, 4*(lane>>4)+reg = channel) is then
+//     ALSO the layout of the residual stream, which therefore lives in registers for the whole forward:
+//     wave w owns channels [64w, 64w+64) of all 80 rows = 80 VGPRs.
+//   * the normalised operand (LN1(x) for token mixing, LN2(x) for channel mixing) is staged in LDS as
+//     U[row][k] with row stride 520 floats: lane (token, g) fetches k = 16q+4g..+3 with one conflict-free
+//     ds_read_b128 and feeds 4 consecutive MFMAs; the weight operand uses the same k permutation and is
+//     pre-swizzled on the host so each wave-instruction reads 1 KiB contiguous from L2.
+//   * token mixing (Conv1d(S,S,1) over the token axis) is a second small MFMA GEMM against a
+//     block-diagonal [R x R] operand; its output lands directly in the residual layout.
+#include "ls_internal.h"
+#include "ls_philox.h"
+
+namespace ls {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp), far inside the 1e-3 parity budget.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// Pointers fetched from the DevWeights block are generic to the compiler; cast them to the global
+// address space so loads are global_load (vmcnt only) instead of flat_load (vmcnt AND lgkmcnt, which
+// would make every LDS wait in the GEMM loops also wait for the weight prefetch).
+typedef const __attribute__((address_space(1))) f4* gf4p;
+typedef const __attribute__((address_space(1))) float* gfp;
+__device__ __forceinline__ gf4p g4(const float* p) { return (gf4p)(const f4*)p; }
+__device__ __forceinline__ gfp g1(const float* p) { return (gfp)p; }
+
+__host__ __device__ constexpr bool tokmix_needed(int S, int t, int m) {
+    const int R = 2 * S;
+    const int r_lo = 16 * t;
+    if (r_lo >= R) return false;
+    const int r_hi = (16 * t + 15 < R - 1) ? 16 * t + 15 : R - 1;
+    const int src_lo = (r_lo / S) * S, src_hi = (r_hi / S + 1) * S - 1;
+    return !(4 * m + 3 < src_lo || 4 * m > src_hi);
+}
+
+template <int S, int NPRE, int JF>
+__global__ __launch_bounds__(512) void k_step(const StepArgs a) {
+    constexpr int R = 2 * S;                 // packed rows: [cond tokens | uncond tokens]
+    constexpr int KXQ = (JF + 15) / 16;      // 16-wide k groups of the x_t part of input_mapping
+    constexpr int KXP = KXQ * 16;
+    constexpr int NOB = (JF + 15) / 16;      // 16-wide output blocks of poseFinal
+    constexpr int OSTR = NOB * 16 + 4;
+    constexpr int MK = (R + 3) / 4;          // k steps of the token-mix GEMM
+    constexpr int NU = NOB * kNT;            // output-projection work units
+    constexpr int MAXU = (NU + kWaves - 1) / kWaves;
+    static_assert(R <= 16 * kNT, "rows must fit the token tiles");
+    static_assert(R * OSTR <= R * kUStride, "OUT overlay must fit the operand buffer");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* U = smem;                         // [R][520]
+    float* psum = smem + R * kUStride;       // [8][80]
+    float* psq = psum + kWaves * 16 * kNT;   // [8][80]
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15;
+    const int g = lane >> 4;
+    const int chw = 64 * w + 4 * g;          // + 16*cb + j  = this lane's channels
+
+    // Row metadata is recomputed where needed (tiles 0..3 are always fully valid; only tile 4 is ragged).
+    auto row_of = [&](int t) { return 16 * t + s16; };
+    auto valid_of = [&](int t) { return (16 * t + 15 < R) ? true : (16 * t + s16 < R); };
+    auto rowc_of = [&](int t) { const int r = 16 * t + s16; return (16 * t + 15 < R || r < R) ? r : R - 1; };
+
+    f4 X[kCB][kNT];
+
+    // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
+    {
+        const float* xin = a.x_in + (size_t)b * kT * JF;
+        for (int idx = tid; idx < R * KXP; idx += 512) {
+            const int r = idx / KXP, k = idx - r * KXP;
+            const int tk = r >= S ? r - S : r;
+            float v = 0.f;
+            if (tk >= NPRE && k < JF) v = xin[(tk - NPRE) * JF + k];
+            U[r * kUStride + k] = v;
+        }
+        __syncthreads();
+        const unsigned long long gidx = a.call ? a.call->sample_offset + (unsigned long long)b : (unsigned long long)b;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f4 acc[2][kNT];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+            gf4p wp = g4(a.W->winx_img) + (size_t)(w * 2 + p) * KXQ * 2 * 64 + lane;
+#pragma unroll 2
+            for (int q = 0; q < KXQ; ++q) {
+                f4 A[2], Bv[kNT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = wp[(q * 2 + c2) * 64];
+#pragma unroll
+                for (int t = 0; t < kNT; ++t)
+                    Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                const int rc = rowc_of(t);
+                const int sq = rc >= S ? 1 : 0;
+                const int tk = rc - sq * S;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const int cb = 2 * p + c2;
+                    const int ch = chw + 16 * cb;
+                    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+                    if (valid_of(t)) {
+                        if (tk >= NPRE) {
+                            const float* st = (sq ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + ch;
+                            v = acc[c2][t] + *reinterpret_cast<const f4*>(st);
+                        } else if (tk == 0) {
+                            // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
+                            const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + ch);
+                            const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + ch);
+                            f4 e;
+                            const float* ep = sq ? a.eps_u : a.eps_c;
+                            if (ep) {
+                                e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + ch);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    e[j] = philox_normal(a.call, gidx, a.step_id, 1u + sq, (unsigned)(ch + j));
+                            }
+                            v = mu + e * sd;
+                        } else {
+                            // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
+                            v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);
+                        }
+                    }
+                    X[cb][t] = v;
+                }
+            }
+        }
+    }
+
+    auto dump_trace = [&](int stage) {
+        if (!a.trace) return;
+        float* tr = a.trace + ((size_t)b * (a.layers + 1) + stage) * R * kD;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+            if (valid_of(t))
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb)
+                    *reinterpret_cast<f4*>(tr + (size_t)row_of(t) * kD + chw + 16 * cb) = X[cb][t];
+    };
+    dump_trace(0);
+
+    // LN_spatial statistics over the 512 channels of each row (mlp_module.py:29-33): two-pass
+    // (mean, then centred biased variance) like the reference; in-lane -> 4 lane groups -> 8 waves.
+    float mean[kNT], rstd[kNT];
+    auto ln_stats = [&]() {
+        float part[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) s += (X[cb][t][0] + X[cb][t][1]) + (X[cb][t][2] + X[cb][t][3]);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            part[t] = s;
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) psum[w * 80 + 16 * t + s16] = part[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) s += psum[ww * 80 + 16 * t + s16];
+            mean[t] = s * (1.0f / kD);
+        }
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = X[cb][t][j] - mean[t];
+                    s += d * d;
+                }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            part[t] = s;
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) psq[w * 80 + 16 * t + s16] = part[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) s += psq[ww * 80 + 16 * t + s16];
+            rstd[t] = rsqrtf(s * (1.0f / kD) + 1e-5f);
+        }
+    };
+    // write LN(x)*alpha+beta of this lane's channels into the LDS operand buffer
+    auto ln_store = [&](const float* alpha, const float* beta) {
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb) {
+            const f4 al = *g4(alpha + chw + 16 * cb);
+            const f4 be = *g4(beta + chw + 16 * cb);
+#pragma unroll
+            for (int t = 0; t < kNT; ++t)
+                if (valid_of(t)) {
+                    f4 u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = (X[cb][t][j] - mean[t]) * rstd[t] * al[j] + be[j];
+                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                }
+        }
+    };
+
+    // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
+    for (int l = 0; l < a.layers; ++l) {
+        {   // x = x + emb  (emb re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
+            const float* te = a.temb + (size_t)b * a.temb_stride + chw;
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                const f4 e = *reinterpret_cast<const f4*>(te + 16 * cb);
+#pragma unroll
+                for (int t = 0; t < kNT; ++t)
+                    if (valid_of(t)) X[cb][t] += e;
+            }
+        }
+        // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
+        ln_stats();
+        ln_store(a.W->ln1a + l * kD, a.W->ln1b + l * kD);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f4 acc[2][kNT];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+            gfp wwp = g1(a.W->ww_img) + (size_t)l * kNT * MK * 64 + lane;
+            const float* up = U + 64 * w + 32 * p + s16;
+#pragma unroll
+            for (int m = 0; m < MK; ++m) {
+                const int srow = (4 * m + 3 < R || 4 * m + g < R) ? 4 * m + g : R - 1;
+                float A[2];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = up[srow * kUStride + 16 * c2];
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    if (tokmix_needed(S, t, m)) {
+                        const float Bt = wwp[(t * MK + m) * 64];
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) acc[c2][t] = MFMA(A[c2], Bt, acc[c2][t]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                if (valid_of(t)) {
+                    const float bt = g1(a.W->btok_rows)[l * 80 + row_of(t)];
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) X[2 * p + c2][t][j] += silu_f(acc[c2][t][j] + bt);
+                }
+            }
+        }
+        // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
+        ln_stats();      // its two barriers also order every wave's token-mix reads before the stores below
+        ln_store(a.W->ln2a + l * kD, a.W->ln2b + l * kD);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f4 acc[2][kNT];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+            gf4p wp = g4(a.W->wch_img) + ((size_t)((l * kWaves + w) * 2 + p) * 32) * 2 * 64 + lane;
+            f4 An[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
+#pragma unroll 2
+            for (int q = 0; q < 32; ++q) {
+                f4 A[2], Bv[kNT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
+                if (q + 1 < 32) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[((q + 1) * 2 + c2) * 64];
+                }
+#pragma unroll
+                for (int t = 0; t < kNT; ++t)
+                    Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int cb = 2 * p + c2;
+                const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * cb);
+#pragma unroll
+                for (int t = 0; t < kNT; ++t)
+                    if (valid_of(t)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) X[cb][t][j] += silu_f(acc[c2][t][j] + bc[j]);
+                    }
+            }
+        }
+        dump_trace(l + 1);
+    }
+
+    // ================= OutputProcess.poseFinal (RAG.py:205-211) ====================================
+    __syncthreads();                       // every wave is done reading the last LN2 operand
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+        if (valid_of(t))
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+                *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = X[cb][t];
+    __syncthreads();
+    f4 res[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = w + kWaves * i;      // wave-uniform
+        res[i] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (u < NU) {
+            const int ob = u / kNT, t = u - ob * kNT;
+            const int rc = (16 * t + s16 < R) ? 16 * t + s16 : R - 1;
+            gf4p wp = g4(a.W->wout_img) + (size_t)ob * 32 * 64 + lane;
+            const float* up = &U[rc * kUStride + 4 * g];
+            f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll 4
+            for (int q = 0; q < 32; ++q) {
+                const f4 A = wp[q * 64];
+                const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * q);
+                a0 = MFMA(A[0], Bv[0], a0);
+                a1 = MFMA(A[1], Bv[1], a1);
+                a0 = MFMA(A[2], Bv[2], a0);
+                a1 = MFMA(A[3], Bv[3], a1);
+            }
+            res[i] = a0 + a1;
+        }
+    }
+    __syncthreads();                       // operand buffer is free: overlay OUT[row][c]
+    float* OUT = U;
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = w + kWaves * i;
+        if (u < NU) {
+            const int ob = u / kNT, t = u - ob * kNT;
+            const int r = 16 * t + s16;
+            if (r < R) *reinterpret_cast<f4*>(&OUT[r * OSTR + 16 * ob + 4 * g]) = res[i];
+        }
+    }
+    __syncthreads();
+
+    // ====== CFG lerp (cfg_sampler.py:31) + posterior / DDIM update (gaussian_diffusion.py:260-282,
+    //        507-558, 745-798), written back in the internal [B][T][JF] layout ======================
+    {
+        const float sc = a.scale ? a.scale[b] : 1.0f;
+        const size_t base = (size_t)b * kT * JF;
+        const unsigned long long gidx = a.call ? a.call->sample_offset + (unsigned long long)b : (unsigned long long)b;
+        for (int idx = tid; idx < kT * JF; idx += 512) {
+            const int f = idx / JF, c = idx - f * JF;
+            const float bo = g1(a.W->bout)[c];
+            const float oc = OUT[(NPRE + f) * OSTR + c] + bo;
+            const float ou = OUT[(S + NPRE + f) * OSTR + c] + bo;
+            if (a.fwd_c) a.fwd_c[base + idx] = oc;
+            if (a.fwd_u) a.fwd_u[base + idx] = ou;
+            float x0 = ou + sc * (oc - ou);
+            if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (a.x0_out) a.x0_out[base + idx] = x0;
+            if (a.sampler != kNone) {
+                const float xt = a.x_in[base + idx];
+                float nz = 0.f;
+                if (a.t_nonzero) {
+                    if (a.noise) {
+                        const size_t bn = a.const_noise ? 0 : (size_t)b;
+                        nz = a.noise[(bn * JF + c) * kT + f];
+                    } else {
+                        nz = philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(c * kT + f));
+                    }
+                }
+                float xn;
+                if (a.sampler == kDDPM) {
+                    xn = a.c0 * x0 + a.c1 * xt;
+                    if (a.t_nonzero) xn += a.c2 * nz;
+                } else {
+                    const float eps = (a.c0 * xt - x0) / a.c1;
+                    xn = x0 * a.c2 + a.c3 * eps;
+                    if (a.t_nonzero) xn += a.c4 * nz;
+                }
+                a.x_out[base + idx] = xn;
+            }
+        }
+    }
+}
+
+size_t step_lds_bytes(Variant v) {
+    const int S = (v == kTED) ? 35 : 36;
+    return (size_t)(2 * S * kUStride + 2 * kWaves * 16 * kNT) * sizeof(float);
+}
+
+// Opt in to >64 KiB dynamic LDS once per process (must happen outside stream capture).
+hipError_t init_step_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<35, 1, 27>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes(kTED));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<36, 2, 282>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes(kBEAT));
+}
+
+hipError_t launch_step(Variant v, const StepArgs& a, int batch, hipStream_t st) {
+    const size_t lds = step_lds_bytes(v);
+    if (v == kTED)
+        hipLaunchKernelGGL((k_step<35, 1, 27>), dim3(batch), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_step<36, 2, 282>), dim3(batch), dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace ls
