@@ -119,21 +119,63 @@ def load_library(build_if_missing: bool = True):
     return lib
 
 
+def _is_cuda(a) -> bool:
+    return hasattr(a, "is_cuda") and bool(a.is_cuda)
+
+
+class _Marshal:
+    """Turns a group of arrays (numpy / torch CPU / torch CUDA) into raw pointers for one ABI call.
+    If ANY member is a CUDA tensor the whole group is passed as device pointers (on_device=1) and outputs
+    are torch CUDA tensors; otherwise everything is host numpy.  Keeps the converted buffers alive."""
+
+    def __init__(self, device_index: int, *members):
+        self.on_device = any(_is_cuda(m) for m in members if m is not None)
+        self.device_index = device_index
+        self.keep = []
+        if self.on_device:
+            import torch
+            self.torch = torch
+            self.dev = torch.device("cuda", device_index)
+            torch.cuda.current_stream(self.dev).synchronize()   # inputs were produced on torch's stream
+
+    def f32(self, a, shape=None):
+        return self._conv(a, np.float32, shape)
+
+    def i64(self, a, shape=None):
+        return self._conv(a, np.int64, shape)
+
+    def _conv(self, a, dtype, shape):
+        if a is None:
+            return None
+        if self.on_device:
+            t = self.torch.as_tensor(a)
+            t = t.to(device=self.dev, dtype=self.torch.float32 if dtype == np.float32 else self.torch.int64).contiguous()
+            if shape is not None:
+                assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+            self.keep.append(t)
+            return C.c_void_p(t.data_ptr())
+        if hasattr(a, "detach"):
+            a = a.detach().cpu().numpy()
+        n = np.ascontiguousarray(a, dtype=dtype)
+        if shape is not None:
+            assert tuple(n.shape) == tuple(shape), (n.shape, tuple(shape))
+        self.keep.append(n)
+        return n.ctypes.data_as(C.c_void_p)
+
+    def out(self, shape):
+        """(object, pointer) for an fp32 output of this call."""
+        if self.on_device:
+            t = self.torch.empty(tuple(shape), dtype=self.torch.float32, device=self.dev)
+            return t, C.c_void_p(t.data_ptr())
+        n = np.empty(tuple(shape), np.float32)
+        return n, n.ctypes.data_as(C.c_void_p)
+
+
 def _np32(a) -> np.ndarray:
     """Host fp32 C-contiguous view/copy of a numpy array or CPU torch tensor."""
     if hasattr(a, "detach"):
         a = a.detach().cpu().numpy()
     return np.ascontiguousarray(a, dtype=np.float32)
-
-
-def _np64i(a) -> np.ndarray:
-    if hasattr(a, "detach"):
-        a = a.detach().cpu().numpy()
-    return np.ascontiguousarray(a, dtype=np.int64)
-
-
-def _ptr(a: np.ndarray):
-    return a.ctypes.data_as(C.c_void_p)
 
 
 class Engine:
@@ -196,17 +238,14 @@ class Engine:
 
     # ---- per call --------------------------------------------------------------------------------
     def prepare(self, y: dict):
-        audio = _np32(y["audio_input"])
-        ox = _np32(y["origin_x"])
-        vid = _np64i(y["vid_indices"])
-        scale = _np32(y["scale"])
-        B = audio.shape[0]
-        assert ox.shape == (B, self.J, self.F, self.T), ox.shape
-        c = LsCond(B, 0, _ptr(audio), _ptr(ox), _ptr(vid), None, _ptr(scale))
-        if self.cfg.n_prefix_tokens == 2:
-            emo = _np64i(y["emo"])
-            emo0 = np.ascontiguousarray(emo[:, 0] if emo.ndim == 2 else emo)
-            c.emo = _ptr(emo0)
+        emo = y.get("emo") if self.cfg.n_prefix_tokens == 2 else None
+        if emo is not None and getattr(emo, "ndim", 1) == 2:
+            emo = emo[:, 0]                                    # y['emo'][:,0], scripts_beat/model/RAG.py:125
+        m = _Marshal(self.device, y["audio_input"], y["origin_x"], y["vid_indices"], y["scale"], emo)
+        B = int(y["audio_input"].shape[0])
+        c = LsCond(B, int(m.on_device), m.f32(y["audio_input"], (B, self.cfg.audio_len)),
+                   m.f32(y["origin_x"], (B, self.J, self.F, self.T)), m.i64(y["vid_indices"], (B,)),
+                   m.i64(emo, (B,)), m.f32(y["scale"], (B,)))
         self._check(self.lib.ls_prepare(self.h, C.byref(c)), "ls_prepare")
         self.batch = B
 
@@ -214,68 +253,68 @@ class Engine:
         return (self.batch, self.J, self.F, self.T)
 
     def forward(self, x, t, eps_c, eps_u, trace=False):
-        x, eps_c, eps_u, t = _np32(x), _np32(eps_c).reshape(self.batch, self.D), _np32(eps_u).reshape(self.batch, self.D), _np64i(t)
-        assert x.shape == self._xshape(), (x.shape, self._xshape())
-        oc, ou, og = (np.empty(self._xshape(), np.float32) for _ in range(3))
-        tr = np.empty((self.batch, self.layers + 1, 2 * self.S, self.D), np.float32) if trace else None
-        a = LsForwardArgs(0, 0, _ptr(x), _ptr(t), _ptr(eps_c), _ptr(eps_u), _ptr(oc), _ptr(ou), _ptr(og),
-                          _ptr(tr) if trace else None)
+        m = _Marshal(self.device, x, t, eps_c, eps_u)
+        B, D = self.batch, self.D
+        eps_c = eps_c.reshape(B, D)
+        eps_u = eps_u.reshape(B, D)
+        oc, poc = m.out(self._xshape())
+        ou, pou = m.out(self._xshape())
+        og, pog = m.out(self._xshape())
+        tr, ptr = m.out((B, self.layers + 1, 2 * self.S, D)) if trace else (None, None)
+        a = LsForwardArgs(int(m.on_device), 0, m.f32(x, self._xshape()), m.i64(t, (B,)), m.f32(eps_c, (B, D)),
+                          m.f32(eps_u, (B, D)), poc, pou, pog, ptr)
         self._check(self.lib.ls_forward(self.h, C.byref(a)), "ls_forward")
         return (oc, ou, og, tr) if trace else (oc, ou, og)
 
     def step(self, sampler, index, x, eps_c, eps_u, noise, eta=0.0, clip_denoised=False):
-        x, noise = _np32(x), _np32(noise)
-        eps_c, eps_u = _np32(eps_c).reshape(self.batch, self.D), _np32(eps_u).reshape(self.batch, self.D)
-        out, x0 = np.empty(self._xshape(), np.float32), np.empty(self._xshape(), np.float32)
-        a = LsStepArgs(sampler, index, 0, eta, int(clip_denoised), 0, _ptr(x), _ptr(eps_c), _ptr(eps_u), _ptr(noise), _ptr(out), _ptr(x0))
+        m = _Marshal(self.device, x, eps_c, eps_u, noise)
+        B, D = self.batch, self.D
+        out, pout = m.out(self._xshape())
+        x0, px0 = m.out(self._xshape())
+        a = LsStepArgs(sampler, index, int(m.on_device), eta, int(clip_denoised), 0, m.f32(x, self._xshape()),
+                       m.f32(eps_c.reshape(B, D)), m.f32(eps_u.reshape(B, D)), m.f32(noise, self._xshape()), pout, px0)
         self._check(self.lib.ls_step(self.h, C.byref(a)), "ls_step")
         return out, x0
 
-    def q_sample(self, index, x_start, noise):
-        x_start, noise = _np32(x_start), _np32(noise)
-        out = np.empty_like(x_start)
-        self._check(self.lib.ls_q_sample(self.h, index, 0, x_start.size, _ptr(x_start), _ptr(noise), _ptr(out)), "ls_q_sample")
-        return out
-
     def sample(self, sampler=LS_SAMPLER_DDPM, x_init=None, eps_tape=None, noise_tape=None, init_image=None,
                skip_timesteps=0, eta=0.0, const_noise=False, dump_steps=None, philox_seed=None, sample_offset=0,
-               use_graph=True, clip_denoised=False):
-        """Run the whole loop. TAPE mode when tapes are given, PHILOX mode when ``philox_seed`` is."""
+               use_graph=True, clip_denoised=False, device_out=False):
+        """Run the whole loop. TAPE mode when tapes are given, PHILOX mode when ``philox_seed`` is.
+        Outputs are torch CUDA tensors if any input is one (or ``device_out``), else numpy."""
+        members = [x_init, eps_tape, noise_tape, init_image]
+        if device_out:
+            import torch
+            members.append(torch.empty(1, device=torch.device("cuda", self.device)))
+        m = _Marshal(self.device, *members)
         a = LsSampleArgs()
-        a.sampler, a.skip_timesteps, a.const_noise, a.on_device = sampler, skip_timesteps, int(const_noise), 0
+        a.sampler, a.skip_timesteps, a.const_noise, a.on_device = sampler, skip_timesteps, int(const_noise), int(m.on_device)
         a.use_graph, a.eta, a.clip_denoised = int(use_graph), eta, int(clip_denoised)
-        keep = []
+        n_exec = self.n_steps - skip_timesteps
         if philox_seed is None:
             a.noise_mode = LS_NOISE_TAPE
-            n_exec = self.n_steps - skip_timesteps
-            e, n = _np32(eps_tape), _np32(noise_tape)
-            assert e.shape == (n_exec, 2, self.batch, self.D), e.shape
-            assert n.shape == (n_exec,) + self._xshape(), n.shape
-            a.eps_tape, a.noise_tape = _ptr(e), _ptr(n)
-            keep += [e, n]
+            a.eps_tape = m.f32(eps_tape, (n_exec, 2, self.batch, self.D))
+            a.noise_tape = m.f32(noise_tape, (n_exec,) + self._xshape())
         else:
             a.noise_mode = LS_NOISE_PHILOX
             a.seed, a.sample_offset = int(philox_seed), int(sample_offset)
-        if x_init is not None:
-            xi = _np32(x_init)
-            assert xi.shape == self._xshape()
-            a.x_init = _ptr(xi)
-            keep.append(xi)
-        if init_image is not None:
-            ii = _np32(init_image)
-            assert ii.shape == self._xshape()
-            a.init_image = _ptr(ii)
-            keep.append(ii)
-        out = np.empty(self._xshape(), np.float32)
-        a.out = _ptr(out)
+        a.x_init = m.f32(x_init, self._xshape())
+        a.init_image = m.f32(init_image, self._xshape())
+        out, a.out = m.out(self._xshape())
         dumps = None
         if dump_steps:
             ds = np.ascontiguousarray(dump_steps, dtype=np.int32)
-            dumps = np.empty((len(ds),) + self._xshape(), np.float32)
-            a.n_dump, a.dump_steps, a.dump_out = len(ds), ds.ctypes.data_as(c_i32p), _ptr(dumps)
-            keep.append(ds)
+            dumps, a.dump_out = m.out((len(ds),) + self._xshape())
+            a.n_dump, a.dump_steps = len(ds), ds.ctypes.data_as(c_i32p)
+            m.keep.append(ds)
         self._check(self.lib.ls_sample(self.h, C.byref(a)), "ls_sample")
         return (out, dumps) if dump_steps else out
+
+    def q_sample(self, index, x_start, noise):
+        m = _Marshal(self.device, x_start, noise)
+        out, pout = m.out(tuple(x_start.shape))
+        n = int(np.prod(x_start.shape))
+        self._check(self.lib.ls_q_sample(self.h, index, int(m.on_device), n, m.f32(x_start), m.f32(noise), pout), "ls_q_sample")
+        return out
 
     def read(self, name: str) -> np.ndarray:
         shapes = {"audio_feat": (self.batch, self.T, 256), "static_c": (self.batch, self.T, self.D),

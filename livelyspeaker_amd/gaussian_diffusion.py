@@ -68,6 +68,10 @@ class LossType(enum.Enum):
         return self in (LossType.KL, LossType.RESCALED_KL)
 
 
+def _as_tensor(a, device):
+    return (a if isinstance(a, th.Tensor) else th.from_numpy(a)).to(device)
+
+
 def _extract_into_tensor(arr, timesteps, broadcast_shape):
     res = th.from_numpy(arr).to(device=timesteps.device)[timesteps].float()
     while len(res.shape) < len(broadcast_shape):
@@ -172,7 +176,7 @@ class GaussianDiffusion:
             noise = noise[[0]].repeat(B, 1, 1, 1)
         out, x0 = eng.step(sampler, i, x, eps_c, eps_u, noise, eta=eta, clip_denoised=clip_denoised)
         dev = x.device
-        return {"sample": th.from_numpy(out).to(dev), "pred_xstart": th.from_numpy(x0).to(dev)}
+        return {"sample": _as_tensor(out, dev), "pred_xstart": _as_tensor(x0, dev)}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                  const_noise=False):
@@ -222,10 +226,11 @@ class GaussianDiffusion:
                 eps[k, 1] = th.randn(B, 1, eng.D)[:, 0]
                 nz[k] = th.randn(*shape)
             kw["eps_tape"], kw["noise_tape"] = eps, nz
+        kw["device_out"] = th.device(device).type == "cuda"
         res = eng.sample(**kw)
         if dump_steps:
-            return [th.from_numpy(d.copy()).to(device) for d in res[1]]
-        return th.from_numpy(res).to(device)
+            return [_as_tensor(d, device).clone() for d in res[1]]
+        return _as_tensor(res, device)
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,

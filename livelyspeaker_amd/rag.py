@@ -116,6 +116,9 @@ class RAG(nn.Module):
         self.output_process = _OutputProcess(self.input_feats, latent_dim)
         self.requires_grad_(False)
 
+        #: reuse the prepared conditioning when the same ``y`` tensors are passed again (the sampling loop calls
+        #: the model T times with one ``y``); set False to re-run the once-per-call stage on every call.
+        self.cache_conditioning = True
         self._engine = None
         self._weights_dirty = True
         self._cond_key = None
@@ -169,7 +172,7 @@ class RAG(nn.Module):
         y['origin_x'][..., self.n_pre_seq:] = 0
         names = ('audio_input', 'origin_x', 'vid_indices', 'scale') + (('emo',) if self.n_prefix_tokens == 2 else ())
         key = tuple((n, y[n].data_ptr(), tuple(y[n].shape), y[n]._version) for n in names)
-        if key != self._cond_key:
+        if key != self._cond_key or not self.cache_conditioning:
             eng.prepare({n: y[n] for n in names})
             self._cond_key = key
         return eng
@@ -185,7 +188,7 @@ class RAG(nn.Module):
             eps_c = eps_u = torch.randn(B, 1, self.latent_dim)
         oc, ou, og = eng.forward(x, timesteps, eps_c, eps_u)
         pick = og if want == "cfg" else (ou if uncond else oc)
-        return torch.from_numpy(pick).to(x.device)
+        return (pick if isinstance(pick, torch.Tensor) else torch.from_numpy(pick)).to(x.device)
 
     def forward(self, x, timesteps, y=None):
         """x: [B, njoints, nfeats, nframes] (x_t); timesteps: [B] int; y: conditioning dict (RAG.py:98-133)."""

@@ -1,0 +1,90 @@
+"""Multi-GPU layer: batch-sharded replicas, one process per GPU.
+
+The path shards perfectly -- no op couples two samples (InstanceNorm is per (sample, channel), LN per
+token, token mixing within a sample, CFG and the sampler update elementwise) -- so there is NO per-step
+collective.  The only communication is:
+  * init:     broadcast of the weights from rank 0 (16.4 MB TED / 18 MB BEAT fp32) over RCCL/xGMI;
+  * per call: optional broadcast/scatter of conditioning produced on one rank (e.g. the frozen CLIP text
+              features of the LivelySpeaker config) and an all_gather of the [B/N, J, F, T] result.
+The reference has no live distributed code to mirror (``mdm_utils/dist_util.py`` is stubbed, :18-41).
+Noise in Philox mode is keyed by the GLOBAL sample index (``sample_offset``), so results do not depend
+on how many GPUs the batch is split over.  Works with backend "nccl" (= RCCL) on GPUs and "gloo" on CPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, world: int, rank: int):
+    """Contiguous split of ``total`` samples: rank r owns [first, first+count)."""
+    base, extra = divmod(total, world)
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def shard_cond(y: dict, world: int, rank: int) -> dict:
+    """Slice every batched tensor of the conditioning dict to this rank's samples."""
+    total = next(v.shape[0] for v in y.values() if torch.is_tensor(v))
+    first, count = shard_range(total, world, rank)
+    return {k: (v[first:first + count].clone() if torch.is_tensor(v) and v.shape[:1] == (total,) else v)
+            for k, v in y.items()}
+
+
+def broadcast_state_dict(sd: dict, device, src: int = 0) -> dict:
+    """Make every rank hold rank ``src``'s weights (one bucketed broadcast per dtype)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return sd
+    keys = sorted(sd.keys())
+    flat = torch.cat([sd[k].reshape(-1).to(torch.float32) for k in keys]).to(device)
+    dist.broadcast(flat, src=src)
+    flat = flat.cpu()
+    out, off = {}, 0
+    for k in keys:
+        n = sd[k].numel()
+        out[k] = flat[off:off + n].reshape(sd[k].shape).clone()
+        off += n
+    return out
+
+
+def broadcast_tensor(t: torch.Tensor, device, src: int = 0) -> torch.Tensor:
+    """Broadcast conditioning computed on one rank (e.g. CLIP text features [B, 512]) to all ranks."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    buf = t.to(device).contiguous()
+    dist.broadcast(buf, src=src)
+    return buf
+
+
+def gather_samples(local: torch.Tensor, total: int) -> torch.Tensor:
+    """all_gather the per-rank [count_r, J, F, T] results into the global [total, J, F, T] tensor
+    (ragged shards are padded to the largest shard)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size()
+    counts = [shard_range(total, world, r)[1] for r in range(world)]
+    pad = max(counts)
+    buf = local.new_zeros((pad,) + tuple(local.shape[1:]))
+    buf[: local.shape[0]] = local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+def sample_sharded(sample_fn, model, global_shape, y_global: dict, diffusion=None, **kwargs) -> torch.Tensor:
+    """Run ``sample_fn`` (``diffusion.p_sample_loop`` / ``ddim_sample_loop``) on this rank's contiguous
+    shard of the batch and return the gathered global result.  ``diffusion.sample_offset`` is set so the
+    Philox streams follow the global sample index."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    total = int(global_shape[0])
+    first, count = shard_range(total, world, rank)
+    y_local = shard_cond(y_global, world, rank)
+    if diffusion is not None:
+        diffusion.sample_offset = first
+    for name in ("init_image", "noise"):
+        if kwargs.get(name) is not None:
+            kwargs[name] = kwargs[name][first:first + count]
+    local = sample_fn(model, (count,) + tuple(global_shape[1:]), model_kwargs={"y": y_local}, **kwargs)
+    return gather_samples(local, total)
