@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -83,6 +84,7 @@ struct ls_handle {
 
     ls_timing timing{};
     CallParams call_host{0, 0};
+    int ablate = 0;         // LS_ABLATE (profiling only; results are wrong when non-zero)
 };
 
 namespace {
@@ -304,6 +306,7 @@ void fill_common(ls_handle* h, StepArgs& a) {
     a.W = static_cast<const DevWeights*>(h->devw.p);
     a.layers = h->cfg.layers;
     a.sampler = kNone;
+    a.ablate = h->ablate;
 }
 
 // per-step scalars, cast fp64 -> fp32 exactly like _extract_into_tensor (gaussian_diffusion.py:1651-1664)
@@ -359,6 +362,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (e != hipSuccess) return fail(nullptr, LS_EHIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
     ls_handle* h = new ls_handle();
     h->cfg = *cfg;
+    if (const char* ab = getenv("LS_ABLATE")) h->ablate = atoi(ab);
     h->var = var;
     h->JF = JF;
     h->S = kT + cfg->n_prefix_tokens;

@@ -69,6 +69,7 @@ struct StepArgs {
     // DDPM: x' = c0*x0 + c1*x_t + nz*c2*noise
     // DDIM: eps = (c0*x_t - x0)/c1 ; x' = x0*c2 + c3*eps + nz*c4*noise
     float* trace;            // [B][L+1][2S][512] or null
+    int ablate;              // profiling only (env LS_ABLATE): 1 skip channel-mix MFMAs, 2 skip token-mix, 4 skip LN stats
 };
 
 // dataset variant of the compiled kernel

@@ -173,6 +173,11 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     // (mean, then centred biased variance) like the reference; in-lane -> 4 lane groups -> 8 waves.
     float mean[kNT], rstd[kNT];
     auto ln_stats = [&]() {
+        if (a.ablate & 4) {
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) { mean[t] = 0.f; rstd[t] = 1.f; }
+            return;
+        }
         float part[kNT];
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
@@ -255,38 +260,36 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         ln_stats();
         ln_store(a.W->ln1a + l * kD, a.W->ln1b + l * kD);
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            f4 acc[2][kNT];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                for (int t = 0; t < kNT; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+        // out[d][r] = sum_r' u[r'][d] * WW[r][r']  as D[channel][row]: A = u^T from LDS, B = the block-diagonal
+        // token weights (same for every workgroup, L1/L2 resident).  Tile by tile so only 18 B + 16 acc
+        // registers are live; the k range of a tile covers just the sequence(s) whose rows it holds.
+        if (!(a.ablate & 2)) {
             gfp wwp = g1(a.W->ww_img) + (size_t)l * kNT * MK * 64 + lane;
-            const float* up = U + 64 * w + 32 * p + s16;
-#pragma unroll
-            for (int m = 0; m < MK; ++m) {
-                const int srow = (4 * m + 3 < R || 4 * m + g < R) ? 4 * m + g : R - 1;
-                float A[2];
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) A[c2] = up[srow * kUStride + 16 * c2];
-#pragma unroll
-                for (int t = 0; t < kNT; ++t) {
-                    if (tokmix_needed(S, t, m)) {
-                        const float Bt = wwp[(t * MK + m) * 64];
-#pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2) acc[c2][t] = MFMA(A[c2], Bt, acc[c2][t]);
-                    }
-                }
-            }
+            const float* up = U + 64 * w + s16;
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
+                float Bt[MK];
+#pragma unroll
+                for (int m = 0; m < MK; ++m)
+                    if (tokmix_needed(S, t, m)) Bt[m] = wwp[(t * MK + m) * 64];
+                f4 acc[kCB];
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MK; ++m) {
+                    if (tokmix_needed(S, t, m)) {
+                        const int srow = (4 * m + 3 < R || 4 * m + g < R) ? 4 * m + g : R - 1;
+#pragma unroll
+                        for (int cb = 0; cb < kCB; ++cb)
+                            acc[cb] = MFMA(up[srow * kUStride + 16 * cb], Bt[m], acc[cb]);
+                    }
+                }
                 if (valid_of(t)) {
                     const float bt = g1(a.W->btok_rows)[l * 80 + row_of(t)];
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2)
+                    for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) X[2 * p + c2][t][j] += silu_f(acc[c2][t][j] + bt);
+                        for (int j = 0; j < 4; ++j) X[cb][t][j] += silu_f(acc[cb][j] + bt);
                 }
             }
         }
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             f4 An[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
+            if (!(a.ablate & 1))
 #pragma unroll 2
             for (int q = 0; q < 32; ++q) {
                 f4 A[2], Bv[kNT];
