@@ -1,0 +1,178 @@
+"""CPU: host-side logic of the drop-in (schedule mirror, init order, RNG draw order, ABI surface).
+No compute calls are made: there is no GPU here and the product has no CPU path."""
+import ctypes
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from livelyspeaker_amd import _lib, gaussian_diffusion as gd, synth
+from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
+from livelyspeaker_amd.model_util import create_model_and_diffusion, load_model_wo_clip
+from livelyspeaker_amd.respace import SpacedDiffusion, space_timesteps
+
+
+def mk_args(steps=1000, njoints=47):
+    return SimpleNamespace(mdm_condm="text", latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1,
+                           arch="trans_enc", emb_trans_dec=False, dataset="humanml", lang_model=None, mlpact="silu",
+                           diffusion_steps=steps, noise_schedule="cosine", sigma_small=True, lambda_vel=1.0,
+                           lambda_rcxyz=0.0, lambda_fc=0.0, njoints=njoints)
+
+
+@pytest.mark.parametrize("steps,resp", [(1000, ""), (1000, "ddim100"), (50, "")])
+def test_product_schedule_tables_bit_identical_to_reference(golden, steps, resp):
+    _, diff = create_model_and_diffusion(mk_args(steps), resp)
+    g = golden["ted"]
+    tag = f"G0_{steps}_{resp or 'full'}"
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                 "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                 "posterior_mean_coef1", "posterior_mean_coef2"):
+        assert np.array_equal(getattr(diff, name), g[f"{tag}_{name}"]), name
+    assert np.array_equal(np.asarray(diff.timestep_map), g[f"{tag}_timestep_map"])
+    assert isinstance(diff, SpacedDiffusion) and diff.num_timesteps == len(g[f"{tag}_betas"])
+
+
+def test_space_timesteps_matches_reference_semantics():
+    assert space_timesteps(1000, "ddim100") == set(range(0, 1000, 10))
+    assert space_timesteps(1000, [1000]) == set(range(1000))
+    assert len(space_timesteps(300, "10,15,20")) == 45
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim999")
+
+
+def test_random_init_replays_reference_order(golden):
+    """torch.manual_seed(s); RAG(...) must consume torch's RNG like scripts/model/RAG.py:56-77 does."""
+    torch.manual_seed(5)
+    model, _ = create_model_and_diffusion(mk_args(), "")
+    sd = {k: v for k, v in model.state_dict().items() if not k.endswith(".pe")}
+    cs = np.array([float(np.abs(v.numpy()).sum()) for _, v in sorted(sd.items())])
+    assert np.array_equal(cs, golden["ted"]["G8_refinit_checksum"])
+    # the reference's degenerate init is reproduced too (mlp_module.py:63-65, RAG.py:67)
+    assert float(sd["backbone.mlps.0.block2.1.weight"].abs().max()) < 1e-8
+    assert torch.all(sd["speaker_embedding.weight"] == 1e-6)
+
+
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_state_dict_contract(ds):
+    cfg = synth.CONFIGS[ds]
+    model, _ = create_model_and_diffusion(mk_args(njoints=cfg.njoints), "", dataset=ds)
+    want = synth.make_state_dict(cfg)
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith(".pe")}
+    assert set(have) == set(want)
+    for k, v in want.items():
+        assert have[k] == v.shape, k
+    pe_keys = sorted(k for k in model.state_dict() if k.endswith(".pe"))
+    assert pe_keys == ["backbone.embed_timestep.sequence_pos_encoder.pe", "backbone.sequence_pos_encoder.pe",
+                       "sequence_pos_encoder.pe"]
+    load_model_wo_clip(model, {k: torch.from_numpy(v) for k, v in want.items()})
+    assert model.eval() is None                      # RAG.train() returns None in the reference (RAG.py:136-137)
+    assert (model.njoints, model.nfeats) == (cfg.njoints, cfg.nfeats)
+    w = ClassifierFreeSampleModel(model)
+    assert (w.njoints, w.nfeats, w.cond_mode, w.translation, w.data_rep) == (cfg.njoints, cfg.nfeats, "text", True, "vec_dir")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ls_hip.h")).read()
+    declared = set(re.findall(r"\b(ls_[a-z_]+)\s*\(", hdr)) - {"ls_handle"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ls_abi_version.restype = ctypes.c_int
+    assert lib.ls_abi_version() == 1
+
+
+def test_abi_struct_sizes_match_header_layout():
+    assert ctypes.sizeof(_lib.LsConfig) == 48
+    assert ctypes.sizeof(_lib.LsSchedule) == 8 + 10 * 8
+    assert ctypes.sizeof(_lib.LsCond) == 8 + 5 * 8
+    assert ctypes.sizeof(_lib.LsSampleArgs) == 40 + 2 * 8 + 4 * 8 + 2 * 8 + 8
+    assert ctypes.sizeof(_lib.LsForwardArgs) == 8 + 8 * 8
+    assert ctypes.sizeof(_lib.LsStepArgs) == 24 + 6 * 8
+    assert ctypes.sizeof(_lib.LsTiming) == 20
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly_not_silently():
+    model, diff = create_model_and_diffusion(mk_args(), "")
+    cfgm = ClassifierFreeSampleModel(model)
+    cfg = synth.TED
+    y = {k: torch.from_numpy(v) for k, v in synth.make_cond(cfg, 2).items()}
+    with pytest.raises(_lib.EngineError):
+        diff.p_sample_loop(cfgm, (2, 9, 3, 34), clip_denoised=False, model_kwargs={"y": y})
+    lib = _lib.load_library()
+    bad = _lib.LsConfig(9, 3, 34, 1, 4, 256, 8, 36267, 1400, 0, 0, 0)       # latent_dim 256 is not built
+    h = ctypes.c_void_p()
+    assert lib.ls_create(ctypes.byref(bad), ctypes.byref(h)) == -5
+    assert b"latent_dim" in lib.ls_last_error(None)
+    bad = _lib.LsConfig(9, 3, 34, 1, 4, 512, 8, 30000, 1400, 0, 0, 0)       # audio length that is not 34 frames
+    assert lib.ls_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+
+
+class _FakeEngine:
+    """Records what the sampler hands to the engine; stands in for libls_hip.so in RNG-order tests."""
+    J, F, T, D, batch, n_steps = 9, 3, 34, 512, 2, 0
+
+    def set_schedule(self, sched):
+        self.n_steps = sched.num_timesteps
+
+    def sample(self, **kw):
+        self.kw = kw
+        return np.zeros((self.batch, self.J, self.F, self.T), np.float32)
+
+
+def test_sampler_draws_noise_in_the_reference_order(monkeypatch):
+    """randn(B,J,F,T) once, then per step randn(B,1,512) x2 and randn(B,J,F,T)."""
+    model, diff = create_model_and_diffusion(mk_args(steps=5), "")
+    cfgm = ClassifierFreeSampleModel(model)
+    fake = _FakeEngine()
+    monkeypatch.setattr(type(model), "_engine_prepared", lambda self, y: fake)
+    y = {"dummy": torch.zeros(2)}
+    torch.manual_seed(99)
+    diff.p_sample_loop(cfgm, (2, 9, 3, 34), clip_denoised=False, model_kwargs={"y": y}, device="cpu", skip_timesteps=2)
+    torch.manual_seed(99)
+    x_init = torch.randn(2, 9, 3, 34)
+    assert torch.equal(torch.as_tensor(fake.kw["x_init"]), x_init)
+    assert tuple(fake.kw["eps_tape"].shape) == (3, 2, 2, 512) and tuple(fake.kw["noise_tape"].shape) == (3, 2, 9, 3, 34)
+    for k in range(3):
+        assert torch.equal(fake.kw["eps_tape"][k, 0], torch.randn(2, 1, 512)[:, 0])
+        assert torch.equal(fake.kw["eps_tape"][k, 1], torch.randn(2, 1, 512)[:, 0])
+        assert torch.equal(fake.kw["noise_tape"][k], torch.randn(2, 9, 3, 34))
+    assert fake.kw["skip_timesteps"] == 2 and fake.kw["clip_denoised"] is False
+    # explicit noise= replaces the initial draw (gaussian_diffusion.py:701-704)
+    given = torch.full((2, 9, 3, 34), 0.5)
+    diff.ddim_sample_loop(cfgm, (2, 9, 3, 34), noise=given, model_kwargs={"y": y}, device="cpu")
+    assert torch.equal(fake.kw["x_init"], given) and fake.kw["sampler"] == _lib.LS_SAMPLER_DDIM
+
+
+def test_sampler_error_behaviour(monkeypatch):
+    model, diff = create_model_and_diffusion(mk_args(steps=5), "")
+    cfgm = ClassifierFreeSampleModel(model)
+    fake = _FakeEngine()
+    monkeypatch.setattr(type(model), "_engine_prepared", lambda self, y: fake)
+    y = {"y": {"d": torch.zeros(2)}}
+    with pytest.raises(NotImplementedError):        # gaussian_diffusion.py:919-920
+        diff.ddim_sample_loop(cfgm, (2, 9, 3, 34), model_kwargs=y, dump_steps=[0])
+    with pytest.raises(NotImplementedError):
+        diff.p_sample_loop(cfgm, (2, 9, 3, 34), model_kwargs=y, cond_fn=lambda *a: None)
+    with pytest.raises(TypeError):
+        diff.p_sample_loop(model, (2, 9, 3, 34), model_kwargs=y)
+    with pytest.raises(ValueError):
+        diff.p_sample_loop(cfgm, (3, 9, 3, 34), model_kwargs=y, device="cpu")
+    model.cond_mask_prob = 0.0
+    assert cfgm(torch.zeros(2, 9, 3, 34), torch.zeros(2, dtype=torch.long), y=y["y"]) is None   # cfg_sampler.py:24-31
+
+
+def test_q_sample_matches_tables():
+    _, diff = create_model_and_diffusion(mk_args(), "ddim100")
+    x0, nz = torch.randn(3, 9, 3, 34), torch.randn(3, 9, 3, 34)
+    t = torch.tensor([0, 50, 99])
+    got = diff.q_sample(x0, t, nz)
+    a = torch.tensor(diff.sqrt_alphas_cumprod[[0, 50, 99]]).float().view(3, 1, 1, 1)
+    b = torch.tensor(diff.sqrt_one_minus_alphas_cumprod[[0, 50, 99]]).float().view(3, 1, 1, 1)
+    assert torch.equal(got, a * x0 + b * nz)

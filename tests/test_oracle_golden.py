@@ -1,0 +1,105 @@
+"""CPU: the oracle (oracle/rag_oracle.py) against the golden vectors that tests/golden/make_golden.py produced
+by importing the reference.  This is what pins the oracle (the reference ships no vectors of its own)."""
+import numpy as np
+import pytest
+
+from conftest import max_abs
+from livelyspeaker_amd import synth
+from oracle import rag_oracle as orc
+
+TOL = 2e-4      # oracle-vs-reference is 6e-5 worst at generation time; contract is 1e-3
+
+
+def _oracle(ds):
+    cfg = synth.CONFIGS[ds]
+    return cfg, orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+
+
+def _g1_inputs(cfg, B=4):
+    g = np.random.Generator(np.random.PCG64(1234))
+    x = g.standard_normal((B, cfg.njoints, cfg.nfeats, cfg.nframes)).astype(np.float32)
+    eps = g.standard_normal((2, B, 512)).astype(np.float32)
+    noise = g.standard_normal(x.shape).astype(np.float32)
+    return x, eps, noise
+
+
+@pytest.mark.parametrize("steps,resp", [(1000, ""), (1000, "ddim100"), (50, "")])
+def test_schedule_tables_bit_identical(golden, steps, resp):
+    g = golden["ted"]
+    sch = orc.Schedule(steps, resp)
+    tag = f"G0_{steps}_{resp or 'full'}"
+    for name in orc.Schedule.TABLES:
+        assert np.array_equal(getattr(sch, name), g[f"{tag}_{name}"]), name
+    assert np.array_equal(sch.timestep_map, g[f"{tag}_timestep_map"])
+
+
+def test_space_timesteps_edge_cases():
+    assert orc.space_timesteps(1000, "ddim100") == list(range(0, 1000, 10))
+    assert orc.space_timesteps(300, "10,15,20")[:3] == [0, 11, 22]
+    assert len(orc.space_timesteps(300, "10,15,20")) == 45
+    with pytest.raises(ValueError):
+        orc.space_timesteps(1000, "ddim999")
+    with pytest.raises(ValueError):
+        orc.space_timesteps(10, "20")
+
+
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_forward_and_audio_encoder(golden, ds):
+    cfg, oracle = _oracle(ds)
+    g = golden[ds]
+    y = synth.make_cond(cfg, 4)
+    x, eps, _ = _g1_inputs(cfg)
+    prep = oracle.prepare(y)
+    assert max_abs(prep["af"], g["G1_audio_feat"]) < 2e-5
+    assert max_abs(prep["mu"][:, None], g["G1_z_mu"]) < 1e-5
+    assert max_abs(prep["logvar"][:, None], g["G1_z_logvar"]) < 1e-5
+    for t in (0, 5, 500, 999):
+        for ui, unc in enumerate((False, True)):
+            out = oracle.forward(x, np.full((4,), t), y, unc, eps[ui])
+            assert max_abs(out, g[f"G1_t{t}_{'u' if unc else 'c'}"]) < TOL, (t, unc)
+    out = oracle.forward(x, np.full((4,), 0), y, False, eps[0], hoisted=False)      # reference-faithful mode
+    assert max_abs(out, g["G1_t0_c"]) < TOL
+
+
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_single_sampler_steps(golden, ds):
+    cfg, oracle = _oracle(ds)
+    g = golden[ds]
+    y = synth.make_cond(cfg, 4)
+    x, eps, noise = _g1_inputs(cfg)
+    oracle.prepare(y)
+    for name, resp, steps in (("p", "", (0, 7, 999)), ("ddim", "ddim100", (0, 50, 99))):
+        sch = orc.Schedule(1000, resp)
+        for t in steps:
+            x0 = oracle.cfg_forward(x, np.full((4,), sch.timestep_map[t]), y, eps[0], eps[1])
+            assert max_abs(x0, g[f"G2_{name}_t{t}_x0"]) < TOL
+            upd = orc.p_sample_update(sch, x, x0, t, noise) if name == "p" else orc.ddim_update(sch, x, x0, t, noise)
+            assert max_abs(upd, g[f"G2_{name}_t{t}_sample"]) < TOL
+
+
+def _loop(ds, steps, resp, ddim, skip, use_init, dump=None):
+    cfg, oracle = _oracle(ds)
+    sch = orc.Schedule(steps, resp)
+    tape = synth.NoiseTape(cfg, 4, sch.num_timesteps - skip)
+    init = synth.make_init_image(cfg, 4) if use_init else None
+    return orc.sample_loop(oracle, sch, synth.make_cond(cfg, 4), tape.x_init, tape.eps, tape.noise, ddim=ddim,
+                           skip_timesteps=skip, init_image=init, dump_steps=dump)
+
+
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_config1_and_refine_loops(golden, ds):
+    g = golden[ds]
+    assert max_abs(_loop(ds, 50, "", False, 0, False), g["G3_ddpm50_final"]) < TOL
+    assert max_abs(_loop(ds, 1000, "ddim100", True, 80, True), g["G4_ddim100_skip80_final"]) < TOL
+
+
+def test_ted_dump_steps_and_full_ddim(golden):
+    g = golden["ted"]
+    out, dumps = _loop("ted", 50, "", False, 0, False, dump=[0, 25, 49])
+    for k, d in zip((0, 25, 49), dumps):
+        assert max_abs(d, g[f"G3_ddpm50_dump_x0_step{k}"]) < TOL
+    assert max_abs(_loop("ted", 1000, "ddim100", True, 0, False), g["G4_ddim100_full_final"]) < TOL
+
+
+def test_ted_1000_step_ddpm(golden):
+    assert max_abs(_loop("ted", 1000, "", False, 0, False), golden["ted"]["G5_ddpm1000_final"]) < TOL

@@ -1,0 +1,112 @@
+"""CPU, world_size 2 over gloo: the multi-GPU shard layer (livelyspeaker_amd/shard.py).  The engine itself
+needs a GPU, so the per-rank sampler here is the CPU oracle (tests may use it); what is under test is the
+partitioning, the weight/conditioning broadcasts, the ragged gather, and shard-invariance of the result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_sample_fn(total, tape):
+    """A p_sample_loop-shaped callable backed by the oracle; noise comes from a GLOBAL tape indexed by the
+    global sample index (what Philox's sample_offset gives the real engine)."""
+    from livelyspeaker_amd import synth
+    from oracle import rag_oracle as orc
+    cfg = synth.TED
+    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    sch = orc.Schedule(3, "")
+
+    def fn(model, shape, model_kwargs=None, **kw):
+        first = model["diffusion"].sample_offset
+        n = shape[0]
+        y = {k: v.numpy() for k, v in model_kwargs["y"].items() if torch.is_tensor(v)}
+        sl = slice(first, first + n)
+        out = orc.sample_loop(oracle, sch, y, tape.x_init[sl], tape.eps[:, :, sl], tape.noise[:, sl])
+        return torch.from_numpy(out)
+    return fn
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from livelyspeaker_amd import shard, synth
+        cfg = synth.TED
+        # 1. weights: rank 0's copy wins
+        sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=7 + rank).items()}
+        sd = shard.broadcast_state_dict(sd, torch.device("cpu"))
+        ref = synth.make_state_dict(cfg, seed=7)
+        assert all(np.array_equal(sd[k].numpy(), ref[k]) for k in ref)
+        # 2. conditioning produced on rank 0 only (e.g. frozen CLIP text features) reaches everyone
+        feat = torch.arange(total * 512, dtype=torch.float32).reshape(total, 512) if rank == 0 else torch.zeros(total, 512)
+        feat = shard.broadcast_tensor(feat, torch.device("cpu"))
+        assert float(feat[-1, -1]) == total * 512 - 1
+        # 3. partition: contiguous, ragged, complete
+        first, count = shard.shard_range(total, world, rank)
+        spans = [shard.shard_range(total, world, r) for r in range(world)]
+        assert sum(c for _, c in spans) == total and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        # 4. sharded sampling + ragged all_gather == unsharded result
+        y = {k: torch.from_numpy(v) for k, v in synth.make_cond(cfg, total).items()}
+        y["text"] = ["ignored"] * total               # non-tensor entries pass through
+        tape = synth.NoiseTape(cfg, total, 3)
+        diffusion = SimpleNamespace(sample_offset=0)
+        fn = _oracle_sample_fn(total, tape)
+        got = shard.sample_sharded(fn, {"diffusion": diffusion}, (total, 9, 3, 34), y, diffusion=diffusion)
+        assert diffusion.sample_offset == first and got.shape == (total, 9, 3, 34)
+        q.put((rank, got.numpy()))
+    except Exception as e:                      # never leave the parent blocked on the queue
+        import traceback
+        q.put((rank, RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [5])
+def test_world2_sharded_equals_unsharded(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for v in results.values():
+        if isinstance(v, Exception):
+            raise v
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(results[0], results[1])
+    # single-process, unsharded reference
+    from types import SimpleNamespace
+    from livelyspeaker_amd import synth
+    cfg = synth.TED
+    tape = synth.NoiseTape(cfg, total, 3)
+    y = {k: torch.from_numpy(v) for k, v in synth.make_cond(cfg, total).items()}
+    diffusion = SimpleNamespace(sample_offset=0)
+    whole = _oracle_sample_fn(total, tape)({"diffusion": diffusion}, (total, 9, 3, 34), model_kwargs={"y": y})
+    assert np.abs(results[0] - whole.numpy()).max() < 2e-5      # BLAS blocking differs with the batch size
+
+
+def test_shard_range_properties():
+    from livelyspeaker_amd import shard
+    for total in (1, 7, 512, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [shard.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
