@@ -182,3 +182,141 @@ def test_ted_dump_steps_full_ddim_and_1000_steps(golden):
         assert d < TOL_LOOP
     finally:
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Drop-in API level (the reference's own call protocol) -------------------------------------------
+def _mk_args(cfg, steps):
+    from types import SimpleNamespace
+    return SimpleNamespace(mdm_condm="text", latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1,
+                           arch="trans_enc", emb_trans_dec=False, dataset="humanml", lang_model=None, mlpact="silu",
+                           diffusion_steps=steps, noise_schedule="cosine", sigma_small=True, lambda_vel=1.0,
+                           lambda_rcxyz=0.0, lambda_fc=0.0, njoints=cfg.njoints)
+
+
+def test_dropin_identical_seeds_mode_vs_reference_cpu_path(golden):
+    """torch.manual_seed(233) + the reference's call sequence (test_RAG_ted.py:166-178, 71-82) must reproduce the
+    reference's CPU-path sample (fixture G7, generated un-patched from the imported reference)."""
+    import torch
+    from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
+    from livelyspeaker_amd.model_util import create_model_and_diffusion, load_model_wo_clip
+    cfg = synth.TED
+    model, diffusion = create_model_and_diffusion(_mk_args(cfg, 50), "")
+    load_model_wo_clip(model, {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()})
+    model = ClassifierFreeSampleModel(model)
+    model.to("cuda:0")
+    model.eval()
+    y = {k: torch.from_numpy(v) for k, v in synth.make_cond(cfg, 4).items()}
+    ox_before = y["origin_x"].clone()
+    torch.manual_seed(233)
+    sample = diffusion.p_sample_loop(model, (4, model.njoints, model.nfeats, 34), clip_denoised=False,
+                                     model_kwargs={"y": y}, skip_timesteps=0, init_image=None, progress=True,
+                                     dump_steps=None, noise=None, const_noise=False)
+    assert sample.is_cuda and tuple(sample.shape) == (4, 9, 3, 34)
+    d = max_abs(sample.cpu().numpy(), golden["ted"]["G7_seed233_ddpm50_final"])
+    print(f"G7 identical-seeds max|d| = {d:.3e}")
+    assert d < TOL_LOOP
+    # RAG.py:110 side effect on the caller's dict
+    assert torch.equal(y["origin_x"][..., :4], ox_before[..., :4]) and float(y["origin_x"][..., 4:].abs().max()) == 0.0
+
+
+def test_dropin_reference_default_init_forward(golden, monkeypatch):
+    """Literal 'random-init' weights: torch.manual_seed(5); RAG(...) replays the reference's init order, and
+    model(x, t, y=...) matches the reference's forward with those weights (fixture G8)."""
+    import torch
+    from livelyspeaker_amd import rag
+    from livelyspeaker_amd.model_util import create_model_and_diffusion
+    cfg = synth.TED
+    torch.manual_seed(5)
+    model, _ = create_model_and_diffusion(_mk_args(cfg, 1000), "")
+    model.to("cuda:0")
+    model.eval()
+    x, eps, _ = _g1_inputs(cfg)
+    y = {k: torch.from_numpy(v) for k, v in synth.make_cond(cfg, 4).items()}
+    monkeypatch.setattr(rag.torch, "randn", lambda *s, **k: torch.from_numpy(eps[0][:, None, :].copy()))
+    out = model(torch.from_numpy(x), torch.full((4,), 500, dtype=torch.long), y=y)
+    assert set(out) == {"output", "z_mu", "z_logvar"} and tuple(out["z_mu"].shape) == (4, 1, 512)
+    d = max_abs(out["output"].numpy(), golden["ted"]["G8_refinit_t500_c"])
+    print(f"G8 reference-init forward max|d| = {d:.3e}")
+    assert d < TOL_FWD
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full size (batch 512): size-independent properties + spot checks against the oracle
+@pytest.fixture(scope="module")
+def big():
+    cfg, eng = _engine("ted")
+    from oracle import rag_oracle as orc
+    B, steps = 512, 12
+    y = synth.make_cond(cfg, B)
+    eng.set_schedule(orc.Schedule(steps, ""))
+    eng.prepare(y)
+    yield dict(cfg=cfg, eng=eng, orc=orc, B=B, steps=steps, y=y)
+    eng.close()
+
+
+def test_full_batch_spot_check_vs_oracle(big):
+    """B=512 through the HIP path; three samples re-run alone through the CPU oracle on the same tape."""
+    from livelyspeaker_amd import _lib
+    cfg, eng, orc, B, steps, y = (big[k] for k in ("cfg", "eng", "orc", "B", "steps", "y"))
+    tape = synth.NoiseTape(cfg, B, steps)
+    out = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise)
+    assert np.isfinite(out).all()
+    pick = [0, 257, 511]
+    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    ys = {k: v[pick] for k, v in y.items()}
+    want = orc.sample_loop(oracle, orc.Schedule(steps, ""), ys, tape.x_init[pick], tape.eps[:, :, pick], tape.noise[:, pick])
+    d = max_abs(out[pick], want)
+    print(f"B=512 spot check max|d| = {d:.3e}")
+    assert d < TOL_LOOP
+    big["tape_out"] = out
+
+
+def test_full_batch_permutation_equivariance_and_determinism(big):
+    """No op couples samples: permuting the batch permutes the result bit-for-bit; replays are bitwise stable."""
+    from livelyspeaker_amd import _lib
+    cfg, eng, B, steps, y = (big[k] for k in ("cfg", "eng", "B", "steps", "y"))
+    tape = synth.NoiseTape(cfg, B, steps)
+    base = big.get("tape_out")
+    if base is None:
+        base = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise)
+    again = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise)
+    assert np.array_equal(base, again)
+    perm = np.random.Generator(np.random.PCG64(5)).permutation(B)
+    eng.prepare({k: v[perm] for k, v in y.items()})
+    out_p = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init[perm], eps_tape=tape.eps[:, :, perm],
+                       noise_tape=tape.noise[:, perm])
+    assert np.array_equal(out_p, base[perm])
+    eng.prepare(y)
+
+
+def test_philox_streams_are_shard_invariant(big):
+    """Config 4's premise: 512 clips on one GPU == two shards of 256 with sample_offset (what 2 GPUs would run)."""
+    from livelyspeaker_amd import _lib
+    eng, B, y = big["eng"], big["B"], big["y"]
+    whole = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=1234, sample_offset=0)
+    assert np.isfinite(whole).all() and float(np.abs(whole).max()) < 50
+    halves = []
+    for r in range(2):
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        eng.prepare({k: v[sl] for k, v in y.items()})
+        halves.append(eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=1234, sample_offset=r * B // 2))
+    assert np.array_equal(np.concatenate(halves), whole)
+    other = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=1235, sample_offset=B // 2)
+    assert not np.array_equal(other, halves[1])
+    eng.prepare(y)
+
+
+def test_philox_noise_is_standard_normal(big):
+    """x_T drawn on device (Philox + Box-Muller): with skip = T-1 and a zero init_image the single q_sample
+    leaves sqrt(1-abar)*noise, so the moments of the device RNG can be checked directly."""
+    from livelyspeaker_amd import _lib
+    cfg, eng, orc, B = big["cfg"], big["eng"], big["orc"], big["B"]
+    sch = orc.Schedule(1000, "")
+    eng.set_schedule(sch)
+    # one executed step at index 0 (no step noise): out = c1*x0 + c2*x_t ; isolate x_T statistics through x_t's weight
+    z = np.zeros((B, cfg.njoints, cfg.nfeats, cfg.nframes), np.float32)
+    a = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=7, skip_timesteps=999, init_image=z)
+    b = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=8, skip_timesteps=999, init_image=z)
+    assert not np.array_equal(a, b)
+    eng.set_schedule(orc.Schedule(big["steps"], ""))
