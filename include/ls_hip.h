@@ -171,6 +171,10 @@ int ls_step(ls_handle* h, const ls_step_args* a);
 int ls_q_sample(ls_handle* h, int index, int on_device, size_t n, const float* x_start,
                 const float* noise, float* out);
 
+/* The x_T draw of PHILOX mode on its own (what ls_sample uses when x_init == NULL): out [batch,J,F,T] ~ N(0,1),
+ * stream keyed by (seed, sample_offset + b). Lets tests check the device RNG's moments and shard-invariance. */
+int ls_philox_x_init(ls_handle* h, int batch, uint64_t seed, uint64_t sample_offset, int on_device, float* out);
+
 /* Read back a prepared intermediate into host memory (parity tests of the once-per-call stages):
  * "audio_feat" [B,T,256], "static_c"/"static_u" [B,T,D], "z_mu"/"z_logvar"/"z_std" [B,D],
  * "temb" [n_steps,D].  Returns the element count, or a negative error. */

@@ -67,7 +67,7 @@ class LsTiming(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize")
+           "ls_get_timing", "ls_synchronize", "ls_philox_x_init")
 
 _lib = None
 
@@ -85,6 +85,13 @@ def load_library(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch bundles its own libamdhip64; if libls_hip.so pulled in /opt/rocm's copy
+    # first, torch's later initialisation reports "No HIP GPUs are available".  Importing torch first makes the
+    # loader resolve our NEEDED libamdhip64.so.N to the copy torch already mapped (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = library_path()
     if build_if_missing and _build.is_stale():
         try:
@@ -113,6 +120,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_read.restype = C.c_longlong
     lib.ls_get_timing.argtypes = [C.c_void_p, C.POINTER(LsTiming)]
     lib.ls_synchronize.argtypes = [C.c_void_p]
+    lib.ls_philox_x_init.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     if lib.ls_abi_version() != 1:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
@@ -314,6 +322,12 @@ class Engine:
         out, pout = m.out(tuple(x_start.shape))
         n = int(np.prod(x_start.shape))
         self._check(self.lib.ls_q_sample(self.h, index, int(m.on_device), n, m.f32(x_start), m.f32(noise), pout), "ls_q_sample")
+        return out
+
+    def philox_x_init(self, batch, seed, sample_offset=0) -> np.ndarray:
+        out = np.empty((batch, self.J, self.F, self.T), np.float32)
+        self._check(self.lib.ls_philox_x_init(self.h, batch, int(seed), int(sample_offset), 0,
+                                              out.ctypes.data_as(C.c_void_p)), "ls_philox_x_init")
         return out
 
     def read(self, name: str) -> np.ndarray:

@@ -84,6 +84,9 @@ struct ls_handle {
 
     ls_timing timing{};
     CallParams call_host{0, 0};
+    DevBuf prof;
+    bool prof_on = false;   // LS_PROF=<workgroup index>: in-kernel s_memtime phase stamps, read with ls_read("prof")
+    int prof_wg = 0;
     int ablate = 0;         // LS_ABLATE (profiling only; results are wrong when non-zero)
 };
 
@@ -307,6 +310,8 @@ void fill_common(ls_handle* h, StepArgs& a) {
     a.layers = h->cfg.layers;
     a.sampler = kNone;
     a.ablate = h->ablate;
+    a.prof = h->prof_on ? static_cast<unsigned long long*>(h->prof.p) : nullptr;
+    a.prof_wg = h->prof_wg;
 }
 
 // per-step scalars, cast fp64 -> fp32 exactly like _extract_into_tensor (gaussian_diffusion.py:1651-1664)
@@ -363,6 +368,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     ls_handle* h = new ls_handle();
     h->cfg = *cfg;
     if (const char* ab = getenv("LS_ABLATE")) h->ablate = atoi(ab);
+    if (const char* pr = getenv("LS_PROF")) { h->prof_on = true; h->prof_wg = atoi(pr); }
     h->var = var;
     h->JF = JF;
     h->S = kT + cfg->n_prefix_tokens;
@@ -381,6 +387,10 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     }
     e = init_step_kernels();
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
+    if (h->prof_on) {
+        std::vector<unsigned long long> z((size_t)kWaves * kProfPoints, 0ull);
+        if (upload(h, h->prof, z.data(), z.size() * sizeof(unsigned long long)) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
+    }
     CallParams cp{0, 0};
     if (upload(h, h->callp, &cp, sizeof cp) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
     *out = h;
@@ -399,7 +409,7 @@ void ls_destroy(ls_handle* h) {
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
-                     &h->callp, &h->eps_tape, &h->noise_tape};
+                     &h->callp, &h->eps_tape, &h->noise_tape, &h->prof};
     for (DevBuf* d : all) d->release();
     for (int i = 0; i < 4; ++i) { h->conv_w[i].release(); h->conv_b[i].release(); }
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -743,6 +753,22 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     return LS_OK;
 }
 
+int ls_philox_x_init(ls_handle* h, int batch, uint64_t seed, uint64_t sample_offset, int on_device, float* out) {
+    if (!h || !out || batch < 1) return fail(h, LS_EINVAL, "ls_philox_x_init: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t nx = (size_t)batch * h->JF * kT * sizeof(float);
+    HIPCHK(h, h->xtmp.ensure(nx));
+    HIPCHK(h, h->xio.ensure(nx));
+    h->call_host = CallParams{seed, sample_offset};
+    HIPCHK(h, hipMemcpyAsync(h->callp.p, &h->call_host, sizeof(CallParams), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_randn_fill(h->xtmp.f(), batch, h->JF, static_cast<const CallParams*>(h->callp.p), 0u, h->stream));
+    HIPCHK(h, launch_from_internal(h->xtmp.f(), h->xio.f(), batch, h->JF, h->stream));
+    int rc = egress(h, out, h->xio.f(), nx, on_device);
+    if (rc != LS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LS_OK;
+}
+
 long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capacity) {
     if (!h || !name || !host_out) return fail(h, LS_EINVAL, "ls_read: null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -750,6 +776,13 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
     const float* src = nullptr;
     size_t cnt = 0;
     const size_t B = (size_t)h->B;
+    if (n == "prof") {
+        if (!h->prof_on) return fail(h, LS_ESTATE, "LS_PROF not set");
+        cnt = (size_t)kWaves * kProfPoints * 2;     // 64-bit stamps as pairs of 32-bit words
+        if (cnt > capacity) return fail(h, LS_EINVAL, "capacity");
+        HIPCHK(h, hipMemcpy(host_out, h->prof.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        return (long long)cnt;
+    }
     if (n == "temb") {
         if (!h->have_sched || !h->committed) return fail(h, LS_ESTATE, "temb needs weights and schedule");
         int rc = ensure_temb_table(h);

@@ -12,7 +12,8 @@ constexpr int kNT = 5;         // 16-row token tiles per workgroup     (2*S = 70
 constexpr int kUStride = 520;  // LDS row stride (floats) of the staged GEMM operand: conflict-free ds_read_b128
 constexpr int kT = 34;         // frames
 constexpr int kAudioFeat = 256;
-constexpr int kPeRows = 5000;  // PositionalEncoding max_len (mlp_module.py:105)
+constexpr int kPeRows = 5000;
+constexpr int kProfPoints = 96;  // PositionalEncoding max_len (mlp_module.py:105)
 
 enum SamplerKind { kDDPM = 0, kDDIM = 1, kNone = 2 };
 
@@ -69,6 +70,8 @@ struct StepArgs {
     // DDPM: x' = c0*x0 + c1*x_t + nz*c2*noise
     // DDIM: eps = (c0*x_t - x0)/c1 ; x' = x0*c2 + c3*eps + nz*c4*noise
     float* trace;            // [B][L+1][2S][512] or null
+    unsigned long long* prof;  // profiling only (env LS_PROF): [8 waves][kProfPoints] s_memtime stamps of workgroup prof_wg
+    int prof_wg;
     int ablate;              // profiling only (env LS_ABLATE): 1 skip channel-mix MFMAs, 2 skip token-mix, 4 skip LN stats
 };
 

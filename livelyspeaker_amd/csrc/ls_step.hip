@@ -70,11 +70,22 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s16 = lane & 15;
-    const int g = lane >> 4;
-    const int chw = 64 * w + 4 * g;          // + 16*cb + j  = this lane's channels
+    int s16 = lane & 15;
+    int g = lane >> 4;
+    int chw = 64 * w + 4 * g;                // + 16*cb + j  = this lane's channels
+    // Register-pressure control: the residual stream (80 VGPRs) must stay in registers for the whole forward.
+    // Left alone, LICM hoists every per-lane address of every phase out of the layer loop and keeps ~100 of them
+    // live across the MFMA loops, which pushes X into scratch (each LayerNorm then reloads it with ~50 serialized
+    // scratch_load + s_waitcnt pairs).  Laundering the lane id at phase boundaries makes those addresses
+    // phase-local: 3 VALU ops to recompute instead of a register held for the whole kernel.
+    auto fresh = [&]() {
+        asm volatile("" : "+v"(lane));
+        s16 = lane & 15;
+        g = lane >> 4;
+        chw = 64 * w + 4 * g;
+    };
 
     // Row metadata is recomputed where needed (tiles 0..3 are always fully valid; only tile 4 is ragged).
     auto row_of = [&](int t) { return 16 * t + s16; };
@@ -82,6 +93,12 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     auto rowc_of = [&](int t) { const int r = 16 * t + s16; return (16 * t + 15 < R || r < R) ? r : R - 1; };
 
     f4 X[kCB][kNT];
+
+    // debug-only phase stamps (LS_PROF): lane 0 of every wave of one workgroup records s_memtime
+    auto stamp = [&](int idx) {
+        if (a.prof && b == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
     // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
     {
@@ -94,6 +111,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             U[r * kUStride + k] = v;
         }
         __syncthreads();
+        fresh();
         const unsigned long long gidx = a.call ? a.call->sample_offset + (unsigned long long)b : (unsigned long long)b;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -168,6 +186,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     *reinterpret_cast<f4*>(tr + (size_t)row_of(t) * kD + chw + 16 * cb) = X[cb][t];
     };
     dump_trace(0);
+    stamp(1);
 
     // LN_spatial statistics over the 512 channels of each row (mlp_module.py:29-33): two-pass
     // (mean, then centred biased variance) like the reference; in-lane -> 4 lane groups -> 8 waves.
@@ -246,6 +265,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 
     // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
     for (int l = 0; l < a.layers; ++l) {
+        fresh();
         {   // x = x + emb  (emb re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
             const float* te = a.temb + (size_t)b * a.temb_stride + chw;
 #pragma unroll
@@ -258,8 +278,12 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         }
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
         ln_stats();
+        stamp(2 + 8 * l);
+        fresh();
         ln_store(a.W->ln1a + l * kD, a.W->ln1b + l * kD);
         __syncthreads();
+        stamp(3 + 8 * l);
+        fresh();
         // out[d][r] = sum_r' u[r'][d] * WW[r][r']  as D[channel][row]: A = u^T from LDS, B = the block-diagonal
         // token weights (same for every workgroup, L1/L2 resident).  Tile by tile so only 18 B + 16 acc
         // registers are live; the k range of a tile covers just the sequence(s) whose rows it holds.
@@ -293,12 +317,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 }
             }
         }
+        stamp(4 + 8 * l);
+        fresh();
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
-        ln_stats();      // its two barriers also order every wave's token-mix reads before the stores below
+        ln_stats();
+        stamp(5 + 8 * l);      // its two barriers also order every wave's token-mix reads before the stores below
         ln_store(a.W->ln2a + l * kD, a.W->ln2b + l * kD);
         __syncthreads();
+        stamp(6 + 8 * l);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+            fresh();
             f4 acc[2][kNT];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
@@ -328,6 +357,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                         for (int t = 0; t < kNT; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
             }
+            fresh();
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int cb = 2 * p + c2;
@@ -339,11 +369,15 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         for (int j = 0; j < 4; ++j) X[cb][t][j] += silu_f(acc[c2][t][j] + bc[j]);
                     }
             }
+            if (p == 0) stamp(7 + 8 * l);
         }
+        stamp(9 + 8 * l);
         dump_trace(l + 1);
     }
 
     // ================= OutputProcess.poseFinal (RAG.py:205-211) ====================================
+    stamp(2 + 8 * a.layers);
+    fresh();
     __syncthreads();                       // every wave is done reading the last LN2 operand
 #pragma unroll
     for (int t = 0; t < kNT; ++t)
@@ -375,6 +409,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             res[i] = a0 + a1;
         }
     }
+    stamp(3 + 8 * a.layers);
+    fresh();
     __syncthreads();                       // operand buffer is free: overlay OUT[row][c]
     float* OUT = U;
 #pragma unroll
@@ -428,6 +464,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             }
         }
     }
+    stamp(4 + 8 * a.layers);
 }
 
 size_t step_lds_bytes(Variant v) {

@@ -14,8 +14,8 @@ C-ABI; the loops below just draw noise in the reference's order and hand the who
 RNG contract ("identical seeds"): with ``noise_source='torch_cpu'`` (default) every
 draw the reference would make is made here from torch's CPU generator, in the same order and
 shape -- ``randn(*shape)`` once, then per step ``randn(B,1,512)`` x2 (style eps of the cond and
-uncond passes) and ``randn(B,J,F,T)`` -- so ``torch.manual_seed(s)`` reproduces the reference's
-CPU-path samples.  ``noise_source='philox'`` draws one 64-bit key from the torch generator and
+uncond passes) and ``randn_like(x)`` with x's strides (contiguous at the first step, [T][B][J][F] memory
+order afterwards) -- so ``torch.manual_seed(s)`` reproduces the reference's CPU-path samples (fixture G7).  ``noise_source='philox'`` draws one 64-bit key from the torch generator and
 generates all noise on the device (throughput mode; statistically equivalent, not bitwise).
 """
 from __future__ import annotations
@@ -171,7 +171,7 @@ class GaussianDiffusion:
         B = x.shape[0]
         eps_c = th.randn(B, 1, eng.D)           # cond pass reparameterize (RAG.py:12), then uncond pass
         eps_u = th.randn(B, 1, eng.D)
-        noise = th.randn(*x.shape)
+        noise = th.randn_like(x, device="cpu", dtype=th.float32)    # follows x's strides like the reference's randn_like(x)
         if const_noise:
             noise = noise[[0]].repeat(B, 1, 1, 1)
         out, x0 = eng.step(sampler, i, x, eps_c, eps_u, noise, eta=eta, clip_denoised=clip_denoised)
@@ -221,10 +221,16 @@ class GaussianDiffusion:
         else:
             eps = th.empty(n_exec, 2, B, eng.D)
             nz = th.empty((n_exec,) + shape)
+            # p_sample/ddim_sample draw `randn_like(x)` (gaussian_diffusion.py:543/787).  x is contiguous at the first
+            # executed step, but from then on it is the model-output-shaped view whose memory order is
+            # [T][B][J][F] (OutputProcess permutes, RAG.py:209-210), and randn_like preserves strides: the generator
+            # stream is consumed in MEMORY order through torch's non-contiguous CPU path.  Reproduce exactly that.
+            first_proto = noise.cpu() if (noise is not None and init_image is None and not skip_timesteps) else th.empty(shape)
+            later_proto = th.empty(shape[3], shape[0], shape[1], shape[2]).permute(1, 2, 3, 0)
             for k in range(n_exec):            # the reference's per-step draw order
                 eps[k, 0] = th.randn(B, 1, eng.D)[:, 0]
                 eps[k, 1] = th.randn(B, 1, eng.D)[:, 0]
-                nz[k] = th.randn(*shape)
+                nz[k] = th.randn_like(first_proto if k == 0 else later_proto, dtype=th.float32)
             kw["eps_tape"], kw["noise_tape"] = eps, nz
         kw["device_out"] = th.device(device).type == "cuda"
         res = eng.sample(**kw)

@@ -308,15 +308,15 @@ def test_philox_streams_are_shard_invariant(big):
 
 
 def test_philox_noise_is_standard_normal(big):
-    """x_T drawn on device (Philox + Box-Muller): with skip = T-1 and a zero init_image the single q_sample
-    leaves sqrt(1-abar)*noise, so the moments of the device RNG can be checked directly."""
-    from livelyspeaker_amd import _lib
-    cfg, eng, orc, B = big["cfg"], big["eng"], big["orc"], big["B"]
-    sch = orc.Schedule(1000, "")
-    eng.set_schedule(sch)
-    # one executed step at index 0 (no step noise): out = c1*x0 + c2*x_t ; isolate x_T statistics through x_t's weight
-    z = np.zeros((B, cfg.njoints, cfg.nfeats, cfg.nframes), np.float32)
-    a = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=7, skip_timesteps=999, init_image=z)
-    b = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=8, skip_timesteps=999, init_image=z)
-    assert not np.array_equal(a, b)
-    eng.set_schedule(orc.Schedule(big["steps"], ""))
+    """Device RNG (Philox4x32-10 + Box-Muller): moments, independence of neighbours, keying by global index."""
+    eng = big["eng"]
+    a = eng.philox_x_init(512, seed=7).astype(np.float64)
+    n = a.size
+    assert abs(a.mean()) < 4 / np.sqrt(n) and abs(a.var() - 1) < 0.02
+    assert abs((a ** 3).mean()) < 0.03 and abs((a ** 4).mean() - 3) < 0.08
+    flat = a.reshape(512, -1)
+    assert abs(np.mean(flat[:, :-1] * flat[:, 1:])) < 0.01 and abs(np.mean(flat[:-1] * flat[1:])) < 0.01
+    assert np.abs(a).max() < 6.5
+    b = eng.philox_x_init(256, seed=7, sample_offset=256)
+    assert np.array_equal(b, a[256:].astype(np.float32))          # stream follows the global sample index
+    assert not np.array_equal(eng.philox_x_init(256, seed=8, sample_offset=256), b)

@@ -139,10 +139,12 @@ def test_sampler_draws_noise_in_the_reference_order(monkeypatch):
     x_init = torch.randn(2, 9, 3, 34)
     assert torch.equal(torch.as_tensor(fake.kw["x_init"]), x_init)
     assert tuple(fake.kw["eps_tape"].shape) == (3, 2, 2, 512) and tuple(fake.kw["noise_tape"].shape) == (3, 2, 9, 3, 34)
+    later = torch.empty(34, 2, 9, 3).permute(1, 2, 3, 0)      # layout of x after the first step (RAG.py:209-210)
     for k in range(3):
         assert torch.equal(fake.kw["eps_tape"][k, 0], torch.randn(2, 1, 512)[:, 0])
         assert torch.equal(fake.kw["eps_tape"][k, 1], torch.randn(2, 1, 512)[:, 0])
-        assert torch.equal(fake.kw["noise_tape"][k], torch.randn(2, 9, 3, 34))
+        want = torch.randn(2, 9, 3, 34) if k == 0 else torch.randn_like(later)
+        assert torch.equal(fake.kw["noise_tape"][k], want)
     assert fake.kw["skip_timesteps"] == 2 and fake.kw["clip_denoised"] is False
     # explicit noise= replaces the initial draw (gaussian_diffusion.py:701-704)
     given = torch.full((2, 9, 3, 34), 0.5)

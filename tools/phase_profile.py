@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""In-kernel phase profile of ls::k_step (debug aid): LS_PROF=<workgroup> makes lane 0 of each wave of that
+workgroup record s_memtime at phase boundaries.  Prints mean cycles per phase (over waves and layers)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LS_PROF", "300")
+from livelyspeaker_amd import _lib, synth          # noqa: E402
+from oracle import rag_oracle as orc               # noqa: E402
+
+ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+cfg = synth.CONFIGS[ds]
+eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
+eng.load_state_dict(synth.make_state_dict(cfg))
+eng.set_schedule(orc.Schedule(8, ""))
+eng.prepare(synth.make_cond(cfg, B))
+for _ in range(2):
+    eng.sample(sampler=0, philox_seed=1)
+raw = np.empty(8 * 96 * 2, np.float32)
+n = eng.lib.ls_read(eng.h, b"prof", raw.ctypes.data_as(_lib.c_f32p), raw.size)
+st = raw.view(np.uint64).reshape(8, 96).astype(np.float64)
+L = 8
+names = ["LN1 stats(+temb)", "LN1 store+bar", "token-mix", "LN2 stats", "LN2 store+bar", "GEMM pass0+epi", "GEMM pass1+epi", "(trace)"]
+print(f"{ds} B={B}: total cycles (wave mean) = {np.mean(st[:, 4 + 8 * L] - st[:, 0]):.0f}")
+print(f"  embed                : {np.mean(st[:, 1] - st[:, 0]):9.0f}")
+prev = st[:, 1].copy()
+acc = np.zeros(7)
+for l in range(L):
+    pts = [2, 3, 4, 5, 6, 7, 9]
+    for i, pnt in enumerate(pts):
+        cur = st[:, pnt + 8 * l]
+        acc[i] += np.mean(cur - prev)
+        prev = cur
+for i in range(7):
+    print(f"  {names[i]:21s}: {acc[i] / L:9.0f} /layer")
+print(f"  X->U + barrier       : {np.mean(st[:, 2 + 8 * L] - prev):9.0f}")
+print(f"  out-proj MFMA        : {np.mean(st[:, 3 + 8 * L] - st[:, 2 + 8 * L]):9.0f}")
+print(f"  OUT + combine        : {np.mean(st[:, 4 + 8 * L] - st[:, 3 + 8 * L]):9.0f}")
+print("  per-wave totals:", (st[:, 4 + 8 * L] - st[:, 0]).astype(int).tolist())
+if os.environ.get("LS_PROF_RAW"):
+    l = 3
+    base = st[:, 1 + 8 * l].min()
+    print("per-wave stamps of layer 3 (cycles since earliest previous-layer end):")
+    for wv in range(8):
+        print(f"  wave {wv}:", [int(st[wv, p + 8 * l] - base) for p in (1, 2, 3, 4, 5, 6, 7, 9)])
