@@ -60,6 +60,9 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int MK = (R + 3) / 4;          // k steps of the token-mix GEMM
     constexpr int NU = NOB * kNT;            // output-projection work units
     constexpr int MAXU = (NU + kWaves - 1) / kWaves;
+    constexpr int kFullTiles = 4;            // token tiles whose 16 rows are all real
+    constexpr int NREM = R - 16 * kFullTiles;  // rows of the ragged last tile (6 TED / 8 BEAT)
+    static_assert(NREM > 0 && NREM <= 16, "ragged tile");
     static_assert(R <= 16 * kNT, "rows must fit the token tiles");
     static_assert(R * OSTR <= R * kUStride, "OUT overlay must fit the operand buffer");
 
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     float* U = smem;                         // [R][520]
     float* psum = smem + R * kUStride;       // [8][80]
     float* psq = psum + kWaves * 16 * kNT;   // [8][80]
+    float* REM = psq + kWaves * 16 * kNT;    // [8 waves][2][NREM][16] remainder-row patch
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -325,22 +329,33 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         ln_store(a.W->ln2a + l * kD, a.W->ln2b + l * kD);
         __syncthreads();
         stamp(6 + 8 * l);
+        // Rows 64..R-1 (6 of the 16 rows of tile 4) would waste 62 % of a fifth MFMA tile = 20 % of all channel-mix
+        // MFMAs.  They are computed instead on the VALU pipe, in the shadow of the MFMAs of tiles 0..3, from the
+        // same A-operand registers: lane (n, g) accumulates W[n][k(g)] * U[row][k(g)] over its k subset, the four
+        // lane groups are summed with two cross-lane adds, and a 6 KB per-wave LDS patch turns [channel-lane][row]
+        // into the residual layout [row-lane][channel-reg].
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             fresh();
-            f4 acc[2][kNT];
+            f4 acc[2][kFullTiles];
+            float racc[2][NREM];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
+            for (int c2 = 0; c2 < 2; ++c2) {
 #pragma unroll
-                for (int t = 0; t < kNT; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < NREM; ++r) racc[c2][r] = 0.f;
+            }
             gf4p wp = g4(a.W->wch_img) + ((size_t)((l * kWaves + w) * 2 + p) * 32) * 2 * 64 + lane;
+            const float* ub = U + s16 * kUStride + 4 * g;                 // tile t: + 16*t*kUStride
+            const float* ur = U + 16 * kFullTiles * kUStride + 4 * g;     // remainder row r: + r*kUStride
             f4 An[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
             if (!(a.ablate & 1))
 #pragma unroll 2
             for (int q = 0; q < 32; ++q) {
-                f4 A[2], Bv[kNT];
+                f4 A[2], Bv[kFullTiles], Ur[NREM];
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
                 if (q + 1 < 32) {
@@ -348,27 +363,51 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[((q + 1) * 2 + c2) * 64];
                 }
 #pragma unroll
-                for (int t = 0; t < kNT; ++t)
-                    Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
+                for (int t = 0; t < kFullTiles; ++t)
+                    Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < NREM; ++r) Ur[r] = *reinterpret_cast<const f4*>(ur + r * kUStride + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                        for (int t = 0; t < kNT; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+                        for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int r = 0; r < NREM; ++r) racc[c2][r] = fmaf(A[c2][j], Ur[r][j], racc[c2][r]);
+                }
             }
             fresh();
+            // remainder rows: sum the 4 k-subsets, then [channel-lane][row] -> [row-lane][channel-reg] through LDS
+            float* rem = REM + w * (2 * NREM * 16);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int r = 0; r < NREM; ++r) {
+                    float v = racc[c2][r];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (g == 0) rem[(c2 * NREM + r) * 16 + s16] = v;
+                }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int cb = 2 * p + c2;
                 const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * cb);
 #pragma unroll
-                for (int t = 0; t < kNT; ++t)
-                    if (valid_of(t)) {
+                for (int t = 0; t < kFullTiles; ++t) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) X[cb][t][j] += silu_f(acc[c2][t][j] + bc[j]);
-                    }
+                    for (int j = 0; j < 4; ++j) X[cb][t][j] += silu_f(acc[c2][t][j] + bc[j]);
+                }
+                if (s16 < NREM) {
+                    const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) X[cb][kFullTiles][j] += silu_f(rv[j] + bc[j]);
+                }
             }
+            __builtin_amdgcn_wave_barrier();
             if (p == 0) stamp(7 + 8 * l);
         }
         stamp(9 + 8 * l);
@@ -469,7 +508,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 
 size_t step_lds_bytes(Variant v) {
     const int S = (v == kTED) ? 35 : 36;
-    return (size_t)(2 * S * kUStride + 2 * kWaves * 16 * kNT) * sizeof(float);
+    const int nrem = 2 * S - 64;
+    return (size_t)(2 * S * kUStride + 2 * kWaves * 16 * kNT + kWaves * 2 * nrem * 16) * sizeof(float);
 }
 
 // Opt in to >64 KiB dynamic LDS once per process (must happen outside stream capture).
