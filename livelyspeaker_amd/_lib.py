@@ -77,7 +77,7 @@ class EngineError(RuntimeError):
 
 
 def library_path() -> str:
-    return _build.LIB
+    return os.environ.get("LS_LIB", _build.LIB)     # LS_LIB: A/B-test an alternative build (tools/ab_variants.py)
 
 
 def load_library(build_if_missing: bool = True):
@@ -93,7 +93,7 @@ def load_library(build_if_missing: bool = True):
     except Exception:
         pass
     path = library_path()
-    if build_if_missing and _build.is_stale():
+    if build_if_missing and "LS_LIB" not in os.environ and _build.is_stale():
         try:
             _build.build_library()
         except Exception as e:      # no hipcc on this box: fall through to whatever .so travelled here

@@ -358,26 +358,36 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 f4 A[2], Bv[kFullTiles], Ur[NREM];
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
-                if (q + 1 < 32) {
+                {
+                    const int qn = (q + 1 < 32) ? q + 1 : 31;       // branch-free prefetch (last one re-reads q=31)
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[((q + 1) * 2 + c2) * 64];
+                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[(qn * 2 + c2) * 64];
                 }
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t)
                     Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
 #pragma unroll
                 for (int r = 0; r < NREM; ++r) Ur[r] = *reinterpret_cast<const f4*>(ur + r * kUStride + 16 * q);
+                // Per k: [8 MFMAs][2*NREM scalar FMAs], order pinned.  A/B-tested on MI355X (tools/ab_variants.py, ms/step
+                // at B=512): this 1.513 | [32 MFMA][8*NREM FMA] 1.526 | compiler's own order 1.627 (it hoists the FMAs
+                // next to their ds_reads and stalls) | fine 2:3 interleave 1.646 | 5th MFMA tile instead of FMAs 1.645.
+                // fp32 MFMA and fp32 VALU share the SIMD's FMA lanes on gfx950 (removing the FMAs saves exactly their
+                // issue time), so the gain is the padding saved (6 rows of work instead of 16), not overlap; v_pk_fma_f32
+                // and s_setprio alternation between the two waves of a SIMD were measured and do not help.
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                         for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                         for (int r = 0; r < NREM; ++r) racc[c2][r] = fmaf(A[c2][j], Ur[r][j], racc[c2][r]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             fresh();
             // remainder rows: sum the 4 k-subsets, then [channel-lane][row] -> [row-lane][channel-reg] through LDS
