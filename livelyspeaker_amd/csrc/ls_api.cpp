@@ -55,7 +55,7 @@ struct ls_handle {
     unsigned weights_version = 0;
 
     // device weights
-    DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, bout, devw;
+    DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
     DevBuf conv_w[4], conv_b[4], win_full, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
     DevBuf te_w0, te_b0, te_w2, te_b2, pe;
 
@@ -222,10 +222,25 @@ int build_images(ls_handle* h) {
                     }
         for (int c = 0; c < JF; ++c) bout[c] = (*bo)[c];
     }
+    // wout_reg_img[w][ob][cb][lane][j] = Wout[c = 16ob + (lane&15)][k = 64w + 16cb + 4(lane>>4) + j]: the k order in which
+    // wave w's residual registers X[cb][.][j] present the hidden state as an MFMA B operand
+    std::vector<float> woutr((size_t)kWaves * NOB * kCB * 64 * 4);
+    {
+        size_t o = 0;
+        for (int w = 0; w < kWaves; ++w)
+            for (int ob = 0; ob < NOB; ++ob)
+                for (int cb = 0; cb < kCB; ++cb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = 16 * ob + (lane & 15);
+                            const int k = 64 * w + 16 * cb + 4 * (lane >> 4) + j;
+                            woutr[o++] = c < JF ? (*Wout)[(size_t)c * D + k] : 0.f;
+                        }
+    }
     int rc;
 #define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
-    UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(bout, bout);
+    UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
     UP(win_full, *Win); UP(win_bias, *bin);
     // raw weights used by the once-per-call kernels
     for (int i = 0; i < 4; ++i) {
@@ -271,7 +286,7 @@ int build_images(ls_handle* h) {
     dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
     dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
-    dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.bout = h->bout.f();
+    dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
     if ((rc = upload(h, h->devw, &dw, sizeof dw)) != LS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return LS_OK;
@@ -403,7 +418,7 @@ void ls_destroy(ls_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graph(h);
     DevBuf* all[] = {&h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
-                     &h->wout_img, &h->bout, &h->devw, &h->win_full, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
+                     &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
                      &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,

@@ -32,7 +32,8 @@ struct DevWeights {
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
     const float* btok_rows;  // [L][80]
     const float* winx_img;   // [8][2 passes][KXQ][2 cb][64][4]   x_t columns of input_mapping
-    const float* wout_img;   // [NOB][32][64][4]   poseFinal
+    const float* wout_img;   // [NOB][32][64][4]   poseFinal, k in natural order (operand staged in LDS)
+    const float* wout_reg_img; // [8][NOB][4][64][4] poseFinal, k in residual-register order (operand = registers)
     const float* bout;       // [NOB*16]
 };
 

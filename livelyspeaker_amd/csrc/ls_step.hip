@@ -27,6 +27,7 @@
 namespace ls {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -64,7 +65,6 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int NREM = R - 16 * kFullTiles;  // rows of the ragged last tile (6 TED / 8 BEAT)
     static_assert(NREM > 0 && NREM <= 16, "ragged tile");
     static_assert(R <= 16 * kNT, "rows must fit the token tiles");
-    static_assert(R * OSTR <= R * kUStride, "OUT overlay must fit the operand buffer");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* U = smem;                         // [R][520]
@@ -106,6 +106,45 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 
     // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
     {
+        // Base value of every row first (its loads overlap the x_t staging below): frame tokens start from the
+        // per-call static projection, prefix tokens from the style sample / emotion embedding.  The x_t columns of
+        // input_mapping are then accumulated ONTO these by using them as the MFMA C operand.
+        const unsigned long long gidx = a.call ? a.call->sample_offset + (unsigned long long)b : (unsigned long long)b;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            const int rc = rowc_of(t);
+            const int sq = rc >= S ? 1 : 0;
+            const int tk = rc - sq * S;
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                const int ch = chw + 16 * cb;
+                f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+                if (valid_of(t)) {
+                    if (tk >= NPRE) {
+                        const float* st = (sq ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + ch;
+                        v = *reinterpret_cast<const f4*>(st);
+                    } else if (tk == 0) {
+                        // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
+                        const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + ch);
+                        const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + ch);
+                        f4 e;
+                        const float* ep = sq ? a.eps_u : a.eps_c;
+                        if (ep) {
+                            e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + ch);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                e[j] = philox_normal(a.call, gidx, a.step_id, 1u + sq, (unsigned)(ch + j));
+                        }
+                        v = mu + e * sd;
+                    } else {
+                        // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
+                        v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);
+                    }
+                }
+                X[cb][t] = v;
+            }
+        }
         const float* xin = a.x_in + (size_t)b * kT * JF;
         for (int idx = tid; idx < R * KXP; idx += 512) {
             const int r = idx / KXP, k = idx - r * KXP;
@@ -116,14 +155,13 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         }
         __syncthreads();
         fresh();
-        const unsigned long long gidx = a.call ? a.call->sample_offset + (unsigned long long)b : (unsigned long long)b;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             f4 acc[2][kNT];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                for (int t = 0; t < kNT; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < kNT; ++t) acc[c2][t] = X[2 * p + c2][t];
             gf4p wp = g4(a.W->winx_img) + (size_t)(w * 2 + p) * KXQ * 2 * 64 + lane;
 #pragma unroll 2
             for (int q = 0; q < KXQ; ++q) {
@@ -141,41 +179,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         for (int t = 0; t < kNT; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
             }
 #pragma unroll
-            for (int t = 0; t < kNT; ++t) {
-                const int rc = rowc_of(t);
-                const int sq = rc >= S ? 1 : 0;
-                const int tk = rc - sq * S;
+            for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
-                    const int cb = 2 * p + c2;
-                    const int ch = chw + 16 * cb;
-                    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-                    if (valid_of(t)) {
-                        if (tk >= NPRE) {
-                            const float* st = (sq ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + ch;
-                            v = acc[c2][t] + *reinterpret_cast<const f4*>(st);
-                        } else if (tk == 0) {
-                            // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
-                            const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + ch);
-                            const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + ch);
-                            f4 e;
-                            const float* ep = sq ? a.eps_u : a.eps_c;
-                            if (ep) {
-                                e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + ch);
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    e[j] = philox_normal(a.call, gidx, a.step_id, 1u + sq, (unsigned)(ch + j));
-                            }
-                            v = mu + e * sd;
-                        } else {
-                            // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
-                            v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);
-                        }
-                    }
-                    X[cb][t] = v;
-                }
-            }
+                for (int t = 0; t < kNT; ++t)
+                    X[2 * p + c2][t] = valid_of(t) ? acc[c2][t] : (f4){0.f, 0.f, 0.f, 0.f};   // pad rows stay zero
         }
     }
 
@@ -192,8 +199,11 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     dump_trace(0);
     stamp(1);
 
-    // LN_spatial statistics over the 512 channels of each row (mlp_module.py:29-33): two-pass
-    // (mean, then centred biased variance) like the reference; in-lane -> 4 lane groups -> 8 waves.
+    // LN_spatial statistics over the 512 channels of each row (mlp_module.py:29-33).  The reference is two-pass
+    // (mean, then centred biased variance).  Here every lane does the two passes over its own 16 channels and the
+    // (mean, M2) pairs are merged pairwise with Chan's parallel-variance update -- across the 4 lane groups with two
+    // cross-lane exchanges, across the 8 waves through LDS -- which is as cancellation-free as two-pass but needs
+    // ONE workgroup barrier per LayerNorm instead of two.
     float mean[kNT], rstd[kNT];
     auto ln_stats = [&]() {
         if (a.ablate & 4) {
@@ -201,53 +211,54 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             for (int t = 0; t < kNT; ++t) { mean[t] = 0.f; rstd[t] = 1.f; }
             return;
         }
-        float part[kNT];
+        f2* pst = reinterpret_cast<f2*>(psum);            // [8 waves][80 rows] (mean, M2) of 64 channels
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
             float s = 0.f;
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) s += (X[cb][t][0] + X[cb][t][1]) + (X[cb][t][2] + X[cb][t][3]);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            part[t] = s;
-        }
-        if (g == 0) {
-#pragma unroll
-            for (int t = 0; t < kNT; ++t) psum[w * 80 + 16 * t + s16] = part[t];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < kNT; ++t) {
-            float s = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < kWaves; ++ww) s += psum[ww * 80 + 16 * t + s16];
-            mean[t] = s * (1.0f / kD);
-        }
-#pragma unroll
-        for (int t = 0; t < kNT; ++t) {
-            float s = 0.f;
+            float m = s * (1.0f / 16.0f), m2 = 0.f;
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float d = X[cb][t][j] - mean[t];
-                    s += d * d;
+                    const float d = X[cb][t][j] - m;
+                    m2 = fmaf(d, d, m2);
                 }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            part[t] = s;
-        }
-        if (g == 0) {
-#pragma unroll
-            for (int t = 0; t < kNT; ++t) psq[w * 80 + 16 * t + s16] = part[t];
+            {   // merge with the lane group 16 lanes away (16 + 16 values), then 32 lanes away (32 + 32)
+                const float mo = __shfl_xor(m, 16), m2o = __shfl_xor(m2, 16);
+                const float d = mo - m;
+                m2 = (m2 + m2o) + d * d * 8.0f;
+                m = 0.5f * (m + mo);
+            }
+            {
+                const float mo = __shfl_xor(m, 32), m2o = __shfl_xor(m2, 32);
+                const float d = mo - m;
+                m2 = (m2 + m2o) + d * d * 16.0f;
+                m = 0.5f * (m + mo);
+            }
+            if (g == 0) pst[w * 80 + 16 * t + s16] = (f2){m, m2};
         }
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
-            float s = 0.f;
+            f2 pw[kWaves];
+            float ms = 0.f, m2s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < kWaves; ++ww) s += psq[ww * 80 + 16 * t + s16];
-            rstd[t] = rsqrtf(s * (1.0f / kD) + 1e-5f);
+            for (int ww = 0; ww < kWaves; ++ww) {
+                pw[ww] = pst[ww * 80 + 16 * t + s16];
+                ms += pw[ww].x;
+                m2s += pw[ww].y;
+            }
+            const float mt = ms * (1.0f / kWaves);
+            float dd = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) {
+                const float d = pw[ww].x - mt;
+                dd = fmaf(d, d, dd);
+            }
+            mean[t] = mt;
+            rstd[t] = rsqrtf((m2s + 64.0f * dd) * (1.0f / kD) + 1e-5f);
         }
     };
     // write LN(x)*alpha+beta of this lane's channels into the LDS operand buffer
@@ -427,51 +438,94 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     // ================= OutputProcess.poseFinal (RAG.py:205-211) ====================================
     stamp(2 + 8 * a.layers);
     fresh();
-    __syncthreads();                       // every wave is done reading the last LN2 operand
-#pragma unroll
-    for (int t = 0; t < kNT; ++t)
-        if (valid_of(t))
-#pragma unroll
-            for (int cb = 0; cb < kCB; ++cb)
-                *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = X[cb][t];
-    __syncthreads();
-    f4 res[MAXU];
-#pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-        const int u = w + kWaves * i;      // wave-uniform
-        res[i] = (f4){0.f, 0.f, 0.f, 0.f};
-        if (u < NU) {
-            const int ob = u / kNT, t = u - ob * kNT;
-            const int rc = (16 * t + s16 < R) ? 16 * t + s16 : R - 1;
-            gf4p wp = g4(a.W->wout_img) + (size_t)ob * 32 * 64 + lane;
-            const float* up = &U[rc * kUStride + 4 * g];
-            f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll 4
-            for (int q = 0; q < 32; ++q) {
-                const f4 A = wp[q * 64];
-                const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * q);
-                a0 = MFMA(A[0], Bv[0], a0);
-                a1 = MFMA(A[1], Bv[1], a1);
-                a0 = MFMA(A[2], Bv[2], a0);
-                a1 = MFMA(A[3], Bv[3], a1);
-            }
-            res[i] = a0 + a1;
-        }
-    }
-    stamp(3 + 8 * a.layers);
-    fresh();
-    __syncthreads();                       // operand buffer is free: overlay OUT[row][c]
+    __syncthreads();                       // every wave is done reading the last LN2 operand: U is free
+    constexpr bool kOutFromRegs = (NOB <= 2);
+    constexpr int OROWS = kOutFromRegs ? kWaves * R : R;      // rows of the OUT / partial buffer overlaid on U
+    static_assert(OROWS * OSTR <= R * kUStride, "OUT overlay must fit the operand buffer");
     float* OUT = U;
+    if constexpr (kOutFromRegs) {
+        // Narrow output (TED, 27 features): every wave contracts over ITS OWN 64 channels straight from the residual
+        // registers (the residual layout is a valid MFMA B operand; the weight image carries the matching k
+        // permutation), writes a [R][32] partial, and the 8 partials are summed in the epilogue below.  No x -> LDS
+        // round trip, no latency-bound k loop on two waves.
+        f4 acc[NOB][kNT];
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-        const int u = w + kWaves * i;
-        if (u < NU) {
-            const int ob = u / kNT, t = u - ob * kNT;
-            const int r = 16 * t + s16;
-            if (r < R) *reinterpret_cast<f4*>(&OUT[r * OSTR + 16 * ob + 4 * g]) = res[i];
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) acc[ob][t] = (f4){0.f, 0.f, 0.f, 0.f};
+        gf4p wr = g4(a.W->wout_reg_img) + (size_t)w * NOB * kCB * 64 + lane;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                const f4 A = wr[(ob * kCB + cb) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t) acc[ob][t] = MFMA(A[j], X[cb][t][j], acc[ob][t]);
+            }
+        stamp(3 + 8 * a.layers);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int t = 0; t < kNT; ++t)
+                if (valid_of(t))
+                    *reinterpret_cast<f4*>(&OUT[(w * R + row_of(t)) * OSTR + 16 * ob + 4 * g]) = acc[ob][t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+            if (valid_of(t))
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb)
+                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = X[cb][t];
+        __syncthreads();
+        f4 res[MAXU];
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = w + kWaves * i;      // wave-uniform
+            res[i] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (u < NU) {
+                const int ob = u / kNT, t = u - ob * kNT;
+                const int rc = (16 * t + s16 < R) ? 16 * t + s16 : R - 1;
+                gf4p wp = g4(a.W->wout_img) + (size_t)ob * 32 * 64 + lane;
+                const float* up = &U[rc * kUStride + 4 * g];
+                f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll 4
+                for (int q = 0; q < 32; ++q) {
+                    const f4 A = wp[q * 64];
+                    const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * q);
+                    a0 = MFMA(A[0], Bv[0], a0);
+                    a1 = MFMA(A[1], Bv[1], a1);
+                    a0 = MFMA(A[2], Bv[2], a0);
+                    a1 = MFMA(A[3], Bv[3], a1);
+                }
+                res[i] = a0 + a1;
+            }
+        }
+        stamp(3 + 8 * a.layers);
+        fresh();
+        __syncthreads();                       // operand buffer is free: overlay OUT[row][c]
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = w + kWaves * i;
+            if (u < NU) {
+                const int ob = u / kNT, t = u - ob * kNT;
+                const int r = 16 * t + s16;
+                if (r < R) *reinterpret_cast<f4*>(&OUT[r * OSTR + 16 * ob + 4 * g]) = res[i];
+            }
         }
     }
     __syncthreads();
+    auto out_at = [&](int r, int c) {
+        if constexpr (kOutFromRegs) {
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) v += OUT[(ww * R + r) * OSTR + c];
+            return v;
+        } else {
+            return OUT[r * OSTR + c];
+        }
+    };
 
     // ====== CFG lerp (cfg_sampler.py:31) + posterior / DDIM update (gaussian_diffusion.py:260-282,
     //        507-558, 745-798), written back in the internal [B][T][JF] layout ======================
@@ -482,8 +536,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         for (int idx = tid; idx < kT * JF; idx += 512) {
             const int f = idx / JF, c = idx - f * JF;
             const float bo = g1(a.W->bout)[c];
-            const float oc = OUT[(NPRE + f) * OSTR + c] + bo;
-            const float ou = OUT[(S + NPRE + f) * OSTR + c] + bo;
+            const float oc = out_at(NPRE + f, c) + bo;
+            const float ou = out_at(S + NPRE + f, c) + bo;
             if (a.fwd_c) a.fwd_c[base + idx] = oc;
             if (a.fwd_u) a.fwd_u[base + idx] = ou;
             float x0 = ou + sc * (oc - ou);
