@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE_STEP = {"ted": 317_431_808, "beat": 362_496_000}     # BASELINE.md section 3 (CFG: 2 forwards, hoisted form)
 MFMA_F32_PEAK_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# HBM bytes per k_step launch from rocprofv3 PMC passes (profiles/r01b_kernel_trace_and_pmc.md): 2*FETCH_SIZE + WRITE_SIZE
+# (KiB -> B, with the guide's gfx950 FETCH_SIZE correction); measured for the default workload only.
+PMC_TRAFFIC_BYTES = {("ted", 512): 219_482_784}
 
 
 def parse():
@@ -183,7 +186,8 @@ def main():
                        "hipgraph": bool(diffusion.use_graph)},
             "roofline": {"bound": "mfma", "kernel": "ls::k_step (fused CFG denoiser + sampler update, 1 launch/step)",
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                         "traffic": PMC_TRAFFIC_BYTES.get((a.dataset, B)), "traffic_unit": "B/launch (rocprofv3 PMC, profiles/)",
                          "kernel_ms": round(kernel_ms, 4), "flop_per_launch": FLOP_PER_SAMPLE_STEP[a.dataset] * B,
                          "prepare_ms_per_call": round(prep_ms / a.steps, 3)},
         }
