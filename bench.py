@@ -109,8 +109,10 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with a single rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = synth.CONFIGS[a.dataset]
@@ -119,7 +121,7 @@ def main():
     # random-init weights of the architecture, re-drawn with non-degenerate scale (the reference's own init
     # zeroes the channel-mix weights); rank 0's copy is broadcast over RCCL so all ranks agree.
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=synth.SEED_WEIGHTS + (0 if rank == 0 else 1)).items()}
-    if world > 1:
+    if use_dist:
         from livelyspeaker_amd import shard
         sd = shard.broadcast_state_dict(sd, dev)
     model.load_state_dict(sd, strict=False)
@@ -142,7 +144,7 @@ def main():
                   progress=False, dump_steps=None, noise=None, const_noise=False)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +164,7 @@ def main():
         prep_ms += tm["prepare_ms"]
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -194,7 +196,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, a)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

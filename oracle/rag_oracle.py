@@ -303,7 +303,7 @@ def ddim_update(sch: Schedule, x, x0, i: int, noise, eta: float = 0.0):
 
 def sample_loop(model: RagOracle, sch: Schedule, y: dict, x_init, eps_tape, noise_tape,
                 ddim=False, eta=0.0, skip_timesteps=0, init_image=None, hoisted=True,
-                dump_steps=None, max_steps=None):
+                dump_steps=None, max_steps=None, clip_denoised=False):
     """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:608-743, 895-1014) with the CFG
     wrapper inlined. eps_tape[k] = (eps_cond, eps_uncond) [2,B,512]; noise_tape[k] [B,J,F,T];
     k counts executed steps. Returns final sample (and pred_xstart dumps if requested)."""
@@ -322,6 +322,8 @@ def sample_loop(model: RagOracle, sch: Schedule, y: dict, x_init, eps_tape, nois
             break
         t_model = np.full((B,), sch.timestep_map[i], dtype=np.int64)     # _WrappedModel, respace.py:125-130
         x0 = model.cfg_forward(img, t_model, y, eps_tape[k][0], eps_tape[k][1], hoisted)
+        if clip_denoised:                                                 # process_xstart, gaussian_diffusion.py:365-371
+            x0 = np.clip(x0, -1, 1)
         if dump_steps is not None and k in dump_steps:
             dumps.append(x0.copy())
         img = (ddim_update(sch, img, x0, i, noise_tape[k], eta) if ddim
