@@ -175,9 +175,13 @@ int build_images(ls_handle* h) {
                             for (int j = 0; j < 4; ++j) {
                                 const int n = 64 * w + 16 * (2 * p + c2) + (lane & 15);
                                 const int k = 16 * q + 4 * (lane >> 4) + j;
-                                wch[o++] = (*W)[(size_t)n * D + k];
+                                wch[o++] = (*W)[(size_t)n * D + k] * (*a2)[k];        // W' = W . diag(alpha2)
                             }
-        memcpy(&bch[(size_t)l * D], b2->data(), D * sizeof(float));
+        for (int n = 0; n < D; ++n) {                                                    // b' = b + W . beta2
+            double acc = (*b2)[n];
+            for (int k = 0; k < D; ++k) acc += (double)(*W)[(size_t)n * D + k] * (double)(*be2)[k];
+            bch[(size_t)l * D + n] = (float)acc;
+        }
         memcpy(&l1a[(size_t)l * D], a1->data(), D * sizeof(float));
         memcpy(&l1b[(size_t)l * D], be1->data(), D * sizeof(float));
         memcpy(&l2a[(size_t)l * D], a2->data(), D * sizeof(float));

@@ -33,6 +33,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp), far inside the 1e-3 parity budget.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// r + SiLU(v) in 5 VALU ops: v_mul (exp2 scale), v_exp, v_add, v_rcp, v_fma -- these epilogues are issue-bound
+__device__ __forceinline__ float silu_acc(float v, float r) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+    return fmaf(v, s, r);
+}
 
 // Pointers fetched from the DevWeights block are generic to the compiler; cast them to the global
 // address space so loads are global_load (vmcnt only) instead of flat_load (vmcnt AND lgkmcnt, which
@@ -261,18 +266,29 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             rstd[t] = rsqrtf((m2s + 64.0f * dd) * (1.0f / kD) + 1e-5f);
         }
     };
-    // write LN(x)*alpha+beta of this lane's channels into the LDS operand buffer
+    // write the normalised operand of this lane's channels into the LDS buffer: LN1 applies alpha/beta here
+    // (2 FMAs per element); LN2's alpha/beta are folded into the channel-mix weights/bias on the host
+    // (W' = W.diag(alpha), b' = b + W.beta), so its operand is just (x - mean) * rstd: 1 FMA per element.
     auto ln_store = [&](const float* alpha, const float* beta) {
+        float nmr[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) nmr[t] = -mean[t] * rstd[t];
 #pragma unroll
         for (int cb = 0; cb < kCB; ++cb) {
-            const f4 al = *g4(alpha + chw + 16 * cb);
-            const f4 be = *g4(beta + chw + 16 * cb);
+            f4 al, be;
+            if (alpha) {
+                al = *g4(alpha + chw + 16 * cb);
+                be = *g4(beta + chw + 16 * cb);
+            }
 #pragma unroll
             for (int t = 0; t < kNT; ++t)
                 if (valid_of(t)) {
                     f4 u;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) u[j] = (X[cb][t][j] - mean[t]) * rstd[t] * al[j] + be[j];
+                    for (int j = 0; j < 4; ++j) {
+                        u[j] = fmaf(X[cb][t][j], rstd[t], nmr[t]);
+                        if (alpha) u[j] = fmaf(u[j], al[j], be[j]);
+                    }
                     *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
                 }
         }
@@ -311,9 +327,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                 for (int m = 0; m < MK; ++m)
                     if (tokmix_needed(S, t, m)) Bt[m] = wwp[(t * MK + m) * 64];
+                const float bt = valid_of(t) ? g1(a.W->btok_rows)[l * 80 + row_of(t)] : 0.f;    // Conv1d bias of this row
                 f4 acc[kCB];
 #pragma unroll
-                for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){bt, bt, bt, bt};
 #pragma unroll
                 for (int m = 0; m < MK; ++m) {
                     if (tokmix_needed(S, t, m)) {
@@ -324,11 +341,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     }
                 }
                 if (valid_of(t)) {
-                    const float bt = g1(a.W->btok_rows)[l * 80 + row_of(t)];
 #pragma unroll
                     for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) X[cb][t][j] += silu_f(acc[cb][j] + bt);
+                        for (int j = 0; j < 4; ++j) X[cb][t][j] = silu_acc(acc[cb][j], X[cb][t][j]);
                 }
             }
         }
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
         ln_stats();
         stamp(5 + 8 * l);      // its two barriers also order every wave's token-mix reads before the stores below
-        ln_store(a.W->ln2a + l * kD, a.W->ln2b + l * kD);
+        ln_store(nullptr, nullptr);
         __syncthreads();
         stamp(6 + 8 * l);
         // Rows 64..R-1 (6 of the 16 rows of tile 4) would waste 62 % of a fifth MFMA tile = 20 % of all channel-mix
@@ -352,8 +368,9 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             float racc[2][NREM];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
+                const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));   // Linear bias (+ W.beta of LN2)
 #pragma unroll
-                for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = bc;
 #pragma unroll
                 for (int r = 0; r < NREM; ++r) racc[c2][r] = 0.f;
             }
@@ -420,12 +437,12 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) X[cb][t][j] += silu_f(acc[c2][t][j] + bc[j]);
+                    for (int j = 0; j < 4; ++j) X[cb][t][j] = silu_acc(acc[c2][t][j], X[cb][t][j]);
                 }
                 if (s16 < NREM) {
                     const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) X[cb][kFullTiles][j] += silu_f(rv[j] + bc[j]);
+                    for (int j = 0; j < 4; ++j) X[cb][kFullTiles][j] = silu_acc(rv[j] + bc[j], X[cb][kFullTiles][j]);
                 }
             }
             __builtin_amdgcn_wave_barrier();

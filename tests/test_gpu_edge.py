@@ -159,6 +159,6 @@ def test_abi_error_behaviour(ted):
     with pytest.raises(L.EngineError, match="DDPM only"):
         eng.sample(sampler=L.LS_SAMPLER_DDIM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise, dump_steps=[0])
     with pytest.raises(L.EngineError, match="skip_timesteps"):
-        eng.sample(sampler=L.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise, skip_timesteps=4)
+        eng.sample(sampler=L.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps[:0], noise_tape=tape.noise[:0], skip_timesteps=4)
     with pytest.raises(L.EngineError):
         eng.step(L.LS_SAMPLER_DDPM, 9, tape.x_init, tape.eps[0, 0], tape.eps[0, 1], tape.noise[0])
