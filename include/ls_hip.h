@@ -182,6 +182,29 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
 int ls_get_timing(const ls_handle* h, ls_timing* out);
 int ls_synchronize(ls_handle* h);
 
+/* ---- SAG decoder ---------------------------------------------------------------
+ * Decoder_TRANSFORMER (scripts/model/motionclip_module.py:98-183), called as SAG.decoder(batch) at
+ * scripts/test_LivelySpeaker_ted.py:88 to produce init_image for the RAG refine loop.  Separate handle: it is a
+ * different network with its own checkpoint (SAG.pth, keys 'decoder.*' with the prefix stripped). */
+typedef struct ls_sag ls_sag;
+typedef struct ls_sag_config {
+    int32_t njoints, nfeats, nframes;   /* 9, 3, 34                                   */
+    int32_t latent_dim, ff_size;        /* 512, 1024                                  */
+    int32_t num_layers, num_heads;      /* 3, 4                                       */
+    int32_t n_pre_poses;                /* 4                                          */
+    int32_t device;
+    int32_t reserved;
+} ls_sag_config;
+int ls_sag_create(const ls_sag_config* cfg, ls_sag** out);
+void ls_sag_destroy(ls_sag* h);
+const char* ls_sag_last_error(const ls_sag* h);
+int ls_sag_set_weight(ls_sag* h, const char* key, const float* data, size_t n);
+int ls_sag_commit_weights(ls_sag* h);
+/* batch['x'] [B,J,F,T], batch['z'] [B,latent] (CLIP text feature), batch['mask'] [B,T] bytes or NULL (all true)
+ * -> batch['output'] [B,J,F,T] */
+int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask,
+                  float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,11 @@ class LsStepArgs(C.Structure):
                 ("sample", C.c_void_p), ("pred_xstart", C.c_void_p)]
 
 
+class LsSagConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("njoints", "nfeats", "nframes", "latent_dim", "ff_size", "num_layers",
+                                         "num_heads", "n_pre_poses", "device", "reserved")]
+
+
 class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32)]
@@ -67,7 +72,8 @@ class LsTiming(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_philox_x_init")
+           "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode")
 
 _lib = None
 
@@ -121,6 +127,14 @@ def load_library(build_if_missing: bool = True):
     lib.ls_get_timing.argtypes = [C.c_void_p, C.POINTER(LsTiming)]
     lib.ls_synchronize.argtypes = [C.c_void_p]
     lib.ls_philox_x_init.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+    lib.ls_sag_create.argtypes = [C.POINTER(LsSagConfig), C.POINTER(C.c_void_p)]
+    lib.ls_sag_destroy.argtypes = [C.c_void_p]
+    lib.ls_sag_destroy.restype = None
+    lib.ls_sag_last_error.argtypes = [C.c_void_p]
+    lib.ls_sag_last_error.restype = C.c_char_p
+    lib.ls_sag_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_sag_commit_weights.argtypes = [C.c_void_p]
+    lib.ls_sag_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if lib.ls_abi_version() != 1:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
@@ -343,3 +357,57 @@ class Engine:
         t = LsTiming()
         self.lib.ls_get_timing(self.h, C.byref(t))
         return {k: getattr(t, k) for k, _ in LsTiming._fields_}
+
+
+class SagEngine:
+    """ctypes wrapper of the SAG decoder handle (ls_sag_*): Decoder_TRANSFORMER.forward on the GPU."""
+
+    def __init__(self, njoints=9, nfeats=3, nframes=34, latent_dim=512, ff_size=1024, num_layers=3, num_heads=4,
+                 n_pre_poses=4, device=0):
+        self.lib = load_library()
+        self.cfg = LsSagConfig(njoints, nfeats, nframes, latent_dim, ff_size, num_layers, num_heads, n_pre_poses, device, 0)
+        self.h = C.c_void_p()
+        rc = self.lib.ls_sag_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise EngineError(f"ls_sag_create failed ({rc}): {self.lib.ls_sag_last_error(None).decode()}")
+        self.J, self.F, self.T, self.D, self.device = njoints, nfeats, nframes, latent_dim, device
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.ls_sag_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.ls_sag_last_error(self.h).decode()}")
+
+    def load_state_dict(self, sd: dict):
+        for k, v in sd.items():
+            a = _np32(v)
+            self._check(self.lib.ls_sag_set_weight(self.h, k.encode(), a.ctypes.data_as(c_f32p), a.size), f"ls_sag_set_weight({k})")
+        self._check(self.lib.ls_sag_commit_weights(self.h), "ls_sag_commit_weights")
+
+    def decode(self, x, z, mask=None):
+        m = _Marshal(self.device, x, z, mask)
+        B = int(x.shape[0])
+        out, pout = m.out((B, self.J, self.F, self.T))
+        pmask = None
+        if mask is not None:
+            if m.on_device:
+                t = m.torch.as_tensor(mask).to(device=m.dev, dtype=m.torch.uint8).contiguous()
+                m.keep.append(t)
+                pmask = C.c_void_p(t.data_ptr())
+            else:
+                a = mask.detach().cpu().numpy() if hasattr(mask, "detach") else mask
+                a = np.ascontiguousarray(a, dtype=np.uint8)
+                m.keep.append(a)
+                pmask = a.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.ls_sag_decode(self.h, B, int(m.on_device), m.f32(x, (B, self.J, self.F, self.T)),
+                                           m.f32(z, (B, self.D)), pmask, pout), "ls_sag_decode")
+        return out

@@ -303,8 +303,8 @@ int build_temb_rows(ls_handle* h, const long long* idx_dev, int n, DevBuf& tmp, 
     float* rows = tmp.f();
     float* hid = tmp.f() + (size_t)n * kD;
     HIPCHK(h, launch_gather_rows(h->pe.f(), reinterpret_cast<const int64_t*>(idx_dev), rows, n, kD, kPeRows, h->stream));
-    HIPCHK(h, launch_linear(rows, kD, h->te_w0.f(), kD, h->te_b0.f(), hid, kD, n, kD, kD, 1, h->stream));
-    HIPCHK(h, launch_linear(hid, kD, h->te_w2.f(), kD, h->te_b2.f(), out.f(), kD, n, kD, kD, 0, h->stream));
+    HIPCHK(h, launch_gemm_nt(rows, kD, h->te_w0.f(), kD, h->te_b0.f(), nullptr, 0, hid, kD, n, kD, kD, 1, h->stream));
+    HIPCHK(h, launch_gemm_nt(hid, kD, h->te_w2.f(), kD, h->te_b2.f(), nullptr, 0, out.f(), kD, n, kD, kD, 0, h->stream));
     return LS_OK;
 }
 
@@ -523,17 +523,17 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     HIPCHK(h, h->static_c.ensure((size_t)B * kT * kD * sizeof(float)));
     HIPCHK(h, h->static_u.ensure((size_t)B * kT * kD * sizeof(float)));
     HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_c.f(), h->feat_u.f(), B, JF, h->cfg.n_pre_seq, st));
-    HIPCHK(h, launch_linear(h->feat_c.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), h->static_c.f(), kD, B * kT, kD, KF, 0, st));
-    HIPCHK(h, launch_linear(h->feat_u.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), h->static_u.f(), kD, B * kT, kD, KF, 0, st));
+    HIPCHK(h, launch_gemm_nt(h->feat_c.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), nullptr, 0, h->static_c.f(), kD, B * kT, kD, KF, 0, st));
+    HIPCHK(h, launch_gemm_nt(h->feat_u.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), nullptr, 0, h->static_u.f(), kD, B * kT, kD, KF, 0, st));
     // ---- speaker style (RAG.py:116-119): z = Embedding[vid]; mu, logvar = Linear(z); std = exp(0.5*logvar)
     HIPCHK(h, h->z.ensure((size_t)B * 256 * sizeof(float)));
     HIPCHK(h, h->z_mu.ensure((size_t)B * kD * sizeof(float)));
     HIPCHK(h, h->z_logvar.ensure((size_t)B * kD * sizeof(float)));
     HIPCHK(h, h->z_std.ensure((size_t)B * kD * sizeof(float)));
     HIPCHK(h, launch_gather_rows(h->spk_emb.f(), static_cast<const int64_t*>(h->vid.p), h->z.f(), B, 256, h->cfg.n_speakers, st));
-    HIPCHK(h, launch_linear(h->z.f(), 256, h->mu_w.f(), 256, h->mu_b.f(), h->z_mu.f(), kD, B, kD, 256, 0, st));
-    HIPCHK(h, launch_linear(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), h->z_logvar.f(), kD, B, kD, 256, 0, st));
-    HIPCHK(h, launch_linear(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), h->z_std.f(), kD, B, kD, 256, 2, st));
+    HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->mu_w.f(), 256, h->mu_b.f(), nullptr, 0, h->z_mu.f(), kD, B, kD, 256, 0, st));
+    HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), nullptr, 0, h->z_logvar.f(), kD, B, kD, 256, 0, st));
+    HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), nullptr, 0, h->z_std.f(), kD, B, kD, 256, 2, st));
     if (h->cfg.n_prefix_tokens == 2) {   // scripts_beat/model/RAG.py:125
         HIPCHK(h, h->emo_tok.ensure((size_t)B * kD * sizeof(float)));
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st));

@@ -90,6 +90,9 @@ hipError_t launch_instnorm_stats(const float* x, float* stats, int rows, int L, 
 // y[M][N] = act(x[M][K] . W[N][ldw]^T + b);  act: 0 none, 1 SiLU, 2 exp(0.5*y)
 hipError_t launch_linear(const float* x, int ldx, const float* w, int ldw, const float* b, float* y, int ldy,
                          int M, int N, int K, int act, hipStream_t st);
+// C[M][N] = act(A[M][K] . W[N][K]^T + bias) (+ R): fp32 MFMA GEMM (ls_gemm.hip); act 3 = exact GELU
+hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
+                          float* C, int ldc, int M, int N, int K, int act, hipStream_t st);
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int rows, int width,
                               int table_rows, hipStream_t st);
 hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
@@ -101,5 +104,14 @@ hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size
 hipError_t launch_randn_fill(float* out_btc, int B, int JF, const CallParams* call, unsigned stream_id,
                              hipStream_t st);
 hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipStream_t st);
+
+// ---- SAG decoder kernels (ls_sag.hip) ----------------------------------------------------------
+hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bmap, const float* pe, float* q, int B,
+                              int JF, int n_pre, int D, hipStream_t st);
+hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, int D, hipStream_t st);
+hipError_t launch_layernorm512(const float* x, const float* bc, const float* w, const float* beta, float* y, int rows,
+                               hipStream_t st);
+hipError_t launch_sag_final(const float* xh, const float* wf, const float* bf, const unsigned char* mask, float* out, int B,
+                            int JF, int D, hipStream_t st);
 
 }  // namespace ls

@@ -146,6 +146,45 @@ def make_init_image(cfg: PathConfig, batch: int, seed: int = SEED_COND + 1000) -
     return _f32(0.3 * g.standard_normal((batch, cfg.njoints, cfg.nfeats, cfg.nframes)))
 
 
+def make_sag_state_dict(cfg: PathConfig = None, seed: int = SEED_WEIGHTS + 100, latent: int = 512, ff: int = 1024,
+                        layers: int = 3) -> dict:
+    """SAG decoder weights under Decoder_TRANSFORMER's state-dict keys (scripts/model/motionclip_module.py:98-136;
+    in the SAG.pth checkpoint they carry a 'decoder.' prefix)."""
+    cfg = cfg or TED
+    g = _rng(seed)
+    D = latent
+    sd = {}
+
+    def uni(shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return _f32(g.uniform(-b, b, size=shape))
+
+    for i in range(layers):
+        p = f"seqTransDecoder.layers.{i}."
+        for att in ("self_attn", "multihead_attn"):
+            sd[p + att + ".in_proj_weight"] = _f32(g.standard_normal((3 * D, D)) / np.sqrt(D))
+            sd[p + att + ".in_proj_bias"] = _f32(0.05 * g.standard_normal((3 * D,)))
+            sd[p + att + ".out_proj.weight"] = uni((D, D), D)
+            sd[p + att + ".out_proj.bias"] = _f32(0.05 * g.standard_normal((D,)))
+        sd[p + "linear1.weight"] = uni((ff, D), D)
+        sd[p + "linear1.bias"] = uni((ff,), D)
+        sd[p + "linear2.weight"] = uni((D, ff), ff)
+        sd[p + "linear2.bias"] = uni((D,), ff)
+        for n in ("norm1", "norm2", "norm3"):
+            sd[p + n + ".weight"] = _f32(1.0 + 0.1 * g.standard_normal((D,)))
+            sd[p + n + ".bias"] = _f32(0.05 * g.standard_normal((D,)))
+    sd["finallayer.weight"] = uni((cfg.jf, D), D)
+    sd["finallayer.bias"] = uni((cfg.jf,), D)
+    sd["mapping.weight"] = uni((D, cfg.jf + 1), cfg.jf + 1)
+    sd["mapping.bias"] = uni((D,), cfg.jf + 1)
+    return sd
+
+
+def make_text_features(batch: int, seed: int = SEED_COND + 2000, latent: int = 512) -> np.ndarray:
+    """Stand-in for clip_model.encode_text(...) (CLIP is an absent third-party package): z ~ 0.3 N(0,1) [B,512]."""
+    return _f32(0.3 * _rng(seed).standard_normal((batch, latent)))
+
+
 class NoiseTape:
     """Pre-drawn N(0,1) tape consumed in the reference's draw order:
     ``randn(B,J,F,T)`` once, then per step ``randn_like(B,1,512)`` (cond pass),

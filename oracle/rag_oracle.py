@@ -331,3 +331,64 @@ def sample_loop(model: RagOracle, sch: Schedule, y: dict, x_init, eps_tape, nois
     if dump_steps is not None:
         return img, dumps
     return img
+
+
+# --------------------------------------------------------------------------- SAG decoder
+def gelu_exact(x):
+    from scipy.special import erf
+    return (0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))).astype(F32)
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    mean = x.mean(axis=-1, keepdims=True, dtype=F32)
+    var = ((x - mean) ** 2).mean(axis=-1, keepdims=True, dtype=F32)
+    return ((x - mean) / np.sqrt(var + F32(eps)) * w + b).astype(F32)
+
+
+class SagDecoderOracle:
+    """Decoder_TRANSFORMER.forward (scripts/model/motionclip_module.py:138-183): 3 post-norm
+    nn.TransformerDecoderLayer (self-attn over the 34 queries, cross-attn to a length-1 memory, GELU FFN)."""
+
+    def __init__(self, sd: dict, njoints=9, nfeats=3, nframes=34, heads=4, n_pre_poses=4):
+        self.sd = {k: np.asarray(v, dtype=F32) for k, v in sd.items()}
+        self.J, self.Fe, self.T, self.H, self.npre = njoints, nfeats, nframes, heads, n_pre_poses
+        self.L = 1 + max(int(k.split(".")[2]) for k in self.sd if k.startswith("seqTransDecoder.layers."))
+
+    def _mha(self, p, q_in, kv_in):
+        sd, H = self.sd, self.H
+        Wi, bi = sd[p + "in_proj_weight"], sd[p + "in_proj_bias"]
+        D = Wi.shape[1]
+        q = q_in @ Wi[:D].T + bi[:D]
+        k = kv_in @ Wi[D:2 * D].T + bi[D:2 * D]
+        v = kv_in @ Wi[2 * D:].T + bi[2 * D:]
+        B, Tq, Tk, hd = q.shape[0], q.shape[1], k.shape[1], D // H
+        qh = q.reshape(B, Tq, H, hd).transpose(0, 2, 1, 3) * F32(1.0 / math.sqrt(hd))
+        kh = k.reshape(B, Tk, H, hd).transpose(0, 2, 1, 3)
+        vh = v.reshape(B, Tk, H, hd).transpose(0, 2, 1, 3)
+        s = qh @ kh.transpose(0, 1, 3, 2)
+        s = np.exp(s - s.max(axis=-1, keepdims=True))
+        s = (s / s.sum(axis=-1, keepdims=True)).astype(F32)
+        o = (s @ vh).transpose(0, 2, 1, 3).reshape(B, Tq, D)
+        return (o @ sd[p + "out_proj.weight"].T + sd[p + "out_proj.bias"]).astype(F32)
+
+    def decode(self, x, z, mask=None):
+        sd = self.sd
+        B = x.shape[0]
+        JF = self.J * self.Fe
+        motion = np.asarray(x, dtype=F32).transpose(0, 3, 1, 2).reshape(B, self.T, JF).copy()
+        pre = np.zeros((B, self.T, JF + 1), dtype=F32)
+        pre[:, :self.npre, :JF] = motion[:, :self.npre]
+        pre[:, :self.npre, JF] = 1                                       # indicating bit (:164-166)
+        h = (pre @ sd["mapping.weight"].T + sd["mapping.bias"]).astype(F32)
+        h = h + positional_row(np.arange(self.T))[None]                  # sequence_pos_encoder (:168), eval mode
+        mem = np.asarray(z, dtype=F32)[:, None, :]
+        for i in range(self.L):
+            p = f"seqTransDecoder.layers.{i}."
+            h = layer_norm(h + self._mha(p + "self_attn.", h, h), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+            h = layer_norm(h + self._mha(p + "multihead_attn.", h, mem), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+            ff = gelu_exact(h @ sd[p + "linear1.weight"].T + sd[p + "linear1.bias"]) @ sd[p + "linear2.weight"].T + sd[p + "linear2.bias"]
+            h = layer_norm(h + ff.astype(F32), sd[p + "norm3.weight"], sd[p + "norm3.bias"])
+        out = (h @ sd["finallayer.weight"].T + sd["finallayer.bias"]).astype(F32)      # [B,T,JF]
+        if mask is not None:
+            out = out * np.asarray(mask, dtype=bool)[:, :, None]                        # "zero for padded area" (:175)
+        return np.ascontiguousarray(out.reshape(B, self.T, self.J, self.Fe).transpose(0, 2, 3, 1))
