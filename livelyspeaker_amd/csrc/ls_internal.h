@@ -87,9 +87,6 @@ hipError_t init_step_kernels();
 hipError_t launch_conv1d(const float* in, const float* stats, const float* w, const float* bias, float* out,
                          int B, int Cin, int Cout, int Lin, int Lout, int stride, int pad, hipStream_t st);
 hipError_t launch_instnorm_stats(const float* x, float* stats, int rows, int L, hipStream_t st);
-// y[M][N] = act(x[M][K] . W[N][ldw]^T + b);  act: 0 none, 1 SiLU, 2 exp(0.5*y)
-hipError_t launch_linear(const float* x, int ldx, const float* w, int ldw, const float* b, float* y, int ldy,
-                         int M, int N, int K, int act, hipStream_t st);
 // C[M][N] = act(A[M][K] . W[N][K]^T + bias) (+ R): fp32 MFMA GEMM (ls_gemm.hip); act 3 = exact GELU
 hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                           float* C, int ldc, int M, int N, int K, int act, hipStream_t st);

@@ -138,63 +138,6 @@ hipError_t launch_instnorm_stats(const float* x, float* stats, int rows, int L, 
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------
-// y[M][N] = act(x[M][K] . W[N][K]^T + b)   (nn.Linear).  64x64 tile, BK=16, 4x4 outputs per thread.
-// Used only once per call (static input projection, mu/logvar, timestep table): 5 GFLOP at B=512.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                int ldw, const float* __restrict__ bias, float* __restrict__ y,
-                                                int ldy, int M, int N, int K, int act) {
-    __shared__ float sx[16][64 + 4];
-    __shared__ float sw[16][64 + 4];
-    const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        __syncthreads();
-        for (int idx = tid; idx < 64 * 16; idx += 256) {
-            const int r = idx >> 4, k = idx & 15;
-            sx[k][r] = (m0 + r < M && k0 + k < K) ? x[(size_t)(m0 + r) * ldx + k0 + k] : 0.f;
-            sw[k][r] = (n0 + r < N && k0 + k < K) ? w[(size_t)(n0 + r) * ldw + k0 + k] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float a[4], bb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = sx[k][tm + i]; bb[i] = sw[k][tn + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + tm + i, n = n0 + tn + j;
-            if (m < M && n < N) {
-                float v = acc[i][j] + (bias ? bias[n] : 0.f);
-                if (act == 1) v = v / (1.0f + expf(-v));
-                else if (act == 2) v = expf(0.5f * v);
-                y[(size_t)m * ldy + n] = v;
-            }
-        }
-}
-
-hipError_t launch_linear(const float* x, int ldx, const float* w, int ldw, const float* b, float* y, int ldy,
-                         int M, int N, int K, int act, hipStream_t st) {
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, st, x, ldx, w, ldw, b, y, ldy, M, N, K, act);
-    return hipGetLastError();
-}
-
 __global__ void k_gather_rows(const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out,
                               int rows, int width, int table_rows) {
     const int r = blockIdx.x;
