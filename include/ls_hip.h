@@ -39,6 +39,10 @@ enum {
 
 enum { LS_SAMPLER_DDPM = 0, LS_SAMPLER_DDIM = 1 };
 enum { LS_NOISE_TAPE = 0, LS_NOISE_PHILOX = 1 };
+/* Arithmetic of the channel-mixing GEMM (92 % of the FLOPs). FP32 (default): v_mfma_f32_16x16x4_f32, exact fp32
+ * products.  BF16X3 (opt-in): each fp32 operand split into bf16 hi+lo, three v_mfma_f32_16x16x32_bf16 per product
+ * (hi.hi + hi.lo + lo.hi, fp32 accumulate): ~2^-16 relative product error, parity-gated at the 1e-3 contract. */
+enum { LS_PRECISION_FP32 = 0, LS_PRECISION_BF16X3 = 1 };
 
 typedef struct ls_handle ls_handle;
 
@@ -162,6 +166,7 @@ const char* ls_last_error(const ls_handle* h);   /* h may be NULL: error of the 
 int ls_set_weight(ls_handle* h, const char* key, const float* data, size_t n);
 int ls_commit_weights(ls_handle* h);
 
+int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; default FP32 */
 int ls_set_schedule(ls_handle* h, const ls_schedule* s);
 int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */
 int ls_sample(ls_handle* h, const ls_sample_args* a);

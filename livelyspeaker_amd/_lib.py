@@ -19,6 +19,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 LS_SAMPLER_DDPM, LS_SAMPLER_DDIM = 0, 1
 LS_NOISE_TAPE, LS_NOISE_PHILOX = 0, 1
+LS_PRECISION_FP32, LS_PRECISION_BF16X3 = 0, 1
 
 
 class LsConfig(C.Structure):
@@ -72,7 +73,7 @@ class LsTiming(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode")
 
 _lib = None
@@ -127,6 +128,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_get_timing.argtypes = [C.c_void_p, C.POINTER(LsTiming)]
     lib.ls_synchronize.argtypes = [C.c_void_p]
     lib.ls_philox_x_init.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+    lib.ls_set_precision.argtypes = [C.c_void_p, C.c_int]
     lib.ls_sag_create.argtypes = [C.POINTER(LsSagConfig), C.POINTER(C.c_void_p)]
     lib.ls_sag_destroy.argtypes = [C.c_void_p]
     lib.ls_sag_destroy.restype = None
@@ -236,6 +238,12 @@ class Engine:
         if rc < 0:
             raise EngineError(f"{what} failed ({rc}): {self.lib.ls_last_error(self.h).decode()}")
         return rc
+
+    def set_precision(self, mode):
+        """'fp32' (exact, default) or 'bf16x3' (split-precision channel mixing on the bf16 matrix cores)."""
+        code = {"fp32": 0, "bf16x3": 1}.get(mode, mode)
+        self._check(self.lib.ls_set_precision(self.h, int(code)), "ls_set_precision")
+        self.precision = mode
 
     # ---- weights / schedule --------------------------------------------------------------------
     def load_state_dict(self, sd: dict):

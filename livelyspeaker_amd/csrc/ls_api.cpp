@@ -39,6 +39,20 @@ const int kConvStride[4] = {5, 6, 6, 6};
 const int kConvPad[4] = {1600, 0, 0, 0};
 const int kConvKey[4] = {0, 3, 6, 9};
 
+// bf16 round-to-nearest-even, as v_cvt_pk_bf16_f32 does on the device side of the split
+unsigned short f32_to_bf16(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+float bf16_to_f32(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 }  // namespace
 
 struct ls_handle {
@@ -55,6 +69,7 @@ struct ls_handle {
     unsigned weights_version = 0;
 
     // device weights
+    DevBuf wch_hi_img, wch_lo_img;
     DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
     DevBuf conv_w[4], conv_b[4], win_full, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
     DevBuf te_w0, te_b0, te_w2, te_b2, pe;
@@ -87,6 +102,7 @@ struct ls_handle {
     DevBuf prof;
     bool prof_on = false;   // LS_PROF=<workgroup index>: in-kernel s_memtime phase stamps, read with ls_read("prof")
     int prof_wg = 0;
+    int precision = 0;      // 0 exact fp32 MFMA, 1 bf16x3 split-precision channel mixing (ls_set_precision)
     int ablate = 0;         // LS_ABLATE (profiling only; results are wrong when non-zero)
 };
 
@@ -153,6 +169,7 @@ int build_images(ls_handle* h) {
     const int MK = h->MK, KXQ = h->KXQ, NOB = h->NOB, KIN = h->KIN;
     std::vector<float> wch((size_t)L * D * D), bch((size_t)L * D), l1a((size_t)L * D), l1b((size_t)L * D),
         l2a((size_t)L * D), l2b((size_t)L * D), ww((size_t)L * kNT * MK * 64), bt((size_t)L * 80, 0.f);
+    std::vector<unsigned short> wch_hi((size_t)L * D * D), wch_lo((size_t)L * D * D);
     char key[160];
     for (int l = 0; l < L; ++l) {
         auto K = [&](const char* suffix) { snprintf(key, sizeof key, "backbone.mlps.%d.%s", l, suffix); return std::string(key); };
@@ -177,6 +194,24 @@ int build_images(ls_handle* h) {
                                 const int k = 16 * q + 4 * (lane >> 4) + j;
                                 wch[o++] = (*W)[(size_t)n * D + k] * (*a2)[k];        // W' = W . diag(alpha2)
                             }
+        // bf16x3 images: W' = hi + lo, operand order of v_mfma_f32_16x16x32_bf16: [l][w][p][q16][c2][lane][8 k]
+        {
+            size_t oh = (size_t)l * D * D;
+            for (int w = 0; w < kWaves; ++w)
+                for (int p = 0; p < 2; ++p)
+                    for (int q = 0; q < 16; ++q)
+                        for (int c2 = 0; c2 < 2; ++c2)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int n = 64 * w + 16 * (2 * p + c2) + (lane & 15);
+                                    const int k = 32 * q + 8 * (lane >> 4) + e;
+                                    const float v = (*W)[(size_t)n * D + k] * (*a2)[k];
+                                    const unsigned short hi = f32_to_bf16(v);
+                                    wch_hi[oh] = hi;
+                                    wch_lo[oh] = f32_to_bf16(v - bf16_to_f32(hi));
+                                    ++oh;
+                                }
+        }
         for (int n = 0; n < D; ++n) {                                                    // b' = b + W . beta2
             double acc = (*b2)[n];
             for (int k = 0; k < D; ++k) acc += (double)(*W)[(size_t)n * D + k] * (double)(*be2)[k];
@@ -243,6 +278,8 @@ int build_images(ls_handle* h) {
     }
     int rc;
 #define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
+    if ((rc = upload(h, h->wch_hi_img, wch_hi.data(), wch_hi.size() * sizeof(unsigned short))) != LS_OK) return rc;
+    if ((rc = upload(h, h->wch_lo_img, wch_lo.data(), wch_lo.size() * sizeof(unsigned short))) != LS_OK) return rc;
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
     UP(win_full, *Win); UP(win_bias, *bin);
@@ -288,6 +325,8 @@ int build_images(ls_handle* h) {
     }
     DevWeights dw{};
     dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
+    dw.wch_hi_img = static_cast<const unsigned short*>(h->wch_hi_img.p);
+    dw.wch_lo_img = static_cast<const unsigned short*>(h->wch_lo_img.p);
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
     dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
     dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
@@ -421,7 +460,7 @@ void ls_destroy(ls_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graph(h);
-    DevBuf* all[] = {&h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
+    DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
                      &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
                      &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
@@ -455,6 +494,14 @@ int ls_commit_weights(ls_handle* h) {
     h->temb_valid = false;
     h->prepared = false;
     free_graph(h);
+    return LS_OK;
+}
+
+int ls_set_precision(ls_handle* h, int mode) {
+    if (!h) return LS_EINVAL;
+    if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3) return fail(h, LS_EINVAL, "unknown precision mode %d", mode);
+    if (mode != h->precision) free_graph(h);
+    h->precision = mode;
     return LS_OK;
 }
 
@@ -575,7 +622,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
         HIPCHK(h, h->trace.ensure((size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float)));
         s.trace = h->trace.f();
     }
-    HIPCHK(h, launch_step(h->var, s, B, st));
+    HIPCHK(h, launch_step(h->var, h->precision, s, B, st));
     float* outs[3] = {a->out_cond, a->out_uncond, a->out_cfg};
     const float* srcs[3] = {h->fwd_c.f(), h->fwd_u.f(), h->fwd_cfg.f()};
     for (int i = 0; i < 3; ++i) {
@@ -617,7 +664,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
     s.noise = h->noise.f();
     s.temb = h->temb.f() + (size_t)a->index * kD; s.temb_stride = 0;
-    HIPCHK(h, launch_step(h->var, s, B, st));
+    HIPCHK(h, launch_step(h->var, h->precision, s, B, st));
     HIPCHK(h, launch_from_internal(h->xb.f(), h->xio.f(), B, JF, st));
     if ((rc = egress(h, a->sample, h->xio.f(), nx, od)) != LS_OK) return rc;
     if (a->pred_xstart) {
@@ -707,7 +754,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     // ---- the loop: for i = T-1-skip ... 0 (gaussian_diffusion.py:724-743 / :994-1014) ----------------
     char keybuf[256];
     {
-        int off = snprintf(keybuf, sizeof keybuf, "B%d s%d e%a k%d n%d c%d cl%d w%u v%u d%d", B, a->sampler, (double)a->eta,
+        int off = snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u d%d", h->precision, B, a->sampler, (double)a->eta,
                            a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, a->n_dump);
         for (int d = 0; d < a->n_dump && off < (int)sizeof keybuf - 12; ++d) off += snprintf(keybuf + off, sizeof keybuf - off, ",%d", a->dump_steps[d]);
     }
@@ -730,7 +777,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
             }
             for (int d = 0; d < a->n_dump; ++d)
                 if (a->dump_steps[d] == k) s.x0_out = h->dump.f() + (size_t)d * nelem;
-            HIPCHK(h, launch_step(h->var, s, B, st));
+            HIPCHK(h, launch_step(h->var, h->precision, s, B, st));
         }
         return LS_OK;
     };

@@ -28,6 +28,10 @@ struct CallParams {
 struct DevWeights {
     const float* wch_img;    // [L][8][2 passes][32 q][2 cb][64 lanes][4]   channel-mix Linear(512,512)
     const float* bch;        // [L][512]
+    // bf16x3 split-precision mode: W' = hi + lo with hi = bf16(W'), lo = bf16(W' - hi); operand order of
+    // v_mfma_f32_16x16x32_bf16 (lane (n, g) holds k = 32q + 8g .. +7): [L][8][2 passes][16 q][2 cb][64 lanes][8]
+    const unsigned short* wch_hi_img;
+    const unsigned short* wch_lo_img;
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
     const float* btok_rows;  // [L][80]
@@ -79,7 +83,8 @@ struct StepArgs {
 // dataset variant of the compiled kernel
 enum Variant { kTED = 0, kBEAT = 1 };
 
-hipError_t launch_step(Variant v, const StepArgs& a, int batch, hipStream_t st);
+// prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
+hipError_t launch_step(Variant v, int prec, const StepArgs& a, int batch, hipStream_t st);
 size_t step_lds_bytes(Variant v);
 hipError_t init_step_kernels();
 

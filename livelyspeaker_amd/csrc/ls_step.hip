@@ -28,6 +28,9 @@ namespace ls {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) bf8* gbf8p;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -56,7 +59,7 @@ __host__ __device__ constexpr bool tokmix_needed(int S, int t, int m) {
     return !(4 * m + 3 < src_lo || 4 * m > src_hi);
 }
 
-template <int S, int NPRE, int JF>
+template <int S, int NPRE, int JF, int PREC>
 __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int R = 2 * S;                 // packed rows: [cond tokens | uncond tokens]
     constexpr int KXQ = (JF + 15) / 16;      // 16-wide k groups of the x_t part of input_mapping
@@ -289,7 +292,22 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         u[j] = fmaf(X[cb][t][j], rstd[t], nmr[t]);
                         if (alpha) u[j] = fmaf(u[j], al[j], be[j]);
                     }
-                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                    if (PREC == 1 && !alpha) {
+                        // bf16x3 operand: u = hi + lo (+ O(2^-17 |u|)), hi = bf16_rne(u), lo = bf16_rne(u - hi);
+                        // two bf16 planes [R][520] in the space of the fp32 buffer
+                        __bf16* Uh = reinterpret_cast<__bf16*>(U);
+                        __bf16* Ul = Uh + R * kUStride;
+                        bf4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            hi[j] = (__bf16)u[j];
+                            lo[j] = (__bf16)(u[j] - (float)hi[j]);
+                        }
+                        *reinterpret_cast<bf4*>(&Uh[row_of(t) * kUStride + chw + 16 * cb]) = hi;
+                        *reinterpret_cast<bf4*>(&Ul[row_of(t) * kUStride + chw + 16 * cb]) = lo;
+                    } else {
+                        *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                    }
                 }
         }
     };
@@ -356,6 +374,75 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         ln_store(nullptr, nullptr);
         __syncthreads();
         stamp(6 + 8 * l);
+        if constexpr (PREC == 1) {
+            // ---- bf16x3 split precision: W'.u ~= hi_w.hi_u + hi_w.lo_u + lo_w.hi_u on v_mfma_f32_16x16x32_bf16 (fp32
+            // accumulate; bf16 x bf16 products are exact in fp32; the dropped lo.lo term and the split residuals are
+            // O(2^-16) relative).  These MFMAs run on the bf16 matrix cores, which do NOT share lanes with the fp32
+            // VALU work of the other phases, and all 5 token tiles are cheap enough to run padded.
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fresh();
+                f4 acc[2][kNT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t) acc[c2][t] = bc;
+                }
+                const size_t wofs = ((size_t)((l * kWaves + w) * 2 + p) * 16) * 2 * 64 + lane;
+                gbf8p wh = (gbf8p)(const bf8*)(a.W->wch_hi_img) + wofs;
+                gbf8p wl = (gbf8p)(const bf8*)(a.W->wch_lo_img) + wofs;
+                const __bf16* Uh = reinterpret_cast<const __bf16*>(U);
+                const __bf16* Ul = Uh + R * kUStride;
+                int rofs[kNT];
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) rofs[t] = rowc_of(t) * kUStride + 8 * g;
+                bf8 Ahn[2], Aln[2];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) { Ahn[c2] = wh[c2 * 64]; Aln[c2] = wl[c2 * 64]; }
+                if (!(a.ablate & 1))
+#pragma unroll 2
+                for (int q = 0; q < 16; ++q) {
+                    bf8 Ah[2], Al[2], Bh[kNT], Bl[kNT];
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) { Ah[c2] = Ahn[c2]; Al[c2] = Aln[c2]; }
+                    const int qn = (q + 1 < 16) ? q + 1 : 15;
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) { Ahn[c2] = wh[(qn * 2 + c2) * 64]; Aln[c2] = wl[(qn * 2 + c2) * 64]; }
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t) {
+                        Bh[t] = *reinterpret_cast<const bf8*>(Uh + rofs[t] + 32 * q);
+                        Bl[t] = *reinterpret_cast<const bf8*>(Ul + rofs[t] + 32 * q);
+                    }
+                    // term-major order: 10 independent accumulators between two MFMAs on the same one
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t)
+                            acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[t], acc[c2][t], 0, 0, 0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t)
+                            acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[t], acc[c2][t], 0, 0, 0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t)
+                            acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[t], acc[c2][t], 0, 0, 0);
+                }
+                fresh();
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t)
+                        if (valid_of(t)) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) X[2 * p + c2][t][j] = silu_acc(acc[c2][t][j], X[2 * p + c2][t][j]);
+                        }
+                if (p == 0) stamp(7 + 8 * l);
+            }
+        } else {
         // Rows 64..R-1 (6 of the 16 rows of tile 4) would waste 62 % of a fifth MFMA tile = 20 % of all channel-mix
         // MFMAs.  They are computed instead on the VALU pipe, in the shadow of the MFMAs of tiles 0..3, from the
         // same A-operand registers: lane (n, g) accumulates W[n][k(g)] * U[row][k(g)] over its k subset, the four
@@ -447,6 +534,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             if (p == 0) stamp(7 + 8 * l);
+        }
         }
         stamp(9 + 8 * l);
         dump_trace(l + 1);
@@ -595,19 +683,22 @@ size_t step_lds_bytes(Variant v) {
 
 // Opt in to >64 KiB dynamic LDS once per process (must happen outside stream capture).
 hipError_t init_step_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<35, 1, 27>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes(kTED));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<36, 2, 282>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes(kBEAT));
+    const void* ks[4] = {reinterpret_cast<const void*>(k_step<35, 1, 27, 0>), reinterpret_cast<const void*>(k_step<35, 1, 27, 1>),
+                         reinterpret_cast<const void*>(k_step<36, 2, 282, 0>), reinterpret_cast<const void*>(k_step<36, 2, 282, 1>)};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)step_lds_bytes(i < 2 ? kTED : kBEAT));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
-hipError_t launch_step(Variant v, const StepArgs& a, int batch, hipStream_t st) {
+hipError_t launch_step(Variant v, int prec, const StepArgs& a, int batch, hipStream_t st) {
     const size_t lds = step_lds_bytes(v);
-    if (v == kTED)
-        hipLaunchKernelGGL((k_step<35, 1, 27>), dim3(batch), dim3(512), lds, st, a);
-    else
-        hipLaunchKernelGGL((k_step<36, 2, 282>), dim3(batch), dim3(512), lds, st, a);
+    if (v == kTED && prec == 0) hipLaunchKernelGGL((k_step<35, 1, 27, 0>), dim3(batch), dim3(512), lds, st, a);
+    else if (v == kTED) hipLaunchKernelGGL((k_step<35, 1, 27, 1>), dim3(batch), dim3(512), lds, st, a);
+    else if (prec == 0) hipLaunchKernelGGL((k_step<36, 2, 282, 0>), dim3(batch), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((k_step<36, 2, 282, 1>), dim3(batch), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 

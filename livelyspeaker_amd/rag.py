@@ -119,6 +119,9 @@ class RAG(nn.Module):
         #: reuse the prepared conditioning when the same ``y`` tensors are passed again (the sampling loop calls
         #: the model T times with one ``y``); set False to re-run the once-per-call stage on every call.
         self.cache_conditioning = True
+        #: 'fp32' = exact fp32 MFMA (default, what parity/bench numbers refer to); 'bf16x3' = opt-in split-precision
+        #: channel mixing (3 bf16 MFMAs per fp32 product, ~2^-16 relative; parity-tested against the 1e-3 contract)
+        self.precision = "fp32"
         self._engine = None
         self._weights_dirty = True
         self._cond_key = None
@@ -163,6 +166,8 @@ class RAG(nn.Module):
             self._engine.load_state_dict(sd)
             self._weights_dirty = False
             self._cond_key = None
+        if getattr(self._engine, "precision", "fp32") != self.precision:
+            self._engine.set_precision(self.precision)
         return self._engine
 
     def _engine_prepared(self, y):

@@ -162,3 +162,51 @@ def test_abi_error_behaviour(ted):
         eng.sample(sampler=L.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps[:0], noise_tape=tape.noise[:0], skip_timesteps=4)
     with pytest.raises(L.EngineError):
         eng.step(L.LS_SAMPLER_DDPM, 9, tape.x_init, tape.eps[0, 0], tape.eps[0, 1], tape.noise[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# Opt-in bf16x3 split-precision mode: same contract (1e-3 max-abs vs the reference), looser than fp32 noise
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_bf16x3_mode_meets_the_parity_contract(ds, golden):
+    golden = golden  # session fixture from conftest
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg = synth.CONFIGS[ds]
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
+    try:
+        eng.load_state_dict(synth.make_state_dict(cfg))
+        eng.set_precision("bf16x3")
+        g = golden[ds]
+        B = 4
+        y = synth.make_cond(cfg, B)
+        eng.prepare(y)
+        gen = np.random.Generator(np.random.PCG64(1234))
+        x = gen.standard_normal((B, cfg.njoints, cfg.nfeats, cfg.nframes)).astype(np.float32)
+        eps = gen.standard_normal((2, B, 512)).astype(np.float32)
+        worst = 0.0
+        for t in (0, 500, 999):
+            oc, ou, _ = eng.forward(x, np.full((B,), t), eps[0], eps[1])
+            worst = max(worst, max_abs(oc, g[f"G1_t{t}_c"]), max_abs(ou, g[f"G1_t{t}_u"]))
+        print(f"{ds} bf16x3 single forward vs reference: {worst:.3e}")
+        assert worst < 1e-3
+        runs = [("G3_ddpm50_final", 50, "", False, 0, False), ("G4_ddim100_skip80_final", 1000, "ddim100", True, 80, True)]
+        if ds == "ted":
+            runs.append(("G5_ddpm1000_final", 1000, "", False, 0, False))
+        for key, steps, resp, ddim, skip, use_init in runs:
+            sch = orc.Schedule(steps, resp)
+            eng.set_schedule(sch)
+            tape = synth.NoiseTape(cfg, B, sch.num_timesteps - skip)
+            out = eng.sample(sampler=_lib.LS_SAMPLER_DDIM if ddim else _lib.LS_SAMPLER_DDPM, x_init=tape.x_init,
+                             eps_tape=tape.eps, noise_tape=tape.noise, skip_timesteps=skip,
+                             init_image=synth.make_init_image(cfg, B) if use_init else None)
+            d = max_abs(out, g[key])
+            print(f"{ds} bf16x3 {key}: max|d| = {d:.3e} (contract 1e-3)")
+            assert d < 1e-3
+        eng.set_precision("fp32")
+        sch = orc.Schedule(50, "")
+        eng.set_schedule(sch)
+        tape = synth.NoiseTape(cfg, B, 50)
+        out = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise)
+        assert max_abs(out, g["G3_ddpm50_final"]) < 3e-4        # switching back restores the exact path
+    finally:
+        eng.close()
