@@ -69,7 +69,7 @@ struct ls_handle {
     unsigned weights_version = 0;
 
     // device weights
-    DevBuf wch_hi_img, wch_lo_img;
+    DevBuf wch_hi_img, wch_lo_img, ww_hi_img, ww_lo_img;
     DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
     DevBuf conv_w[4], conv_b[4], win_full, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
     DevBuf te_w0, te_b0, te_w2, te_b2, pe;
@@ -170,6 +170,8 @@ int build_images(ls_handle* h) {
     std::vector<float> wch((size_t)L * D * D), bch((size_t)L * D), l1a((size_t)L * D), l1b((size_t)L * D),
         l2a((size_t)L * D), l2b((size_t)L * D), ww((size_t)L * kNT * MK * 64), bt((size_t)L * 80, 0.f);
     std::vector<unsigned short> wch_hi((size_t)L * D * D), wch_lo((size_t)L * D * D);
+    const int KS = (R + 31) / 32;
+    std::vector<unsigned short> wwh((size_t)L * kNT * KS * 64 * 8), wwl((size_t)L * kNT * KS * 64 * 8);
     char key[160];
     for (int l = 0; l < L; ++l) {
         auto K = [&](const char* suffix) { snprintf(key, sizeof key, "backbone.mlps.%d.%s", l, suffix); return std::string(key); };
@@ -230,6 +232,18 @@ int build_images(ls_handle* h) {
                     if (r < R && rp < R && r / S == rp / S) v = (*Wt)[(size_t)(r % S) * S + (rp % S)];
                     ww[(((size_t)l * kNT + t) * MK + m) * 64 + lane] = v;
                 }
+        // bf16x3 token-mix images: [l][t][ks][lane][e] = WW[r = 16t + (lane&15)][r' = 32ks + 8(lane>>4) + e]
+        for (int t = 0; t < kNT; ++t)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 16 * t + (lane & 15), rp = 32 * ks + 8 * (lane >> 4) + e;
+                        float v = 0.f;
+                        if (r < R && rp < R && r / S == rp / S) v = (*Wt)[(size_t)(r % S) * S + (rp % S)];
+                        const size_t o = ((((size_t)l * kNT + t) * KS + ks) * 64 + lane) * 8 + e;
+                        wwh[o] = f32_to_bf16(v);
+                        wwl[o] = f32_to_bf16(v - bf16_to_f32(wwh[o]));
+                    }
         for (int r = 0; r < R; ++r) bt[(size_t)l * 80 + r] = (*b1)[r % S];
     }
     const auto* Win = find_w(h, "input_mapping.weight", (size_t)D * KIN);        // RAG.py:62
@@ -280,6 +294,8 @@ int build_images(ls_handle* h) {
 #define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
     if ((rc = upload(h, h->wch_hi_img, wch_hi.data(), wch_hi.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->wch_lo_img, wch_lo.data(), wch_lo.size() * sizeof(unsigned short))) != LS_OK) return rc;
+    if ((rc = upload(h, h->ww_hi_img, wwh.data(), wwh.size() * sizeof(unsigned short))) != LS_OK) return rc;
+    if ((rc = upload(h, h->ww_lo_img, wwl.data(), wwl.size() * sizeof(unsigned short))) != LS_OK) return rc;
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
     UP(win_full, *Win); UP(win_bias, *bin);
@@ -327,6 +343,8 @@ int build_images(ls_handle* h) {
     dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
     dw.wch_hi_img = static_cast<const unsigned short*>(h->wch_hi_img.p);
     dw.wch_lo_img = static_cast<const unsigned short*>(h->wch_lo_img.p);
+    dw.ww_hi_img = static_cast<const unsigned short*>(h->ww_hi_img.p);
+    dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
     dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
     dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
@@ -460,7 +478,7 @@ void ls_destroy(ls_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graph(h);
-    DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
+    DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->ww_hi_img, &h->ww_lo_img, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
                      &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
                      &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,

@@ -32,6 +32,8 @@ struct DevWeights {
     // v_mfma_f32_16x16x32_bf16 (lane (n, g) holds k = 32q + 8g .. +7): [L][8][2 passes][16 q][2 cb][64 lanes][8]
     const unsigned short* wch_hi_img;
     const unsigned short* wch_lo_img;
+    const unsigned short* ww_hi_img;   // [L][5][KS][64][8]  block-diagonal token weights, bf16 hi / lo planes
+    const unsigned short* ww_lo_img;
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
     const float* btok_rows;  // [L][80]

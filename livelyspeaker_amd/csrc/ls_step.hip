@@ -59,6 +59,16 @@ __host__ __device__ constexpr bool tokmix_needed(int S, int t, int m) {
     return !(4 * m + 3 < src_lo || 4 * m > src_hi);
 }
 
+// same for the bf16 token-mix MFMA, whose k step covers 32 source rows
+__host__ __device__ constexpr bool tokmix_needed32(int S, int t, int ks) {
+    const int R = 2 * S;
+    const int r_lo = 16 * t;
+    if (r_lo >= R) return false;
+    const int r_hi = (16 * t + 15 < R - 1) ? 16 * t + 15 : R - 1;
+    const int src_lo = (r_lo / S) * S, src_hi = (r_hi / S + 1) * S - 1;
+    return !(32 * ks + 31 < src_lo || 32 * ks > src_hi);
+}
+
 template <int S, int NPRE, int JF, int PREC>
 __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int R = 2 * S;                 // packed rows: [cond tokens | uncond tokens]
@@ -71,14 +81,16 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int MAXU = (NU + kWaves - 1) / kWaves;
     constexpr int kFullTiles = 4;            // token tiles whose 16 rows are all real
     constexpr int NREM = R - 16 * kFullTiles;  // rows of the ragged last tile (6 TED / 8 BEAT)
+    constexpr int NG = (R + 7) / 8;            // 8-row groups of the transposed bf16 operand of token mixing
+    constexpr int KS = (R + 31) / 32;          // k steps (32 source rows) of the bf16 token-mix MFMA
+    static_assert(2 * NG * kD * 8 * 2 <= (R * kUStride + kWaves * 2 * NREM * 16) * 4, "bf16 token-mix planes must fit U + REM");
     static_assert(NREM > 0 && NREM <= 16, "ragged tile");
     static_assert(R <= 16 * kNT, "rows must fit the token tiles");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* U = smem;                         // [R][520]
-    float* psum = smem + R * kUStride;       // [8][80]
-    float* psq = psum + kWaves * 16 * kNT;   // [8][80]
-    float* REM = psq + kWaves * 16 * kNT;    // [8 waves][2][NREM][16] remainder-row patch
+    float* psum = smem;                      // [8][80] (mean, M2) pairs of the LayerNorm merge
+    float* U = smem + 2 * kWaves * 16 * kNT; // [R][520] fp32 operand / two bf16 planes (bf16x3 mode)
+    float* REM = U + R * kUStride;           // [8 waves][2][NREM][16] remainder-row patch (fp32 mode)
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -285,14 +297,34 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             }
 #pragma unroll
             for (int t = 0; t < kNT; ++t)
-                if (valid_of(t)) {
+                if (PREC == 1 && alpha && !valid_of(t) && row_of(t) < 8 * NG) {
+                    __bf16* Th = reinterpret_cast<__bf16*>(U);
+                    __bf16* Tl = Th + NG * kD * 8;
+                    const int r = row_of(t);
+                    const int o = ((r >> 3) * kD + chw + 16 * cb) * 8 + (r & 7);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { Th[o + 8 * j] = (__bf16)0.f; Tl[o + 8 * j] = (__bf16)0.f; }
+                } else if (valid_of(t)) {
                     f4 u;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         u[j] = fmaf(X[cb][t][j], rstd[t], nmr[t]);
                         if (alpha) u[j] = fmaf(u[j], al[j], be[j]);
                     }
-                    if (PREC == 1 && !alpha) {
+                    if (PREC == 1 && alpha) {
+                        // token-mix operand, bf16x3: the contraction runs over ROWS, so the MFMA A operand needs 8
+                        // consecutive source rows of one channel in 16 contiguous bytes: UT[row/8][channel][row%8]
+                        __bf16* Th = reinterpret_cast<__bf16*>(U);
+                        __bf16* Tl = Th + NG * kD * 8;
+                        const int r = row_of(t);
+                        const int o = ((r >> 3) * kD + chw + 16 * cb) * 8 + (r & 7);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const __bf16 hi = (__bf16)u[j];
+                            Th[o + 8 * j] = hi;
+                            Tl[o + 8 * j] = (__bf16)(u[j] - (float)hi);
+                        }
+                    } else if (PREC == 1 && !alpha) {
                         // bf16x3 operand: u = hi + lo (+ O(2^-17 |u|)), hi = bf16_rne(u), lo = bf16_rne(u - hi);
                         // two bf16 planes [R][520] in the space of the fp32 buffer
                         __bf16* Uh = reinterpret_cast<__bf16*>(U);
@@ -336,7 +368,47 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         // out[d][r] = sum_r' u[r'][d] * WW[r][r']  as D[channel][row]: A = u^T from LDS, B = the block-diagonal
         // token weights (same for every workgroup, L1/L2 resident).  Tile by tile so only 18 B + 16 acc
         // registers are live; the k range of a tile covers just the sequence(s) whose rows it holds.
-        if (!(a.ablate & 2)) {
+        if constexpr (PREC == 1) {
+            if (!(a.ablate & 2)) {
+                const __bf16* Th = reinterpret_cast<const __bf16*>(U);
+                const __bf16* Tl = Th + NG * kD * 8;
+                gbf8p wwh = (gbf8p)(const bf8*)(a.W->ww_hi_img) + (size_t)l * kNT * KS * 64 + lane;
+                gbf8p wwl = (gbf8p)(const bf8*)(a.W->ww_lo_img) + (size_t)l * kNT * KS * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    const float bt = valid_of(t) ? g1(a.W->btok_rows)[l * 80 + row_of(t)] : 0.f;
+                    f4 acc[kCB];
+#pragma unroll
+                    for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){bt, bt, bt, bt};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (tokmix_needed32(S, t, ks)) {
+                            const bf8 Bh = wwh[(t * KS + ks) * 64], Bl = wwl[(t * KS + ks) * 64];
+                            const int grp = (4 * ks + 3 < NG || 4 * ks + g < NG) ? 4 * ks + g : NG - 1;   // clamp: weights are 0 there
+                            const int ao = (grp * kD + 64 * w + s16) * 8;
+                            bf8 Ah[kCB], Al[kCB];
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) {
+                                Ah[cb] = *reinterpret_cast<const bf8*>(Th + ao + 16 * cb * 8);
+                                Al[cb] = *reinterpret_cast<const bf8*>(Tl + ao + 16 * cb * 8);
+                            }
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[cb], Bh, acc[cb], 0, 0, 0);
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[cb], Bl, acc[cb], 0, 0, 0);
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[cb], Bh, acc[cb], 0, 0, 0);
+                        }
+                    }
+                    if (valid_of(t)) {
+#pragma unroll
+                        for (int cb = 0; cb < kCB; ++cb)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) X[cb][t][j] = silu_acc(acc[cb][j], X[cb][t][j]);
+                    }
+                }
+            }
+        } else if (!(a.ablate & 2)) {
             gfp wwp = g1(a.W->ww_img) + (size_t)l * kNT * MK * 64 + lane;
             const float* up = U + 64 * w + s16;
 #pragma unroll
