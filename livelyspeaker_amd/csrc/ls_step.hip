@@ -83,7 +83,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int NREM = R - 16 * kFullTiles;  // rows of the ragged last tile (6 TED / 8 BEAT)
     constexpr int NG = (R + 7) / 8;            // 8-row groups of the transposed bf16 operand of token mixing
     constexpr int KS = (R + 31) / 32;          // k steps (32 source rows) of the bf16 token-mix MFMA
-    static_assert(2 * NG * kD * 8 * 2 <= (R * kUStride + kWaves * 2 * NREM * 16) * 4, "bf16 token-mix planes must fit U + REM");
+    constexpr int kGrpStride = kD * 8 + 16;    // bf16 per 8-row group (+32 B so the two row halves of a tile miss each other's banks)
+    static_assert(2 * NG * kGrpStride * 2 <= (R * kUStride + kWaves * 2 * NREM * 16) * 4, "bf16 token-mix planes must fit U + REM");
     static_assert(NREM > 0 && NREM <= 16, "ragged tile");
     static_assert(R <= 16 * kNT, "rows must fit the token tiles");
 
@@ -299,11 +300,11 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             for (int t = 0; t < kNT; ++t)
                 if (PREC == 1 && alpha && !valid_of(t) && row_of(t) < 8 * NG) {
                     __bf16* Th = reinterpret_cast<__bf16*>(U);
-                    __bf16* Tl = Th + NG * kD * 8;
+                    __bf16* Tl = Th + NG * kGrpStride;
                     const int r = row_of(t);
-                    const int o = ((r >> 3) * kD + chw + 16 * cb) * 8 + (r & 7);
+                    const int o = (r >> 3) * kGrpStride + (64 * w + 16 * cb + g) * 8 + (r & 7);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { Th[o + 8 * j] = (__bf16)0.f; Tl[o + 8 * j] = (__bf16)0.f; }
+                    for (int j = 0; j < 4; ++j) { Th[o + 32 * j] = (__bf16)0.f; Tl[o + 32 * j] = (__bf16)0.f; }
                 } else if (valid_of(t)) {
                     f4 u;
 #pragma unroll
@@ -314,15 +315,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     if (PREC == 1 && alpha) {
                         // token-mix operand, bf16x3: the contraction runs over ROWS, so the MFMA A operand needs 8
                         // consecutive source rows of one channel in 16 contiguous bytes: UT[row/8][channel][row%8]
+                        // slot of channel (g, j) inside its 16-channel block is 4*j + g (bit-fields swapped), so the four lane
+                        // groups of one ds_write_b16 hit four different 16-byte slots instead of two
                         __bf16* Th = reinterpret_cast<__bf16*>(U);
-                        __bf16* Tl = Th + NG * kD * 8;
+                        __bf16* Tl = Th + NG * kGrpStride;
                         const int r = row_of(t);
-                        const int o = ((r >> 3) * kD + chw + 16 * cb) * 8 + (r & 7);
+                        const int o = (r >> 3) * kGrpStride + (64 * w + 16 * cb + g) * 8 + (r & 7);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const __bf16 hi = (__bf16)u[j];
-                            Th[o + 8 * j] = hi;
-                            Tl[o + 8 * j] = (__bf16)(u[j] - (float)hi);
+                            Th[o + 32 * j] = hi;
+                            Tl[o + 32 * j] = (__bf16)(u[j] - (float)hi);
                         }
                     } else if (PREC == 1 && !alpha) {
                         // bf16x3 operand: u = hi + lo (+ O(2^-17 |u|)), hi = bf16_rne(u), lo = bf16_rne(u - hi);
@@ -349,20 +352,24 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         fresh();
         {   // x = x + emb  (emb re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
             const float* te = a.temb + (size_t)b * a.temb_stride + chw;
+            f4 e[kCB];
 #pragma unroll
-            for (int cb = 0; cb < kCB; ++cb) {
-                const f4 e = *reinterpret_cast<const f4*>(te + 16 * cb);
+            for (int cb = 0; cb < kCB; ++cb) e[cb] = *reinterpret_cast<const f4*>(te + 16 * cb);
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
                 for (int t = 0; t < kNT; ++t)
-                    if (valid_of(t)) X[cb][t] += e;
-            }
+                    if (valid_of(t)) X[cb][t] += e[cb];
         }
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
         ln_stats();
         stamp(2 + 8 * l);
         fresh();
         ln_store(a.W->ln1a + l * kD, a.W->ln1b + l * kD);
-        __syncthreads();
+        // no workgroup barrier here: token mixing contracts over ROWS, so wave w only reads back the 64 channel columns
+        // it has just written itself (LDS operations of one wave execute in order); the LN statistics barrier above
+        // already ordered these stores after every wave's reads of the previous operand.
+        __builtin_amdgcn_wave_barrier();
         stamp(3 + 8 * l);
         fresh();
         // out[d][r] = sum_r' u[r'][d] * WW[r][r']  as D[channel][row]: A = u^T from LDS, B = the block-diagonal
@@ -371,7 +378,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         if constexpr (PREC == 1) {
             if (!(a.ablate & 2)) {
                 const __bf16* Th = reinterpret_cast<const __bf16*>(U);
-                const __bf16* Tl = Th + NG * kD * 8;
+                const __bf16* Tl = Th + NG * kGrpStride;
+                const int slot = ((s16 & 3) << 2) | (s16 >> 2);      // channel i = 4g'+j' of a block lives in slot 4j'+g'
                 gbf8p wwh = (gbf8p)(const bf8*)(a.W->ww_hi_img) + (size_t)l * kNT * KS * 64 + lane;
                 gbf8p wwl = (gbf8p)(const bf8*)(a.W->ww_lo_img) + (size_t)l * kNT * KS * 64 + lane;
 #pragma unroll
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         if (tokmix_needed32(S, t, ks)) {
                             const bf8 Bh = wwh[(t * KS + ks) * 64], Bl = wwl[(t * KS + ks) * 64];
                             const int grp = (4 * ks + 3 < NG || 4 * ks + g < NG) ? 4 * ks + g : NG - 1;   // clamp: weights are 0 there
-                            const int ao = (grp * kD + 64 * w + s16) * 8;
+                            const int ao = grp * kGrpStride + (64 * w + slot) * 8;
                             bf8 Ah[kCB], Al[kCB];
 #pragma unroll
                             for (int cb = 0; cb < kCB; ++cb) {
