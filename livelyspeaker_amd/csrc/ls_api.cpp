@@ -70,6 +70,7 @@ struct ls_handle {
 
     // device weights
     DevBuf wch_hi_img, wch_lo_img, ww_hi_img, ww_lo_img;
+    DevBuf winx_seq_img, wch_seq_hi_img, wch_seq_lo_img, ww_seq_hi_img, ww_seq_lo_img, btok_seq, wout_hi_img, wout_lo_img, out_raw;
     DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
     DevBuf conv_w[4], conv_b[4], win_full, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
     DevBuf te_w0, te_b0, te_w2, te_b2, pe;
@@ -107,6 +108,8 @@ struct ls_handle {
 };
 
 namespace {
+
+hipError_t run_step(ls_handle* h, StepArgs& s, int B, hipStream_t st);
 
 int fail(ls_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -171,6 +174,8 @@ int build_images(ls_handle* h) {
         l2a((size_t)L * D), l2b((size_t)L * D), ww((size_t)L * kNT * MK * 64), bt((size_t)L * 80, 0.f);
     std::vector<unsigned short> wch_hi((size_t)L * D * D), wch_lo((size_t)L * D * D);
     const int KS = (R + 31) / 32;
+    std::vector<unsigned short> wcs_hi((size_t)L * D * D), wcs_lo((size_t)L * D * D), wws_hi((size_t)L * 3 * 2 * 64 * 8), wws_lo((size_t)L * 3 * 2 * 64 * 8);
+    std::vector<float> bts((size_t)L * 48, 0.f);
     std::vector<unsigned short> wwh((size_t)L * kNT * KS * 64 * 8), wwl((size_t)L * kNT * KS * 64 * 8);
     char key[160];
     for (int l = 0; l < L; ++l) {
@@ -213,6 +218,34 @@ int build_images(ls_handle* h) {
                                     wch_lo[oh] = f32_to_bf16(v - bf16_to_f32(hi));
                                     ++oh;
                                 }
+        }
+        {   // per-pass variant: [l][w4][p][q16][c4][lane][8],  n = 128w + 16(4p+c) + (lane&15)
+            size_t oh = (size_t)l * D * D;
+            for (int w = 0; w < 4; ++w)
+                for (int p = 0; p < 2; ++p)
+                    for (int q = 0; q < 16; ++q)
+                        for (int c = 0; c < 4; ++c)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int n = 128 * w + 16 * (4 * p + c) + (lane & 15);
+                                    const int k = 32 * q + 8 * (lane >> 4) + e;
+                                    const float v = (*W)[(size_t)n * D + k] * (*a2)[k];
+                                    const unsigned short hi = f32_to_bf16(v);
+                                    wcs_hi[oh] = hi;
+                                    wcs_lo[oh] = f32_to_bf16(v - bf16_to_f32(hi));
+                                    ++oh;
+                                }
+            for (int t = 0; t < 3; ++t)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = 16 * t + (lane & 15), rp = 32 * ks + 8 * (lane >> 4) + e;
+                            const float v = (r < S && rp < S) ? (*Wt)[(size_t)r * S + rp] : 0.f;
+                            const size_t o = ((((size_t)l * 3 + t) * 2 + ks) * 64 + lane) * 8 + e;
+                            wws_hi[o] = f32_to_bf16(v);
+                            wws_lo[o] = f32_to_bf16(v - bf16_to_f32(wws_hi[o]));
+                        }
+            for (int r = 0; r < S; ++r) bts[(size_t)l * 48 + r] = (*b1)[r];
         }
         for (int n = 0; n < D; ++n) {                                                    // b' = b + W . beta2
             double acc = (*b2)[n];
@@ -275,6 +308,34 @@ int build_images(ls_handle* h) {
                     }
         for (int c = 0; c < JF; ++c) bout[c] = (*bo)[c];
     }
+    // per-pass variant: x_t columns of input_mapping [w4][h][q][c4][lane][4] and poseFinal as bf16 hi/lo [ob][q16][lane][8]
+    std::vector<float> winxs((size_t)4 * 2 * KXQ * 4 * 64 * 4);
+    std::vector<unsigned short> wo_hi((size_t)NOB * 16 * 64 * 8), wo_lo((size_t)NOB * 16 * 64 * 8);
+    {
+        size_t o = 0;
+        for (int w = 0; w < 4; ++w)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int q = 0; q < KXQ; ++q)
+                    for (int c = 0; c < 4; ++c)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = 128 * w + 16 * (4 * hh + c) + (lane & 15);
+                                const int k = 16 * q + 4 * (lane >> 4) + j;
+                                winxs[o++] = k < JF ? (*Win)[(size_t)n * KIN + k] : 0.f;
+                            }
+        o = 0;
+        for (int ob = 0; ob < NOB; ++ob)
+            for (int q = 0; q < 16; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = 16 * ob + (lane & 15);
+                        const int k = 32 * q + 8 * (lane >> 4) + e;
+                        const float v = c < JF ? (*Wout)[(size_t)c * D + k] : 0.f;
+                        wo_hi[o] = f32_to_bf16(v);
+                        wo_lo[o] = f32_to_bf16(v - bf16_to_f32(wo_hi[o]));
+                        ++o;
+                    }
+    }
     // wout_reg_img[w][ob][cb][lane][j] = Wout[c = 16ob + (lane&15)][k = 64w + 16cb + 4(lane>>4) + j]: the k order in which
     // wave w's residual registers X[cb][.][j] present the hidden state as an MFMA B operand
     std::vector<float> woutr((size_t)kWaves * NOB * kCB * 64 * 4);
@@ -296,6 +357,10 @@ int build_images(ls_handle* h) {
     if ((rc = upload(h, h->wch_lo_img, wch_lo.data(), wch_lo.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->ww_hi_img, wwh.data(), wwh.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->ww_lo_img, wwl.data(), wwl.size() * sizeof(unsigned short))) != LS_OK) return rc;
+#define UPS(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof((vec)[0]))) != LS_OK) return rc
+    UPS(winx_seq_img, winxs); UPS(wch_seq_hi_img, wcs_hi); UPS(wch_seq_lo_img, wcs_lo); UPS(ww_seq_hi_img, wws_hi);
+    UPS(ww_seq_lo_img, wws_lo); UPS(btok_seq, bts); UPS(wout_hi_img, wo_hi); UPS(wout_lo_img, wo_lo);
+#undef UPS
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
     UP(win_full, *Win); UP(win_bias, *bin);
@@ -345,6 +410,14 @@ int build_images(ls_handle* h) {
     dw.wch_lo_img = static_cast<const unsigned short*>(h->wch_lo_img.p);
     dw.ww_hi_img = static_cast<const unsigned short*>(h->ww_hi_img.p);
     dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
+    dw.winx_seq_img = h->winx_seq_img.f();
+    dw.wch_seq_hi_img = static_cast<const unsigned short*>(h->wch_seq_hi_img.p);
+    dw.wch_seq_lo_img = static_cast<const unsigned short*>(h->wch_seq_lo_img.p);
+    dw.ww_seq_hi_img = static_cast<const unsigned short*>(h->ww_seq_hi_img.p);
+    dw.ww_seq_lo_img = static_cast<const unsigned short*>(h->ww_seq_lo_img.p);
+    dw.btok_seq = h->btok_seq.f();
+    dw.wout_hi_img = static_cast<const unsigned short*>(h->wout_hi_img.p);
+    dw.wout_lo_img = static_cast<const unsigned short*>(h->wout_lo_img.p);
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
     dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
     dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
@@ -373,6 +446,16 @@ int ensure_temb_table(ls_handle* h) {
     if (rc != LS_OK) return rc;
     h->temb_valid = true;
     return LS_OK;
+}
+
+// precision 0: exact fp32 (k_step); 1: bf16x3, one workgroup per CFG pass (k_seq + k_cfg_update);
+// 2: bf16x3 inside the one-workgroup-per-sample kernel (k_step<.., 1>), kept for A/B comparison
+hipError_t run_step(ls_handle* h, StepArgs& s, int B, hipStream_t st) {
+    if (h->precision == 1) {
+        s.out_raw = h->out_raw.f();
+        return launch_step_seq(h->var, s, B, st);
+    }
+    return launch_step(h->var, h->precision == 2 ? 1 : 0, s, B, st);
 }
 
 void fill_common(ls_handle* h, StepArgs& a) {
@@ -461,6 +544,8 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
+    e = init_seq_kernels();
+    if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(seq kernel LDS): %s", hipGetErrorString(e)); }
     e = init_step_kernels();
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
     if (h->prof_on) {
@@ -478,7 +563,8 @@ void ls_destroy(ls_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graph(h);
-    DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->ww_hi_img, &h->ww_lo_img, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
+    DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->ww_hi_img, &h->ww_lo_img, &h->winx_seq_img, &h->wch_seq_hi_img,
+                     &h->wch_seq_lo_img, &h->ww_seq_hi_img, &h->ww_seq_lo_img, &h->btok_seq, &h->wout_hi_img, &h->wout_lo_img, &h->out_raw, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
                      &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
                      &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
@@ -517,7 +603,8 @@ int ls_commit_weights(ls_handle* h) {
 
 int ls_set_precision(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
-    if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3) return fail(h, LS_EINVAL, "unknown precision mode %d", mode);
+    if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3 && mode != LS_PRECISION_BF16X3_FUSED)
+        return fail(h, LS_EINVAL, "unknown precision mode %d", mode);
     if (mode != h->precision) free_graph(h);
     h->precision = mode;
     return LS_OK;
@@ -603,6 +690,7 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
         HIPCHK(h, h->emo_tok.ensure((size_t)B * kD * sizeof(float)));
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st));
     }
+    { const void* old_raw = h->out_raw.p; HIPCHK(h, h->out_raw.ensure((size_t)B * 2 * kT * JF * sizeof(float))); if (old_raw != h->out_raw.p) free_graph(h); }
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipEventElapsedTime(&h->timing.prepare_ms, h->ev[0], h->ev[1]));
@@ -640,7 +728,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
         HIPCHK(h, h->trace.ensure((size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float)));
         s.trace = h->trace.f();
     }
-    HIPCHK(h, launch_step(h->var, h->precision, s, B, st));
+    HIPCHK(h, run_step(h, s, B, st));
     float* outs[3] = {a->out_cond, a->out_uncond, a->out_cfg};
     const float* srcs[3] = {h->fwd_c.f(), h->fwd_u.f(), h->fwd_cfg.f()};
     for (int i = 0; i < 3; ++i) {
@@ -682,7 +770,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
     s.noise = h->noise.f();
     s.temb = h->temb.f() + (size_t)a->index * kD; s.temb_stride = 0;
-    HIPCHK(h, launch_step(h->var, h->precision, s, B, st));
+    HIPCHK(h, run_step(h, s, B, st));
     HIPCHK(h, launch_from_internal(h->xb.f(), h->xio.f(), B, JF, st));
     if ((rc = egress(h, a->sample, h->xio.f(), nx, od)) != LS_OK) return rc;
     if (a->pred_xstart) {
@@ -795,7 +883,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
             }
             for (int d = 0; d < a->n_dump; ++d)
                 if (a->dump_steps[d] == k) s.x0_out = h->dump.f() + (size_t)d * nelem;
-            HIPCHK(h, launch_step(h->var, h->precision, s, B, st));
+            HIPCHK(h, run_step(h, s, B, st));
         }
         return LS_OK;
     };

@@ -34,6 +34,15 @@ struct DevWeights {
     const unsigned short* wch_lo_img;
     const unsigned short* ww_hi_img;   // [L][5][KS][64][8]  block-diagonal token weights, bf16 hi / lo planes
     const unsigned short* ww_lo_img;
+    // per-pass variant (ls_step_seq.hip: 4 waves x 128 channels, one sequence = 3 token tiles)
+    const float* winx_seq_img;            // [4][2 halves][KXQ][4 cb][64][4]
+    const unsigned short* wch_seq_hi_img; // [L][4][2 passes][16 q][4 cb][64][8]
+    const unsigned short* wch_seq_lo_img;
+    const unsigned short* ww_seq_hi_img;  // [L][3][2][64][8]   Wt (single sequence), bf16 hi / lo
+    const unsigned short* ww_seq_lo_img;
+    const float* btok_seq;                // [L][48]
+    const unsigned short* wout_hi_img;    // [NOB][16 q][64][8]  poseFinal, bf16 hi / lo
+    const unsigned short* wout_lo_img;
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
     const float* btok_rows;  // [L][80]
@@ -51,6 +60,7 @@ struct StepArgs {
     float* x0_out;       // pred_xstart (CFG-combined)    (nullable)
     float* fwd_c;        // raw cond / uncond model outputs (nullable)
     float* fwd_u;
+    float* out_raw;      // per-pass variant: raw model outputs [B][2 passes][T][JF] handed to k_cfg_update
     // prepared conditioning
     const float* static_c;   // [B][T][512]  W_in[:,JF:] . [prefix poses | bit | audio] + b
     const float* static_u;   // same with the audio term masked
@@ -89,6 +99,9 @@ enum Variant { kTED = 0, kBEAT = 1 };
 hipError_t launch_step(Variant v, int prec, const StepArgs& a, int batch, hipStream_t st);
 size_t step_lds_bytes(Variant v);
 hipError_t init_step_kernels();
+hipError_t init_seq_kernels();
+// bf16x3, one workgroup per CFG pass + CFG/sampler-update kernel (ls_step_seq.hip)
+hipError_t launch_step_seq(Variant v, const StepArgs& a, int batch, hipStream_t st);
 
 // ---- once-per-call kernels (ls_prepare.hip) ------------------------------------------------
 hipError_t launch_conv1d(const float* in, const float* stats, const float* w, const float* bias, float* out,

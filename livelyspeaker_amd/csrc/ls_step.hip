@@ -21,34 +21,9 @@
 //     pre-swizzled on the host so each wave-instruction reads 1 KiB contiguous from L2.
 //   * token mixing (Conv1d(S,S,1) over the token axis) is a second small MFMA GEMM against a
 //     block-diagonal [R x R] operand; its output lands directly in the residual layout.
-#include "ls_internal.h"
-#include "ls_philox.h"
+#include "ls_step_common.h"
 
 namespace ls {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) bf8* gbf8p;
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-// x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp), far inside the 1e-3 parity budget.
-__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// r + SiLU(v) in 5 VALU ops: v_mul (exp2 scale), v_exp, v_add, v_rcp, v_fma -- these epilogues are issue-bound
-__device__ __forceinline__ float silu_acc(float v, float r) {
-    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
-    return fmaf(v, s, r);
-}
-
-// Pointers fetched from the DevWeights block are generic to the compiler; cast them to the global
-// address space so loads are global_load (vmcnt only) instead of flat_load (vmcnt AND lgkmcnt, which
-// would make every LDS wait in the GEMM loops also wait for the weight prefetch).
-typedef const __attribute__((address_space(1))) f4* gf4p;
-typedef const __attribute__((address_space(1))) float* gfp;
-__device__ __forceinline__ gf4p g4(const float* p) { return (gf4p)(const f4*)p; }
-__device__ __forceinline__ gfp g1(const float* p) { return (gfp)p; }
 
 __host__ __device__ constexpr bool tokmix_needed(int S, int t, int m) {
     const int R = 2 * S;

@@ -166,16 +166,16 @@ def test_abi_error_behaviour(ted):
 
 # ------------------------------------------------------------------------------------------------
 # Opt-in bf16x3 split-precision mode: same contract (1e-3 max-abs vs the reference), looser than fp32 noise
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_fused"])
 @pytest.mark.parametrize("ds", ["ted", "beat"])
-def test_bf16x3_mode_meets_the_parity_contract(ds, golden):
-    golden = golden  # session fixture from conftest
+def test_bf16x3_mode_meets_the_parity_contract(ds, mode, golden):
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
     cfg = synth.CONFIGS[ds]
     eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
     try:
         eng.load_state_dict(synth.make_state_dict(cfg))
-        eng.set_precision("bf16x3")
+        eng.set_precision(mode)
         g = golden[ds]
         B = 4
         y = synth.make_cond(cfg, B)
@@ -187,7 +187,7 @@ def test_bf16x3_mode_meets_the_parity_contract(ds, golden):
         for t in (0, 500, 999):
             oc, ou, _ = eng.forward(x, np.full((B,), t), eps[0], eps[1])
             worst = max(worst, max_abs(oc, g[f"G1_t{t}_c"]), max_abs(ou, g[f"G1_t{t}_u"]))
-        print(f"{ds} bf16x3 single forward vs reference: {worst:.3e}")
+        print(f"{ds} {mode} single forward vs reference: {worst:.3e}")
         assert worst < 1e-3
         runs = [("G3_ddpm50_final", 50, "", False, 0, False), ("G4_ddim100_skip80_final", 1000, "ddim100", True, 80, True)]
         if ds == "ted":
@@ -200,7 +200,7 @@ def test_bf16x3_mode_meets_the_parity_contract(ds, golden):
                              eps_tape=tape.eps, noise_tape=tape.noise, skip_timesteps=skip,
                              init_image=synth.make_init_image(cfg, B) if use_init else None)
             d = max_abs(out, g[key])
-            print(f"{ds} bf16x3 {key}: max|d| = {d:.3e} (contract 1e-3)")
+            print(f"{ds} {mode} {key}: max|d| = {d:.3e} (contract 1e-3)")
             assert d < 1e-3
         eng.set_precision("fp32")
         sch = orc.Schedule(50, "")
