@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3 measurement")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x3_fused"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x3_perpass"],
                     help="fp32 = exact (headline); bf16x3 = opt-in split-precision channel mixing")
     return ap.parse_args()
 

@@ -43,7 +43,7 @@ enum { LS_NOISE_TAPE = 0, LS_NOISE_PHILOX = 1 };
  * products.  BF16X3 (opt-in): each fp32 operand split into bf16 hi+lo, three v_mfma_f32_16x16x32_bf16 per product
  * (hi.hi + hi.lo + lo.hi, fp32 accumulate): ~2^-16 relative product error, parity-gated at the 1e-3 contract. */
 enum { LS_PRECISION_FP32 = 0, LS_PRECISION_BF16X3 = 1,
-       LS_PRECISION_BF16X3_FUSED = 2 /* same arithmetic inside the one-workgroup-per-sample kernel (A/B reference) */ };
+       LS_PRECISION_BF16X3_PERPASS = 2 /* same arithmetic, one workgroup per CFG pass; slower, kept as A/B reference */ };
 
 typedef struct ls_handle ls_handle;
 

@@ -241,7 +241,7 @@ class Engine:
 
     def set_precision(self, mode):
         """'fp32' (exact, default) or 'bf16x3' (split-precision channel mixing on the bf16 matrix cores)."""
-        code = {"fp32": 0, "bf16x3": 1, "bf16x3_fused": 2}.get(mode, mode)
+        code = {"fp32": 0, "bf16x3": 1, "bf16x3_perpass": 2}.get(mode, mode)
         self._check(self.lib.ls_set_precision(self.h, int(code)), "ls_set_precision")
         self.precision = mode
 

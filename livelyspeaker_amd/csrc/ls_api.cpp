@@ -448,14 +448,15 @@ int ensure_temb_table(ls_handle* h) {
     return LS_OK;
 }
 
-// precision 0: exact fp32 (k_step); 1: bf16x3, one workgroup per CFG pass (k_seq + k_cfg_update);
-// 2: bf16x3 inside the one-workgroup-per-sample kernel (k_step<.., 1>), kept for A/B comparison
+// precision 0: exact fp32 (k_step<..,0>); 1: bf16x3 inside the same one-workgroup-per-sample kernel (k_step<..,1>);
+// 2: bf16x3 with one workgroup per CFG pass (k_seq + k_cfg_update) -- measured SLOWER (0.84 vs 0.67 ms/step at B=512:
+// every workgroup streams the whole 1 MB/layer of hi+lo weights for 48 rows instead of 80), kept as an A/B reference
 hipError_t run_step(ls_handle* h, StepArgs& s, int B, hipStream_t st) {
-    if (h->precision == 1) {
+    if (h->precision == 2) {
         s.out_raw = h->out_raw.f();
         return launch_step_seq(h->var, s, B, st);
     }
-    return launch_step(h->var, h->precision == 2 ? 1 : 0, s, B, st);
+    return launch_step(h->var, h->precision == 1 ? 1 : 0, s, B, st);
 }
 
 void fill_common(ls_handle* h, StepArgs& a) {
@@ -603,7 +604,7 @@ int ls_commit_weights(ls_handle* h) {
 
 int ls_set_precision(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
-    if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3 && mode != LS_PRECISION_BF16X3_FUSED)
+    if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3 && mode != LS_PRECISION_BF16X3_PERPASS)
         return fail(h, LS_EINVAL, "unknown precision mode %d", mode);
     if (mode != h->precision) free_graph(h);
     h->precision = mode;

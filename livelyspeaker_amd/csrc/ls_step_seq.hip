@@ -9,6 +9,11 @@
 // other's MFMAs.  The price is row padding 48/35 on the (now cheap) MFMAs and a tiny second kernel for the CFG lerp
 // + sampler update, because the two passes of a sample no longer meet inside one workgroup.
 //
+// MEASURED RESULT (MI355X, B=512): this variant is SLOWER than the fused kernel, 0.84 vs 0.67 ms/step.  Two workgroups
+// per CU are co-resident as intended, but each streams the full 1 MB/layer of hi+lo weights for 48 rows (fused: 80),
+// doubling L2->CU weight traffic to ~10 TB/s, and waves wait MORE (57 % vs 46 % in s_waitcnt).  It is kept as precision
+// mode LS_PRECISION_BF16X3_PERPASS for A/B runs (it is parity-tested); the product uses ls_step.hip for both precisions.
+//
 // Same math, layouts and reference citations as ls_step.hip (see there); wave w owns channels [128w, 128w+128).
 #include "ls_step_common.h"
 

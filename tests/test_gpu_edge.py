@@ -166,7 +166,7 @@ def test_abi_error_behaviour(ted):
 
 # ------------------------------------------------------------------------------------------------
 # Opt-in bf16x3 split-precision mode: same contract (1e-3 max-abs vs the reference), looser than fp32 noise
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_fused"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_perpass"])
 @pytest.mark.parametrize("ds", ["ted", "beat"])
 def test_bf16x3_mode_meets_the_parity_contract(ds, mode, golden):
     from livelyspeaker_amd import _lib
