@@ -211,6 +211,25 @@ int ls_sag_commit_weights(ls_sag* h);
 int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask,
                   float* out);
 
+/* ---- caller-side post-processing of sampled clips ---------------------------------
+ * scripts/test_RAG_ted.py:84-111 (layout change, mean add, per-bone normalisation, joint-angle change curve, motion
+ * beats) and convert_dir_vec_to_pose (scripts/utils/data_utils.py:77-97).  Stateless; dataset constants are passed in. */
+typedef struct ls_post_config {
+    int32_t njoints;            /* direction vectors per frame: 9 (TED)                          */
+    int32_t n_pairs;            /* angle pairs: 4 (test_RAG_ted.py:24-29)                        */
+    int32_t n_pose_joints;      /* 10                                                            */
+    float thres;                /* 0.03 (:32)                                                    */
+    int32_t pair_a[8], pair_b[8];
+    float change_angle[8];      /* (:30)                                                         */
+    int32_t bone_parent[16], bone_child[16];   /* dir_vec_pairs (data_utils.py:13-14)            */
+    float bone_len[16];
+    float mean_dir_vec[48];     /* (:22)                                                         */
+} ls_post_config;
+/* sample [B,J,3,34] -> aligned [B,34,J*3], pose [B,34,n_pose_joints,3], angle_diff [B,34], beat_mask [B,34] (bytes);
+ * any output may be NULL.  Pointers are device pointers iff on_device. */
+int ls_ted_post(int device, int on_device, int batch, const ls_post_config* c, const float* sample, float* aligned,
+                float* pose, float* angle_diff, unsigned char* beat_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,13 @@ class LsSagConfig(C.Structure):
                                          "num_heads", "n_pre_poses", "device", "reserved")]
 
 
+class LsPostConfig(C.Structure):
+    _fields_ = [("njoints", C.c_int32), ("n_pairs", C.c_int32), ("n_pose_joints", C.c_int32), ("thres", C.c_float),
+                ("pair_a", C.c_int32 * 8), ("pair_b", C.c_int32 * 8), ("change_angle", C.c_float * 8),
+                ("bone_parent", C.c_int32 * 16), ("bone_child", C.c_int32 * 16), ("bone_len", C.c_float * 16),
+                ("mean_dir_vec", C.c_float * 48)]
+
+
 class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32)]
@@ -74,7 +81,7 @@ class LsTiming(C.Structure):
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
            "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
-           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode")
+           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_ted_post")
 
 _lib = None
 
@@ -137,6 +144,8 @@ def load_library(build_if_missing: bool = True):
     lib.ls_sag_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     lib.ls_sag_commit_weights.argtypes = [C.c_void_p]
     lib.ls_sag_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ls_ted_post.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(LsPostConfig), C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]
     if lib.ls_abi_version() != 1:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib

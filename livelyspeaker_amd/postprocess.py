@@ -1,0 +1,62 @@
+"""Caller-side plumbing around the sampler: what ``scripts/test_RAG_ted.py:84-111`` and
+``scripts/utils/data_utils.py:77-97`` do with a sampled batch, as one small GPU kernel (``ls_ted_post``).
+
+The numbers below are DATASET CONSTANTS of the TED gesture data as published in the reference's scripts
+(mean direction vector ``test_RAG_ted.py:22``, angle pairs ``:24-29``, per-pair normalisers ``:30``, beat
+threshold ``:32``, bone tree and lengths ``utils/data_utils.py:13-14``); they are data, passed to the kernel."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+TED_MEAN_DIR_VEC = np.array([0.0154009, -0.9690125, -0.0884354, -0.0022264, -0.8655276, 0.4342174, -0.0035145, -0.8755367,
+                             -0.4121039, -0.9236511, 0.3061306, -0.0012415, -0.5155854, 0.8129665, 0.0871897, 0.2348464,
+                             0.1846561, 0.8091402, 0.9271948, 0.2960011, -0.013189, 0.5233978, 0.8092403, 0.0725451,
+                             -0.2037076, 0.1924306, 0.8196916], dtype=np.float32)
+TED_ANGLE_PAIRS = [(3, 4), (4, 5), (6, 7), (7, 8)]
+TED_CHANGE_ANGLE = [0.0034540758933871984, 0.007043459918349981, 0.003493624273687601, 0.007205077446997166]
+TED_BEAT_THRES = 0.03
+TED_DIR_VEC_PAIRS = [(0, 1, 0.26), (1, 2, 0.18), (2, 3, 0.14), (1, 4, 0.22), (4, 5, 0.36), (5, 6, 0.33), (1, 7, 0.22),
+                     (7, 8, 0.36), (8, 9, 0.33)]
+TED_FPS = 15.0
+
+
+def ted_post_config() -> "_lib.LsPostConfig":
+    c = _lib.LsPostConfig()
+    c.njoints, c.n_pairs, c.n_pose_joints, c.thres = 9, len(TED_ANGLE_PAIRS), 10, TED_BEAT_THRES
+    for k, (a, b) in enumerate(TED_ANGLE_PAIRS):
+        c.pair_a[k], c.pair_b[k], c.change_angle[k] = a, b, TED_CHANGE_ANGLE[k]
+    for j, (pa, ch, ln) in enumerate(TED_DIR_VEC_PAIRS):
+        c.bone_parent[j], c.bone_child[j], c.bone_len[j] = pa, ch, ln
+    for j, v in enumerate(TED_MEAN_DIR_VEC):
+        c.mean_dir_vec[j] = float(v)
+    return c
+
+
+def ted_postprocess(sample, device: int = 0, want_pose: bool = True) -> dict:
+    """sample: [B, 9, 3, 34] (numpy, CPU tensor or CUDA tensor as returned by the sampler).
+    Returns aligned_motions [B,34,27], pose [B,34,10,3], angle_diff [B,34], beat_mask [B,34] (bool) and
+    motion_beat_times (list of lists of seconds, t/15 as in test_RAG_ted.py:111)."""
+    lib = _lib.load_library()
+    m = _lib._Marshal(device, sample)
+    B = int(sample.shape[0])
+    cfg = ted_post_config()
+    aligned, p_al = m.out((B, 34, 27))
+    pose, p_pose = m.out((B, 34, 10, 3)) if want_pose else (None, None)
+    diff, p_diff = m.out((B, 34))
+    if m.on_device:
+        mask = m.torch.empty((B, 34), dtype=m.torch.uint8, device=m.dev)
+        p_mask = C.c_void_p(mask.data_ptr())
+    else:
+        mask = np.empty((B, 34), np.uint8)
+        p_mask = mask.ctypes.data_as(C.c_void_p)
+    rc = lib.ls_ted_post(device, int(m.on_device), B, C.byref(cfg), m.f32(sample, (B, 9, 3, 34)), p_al, p_pose, p_diff, p_mask)
+    if rc != 0:
+        raise _lib.EngineError(f"ls_ted_post failed ({rc})")
+    mask_np = mask.cpu().numpy() if m.on_device else mask
+    beats = [[float(t) / TED_FPS for t in np.nonzero(mask_np[b])[0]] for b in range(B)]
+    return {"aligned_motions": aligned, "pose": pose, "angle_diff": diff,
+            "beat_mask": mask.bool() if m.on_device else mask.astype(bool), "motion_beat_times": beats}

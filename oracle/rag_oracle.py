@@ -392,3 +392,26 @@ class SagDecoderOracle:
         if mask is not None:
             out = out * np.asarray(mask, dtype=bool)[:, :, None]                        # "zero for padded area" (:175)
         return np.ascontiguousarray(out.reshape(B, self.T, self.J, self.Fe).transpose(0, 2, 3, 1))
+
+
+# --------------------------------------------------------------------------- caller plumbing
+def ted_post(sample, mean_dir_vec, angle_pairs, change_angle, thres, dir_vec_pairs):
+    """scripts/test_RAG_ted.py:84-111 and convert_dir_vec_to_pose (scripts/utils/data_utils.py:77-97) restated."""
+    B = sample.shape[0]
+    aligned = np.ascontiguousarray(np.asarray(sample, dtype=F32).transpose(0, 3, 1, 2).reshape(B, sample.shape[3], -1))
+    vec = (aligned + np.asarray(mean_dir_vec, dtype=F32)).astype(F32)
+    v = vec.reshape(B, aligned.shape[1], -1, 3)
+    n = v / np.maximum(np.sqrt((v * v).sum(-1, keepdims=True)), F32(1e-12))
+    diff = np.zeros((B, aligned.shape[1]), dtype=F32)
+    for k, (pa, pb) in enumerate(angle_pairs):
+        ip = np.clip((n[:, :, pa] * n[:, :, pb]).sum(-1), -1, 1)
+        ang = (np.arccos(ip) / F32(math.pi)).astype(F32)
+        diff[:, 1:] += np.abs(ang[:, 1:] - ang[:, :-1]) / F32(change_angle[k]) / F32(len(change_angle))
+    mask = np.zeros((B, aligned.shape[1]), dtype=bool)
+    for t in range(2, 33):
+        c, l, r = diff[:, t], diff[:, t - 1], diff[:, t + 1]
+        mask[:, t] = (c < l) & (c < r) & ((l - c >= thres) | (r - c >= thres))
+    pose = np.zeros((B, aligned.shape[1], 10, 3), dtype=np.float64)
+    for j, (pa, ch, ln) in enumerate(dir_vec_pairs):
+        pose[:, :, ch] = pose[:, :, pa] + ln * v[:, :, j]
+    return {"aligned": aligned, "angle_diff": diff, "beat_mask": mask, "pose": pose}

@@ -1,0 +1,48 @@
+"""Caller plumbing row: layout change, mean add, bone normalisation, joint-angle change
+curve, motion beats, dir-vec -> pose.  Oracle vs fixture G9 (CPU); HIP kernel vs fixture and oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, max_abs
+from livelyspeaker_amd import postprocess as pp
+
+
+@pytest.fixture(scope="module")
+def g9():
+    return np.load(os.path.join(GOLDEN, "post_golden.npz"))
+
+
+def _sample():
+    return np.load(os.path.join(GOLDEN, "ted_golden.npz"))["G5_ddpm1000_final"]
+
+
+def test_oracle_matches_reference_fixture(g9):
+    from oracle import rag_oracle as orc
+    o = orc.ted_post(_sample(), pp.TED_MEAN_DIR_VEC, pp.TED_ANGLE_PAIRS, pp.TED_CHANGE_ANGLE, pp.TED_BEAT_THRES, pp.TED_DIR_VEC_PAIRS)
+    assert np.array_equal(o["aligned"], g9["G9_aligned"])
+    assert max_abs(o["angle_diff"], g9["G9_angle_diff"]) < 1e-3       # acos near +-1 amplifies fp32 rounding
+    assert max_abs(o["pose"], g9["G9_pose"]) < 1e-6
+    assert np.array_equal(o["beat_mask"], g9["G9_beat_mask"]) and g9["G9_beat_mask"].sum() > 0
+
+
+@pytest.mark.gpu
+def test_hip_post_vs_reference_fixture(g9):
+    import torch
+    s = _sample()
+    r = pp.ted_postprocess(s)
+    assert np.array_equal(r["aligned_motions"], g9["G9_aligned"])
+    assert max_abs(r["pose"], g9["G9_pose"]) < 1e-5
+    d = max_abs(r["angle_diff"], g9["G9_angle_diff"])
+    print("angle_diff max|d| =", d)
+    assert d < 2e-3
+    # beats are a thresholded local-minimum test: equal wherever the curve is not within rounding of the threshold
+    assert (r["beat_mask"] != g9["G9_beat_mask"]).sum() <= 1
+    assert r["motion_beat_times"][0] == [float(t) / 15.0 for t in np.nonzero(r["beat_mask"][0])[0]]
+    # device-resident path (what the sampler returns) and a caller-sized batch
+    big = torch.from_numpy(np.tile(s, (128, 1, 1, 1))).cuda()
+    rb = pp.ted_postprocess(big)
+    assert rb["aligned_motions"].is_cuda and tuple(rb["pose"].shape) == (512, 34, 10, 3)
+    assert np.array_equal(rb["angle_diff"][:4].cpu().numpy(), r["angle_diff"])
+    assert np.array_equal(rb["beat_mask"][508:].cpu().numpy(), r["beat_mask"])
