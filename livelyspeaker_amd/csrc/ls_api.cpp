@@ -72,6 +72,7 @@ struct ls_handle {
     DevBuf wch_hi_img, wch_lo_img, ww_hi_img, ww_lo_img;
     DevBuf winx_seq_img, wch_seq_hi_img, wch_seq_lo_img, ww_seq_hi_img, ww_seq_lo_img, btok_seq, wout_hi_img, wout_lo_img, out_raw;
     DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
+    DevBuf conv_img[4];     // MFMA operand images of the stride-6 conv layers (ls_conv.hip)
     DevBuf conv_w[4], conv_b[4], win_full, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
     DevBuf te_w0, te_b0, te_w2, te_b2, pe;
 
@@ -372,6 +373,21 @@ int build_images(ls_handle* h) {
         const auto* cb = find_w(h, key, kConvCout[i]);
         if (!cw || !cb) return LS_ESTATE;
         UP(conv_w[i], *cw); UP(conv_b[i], *cb);
+        if (i > 0) {
+            // image [co tile][chunk][k][lane][cig]: W[co = 16*ct + (lane&15)][ci = 16*chunk + 4*cig + (lane>>4)][k]
+            const int Cin = kConvCin[i], Cout = kConvCout[i], nchunk = Cin / 16;
+            std::vector<float> img((size_t)Cout * Cin * 15 / 16 * 16);
+            size_t o = 0;
+            for (int ct = 0; ct < Cout / 16; ++ct)
+                for (int ch = 0; ch < nchunk; ++ch)
+                    for (int k = 0; k < 15; ++k)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int cig = 0; cig < 4; ++cig) {
+                                const int co = 16 * ct + (lane & 15), ci = 16 * ch + 4 * cig + (lane >> 4);
+                                img[o++] = (*cw)[((size_t)co * Cin + ci) * 15 + k];
+                            }
+            UP(conv_img[i], img);
+        }
     }
     const auto* se = find_w(h, "speaker_embedding.weight", (size_t)h->cfg.n_speakers * 256);   // RAG.py:65-69
     const auto* mw = find_w(h, "speaker_mu.weight", (size_t)D * 256);
@@ -574,7 +590,7 @@ void ls_destroy(ls_handle* h) {
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->prof};
     for (DevBuf* d : all) d->release();
-    for (int i = 0; i < 4; ++i) { h->conv_w[i].release(); h->conv_b[i].release(); }
+    for (int i = 0; i < 4; ++i) { h->conv_w[i].release(); h->conv_b[i].release(); h->conv_img[i].release(); }
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -660,8 +676,12 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     const float* in_stats = nullptr;
     for (int i = 0; i < 4; ++i) {
         HIPCHK(h, outs[i]->ensure((size_t)B * kConvCout[i] * Lc[i + 1] * sizeof(float)));
-        HIPCHK(h, launch_conv1d(in, in_stats, h->conv_w[i].f(), h->conv_b[i].f(), outs[i]->f(), B, kConvCin[i], kConvCout[i],
-                                Lc[i], Lc[i + 1], kConvStride[i], kConvPad[i], st));
+        if (i == 0)     // Cin = 1: 15-tap FIR, stays on the VALU kernel
+            HIPCHK(h, launch_conv1d(in, in_stats, h->conv_w[i].f(), h->conv_b[i].f(), outs[i]->f(), B, kConvCin[i], kConvCout[i],
+                                    Lc[i], Lc[i + 1], kConvStride[i], kConvPad[i], st));
+        else
+            HIPCHK(h, launch_conv1d_mfma(in, in_stats, h->conv_img[i].f(), h->conv_b[i].f(), outs[i]->f(), B, kConvCin[i],
+                                         kConvCout[i], Lc[i], Lc[i + 1], st));
         if (i < 3) {
             HIPCHK(h, stats[i]->ensure((size_t)B * kConvCout[i] * 2 * sizeof(float)));
             HIPCHK(h, launch_instnorm_stats(outs[i]->f(), stats[i]->f(), B * kConvCout[i], Lc[i + 1], st));

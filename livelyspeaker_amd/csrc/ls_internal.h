@@ -106,6 +106,9 @@ hipError_t launch_step_seq(Variant v, const StepArgs& a, int batch, hipStream_t 
 // ---- once-per-call kernels (ls_prepare.hip) ------------------------------------------------
 hipError_t launch_conv1d(const float* in, const float* stats, const float* w, const float* bias, float* out,
                          int B, int Cin, int Cout, int Lin, int Lout, int stride, int pad, hipStream_t st);
+// stride-6 layers on MFMA (ls_conv.hip); wimg = per-lane operand image built by ls_api.cpp
+hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* wimg, const float* bias, float* out, int B,
+                              int Cin, int Cout, int Lin, int Lout, hipStream_t st);
 hipError_t launch_instnorm_stats(const float* x, float* stats, int rows, int L, hipStream_t st);
 // C[M][N] = act(A[M][K] . W[N][K]^T + bias) (+ R): fp32 MFMA GEMM (ls_gemm.hip); act 3 = exact GELU
 hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
