@@ -56,6 +56,12 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int MAXU = (NU + kWaves - 1) / kWaves;
     constexpr int kFullTiles = 4;            // token tiles whose 16 rows are all real
     constexpr int NREM = R - 16 * kFullTiles;  // rows of the ragged last tile (6 TED / 8 BEAT)
+    // Ragged rows: scalar FMAs (TED, 6 rows) or v_mfma_f32_4x4x1_16b row groups (BEAT, 8 rows = 2 full groups).
+    // Measured on MI355X: the 4x4x1 MFMA issues in 16 cycles = 16 MAC/cycle, the same rate as a wave64 v_fma_f32,
+    // so it only pays when no group is padded (BEAT 0.898 -> 0.867 ms/step: fewer LDS reads; TED 1.494 -> 1.518).
+    constexpr bool kRemMfma = (NREM % 4 == 0);
+    constexpr int NRG = kRemMfma ? NREM / 4 : 1;   // 4-row groups (MFMA path)
+    constexpr int NRV = kRemMfma ? 1 : NREM;       // rows (VALU path)
     constexpr int NG = (R + 7) / 8;            // 8-row groups of the transposed bf16 operand of token mixing
     constexpr int KS = (R + 31) / 32;          // k steps (32 source rows) of the bf16 token-mix MFMA
     constexpr int kGrpStride = kD * 8 + 16;    // bf16 per 8-row group (+32 B so the two row halves of a tile miss each other's banks)
@@ -507,25 +513,29 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         for (int p = 0; p < 2; ++p) {
             fresh();
             f4 acc[2][kFullTiles];
-            float racc[2][NREM];
+            float racc[2][NRV];
+            f4 racc4[2][NRG];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));   // Linear bias (+ W.beta of LN2)
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = bc;
 #pragma unroll
-                for (int r = 0; r < NREM; ++r) racc[c2][r] = 0.f;
+                for (int r = 0; r < NRV; ++r) racc[c2][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < NRG; ++r) racc4[c2][r] = (f4){0.f, 0.f, 0.f, 0.f};
             }
             gf4p wp = g4(a.W->wch_img) + ((size_t)((l * kWaves + w) * 2 + p) * 32) * 2 * 64 + lane;
             const float* ub = U + s16 * kUStride + 4 * g;                 // tile t: + 16*t*kUStride
-            const float* ur = U + 16 * kFullTiles * kUStride + 4 * g;     // remainder row r: + r*kUStride
+            // VALU path: remainder row r at + r*kUStride (all lanes the same row); MFMA path: lane's row (lane&3) of group rg at + 4*rg*kUStride
+            const float* ur = U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g;
             f4 An[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
             if (!(a.ablate & 1))
 #pragma unroll 2
             for (int q = 0; q < 32; ++q) {
-                f4 A[2], Bv[kFullTiles], Ur[NREM];
+                f4 A[2], Bv[kFullTiles], Ur[kRemMfma ? NRG : NRV];
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
                 {
@@ -537,12 +547,14 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 for (int t = 0; t < kFullTiles; ++t)
                     Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
 #pragma unroll
-                for (int r = 0; r < NREM; ++r) Ur[r] = *reinterpret_cast<const f4*>(ur + r * kUStride + 16 * q);
+                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r)
+                    Ur[r] = *reinterpret_cast<const f4*>(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
                 // Per k: [8 MFMAs][2*NREM scalar FMAs], order pinned.  A/B-tested on MI355X (tools/ab_variants.py, ms/step
                 // at B=512): this 1.513 | [32 MFMA][8*NREM FMA] 1.526 | compiler's own order 1.627 (it hoists the FMAs
                 // next to their ds_reads and stalls) | fine 2:3 interleave 1.646 | 5th MFMA tile instead of FMAs 1.645.
                 // fp32 MFMA and fp32 VALU share the SIMD's FMA lanes on gfx950 (removing the FMAs saves exactly their
-                // issue time), so the gain is the padding saved (6 rows of work instead of 16), not overlap; v_pk_fma_f32
+                // issue time), so the gain is the padding saved (6 rows of work instead of 16), not overlap; v_pk_fma_f32,
+                // v_mfma_f32_4x4x1_16b (16 cycles/issue: 1.518 with rows padded to 8)
                 // and s_setprio alternation between the two waves of a SIMD were measured and do not help.
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -553,9 +565,18 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2)
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        if constexpr (kRemMfma) {
+                            // block (g, n>>2) = {4 channels} x {4 rows} over the lane's own k subset: the A operand is the
+                            // same register the 16x16x4 MFMAs use
 #pragma unroll
-                        for (int r = 0; r < NREM; ++r) racc[c2][r] = fmaf(A[c2][j], Ur[r][j], racc[c2][r]);
+                            for (int r = 0; r < NRG; ++r)
+                                racc4[c2][r] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[c2][j], Ur[r][j], racc4[c2][r], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NRV; ++r) racc[c2][r] = fmaf(A[c2][j], Ur[r][j], racc[c2][r]);
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -563,14 +584,29 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             // remainder rows: sum the 4 k-subsets, then [channel-lane][row] -> [row-lane][channel-reg] through LDS
             float* rem = REM + w * (2 * NREM * 16);
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
+            for (int c2 = 0; c2 < 2; ++c2) {
+                if constexpr (kRemMfma) {
 #pragma unroll
-                for (int r = 0; r < NREM; ++r) {
-                    float v = racc[c2][r];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
-                    if (g == 0) rem[(c2 * NREM + r) * 16 + s16] = v;
+                    for (int r = 0; r < NRG; ++r) {
+                        f4 v = racc4[c2][r];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] += __shfl_xor(v[i], 16);
+                            v[i] += __shfl_xor(v[i], 32);
+                        }
+                        // lane (block = lane>>2, row = lane&3) holds channels 4*(s16>>2)..+3 of row 4r + (lane&3)
+                        if (g == 0) *reinterpret_cast<f4*>(&rem[(c2 * NREM + 4 * r + (lane & 3)) * 16 + 4 * (s16 >> 2)]) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NRV; ++r) {
+                        float v = racc[c2][r];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        if (g == 0) rem[(c2 * NREM + r) * 16 + s16] = v;
+                    }
                 }
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
