@@ -185,6 +185,24 @@ def make_text_features(batch: int, seed: int = SEED_COND + 2000, latent: int = 5
     return _f32(0.3 * _rng(seed).standard_normal((batch, latent)))
 
 
+def make_train_batch(cfg: PathConfig, batch: int, step: int = 0, first_sample: int = 0, total: int | None = None):
+    """Deterministic training batch + the step's random draws, in the reference's draw order
+    (x_start/cond from the data loader, then noise = randn_like(x_start) gaussian_diffusion.py:1281, the mask_cond
+    bernoulli RAG.py:88, eps = randn_like(z_mu) RAG.py:12).  Returns (x_start, y, noise, drop, eps)."""
+    total = batch if total is None else total
+    y = make_cond(cfg, total, seed=SEED_COND + 10 * step)
+    g = _rng(4242 + step)
+    x_start = _f32(0.4 * g.standard_normal((total, cfg.njoints, cfg.nfeats, cfg.nframes)))
+    y["origin_x"] = x_start.copy()                      # train_loop.py:131: 'origin_x': motion.clone()
+    noise = _f32(g.standard_normal(x_start.shape))
+    drop = (g.uniform(size=(total,)) < 0.34).astype(np.float32)
+    drop[0], drop[1 % total] = 1.0, 0.0                 # both mask_cond branches present in every batch
+    eps = _f32(g.standard_normal((total, cfg.latent_dim)))
+    sl = slice(first_sample, first_sample + batch)
+    y = {k: v[sl].copy() for k, v in y.items()}
+    return x_start[sl].copy(), y, noise[sl].copy(), drop[sl].copy(), eps[sl].copy()
+
+
 class NoiseTape:
     """Pre-drawn N(0,1) tape consumed in the reference's draw order:
     ``randn(B,J,F,T)`` once, then per step ``randn_like(B,1,512)`` (cond pass),
