@@ -230,6 +230,59 @@ typedef struct ls_post_config {
 int ls_ted_post(int device, int on_device, int batch, const ls_post_config* c, const float* sample, float* aligned,
                 float* pose, float* angle_diff, unsigned char* beat_mask);
 
+/* ---- training step ----------------------------------------------------------------
+ * One optimisation step of the RAG denoiser as TrainLoop.run_step runs it (scripts/train_utils/train_loop.py:146-186):
+ *   x_t = q_sample(x_start, t, noise)                                  gaussian_diffusion.py:1281-1282
+ *   out = RAG.forward(x_t, t, y) in training mode (mask_cond dropout)  scripts/model/RAG.py:79-133
+ *   loss = huber(x_start, out) + lambda_vel * huber(velocities) + kld_weight * KLD(z_mu, z_logvar)
+ *                                                                      gaussian_diffusion.py:1347-1396, train_loop.py:178
+ *   backward through every parameter, then torch.optim.AdamW           train_loop.py:57-59, fp16_util.py:183-187
+ * The trainer owns fp32 master parameters, gradients and Adam moments as FLAT device arrays with one layout
+ * (ls_train_param_info); gradients are written to a caller-provided device array so that a data-parallel caller can
+ * all-reduce it (RCCL) between ls_train_forward_backward and ls_train_adamw.  Random draws are inputs, in the
+ * reference's order: t, noise = randn_like(x_start), drop = bernoulli(cond_mask_prob) [B], eps = randn_like(z_mu). */
+typedef struct ls_trainer ls_trainer;
+typedef struct ls_train_config {
+    ls_config model;
+    float lambda_vel;         /* 1.0  (parser_util.py:109)            */
+    float kld_weight;         /* 0.01 (train_loop.py:178)             */
+    int32_t diffusion_steps;  /* length of the q_sample tables        */
+    int32_t reserved;
+} ls_train_config;
+typedef struct ls_train_batch {
+    int32_t batch;
+    int32_t on_device;            /* 1: tensor pointers below are device pointers (t stays a HOST pointer) */
+    const float* x_start;         /* [B,J,F,T] motion                                            */
+    const int64_t* t;             /* [B] HOST: diffusion timestep per sample (schedule_sampler)  */
+    const float* noise;           /* [B,J,F,T]                                                   */
+    const float* drop;            /* [B] 1.0 = drop the audio condition for this sample          */
+    const float* eps;             /* [B,512]                                                     */
+    const float* audio_input;     /* [B,audio_len]                                               */
+    const float* origin_x;        /* [B,J,F,T]                                                   */
+    const int64_t* vid_indices;   /* [B]                                                         */
+    const int64_t* emo;           /* [B,T] or NULL (TED)                                         */
+} ls_train_batch;
+typedef struct ls_train_terms { float rot_mse, vel_mse, kld, loss, total; float fwd_ms, bwd_ms, reserved; } ls_train_terms;
+
+int ls_train_create(const ls_train_config* cfg, ls_trainer** out);
+void ls_train_destroy(ls_trainer* h);
+const char* ls_train_last_error(const ls_trainer* h);
+/* q_sample tables of GaussianDiffusion.__init__ (fp64, diffusion_steps entries) and _WrappedModel's timestep map */
+int ls_train_set_schedule(ls_trainer* h, const double* sqrt_alphas_cumprod, const double* sqrt_one_minus_alphas_cumprod,
+                          const int64_t* timestep_map);
+/* parameter table: reference state-dict key, offset and element count inside the flat arrays */
+int ls_train_param_count(const ls_trainer* h);
+int64_t ls_train_flat_size(const ls_trainer* h);
+int ls_train_param_info(const ls_trainer* h, int index, char* key, size_t key_cap, int64_t* offset, int64_t* numel);
+int ls_train_set_weight(ls_trainer* h, const char* key, const float* data, size_t n);   /* host -> master params   */
+int ls_train_get_weight(ls_trainer* h, const char* key, float* out, size_t n);           /* master params -> host   */
+/* forward + loss + backward; grad: DEVICE array of ls_train_flat_size floats, overwritten */
+int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* b, float* grad, ls_train_terms* terms);
+/* AdamW on the master parameters from a DEVICE gradient array; the step counter is the trainer's (starts at 1) */
+int ls_train_adamw(ls_trainer* h, const float* grad, float lr, float beta1, float beta2, float eps, float weight_decay);
+/* debug / test access to a named internal tensor of the last forward ("out" [B,T,JF], "x_t", "audio_feat" ...) */
+int ls_train_read(ls_trainer* h, const char* what, float* out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,10 +78,28 @@ class LsTiming(C.Structure):
                 ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32)]
 
 
+class LsTrainConfig(C.Structure):
+    _fields_ = [("model", LsConfig), ("lambda_vel", C.c_float), ("kld_weight", C.c_float), ("diffusion_steps", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class LsTrainBatch(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("on_device", C.c_int32), ("x_start", C.c_void_p), ("t", C.c_void_p), ("noise", C.c_void_p),
+                ("drop", C.c_void_p), ("eps", C.c_void_p), ("audio_input", C.c_void_p), ("origin_x", C.c_void_p),
+                ("vid_indices", C.c_void_p), ("emo", C.c_void_p)]
+
+
+class LsTrainTerms(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("rot_mse", "vel_mse", "kld", "loss", "total", "fwd_ms", "bwd_ms", "reserved")]
+
+
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
            "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
-           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_ted_post")
+           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_ted_post",
+           "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
+           "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
+           "ls_train_adamw", "ls_train_read")
 
 _lib = None
 
@@ -146,6 +164,21 @@ def load_library(build_if_missing: bool = True):
     lib.ls_sag_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ls_ted_post.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(LsPostConfig), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]
+    lib.ls_train_create.argtypes = [C.POINTER(LsTrainConfig), C.POINTER(C.c_void_p)]
+    lib.ls_train_destroy.argtypes = [C.c_void_p]
+    lib.ls_train_destroy.restype = None
+    lib.ls_train_last_error.argtypes = [C.c_void_p]
+    lib.ls_train_last_error.restype = C.c_char_p
+    lib.ls_train_set_schedule.argtypes = [C.c_void_p, c_f64p, c_f64p, c_i64p]
+    lib.ls_train_param_count.argtypes = [C.c_void_p]
+    lib.ls_train_flat_size.argtypes = [C.c_void_p]
+    lib.ls_train_flat_size.restype = C.c_int64
+    lib.ls_train_param_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, c_i64p, c_i64p]
+    lib.ls_train_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_train_get_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_train_forward_backward.argtypes = [C.c_void_p, C.POINTER(LsTrainBatch), C.c_void_p, C.POINTER(LsTrainTerms)]
+    lib.ls_train_adamw.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+    lib.ls_train_read.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     if lib.ls_abi_version() != 1:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
@@ -428,3 +461,102 @@ class SagEngine:
         self._check(self.lib.ls_sag_decode(self.h, B, int(m.on_device), m.f32(x, (B, self.J, self.F, self.T)),
                                            m.f32(z, (B, self.D)), pmask, pout), "ls_sag_decode")
         return out
+
+
+class Trainer:
+    """ctypes wrapper of the training-step handle (ls_train_*).  Master parameters, gradients and Adam moments are flat
+    device arrays; ``grad`` is a torch CUDA tensor owned by this object so a data-parallel caller can all-reduce it
+    (RCCL) between ``forward_backward`` and ``adamw``."""
+
+    def __init__(self, njoints, nfeats, n_prefix_tokens, audio_len, n_emotions=0, nframes=34, n_pre_seq=4, layers=8,
+                 n_speakers=1400, device=0, diffusion_steps=1000, lambda_vel=1.0, kld_weight=0.01):
+        import torch
+        self.lib = load_library()
+        self.cfg = LsTrainConfig(LsConfig(njoints, nfeats, nframes, n_prefix_tokens, n_pre_seq, 512, layers, audio_len, n_speakers,
+                                          n_emotions, device, 0), lambda_vel, kld_weight, diffusion_steps, 0)
+        self.h = C.c_void_p()
+        rc = self.lib.ls_train_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise EngineError(f"ls_train_create failed ({rc}): {self.lib.ls_train_last_error(None).decode()}")
+        self.J, self.F, self.T, self.device, self.n_prefix = njoints, nfeats, nframes, device, n_prefix_tokens
+        self.params = {}
+        key = C.create_string_buffer(256)
+        off, num = C.c_int64(), C.c_int64()
+        for i in range(self.lib.ls_train_param_count(self.h)):
+            self._check(self.lib.ls_train_param_info(self.h, i, key, 256, C.byref(off), C.byref(num)), "ls_train_param_info")
+            self.params[key.value.decode()] = (int(off.value), int(num.value))
+        self.flat_size = int(self.lib.ls_train_flat_size(self.h))
+        self.grad = torch.zeros(self.flat_size, dtype=torch.float32, device=torch.device("cuda", device))
+        self.shapes = {}
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.ls_train_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.ls_train_last_error(self.h).decode()}")
+
+    def load_state_dict(self, sd: dict):
+        for k, v in sd.items():
+            a = _np32(v)
+            self.shapes[k] = tuple(a.shape)
+            self._check(self.lib.ls_train_set_weight(self.h, k.encode(), a.ctypes.data_as(c_f32p), a.size), f"ls_train_set_weight({k})")
+
+    def state_dict(self) -> dict:
+        out = {}
+        for k, (_, n) in self.params.items():
+            a = np.empty(n, np.float32)
+            self._check(self.lib.ls_train_get_weight(self.h, k.encode(), a.ctypes.data_as(c_f32p), n), f"ls_train_get_weight({k})")
+            out[k] = a.reshape(self.shapes.get(k, (n,)))
+        return out
+
+    def set_schedule(self, sched):
+        """sched: anything with .sqrt_alphas_cumprod, .sqrt_one_minus_alphas_cumprod (fp64) and .timestep_map."""
+        a = np.ascontiguousarray(sched.sqrt_alphas_cumprod, dtype=np.float64)
+        b = np.ascontiguousarray(sched.sqrt_one_minus_alphas_cumprod, dtype=np.float64)
+        m = np.ascontiguousarray(sched.timestep_map, dtype=np.int64)
+        if not (len(a) == len(b) == len(m) == self.cfg.diffusion_steps):
+            raise EngineError("schedule length does not match diffusion_steps")
+        self._check(self.lib.ls_train_set_schedule(self.h, a.ctypes.data_as(c_f64p), b.ctypes.data_as(c_f64p), m.ctypes.data_as(c_i64p)),
+                    "ls_train_set_schedule")
+
+    def forward_backward(self, x_start, t, noise, y: dict, drop, eps) -> dict:
+        """One forward + loss + backward; gradients land in ``self.grad`` (flat, device). Returns the loss terms."""
+        import torch
+        m = _Marshal(self.device, x_start, noise, drop, eps, y["audio_input"], y["origin_x"], y["vid_indices"], y.get("emo"))
+        B = int(x_start.shape[0])
+        xs = (B, self.J, self.F, self.T)
+        tt = np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.int64)
+        assert tt.shape == (B,)
+        tb = LsTrainBatch(B, int(m.on_device), m.f32(x_start, xs), tt.ctypes.data_as(C.c_void_p), m.f32(noise, xs), m.f32(drop, (B,)),
+                          m.f32(np.asarray(eps).reshape(B, 512) if not hasattr(eps, "detach") else eps.reshape(B, 512), (B, 512)),
+                          m.f32(y["audio_input"]), m.f32(y["origin_x"], xs), m.i64(y["vid_indices"], (B,)),
+                          m.i64(y["emo"], (B, self.T)) if self.n_prefix == 2 else None)
+        terms = LsTrainTerms()
+        torch.cuda.current_stream(self.grad.device).synchronize()
+        self._check(self.lib.ls_train_forward_backward(self.h, C.byref(tb), C.c_void_p(self.grad.data_ptr()), C.byref(terms)),
+                    "ls_train_forward_backward")
+        return {n: float(getattr(terms, n)) for n in ("rot_mse", "vel_mse", "kld", "loss", "total", "fwd_ms", "bwd_ms")}
+
+    def grads(self) -> dict:
+        g = self.grad.detach().cpu().numpy()
+        return {k: g[o:o + n].reshape(self.shapes.get(k, (n,))).copy() for k, (o, n) in self.params.items()}
+
+    def adamw(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        import torch
+        torch.cuda.current_stream(self.grad.device).synchronize()     # an all-reduce of self.grad may still be in flight
+        self._check(self.lib.ls_train_adamw(self.h, C.c_void_p(self.grad.data_ptr()), lr, betas[0], betas[1], eps, weight_decay),
+                    "ls_train_adamw")
+
+    def read(self, name: str, shape) -> np.ndarray:
+        a = np.empty(tuple(shape), np.float32)
+        self._check(self.lib.ls_train_read(self.h, name.encode(), a.ctypes.data_as(c_f32p), a.size), f"ls_train_read({name})")
+        return a

@@ -1,0 +1,89 @@
+// Training-step internals: strided GEMM arguments and kernel launchers shared by
+// ls_train_gemm.hip, ls_train_kernels.hip and ls_train_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstddef>
+#include <cstdint>
+
+namespace ls {
+
+// element (r, k) of an operand lives at p[(r / ri) * ro + (r % ri) * rs + (k / ki) * ko + (k % ki) * ks]
+struct GemmOperand {
+    const float* p;
+    int ri; long long ro, rs;
+    int ki; long long ko, ks;
+    int vec;                 // float4 loads along the contiguous index are legal (set by gemm_operand())
+};
+
+struct GemmArgs {
+    GemmOperand A, B;        // C[m][n] = sum_k A(m,k) * B(n,k)
+    float* C;                // element (m, n) at C[(m / cri) * cro + (m % cri) * crs + n * cns]; Cpre and R share the addressing
+    int cri; long long cro, crs, cns;
+    const float* bias;       // [N] or null
+    float* Cpre;             // pre-activation copy or null
+    const float* R;          // residual added after the activation or null
+    int act;                 // 0 none, 1 SiLU
+    int accumulate;          // C += result
+    int M, N, K, kchunk;
+    float* ws;               // split-K workspace
+    size_t ws_floats;
+};
+
+inline GemmOperand gemm_operand(const float* p, int ri, long long ro, long long rs, int ki, long long ko, long long ks, bool kcontig,
+                                int rows, int K) {
+    GemmOperand o{p, ri, ro, rs, ki, ko, ks, 0};
+    const bool aligned = ((uintptr_t)p & 15) == 0;
+    auto m4 = [](long long v) { return (v & 3) == 0; };
+    if (kcontig) o.vec = aligned && ks == 1 && (ki >= K || (m4(ki) && m4(ko))) && m4(rs) && (ri >= rows || m4(ro));
+    else o.vec = aligned && rs == 1 && (ri >= rows || (m4(ri) && m4(ro))) && m4(ks) && (ki >= K || m4(ko));
+    return o;
+}
+// row-major matrix [rows][ld], reduction index contiguous
+inline GemmOperand op_rows(const float* p, long long ld, int rows, int K) { return gemm_operand(p, INT_MAX, 0, ld, INT_MAX, 0, 1, true, rows, K); }
+// the same memory read down its columns: operand row r = matrix column r, reduction index = matrix row
+inline GemmOperand op_cols(const float* p, long long ld, int rows, int K) { return gemm_operand(p, INT_MAX, 0, 1, INT_MAX, 0, ld, false, rows, K); }
+
+hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits, hipStream_t st);
+
+struct TrainDims { int B, S, T, NPRE, JF, KF, KFP, D, L; };   // KF = 2*JF+1+256 input_mapping fan-in, KFP = padded to 4
+
+// ---- forward ----
+hipError_t launch_build_feat_train(const float* x_start, const float* noise, const float* origin_x, const float* c4, const float* drop,
+                                   const float* ca, const float* cb, float* feat, float* x_t, TrainDims d, int n_pre_seq, hipStream_t st);
+hipError_t launch_ln_fwd(const float* xin, const float* emb, int S, float* x1, float* u, float* stats, const float* alpha,
+                         const float* beta, int rows, hipStream_t st);
+hipError_t launch_tokmix_fwd(const float* u, const float* x1, const float* wt, const float* bt, float* a1, float* x2, int B, int S,
+                             hipStream_t st);
+hipError_t launch_style_fwd(const float* mu, const float* lv, const float* eps, const float* emo_w, const int64_t* emo, int emo_stride,
+                            float* x0, float* kld_partial, int B, int S, int NPRE, hipStream_t st);
+hipError_t launch_loss(const float* out, const float* x_start, float* dout, float* partial, TrainDims d, float lambda_vel, hipStream_t st);
+hipError_t launch_finish_terms(const float* loss_partial, int n_loss, const float* kld_partial, int n_kld, float* terms, TrainDims d,
+                               float lambda_vel, float kld_weight, hipStream_t st);
+// ---- backward ----
+hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, float* partial, int rows, int nwaves, hipStream_t st);
+hipError_t launch_ln_bwd(const float* du, const float* x, const float* stats, const float* alpha, float* g, float* partial, int rows,
+                         int nwaves, hipStream_t st);
+hipError_t launch_tokmix_bwd(const float* g, const float* a1, const float* u1, const float* wt, float* du, float* pw, float* pb, int B,
+                             int S, hipStream_t st);
+hipError_t launch_partial_reduce(const float* partial, int n, long long stride, int cols, float* out, int accumulate, hipStream_t st);
+// partial[nblk][cols]; follow with launch_partial_reduce(partial, nblk, cols, cols, ...)
+hipError_t launch_colsum(const float* in, int ri, long long ro, long long rs, int rows, int cols, float* partial, int nblk, hipStream_t st);
+hipError_t launch_tok_sum(const float* g, float* demb, int B, int S, int accumulate, hipStream_t st);
+hipError_t launch_style_bwd(const float* g0, const float* mu, const float* lv, const float* eps, float* dmu, float* dlv, int B, int S,
+                            float kld_weight, hipStream_t st);
+hipError_t launch_scatter_rows(const float* src, long long src_stride, const int64_t* idx, int idx_stride, int n, int cols, float* table,
+                               hipStream_t st);
+hipError_t launch_scale_rows(float* x, const float* drop, int B, int per_sample, hipStream_t st);
+// ---- audio encoder backward ----
+hipError_t launch_im2col(const float* in, const float* stats, float* col, int B, int Cin, int Lin, int Lout, int stride, int pad,
+                         hipStream_t st);
+hipError_t launch_in_bwd(const float* dcol, const float* craw, const float* stats, float* dc, int B, int C, int L, int Lout_next,
+                         hipStream_t st);
+hipError_t launch_rowsum_bcl(const float* dc, float* partial, int B, int C, int L, hipStream_t st);
+hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
+// ---- optimiser ----
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                        float bc1, float bc2, hipStream_t st);
+
+}  // namespace ls

@@ -1,0 +1,571 @@
+// C-ABI of the training step (include/ls_hip.h "training step").
+// Orchestrates the forward (saving activations), the losses, the backward and AdamW on one HIP stream.
+// Layout of the flat parameter / gradient / moment arrays: one entry per reference state-dict key, every entry starts
+// on a 4-float boundary (float4 loads); the padding stays zero in all four arrays.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ls_hip.h"
+#include "ls_internal.h"
+#include "ls_train.h"
+
+using namespace ls;
+
+namespace {
+
+std::string g_train_create_error;
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    float* f() const { return static_cast<float*>(p); }
+};
+
+struct Param { std::string key; int64_t off, n; };
+
+const int kCin[4] = {1, 32, 64, 128}, kCout[4] = {32, 64, 128, 256}, kStride[4] = {5, 6, 6, 6}, kPad[4] = {1600, 0, 0, 0}, kKey[4] = {0, 3, 6, 9};
+constexpr int kSpk = 256, kAud = 256, kNW = 1024;   // kD, kPeRows come from ls_internal.h; kNW: waves of the row-loop kernels
+
+}  // namespace
+
+struct ls_trainer {
+    ls_train_config cfg{};
+    TrainDims d{};
+    int convL[5] = {0, 0, 0, 0, 0};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::string err;
+    std::vector<Param> table;
+    std::map<std::string, int> index;
+    int64_t flat = 0;
+    Buf P, M, V;                         // master params, Adam moments
+    int64_t adam_step = 0;
+    bool have_sched = false;
+    std::vector<double> sac, s1mac;
+    std::vector<int64_t> tmap;
+    Buf pe;
+    // batch-sized buffers
+    int capB = 0;
+    Buf x_start, noise, drop, eps, audio, origin_x, vid, emo, ca, cb, tidx;
+    Buf c[4], st[3], img[4], feat, x_t, zc, mu, lv, pe_rows, pre1, hid, emb, xcur;
+    std::vector<Buf> X1, A1, X2, A2, U1, U2, S1, S2;
+    Buf out, dout, lossp, kldp, terms, G, T1, T2, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dcol, dc[3], ws;
+    size_t ws_floats = 0;
+    int B = 0;
+    bool have_forward = false;
+};
+
+namespace {
+
+int fail(ls_trainer* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_train_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail((h), LS_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+void add_param(ls_trainer* h, const std::string& key, int64_t n) {
+    h->index[key] = (int)h->table.size();
+    h->table.push_back({key, h->flat, n});
+    h->flat += (n + 3) / 4 * 4;
+}
+
+float* P(ls_trainer* h, const std::string& key) { return h->P.f() + h->table[h->index.at(key)].off; }
+float* Gr(ls_trainer* h, float* grad, const std::string& key) { return grad + h->table[h->index.at(key)].off; }
+std::string lk(int l, const char* s) { return "backbone.mlps." + std::to_string(l) + "." + s; }
+std::string ck(int i, const char* s) { return "audio_encoder.feat_extractor." + std::to_string(kKey[i]) + "." + s; }
+
+int ingest(ls_trainer* h, Buf& dst, const void* src, size_t bytes, bool on_device) {
+    HIPCHK(h, dst.ensure(bytes ? bytes : 4));
+    if (bytes) HIPCHK(h, hipMemcpyAsync(dst.p, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    return LS_OK;
+}
+
+int splits_for(int M, int N, int K) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int s = (768 + tiles - 1) / tiles;
+    const int smax = K / 256 > 0 ? K / 256 : 1;
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
+}
+
+GemmArgs gemm(GemmOperand A, GemmOperand B, float* C, long long ldc, int M, int N, int K) {
+    GemmArgs a{};
+    a.A = A; a.B = B; a.C = C;
+    a.cri = INT_MAX; a.cro = 0; a.crs = ldc; a.cns = 1;
+    a.M = M; a.N = N; a.K = K;
+    return a;
+}
+
+// weight gradient: C[n_out][n_in] = sum over rows of dY(:, n_out) * X(:, n_in); split over the row index
+hipError_t wgrad(ls_trainer* h, GemmOperand dy_cols, GemmOperand x_cols, bool a_k, bool b_k, float* C, long long ldc, int M, int N, int K) {
+    GemmArgs a = gemm(dy_cols, x_cols, C, ldc, M, N, K);
+    a.ws = h->ws.f(); a.ws_floats = h->ws_floats;
+    int s = splits_for(M, N, K);
+    while (s > 1 && (size_t)s * M * N > h->ws_floats) --s;
+    return launch_gemm_tr(a, a_k, b_k, s, h->stream);
+}
+
+int ensure_batch(ls_trainer* h, int B) {
+    if (B <= h->capB) return LS_OK;
+    const TrainDims& d0 = h->d;
+    const size_t R = (size_t)B * d0.S, nx = (size_t)B * d0.JF * d0.T;
+    const int* L = h->convL;
+    auto E = [&](Buf& b, size_t floats) { return b.ensure(floats * sizeof(float)); };
+    HIPCHK(h, E(h->x_start, nx)); HIPCHK(h, E(h->noise, nx)); HIPCHK(h, E(h->origin_x, nx)); HIPCHK(h, E(h->x_t, nx));
+    HIPCHK(h, E(h->drop, B)); HIPCHK(h, E(h->eps, (size_t)B * kD)); HIPCHK(h, E(h->audio, (size_t)B * L[0]));
+    HIPCHK(h, h->vid.ensure((size_t)B * 8)); HIPCHK(h, h->emo.ensure((size_t)B * d0.T * 8)); HIPCHK(h, h->tidx.ensure((size_t)B * 8));
+    HIPCHK(h, E(h->ca, B)); HIPCHK(h, E(h->cb, B));
+    for (int i = 0; i < 4; ++i) HIPCHK(h, E(h->c[i], (size_t)B * kCout[i] * L[i + 1]));
+    for (int i = 0; i < 3; ++i) { HIPCHK(h, E(h->st[i], (size_t)B * kCout[i] * 2)); HIPCHK(h, E(h->dc[i], (size_t)B * kCout[i] * L[i + 1])); }
+    HIPCHK(h, E(h->feat, (size_t)B * d0.T * d0.KFP));
+    HIPCHK(h, E(h->zc, (size_t)B * kSpk)); HIPCHK(h, E(h->dzc, (size_t)B * kSpk));
+    for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));
+    for (Buf* b : {&h->xcur, &h->G, &h->T1, &h->T2}) HIPCHK(h, E(*b, R * kD));
+    for (auto* v : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2}) {
+        v->resize(d0.L);
+        for (auto& b : *v) HIPCHK(h, E(b, R * kD));
+    }
+    for (auto* v : {&h->S1, &h->S2}) {
+        v->resize(d0.L);
+        for (auto& b : *v) HIPCHK(h, E(b, R * 2));
+    }
+    HIPCHK(h, E(h->out, (size_t)B * d0.T * d0.JF)); HIPCHK(h, E(h->dout, (size_t)B * d0.T * d0.JF));
+    HIPCHK(h, E(h->lossp, 2 * ((size_t)B * d0.JF / 256 + 2))); HIPCHK(h, E(h->kldp, B)); HIPCHK(h, E(h->terms, 8));
+    HIPCHK(h, E(h->part, (size_t)kNW * 2 * kD + (size_t)B * 128 + 4096 * 512));
+    HIPCHK(h, E(h->pw, (size_t)B * 4 * d0.S * d0.S)); HIPCHK(h, E(h->pb, (size_t)B * 4 * d0.S));
+    HIPCHK(h, E(h->dAf, (size_t)B * d0.T * kAud));
+    const size_t colmax = (size_t)B * L[2] * kCin[1] * 15;      // conv2's im2col is the largest: B*1313*480
+    size_t col0 = (size_t)B * L[1] * 15;
+    HIPCHK(h, E(h->col, colmax > col0 ? colmax : col0)); HIPCHK(h, E(h->dcol, colmax));
+    h->ws_floats = (size_t)48 << 20;
+    HIPCHK(h, E(h->ws, h->ws_floats));
+    h->capB = B;
+    return LS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ls_train_create(const ls_train_config* cfg, ls_trainer** out) {
+    if (!cfg || !out) return fail(nullptr, LS_EINVAL, "ls_train_create: null argument");
+    const ls_config& m = cfg->model;
+    if (m.latent_dim != kD || m.nframes != 34 || m.layers < 1 || m.layers > 16 || (m.n_prefix_tokens != 1 && m.n_prefix_tokens != 2) ||
+        (m.n_prefix_tokens == 2 && m.n_emotions <= 0) || m.njoints <= 0 || m.nfeats <= 0 || m.n_speakers <= 0 || cfg->diffusion_steps <= 0)
+        return fail(nullptr, LS_EUNSUPPORTED, "ls_train_create: unsupported configuration");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, LS_EHIP, "ls_train_create: no HIP device (the training step has no CPU path)");
+    if (m.device < 0 || m.device >= n) return fail(nullptr, LS_EINVAL, "ls_train_create: device %d out of range", m.device);
+    ls_trainer* h = new ls_trainer();
+    h->cfg = *cfg;
+    TrainDims& d = h->d;
+    d.B = 0; d.T = m.nframes; d.NPRE = m.n_prefix_tokens; d.S = d.T + d.NPRE; d.JF = m.njoints * m.nfeats;
+    d.KF = 2 * d.JF + 1 + kAud; d.KFP = (d.KF + 3) / 4 * 4; d.D = kD; d.L = m.layers;
+    h->convL[0] = m.audio_len;
+    for (int i = 0; i < 4; ++i) h->convL[i + 1] = (h->convL[i] + 2 * kPad[i] - 15) / kStride[i] + 1;
+    if (h->convL[4] != d.T) { delete h; return fail(nullptr, LS_EINVAL, "ls_train_create: audio_len %d gives %d audio frames, need %d", m.audio_len, h->convL[4], d.T); }
+    for (int l = 0; l < d.L; ++l) {
+        add_param(h, lk(l, "block1.0.alpha"), kD); add_param(h, lk(l, "block1.0.beta"), kD);
+        add_param(h, lk(l, "block1.1.weight"), (int64_t)d.S * d.S); add_param(h, lk(l, "block1.1.bias"), d.S);
+        add_param(h, lk(l, "block2.0.alpha"), kD); add_param(h, lk(l, "block2.0.beta"), kD);
+        add_param(h, lk(l, "block2.1.weight"), (int64_t)kD * kD); add_param(h, lk(l, "block2.1.bias"), kD);
+    }
+    for (int j : {0, 2}) {
+        add_param(h, "backbone.embed_timestep.time_embed." + std::to_string(j) + ".weight", (int64_t)kD * kD);
+        add_param(h, "backbone.embed_timestep.time_embed." + std::to_string(j) + ".bias", kD);
+    }
+    add_param(h, "input_mapping.weight", (int64_t)kD * d.KF); add_param(h, "input_mapping.bias", kD);
+    add_param(h, "speaker_embedding.weight", (int64_t)m.n_speakers * kSpk);
+    add_param(h, "speaker_mu.weight", (int64_t)kD * kSpk); add_param(h, "speaker_mu.bias", kD);
+    add_param(h, "speaker_logvar.weight", (int64_t)kD * kSpk); add_param(h, "speaker_logvar.bias", kD);
+    for (int i = 0; i < 4; ++i) { add_param(h, ck(i, "weight"), (int64_t)kCout[i] * kCin[i] * 15); add_param(h, ck(i, "bias"), kCout[i]); }
+    add_param(h, "output_process.poseFinal.weight", (int64_t)d.JF * kD); add_param(h, "output_process.poseFinal.bias", d.JF);
+    if (d.NPRE == 2) add_param(h, "emotion_embedding.weight", (int64_t)m.n_emotions * kD);
+
+    auto bail = [&](const char* what, hipError_t e) {
+        fail(nullptr, LS_EHIP, "ls_train_create: %s: %s", what, hipGetErrorString(e));
+        ls_train_destroy(h);
+        return LS_EHIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(m.device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (Buf* b : {&h->P, &h->M, &h->V}) {
+        if ((e = b->ensure((size_t)h->flat * 4)) != hipSuccess) return bail("hipMalloc(params)", e);
+        if ((e = hipMemsetAsync(b->p, 0, (size_t)h->flat * 4, h->stream)) != hipSuccess) return bail("hipMemset", e);
+    }
+    // PositionalEncoding.pe (mlp_module.py:104-116), a buffer, recomputed
+    std::vector<float> pe((size_t)kPeRows * kD);
+    for (int p = 0; p < kPeRows; ++p)
+        for (int i = 0; i < kD / 2; ++i) {
+            const float div = expf((float)(2 * i) * (-logf(10000.0f) / (float)kD));
+            pe[(size_t)p * kD + 2 * i] = sinf((float)p * div);
+            pe[(size_t)p * kD + 2 * i + 1] = cosf((float)p * div);
+        }
+    if ((e = h->pe.ensure(pe.size() * 4)) != hipSuccess) return bail("hipMalloc(pe)", e);
+    if ((e = hipMemcpy(h->pe.p, pe.data(), pe.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(pe)", e);
+    for (int i = 1; i < 4; ++i)
+        if ((e = h->img[i].ensure((size_t)kCout[i] * kCin[i] * 15 * 4)) != hipSuccess) return bail("hipMalloc(img)", e);
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("sync", e);
+    *out = h;
+    return LS_OK;
+}
+
+void ls_train_destroy(ls_trainer* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.model.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo,
+                             &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
+                             &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->T1, &h->T2, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
+                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->col, &h->dcol, &h->ws};
+    for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); }
+    for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
+    for (auto* v : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->S1, &h->S2}) for (auto& b : *v) all.push_back(&b);
+    for (Buf* b : all) b->release();
+    for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* ls_train_last_error(const ls_trainer* h) { return h ? h->err.c_str() : g_train_create_error.c_str(); }
+
+int ls_train_set_schedule(ls_trainer* h, const double* sac, const double* s1mac, const int64_t* tmap) {
+    if (!h || !sac || !s1mac || !tmap) return fail(h, LS_EINVAL, "ls_train_set_schedule: null argument");
+    const int n = h->cfg.diffusion_steps;
+    h->sac.assign(sac, sac + n); h->s1mac.assign(s1mac, s1mac + n); h->tmap.assign(tmap, tmap + n);
+    for (int i = 0; i < n; ++i)
+        if (tmap[i] < 0 || tmap[i] >= kPeRows) return fail(h, LS_EINVAL, "ls_train_set_schedule: timestep_map[%d] = %lld out of range", i, (long long)tmap[i]);
+    h->have_sched = true;
+    return LS_OK;
+}
+
+int ls_train_param_count(const ls_trainer* h) { return h ? (int)h->table.size() : 0; }
+int64_t ls_train_flat_size(const ls_trainer* h) { return h ? h->flat : 0; }
+
+int ls_train_param_info(const ls_trainer* h, int index, char* key, size_t key_cap, int64_t* offset, int64_t* numel) {
+    if (!h || index < 0 || index >= (int)h->table.size()) return LS_EINVAL;
+    const Param& p = h->table[index];
+    if (key && key_cap) { strncpy(key, p.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+    if (offset) *offset = p.off;
+    if (numel) *numel = p.n;
+    return LS_OK;
+}
+
+int ls_train_set_weight(ls_trainer* h, const char* key, const float* data, size_t n) {
+    if (!h || !key || !data) return fail(h, LS_EINVAL, "ls_train_set_weight: null argument");
+    std::string k(key);
+    if (k.size() >= 3 && k.compare(k.size() - 3, 3, ".pe") == 0) return LS_OK;
+    auto it = h->index.find(k);
+    if (it == h->index.end()) return fail(h, LS_EINVAL, "ls_train_set_weight: unexpected key '%s'", key);
+    const Param& p = h->table[it->second];
+    if ((int64_t)n != p.n) return fail(h, LS_EINVAL, "ls_train_set_weight: '%s' has %zu elements, expected %lld", key, n, (long long)p.n);
+    HIPCHK(h, hipSetDevice(h->cfg.model.device));
+    HIPCHK(h, hipMemcpy(h->P.f() + p.off, data, n * 4, hipMemcpyHostToDevice));
+    return LS_OK;
+}
+
+int ls_train_get_weight(ls_trainer* h, const char* key, float* out, size_t n) {
+    if (!h || !key || !out) return fail(h, LS_EINVAL, "ls_train_get_weight: null argument");
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return fail(h, LS_EINVAL, "ls_train_get_weight: unknown key '%s'", key);
+    const Param& p = h->table[it->second];
+    if ((int64_t)n != p.n) return fail(h, LS_EINVAL, "ls_train_get_weight: '%s' has %lld elements, got room for %zu", key, (long long)p.n, n);
+    HIPCHK(h, hipSetDevice(h->cfg.model.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->P.f() + p.off, n * 4, hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
+int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* grad, ls_train_terms* terms) {
+    if (!h || !tb || !grad) return fail(h, LS_EINVAL, "ls_train_forward_backward: null argument");
+    if (!h->have_sched) return fail(h, LS_ESTATE, "ls_train_forward_backward: ls_train_set_schedule has not been called");
+    const int B = tb->batch;
+    if (B <= 0) return fail(h, LS_EINVAL, "ls_train_forward_backward: batch must be positive");
+    if (!tb->x_start || !tb->t || !tb->noise || !tb->drop || !tb->eps || !tb->audio_input || !tb->origin_x || !tb->vid_indices)
+        return fail(h, LS_EINVAL, "ls_train_forward_backward: a required tensor is null");
+    TrainDims d = h->d;
+    d.B = B;
+    if (d.NPRE == 2 && !tb->emo) return fail(h, LS_EINVAL, "ls_train_forward_backward: emo is required for the 2-prefix-token model");
+    HIPCHK(h, hipSetDevice(h->cfg.model.device));
+    int rc = ensure_batch(h, B);
+    if (rc != LS_OK) return rc;
+    hipStream_t st = h->stream;
+    const bool od = tb->on_device != 0;
+    const size_t nx = (size_t)B * d.JF * d.T * 4;
+    const int* L = h->convL;
+    const int S = d.S, T = d.T, R = B * S, BT = B * T, JF = d.JF;
+
+    // ---- host side of q_sample / timestep lookup ----
+    std::vector<float> ca(B), cb(B);
+    std::vector<int64_t> tm(B);
+    for (int b = 0; b < B; ++b) {
+        const int64_t t = tb->t[b];
+        if (t < 0 || t >= h->cfg.diffusion_steps) return fail(h, LS_EINVAL, "ls_train_forward_backward: t[%d] = %lld out of range", b, (long long)t);
+        ca[b] = (float)h->sac[t]; cb[b] = (float)h->s1mac[t]; tm[b] = h->tmap[t];
+    }
+    if ((rc = ingest(h, h->ca, ca.data(), B * 4, false)) || (rc = ingest(h, h->cb, cb.data(), B * 4, false)) ||
+        (rc = ingest(h, h->tidx, tm.data(), B * 8, false)) || (rc = ingest(h, h->x_start, tb->x_start, nx, od)) ||
+        (rc = ingest(h, h->noise, tb->noise, nx, od)) || (rc = ingest(h, h->origin_x, tb->origin_x, nx, od)) ||
+        (rc = ingest(h, h->drop, tb->drop, B * 4, od)) || (rc = ingest(h, h->eps, tb->eps, (size_t)B * kD * 4, od)) ||
+        (rc = ingest(h, h->audio, tb->audio_input, (size_t)B * L[0] * 4, od)) || (rc = ingest(h, h->vid, tb->vid_indices, B * 8, od)))
+        return rc;
+    if (d.NPRE == 2 && (rc = ingest(h, h->emo, tb->emo, (size_t)B * T * 8, od))) return rc;
+    HIPCHK(h, hipStreamSynchronize(st));      // host staging vectors go out of scope below
+    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    HIPCHK(h, hipMemsetAsync(grad, 0, (size_t)h->flat * 4, st));
+
+    // ================= forward =================
+    // WavEncoder (audio_enc.py:9-25): raw conv outputs + InstanceNorm statistics are kept for the backward
+    HIPCHK(h, launch_conv1d(h->audio.f(), nullptr, P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), B, 1, kCout[0], L[0], L[1], kStride[0],
+                            kPad[0], st));
+    HIPCHK(h, launch_instnorm_stats(h->c[0].f(), h->st[0].f(), B * kCout[0], L[1], st));
+    for (int i = 1; i < 4; ++i) {
+        HIPCHK(h, launch_build_conv_img(P(h, ck(i, "weight")), h->img[i].f(), kCin[i], kCout[i], st));
+        HIPCHK(h, launch_conv1d_mfma(h->c[i - 1].f(), h->st[i - 1].f(), h->img[i].f(), P(h, ck(i, "bias")), h->c[i].f(), B, kCin[i], kCout[i], L[i],
+                                     L[i + 1], st));
+        if (i < 3) HIPCHK(h, launch_instnorm_stats(h->c[i].f(), h->st[i].f(), B * kCout[i], L[i + 1], st));
+    }
+    HIPCHK(h, launch_build_feat_train(h->x_start.f(), h->noise.f(), h->origin_x.f(), h->c[3].f(), h->drop.f(), h->ca.f(), h->cb.f(), h->feat.f(),
+                                      h->x_t.f(), d, h->cfg.model.n_pre_seq, st));
+    {   // input_mapping (RAG.py:114) -> frame rows of the token sequence
+        GemmArgs a = gemm(op_rows(h->feat.f(), d.KFP, BT, d.KF), op_rows(P(h, "input_mapping.weight"), d.KF, kD, d.KF),
+                          h->xcur.f() + (size_t)d.NPRE * kD, kD, BT, kD, d.KF);
+        a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
+        a.bias = P(h, "input_mapping.bias");
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    HIPCHK(h, launch_gather_rows(P(h, "speaker_embedding.weight"), reinterpret_cast<const int64_t*>(h->vid.p), h->zc.f(), B, kSpk,
+                                 h->cfg.model.n_speakers, st));
+    for (int k = 0; k < 2; ++k) {
+        GemmArgs a = gemm(op_rows(h->zc.f(), kSpk, B, kSpk), op_rows(P(h, k ? "speaker_logvar.weight" : "speaker_mu.weight"), kSpk, kD, kSpk),
+                          k ? h->lv.f() : h->mu.f(), kD, B, kD, kSpk);
+        a.bias = P(h, k ? "speaker_logvar.bias" : "speaker_mu.bias");
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    HIPCHK(h, launch_style_fwd(h->mu.f(), h->lv.f(), h->eps.f(), d.NPRE == 2 ? P(h, "emotion_embedding.weight") : nullptr,
+                               reinterpret_cast<const int64_t*>(h->emo.p), T, h->xcur.f(), h->kldp.f(), B, S, d.NPRE, st));
+    // TimestepEmbedder (mlp_module.py:123-136)
+    HIPCHK(h, launch_gather_rows(h->pe.f(), reinterpret_cast<const int64_t*>(h->tidx.p), h->pe_rows.f(), B, kD, kPeRows, st));
+    {
+        GemmArgs a = gemm(op_rows(h->pe_rows.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.0.weight"), kD, kD, kD), h->hid.f(),
+                          kD, B, kD, kD);
+        a.bias = P(h, "backbone.embed_timestep.time_embed.0.bias"); a.Cpre = h->pre1.f(); a.act = 1;
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+        GemmArgs b2 = gemm(op_rows(h->hid.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.2.weight"), kD, kD, kD), h->emb.f(), kD,
+                           B, kD, kD);
+        b2.bias = P(h, "backbone.embed_timestep.time_embed.2.bias");
+        HIPCHK(h, launch_gemm_tr(b2, true, true, 1, st));
+    }
+    for (int l = 0; l < d.L; ++l) {   // MLPblock.forward (mlp_module.py:67-74)
+        HIPCHK(h, launch_ln_fwd(h->xcur.f(), h->emb.f(), S, h->X1[l].f(), h->U1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")),
+                                P(h, lk(l, "block1.0.beta")), R, st));
+        HIPCHK(h, launch_tokmix_fwd(h->U1[l].f(), h->X1[l].f(), P(h, lk(l, "block1.1.weight")), P(h, lk(l, "block1.1.bias")), h->A1[l].f(),
+                                    h->X2[l].f(), B, S, st));
+        HIPCHK(h, launch_ln_fwd(h->X2[l].f(), nullptr, S, nullptr, h->U2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")),
+                                P(h, lk(l, "block2.0.beta")), R, st));
+        GemmArgs a = gemm(op_rows(h->U2[l].f(), kD, R, kD), op_rows(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->xcur.f(), kD, R, kD, kD);
+        a.bias = P(h, lk(l, "block2.1.bias")); a.Cpre = h->A2[l].f(); a.act = 1; a.R = h->X2[l].f();
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    {   // OutputProcess.poseFinal on the frame rows (RAG.py:128-129, 205-211)
+        GemmArgs a = gemm(gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
+                          op_rows(P(h, "output_process.poseFinal.weight"), kD, JF, kD), h->out.f(), JF, BT, JF, kD);
+        a.bias = P(h, "output_process.poseFinal.bias");
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    const int nlb = (B * JF + 255) / 256;
+    HIPCHK(h, launch_loss(h->out.f(), h->x_start.f(), h->dout.f(), h->lossp.f(), d, h->cfg.lambda_vel, st));
+    HIPCHK(h, launch_finish_terms(h->lossp.f(), nlb, h->kldp.f(), B, h->terms.f(), d, h->cfg.lambda_vel, h->cfg.kld_weight, st));
+    HIPCHK(h, hipEventRecord(h->ev[1], st));
+
+    // ================= backward =================
+    float* part = h->part.f();
+    auto colsum_to = [&](const float* in, int ri, long long ro, long long rs, int rows, int cols, float* dst) -> hipError_t {
+        int nblk = rows / 64;
+        if (nblk < 1) nblk = 1;
+        if (nblk > 512) nblk = 512;
+        hipError_t e = launch_colsum(in, ri, ro, rs, rows, cols, part, nblk, st);
+        if (e != hipSuccess) return e;
+        return launch_partial_reduce(part, nblk, cols, cols, dst, 0, st);
+    };
+    // poseFinal
+    HIPCHK(h, wgrad(h, op_cols(h->dout.f(), JF, JF, BT), gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, INT_MAX, 0, 1, T, (long long)S * kD, kD, false, kD, BT),
+                    false, false, Gr(h, grad, "output_process.poseFinal.weight"), kD, JF, kD, BT));
+    HIPCHK(h, colsum_to(h->dout.f(), INT_MAX, 0, JF, BT, JF, Gr(h, grad, "output_process.poseFinal.bias")));
+    HIPCHK(h, hipMemsetAsync(h->G.p, 0, (size_t)R * kD * 4, st));
+    {
+        GemmArgs a = gemm(op_rows(h->dout.f(), JF, BT, JF), op_cols(P(h, "output_process.poseFinal.weight"), kD, kD, JF),
+                          h->G.f() + (size_t)d.NPRE * kD, kD, BT, kD, JF);
+        a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+    }
+    for (int l = d.L - 1; l >= 0; --l) {
+        // block2: x3 = x2 + SiLU(LN2(x2) Wch^T + b)
+        HIPCHK(h, launch_silu_bwd_colsum(h->G.f(), h->A2[l].f(), h->T1.f(), part, R, kNW, st));
+        HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, lk(l, "block2.1.bias")), 0, st));
+        HIPCHK(h, wgrad(h, op_cols(h->T1.f(), kD, kD, R), op_cols(h->U2[l].f(), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")), kD,
+                        kD, kD, R));
+        {
+            GemmArgs a = gemm(op_rows(h->T1.f(), kD, R, kD), op_cols(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->T2.f(), kD, R, kD, kD);
+            HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        }
+        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")), h->G.f(), part, R, kNW, st));
+        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
+        HIPCHK(h, launch_partial_reduce(part + kD, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block2.0.beta")), 0, st));
+        // block1: x2 = x1 + SiLU(Wt LN1(x1) + bt)
+        HIPCHK(h, launch_tokmix_bwd(h->G.f(), h->A1[l].f(), h->U1[l].f(), P(h, lk(l, "block1.1.weight")), h->T2.f(), h->pw.f(), h->pb.f(), B, S, st));
+        HIPCHK(h, launch_partial_reduce(h->pw.f(), B * 4, (long long)S * S, S * S, Gr(h, grad, lk(l, "block1.1.weight")), 0, st));
+        HIPCHK(h, launch_partial_reduce(h->pb.f(), B * 4, S, S, Gr(h, grad, lk(l, "block1.1.bias")), 0, st));
+        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")), h->G.f(), part, R, kNW, st));
+        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
+        HIPCHK(h, launch_partial_reduce(part + kD, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block1.0.beta")), 0, st));
+        HIPCHK(h, launch_tok_sum(h->G.f(), h->demb.f(), B, S, l != d.L - 1, st));
+    }
+    // G = d loss / d [style | (emotion) | input_mapping rows]
+    HIPCHK(h, launch_style_bwd(h->G.f(), h->mu.f(), h->lv.f(), h->eps.f(), h->dmu.f(), h->dlv.f(), B, S, h->cfg.kld_weight, st));
+    for (int k = 0; k < 2; ++k) {
+        const float* dz = k ? h->dlv.f() : h->dmu.f();
+        const char* wk = k ? "speaker_logvar.weight" : "speaker_mu.weight";
+        HIPCHK(h, wgrad(h, op_cols(dz, kD, kD, B), op_cols(h->zc.f(), kSpk, kSpk, B), false, false, Gr(h, grad, wk), kSpk, kD, kSpk, B));
+        HIPCHK(h, colsum_to(dz, INT_MAX, 0, kD, B, kD, Gr(h, grad, k ? "speaker_logvar.bias" : "speaker_mu.bias")));
+        GemmArgs a = gemm(op_rows(dz, kD, B, kD), op_cols(P(h, wk), kSpk, kSpk, kD), h->dzc.f(), kSpk, B, kSpk, kD);
+        a.accumulate = k;
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+    }
+    HIPCHK(h, launch_scatter_rows(h->dzc.f(), kSpk, reinterpret_cast<const int64_t*>(h->vid.p), 1, B, kSpk, Gr(h, grad, "speaker_embedding.weight"), st));
+    if (d.NPRE == 2)
+        HIPCHK(h, launch_scatter_rows(h->G.f() + kD, (long long)S * kD, reinterpret_cast<const int64_t*>(h->emo.p), T, B, kD,
+                                      Gr(h, grad, "emotion_embedding.weight"), st));
+    // input_mapping
+    const float* dH = h->G.f() + (size_t)d.NPRE * kD;
+    HIPCHK(h, wgrad(h, gemm_operand(dH, INT_MAX, 0, 1, T, (long long)S * kD, kD, false, kD, BT), op_cols(h->feat.f(), d.KFP, d.KF, BT), false, false,
+                    Gr(h, grad, "input_mapping.weight"), d.KF, kD, d.KF, BT));
+    HIPCHK(h, colsum_to(dH, T, (long long)S * kD, kD, BT, kD, Gr(h, grad, "input_mapping.bias")));
+    {   // d audio features = dH . Win[:, 2JF+1:], then the mask_cond scale
+        GemmArgs a = gemm(gemm_operand(dH, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
+                          gemm_operand(P(h, "input_mapping.weight") + 2 * JF + 1, INT_MAX, 0, 1, INT_MAX, 0, d.KF, false, kAud, kD), h->dAf.f(), kAud,
+                          BT, kAud, kD);
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, launch_scale_rows(h->dAf.f(), h->drop.f(), B, T * kAud, st));
+    }
+    // TimestepEmbedder
+    {
+        const char* w0 = "backbone.embed_timestep.time_embed.0.weight";
+        const char* w2 = "backbone.embed_timestep.time_embed.2.weight";
+        HIPCHK(h, wgrad(h, op_cols(h->demb.f(), kD, kD, B), op_cols(h->hid.f(), kD, kD, B), false, false, Gr(h, grad, w2), kD, kD, kD, B));
+        HIPCHK(h, colsum_to(h->demb.f(), INT_MAX, 0, kD, B, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.2.bias")));
+        GemmArgs a = gemm(op_rows(h->demb.f(), kD, B, kD), op_cols(P(h, w2), kD, kD, kD), h->dhid.f(), kD, B, kD, kD);
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, launch_silu_bwd_colsum(h->dhid.f(), h->pre1.f(), h->dhid.f(), part, B, kNW, st));
+        HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.0.bias"), 0, st));
+        HIPCHK(h, wgrad(h, op_cols(h->dhid.f(), kD, kD, B), op_cols(h->pe_rows.f(), kD, kD, B), false, false, Gr(h, grad, w0), kD, kD, kD, B));
+    }
+    // WavEncoder backward, last layer first.  dC4(b, co, p) = dAf[(b*T + p)][co]
+    {
+        const int W4 = kCin[3] * 15;
+        HIPCHK(h, launch_im2col(h->c[2].f(), h->st[2].f(), h->col.f(), B, kCin[3], L[3], L[4], 6, 0, st));
+        HIPCHK(h, wgrad(h, op_cols(h->dAf.f(), kAud, kAud, BT), op_cols(h->col.f(), W4, W4, BT), false, false, Gr(h, grad, ck(3, "weight")), W4, kAud,
+                        W4, BT));
+        HIPCHK(h, colsum_to(h->dAf.f(), INT_MAX, 0, kAud, BT, kAud, Gr(h, grad, ck(3, "bias"))));
+        GemmArgs a = gemm(op_rows(h->dAf.f(), kAud, BT, kAud), op_cols(P(h, ck(3, "weight")), W4, W4, kAud), h->dcol.f(), W4, BT, W4, kAud);
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, launch_in_bwd(h->dcol.f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), B, kCout[2], L[3], L[4], st));
+    }
+    for (int i = 2; i >= 1; --i) {      // conv3 (i=2), conv2 (i=1): dC_i = dc[i] [B][Cout_i][L_{i+1}]
+        const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15, BP = B * Lo;
+        HIPCHK(h, launch_im2col(h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], L[i], Lo, 6, 0, st));
+        HIPCHK(h, wgrad(h, gemm_operand(h->dc[i].f(), INT_MAX, 0, Lo, Lo, (long long)C * Lo, 1, true, C, BP), op_cols(h->col.f(), W, W, BP), true, false,
+                        Gr(h, grad, ck(i, "weight")), W, C, W, BP));
+        HIPCHK(h, launch_rowsum_bcl(h->dc[i].f(), part, B, C, Lo, st));
+        HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(i, "bias")), 0, st));
+        GemmArgs a = gemm(gemm_operand(h->dc[i].f(), Lo, (long long)C * Lo, 1, INT_MAX, 0, Lo, false, BP, C), op_cols(P(h, ck(i, "weight")), W, W, C),
+                          h->dcol.f(), W, BP, W, C);
+        HIPCHK(h, launch_gemm_tr(a, false, false, 1, st));
+        HIPCHK(h, launch_in_bwd(h->dcol.f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), B, kCout[i - 1], L[i], Lo, st));
+    }
+    {   // conv1: weight / bias gradient only (its input is data)
+        const int C = kCout[0], Lo = L[1], BP = B * Lo;
+        HIPCHK(h, launch_im2col(h->audio.f(), nullptr, h->col.f(), B, 1, L[0], Lo, kStride[0], kPad[0], st));
+        HIPCHK(h, wgrad(h, gemm_operand(h->dc[0].f(), INT_MAX, 0, Lo, Lo, (long long)C * Lo, 1, true, C, BP), op_cols(h->col.f(), 15, 15, BP), true, false,
+                        Gr(h, grad, ck(0, "weight")), 15, C, 15, BP));
+        HIPCHK(h, launch_rowsum_bcl(h->dc[0].f(), part, B, C, Lo, st));
+        HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(0, "bias")), 0, st));
+    }
+    HIPCHK(h, hipEventRecord(h->ev[2], st));
+    float tv[8] = {0};
+    HIPCHK(h, hipMemcpyAsync(tv, h->terms.p, 5 * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->B = B;
+    h->have_forward = true;
+    if (terms) {
+        terms->rot_mse = tv[0]; terms->vel_mse = tv[1]; terms->kld = tv[2]; terms->loss = tv[3]; terms->total = tv[4];
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); terms->fwd_ms = ms;
+        (void)hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); terms->bwd_ms = ms;
+        terms->reserved = 0.f;
+    }
+    return LS_OK;
+}
+
+int ls_train_adamw(ls_trainer* h, const float* grad, float lr, float beta1, float beta2, float eps, float weight_decay) {
+    if (!h || !grad) return fail(h, LS_EINVAL, "ls_train_adamw: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.model.device));
+    h->adam_step += 1;
+    const float bc1 = 1.0f - powf(beta1, (float)h->adam_step), bc2 = 1.0f - powf(beta2, (float)h->adam_step);
+    HIPCHK(h, launch_adamw(h->P.f(), grad, h->M.f(), h->V.f(), (size_t)h->flat, lr, beta1, beta2, eps, weight_decay, bc1, bc2, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LS_OK;
+}
+
+int ls_train_read(ls_trainer* h, const char* what, float* out, size_t n) {
+    if (!h || !what || !out) return fail(h, LS_EINVAL, "ls_train_read: null argument");
+    if (!h->have_forward) return fail(h, LS_ESTATE, "ls_train_read: no forward has run");
+    const TrainDims& d = h->d;
+    const size_t B = (size_t)h->B;
+    const std::string w(what);
+    const float* src = nullptr;
+    size_t need = 0;
+    if (w == "out") { src = h->out.f(); need = B * d.T * d.JF; }
+    else if (w == "x_t") { src = h->x_t.f(); need = B * d.JF * d.T; }
+    else if (w == "audio_feat") { src = h->c[3].f(); need = B * kAud * d.T; }
+    else if (w == "z_mu") { src = h->mu.f(); need = B * kD; }
+    else if (w == "z_logvar") { src = h->lv.f(); need = B * kD; }
+    else if (w == "emb") { src = h->emb.f(); need = B * kD; }
+    else if (w == "x_last") { src = h->xcur.f(); need = B * d.S * kD; }
+    else return fail(h, LS_EINVAL, "ls_train_read: unknown tensor '%s'", what);
+    if (n != need) return fail(h, LS_EINVAL, "ls_train_read: '%s' has %zu elements, buffer has %zu", what, need, n);
+    HIPCHK(h, hipSetDevice(h->cfg.model.device));
+    HIPCHK(h, hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
+}  // extern "C"

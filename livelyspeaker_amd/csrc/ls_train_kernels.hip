@@ -1,0 +1,564 @@
+// Non-GEMM kernels of the training step: q_sample + feature build, LN_spatial forward/backward,
+// token-mixing forward/backward, reparameterisation + KLD, Huber / velocity losses and their gradient, InstanceNorm
+// + LeakyReLU backward of the audio encoder (through an explicit im2col, 288 GB of HBM make the 1.3 GB column buffer a
+// non-issue), deterministic partial-sum reductions (no float atomics), AdamW.  All fp32.  Row kernels give one 64-lane
+// wave a 512-channel row (2 float4 per lane).
+#include "ls_internal.h"
+#include "ls_train.h"
+
+namespace ls {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int kDm = 512;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + expf(-a)); }
+__device__ __forceinline__ float silu_f_(float a) { return a * sigmoidf_(a); }
+__device__ __forceinline__ float silu_grad(float a) {
+    const float s = sigmoidf_(a);
+    return s * (1.0f + a * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// q_sample (gaussian_diffusion.py:240-258) fused into the InputProcess / input_mapping operand (RAG.py:106-114, 184-192):
+// feat[(b,t)][:] = [x_t[b,:,t] | origin_x[b,:,t] (t < n_pre_seq) | bit | conv4[b,:,t] * (1 - drop[b])], zero padded to KFP
+__global__ void k_build_feat_train(const float* __restrict__ x_start, const float* __restrict__ noise,
+                                   const float* __restrict__ origin_x, const float* __restrict__ c4, const float* __restrict__ drop,
+                                   const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ feat,
+                                   float* __restrict__ x_t, TrainDims d, int n_pre_seq) {
+    const int b = blockIdx.x / d.T, t = blockIdx.x % d.T;
+    float* fr = feat + (size_t)blockIdx.x * d.KFP;
+    const float keep = 1.0f - drop[b];
+    for (int j = threadIdx.x; j < d.KFP; j += blockDim.x) {
+        float v = 0.f;
+        if (j < d.JF) {
+            const size_t i = ((size_t)b * d.JF + j) * d.T + t;
+            v = ca[b] * x_start[i] + cb[b] * noise[i];
+            x_t[i] = v;
+        } else if (j < 2 * d.JF) {
+            v = t < n_pre_seq ? origin_x[((size_t)b * d.JF + (j - d.JF)) * d.T + t] : 0.f;
+        } else if (j == 2 * d.JF) {
+            v = t < n_pre_seq ? 1.f : 0.f;
+        } else if (j < d.KF) {
+            v = c4[((size_t)b * 256 + (j - 2 * d.JF - 1)) * d.T + t] * keep;
+        }
+        fr[j] = v;
+    }
+}
+
+hipError_t launch_build_feat_train(const float* x_start, const float* noise, const float* origin_x, const float* c4, const float* drop,
+                                   const float* ca, const float* cb, float* feat, float* x_t, TrainDims d, int n_pre_seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_feat_train, dim3(d.B * d.T), dim3(256), 0, st, x_start, noise, origin_x, c4, drop, ca, cb, feat, x_t, d,
+                       n_pre_seq);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LN_spatial forward (mlp_module.py:21-35), optionally preceded by the timestep-embedding add (MLPblock.forward :68-69)
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ xin, const float* __restrict__ emb, int S,
+                                                float* __restrict__ x1, float* __restrict__ u, float* __restrict__ stats,
+                                                const float* __restrict__ alpha, const float* __restrict__ beta, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f4* xr = reinterpret_cast<const f4*>(xin + (size_t)row * kDm);
+    f4 a = xr[lane], b = xr[64 + lane];
+    if (emb) {
+        const f4* er = reinterpret_cast<const f4*>(emb + (size_t)(row / S) * kDm);
+        a += er[lane];
+        b += er[64 + lane];
+        f4* o = reinterpret_cast<f4*>(x1 + (size_t)row * kDm);
+        o[lane] = a;
+        o[64 + lane] = b;
+    }
+    const float mean = wave_sum((a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3])) * (1.0f / kDm);
+    const f4 da = a - mean, db = b - mean;
+    const float var = wave_sum((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3]) + (db[0] * db[0] + db[1] * db[1]) +
+                               (db[2] * db[2] + db[3] * db[3])) * (1.0f / kDm);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const f4* al = reinterpret_cast<const f4*>(alpha);
+    const f4* be = reinterpret_cast<const f4*>(beta);
+    f4* uo = reinterpret_cast<f4*>(u + (size_t)row * kDm);
+    uo[lane] = da * rstd * al[lane] + be[lane];
+    uo[64 + lane] = db * rstd * al[64 + lane] + be[64 + lane];
+    if (lane == 0) {
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = rstd;
+    }
+}
+
+hipError_t launch_ln_fwd(const float* xin, const float* emb, int S, float* x1, float* u, float* stats, const float* alpha,
+                         const float* beta, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, st, xin, emb, S, x1, u, stats, alpha, beta, rows);
+    return hipGetLastError();
+}
+
+// LN_spatial backward: g[row] += rstd * (gy - mean(gy) - xhat * mean(gy * xhat)), gy = du * alpha; per-wave partial
+// column sums of du*xhat (-> d alpha) and du (-> d beta) in partial[wave][2][512]
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ stats,
+                                                const float* __restrict__ alpha, float* __restrict__ g, float* __restrict__ partial,
+                                                int rows, int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const f4* al = reinterpret_cast<const f4*>(alpha);
+    const f4 al0 = al[lane], al1 = al[64 + lane];
+    f4 sa0 = (f4){0.f, 0.f, 0.f, 0.f}, sa1 = sa0, sb0 = sa0, sb1 = sa0;
+    for (int row = gw; row < rows; row += nwaves) {
+        const f4* dr = reinterpret_cast<const f4*>(du + (size_t)row * kDm);
+        const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * kDm);
+        const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
+        const f4 d0 = dr[lane], d1 = dr[64 + lane];
+        const f4 h0 = (xr[lane] - mean) * rstd, h1 = (xr[64 + lane] - mean) * rstd;
+        const f4 y0 = d0 * al0, y1 = d1 * al1;
+        const float m1 = wave_sum((y0[0] + y0[1]) + (y0[2] + y0[3]) + (y1[0] + y1[1]) + (y1[2] + y1[3])) * (1.0f / kDm);
+        const f4 p0 = y0 * h0, p1 = y1 * h1;
+        const float m2 = wave_sum((p0[0] + p0[1]) + (p0[2] + p0[3]) + (p1[0] + p1[1]) + (p1[2] + p1[3])) * (1.0f / kDm);
+        f4* gr = reinterpret_cast<f4*>(g + (size_t)row * kDm);
+        gr[lane] += (y0 - m1 - h0 * m2) * rstd;
+        gr[64 + lane] += (y1 - m1 - h1 * m2) * rstd;
+        sa0 += d0 * h0; sa1 += d1 * h1;
+        sb0 += d0; sb1 += d1;
+    }
+    f4* po = reinterpret_cast<f4*>(partial + (size_t)gw * 2 * kDm);
+    po[lane] = sa0; po[64 + lane] = sa1;
+    po[128 + lane] = sb0; po[192 + lane] = sb1;
+}
+
+hipError_t launch_ln_bwd(const float* du, const float* x, const float* stats, const float* alpha, float* g, float* partial, int rows,
+                         int nwaves, hipStream_t st) {
+    hipLaunchKernelGGL(k_ln_bwd, dim3(nwaves / 4), dim3(256), 0, st, du, x, stats, alpha, g, partial, rows, nwaves);
+    return hipGetLastError();
+}
+
+// da = g * silu'(apre); per-wave partial column sums of da in partial[wave][512] (-> bias gradient)
+__global__ __launch_bounds__(256) void k_silu_bwd_colsum(const float* __restrict__ g, const float* __restrict__ apre,
+                                                         float* __restrict__ da, float* __restrict__ partial, int rows, int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    for (int row = gw; row < rows; row += nwaves) {
+        const f4* gr = reinterpret_cast<const f4*>(g + (size_t)row * kDm);
+        const f4* ar = reinterpret_cast<const f4*>(apre + (size_t)row * kDm);
+        f4 d0 = gr[lane], d1 = gr[64 + lane];
+        const f4 a0 = ar[lane], a1 = ar[64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d0[e] *= silu_grad(a0[e]);
+            d1[e] *= silu_grad(a1[e]);
+        }
+        f4* o = reinterpret_cast<f4*>(da + (size_t)row * kDm);
+        o[lane] = d0; o[64 + lane] = d1;
+        s0 += d0; s1 += d1;
+    }
+    f4* po = reinterpret_cast<f4*>(partial + (size_t)gw * kDm);
+    po[lane] = s0; po[64 + lane] = s1;
+}
+
+hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, float* partial, int rows, int nwaves, hipStream_t st) {
+    hipLaunchKernelGGL(k_silu_bwd_colsum, dim3(nwaves / 4), dim3(256), 0, st, g, apre, da, partial, rows, nwaves);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Token mixing (Conv1d(S,S,1) over the token axis, mlp_module.py:51-55): a1[b][s'][c] = bt[s'] + sum_s wt[s'][s] u[b][s][c];
+// x2 = x1 + SiLU(a1).  Workgroup = (sample, 128-channel slab).
+constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36;
+
+__global__ __launch_bounds__(256) void k_tokmix_fwd(const float* __restrict__ u, const float* __restrict__ x1, const float* __restrict__ wt,
+                                                    const float* __restrict__ bt, float* __restrict__ a1, float* __restrict__ x2, int S) {
+    __shared__ float us[kTokMaxS * kTokLd];
+    __shared__ float ws[kTokMaxS * kTokMaxS];
+    const int b = blockIdx.x, c0 = blockIdx.y * kTokC, tid = threadIdx.x;
+    for (int i = tid; i < S * kTokC; i += 256) us[(i / kTokC) * kTokLd + (i % kTokC)] = u[((size_t)b * S + i / kTokC) * kDm + c0 + (i % kTokC)];
+    for (int i = tid; i < S * S; i += 256) ws[i] = wt[i];
+    __syncthreads();
+    const int c = tid & (kTokC - 1);
+    for (int sp = tid >> 7; sp < S; sp += 2) {
+        float acc = bt[sp];
+        for (int s = 0; s < S; ++s) acc = fmaf(ws[sp * S + s], us[s * kTokLd + c], acc);
+        const size_t o = ((size_t)b * S + sp) * kDm + c0 + c;
+        a1[o] = acc;
+        x2[o] = x1[o] + silu_f_(acc);
+    }
+}
+
+hipError_t launch_tokmix_fwd(const float* u, const float* x1, const float* wt, const float* bt, float* a1, float* x2, int B, int S,
+                             hipStream_t st) {
+    if (S > kTokMaxS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tokmix_fwd, dim3(B, kDm / kTokC), dim3(256), 0, st, u, x1, wt, bt, a1, x2, S);
+    return hipGetLastError();
+}
+
+// backward: da = g * silu'(a1); du[b][s][c] = sum_s' wt[s'][s] da[s'][c]; per-workgroup partials
+// pw[(b,slab)][s'][s] = sum_c da[s'][c] u1[s][c], pb[(b,slab)][s'] = sum_c da[s'][c]
+__global__ __launch_bounds__(256) void k_tokmix_bwd(const float* __restrict__ g, const float* __restrict__ a1, const float* __restrict__ u1,
+                                                    const float* __restrict__ wt, float* __restrict__ du, float* __restrict__ pw,
+                                                    float* __restrict__ pb, int S) {
+    __shared__ float das[kTokMaxS * kTokLd];
+    __shared__ float us[kTokMaxS * kTokLd];
+    __shared__ float ws[kTokMaxS * kTokMaxS];
+    const int b = blockIdx.x, c0 = blockIdx.y * kTokC, tid = threadIdx.x;
+    for (int i = tid; i < S * kTokC; i += 256) {
+        const size_t o = ((size_t)b * S + i / kTokC) * kDm + c0 + (i % kTokC);
+        das[(i / kTokC) * kTokLd + (i % kTokC)] = g[o] * silu_grad(a1[o]);
+        us[(i / kTokC) * kTokLd + (i % kTokC)] = u1[o];
+    }
+    for (int i = tid; i < S * S; i += 256) ws[i] = wt[i];
+    __syncthreads();
+    const int c = tid & (kTokC - 1);
+    for (int s = tid >> 7; s < S; s += 2) {
+        float acc = 0.f;
+        for (int sp = 0; sp < S; ++sp) acc = fmaf(ws[sp * S + s], das[sp * kTokLd + c], acc);
+        du[((size_t)b * S + s) * kDm + c0 + c] = acc;
+    }
+    const size_t blk = (size_t)b * gridDim.y + blockIdx.y;
+    for (int o = tid; o < S * S; o += 256) {
+        const int sp = o / S, s = o % S;
+        float acc = 0.f;
+        for (int cc = 0; cc < kTokC; ++cc) acc = fmaf(das[sp * kTokLd + cc], us[s * kTokLd + cc], acc);
+        pw[blk * S * S + o] = acc;
+    }
+    for (int sp = tid; sp < S; sp += 256) {
+        float acc = 0.f;
+        for (int cc = 0; cc < kTokC; ++cc) acc += das[sp * kTokLd + cc];
+        pb[blk * S + sp] = acc;
+    }
+}
+
+hipError_t launch_tokmix_bwd(const float* g, const float* a1, const float* u1, const float* wt, float* du, float* pw, float* pb, int B,
+                             int S, hipStream_t st) {
+    if (S > kTokMaxS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tokmix_bwd, dim3(B, kDm / kTokC), dim3(256), 0, st, g, a1, u1, wt, du, pw, pb, S);
+    return hipGetLastError();
+}
+
+// out[c] (+)= sum_{i<n} partial[i*stride + c], summed in index order (deterministic)
+__global__ void k_partial_reduce(const float* __restrict__ partial, int n, long long stride, int cols, float* __restrict__ out,
+                                 int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        s0 += partial[(size_t)i * stride + c];
+        s1 += partial[(size_t)(i + 1) * stride + c];
+        s2 += partial[(size_t)(i + 2) * stride + c];
+        s3 += partial[(size_t)(i + 3) * stride + c];
+    }
+    for (; i < n; ++i) s0 += partial[(size_t)i * stride + c];
+    const float v = (s0 + s1) + (s2 + s3);
+    out[c] = accumulate ? out[c] + v : v;
+}
+
+hipError_t launch_partial_reduce(const float* partial, int n, long long stride, int cols, float* out, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(k_partial_reduce, dim3((cols + 255) / 256), dim3(256), 0, st, partial, n, stride, cols, out, accumulate);
+    return hipGetLastError();
+}
+
+// Column sums of a row-strided matrix: partial[blk][c] = sum over this block's rows of in[(r / ri) * ro + (r % ri) * rs + c].
+// Block = 64 columns x 4 row lanes; a following k_partial_reduce over blocks finishes the sum in a fixed order.
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ in, int ri, long long ro, long long rs, int rows, int cols,
+                                                float* __restrict__ partial, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + q; r < r1; r += 4) s += in[(size_t)(r / ri) * ro + (size_t)(r % ri) * rs + c];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < cols) partial[(size_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+hipError_t launch_colsum(const float* in, int ri, long long ro, long long rs, int rows, int cols, float* partial, int nblk, hipStream_t st) {
+    const int rpb = (rows + nblk - 1) / nblk;
+    hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64, nblk), dim3(256), 0, st, in, ri, ro, rs, rows, cols, partial, rpb);
+    return hipGetLastError();
+}
+
+// demb[b][c] (+)= sum_s g[b][s][c]   (x = x + emb broadcast over tokens, mlp_module.py:68-69)
+__global__ void k_tok_sum(const float* __restrict__ g, float* __restrict__ demb, int S, int accumulate) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    float s = 0.f;
+    for (int t = 0; t < S; ++t) s += g[((size_t)b * S + t) * kDm + c];
+    const size_t o = (size_t)b * kDm + c;
+    demb[o] = accumulate ? demb[o] + s : s;
+}
+
+hipError_t launch_tok_sum(const float* g, float* demb, int B, int S, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(k_tok_sum, dim3(B), dim3(kDm), 0, st, g, demb, S, accumulate);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// style token = reparameterize(mu, logvar) (RAG.py:10-13, :118-120), optional emotion token (scripts_beat/model/RAG.py:125),
+// and the per-sample sum of (1 + lv - mu^2 - exp(lv)) for the KLD term (gaussian_diffusion.py:1392)
+__global__ __launch_bounds__(512) void k_style_fwd(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                                                   const float* __restrict__ emo_w, const int64_t* __restrict__ emo, int emo_stride,
+                                                   float* __restrict__ x0, float* __restrict__ kld_partial, int S, int NPRE) {
+    __shared__ float red[8];
+    const int b = blockIdx.x, c = threadIdx.x;
+    const size_t i = (size_t)b * kDm + c;
+    const float m = mu[i], l = lv[i];
+    x0[((size_t)b * S) * kDm + c] = m + eps[i] * expf(0.5f * l);
+    if (NPRE == 2) x0[((size_t)b * S + 1) * kDm + c] = emo_w[(size_t)emo[(size_t)b * emo_stride] * kDm + c];
+    float v = wave_sum(1.0f + l - m * m - expf(l));
+    if ((c & 63) == 0) red[c >> 6] = v;
+    __syncthreads();
+    if (c == 0) kld_partial[b] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+hipError_t launch_style_fwd(const float* mu, const float* lv, const float* eps, const float* emo_w, const int64_t* emo, int emo_stride,
+                            float* x0, float* kld_partial, int B, int S, int NPRE, hipStream_t st) {
+    hipLaunchKernelGGL(k_style_fwd, dim3(B), dim3(kDm), 0, st, mu, lv, eps, emo_w, emo, emo_stride, x0, kld_partial, S, NPRE);
+    return hipGetLastError();
+}
+
+// d mu = g0 + kw * mu / (B*512);  d logvar = g0 * eps * 0.5 * exp(0.5 lv) - kw * 0.5 * (1 - exp(lv)) / (B*512)
+__global__ __launch_bounds__(512) void k_style_bwd(const float* __restrict__ g0, const float* __restrict__ mu, const float* __restrict__ lv,
+                                                   const float* __restrict__ eps, float* __restrict__ dmu, float* __restrict__ dlv, int S,
+                                                   float kscale) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const size_t i = (size_t)b * kDm + c;
+    const float gs = g0[((size_t)b * S) * kDm + c];
+    const float l = lv[i];
+    dmu[i] = gs + kscale * mu[i];
+    dlv[i] = gs * eps[i] * 0.5f * expf(0.5f * l) - 0.5f * kscale * (1.0f - expf(l));
+}
+
+hipError_t launch_style_bwd(const float* g0, const float* mu, const float* lv, const float* eps, float* dmu, float* dlv, int B, int S,
+                            float kld_weight, hipStream_t st) {
+    hipLaunchKernelGGL(k_style_bwd, dim3(B), dim3(kDm), 0, st, g0, mu, lv, eps, dmu, dlv, S, kld_weight / ((float)B * kDm));
+    return hipGetLastError();
+}
+
+// table[idx[i]][c] += src[i][c], i in order (deterministic even with repeated indices): embedding gradients
+__global__ void k_scatter_rows(const float* __restrict__ src, long long src_stride, const int64_t* __restrict__ idx, int idx_stride, int n,
+                               int cols, float* __restrict__ table) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int i = 0; i < n; ++i) table[(size_t)idx[(size_t)i * idx_stride] * cols + c] += src[(size_t)i * src_stride + c];
+}
+
+hipError_t launch_scatter_rows(const float* src, long long src_stride, const int64_t* idx, int idx_stride, int n, int cols, float* table,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(k_scatter_rows, dim3((cols + 255) / 256), dim3(256), 0, st, src, src_stride, idx, idx_stride, n, cols, table);
+    return hipGetLastError();
+}
+
+__global__ void k_scale_rows(float* __restrict__ x, const float* __restrict__ drop, int per_sample, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= 1.0f - drop[i / per_sample];
+}
+
+hipError_t launch_scale_rows(float* x, const float* drop, int B, int per_sample, hipStream_t st) {
+    const size_t n = (size_t)B * per_sample;
+    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, drop, per_sample, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// compute_huber on poses and on frame-to-frame velocities (gaussian_diffusion.py:21-24, :1381-1387) and d loss / d out.
+// out / dout: [(b,t)][JF]; x_start: [b][JF][t].  partial[block] = {sum huber(rot), sum huber(vel)} (before * beta / N)
+__global__ __launch_bounds__(256) void k_loss(const float* __restrict__ out, const float* __restrict__ x_start, float* __restrict__ dout,
+                                              float* __restrict__ partial, TrainDims d, float lambda_vel) {
+    __shared__ float red[2][4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float beta = 0.1f, ib = 10.0f;
+    const float in_rot = 1.0f / ((float)d.B * d.JF * d.T), in_vel = lambda_vel / ((float)d.B * d.JF * (d.T - 1));
+    float srot = 0.f, svel = 0.f;
+    if (i < d.B * d.JF) {
+        const int b = i / d.JF, j = i % d.JF;
+        const float* xs = x_start + (size_t)i * d.T;
+        float po = 0.f, px = 0.f, gprev = 0.f;
+        for (int t = 0; t < d.T; ++t) {
+            const size_t oi = ((size_t)b * d.T + t) * d.JF + j;
+            const float o = out[oi], x = xs[t];
+            const float z = (o - x) * ib, az = fabsf(z);
+            srot += az < 1.f ? 0.5f * z * z : az - 0.5f;
+            float gcur = fminf(fmaxf(z, -1.f), 1.f) * in_rot;
+            if (t > 0) {
+                const float zv = ((o - po) - (x - px)) * ib, azv = fabsf(zv);
+                svel += azv < 1.f ? 0.5f * zv * zv : azv - 0.5f;
+                const float gv = fminf(fmaxf(zv, -1.f), 1.f) * in_vel;
+                gcur += gv;
+                gprev -= gv;
+                dout[oi - d.JF] = gprev;
+            }
+            gprev = gcur;
+            po = o; px = x;
+        }
+        dout[((size_t)b * d.T + d.T - 1) * d.JF + j] = gprev;
+    }
+    (void)beta;
+    srot = wave_sum(srot); svel = wave_sum(svel);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = srot; red[1][threadIdx.x >> 6] = svel; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+hipError_t launch_loss(const float* out, const float* x_start, float* dout, float* partial, TrainDims d, float lambda_vel, hipStream_t st) {
+    hipLaunchKernelGGL(k_loss, dim3((d.B * d.JF + 255) / 256), dim3(256), 0, st, out, x_start, dout, partial, d, lambda_vel);
+    return hipGetLastError();
+}
+
+// terms = {rot_mse, vel_mse, kld, loss = rot + lambda_vel*vel, total = loss + kld_weight*kld}  (train_loop.py:178)
+__global__ void k_finish_terms(const float* __restrict__ lp, int n_loss, const float* __restrict__ kp, int n_kld, float* __restrict__ terms,
+                               TrainDims d, float lambda_vel, float kld_weight) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double r = 0.0, v = 0.0, k = 0.0;
+    for (int i = 0; i < n_loss; ++i) { r += lp[2 * i]; v += lp[2 * i + 1]; }
+    for (int i = 0; i < n_kld; ++i) k += kp[i];
+    const float rot = (float)(r * 0.1 / ((double)d.B * d.JF * d.T));
+    const float vel = (float)(v * 0.1 / ((double)d.B * d.JF * (d.T - 1)));
+    const float kld = (float)(-0.5 * k / ((double)d.B * kDm));
+    terms[0] = rot; terms[1] = vel; terms[2] = kld;
+    terms[3] = rot + lambda_vel * vel;
+    terms[4] = terms[3] + kld_weight * kld;
+}
+
+hipError_t launch_finish_terms(const float* loss_partial, int n_loss, const float* kld_partial, int n_kld, float* terms, TrainDims d,
+                               float lambda_vel, float kld_weight, hipStream_t st) {
+    hipLaunchKernelGGL(k_finish_terms, dim3(1), dim3(64), 0, st, loss_partial, n_loss, kld_partial, n_kld, terms, d, lambda_vel, kld_weight);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Audio encoder backward (audio_enc.py:9-20).  col[(b,p)][ci*15+k] = act(in[b][ci][p*stride + k - pad]),
+// act = LeakyReLU(0.3)(InstanceNorm) of the raw previous conv output when stats != null.
+__global__ void k_im2col(const float* __restrict__ in, const float* __restrict__ stats, float* __restrict__ col, int Cin, int Lin, int Lout,
+                         int stride, int pad, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int W = Cin * 15;
+    const int j = (int)(i % W);
+    const size_t bp = i / W;
+    const int p = (int)(bp % Lout), b = (int)(bp / Lout);
+    const int ci = j / 15, k = j % 15;
+    const int x = p * stride + k - pad;
+    float v = 0.f;
+    if (x >= 0 && x < Lin) {
+        const size_t row = (size_t)b * Cin + ci;
+        v = in[row * Lin + x];
+        if (stats) {
+            v = (v - stats[row * 2]) * stats[row * 2 + 1];
+            v = v >= 0.f ? v : 0.3f * v;
+        }
+    }
+    col[i] = v;
+}
+
+hipError_t launch_im2col(const float* in, const float* stats, float* col, int B, int Cin, int Lin, int Lout, int stride, int pad,
+                         hipStream_t st) {
+    const size_t total = (size_t)B * Lout * Cin * 15;
+    hipLaunchKernelGGL(k_im2col, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, stats, col, Cin, Lin, Lout, stride, pad, total);
+    return hipGetLastError();
+}
+
+// One workgroup per (b, c) row of a conv output that feeds InstanceNorm1d + LeakyReLU(0.3) + the next stride-6 conv.
+// dA[x] = sum_{p,k: 6p+k = x} dcol[(b,p)][c*15+k] (col2im gather), dy = dA * lrelu'(y), y = (craw - mean) * rstd,
+// dc = rstd * (dy - mean(dy) - y * mean(dy*y)).
+__global__ __launch_bounds__(256) void k_in_bwd(const float* __restrict__ dcol, const float* __restrict__ craw, const float* __restrict__ stats,
+                                                float* __restrict__ dc, int C, int L, int Lout_next) {
+    __shared__ float red[2][4];
+    const size_t row = blockIdx.x;
+    const int b = (int)(row / C), c = (int)(row % C);
+    const int W = C * 15, tid = threadIdx.x;
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const float* cr = craw + row * L;
+    float* dr = dc + row * L;
+    float s1 = 0.f, s2 = 0.f;
+    for (int x = tid; x < L; x += 256) {
+        int p1 = x / 6;
+        if (p1 > Lout_next - 1) p1 = Lout_next - 1;
+        int p0 = (x - 14 + 5) / 6;
+        if (x - 14 < 0) p0 = 0;
+        float da = 0.f;
+        for (int p = p0; p <= p1; ++p) da += dcol[((size_t)b * Lout_next + p) * W + c * 15 + (x - 6 * p)];
+        const float y = (cr[x] - mean) * rstd;
+        const float dy = y >= 0.f ? da : 0.3f * da;
+        dr[x] = dy;
+        s1 += dy;
+        s2 += dy * y;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    const float m1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)L;
+    const float m2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)L;
+    for (int x = tid; x < L; x += 256) {
+        const float y = (cr[x] - mean) * rstd;
+        dr[x] = rstd * (dr[x] - m1 - y * m2);
+    }
+}
+
+hipError_t launch_in_bwd(const float* dcol, const float* craw, const float* stats, float* dc, int B, int C, int L, int Lout_next,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(k_in_bwd, dim3(B * C), dim3(256), 0, st, dcol, craw, stats, dc, C, L, Lout_next);
+    return hipGetLastError();
+}
+
+// partial[b][c] = sum_x dc[b][c][x]  (-> conv bias gradient after a reduce over b)
+__global__ __launch_bounds__(64) void k_rowsum_bcl(const float* __restrict__ dc, float* __restrict__ partial, int L) {
+    const size_t row = blockIdx.x;
+    float s = 0.f;
+    for (int x = threadIdx.x; x < L; x += 64) s += dc[row * L + x];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) partial[row] = s;
+}
+
+hipError_t launch_rowsum_bcl(const float* dc, float* partial, int B, int C, int L, hipStream_t st) {
+    hipLaunchKernelGGL(k_rowsum_bcl, dim3(B * C), dim3(64), 0, st, dc, partial, L);
+    return hipGetLastError();
+}
+
+// per-lane MFMA operand image of a stride-6 conv weight (layout documented in ls_conv.hip), rebuilt after every optimiser step
+__global__ void k_build_conv_img(const float* __restrict__ w, float* __restrict__ img, int Cin, int Cout) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)Cout * Cin * 15;
+    if (i >= total) return;
+    const int cig = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    size_t r = i >> 8;
+    const int k = (int)(r % 15); r /= 15;
+    const int nchunk = Cin / 16;
+    const int ch = (int)(r % nchunk), ct = (int)(r / nchunk);
+    const int co = 16 * ct + (lane & 15), ci = 16 * ch + 4 * cig + (lane >> 4);
+    img[i] = w[((size_t)co * Cin + ci) * 15 + k];
+}
+
+hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st) {
+    const size_t total = (size_t)Cout * Cin * 15;
+    hipLaunchKernelGGL(k_build_conv_img, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, img, Cin, Cout);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// torch.optim.AdamW (decoupled weight decay, bias-corrected), train_loop.py:57-59
+__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                        float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+}
+
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                        float bc1, float bc2, hipStream_t st) {
+    hipLaunchKernelGGL(k_adamw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+    return hipGetLastError();
+}
+
+}  // namespace ls
