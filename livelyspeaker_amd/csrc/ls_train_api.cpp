@@ -512,11 +512,11 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
         HIPCHK(h, launch_gemm_tr(a, false, false, 1, st));
         HIPCHK(h, launch_in_bwd(h->dcol.f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), B, kCout[i - 1], L[i], Lo, st));
     }
-    {   // conv1: weight / bias gradient only (its input is data)
-        const int C = kCout[0], Lo = L[1], BP = B * Lo;
-        HIPCHK(h, launch_im2col(h->audio.f(), nullptr, h->col.f(), B, 1, L[0], Lo, kStride[0], kPad[0], st));
-        HIPCHK(h, wgrad(h, gemm_operand(h->dc[0].f(), INT_MAX, 0, Lo, Lo, (long long)C * Lo, 1, true, C, BP), op_cols(h->col.f(), 15, 15, BP), true, false,
-                        Gr(h, grad, ck(0, "weight")), 15, C, 15, BP));
+    {   // conv1: weight / bias gradient only (its input is data); partials go to the (now free) column buffer
+        const int C = kCout[0], Lo = L[1];
+        int nchunk = 0;
+        HIPCHK(h, launch_conv1_wgrad(h->dc[0].f(), h->audio.f(), h->col.f(), B, L[0], Lo, kStride[0], kPad[0], &nchunk, st));
+        HIPCHK(h, launch_partial_reduce(h->col.f(), B * nchunk, C * 15, C * 15, Gr(h, grad, ck(0, "weight")), 0, st));
         HIPCHK(h, launch_rowsum_bcl(h->dc[0].f(), part, B, C, Lo, st));
         HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(0, "bias")), 0, st));
     }

@@ -21,48 +21,66 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTM = 128, kTK = 32, kLdK = kTK + 4, kLdR = kTM + 4;
 
-__device__ __forceinline__ size_t op_off(const GemmOperand& o, int r, int k) {
-    return (size_t)(r / o.ri) * o.ro + (size_t)(r % o.ri) * o.rs + (size_t)(k / o.ki) * o.ko + (size_t)(k % o.ki) * o.ks;
+// two-level index -> offset; the single-level case (inner extent INT_MAX) skips the integer division
+__device__ __forceinline__ size_t lvl(int i, int inner, long long so, long long si) {
+    if (inner == INT_MAX) return (size_t)i * si;
+    return (size_t)(i / inner) * so + (size_t)(i % inner) * si;
 }
 
 // Stage a 128 x 32 tile of one operand.  KC: threads adjacent along k (operand is k-contiguous) -> LDS [row][k];
-// otherwise threads adjacent along rows -> LDS [k][row].
+// otherwise threads adjacent along rows -> LDS [k][row].  roff[]: the thread's row offsets, computed once per kernel.
 template <bool KC>
-__device__ __forceinline__ void stage(float* s, const GemmOperand& o, int r0, int R, int k0, int k1, int tid) {
+__device__ __forceinline__ void stage(float* s, const GemmOperand& o, const size_t (&roff)[4], int r0, int R, int k0, int k1, int tid) {
     if (KC) {
-        const bool vec = o.vec;
+        const int c4 = (tid & 7) * 4, k = k0 + c4;
+        size_t koff[4];
+        const bool vec = o.vec && k + 3 < k1;
+        if (vec) koff[0] = lvl(k, o.ki, o.ko, o.ks);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) koff[e] = lvl(k + e, o.ki, o.ko, o.ks);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            const int r = (tid >> 3) + 32 * i;
             f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-            const int k = k0 + c4;
             if (r0 + r < R) {
-                if (vec && k + 3 < k1) v = *reinterpret_cast<const f4*>(o.p + op_off(o, r0 + r, k));
+                if (vec) v = *reinterpret_cast<const f4*>(o.p + roff[i] + koff[0]);
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (k + e < k1) v[e] = o.p[op_off(o, r0 + r, k + e)];
+                    for (int e = 0; e < 4; ++e) if (k + e < k1) v[e] = o.p[roff[i] + koff[e]];
                 }
             }
             *reinterpret_cast<f4*>(&s[r * kLdK + c4]) = v;
         }
     } else {
-        const bool vec = o.vec;
+        const int r4 = (tid & 31) * 4;
+        const bool vec = o.vec && r0 + r4 + 3 < R;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int kk = idx >> 5, r4 = (idx & 31) * 4;
+            const int kk = (tid >> 5) + 8 * i, k = k0 + kk;
             f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-            const int k = k0 + kk;
             if (k < k1) {
-                if (vec && r0 + r4 + 3 < R) v = *reinterpret_cast<const f4*>(o.p + op_off(o, r0 + r4, k));
+                const size_t koff = lvl(k, o.ki, o.ko, o.ks);
+                if (vec) v = *reinterpret_cast<const f4*>(o.p + roff[0] + koff);
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (r0 + r4 + e < R) v[e] = o.p[op_off(o, r0 + r4 + e, k)];
+                    for (int e = 0; e < 4; ++e) if (r0 + r4 + e < R) v[e] = o.p[roff[e] + koff];
                 }
             }
             *reinterpret_cast<f4*>(&s[kk * kLdR + r4]) = v;
         }
+    }
+}
+
+// per-thread row offsets of the tile rows this thread stages (KC: rows (tid>>3) + 32 i; else rows 4 (tid&31) + e)
+template <bool KC>
+__device__ __forceinline__ void row_offsets(const GemmOperand& o, size_t (&roff)[4], int r0, int R, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + (KC ? (tid >> 3) + 32 * i : (tid & 31) * 4 + i);
+        if (r >= R) r = R - 1;
+        roff[i] = lvl(r, o.ri, o.ro, o.rs);
     }
 }
 
@@ -95,10 +113,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tr(const GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    size_t roffA[4], roffB[4];
+    row_offsets<AK>(a.A, roffA, m0, a.M, tid);
+    row_offsets<BK>(a.B, roffB, n0, a.N, tid);
     for (int k0 = kbeg; k0 < kend; k0 += kTK) {
         __syncthreads();
-        stage<AK>(sA, a.A, m0, a.M, k0, kend, tid);
-        stage<BK>(sB, a.B, n0, a.N, k0, kend, tid);
+        stage<AK>(sA, a.A, roffA, m0, a.M, k0, kend, tid);
+        stage<BK>(sB, a.B, roffB, n0, a.N, k0, kend, tid);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < kTK / 16; ++kk) {
@@ -119,25 +140,51 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tr(const GemmArgs a) {
     // lane (m = s16 of m tile j, g) holds n = n0 + wn*64 + 16*i + 4*g + {0..3}
     const bool partial = gridDim.z > 1;
     float* Cz = partial ? a.ws + (size_t)z * a.M * a.N : nullptr;
+    const bool cvec = a.cns == 1 && (a.crs & 3) == 0 && (a.cri == INT_MAX || (a.cro & 3) == 0) && ((uintptr_t)a.C & 15) == 0 &&
+                      (!a.Cpre || ((uintptr_t)a.Cpre & 15) == 0) && (!a.R || ((uintptr_t)a.R & 15) == 0) &&
+                      (!a.bias || ((uintptr_t)a.bias & 15) == 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + 16 * j + s16;
         if (m >= a.M) continue;
+        const size_t crow = partial ? (size_t)m * a.N : lvl(m, a.cri, a.cro, a.crs);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn * 64 + 16 * i + 4 * g;
+            if (n >= a.N) continue;
+            f4 v = acc[i][j];
+            if (partial) {
+                if ((a.N & 3) == 0) *reinterpret_cast<f4*>(&Cz[crow + n]) = v;
+                else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (n + e >= a.N) continue;
-                float v = acc[i][j][e];
-                if (partial) { Cz[(size_t)m * a.N + n + e] = v; continue; }
-                if (a.bias) v += a.bias[n + e];
-                const size_t co = (size_t)(m / a.cri) * a.cro + (size_t)(m % a.cri) * a.crs + (size_t)(n + e) * a.cns;
-                if (a.Cpre) a.Cpre[co] = v;
-                if (a.act == 1) v = v / (1.0f + expf(-v));
-                if (a.R) v += a.R[co];
-                if (a.accumulate) v += a.C[co];
-                a.C[co] = v;
+                    for (int e = 0; e < 4; ++e) if (n + e < a.N) Cz[crow + n + e] = v[e];
+                }
+                continue;
+            }
+            if (cvec && n + 3 < a.N) {
+                const size_t co = crow + n;
+                if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
+                if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co) = v;
+                if (a.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+                }
+                if (a.R) v += *reinterpret_cast<const f4*>(a.R + co);
+                if (a.accumulate) v += *reinterpret_cast<const f4*>(a.C + co);
+                *reinterpret_cast<f4*>(a.C + co) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= a.N) continue;
+                    float x = v[e];
+                    if (a.bias) x += a.bias[n + e];
+                    const size_t co = crow + (size_t)(n + e) * a.cns;
+                    if (a.Cpre) a.Cpre[co] = x;
+                    if (a.act == 1) x = x / (1.0f + expf(-x));
+                    if (a.R) x += a.R[co];
+                    if (a.accumulate) x += a.C[co];
+                    a.C[co] = x;
+                }
             }
         }
     }

@@ -236,26 +236,36 @@ hipError_t launch_tokmix_bwd(const float* g, const float* a1, const float* u1, c
     return hipGetLastError();
 }
 
-// out[c] (+)= sum_{i<n} partial[i*stride + c], summed in index order (deterministic)
-__global__ void k_partial_reduce(const float* __restrict__ partial, int n, long long stride, int cols, float* __restrict__ out,
-                                 int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// out[c] (+)= sum_{i<n} partial[i*stride + c] in a fixed order (deterministic): block = 64 columns x 16 index lanes,
+// lane q sums i = q, q+16, ... with four independent accumulators, the 16 lanes are then combined through LDS in order.
+__global__ __launch_bounds__(1024) void k_partial_reduce(const float* __restrict__ partial, int n, long long stride, int cols,
+                                                         float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-    for (; i + 3 < n; i += 4) {
-        s0 += partial[(size_t)i * stride + c];
-        s1 += partial[(size_t)(i + 1) * stride + c];
-        s2 += partial[(size_t)(i + 2) * stride + c];
-        s3 += partial[(size_t)(i + 3) * stride + c];
+    if (c < cols) {
+        int i = q;
+        for (; i + 48 < n; i += 64) {
+            s0 += partial[(size_t)i * stride + c];
+            s1 += partial[(size_t)(i + 16) * stride + c];
+            s2 += partial[(size_t)(i + 32) * stride + c];
+            s3 += partial[(size_t)(i + 48) * stride + c];
+        }
+        for (; i < n; i += 16) s0 += partial[(size_t)i * stride + c];
     }
-    for (; i < n; ++i) s0 += partial[(size_t)i * stride + c];
-    const float v = (s0 + s1) + (s2 + s3);
-    out[c] = accumulate ? out[c] + v : v;
+    red[q][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && c < cols) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][cl];
+        out[c] = accumulate ? out[c] + v : v;
+    }
 }
 
 hipError_t launch_partial_reduce(const float* partial, int n, long long stride, int cols, float* out, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(k_partial_reduce, dim3((cols + 255) / 256), dim3(256), 0, st, partial, n, stride, cols, out, accumulate);
+    hipLaunchKernelGGL(k_partial_reduce, dim3((cols + 63) / 64), dim3(1024), 0, st, partial, n, stride, cols, out, accumulate);
     return hipGetLastError();
 }
 
@@ -502,6 +512,48 @@ __global__ __launch_bounds__(256) void k_in_bwd(const float* __restrict__ dcol, 
 hipError_t launch_in_bwd(const float* dcol, const float* craw, const float* stats, float* dc, int B, int C, int L, int Lout_next,
                          hipStream_t st) {
     hipLaunchKernelGGL(k_in_bwd, dim3(B * C), dim3(256), 0, st, dcol, craw, stats, dc, C, L, Lout_next);
+    return hipGetLastError();
+}
+
+// conv1 (Cin = 1, k 15, stride 5, pad 1600) weight gradient without an im2col: workgroup = (256-position chunk, sample),
+// thread (co, k) accumulates sum_p dC1[b][co][p] * wav[b][5p + k - 1600] from LDS; partial[(b, chunk)][co*15 + k].
+constexpr int kC1P = 256, kC1Ld = kC1P + 4;
+__global__ __launch_bounds__(512) void k_conv1_wgrad(const float* __restrict__ dc, const float* __restrict__ wav, float* __restrict__ partial,
+                                                     int Lin, int Lout, int stride, int pad) {
+    __shared__ __attribute__((aligned(16))) float dcs[32 * kC1Ld];
+    __shared__ float wavs[kC1P * 5 + 16];
+    const int b = blockIdx.y, p0 = blockIdx.x * kC1P, tid = threadIdx.x;
+    for (int i = tid; i < 32 * kC1P; i += 512) {
+        const int co = i / kC1P, p = i % kC1P;
+        dcs[co * kC1Ld + p] = p0 + p < Lout ? dc[((size_t)b * 32 + co) * Lout + p0 + p] : 0.f;
+    }
+    const int x0 = p0 * stride - pad;
+    for (int i = tid; i < kC1P * 5 + 16; i += 512) {
+        const int x = x0 + i;
+        wavs[i] = (x >= 0 && x < Lin) ? wav[(size_t)b * Lin + x] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 480) {
+        const int co = tid / 15, k = tid % 15;
+        const float* dr = dcs + co * kC1Ld;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int p = 0; p < kC1P; p += 4) {
+            const f4 d = *reinterpret_cast<const f4*>(dr + p);
+            a0 = fmaf(d[0], wavs[5 * p + k], a0);
+            a1 = fmaf(d[1], wavs[5 * p + 5 + k], a1);
+            a2 = fmaf(d[2], wavs[5 * p + 10 + k], a2);
+            a3 = fmaf(d[3], wavs[5 * p + 15 + k], a3);
+        }
+        partial[((size_t)b * gridDim.x + blockIdx.x) * 480 + tid] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+hipError_t launch_conv1_wgrad(const float* dc, const float* wav, float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk,
+                              hipStream_t st) {
+    if (stride != 5) return hipErrorInvalidValue;
+    const int nc = (Lout + kC1P - 1) / kC1P;
+    *nchunk = nc;
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nc, B), dim3(512), 0, st, dc, wav, partial, Lin, Lout, stride, pad);
     return hipGetLastError();
 }
 
