@@ -276,6 +276,11 @@ int64_t ls_train_flat_size(const ls_trainer* h);
 int ls_train_param_info(const ls_trainer* h, int index, char* key, size_t key_cap, int64_t* offset, int64_t* numel);
 int ls_train_set_weight(ls_trainer* h, const char* key, const float* data, size_t n);   /* host -> master params   */
 int ls_train_get_weight(ls_trainer* h, const char* key, float* out, size_t n);           /* master params -> host   */
+/* optimizer state for checkpoint / resume (opt%09d.pt, train_loop.py:222-227): which = 1 exp_avg, 2 exp_avg_sq */
+int ls_train_get_moment(ls_trainer* h, int which, const char* key, float* out, size_t n);
+int ls_train_set_moment(ls_trainer* h, int which, const char* key, const float* data, size_t n);
+int64_t ls_train_get_step(const ls_trainer* h);
+int ls_train_set_step(ls_trainer* h, int64_t step);
 /* forward + loss + backward; grad: DEVICE array of ls_train_flat_size floats, overwritten */
 int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* b, float* grad, ls_train_terms* terms);
 /* AdamW on the master parameters from a DEVICE gradient array; the step counter is the trainer's (starts at 1) */

@@ -99,7 +99,7 @@ EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_ted_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
-           "ls_train_adamw", "ls_train_read")
+           "ls_train_adamw", "ls_train_read", "ls_train_get_moment", "ls_train_set_moment", "ls_train_get_step", "ls_train_set_step")
 
 _lib = None
 
@@ -179,6 +179,11 @@ def load_library(build_if_missing: bool = True):
     lib.ls_train_forward_backward.argtypes = [C.c_void_p, C.POINTER(LsTrainBatch), C.c_void_p, C.POINTER(LsTrainTerms)]
     lib.ls_train_adamw.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.ls_train_read.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_train_get_moment.argtypes = [C.c_void_p, C.c_int, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_train_set_moment.argtypes = [C.c_void_p, C.c_int, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_train_get_step.argtypes = [C.c_void_p]
+    lib.ls_train_get_step.restype = C.c_int64
+    lib.ls_train_set_step.argtypes = [C.c_void_p, C.c_int64]
     if lib.ls_abi_version() != 1:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
@@ -555,6 +560,23 @@ class Trainer:
         torch.cuda.current_stream(self.grad.device).synchronize()     # an all-reduce of self.grad may still be in flight
         self._check(self.lib.ls_train_adamw(self.h, C.c_void_p(self.grad.data_ptr()), lr, betas[0], betas[1], eps, weight_decay),
                     "ls_train_adamw")
+
+    def optimizer_state(self) -> dict:
+        """{'step': int, 'exp_avg': {key: array}, 'exp_avg_sq': {key: array}} (what opt%09d.pt holds, train_loop.py:222-227)."""
+        out = {"step": int(self.lib.ls_train_get_step(self.h)), "exp_avg": {}, "exp_avg_sq": {}}
+        for which, name in ((1, "exp_avg"), (2, "exp_avg_sq")):
+            for k, (_, n) in self.params.items():
+                a = np.empty(n, np.float32)
+                self._check(self.lib.ls_train_get_moment(self.h, which, k.encode(), a.ctypes.data_as(c_f32p), n), "ls_train_get_moment")
+                out[name][k] = a.reshape(self.shapes.get(k, (n,)))
+        return out
+
+    def load_optimizer_state(self, st: dict):
+        for which, name in ((1, "exp_avg"), (2, "exp_avg_sq")):
+            for k, v in st[name].items():
+                a = _np32(v)
+                self._check(self.lib.ls_train_set_moment(self.h, which, k.encode(), a.ctypes.data_as(c_f32p), a.size), "ls_train_set_moment")
+        self._check(self.lib.ls_train_set_step(self.h, int(st["step"])), "ls_train_set_step")
 
     def read(self, name: str, shape) -> np.ndarray:
         a = np.empty(tuple(shape), np.float32)

@@ -305,6 +305,29 @@ int ls_train_get_weight(ls_trainer* h, const char* key, float* out, size_t n) {
     return LS_OK;
 }
 
+static int moment_io(ls_trainer* h, int which, const char* key, float* out, const float* in, size_t n) {
+    if (!h || !key || (!out && !in)) return fail(h, LS_EINVAL, "ls_train_*_moment: null argument");
+    if (which != 1 && which != 2) return fail(h, LS_EINVAL, "ls_train_*_moment: which must be 1 (exp_avg) or 2 (exp_avg_sq)");
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return fail(h, LS_EINVAL, "ls_train_*_moment: unknown key '%s'", key);
+    const Param& p = h->table[it->second];
+    if ((int64_t)n != p.n) return fail(h, LS_EINVAL, "ls_train_*_moment: '%s' has %lld elements, got %zu", key, (long long)p.n, n);
+    HIPCHK(h, hipSetDevice(h->cfg.model.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float* dev = (which == 1 ? h->M.f() : h->V.f()) + p.off;
+    if (out) HIPCHK(h, hipMemcpy(out, dev, n * 4, hipMemcpyDeviceToHost));
+    else HIPCHK(h, hipMemcpy(dev, in, n * 4, hipMemcpyHostToDevice));
+    return LS_OK;
+}
+int ls_train_get_moment(ls_trainer* h, int which, const char* key, float* out, size_t n) { return moment_io(h, which, key, out, nullptr, n); }
+int ls_train_set_moment(ls_trainer* h, int which, const char* key, const float* data, size_t n) { return moment_io(h, which, key, nullptr, data, n); }
+int64_t ls_train_get_step(const ls_trainer* h) { return h ? h->adam_step : 0; }
+int ls_train_set_step(ls_trainer* h, int64_t step) {
+    if (!h || step < 0) return fail(h, LS_EINVAL, "ls_train_set_step: bad argument");
+    h->adam_step = step;
+    return LS_OK;
+}
+
 int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* grad, ls_train_terms* terms) {
     if (!h || !tb || !grad) return fail(h, LS_EINVAL, "ls_train_forward_backward: null argument");
     if (!h->have_sched) return fail(h, LS_ESTATE, "ls_train_forward_backward: ls_train_set_schedule has not been called");

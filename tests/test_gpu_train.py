@@ -123,3 +123,96 @@ def test_train_argument_errors():
         tr.load_state_dict({"not.a.key": np.zeros(3, np.float32)})
     with pytest.raises(_lib.EngineError):
         tr.load_state_dict({"input_mapping.bias": np.zeros(3, np.float32)})              # wrong size
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Host mirror: TrainLoop drop-in (scripts/train_utils/train_loop.py) driving the engine
+def _loop_fixture(tmp_path, steps_data, resume=""):
+    import torch
+    from types import SimpleNamespace
+    from livelyspeaker_amd.model_util import create_model_and_diffusion
+    from livelyspeaker_amd.train_loop import TrainLoop
+    cfg = synth.CONFIGS["ted"]
+    margs = SimpleNamespace(mdm_condm="text", latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1, arch="trans_enc",
+                            emb_trans_dec=False, dataset="humanml", lang_model=None, mlpact="silu", diffusion_steps=1000,
+                            noise_schedule="cosine", sigma_small=True, lambda_vel=1.0, lambda_rcxyz=0.0, lambda_fc=0.0, njoints=9)
+    model, diffusion = create_model_and_diffusion(margs, "")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}, strict=False)
+    model.to("cuda:0")
+    model.train()
+    targs = SimpleNamespace(batch_size=B, lr=1e-4, weight_decay=0.0, lr_anneal_steps=0, log_interval=1000, save_interval=1000,
+                            resume_checkpoint=resume, epochs=1, save_dir=str(tmp_path), overwrite=True, dataset="ted")
+    return cfg, model, diffusion, TrainLoop(targs, None, model, diffusion, steps_data)
+
+
+def _batches(cfg, n, start=0):
+    import torch
+    out = []
+    for s in range(start, start + n):
+        x_start, y, _, _, _ = synth.make_train_batch(cfg, B, s)
+        cond = {"y": {k: torch.from_numpy(v) for k, v in y.items()}}
+        out.append((torch.from_numpy(x_start), cond))
+    return out
+
+
+def test_trainloop_reproduces_oracle_trajectory_with_reference_draw_order():
+    """Seeds -> the loop's own draws (np.random.choice, randn, bernoulli, randn) are replayed for the oracle in the
+    reference's order; losses must agree step by step and the trained weights must land back in the model."""
+    import torch
+    cfg = synth.CONFIGS["ted"]
+    data = _batches(cfg, 3)
+    _, model, diffusion, loop = _loop_fixture("/tmp/ls_train_a", data)
+    np.random.seed(21)
+    torch.manual_seed(21)
+    losses = []
+    for motion, cond in data:
+        loop.run_step(motion, cond)
+        losses.append(loop.last_losses["total"])
+        loop.step += 1
+    # oracle with the same stream
+    oracle = tro.TrainOracle(synth.make_state_dict(cfg), cfg.n_prefix_tokens)
+    np.random.seed(21)
+    torch.manual_seed(21)
+    for i, (motion, cond) in enumerate(_batches(cfg, 3)):
+        t = np.random.choice(1000, size=(B,), p=np.ones(1000) / 1000)
+        noise = torch.randn(tuple(motion.shape)).numpy()
+        drop = torch.bernoulli(torch.ones(B) * 0.1).numpy()
+        eps = torch.randn(B, 1, 512).numpy().reshape(B, 512)
+        y = {k: v.numpy() for k, v in cond["y"].items()}
+        _, ototal, ograds, _ = oracle.forward_backward(motion.numpy(), t, noise, y, drop, eps)
+        oracle.optimizer_step(ograds)
+        assert abs(losses[i] - ototal) <= 1e-4 * max(1.0, abs(ototal)), (i, losses[i], ototal)
+    loop.sync_model()
+    w = model.state_dict()["output_process.poseFinal.weight"].cpu().numpy()
+    assert np.abs(w - oracle.state_dict()["output_process.poseFinal.weight"]).max() < 1e-3
+    assert np.abs(w - synth.make_state_dict(cfg)["output_process.poseFinal.weight"]).max() > 1e-5     # it did train
+
+
+def test_trainloop_checkpoint_resume_is_bit_identical(tmp_path):
+    import torch
+    cfg = synth.CONFIGS["ted"]
+
+    def run(loop, data):
+        for motion, cond in data:
+            loop.run_step(motion, cond)
+            loop.step += 1
+
+    np.random.seed(3); torch.manual_seed(3)
+    _, _, _, full = _loop_fixture(tmp_path / "full", None)
+    run(full, _batches(cfg, 4))
+    ref = full.trainer.state_dict()
+
+    np.random.seed(3); torch.manual_seed(3)
+    _, _, _, first = _loop_fixture(tmp_path / "ck", None)
+    run(first, _batches(cfg, 2))
+    first.save()
+    ck = os.path.join(str(tmp_path / "ck"), "model000000002.pt")
+    assert os.path.exists(ck) and os.path.exists(os.path.join(str(tmp_path / "ck"), "opt000000002.pt"))
+    rng_np, rng_t = np.random.get_state(), torch.get_rng_state()
+    _, _, _, second = _loop_fixture(tmp_path / "ck", None, resume=ck)
+    assert second.resume_step == 2 and second.trainer.optimizer_state()["step"] == 2
+    np.random.set_state(rng_np); torch.set_rng_state(rng_t)
+    run(second, _batches(cfg, 2, start=2))
+    got = second.trainer.state_dict()
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k

@@ -178,3 +178,33 @@ def test_q_sample_matches_tables():
     a = torch.tensor(diff.sqrt_alphas_cumprod[[0, 50, 99]]).float().view(3, 1, 1, 1)
     b = torch.tensor(diff.sqrt_one_minus_alphas_cumprod[[0, 50, 99]]).float().view(3, 1, 1, 1)
     assert torch.equal(got, a * x0 + b * nz)
+
+
+def test_train_abi_struct_sizes_match_header_layout():
+    import ctypes as C
+    from livelyspeaker_amd import _lib
+    # ls_train_config = ls_config (12 x int32) + 2 floats + 2 int32; ls_train_batch = 2 x int32 + 9 pointers; terms = 8 floats
+    assert C.sizeof(_lib.LsTrainConfig) == 12 * 4 + 16
+    assert C.sizeof(_lib.LsTrainBatch) == 8 + 9 * 8
+    assert C.sizeof(_lib.LsTrainTerms) == 32
+    assert _lib.LsTrainBatch.t.offset == 16 and _lib.LsTrainBatch.emo.offset == 72
+
+
+def test_uniform_sampler_replays_numpy_choice_stream():
+    import numpy as np
+    from types import SimpleNamespace
+    from livelyspeaker_amd.resample import create_named_schedule_sampler
+    import pytest
+    s = create_named_schedule_sampler("uniform", SimpleNamespace(num_timesteps=1000))
+    np.random.seed(5)
+    t, w = s.sample(16, "cpu")
+    np.random.seed(5)
+    want = np.random.choice(1000, size=(16,), p=np.ones(1000) / 1000)
+    assert np.array_equal(t.numpy(), want) and float(w.min()) == 1.0 == float(w.max())
+    with pytest.raises(NotImplementedError):
+        create_named_schedule_sampler("loss-second-moment", SimpleNamespace(num_timesteps=10))
+
+
+def test_parse_resume_step_from_filename():
+    from livelyspeaker_amd.train_loop import parse_resume_step_from_filename as f
+    assert f("save/x/model000012345.pt") == 12345 and f("nothing.pt") == 0 and f("modelabc.pt") == 0

@@ -110,3 +110,52 @@ def test_shard_range_properties():
             spans = [shard.shard_range(total, world, r) for r in range(world)]
             assert spans[0][0] == 0 and sum(c for _, c in spans) == total
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+# ---- data-parallel training step: the only real collective of the build ------------------------
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from livelyspeaker_amd import synth
+        from livelyspeaker_amd.train_loop import allreduce_mean_
+        from oracle import train_oracle as tro
+        cfg = synth.TED
+        total = 4
+        per = total // world
+        sd = synth.make_state_dict(cfg)
+        t_all = np.array([0, 999, 321, 77])
+        x, y, noise, drop, eps = synth.make_train_batch(cfg, per, 0, first_sample=rank * per, total=total)
+        oracle = tro.TrainOracle(sd, cfg.n_prefix_tokens)
+        _, loss, grads, _ = oracle.forward_backward(x, t_all[rank * per:(rank + 1) * per], noise, y, drop, eps)
+        keys = sorted(grads)
+        flat = torch.from_numpy(np.concatenate([grads[k].ravel() for k in keys]))
+        allreduce_mean_(flat)                                   # what TrainLoop.forward_backward does with trainer.grad
+        if rank == 0:
+            xf, yf, nf, df, ef = synth.make_train_batch(cfg, total, 0)
+            _, _, gfull, _ = tro.TrainOracle(sd, cfg.n_prefix_tokens).forward_backward(xf, t_all, nf, yf, df, ef)
+            want = np.concatenate([gfull[k].ravel() for k in keys])
+            err = float(np.abs(flat.numpy() - want).max() / np.abs(want).max())
+            q.put(("ok", err))
+        dist.barrier()
+    except Exception as e:                                       # surface the failure instead of hanging the parent
+        q.put(("error", repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_data_parallel_gradient_equals_full_batch_gradient():
+    """Mean of the per-shard gradients (all-reduce / world) == gradient of the full batch: every loss term is a mean
+    over the batch, shards are equal-sized."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, val = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+    assert status == "ok", val
+    assert val < 1e-5, val
