@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3 measurement")
+    ap.add_argument("--train-leg", action="store_true", help="also time the training step (default on at 1 GPU; at N>1 it "
+                    "adds the RCCL gradient all-reduce, the build's only collective)")
+    ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x3_perpass"],
                     help="fp32 = exact (headline); bf16x3 = opt-in split-precision channel mixing")
     return ap.parse_args()
@@ -94,6 +97,58 @@ def cpu_baseline(cfg, args):
                       f"{n_exec} steps; reference-faithful mode (audio encoder re-run 2x/step) {n_f} steps "
                       f"({t_f * 1e3:.1f} ms/step)",
             "reference_faithful_value": round(frames / (n_exec * t_f), 3)}
+
+
+def train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence):
+    """Time TrainLoop.run_step-equivalent work: forward + losses + backward (ls_train_forward_backward), gradient
+    all-reduce over the ranks (RCCL, only when world > 1), AdamW.  Batch per GPU = --batch (reference default 512)."""
+    import numpy as np
+    import torch
+    from livelyspeaker_amd import _lib, synth
+    from livelyspeaker_amd.train_loop import allreduce_mean_
+    B = a.batch
+    tr = _lib.Trainer(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, device=dev.index,
+                      diffusion_steps=1000)
+    tr.load_state_dict({k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if not k.endswith(".pe")})
+    tr.set_schedule(_train_schedule(a))
+    x_start, y, noise, drop, eps = synth.make_train_batch(cfg, B, 0, first_sample=rank * B, total=world * B)
+    tod = lambda v: torch.from_numpy(np.asarray(v)).to(dev)
+    x_start, noise, drop, eps = tod(x_start), tod(noise), tod(drop), tod(eps)
+    y = {k: tod(v) for k, v in y.items()}
+    t = np.random.Generator(np.random.PCG64(rank)).integers(0, 1000, size=(B,))
+    n = 4
+    fwd = bwd = 0.0
+    terms = None
+    for i in range(n + 1):
+        if i == 1:
+            fence()
+            t0 = time.perf_counter()
+        terms = tr.forward_backward(x_start, t, noise, y, drop, eps)
+        allreduce_mean_(tr.grad)
+        tr.adamw()
+        if i >= 1:
+            fwd += terms["fwd_ms"]
+            bwd += terms["bwd_ms"]
+    fence()
+    el = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        el = float(tt.item())
+    tr.close()
+    return {"what": "forward + Huber/velocity/KLD losses + backward + AdamW (ls_train_*), fp32, inputs resident in HBM",
+            "value": round(world * B * n / el, 1), "unit": "samples/s", "ms_per_step": round(el / n * 1e3, 3),
+            "fwd_ms": round(fwd / n, 3), "bwd_ms": round(bwd / n, 3), "batch_per_gpu": B,
+            "gradient_allreduce": "RCCL, 1 bucket of 16 MB, averaged" if world > 1 else "none (1 GPU)",
+            "loss_after": round(terms["total"], 5),
+            "parity": "gradients within 8e-6 (rel. to max|g|) of the reference-pinned oracle, tests/test_gpu_train.py"}
+
+
+def _train_schedule(a):
+    from livelyspeaker_amd.model_util import create_gaussian_diffusion
+    from types import SimpleNamespace
+    return create_gaussian_diffusion(SimpleNamespace(diffusion_steps=1000, noise_schedule="cosine", sigma_small=True, lambda_vel=1.0,
+                                                     lambda_rcxyz=0.0, lambda_fc=0.0), "")
 
 
 def main():
@@ -201,6 +256,14 @@ def main():
                  "note": "opt-in (RAG.precision / ls_set_precision); the headline value above is the exact-fp32 path"}
         model.precision = "fp32"
 
+    # Secondary leg: one optimisation step of the denoiser, data-parallel over the ranks.
+    train = None
+    if (a.train_leg or world == 1) and not a.no_train_leg and a.precision == "fp32":
+        try:
+            train = train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence)
+        except Exception as e:                      # never let the secondary leg take the headline line down
+            train = {"error": repr(e)[:300]}
+
     if rank == 0:
         frames = world * B * cfg.nframes * a.steps
         n_exec = diffusion.num_timesteps - a.skip
@@ -230,6 +293,8 @@ def main():
         }
         if split is not None:
             rec["split_precision"] = split
+        if train is not None:
+            rec["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, a)
         print(json.dumps(rec), flush=True)
