@@ -136,7 +136,22 @@ def train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         el = float(tt.item())
     tr.close()
-    return {"what": "forward + Huber/velocity/KLD losses + backward + AdamW (ls_train_*), fp32, inputs resident in HBM",
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        # the torch-CPU oracle (autograd) on this box's host cores, bounded sample: B=32, 2 steps after one warm-up
+        from oracle import train_oracle as tro
+        nthr = torch.get_num_threads()
+        orc_t = tro.TrainOracle({k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if not k.endswith(".pe")},
+                                cfg.n_prefix_tokens)
+        xs, yy, nz, dr, ep = synth.make_train_batch(cfg, 32, 0)
+        tt0 = np.random.Generator(np.random.PCG64(0)).integers(0, 1000, size=(32,))
+        orc_t.optimizer_step(orc_t.forward_backward(xs, tt0, nz, yy, dr, ep)[2])
+        c0 = time.perf_counter()
+        for _ in range(2):
+            orc_t.optimizer_step(orc_t.forward_backward(xs, tt0, nz, yy, dr, ep)[2])
+        cpu = {"value": round(2 * 32 / (time.perf_counter() - c0), 2), "unit": "samples/s", "cores": nthr, "kind": "port",
+               "sample": "torch-CPU oracle (oracle/train_oracle.py), B=32, 2 steps after 1 warm-up"}
+    return {"cpu_baseline": cpu, "what": "forward + Huber/velocity/KLD losses + backward + AdamW (ls_train_*), fp32, inputs resident in HBM",
             "value": round(world * B * n / el, 1), "unit": "samples/s", "ms_per_step": round(el / n * 1e3, 3),
             "fwd_ms": round(fwd / n, 3), "bwd_ms": round(bwd / n, 3), "batch_per_gpu": B,
             "gradient_allreduce": "RCCL, 1 bucket of 16 MB, averaged" if world > 1 else "none (1 GPU)",
