@@ -288,6 +288,27 @@ int ls_train_adamw(ls_trainer* h, const float* grad, float lr, float beta1, floa
 /* debug / test access to a named internal tensor of the last forward ("out" [B,T,JF], "x_t", "audio_feat" ...) */
 int ls_train_read(ls_trainer* h, const char* what, float* out, size_t n);
 
+/* ---- FGD feature extractor -------------------------------------------------------
+ * EmbeddingNet(...).pose_encoder in eval mode: poses [B, n_frames, pose_dim] -> latent mean [B, base]
+ * (scripts/model/embedding_net.py:41-83, 261-270; BEAT HalfEmbeddingNet scripts_beat/model/motion_autoencoder.py:38-73,
+ * 156-167).  Keys are the auto-encoder checkpoint's ('gen_dict'): pose_encoder.* are used, decoder.* / fc_logvar are
+ * accepted and ignored.  Frechet distance / diversity on the features stay host code (ted_evaluator.py:61-152). */
+typedef struct ls_eval ls_eval;
+typedef struct ls_eval_config {
+    int32_t pose_dim;   /* 27 TED                                   */
+    int32_t n_frames;   /* 34                                       */
+    int32_t base;       /* latent size: 32 TED | vae_length BEAT    */
+    int32_t hidden1;    /* out_net widths: 256, 128 TED | 4*base, 2*base BEAT */
+    int32_t hidden2;
+    int32_t device;
+} ls_eval_config;
+int ls_eval_create(const ls_eval_config* cfg, ls_eval** out);
+void ls_eval_destroy(ls_eval* h);
+const char* ls_eval_last_error(const ls_eval* h);
+int ls_eval_set_weight(ls_eval* h, const char* key, const float* data, size_t n);
+int ls_eval_commit_weights(ls_eval* h);
+int ls_eval_features(ls_eval* h, int batch, int on_device, const float* poses, float* feat);
+
 #ifdef __cplusplus
 }
 #endif

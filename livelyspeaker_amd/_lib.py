@@ -93,13 +93,18 @@ class LsTrainTerms(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("rot_mse", "vel_mse", "kld", "loss", "total", "fwd_ms", "bwd_ms", "reserved")]
 
 
+class LsEvalConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("pose_dim", "n_frames", "base", "hidden1", "hidden2", "device")]
+
+
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
            "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_ted_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
-           "ls_train_adamw", "ls_train_read", "ls_train_get_moment", "ls_train_set_moment", "ls_train_get_step", "ls_train_set_step")
+           "ls_train_adamw", "ls_train_read", "ls_train_get_moment", "ls_train_set_moment", "ls_train_get_step", "ls_train_set_step",
+           "ls_eval_create", "ls_eval_destroy", "ls_eval_last_error", "ls_eval_set_weight", "ls_eval_commit_weights", "ls_eval_features")
 
 _lib = None
 
@@ -184,6 +189,14 @@ def load_library(build_if_missing: bool = True):
     lib.ls_train_get_step.argtypes = [C.c_void_p]
     lib.ls_train_get_step.restype = C.c_int64
     lib.ls_train_set_step.argtypes = [C.c_void_p, C.c_int64]
+    lib.ls_eval_create.argtypes = [C.POINTER(LsEvalConfig), C.POINTER(C.c_void_p)]
+    lib.ls_eval_destroy.argtypes = [C.c_void_p]
+    lib.ls_eval_destroy.restype = None
+    lib.ls_eval_last_error.argtypes = [C.c_void_p]
+    lib.ls_eval_last_error.restype = C.c_char_p
+    lib.ls_eval_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
+    lib.ls_eval_commit_weights.argtypes = [C.c_void_p]
+    lib.ls_eval_features.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     if lib.ls_abi_version() != 1:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
@@ -582,3 +595,44 @@ class Trainer:
         a = np.empty(tuple(shape), np.float32)
         self._check(self.lib.ls_train_read(self.h, name.encode(), a.ctypes.data_as(c_f32p), a.size), f"ls_train_read({name})")
         return a
+
+
+class EvalEngine:
+    """ctypes wrapper of the FGD feature extractor (ls_eval_*): PoseEncoderConv in eval mode on the GPU."""
+
+    def __init__(self, pose_dim=27, n_frames=34, base=32, hidden=(256, 128), device=0):
+        self.lib = load_library()
+        self.cfg = LsEvalConfig(pose_dim, n_frames, base, hidden[0], hidden[1], device)
+        self.h = C.c_void_p()
+        rc = self.lib.ls_eval_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise EngineError(f"ls_eval_create failed ({rc}): {self.lib.ls_eval_last_error(None).decode()}")
+        self.pose_dim, self.T, self.base, self.device = pose_dim, n_frames, base, device
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.ls_eval_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.ls_eval_last_error(self.h).decode()}")
+
+    def load_state_dict(self, sd: dict):
+        for k, v in sd.items():
+            a = _np32(v).ravel()
+            self._check(self.lib.ls_eval_set_weight(self.h, k.encode(), a.ctypes.data_as(c_f32p), a.size), f"ls_eval_set_weight({k})")
+        self._check(self.lib.ls_eval_commit_weights(self.h), "ls_eval_commit_weights")
+
+    def features(self, poses):
+        m = _Marshal(self.device, poses)
+        B = int(poses.shape[0])
+        out, pout = m.out((B, self.base))
+        self._check(self.lib.ls_eval_features(self.h, B, int(m.on_device), m.f32(poses, (B, self.T, self.pose_dim)), pout), "ls_eval_features")
+        return out

@@ -185,6 +185,50 @@ def make_text_features(batch: int, seed: int = SEED_COND + 2000, latent: int = 5
     return _f32(0.3 * _rng(seed).standard_normal((batch, latent)))
 
 
+def make_embedding_net_state_dict(pose_dim: int = 27, base: int = 32, seed: int = SEED_WEIGHTS + 200, hidden=(8, 4)) -> dict:
+    """Pose-encoder part of the FGD auto-encoder under EmbeddingNet's state-dict keys (scripts/model/embedding_net.py:41-66,
+    checkpoint entry 'gen_dict'; hidden = out_net widths in units of base: (8, 4) TED 384-256-128-32, (4, 2) BEAT
+    motion_autoencoder.py:48-56); BatchNorm running statistics are drawn non-trivial so that eval-mode folding is tested."""
+    g = _rng(seed)
+    sd = {}
+
+    def uni(shape, fan_in):
+        b = 2.5 / np.sqrt(fan_in)          # gain > 1 so that features keep O(1) spread through the 8 layers
+        return _f32(g.uniform(-b, b, size=shape))
+
+    def bn(p, n):
+        sd[p + "weight"] = _f32(1.0 + 0.2 * g.standard_normal(n))
+        sd[p + "bias"] = _f32(0.1 * g.standard_normal(n))
+        sd[p + "running_mean"] = _f32(0.2 * g.standard_normal(n))
+        sd[p + "running_var"] = _f32(g.uniform(0.5, 1.5, size=n))
+
+    for i, (cin, cout, k) in enumerate(((pose_dim, base, 3), (base, 2 * base, 3), (2 * base, 2 * base, 4))):
+        sd[f"pose_encoder.net.{i}.0.weight"] = uni((cout, cin, k), cin * k)
+        sd[f"pose_encoder.net.{i}.0.bias"] = uni((cout,), cin * k)
+        bn(f"pose_encoder.net.{i}.1.", cout)
+    sd["pose_encoder.net.3.weight"] = uni((base, 2 * base, 3), 2 * base * 3)
+    sd["pose_encoder.net.3.bias"] = uni((base,), 2 * base * 3)
+    h1, h2 = hidden[0] * base, hidden[1] * base
+    for lin, (fin, fout) in ((0, (12 * base, h1)), (3, (h1, h2)), (6, (h2, base))):
+        sd[f"pose_encoder.out_net.{lin}.weight"] = uni((fout, fin), fin)
+        sd[f"pose_encoder.out_net.{lin}.bias"] = uni((fout,), fin)
+        if lin != 6:
+            bn(f"pose_encoder.out_net.{lin + 1}.", fout)
+    for n in ("fc_mu", "fc_logvar"):
+        sd[f"pose_encoder.{n}.weight"] = uni((base, base), base)
+        sd[f"pose_encoder.{n}.bias"] = uni((base,), base)
+    return sd
+
+
+def make_pose_sets(n: int, pose_dim: int = 27, nframes: int = 34, seed: int = SEED_COND + 3000):
+    """(generated, real) pose clips [n, nframes, pose_dim] for the evaluator: real ~ smooth random walks, generated = real +
+    perturbation, so the Frechet distance is finite and non-trivial."""
+    g = _rng(seed)
+    real = _f32(np.cumsum(0.15 * g.standard_normal((n, nframes, pose_dim)), axis=1))
+    gen = _f32(0.7 * real + 0.3 * g.standard_normal((n, nframes, pose_dim)) + 0.2)
+    return gen, real
+
+
 def make_train_batch(cfg: PathConfig, batch: int, step: int = 0, first_sample: int = 0, total: int | None = None):
     """Deterministic training batch + the step's random draws, in the reference's draw order
     (x_start/cond from the data loader, then noise = randn_like(x_start) gaussian_diffusion.py:1281, the mask_cond
