@@ -8,6 +8,7 @@
 // decides how threads are laid over the tile when it is staged (coalesced global reads) and how it sits in LDS:
 //   K-contiguous operand: LDS [row][k] (stride 36), MFMA operand = one ds_read_b128;
 //   row-contiguous operand: LDS [k][row] (stride 132), staged with float4 writes, MFMA operand = 4 ds_read_b32.
+// The next K tile is fetched into registers while the current one is multiplied (software pipelining).
 // v_mfma_f32_16x16x4_f32, 128x128 tile / 256 threads, K chunk 32, same transposed accumulator form as ls_gemm.hip.
 // Split-K (gridDim.z > 1) writes partial tiles to a workspace which k_splitk_reduce sums in a fixed order
 // (deterministic: no float atomics anywhere in the training step).
@@ -27,10 +28,11 @@ __device__ __forceinline__ size_t lvl(int i, int inner, long long so, long long 
     return (size_t)(i / inner) * so + (size_t)(i % inner) * si;
 }
 
-// Stage a 128 x 32 tile of one operand.  KC: threads adjacent along k (operand is k-contiguous) -> LDS [row][k];
-// otherwise threads adjacent along rows -> LDS [k][row].  roff[]: the thread's row offsets, computed once per kernel.
+// Fetch this thread's share of a 128 x 32 operand tile into registers (global loads only; they stay in flight while the
+// previous tile is multiplied).  KC: threads adjacent along k (operand is k-contiguous); otherwise adjacent along rows.
+// roff[]: the thread's row offsets, computed once per kernel.
 template <bool KC>
-__device__ __forceinline__ void stage(float* s, const GemmOperand& o, const size_t (&roff)[4], int r0, int R, int k0, int k1, int tid) {
+__device__ __forceinline__ void fetch(f4 (&v)[4], const GemmOperand& o, const size_t (&roff)[4], int r0, int R, int k0, int k1, int tid) {
     if (KC) {
         const int c4 = (tid & 7) * 4, k = k0 + c4;
         size_t koff[4];
@@ -43,33 +45,41 @@ __device__ __forceinline__ void stage(float* s, const GemmOperand& o, const size
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (tid >> 3) + 32 * i;
-            f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+            v[i] = (f4){0.f, 0.f, 0.f, 0.f};
             if (r0 + r < R) {
-                if (vec) v = *reinterpret_cast<const f4*>(o.p + roff[i] + koff[0]);
+                if (vec) v[i] = *reinterpret_cast<const f4*>(o.p + roff[i] + koff[0]);
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (k + e < k1) v[e] = o.p[roff[i] + koff[e]];
+                    for (int e = 0; e < 4; ++e) if (k + e < k1) v[i][e] = o.p[roff[i] + koff[e]];
                 }
             }
-            *reinterpret_cast<f4*>(&s[r * kLdK + c4]) = v;
         }
     } else {
         const int r4 = (tid & 31) * 4;
         const bool vec = o.vec && r0 + r4 + 3 < R;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kk = (tid >> 5) + 8 * i, k = k0 + kk;
-            f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+            const int k = k0 + (tid >> 5) + 8 * i;
+            v[i] = (f4){0.f, 0.f, 0.f, 0.f};
             if (k < k1) {
                 const size_t koff = lvl(k, o.ki, o.ko, o.ks);
-                if (vec) v = *reinterpret_cast<const f4*>(o.p + roff[0] + koff);
+                if (vec) v[i] = *reinterpret_cast<const f4*>(o.p + roff[0] + koff);
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (r0 + r4 + e < R) v[e] = o.p[roff[e] + koff];
+                    for (int e = 0; e < 4; ++e) if (r0 + r4 + e < R) v[i][e] = o.p[roff[e] + koff];
                 }
             }
-            *reinterpret_cast<f4*>(&s[kk * kLdR + r4]) = v;
         }
+    }
+}
+
+// registers -> LDS: K-contiguous operands as [row][k] (stride 36), row-contiguous ones as [k][row] (stride 132)
+template <bool KC>
+__device__ __forceinline__ void put(float* s, const f4 (&v)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (KC) *reinterpret_cast<f4*>(&s[((tid >> 3) + 32 * i) * kLdK + (tid & 7) * 4]) = v[i];
+        else *reinterpret_cast<f4*>(&s[((tid >> 5) + 8 * i) * kLdR + (tid & 31) * 4]) = v[i];
     }
 }
 
@@ -94,7 +104,7 @@ __device__ __forceinline__ f4 frag(const float* s, int row, int kk, int g) {
 }
 
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void k_gemm_tr(const GemmArgs a) {
+__global__ __launch_bounds__(256, 3) void k_gemm_tr(const GemmArgs a) {
     constexpr int SA = AK ? kTM * kLdK : kTK * kLdR;
     constexpr int SB = BK ? kTM * kLdK : kTK * kLdR;
     __shared__ __attribute__((aligned(16))) float sA[SA];
@@ -116,25 +126,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tr(const GemmArgs a) {
     size_t roffA[4], roffB[4];
     row_offsets<AK>(a.A, roffA, m0, a.M, tid);
     row_offsets<BK>(a.B, roffB, n0, a.N, tid);
+    f4 ra[4], rb[4];
+    fetch<AK>(ra, a.A, roffA, m0, a.M, kbeg, kend, tid);
+    fetch<BK>(rb, a.B, roffB, n0, a.N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += kTK) {
         __syncthreads();
-        stage<AK>(sA, a.A, roffA, m0, a.M, k0, kend, tid);
-        stage<BK>(sB, a.B, roffB, n0, a.N, k0, kend, tid);
+        put<AK>(sA, ra, tid);
+        put<BK>(sB, rb, tid);
         __syncthreads();
+        if (k0 + kTK < kend) {              // next tile's global loads overlap this tile's MFMAs
+            fetch<AK>(ra, a.A, roffA, m0, a.M, k0 + kTK, kend, tid);
+            fetch<BK>(rb, a.B, roffB, n0, a.N, k0 + kTK, kend, tid);
+        }
 #pragma unroll
         for (int kk = 0; kk < kTK / 16; ++kk) {
-            f4 bf[4], af[4];
+            f4 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf[i] = frag<BK>(sB, wn * 64 + 16 * i + s16, kk, g);
-                af[i] = frag<AK>(sA, wm * 64 + 16 * i + s16, kk, g);
+            for (int j = 0; j < 4; ++j) af[j] = frag<AK>(sA, wm * 64 + 16 * j + s16, kk, g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {       // one B fragment live at a time keeps the kernel at 3 waves / SIMD
+                const f4 bf = frag<BK>(sB, wn * 64 + 16 * i + s16, kk, g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(bf[e], af[j][e], acc[i][j]);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(bf[i][e], af[j][e], acc[i][j]);
         }
     }
     // lane (m = s16 of m tile j, g) holds n = n0 + wn*64 + 16*i + 4*g + {0..3}
