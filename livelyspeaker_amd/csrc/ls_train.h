@@ -83,6 +83,9 @@ hipError_t launch_in_bwd(const float* dcol, const float* craw, const float* stat
 // partial[(b, chunk)][480]; *nchunk = chunks per sample
 hipError_t launch_conv1_wgrad(const float* dc, const float* wav, float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk,
                               hipStream_t st);
+// implicit-GEMM weight gradient of a stride-6 conv layer (ls_conv.hip); partial[ngroups][Cout][Cin*15]
+hipError_t launch_conv_wgrad(const float* dc, const float* in, const float* stats, float* partial, int B, int Cin, int Cout, int Lin, int Lout,
+                             int spw, int* ngroups, hipStream_t st);
 hipError_t launch_rowsum_bcl(const float* dc, float* partial, int B, int C, int L, hipStream_t st);
 hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
 // ---- optimiser ----

@@ -525,9 +525,11 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
     }
     for (int i = 2; i >= 1; --i) {      // conv3 (i=2), conv2 (i=1): dC_i = dc[i] [B][Cout_i][L_{i+1}]
         const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15, BP = B * Lo;
-        HIPCHK(h, launch_im2col(h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], L[i], Lo, 6, 0, st));
-        HIPCHK(h, wgrad(h, gemm_operand(h->dc[i].f(), INT_MAX, 0, Lo, Lo, (long long)C * Lo, 1, true, C, BP), op_cols(h->col.f(), W, W, BP), true, false,
-                        Gr(h, grad, ck(i, "weight")), W, C, W, BP));
+        {   // weight gradient: implicit GEMM straight from the raw conv output of the layer below (no im2col)
+            int ng = 0;
+            HIPCHK(h, launch_conv_wgrad(h->dc[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], C, L[i], Lo, i == 1 ? 2 : 8, &ng, st));   // 512 workgroups = 2 per CU, no tail round
+            HIPCHK(h, launch_partial_reduce(h->col.f(), ng, (long long)C * W, C * W, Gr(h, grad, ck(i, "weight")), 0, st));
+        }
         HIPCHK(h, launch_rowsum_bcl(h->dc[i].f(), part, B, C, Lo, st));
         HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(i, "bias")), 0, st));
         GemmArgs a = gemm(gemm_operand(h->dc[i].f(), Lo, (long long)C * Lo, 1, INT_MAX, 0, Lo, false, BP, C), op_cols(P(h, ck(i, "weight")), W, W, C),
