@@ -165,24 +165,33 @@ hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Token mixing (Conv1d(S,S,1) over the token axis, mlp_module.py:51-55): a1[b][s'][c] = bt[s'] + sum_s wt[s'][s] u[b][s][c];
-// x2 = x1 + SiLU(a1).  Workgroup = (sample, 128-channel slab).
-constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36;
+// x2 = x1 + SiLU(a1).  Workgroup = (sample, 128-channel slab); every thread register-tiles 4 outputs so that each pair of
+// LDS operand reads feeds 4 FMAs (the kernels are LDS-bandwidth bound).
+constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36, kTokWs = kTokMaxS + 4;     // ws rows padded to 40 (float4 reads)
 
 __global__ __launch_bounds__(256) void k_tokmix_fwd(const float* __restrict__ u, const float* __restrict__ x1, const float* __restrict__ wt,
                                                     const float* __restrict__ bt, float* __restrict__ a1, float* __restrict__ x2, int S) {
     __shared__ float us[kTokMaxS * kTokLd];
-    __shared__ float ws[kTokMaxS * kTokMaxS];
+    __shared__ __attribute__((aligned(16))) float wsT[kTokMaxS * kTokWs];       // wsT[s][s'] = wt[s'][s]
     const int b = blockIdx.x, c0 = blockIdx.y * kTokC, tid = threadIdx.x;
     for (int i = tid; i < S * kTokC; i += 256) us[(i / kTokC) * kTokLd + (i % kTokC)] = u[((size_t)b * S + i / kTokC) * kDm + c0 + (i % kTokC)];
-    for (int i = tid; i < S * S; i += 256) ws[i] = wt[i];
+    for (int i = tid; i < kTokMaxS * kTokWs; i += 256) {
+        const int s = i / kTokWs, sp = i % kTokWs;
+        wsT[i] = (s < S && sp < S) ? wt[sp * S + s] : 0.f;
+    }
     __syncthreads();
     const int c = tid & (kTokC - 1);
-    for (int sp = tid >> 7; sp < S; sp += 2) {
-        float acc = bt[sp];
-        for (int s = 0; s < S; ++s) acc = fmaf(ws[sp * S + s], us[s * kTokLd + c], acc);
-        const size_t o = ((size_t)b * S + sp) * kDm + c0 + c;
-        a1[o] = acc;
-        x2[o] = x1[o] + silu_f_(acc);
+    for (int sp0 = 4 * (tid >> 7); sp0 < S; sp0 += 8) {          // 4 output tokens sp0..sp0+3 per thread
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) acc += *reinterpret_cast<const f4*>(&wsT[s * kTokWs + sp0]) * us[s * kTokLd + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (sp0 + e >= S) break;
+            const float v = acc[e] + bt[sp0 + e];
+            const size_t o = ((size_t)b * S + sp0 + e) * kDm + c0 + c;
+            a1[o] = v;
+            x2[o] = x1[o] + silu_f_(v);
+        }
     }
 }
 
@@ -198,29 +207,55 @@ hipError_t launch_tokmix_fwd(const float* u, const float* x1, const float* wt, c
 __global__ __launch_bounds__(256) void k_tokmix_bwd(const float* __restrict__ g, const float* __restrict__ a1, const float* __restrict__ u1,
                                                     const float* __restrict__ wt, float* __restrict__ du, float* __restrict__ pw,
                                                     float* __restrict__ pb, int S) {
-    __shared__ float das[kTokMaxS * kTokLd];
-    __shared__ float us[kTokMaxS * kTokLd];
-    __shared__ float ws[kTokMaxS * kTokMaxS];
+    __shared__ float das[(kTokMaxS + 4) * kTokLd];
+    __shared__ float us[(kTokMaxS + 4) * kTokLd];
+    __shared__ __attribute__((aligned(16))) float ws[kTokMaxS * kTokWs];        // ws[s'][s] = wt[s'][s], rows padded
     const int b = blockIdx.x, c0 = blockIdx.y * kTokC, tid = threadIdx.x;
-    for (int i = tid; i < S * kTokC; i += 256) {
-        const size_t o = ((size_t)b * S + i / kTokC) * kDm + c0 + (i % kTokC);
-        das[(i / kTokC) * kTokLd + (i % kTokC)] = g[o] * silu_grad(a1[o]);
-        us[(i / kTokC) * kTokLd + (i % kTokC)] = u1[o];
+    for (int i = tid; i < (kTokMaxS + 4) * kTokC; i += 256) {
+        const int r = i / kTokC, cc = i % kTokC;
+        float dv = 0.f, uv = 0.f;
+        if (r < S) {
+            const size_t o = ((size_t)b * S + r) * kDm + c0 + cc;
+            dv = g[o] * silu_grad(a1[o]);
+            uv = u1[o];
+        }
+        das[r * kTokLd + cc] = dv;                       // rows S..S+3 are zero so that the 4-wide tiles below need no masks
+        us[r * kTokLd + cc] = uv;
     }
-    for (int i = tid; i < S * S; i += 256) ws[i] = wt[i];
+    for (int i = tid; i < kTokMaxS * kTokWs; i += 256) {
+        const int sp = i / kTokWs, s = i % kTokWs;
+        ws[i] = (sp < S && s < S) ? wt[sp * S + s] : 0.f;
+    }
     __syncthreads();
     const int c = tid & (kTokC - 1);
-    for (int s = tid >> 7; s < S; s += 2) {
-        float acc = 0.f;
-        for (int sp = 0; sp < S; ++sp) acc = fmaf(ws[sp * S + s], das[sp * kTokLd + c], acc);
-        du[((size_t)b * S + s) * kDm + c0 + c] = acc;
+    for (int s0 = 4 * (tid >> 7); s0 < S; s0 += 8) {              // du for 4 tokens s0..s0+3
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < S; ++sp) acc += *reinterpret_cast<const f4*>(&ws[sp * kTokWs + s0]) * das[sp * kTokLd + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (s0 + e < S) du[((size_t)b * S + s0 + e) * kDm + c0 + c] = acc[e];
     }
+    // weight-gradient partial: 2 x 4 register tile per thread, 6 LDS reads per 8 FMAs
     const size_t blk = (size_t)b * gridDim.y + blockIdx.y;
-    for (int o = tid; o < S * S; o += 256) {
-        const int sp = o / S, s = o % S;
-        float acc = 0.f;
-        for (int cc = 0; cc < kTokC; ++cc) acc = fmaf(das[sp * kTokLd + cc], us[s * kTokLd + cc], acc);
-        pw[blk * S * S + o] = acc;
+    const int nsp = (S + 1) / 2, ns4 = (S + 3) / 4;
+    for (int o = tid; o < nsp * ns4; o += 256) {
+        const int sp = 2 * (o / ns4), s = 4 * (o % ns4);
+        float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < kTokC; ++cc) {
+            const float d0 = das[sp * kTokLd + cc], d1 = das[(sp + 1) * kTokLd + cc];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float uv = us[(s + e) * kTokLd + cc];
+                r0[e] = fmaf(d0, uv, r0[e]);
+                r1[e] = fmaf(d1, uv, r1[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (s + e >= S) break;
+            pw[blk * S * S + (size_t)sp * S + s + e] = r0[e];
+            if (sp + 1 < S) pw[blk * S * S + (size_t)(sp + 1) * S + s + e] = r1[e];
+        }
     }
     for (int sp = tid; sp < S; sp += 256) {
         float acc = 0.f;
@@ -346,17 +381,25 @@ hipError_t launch_style_bwd(const float* g0, const float* mu, const float* lv, c
     return hipGetLastError();
 }
 
-// table[idx[i]][c] += src[i][c], i in order (deterministic even with repeated indices): embedding gradients
-__global__ void k_scatter_rows(const float* __restrict__ src, long long src_stride, const int64_t* __restrict__ idx, int idx_stride, int n,
-                               int cols, float* __restrict__ table) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    for (int i = 0; i < n; ++i) table[(size_t)idx[(size_t)i * idx_stride] * cols + c] += src[(size_t)i * src_stride + c];
+// table[idx[i]][c] += src[i][c]: embedding gradients.  Deterministic with repeated indices and still parallel: block i
+// does the work only if it is the FIRST occurrence of its index, and then adds every later occurrence in order.
+__global__ __launch_bounds__(256) void k_scatter_rows(const float* __restrict__ src, long long src_stride, const int64_t* __restrict__ idx,
+                                                      int idx_stride, int n, int cols, float* __restrict__ table) {
+    const int i = blockIdx.x;
+    const int64_t me = idx[(size_t)i * idx_stride];
+    for (int j = 0; j < i; ++j)
+        if (idx[(size_t)j * idx_stride] == me) return;            // uniform across the block
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float acc = table[(size_t)me * cols + c];
+        for (int j = i; j < n; ++j)
+            if (idx[(size_t)j * idx_stride] == me) acc += src[(size_t)j * src_stride + c];
+        table[(size_t)me * cols + c] = acc;
+    }
 }
 
 hipError_t launch_scatter_rows(const float* src, long long src_stride, const int64_t* idx, int idx_stride, int n, int cols, float* table,
                                hipStream_t st) {
-    hipLaunchKernelGGL(k_scatter_rows, dim3((cols + 255) / 256), dim3(256), 0, st, src, src_stride, idx, idx_stride, n, cols, table);
+    hipLaunchKernelGGL(k_scatter_rows, dim3(n), dim3(256), 0, st, src, src_stride, idx, idx_stride, n, cols, table);
     return hipGetLastError();
 }
 
