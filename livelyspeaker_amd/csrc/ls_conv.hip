@@ -209,3 +209,171 @@ hipError_t launch_conv_wgrad(const float* dc, const float* in, const float* stat
 }
 
 }  // namespace ls
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Data gradient of the stride-6 conv layers as an implicit GEMM, fused with LeakyReLU' and the first half of the
+// InstanceNorm backward (training step).  With x = 6q + r:
+//     dAct[b][ci][x] = sum_co sum_{t : r + 6t <= 14} W[co][ci][r + 6t] * dC[b][co][q - t]
+// i.e. six phase GEMMs (r = 0..5) with 3,3,3,2,2,2 taps -> 15 (r,t) pairs, no wasted multiplies.  MFMA M axis = 16 input
+// channels, N axis = 16 values of q, K = 4 output channels per MFMA for one (r,t).  Workgroup = (sample, 64 q = 384 x,
+// 32 input channels); wave w owns channel tile w&1 and q tiles 2(w>>1), 2(w>>1)+1 with one accumulator per phase.
+// dC [64 co][66 q incl. halo] is staged in LDS per 64-output-channel chunk; the weight operand comes from a per-lane
+// image [ci tile][co group of 4][pair][lane] rebuilt after every optimiser step (k_build_dgrad_img).
+// Epilogue: y = InstanceNorm(c_raw), dy = dAct * lrelu'(y) is written to dc, and per-(sample, channel) partial sums of
+// dy and dy*y go to `partial`; k_in_finalize turns dy into d c_raw = rstd * (dy - mean(dy) - y * mean(dy*y)).
+namespace ls {
+
+constexpr int kDgQT = 64, kDgDld = kDgQT + 4, kDgCo = 64;
+
+__global__ void k_build_dgrad_img(const float* __restrict__ w, float* __restrict__ img, int Cin, int Cout) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(Cin / 16) * (Cout / 4) * 16 * 64;
+    if (i >= total) return;
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), pq = (int)((i >> 8) & 3);
+    size_t rr = i >> 10;
+    const int cog = (int)(rr % (Cout / 4)), cit = (int)(rr / (Cout / 4));
+    const int pair = 4 * pq + e;
+    float v = 0.f;
+    if (pair < 15) {
+        const int t = pair < 12 ? pair / 6 : 2, r = pair < 12 ? pair % 6 : pair - 12;
+        const int co = 4 * cog + (lane >> 4), ci = 16 * cit + (lane & 15);
+        v = w[((size_t)co * Cin + ci) * 15 + r + 6 * t];
+    }
+    img[i] = v;
+}
+
+hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout, hipStream_t st) {
+    const size_t total = (size_t)(Cin / 16) * (Cout / 4) * 16 * 64;
+    hipLaunchKernelGGL(k_build_dgrad_img, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, img, Cin, Cout);
+    return hipGetLastError();
+}
+
+// dC element (b, co, p) at dc_in[b*sb + co*sc + p*sp]
+__global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc_in, long long sb, long long sc, long long sp,
+                                                    const float* __restrict__ wimg, const float* __restrict__ craw, const float* __restrict__ stats,
+                                                    float* __restrict__ dc_out, float* __restrict__ partial, int Cin, int Cout, int Lx, int Lout) {
+    __shared__ float dcs[kDgCo * kDgDld];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, ci0 = blockIdx.y * 32, q0 = blockIdx.x * kDgQT;
+    const int cit = w & 1, qh = w >> 1;
+
+    f4 acc[2][6];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[qt][r] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const f4* wp = reinterpret_cast<const f4*>(wimg) + ((size_t)(blockIdx.y * 2 + cit) * (Cout / 4)) * 4 * 64 + lane;
+    const int bbase = g * kDgDld + 32 * qh + s16 + 2;             // + 4*cogl*Dld*... see below: row = 4*cogl + g
+
+    for (int cc = 0; cc < Cout / kDgCo; ++cc) {
+        __syncthreads();
+        for (int idx = tid; idx < kDgCo * (kDgQT + 2); idx += 256) {
+            const int co = idx / (kDgQT + 2), jj = idx - co * (kDgQT + 2);
+            const int p = q0 - 2 + jj;
+            const int pc = min(max(p, 0), Lout - 1);                  // clamped address: branch-free load
+            const float v = dc_in[(size_t)b * sb + (size_t)(cc * kDgCo + co) * sc + (size_t)pc * sp];
+            dcs[co * kDgDld + jj] = (p >= 0 && p < Lout) ? v : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int cogl = 0; cogl < kDgCo / 4; ++cogl) {
+            const f4* wc = wp + (size_t)(cc * (kDgCo / 4) + cogl) * 4 * 64;
+            f4 A[4];
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) A[pq] = wc[pq * 64];
+            const float* br = dcs + (4 * cogl) * kDgDld + bbase;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float B0 = br[-t], B1 = br[16 - t];
+#pragma unroll
+                for (int r = 0; r < (t < 2 ? 6 : 3); ++r) {
+                    const int pair = t < 2 ? t * 6 + r : 12 + r;
+                    acc[0][r] = MFMA(A[pair >> 2][pair & 3], B0, acc[0][r]);
+                    acc[1][r] = MFMA(A[pair >> 2][pair & 3], B1, acc[1][r]);
+                }
+            }
+        }
+    }
+    // epilogue: lane (q = s16, g) holds input channels ci0 + 16 cit + 4 g + e
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mean[4], rstd[4];
+    size_t rowoff[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t row = (size_t)b * Cin + ci0 + 16 * cit + 4 * g + e;
+        mean[e] = stats[row * 2];
+        rstd[e] = stats[row * 2 + 1];
+        rowoff[e] = row * Lx;
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 32 * qh + 16 * qt + s16;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int x = 6 * q + r;
+            if (x < Lx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = (craw[rowoff[e] + x] - mean[e]) * rstd[e];
+                    const float dy = y >= 0.f ? acc[qt][r][e] : 0.3f * acc[qt][r][e];
+                    dc_out[rowoff[e] + x] = dy;
+                    s1[e] += dy;
+                    s2[e] += dy * y;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            s1[e] += __shfl_xor(s1[e], o);
+            s2[e] += __shfl_xor(s2[e], o);
+        }
+    }
+    if (s16 == 0) {
+        const int nslot = gridDim.x * 2, slot = blockIdx.x * 2 + qh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t row = (size_t)b * Cin + ci0 + 16 * cit + 4 * g + e;
+            partial[(row * nslot + slot) * 2] = s1[e];
+            partial[(row * nslot + slot) * 2 + 1] = s2[e];
+        }
+    }
+}
+
+// one workgroup per (sample, channel) row: d c_raw = rstd * (dy - mean(dy) - y * mean(dy * y)), in place on dc
+__global__ __launch_bounds__(256) void k_in_finalize(float* __restrict__ dc, const float* __restrict__ craw, const float* __restrict__ stats,
+                                                     const float* __restrict__ partial, int nslot, int L) {
+    const size_t row = blockIdx.x;
+    float a = 0.f, c2 = 0.f;
+    for (int i = 0; i < nslot; ++i) {                                  // fixed order, every thread the same
+        a += partial[(row * nslot + i) * 2];
+        c2 += partial[(row * nslot + i) * 2 + 1];
+    }
+    const float m1 = a / (float)L, m2 = c2 / (float)L;
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const float* cr = craw + row * L;
+    float* dr = dc + row * L;
+    for (int x = threadIdx.x; x < L; x += 256) {
+        const float y = (cr[x] - mean) * rstd;
+        dr[x] = rstd * (dr[x] - m1 - y * m2);
+    }
+}
+
+hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
+                             const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, hipStream_t st) {
+    if (Cin % 32 || Cout % kDgCo) return hipErrorInvalidValue;
+    const int nq = (Lx + 5) / 6;
+    dim3 grid((nq + kDgQT - 1) / kDgQT, Cin / 32, B);
+    hipLaunchKernelGGL(k_conv_dgrad, grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, dc_out, partial, Cin, Cout, Lx, Lout);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_in_finalize, dim3(B * Cin), dim3(256), 0, st, dc_out, craw, stats, partial, (int)grid.x * 2, Lx);
+    return hipGetLastError();
+}
+
+}  // namespace ls

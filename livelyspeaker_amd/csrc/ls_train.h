@@ -86,6 +86,10 @@ hipError_t launch_conv1_wgrad(const float* dc, const float* wav, float* partial,
 // implicit-GEMM weight gradient of a stride-6 conv layer (ls_conv.hip); partial[ngroups][Cout][Cin*15]
 hipError_t launch_conv_wgrad(const float* dc, const float* in, const float* stats, float* partial, int B, int Cin, int Cout, int Lin, int Lout,
                              int spw, int* ngroups, hipStream_t st);
+// implicit-GEMM data gradient + LeakyReLU' + InstanceNorm backward of a stride-6 conv layer (ls_conv.hip)
+hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
+hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
+                             const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, hipStream_t st);
 hipError_t launch_rowsum_bcl(const float* dc, float* partial, int B, int C, int L, hipStream_t st);
 hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
 // ---- optimiser ----

@@ -62,9 +62,9 @@ struct ls_trainer {
     // batch-sized buffers
     int capB = 0;
     Buf x_start, noise, drop, eps, audio, origin_x, vid, emo, ca, cb, tidx;
-    Buf c[4], st[3], img[4], feat, x_t, zc, mu, lv, pe_rows, pre1, hid, emb, xcur;
+    Buf c[4], st[3], img[4], dimg[4], feat, x_t, zc, mu, lv, pe_rows, pre1, hid, emb, xcur;
     std::vector<Buf> X1, A1, X2, A2, U1, U2, S1, S2;
-    Buf out, dout, lossp, kldp, terms, G, T1, T2, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dcol, dc[3], ws;
+    Buf out, dout, lossp, kldp, terms, G, T1, T2, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dc[3], ws;
     size_t ws_floats = 0;
     int B = 0;
     bool have_forward = false;
@@ -157,12 +157,18 @@ int ensure_batch(ls_trainer* h, int B) {
     }
     HIPCHK(h, E(h->out, (size_t)B * d0.T * d0.JF)); HIPCHK(h, E(h->dout, (size_t)B * d0.T * d0.JF));
     HIPCHK(h, E(h->lossp, 2 * ((size_t)B * d0.JF / 256 + 2))); HIPCHK(h, E(h->kldp, B)); HIPCHK(h, E(h->terms, 8));
-    HIPCHK(h, E(h->part, (size_t)kNW * 2 * kD + (size_t)B * 128 + 4096 * 512));
+    HIPCHK(h, E(h->part, (size_t)kNW * 2 * kD + (size_t)B * 128 + 4096 * 512 + (size_t)B * 32 * 2 * 2 * ((L[1] + 5) / 6 / 64 + 1)));
     HIPCHK(h, E(h->pw, (size_t)B * 4 * d0.S * d0.S)); HIPCHK(h, E(h->pb, (size_t)B * 4 * d0.S));
     HIPCHK(h, E(h->dAf, (size_t)B * d0.T * kAud));
-    const size_t colmax = (size_t)B * L[2] * kCin[1] * 15;      // conv2's im2col is the largest: B*1313*480
-    size_t col0 = (size_t)B * L[1] * 15;
-    HIPCHK(h, E(h->col, colmax > col0 ? colmax : col0)); HIPCHK(h, E(h->dcol, colmax));
+    // col: conv4's im2col [B*34][1920] and the partial-sum workspace of the implicit-GEMM weight gradients
+    size_t colmax = (size_t)B * L[4] * kCin[3] * 15;
+    for (int i = 1; i < 3; ++i) {
+        const size_t need = (size_t)((B + 1) / 2) * kCout[i] * kCin[i] * 15;
+        if (need > colmax) colmax = need;
+    }
+    const size_t c1need = (size_t)B * ((L[1] + 255) / 256) * 480;
+    if (c1need > colmax) colmax = c1need;
+    HIPCHK(h, E(h->col, colmax));
     h->ws_floats = (size_t)48 << 20;
     HIPCHK(h, E(h->ws, h->ws_floats));
     h->capB = B;
@@ -232,8 +238,10 @@ int ls_train_create(const ls_train_config* cfg, ls_trainer** out) {
         }
     if ((e = h->pe.ensure(pe.size() * 4)) != hipSuccess) return bail("hipMalloc(pe)", e);
     if ((e = hipMemcpy(h->pe.p, pe.data(), pe.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(pe)", e);
-    for (int i = 1; i < 4; ++i)
+    for (int i = 1; i < 4; ++i) {
         if ((e = h->img[i].ensure((size_t)kCout[i] * kCin[i] * 15 * 4)) != hipSuccess) return bail("hipMalloc(img)", e);
+        if ((e = h->dimg[i].ensure((size_t)kCout[i] * kCin[i] * 16 * 4)) != hipSuccess) return bail("hipMalloc(dimg)", e);
+    }
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("sync", e);
     *out = h;
     return LS_OK;
@@ -246,8 +254,8 @@ void ls_train_destroy(ls_trainer* h) {
     std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo,
                              &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
                              &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->T1, &h->T2, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
-                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->col, &h->dcol, &h->ws};
-    for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); }
+                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->col, &h->ws};
+    for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
     for (auto* v : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->S1, &h->S2}) for (auto& b : *v) all.push_back(&b);
     for (Buf* b : all) b->release();
@@ -519,12 +527,13 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
         HIPCHK(h, wgrad(h, op_cols(h->dAf.f(), kAud, kAud, BT), op_cols(h->col.f(), W4, W4, BT), false, false, Gr(h, grad, ck(3, "weight")), W4, kAud,
                         W4, BT));
         HIPCHK(h, colsum_to(h->dAf.f(), INT_MAX, 0, kAud, BT, kAud, Gr(h, grad, ck(3, "bias"))));
-        GemmArgs a = gemm(op_rows(h->dAf.f(), kAud, BT, kAud), op_cols(P(h, ck(3, "weight")), W4, W4, kAud), h->dcol.f(), W4, BT, W4, kAud);
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
-        HIPCHK(h, launch_in_bwd(h->dcol.f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), B, kCout[2], L[3], L[4], st));
+        // data gradient: implicit GEMM + LeakyReLU' + InstanceNorm backward; dC4(b, co, p) = dAf[(b*T + p)][co]
+        HIPCHK(h, launch_build_dgrad_img(P(h, ck(3, "weight")), h->dimg[3].f(), kCin[3], kCout[3], st));
+        HIPCHK(h, launch_conv_dgrad(h->dAf.f(), (long long)T * kAud, 1, kAud, h->dimg[3].f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), part, B,
+                                    kCin[3], kCout[3], L[3], L[4], st));
     }
     for (int i = 2; i >= 1; --i) {      // conv3 (i=2), conv2 (i=1): dC_i = dc[i] [B][Cout_i][L_{i+1}]
-        const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15, BP = B * Lo;
+        const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15;
         {   // weight gradient: implicit GEMM straight from the raw conv output of the layer below (no im2col)
             int ng = 0;
             HIPCHK(h, launch_conv_wgrad(h->dc[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], C, L[i], Lo, i == 1 ? 2 : 8, &ng, st));   // 512 workgroups = 2 per CU, no tail round
@@ -532,10 +541,9 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
         }
         HIPCHK(h, launch_rowsum_bcl(h->dc[i].f(), part, B, C, Lo, st));
         HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(i, "bias")), 0, st));
-        GemmArgs a = gemm(gemm_operand(h->dc[i].f(), Lo, (long long)C * Lo, 1, INT_MAX, 0, Lo, false, BP, C), op_cols(P(h, ck(i, "weight")), W, W, C),
-                          h->dcol.f(), W, BP, W, C);
-        HIPCHK(h, launch_gemm_tr(a, false, false, 1, st));
-        HIPCHK(h, launch_in_bwd(h->dcol.f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), B, kCout[i - 1], L[i], Lo, st));
+        HIPCHK(h, launch_build_dgrad_img(P(h, ck(i, "weight")), h->dimg[i].f(), kCin[i], C, st));
+        HIPCHK(h, launch_conv_dgrad(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), part, B,
+                                    kCin[i], C, L[i], Lo, st));
     }
     {   // conv1: weight / bias gradient only (its input is data); partials go to the (now free) column buffer
         const int C = kCout[0], Lo = L[1];
