@@ -470,15 +470,15 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
             HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
         }
         HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")), h->G.f(), part, R, kNW, st));
-        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
-        HIPCHK(h, launch_partial_reduce(part + kD, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block2.0.beta")), 0, st));
+        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
+        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
         // block1: x2 = x1 + SiLU(Wt LN1(x1) + bt)
         HIPCHK(h, launch_tokmix_bwd(h->G.f(), h->A1[l].f(), h->U1[l].f(), P(h, lk(l, "block1.1.weight")), h->T2.f(), h->pw.f(), h->pb.f(), B, S, st));
         HIPCHK(h, launch_partial_reduce(h->pw.f(), B * 4, (long long)S * S, S * S, Gr(h, grad, lk(l, "block1.1.weight")), 0, st));
         HIPCHK(h, launch_partial_reduce(h->pb.f(), B * 4, S, S, Gr(h, grad, lk(l, "block1.1.bias")), 0, st));
         HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")), h->G.f(), part, R, kNW, st));
-        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
-        HIPCHK(h, launch_partial_reduce(part + kD, kNW, 2 * kD, kD, Gr(h, grad, lk(l, "block1.0.beta")), 0, st));
+        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
+        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
         HIPCHK(h, launch_tok_sum(h->G.f(), h->demb.f(), B, S, l != d.L - 1, st));
     }
     // G = d loss / d [style | (emotion) | input_mapping rows]
