@@ -216,3 +216,34 @@ def test_trainloop_checkpoint_resume_is_bit_identical(tmp_path):
     got = second.trainer.state_dict()
     for k in ref:
         assert np.array_equal(ref[k], got[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Full training batch (B=512, the reference's default -b 512): size-independent properties instead of the CPU oracle
+def test_full_batch_gradient_is_deterministic_and_equals_mean_of_half_batches():
+    """Every loss term is a mean over the batch, so grad(full) == (grad(first half) + grad(second half)) / 2; and the
+    step has no float atomics, so repeating it gives bit-identical gradients."""
+    import torch
+    cfg, sd, tr = make("ted")
+    Bf = 512
+    x_start, y, noise, drop, eps = synth.make_train_batch(cfg, Bf, 3)
+    t = np.random.Generator(np.random.PCG64(9)).integers(0, 1000, size=(Bf,))
+    terms = tr.forward_backward(x_start, t, noise, y, drop, eps)
+    g_full = tr.grad.clone()
+    terms2 = tr.forward_backward(x_start, t, noise, y, drop, eps)
+    assert torch.equal(g_full, tr.grad) and terms["total"] == terms2["total"]
+    halves, losses = [], []
+    for sl in (slice(0, Bf // 2), slice(Bf // 2, Bf)):
+        yy = {k: v[sl] for k, v in y.items()}
+        tt = tr.forward_backward(x_start[sl], t[sl], noise[sl], yy, drop[sl], eps[sl])
+        halves.append(tr.grad.clone())
+        losses.append(tt["total"])
+    g_mean = (halves[0] + halves[1]) / 2
+    assert abs(terms["total"] - (losses[0] + losses[1]) / 2) < 1e-5 * abs(terms["total"])
+    g_full_np, g_mean_np = g_full.cpu().numpy(), g_mean.cpu().numpy()
+    for k, (o, n) in tr.params.items():
+        if k in NULL_GRAD:
+            continue
+        a, b = g_full_np[o:o + n], g_mean_np[o:o + n]
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max() + 1e-9, k
+    assert np.isfinite(g_full_np).all()
