@@ -78,8 +78,6 @@ hipError_t launch_scale_rows(float* x, const float* drop, int B, int per_sample,
 // ---- audio encoder backward ----
 hipError_t launch_im2col(const float* in, const float* stats, float* col, int B, int Cin, int Lin, int Lout, int stride, int pad,
                          hipStream_t st);
-hipError_t launch_in_bwd(const float* dcol, const float* craw, const float* stats, float* dc, int B, int C, int L, int Lout_next,
-                         hipStream_t st);
 // partial[(b, chunk)][480]; *nchunk = chunks per sample
 hipError_t launch_conv1_wgrad(const float* dc, const float* wav, float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk,
                               hipStream_t st);

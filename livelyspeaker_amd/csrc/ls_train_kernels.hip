@@ -1,7 +1,6 @@
 // Non-GEMM kernels of the training step: q_sample + feature build, LN_spatial forward/backward,
-// token-mixing forward/backward, reparameterisation + KLD, Huber / velocity losses and their gradient, InstanceNorm
-// + LeakyReLU backward of the audio encoder (through an explicit im2col, 288 GB of HBM make the 1.3 GB column buffer a
-// non-issue), deterministic partial-sum reductions (no float atomics), AdamW.  All fp32.  Row kernels give one 64-lane
+// token-mixing forward/backward, reparameterisation + KLD, Huber / velocity losses and their gradient, conv1's weight
+// gradient, deterministic partial-sum reductions (no float atomics), AdamW.  All fp32.  Row kernels give one 64-lane
 // wave a 512-channel row (2 float4 per lane).
 #include "ls_internal.h"
 #include "ls_train.h"
@@ -484,7 +483,8 @@ hipError_t launch_finish_terms(const float* loss_partial, int n_loss, const floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Audio encoder backward (audio_enc.py:9-20).  col[(b,p)][ci*15+k] = act(in[b][ci][p*stride + k - pad]),
+// Audio encoder backward helpers (audio_enc.py:9-20); the stride-6 layers' gradients are implicit GEMMs in ls_conv.hip.
+// im2col (only conv4's weight gradient still uses it: 34 positions): col[(b,p)][ci*15+k] = act(in[b][ci][p*stride + k - pad]),
 // act = LeakyReLU(0.3)(InstanceNorm) of the raw previous conv output when stats != null.
 __global__ void k_im2col(const float* __restrict__ in, const float* __restrict__ stats, float* __restrict__ col, int Cin, int Lin, int Lout,
                          int stride, int pad, size_t total) {
@@ -512,49 +512,6 @@ hipError_t launch_im2col(const float* in, const float* stats, float* col, int B,
                          hipStream_t st) {
     const size_t total = (size_t)B * Lout * Cin * 15;
     hipLaunchKernelGGL(k_im2col, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, stats, col, Cin, Lin, Lout, stride, pad, total);
-    return hipGetLastError();
-}
-
-// One workgroup per (b, c) row of a conv output that feeds InstanceNorm1d + LeakyReLU(0.3) + the next stride-6 conv.
-// dA[x] = sum_{p,k: 6p+k = x} dcol[(b,p)][c*15+k] (col2im gather), dy = dA * lrelu'(y), y = (craw - mean) * rstd,
-// dc = rstd * (dy - mean(dy) - y * mean(dy*y)).
-__global__ __launch_bounds__(256) void k_in_bwd(const float* __restrict__ dcol, const float* __restrict__ craw, const float* __restrict__ stats,
-                                                float* __restrict__ dc, int C, int L, int Lout_next) {
-    __shared__ float red[2][4];
-    const size_t row = blockIdx.x;
-    const int b = (int)(row / C), c = (int)(row % C);
-    const int W = C * 15, tid = threadIdx.x;
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    const float* cr = craw + row * L;
-    float* dr = dc + row * L;
-    float s1 = 0.f, s2 = 0.f;
-    for (int x = tid; x < L; x += 256) {
-        int p1 = x / 6;
-        if (p1 > Lout_next - 1) p1 = Lout_next - 1;
-        int p0 = (x - 14 + 5) / 6;
-        if (x - 14 < 0) p0 = 0;
-        float da = 0.f;
-        for (int p = p0; p <= p1; ++p) da += dcol[((size_t)b * Lout_next + p) * W + c * 15 + (x - 6 * p)];
-        const float y = (cr[x] - mean) * rstd;
-        const float dy = y >= 0.f ? da : 0.3f * da;
-        dr[x] = dy;
-        s1 += dy;
-        s2 += dy * y;
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
-    __syncthreads();
-    const float m1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)L;
-    const float m2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)L;
-    for (int x = tid; x < L; x += 256) {
-        const float y = (cr[x] - mean) * rstd;
-        dr[x] = rstd * (dr[x] - m1 - y * m2);
-    }
-}
-
-hipError_t launch_in_bwd(const float* dcol, const float* craw, const float* stats, float* dc, int B, int C, int L, int Lout_next,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(k_in_bwd, dim3(B * C), dim3(256), 0, st, dcol, craw, stats, dc, C, L, Lout_next);
     return hipGetLastError();
 }
 
