@@ -17,7 +17,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kCvK = 15, kCvS = 6, kCvTP = 64, kCvCI = 16, kCvTC = 64;
 constexpr int kCvWin = (kCvTP - 1) * kCvS + kCvK;      // 393 input samples per channel per tile
 constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the 4 lane groups (channels) hit different banks
-constexpr int kCvSteps = kCvK * kCvCI / 4;             // 60 MFMA k-steps per chunk
 
 // wimg: [co tile (Cout/16)][chunk (Cin/16)][step4 (15)][lane 64][4]: element e of step4 q is MFMA step s = 4q+e,
 //       tap k = s / 4 ... see build_conv_image() in ls_api.cpp: step s -> (k = s / 4, cig = s % 4), ci = 4*cig + g
@@ -103,7 +102,7 @@ hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* 
 // Partial sums per sample group go to a workspace that k_partial_reduce sums in index order (deterministic).
 namespace ls {
 
-constexpr int kWgCo = 64, kWgCi = 16, kWgCols = kWgCi * 15, kWgPT = 64, kWgDld = kWgPT + 4;
+constexpr int kWgCo = 64, kWgCi = 16, kWgPT = 64, kWgDld = kWgPT + 4;      // 64 output channels x 16 input channels (240 columns)
 constexpr int kWgWin = (kWgPT - 1) * 6 + 15, kWgWinP = kWgWin + 1;      // 393 -> 394
 
 __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ dc, const float* __restrict__ in, const float* __restrict__ stats,
