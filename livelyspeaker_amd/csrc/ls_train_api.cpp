@@ -175,6 +175,214 @@ int ensure_batch(ls_trainer* h, int B) {
     return LS_OK;
 }
 
+// locals shared by the stages of one step
+#define TRAIN_LOCALS(h, d)                                                                                   \
+    const int B = (d).B, S = (d).S, T = (d).T, R = B * S, BT = B * T, JF = (d).JF;                           \
+    const int* L = (h)->convL;                                                                               \
+    hipStream_t st = (h)->stream;                                                                            \
+    float* part = (h)->part.f();                                                                             \
+    (void)S; (void)T; (void)R; (void)BT; (void)JF; (void)L; (void)part
+
+// column sums of a row-strided matrix into dst[cols] (bias gradients), deterministic two-stage reduction
+static hipError_t colsum_to(ls_trainer* h, const float* in, int ri, long long ro, long long rs, int rows, int cols, float* dst) {
+    int nblk = rows / 64;
+    if (nblk < 1) nblk = 1;
+    if (nblk > 512) nblk = 512;
+    hipError_t e = launch_colsum(in, ri, ro, rs, rows, cols, h->part.f(), nblk, h->stream);
+    if (e != hipSuccess) return e;
+    return launch_partial_reduce(h->part.f(), nblk, cols, cols, dst, 0, h->stream);
+}
+
+// forward pass with every activation the backward needs kept in HBM; ends with the losses and d loss / d out
+static int train_forward(ls_trainer* h, const TrainDims& d) {
+    TRAIN_LOCALS(h, d);
+    // WavEncoder (audio_enc.py:9-25): raw conv outputs + InstanceNorm statistics are kept for the backward
+    HIPCHK(h, launch_conv1d(h->audio.f(), nullptr, P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), B, 1, kCout[0], L[0], L[1], kStride[0],
+                            kPad[0], st));
+    HIPCHK(h, launch_instnorm_stats(h->c[0].f(), h->st[0].f(), B * kCout[0], L[1], st));
+    for (int i = 1; i < 4; ++i) {
+        HIPCHK(h, launch_build_conv_img(P(h, ck(i, "weight")), h->img[i].f(), kCin[i], kCout[i], st));
+        HIPCHK(h, launch_conv1d_mfma(h->c[i - 1].f(), h->st[i - 1].f(), h->img[i].f(), P(h, ck(i, "bias")), h->c[i].f(), B, kCin[i], kCout[i], L[i],
+                                     L[i + 1], st));
+        if (i < 3) HIPCHK(h, launch_instnorm_stats(h->c[i].f(), h->st[i].f(), B * kCout[i], L[i + 1], st));
+    }
+    HIPCHK(h, launch_build_feat_train(h->x_start.f(), h->noise.f(), h->origin_x.f(), h->c[3].f(), h->drop.f(), h->ca.f(), h->cb.f(), h->feat.f(),
+                                      h->x_t.f(), d, h->cfg.model.n_pre_seq, st));
+    {   // input_mapping (RAG.py:114) -> frame rows of the token sequence
+        GemmArgs a = gemm(op_rows(h->feat.f(), d.KFP, BT, d.KF), op_rows(P(h, "input_mapping.weight"), d.KF, kD, d.KF),
+                          h->xcur.f() + (size_t)d.NPRE * kD, kD, BT, kD, d.KF);
+        a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
+        a.bias = P(h, "input_mapping.bias");
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    HIPCHK(h, launch_gather_rows(P(h, "speaker_embedding.weight"), reinterpret_cast<const int64_t*>(h->vid.p), h->zc.f(), B, kSpk,
+                                 h->cfg.model.n_speakers, st));
+    for (int k = 0; k < 2; ++k) {
+        GemmArgs a = gemm(op_rows(h->zc.f(), kSpk, B, kSpk), op_rows(P(h, k ? "speaker_logvar.weight" : "speaker_mu.weight"), kSpk, kD, kSpk),
+                          k ? h->lv.f() : h->mu.f(), kD, B, kD, kSpk);
+        a.bias = P(h, k ? "speaker_logvar.bias" : "speaker_mu.bias");
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    HIPCHK(h, launch_style_fwd(h->mu.f(), h->lv.f(), h->eps.f(), d.NPRE == 2 ? P(h, "emotion_embedding.weight") : nullptr,
+                               reinterpret_cast<const int64_t*>(h->emo.p), T, h->xcur.f(), h->kldp.f(), B, S, d.NPRE, st));
+    // TimestepEmbedder (mlp_module.py:123-136)
+    HIPCHK(h, launch_gather_rows(h->pe.f(), reinterpret_cast<const int64_t*>(h->tidx.p), h->pe_rows.f(), B, kD, kPeRows, st));
+    {
+        GemmArgs a = gemm(op_rows(h->pe_rows.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.0.weight"), kD, kD, kD), h->hid.f(),
+                          kD, B, kD, kD);
+        a.bias = P(h, "backbone.embed_timestep.time_embed.0.bias"); a.Cpre = h->pre1.f(); a.act = 1;
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+        GemmArgs b2 = gemm(op_rows(h->hid.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.2.weight"), kD, kD, kD), h->emb.f(), kD,
+                           B, kD, kD);
+        b2.bias = P(h, "backbone.embed_timestep.time_embed.2.bias");
+        HIPCHK(h, launch_gemm_tr(b2, true, true, 1, st));
+    }
+    for (int l = 0; l < d.L; ++l) {   // MLPblock.forward (mlp_module.py:67-74)
+        HIPCHK(h, launch_ln_fwd(h->xcur.f(), h->emb.f(), S, h->X1[l].f(), h->U1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")),
+                                P(h, lk(l, "block1.0.beta")), R, st));
+        HIPCHK(h, launch_tokmix_fwd(h->U1[l].f(), h->X1[l].f(), P(h, lk(l, "block1.1.weight")), P(h, lk(l, "block1.1.bias")), h->A1[l].f(),
+                                    h->X2[l].f(), B, S, st));
+        HIPCHK(h, launch_ln_fwd(h->X2[l].f(), nullptr, S, nullptr, h->U2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")),
+                                P(h, lk(l, "block2.0.beta")), R, st));
+        GemmArgs a = gemm(op_rows(h->U2[l].f(), kD, R, kD), op_rows(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->xcur.f(), kD, R, kD, kD);
+        a.bias = P(h, lk(l, "block2.1.bias")); a.Cpre = h->A2[l].f(); a.act = 1; a.R = h->X2[l].f();
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    {   // OutputProcess.poseFinal on the frame rows (RAG.py:128-129, 205-211)
+        GemmArgs a = gemm(gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
+                          op_rows(P(h, "output_process.poseFinal.weight"), kD, JF, kD), h->out.f(), JF, BT, JF, kD);
+        a.bias = P(h, "output_process.poseFinal.bias");
+        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    }
+    const int nlb = (B * JF + 255) / 256;
+    HIPCHK(h, launch_loss(h->out.f(), h->x_start.f(), h->dout.f(), h->lossp.f(), d, h->cfg.lambda_vel, st));
+    HIPCHK(h, launch_finish_terms(h->lossp.f(), nlb, h->kldp.f(), B, h->terms.f(), d, h->cfg.lambda_vel, h->cfg.kld_weight, st));
+    return LS_OK;
+}
+
+// poseFinal and the 8 MLPblocks; leaves d loss / d [style | (emotion) | input_mapping rows] in h->G and d emb in h->demb
+static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) {
+    TRAIN_LOCALS(h, d);
+    // poseFinal
+    HIPCHK(h, wgrad(h, op_cols(h->dout.f(), JF, JF, BT), gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, INT_MAX, 0, 1, T, (long long)S * kD, kD, false, kD, BT),
+                    false, false, Gr(h, grad, "output_process.poseFinal.weight"), kD, JF, kD, BT));
+    HIPCHK(h, colsum_to(h, h->dout.f(), INT_MAX, 0, JF, BT, JF, Gr(h, grad, "output_process.poseFinal.bias")));
+    HIPCHK(h, hipMemsetAsync(h->G.p, 0, (size_t)R * kD * 4, st));
+    {
+        GemmArgs a = gemm(op_rows(h->dout.f(), JF, BT, JF), op_cols(P(h, "output_process.poseFinal.weight"), kD, kD, JF),
+                          h->G.f() + (size_t)d.NPRE * kD, kD, BT, kD, JF);
+        a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+    }
+    for (int l = d.L - 1; l >= 0; --l) {
+        // block2: x3 = x2 + SiLU(LN2(x2) Wch^T + b)
+        HIPCHK(h, launch_silu_bwd_colsum(h->G.f(), h->A2[l].f(), h->T1.f(), part, R, kNW, st));
+        HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, lk(l, "block2.1.bias")), 0, st));
+        HIPCHK(h, wgrad(h, op_cols(h->T1.f(), kD, kD, R), op_cols(h->U2[l].f(), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")), kD,
+                        kD, kD, R));
+        {
+            GemmArgs a = gemm(op_rows(h->T1.f(), kD, R, kD), op_cols(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->T2.f(), kD, R, kD, kD);
+            HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        }
+        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")), h->G.f(), part, R, kNW, st));
+        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
+        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
+        // block1: x2 = x1 + SiLU(Wt LN1(x1) + bt)
+        HIPCHK(h, launch_tokmix_bwd(h->G.f(), h->A1[l].f(), h->U1[l].f(), P(h, lk(l, "block1.1.weight")), h->T2.f(), h->pw.f(), h->pb.f(), B, S, st));
+        HIPCHK(h, launch_partial_reduce(h->pw.f(), B * 4, (long long)S * S, S * S, Gr(h, grad, lk(l, "block1.1.weight")), 0, st));
+        HIPCHK(h, launch_partial_reduce(h->pb.f(), B * 4, S, S, Gr(h, grad, lk(l, "block1.1.bias")), 0, st));
+        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")), h->G.f(), part, R, kNW, st));
+        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
+        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
+        HIPCHK(h, launch_tok_sum(h->G.f(), h->demb.f(), B, S, l != d.L - 1, st));
+    }
+    return LS_OK;
+}
+
+// style / speaker / emotion embeddings, input_mapping, timestep embedder; leaves d loss / d audio features in h->dAf
+static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad) {
+    TRAIN_LOCALS(h, d);
+    // G = d loss / d [style | (emotion) | input_mapping rows]
+    HIPCHK(h, launch_style_bwd(h->G.f(), h->mu.f(), h->lv.f(), h->eps.f(), h->dmu.f(), h->dlv.f(), B, S, h->cfg.kld_weight, st));
+    for (int k = 0; k < 2; ++k) {
+        const float* dz = k ? h->dlv.f() : h->dmu.f();
+        const char* wk = k ? "speaker_logvar.weight" : "speaker_mu.weight";
+        HIPCHK(h, wgrad(h, op_cols(dz, kD, kD, B), op_cols(h->zc.f(), kSpk, kSpk, B), false, false, Gr(h, grad, wk), kSpk, kD, kSpk, B));
+        HIPCHK(h, colsum_to(h, dz, INT_MAX, 0, kD, B, kD, Gr(h, grad, k ? "speaker_logvar.bias" : "speaker_mu.bias")));
+        GemmArgs a = gemm(op_rows(dz, kD, B, kD), op_cols(P(h, wk), kSpk, kSpk, kD), h->dzc.f(), kSpk, B, kSpk, kD);
+        a.accumulate = k;
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+    }
+    HIPCHK(h, launch_scatter_rows(h->dzc.f(), kSpk, reinterpret_cast<const int64_t*>(h->vid.p), 1, B, kSpk, Gr(h, grad, "speaker_embedding.weight"), st));
+    if (d.NPRE == 2)
+        HIPCHK(h, launch_scatter_rows(h->G.f() + kD, (long long)S * kD, reinterpret_cast<const int64_t*>(h->emo.p), T, B, kD,
+                                      Gr(h, grad, "emotion_embedding.weight"), st));
+    // input_mapping
+    const float* dH = h->G.f() + (size_t)d.NPRE * kD;
+    HIPCHK(h, wgrad(h, gemm_operand(dH, INT_MAX, 0, 1, T, (long long)S * kD, kD, false, kD, BT), op_cols(h->feat.f(), d.KFP, d.KF, BT), false, false,
+                    Gr(h, grad, "input_mapping.weight"), d.KF, kD, d.KF, BT));
+    HIPCHK(h, colsum_to(h, dH, T, (long long)S * kD, kD, BT, kD, Gr(h, grad, "input_mapping.bias")));
+    {   // d audio features = dH . Win[:, 2JF+1:], then the mask_cond scale
+        GemmArgs a = gemm(gemm_operand(dH, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
+                          gemm_operand(P(h, "input_mapping.weight") + 2 * JF + 1, INT_MAX, 0, 1, INT_MAX, 0, d.KF, false, kAud, kD), h->dAf.f(), kAud,
+                          BT, kAud, kD);
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, launch_scale_rows(h->dAf.f(), h->drop.f(), B, T * kAud, st));
+    }
+    // TimestepEmbedder
+    {
+        const char* w0 = "backbone.embed_timestep.time_embed.0.weight";
+        const char* w2 = "backbone.embed_timestep.time_embed.2.weight";
+        HIPCHK(h, wgrad(h, op_cols(h->demb.f(), kD, kD, B), op_cols(h->hid.f(), kD, kD, B), false, false, Gr(h, grad, w2), kD, kD, kD, B));
+        HIPCHK(h, colsum_to(h, h->demb.f(), INT_MAX, 0, kD, B, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.2.bias")));
+        GemmArgs a = gemm(op_rows(h->demb.f(), kD, B, kD), op_cols(P(h, w2), kD, kD, kD), h->dhid.f(), kD, B, kD, kD);
+        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, launch_silu_bwd_colsum(h->dhid.f(), h->pre1.f(), h->dhid.f(), part, B, kNW, st));
+        HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.0.bias"), 0, st));
+        HIPCHK(h, wgrad(h, op_cols(h->dhid.f(), kD, kD, B), op_cols(h->pe_rows.f(), kD, kD, B), false, false, Gr(h, grad, w0), kD, kD, kD, B));
+    }
+    return LS_OK;
+}
+
+// WavEncoder backward, last layer first
+static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) {
+    TRAIN_LOCALS(h, d);
+    // WavEncoder backward, last layer first.  dC4(b, co, p) = dAf[(b*T + p)][co]
+    {
+        const int W4 = kCin[3] * 15;
+        HIPCHK(h, launch_im2col(h->c[2].f(), h->st[2].f(), h->col.f(), B, kCin[3], L[3], L[4], 6, 0, st));
+        HIPCHK(h, wgrad(h, op_cols(h->dAf.f(), kAud, kAud, BT), op_cols(h->col.f(), W4, W4, BT), false, false, Gr(h, grad, ck(3, "weight")), W4, kAud,
+                        W4, BT));
+        HIPCHK(h, colsum_to(h, h->dAf.f(), INT_MAX, 0, kAud, BT, kAud, Gr(h, grad, ck(3, "bias"))));
+        // data gradient: implicit GEMM + LeakyReLU' + InstanceNorm backward; dC4(b, co, p) = dAf[(b*T + p)][co]
+        HIPCHK(h, launch_build_dgrad_img(P(h, ck(3, "weight")), h->dimg[3].f(), kCin[3], kCout[3], st));
+        HIPCHK(h, launch_conv_dgrad(h->dAf.f(), (long long)T * kAud, 1, kAud, h->dimg[3].f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), part, B,
+                                    kCin[3], kCout[3], L[3], L[4], st));
+    }
+    for (int i = 2; i >= 1; --i) {      // conv3 (i=2), conv2 (i=1): dC_i = dc[i] [B][Cout_i][L_{i+1}]
+        const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15;
+        {   // weight gradient: implicit GEMM straight from the raw conv output of the layer below (no im2col)
+            int ng = 0;
+            HIPCHK(h, launch_conv_wgrad(h->dc[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], C, L[i], Lo, i == 1 ? 2 : 8, &ng, st));   // 512 workgroups = 2 per CU, no tail round
+            HIPCHK(h, launch_partial_reduce(h->col.f(), ng, (long long)C * W, C * W, Gr(h, grad, ck(i, "weight")), 0, st));
+        }
+        HIPCHK(h, launch_rowsum_bcl(h->dc[i].f(), part, B, C, Lo, st));
+        HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(i, "bias")), 0, st));
+        HIPCHK(h, launch_build_dgrad_img(P(h, ck(i, "weight")), h->dimg[i].f(), kCin[i], C, st));
+        HIPCHK(h, launch_conv_dgrad(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), part, B,
+                                    kCin[i], C, L[i], Lo, st));
+    }
+    {   // conv1: weight / bias gradient only (its input is data); partials go to the (now free) column buffer
+        const int C = kCout[0], Lo = L[1];
+        int nchunk = 0;
+        HIPCHK(h, launch_conv1_wgrad(h->dc[0].f(), h->audio.f(), h->col.f(), B, L[0], Lo, kStride[0], kPad[0], &nchunk, st));
+        HIPCHK(h, launch_partial_reduce(h->col.f(), B * nchunk, C * 15, C * 15, Gr(h, grad, ck(0, "weight")), 0, st));
+        HIPCHK(h, launch_rowsum_bcl(h->dc[0].f(), part, B, C, Lo, st));
+        HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(0, "bias")), 0, st));
+    }
+    return LS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -353,7 +561,7 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
     const bool od = tb->on_device != 0;
     const size_t nx = (size_t)B * d.JF * d.T * 4;
     const int* L = h->convL;
-    const int S = d.S, T = d.T, R = B * S, BT = B * T, JF = d.JF;
+    const int T = d.T;
 
     // ---- host side of q_sample / timestep lookup ----
     std::vector<float> ca(B), cb(B);
@@ -374,185 +582,11 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     HIPCHK(h, hipMemsetAsync(grad, 0, (size_t)h->flat * 4, st));
 
-    // ================= forward =================
-    // WavEncoder (audio_enc.py:9-25): raw conv outputs + InstanceNorm statistics are kept for the backward
-    HIPCHK(h, launch_conv1d(h->audio.f(), nullptr, P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), B, 1, kCout[0], L[0], L[1], kStride[0],
-                            kPad[0], st));
-    HIPCHK(h, launch_instnorm_stats(h->c[0].f(), h->st[0].f(), B * kCout[0], L[1], st));
-    for (int i = 1; i < 4; ++i) {
-        HIPCHK(h, launch_build_conv_img(P(h, ck(i, "weight")), h->img[i].f(), kCin[i], kCout[i], st));
-        HIPCHK(h, launch_conv1d_mfma(h->c[i - 1].f(), h->st[i - 1].f(), h->img[i].f(), P(h, ck(i, "bias")), h->c[i].f(), B, kCin[i], kCout[i], L[i],
-                                     L[i + 1], st));
-        if (i < 3) HIPCHK(h, launch_instnorm_stats(h->c[i].f(), h->st[i].f(), B * kCout[i], L[i + 1], st));
-    }
-    HIPCHK(h, launch_build_feat_train(h->x_start.f(), h->noise.f(), h->origin_x.f(), h->c[3].f(), h->drop.f(), h->ca.f(), h->cb.f(), h->feat.f(),
-                                      h->x_t.f(), d, h->cfg.model.n_pre_seq, st));
-    {   // input_mapping (RAG.py:114) -> frame rows of the token sequence
-        GemmArgs a = gemm(op_rows(h->feat.f(), d.KFP, BT, d.KF), op_rows(P(h, "input_mapping.weight"), d.KF, kD, d.KF),
-                          h->xcur.f() + (size_t)d.NPRE * kD, kD, BT, kD, d.KF);
-        a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
-        a.bias = P(h, "input_mapping.bias");
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
-    }
-    HIPCHK(h, launch_gather_rows(P(h, "speaker_embedding.weight"), reinterpret_cast<const int64_t*>(h->vid.p), h->zc.f(), B, kSpk,
-                                 h->cfg.model.n_speakers, st));
-    for (int k = 0; k < 2; ++k) {
-        GemmArgs a = gemm(op_rows(h->zc.f(), kSpk, B, kSpk), op_rows(P(h, k ? "speaker_logvar.weight" : "speaker_mu.weight"), kSpk, kD, kSpk),
-                          k ? h->lv.f() : h->mu.f(), kD, B, kD, kSpk);
-        a.bias = P(h, k ? "speaker_logvar.bias" : "speaker_mu.bias");
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
-    }
-    HIPCHK(h, launch_style_fwd(h->mu.f(), h->lv.f(), h->eps.f(), d.NPRE == 2 ? P(h, "emotion_embedding.weight") : nullptr,
-                               reinterpret_cast<const int64_t*>(h->emo.p), T, h->xcur.f(), h->kldp.f(), B, S, d.NPRE, st));
-    // TimestepEmbedder (mlp_module.py:123-136)
-    HIPCHK(h, launch_gather_rows(h->pe.f(), reinterpret_cast<const int64_t*>(h->tidx.p), h->pe_rows.f(), B, kD, kPeRows, st));
-    {
-        GemmArgs a = gemm(op_rows(h->pe_rows.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.0.weight"), kD, kD, kD), h->hid.f(),
-                          kD, B, kD, kD);
-        a.bias = P(h, "backbone.embed_timestep.time_embed.0.bias"); a.Cpre = h->pre1.f(); a.act = 1;
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
-        GemmArgs b2 = gemm(op_rows(h->hid.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.2.weight"), kD, kD, kD), h->emb.f(), kD,
-                           B, kD, kD);
-        b2.bias = P(h, "backbone.embed_timestep.time_embed.2.bias");
-        HIPCHK(h, launch_gemm_tr(b2, true, true, 1, st));
-    }
-    for (int l = 0; l < d.L; ++l) {   // MLPblock.forward (mlp_module.py:67-74)
-        HIPCHK(h, launch_ln_fwd(h->xcur.f(), h->emb.f(), S, h->X1[l].f(), h->U1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")),
-                                P(h, lk(l, "block1.0.beta")), R, st));
-        HIPCHK(h, launch_tokmix_fwd(h->U1[l].f(), h->X1[l].f(), P(h, lk(l, "block1.1.weight")), P(h, lk(l, "block1.1.bias")), h->A1[l].f(),
-                                    h->X2[l].f(), B, S, st));
-        HIPCHK(h, launch_ln_fwd(h->X2[l].f(), nullptr, S, nullptr, h->U2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")),
-                                P(h, lk(l, "block2.0.beta")), R, st));
-        GemmArgs a = gemm(op_rows(h->U2[l].f(), kD, R, kD), op_rows(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->xcur.f(), kD, R, kD, kD);
-        a.bias = P(h, lk(l, "block2.1.bias")); a.Cpre = h->A2[l].f(); a.act = 1; a.R = h->X2[l].f();
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
-    }
-    {   // OutputProcess.poseFinal on the frame rows (RAG.py:128-129, 205-211)
-        GemmArgs a = gemm(gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
-                          op_rows(P(h, "output_process.poseFinal.weight"), kD, JF, kD), h->out.f(), JF, BT, JF, kD);
-        a.bias = P(h, "output_process.poseFinal.bias");
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
-    }
-    const int nlb = (B * JF + 255) / 256;
-    HIPCHK(h, launch_loss(h->out.f(), h->x_start.f(), h->dout.f(), h->lossp.f(), d, h->cfg.lambda_vel, st));
-    HIPCHK(h, launch_finish_terms(h->lossp.f(), nlb, h->kldp.f(), B, h->terms.f(), d, h->cfg.lambda_vel, h->cfg.kld_weight, st));
+    if ((rc = train_forward(h, d)) != LS_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[1], st));
-
-    // ================= backward =================
-    float* part = h->part.f();
-    auto colsum_to = [&](const float* in, int ri, long long ro, long long rs, int rows, int cols, float* dst) -> hipError_t {
-        int nblk = rows / 64;
-        if (nblk < 1) nblk = 1;
-        if (nblk > 512) nblk = 512;
-        hipError_t e = launch_colsum(in, ri, ro, rs, rows, cols, part, nblk, st);
-        if (e != hipSuccess) return e;
-        return launch_partial_reduce(part, nblk, cols, cols, dst, 0, st);
-    };
-    // poseFinal
-    HIPCHK(h, wgrad(h, op_cols(h->dout.f(), JF, JF, BT), gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, INT_MAX, 0, 1, T, (long long)S * kD, kD, false, kD, BT),
-                    false, false, Gr(h, grad, "output_process.poseFinal.weight"), kD, JF, kD, BT));
-    HIPCHK(h, colsum_to(h->dout.f(), INT_MAX, 0, JF, BT, JF, Gr(h, grad, "output_process.poseFinal.bias")));
-    HIPCHK(h, hipMemsetAsync(h->G.p, 0, (size_t)R * kD * 4, st));
-    {
-        GemmArgs a = gemm(op_rows(h->dout.f(), JF, BT, JF), op_cols(P(h, "output_process.poseFinal.weight"), kD, kD, JF),
-                          h->G.f() + (size_t)d.NPRE * kD, kD, BT, kD, JF);
-        a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
-    }
-    for (int l = d.L - 1; l >= 0; --l) {
-        // block2: x3 = x2 + SiLU(LN2(x2) Wch^T + b)
-        HIPCHK(h, launch_silu_bwd_colsum(h->G.f(), h->A2[l].f(), h->T1.f(), part, R, kNW, st));
-        HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, lk(l, "block2.1.bias")), 0, st));
-        HIPCHK(h, wgrad(h, op_cols(h->T1.f(), kD, kD, R), op_cols(h->U2[l].f(), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")), kD,
-                        kD, kD, R));
-        {
-            GemmArgs a = gemm(op_rows(h->T1.f(), kD, R, kD), op_cols(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->T2.f(), kD, R, kD, kD);
-            HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
-        }
-        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")), h->G.f(), part, R, kNW, st));
-        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
-        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
-        // block1: x2 = x1 + SiLU(Wt LN1(x1) + bt)
-        HIPCHK(h, launch_tokmix_bwd(h->G.f(), h->A1[l].f(), h->U1[l].f(), P(h, lk(l, "block1.1.weight")), h->T2.f(), h->pw.f(), h->pb.f(), B, S, st));
-        HIPCHK(h, launch_partial_reduce(h->pw.f(), B * 4, (long long)S * S, S * S, Gr(h, grad, lk(l, "block1.1.weight")), 0, st));
-        HIPCHK(h, launch_partial_reduce(h->pb.f(), B * 4, S, S, Gr(h, grad, lk(l, "block1.1.bias")), 0, st));
-        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")), h->G.f(), part, R, kNW, st));
-        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
-        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
-        HIPCHK(h, launch_tok_sum(h->G.f(), h->demb.f(), B, S, l != d.L - 1, st));
-    }
-    // G = d loss / d [style | (emotion) | input_mapping rows]
-    HIPCHK(h, launch_style_bwd(h->G.f(), h->mu.f(), h->lv.f(), h->eps.f(), h->dmu.f(), h->dlv.f(), B, S, h->cfg.kld_weight, st));
-    for (int k = 0; k < 2; ++k) {
-        const float* dz = k ? h->dlv.f() : h->dmu.f();
-        const char* wk = k ? "speaker_logvar.weight" : "speaker_mu.weight";
-        HIPCHK(h, wgrad(h, op_cols(dz, kD, kD, B), op_cols(h->zc.f(), kSpk, kSpk, B), false, false, Gr(h, grad, wk), kSpk, kD, kSpk, B));
-        HIPCHK(h, colsum_to(dz, INT_MAX, 0, kD, B, kD, Gr(h, grad, k ? "speaker_logvar.bias" : "speaker_mu.bias")));
-        GemmArgs a = gemm(op_rows(dz, kD, B, kD), op_cols(P(h, wk), kSpk, kSpk, kD), h->dzc.f(), kSpk, B, kSpk, kD);
-        a.accumulate = k;
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
-    }
-    HIPCHK(h, launch_scatter_rows(h->dzc.f(), kSpk, reinterpret_cast<const int64_t*>(h->vid.p), 1, B, kSpk, Gr(h, grad, "speaker_embedding.weight"), st));
-    if (d.NPRE == 2)
-        HIPCHK(h, launch_scatter_rows(h->G.f() + kD, (long long)S * kD, reinterpret_cast<const int64_t*>(h->emo.p), T, B, kD,
-                                      Gr(h, grad, "emotion_embedding.weight"), st));
-    // input_mapping
-    const float* dH = h->G.f() + (size_t)d.NPRE * kD;
-    HIPCHK(h, wgrad(h, gemm_operand(dH, INT_MAX, 0, 1, T, (long long)S * kD, kD, false, kD, BT), op_cols(h->feat.f(), d.KFP, d.KF, BT), false, false,
-                    Gr(h, grad, "input_mapping.weight"), d.KF, kD, d.KF, BT));
-    HIPCHK(h, colsum_to(dH, T, (long long)S * kD, kD, BT, kD, Gr(h, grad, "input_mapping.bias")));
-    {   // d audio features = dH . Win[:, 2JF+1:], then the mask_cond scale
-        GemmArgs a = gemm(gemm_operand(dH, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
-                          gemm_operand(P(h, "input_mapping.weight") + 2 * JF + 1, INT_MAX, 0, 1, INT_MAX, 0, d.KF, false, kAud, kD), h->dAf.f(), kAud,
-                          BT, kAud, kD);
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
-        HIPCHK(h, launch_scale_rows(h->dAf.f(), h->drop.f(), B, T * kAud, st));
-    }
-    // TimestepEmbedder
-    {
-        const char* w0 = "backbone.embed_timestep.time_embed.0.weight";
-        const char* w2 = "backbone.embed_timestep.time_embed.2.weight";
-        HIPCHK(h, wgrad(h, op_cols(h->demb.f(), kD, kD, B), op_cols(h->hid.f(), kD, kD, B), false, false, Gr(h, grad, w2), kD, kD, kD, B));
-        HIPCHK(h, colsum_to(h->demb.f(), INT_MAX, 0, kD, B, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.2.bias")));
-        GemmArgs a = gemm(op_rows(h->demb.f(), kD, B, kD), op_cols(P(h, w2), kD, kD, kD), h->dhid.f(), kD, B, kD, kD);
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
-        HIPCHK(h, launch_silu_bwd_colsum(h->dhid.f(), h->pre1.f(), h->dhid.f(), part, B, kNW, st));
-        HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.0.bias"), 0, st));
-        HIPCHK(h, wgrad(h, op_cols(h->dhid.f(), kD, kD, B), op_cols(h->pe_rows.f(), kD, kD, B), false, false, Gr(h, grad, w0), kD, kD, kD, B));
-    }
-    // WavEncoder backward, last layer first.  dC4(b, co, p) = dAf[(b*T + p)][co]
-    {
-        const int W4 = kCin[3] * 15;
-        HIPCHK(h, launch_im2col(h->c[2].f(), h->st[2].f(), h->col.f(), B, kCin[3], L[3], L[4], 6, 0, st));
-        HIPCHK(h, wgrad(h, op_cols(h->dAf.f(), kAud, kAud, BT), op_cols(h->col.f(), W4, W4, BT), false, false, Gr(h, grad, ck(3, "weight")), W4, kAud,
-                        W4, BT));
-        HIPCHK(h, colsum_to(h->dAf.f(), INT_MAX, 0, kAud, BT, kAud, Gr(h, grad, ck(3, "bias"))));
-        // data gradient: implicit GEMM + LeakyReLU' + InstanceNorm backward; dC4(b, co, p) = dAf[(b*T + p)][co]
-        HIPCHK(h, launch_build_dgrad_img(P(h, ck(3, "weight")), h->dimg[3].f(), kCin[3], kCout[3], st));
-        HIPCHK(h, launch_conv_dgrad(h->dAf.f(), (long long)T * kAud, 1, kAud, h->dimg[3].f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), part, B,
-                                    kCin[3], kCout[3], L[3], L[4], st));
-    }
-    for (int i = 2; i >= 1; --i) {      // conv3 (i=2), conv2 (i=1): dC_i = dc[i] [B][Cout_i][L_{i+1}]
-        const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15;
-        {   // weight gradient: implicit GEMM straight from the raw conv output of the layer below (no im2col)
-            int ng = 0;
-            HIPCHK(h, launch_conv_wgrad(h->dc[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], C, L[i], Lo, i == 1 ? 2 : 8, &ng, st));   // 512 workgroups = 2 per CU, no tail round
-            HIPCHK(h, launch_partial_reduce(h->col.f(), ng, (long long)C * W, C * W, Gr(h, grad, ck(i, "weight")), 0, st));
-        }
-        HIPCHK(h, launch_rowsum_bcl(h->dc[i].f(), part, B, C, Lo, st));
-        HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(i, "bias")), 0, st));
-        HIPCHK(h, launch_build_dgrad_img(P(h, ck(i, "weight")), h->dimg[i].f(), kCin[i], C, st));
-        HIPCHK(h, launch_conv_dgrad(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), part, B,
-                                    kCin[i], C, L[i], Lo, st));
-    }
-    {   // conv1: weight / bias gradient only (its input is data); partials go to the (now free) column buffer
-        const int C = kCout[0], Lo = L[1];
-        int nchunk = 0;
-        HIPCHK(h, launch_conv1_wgrad(h->dc[0].f(), h->audio.f(), h->col.f(), B, L[0], Lo, kStride[0], kPad[0], &nchunk, st));
-        HIPCHK(h, launch_partial_reduce(h->col.f(), B * nchunk, C * 15, C * 15, Gr(h, grad, ck(0, "weight")), 0, st));
-        HIPCHK(h, launch_rowsum_bcl(h->dc[0].f(), part, B, C, Lo, st));
-        HIPCHK(h, launch_partial_reduce(part, B, C, C, Gr(h, grad, ck(0, "bias")), 0, st));
-    }
+    if ((rc = train_backward_mixer(h, d, grad)) != LS_OK || (rc = train_backward_inputs(h, d, grad)) != LS_OK ||
+        (rc = train_backward_audio(h, d, grad)) != LS_OK)
+        return rc;
     HIPCHK(h, hipEventRecord(h->ev[2], st));
     float tv[8] = {0};
     HIPCHK(h, hipMemcpyAsync(tv, h->terms.p, 5 * 4, hipMemcpyDeviceToHost, st));
