@@ -30,7 +30,7 @@ FLOP_PER_SAMPLE_STEP = {"ted": 317_431_808, "beat": 362_496_000}     # BASELINE.
 MFMA_F32_PEAK_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # HBM bytes per k_step launch from rocprofv3 PMC passes (profiles/r01b_kernel_trace_and_pmc.md): 2*FETCH_SIZE + WRITE_SIZE
 # (KiB -> B, with the guide's gfx950 FETCH_SIZE correction); measured for the default workload only.
-PMC_TRAFFIC_BYTES = {("ted", 512): 219_482_784}
+PMC_TRAFFIC_BYTES = {("ted", 512): 218_940_170}      # profiles/r01e_final_kernel_trace_and_pmc.md
 
 
 def parse():
