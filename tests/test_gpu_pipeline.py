@@ -1,0 +1,60 @@
+"""The components composed as scripts/test_LivelySpeaker_ted.py composes them (SAG decoder -> init_image -> CFG RAG, ddim100
+with skip_timesteps=80 -> post-processing -> FGD evaluator), drop-in modules on the GPU vs the CPU oracles chained the same
+way on the same synthetic inputs and the same torch-CPU random draws.  Catches layout / hand-over mistakes between parts that
+the per-component parity tests cannot see."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_livelyspeaker_pipeline_matches_chained_oracles():
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import livelyspeaker_ted as ex
+    from livelyspeaker_amd import postprocess as pp
+    from livelyspeaker_amd import synth
+    from oracle import eval_oracle as evo
+    from oracle import rag_oracle as orc
+
+    B, scale, skip = 6, 2.5, 80
+    cfg, model, diffusion, sag_decoder, evaluator = ex.build()
+    vec_seq, batch, cond = ex.make_inputs(cfg, B, guidance_param=scale)
+    decoded, sample = ex.infer(model, diffusion, sag_decoder, batch, cond, skip_steps=skip, seed=11)
+    post = pp.ted_postprocess(sample)
+    real = vec_seq.permute(0, 3, 1, 2).reshape(B, 34, -1)
+    feat = evaluator.net(post["aligned_motions"], variational_encoding=False)[0].cpu().numpy()
+
+    # ---- the same chain on the CPU oracles, replaying the loop's torch-CPU draws (reference order) ----
+    y = synth.make_cond(cfg, B, scale=scale)
+    sag = orc.SagDecoderOracle(synth.make_sag_state_dict(cfg))
+    init = sag.decode(y["origin_x"], synth.make_text_features(B), None)
+    assert np.abs(decoded.cpu().numpy() - init).max() < 1e-4
+    sch = orc.Schedule(1000, "ddim100")
+    n_exec = sch.num_timesteps - skip
+    torch.manual_seed(11)
+    shape = (B, 9, 3, 34)
+    x_init = torch.randn(*shape).numpy()
+    eps_tape, noise_tape = [], []
+    proto = torch.empty(shape)
+    for k in range(n_exec):
+        ec, eu = torch.randn(B, 1, 512).numpy().reshape(B, 512), torch.randn(B, 1, 512).numpy().reshape(B, 512)
+        eps_tape.append(np.stack([ec, eu]))
+        if k >= 1:                                     # the reference's x is a permuted view after the first step (G7)
+            proto = torch.empty(34, B, 9, 3).permute(1, 2, 3, 0)
+        noise_tape.append(torch.randn_like(proto).numpy())
+    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    want = orc.sample_loop(oracle, sch, y, x_init, eps_tape, noise_tape, ddim=True, eta=0.0, skip_timesteps=skip, init_image=init)
+    d = float(np.abs(sample.cpu().numpy() - want).max())
+    print(f"pipeline sample max|d| = {d:.3e}")
+    assert d < 1e-3
+    opost = orc.ted_post(want, pp.TED_MEAN_DIR_VEC, pp.TED_ANGLE_PAIRS, pp.TED_CHANGE_ANGLE, pp.TED_BEAT_THRES, pp.TED_DIR_VEC_PAIRS)
+    assert np.abs(post["aligned_motions"].cpu().numpy() - opost["aligned"]).max() < 1e-3
+    assert np.abs(post["pose"].cpu().numpy() - opost["pose"]).max() < 2e-3
+    ofeat = evo.pose_encoder(synth.make_embedding_net_state_dict(27, 32), opost["aligned"])
+    assert np.abs(feat - ofeat).max() < 2e-3 * max(1.0, float(np.abs(ofeat).max()))
+    assert real.shape == (B, 34, 27)
