@@ -74,6 +74,10 @@ class TrainLoop:
         self.speaker_model = getattr(getattr(data, "dataset", None), "speaker_model", None)
         self.cur_lr = self.lr
         self.last_losses = {}
+        #: where the step's random draws are made: "cpu" = torch's CPU generator in the reference's order (reproduces the
+        #: reference's CPU-path stream; ~3 ms of host RNG + H2D per step at B=512), "cuda" = torch's generator of the
+        #: training device, same order, no host work (what the reference effectively does when it trains on a GPU).
+        self.noise_device = "cpu"
 
         di = model._device_index()
         self.device = torch.device("cuda", di)
@@ -141,10 +145,11 @@ class TrainLoop:
         y = cond['y']
         B = batch.shape[0]
         t, weights = self.schedule_sampler.sample(B, "cpu")
-        noise = torch.randn(tuple(batch.shape))                                  # th.randn_like(x_start)
+        nd = self.device if self.noise_device == "cuda" else torch.device("cpu")
+        noise = torch.randn(tuple(batch.shape), device=nd)                       # th.randn_like(x_start)
         p = float(getattr(self.model, "cond_mask_prob", 0.0))
-        drop = torch.bernoulli(torch.ones(B) * p) if p > 0. else torch.zeros(B)   # mask_cond (training mode)
-        eps = torch.randn(B, 1, 512)                                             # reparameterize
+        drop = torch.bernoulli(torch.ones(B, device=nd) * p) if p > 0. else torch.zeros(B, device=nd)   # mask_cond (training mode)
+        eps = torch.randn(B, 1, 512, device=nd)                                  # reparameterize
         yy = {k: y[k] for k in ('audio_input', 'origin_x', 'vid_indices') + (('emo',) if self.model.n_prefix_tokens == 2 else ())}
         yy['origin_x'][..., self.model.n_pre_seq:] = 0                           # RAG.py:110, in place like the reference
         dev = self.device

@@ -1,0 +1,25 @@
+import sys, time, os
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from types import SimpleNamespace
+from livelyspeaker_amd import synth, _lib
+from livelyspeaker_amd.model_util import create_model_and_diffusion
+from livelyspeaker_amd.train_loop import TrainLoop
+cfg = synth.TED; B = 512; dev = "cuda:0"
+margs = SimpleNamespace(mdm_condm="text", latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1, arch="trans_enc", emb_trans_dec=False, dataset="humanml", lang_model=None, mlpact="silu", diffusion_steps=1000, noise_schedule="cosine", sigma_small=True, lambda_vel=1.0, lambda_rcxyz=0.0, lambda_fc=0.0, njoints=9)
+model, diffusion = create_model_and_diffusion(margs, '')
+model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}, strict=False); model.to(dev); model.train()
+targs = SimpleNamespace(batch_size=B, lr=1e-4, weight_decay=0.0, lr_anneal_steps=0, log_interval=1000, save_interval=10**9, resume_checkpoint="", epochs=1, save_dir="/tmp/x", overwrite=True, dataset="ted")
+loop = TrainLoop(targs, None, model, diffusion, None); loop.noise_device = "cuda"
+x_start, y, _, _, _ = synth.make_train_batch(cfg, B, 0)
+xs = torch.from_numpy(x_start).to(dev); cond = {"y": {k: torch.from_numpy(v).to(dev) for k, v in y.items()}}
+import cProfile, pstats
+for i in range(3): loop.run_step(xs, cond)
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+t0 = time.perf_counter()
+for i in range(20): loop.run_step(xs, cond)
+torch.cuda.synchronize()
+print("ms/step", (time.perf_counter() - t0) * 50)
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
