@@ -90,7 +90,7 @@ struct ls_handle {
     bool prepared = false;
     DevBuf audio, origin_x, vid, emo, scale;
     DevBuf c1, c2, c3, c4, st1, st2, st3, feat_c, feat_u, static_c, static_u, z, z_mu, z_logvar, z_std, emo_tok;
-    DevBuf audio_feat;
+    DevBuf audio_feat, spart;
     DevBuf xa, xb, xtmp, xio, fwd_c, fwd_u, fwd_cfg, eps, noise, tfwd, tfwd_tmp, tidx, dump, trace, callp;
     DevBuf eps_tape, noise_tape;
 
@@ -586,7 +586,7 @@ void ls_destroy(ls_handle* h) {
                      &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
-                     &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
+                     &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->prof};
     for (DevBuf* d : all) d->release();
@@ -674,19 +674,29 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     DevBuf* stats[3] = {&h->st1, &h->st2, &h->st3};
     const float* in = h->audio.f();
     const float* in_stats = nullptr;
+    // every conv kernel also produces the InstanceNorm statistics of its own output (partials -> k_stats_merge), so the
+    // activations are written once and read once
+    {
+        size_t need = 0;
+        for (int i = 0; i < 3; ++i) {
+            const size_t n = (size_t)B * kConvCout[i] * ((Lc[i + 1] + 63) / 64) * 4 * 3;
+            if (n > need) need = n;
+        }
+        HIPCHK(h, h->spart.ensure(need * sizeof(float)));
+    }
     for (int i = 0; i < 4; ++i) {
         HIPCHK(h, outs[i]->ensure((size_t)B * kConvCout[i] * Lc[i + 1] * sizeof(float)));
-        if (i == 0)     // Cin = 1: 15-tap FIR, stays on the VALU kernel
-            HIPCHK(h, launch_conv1d(in, in_stats, h->conv_w[i].f(), h->conv_b[i].f(), outs[i]->f(), B, kConvCin[i], kConvCout[i],
-                                    Lc[i], Lc[i + 1], kConvStride[i], kConvPad[i], st));
-        else
-            HIPCHK(h, launch_conv1d_mfma(in, in_stats, h->conv_img[i].f(), h->conv_b[i].f(), outs[i]->f(), B, kConvCin[i],
-                                         kConvCout[i], Lc[i], Lc[i + 1], st));
+        float* ostats = nullptr;
         if (i < 3) {
             HIPCHK(h, stats[i]->ensure((size_t)B * kConvCout[i] * 2 * sizeof(float)));
-            HIPCHK(h, launch_instnorm_stats(outs[i]->f(), stats[i]->f(), B * kConvCout[i], Lc[i + 1], st));
-            in_stats = stats[i]->f();
+            ostats = stats[i]->f();
         }
+        if (i == 0)     // Cin = 1: a 15-tap FIR per channel, bound by the output write
+            HIPCHK(h, launch_conv1_fwd(in, h->conv_w[0].f(), h->conv_b[0].f(), outs[0]->f(), ostats, h->spart.f(), B, Lc[0], Lc[1], kConvPad[0], st));
+        else
+            HIPCHK(h, launch_conv1d_mfma(in, in_stats, h->conv_img[i].f(), h->conv_b[i].f(), outs[i]->f(), ostats, h->spart.f(), B, kConvCin[i],
+                                         kConvCout[i], Lc[i], Lc[i + 1], st));
+        in_stats = ostats;
         in = outs[i]->f();
     }
     // ---- static part of input_mapping (RAG.py:110-114): columns JF.. of W_in act on [prefix poses | bit | audio]

@@ -22,7 +22,7 @@ constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the
 //       tap k = s / 4 ... see build_conv_image() in ls_api.cpp: step s -> (k = s / 4, cig = s % 4), ci = 4*cig + g
 __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
                                                      const float* __restrict__ wimg, const float* __restrict__ bias,
-                                                     float* __restrict__ out, int Cin, int Cout, int Lin, int Lout) {
+                                                     float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout) {
     __shared__ float sIn[kCvCI * kCvWinP];
     const int b = blockIdx.z, co0 = blockIdx.y * kCvTC, p0 = blockIdx.x * kCvTP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,23 +71,153 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ i
         }
     }
     const int p = p0 + 16 * w + s16;
-    if (p < Lout) {
+    const bool valid = p < Lout;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = co0 + 16 * t + 4 * g + j;
-                if (co < Cout) out[((size_t)b * Cout + co) * Lout + p] = acc[t][j] + bias[co];
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + 16 * t + 4 * g + j;
+            const float v = acc[t][j] + bias[co];
+            if (valid) out[((size_t)b * Cout + co) * Lout + p] = v;
+            if (spart) {
+                // InstanceNorm statistics of this wave's 16 positions (lanes sharing g), two-pass inside the tile:
+                // (count, mean, M2) per (sample, channel, position tile); k_stats_merge combines them (Chan et al.)
+                const int nv = min(16, max(0, Lout - (p0 + 16 * w)));
+                float s1 = valid ? v : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) s1 += __shfl_xor(s1, o);
+                const float mean = nv > 0 ? s1 / (float)nv : 0.f;
+                const float d = valid ? v - mean : 0.f;
+                float m2 = d * d;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
+                if (s16 == 0) {
+                    float* sp = spart + (((size_t)b * Cout + co) * (gridDim.x * 4) + blockIdx.x * 4 + w) * 3;
+                    sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
+                }
             }
+        }
+}
+
+// stats[row] = (mean, 1/sqrt(biased var + 1e-5)) from np partial (count, mean, M2) triples per row, merged in index order
+// with the parallel-variance update (Chan, Golub, LeVeque): exact-arithmetic equivalent of the two-pass statistics.
+__global__ __launch_bounds__(256) void k_stats_merge(const float* __restrict__ spart, float* __restrict__ stats, int rows, int np) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);              // one wave per row
+    if (row >= rows) return;
+    const float* sp = spart + (size_t)row * np * 3;
+    // merged in double: the mean decides the sign of every normalised activation, i.e. which LeakyReLU slope its gradient
+    // gets; keeping it within 1 ulp of the exact mean makes that decision agree with a two-pass fp32 reference
+    auto merge = [](double& n, double& mean, double& m2, double nb, double mb, double qb) {
+        const double nt = n + nb;
+        if (nt > 0.0) {
+            const double delta = mb - mean, f = nb / nt;
+            mean += delta * f;
+            m2 += qb + delta * delta * (n * f);
+            n = nt;
+        }
+    };
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int i = lane; i < np; i += 64) merge(n, mean, m2, (double)sp[3 * i], (double)sp[3 * i + 1], (double)sp[3 * i + 2]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {                                 // butterfly: every lane ends with the full merge
+        const double nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
+        merge(n, mean, m2, nb, mb, qb);
+    }
+    if (lane == 0) {
+        stats[(size_t)row * 2] = (float)mean;
+        stats[(size_t)row * 2 + 1] = (float)(1.0 / sqrt(m2 / n + 1e-5));
     }
 }
 
-hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* wimg, const float* bias, float* out, int B,
-                              int Cin, int Cout, int Lin, int Lout, hipStream_t st) {
-    if (Cin % kCvCI || Cout % kCvTC || !stats) return hipErrorInvalidValue;
-    dim3 grid((Lout + kCvTP - 1) / kCvTP, Cout / kCvTC, B);
-    hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(256), 0, st, in, stats, wimg, bias, out, Cin, Cout, Lin, Lout);
+hipError_t launch_stats_merge(const float* spart, float* stats, int rows, int np, hipStream_t st) {
+    hipLaunchKernelGGL(k_stats_merge, dim3((rows + 3) / 4), dim3(256), 0, st, spart, stats, rows, np);
     return hipGetLastError();
+}
+
+// out_stats != null: also produce the InstanceNorm statistics of the OUTPUT (fused, no second pass over it); spart is a
+// workspace of B * Cout * ceil(Lout / 64) * 4 * 3 floats
+hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* wimg, const float* bias, float* out, float* out_stats,
+                              float* spart, int B, int Cin, int Cout, int Lin, int Lout, hipStream_t st) {
+    if (Cin % kCvCI || Cout % kCvTC || !stats || (out_stats && !spart)) return hipErrorInvalidValue;
+    dim3 grid((Lout + kCvTP - 1) / kCvTP, Cout / kCvTC, B);
+    hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(256), 0, st, in, stats, wimg, bias, out, out_stats ? spart : nullptr, Cin, Cout, Lin, Lout);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !out_stats) return e;
+    return launch_stats_merge(spart, out_stats, B * Cout, (int)grid.x * 4, st);
+}
+
+// conv1 (audio_enc.py:10): Conv1d(1, 32, 15, stride 5, padding 1600) on the raw waveform + the InstanceNorm statistics of
+// its output, one pass.  Thread = one output position, all 32 channels in registers; the 480 weights are wave-uniform
+// (scalar loads), the 5130-sample input window of the workgroup's 1024 positions sits in LDS; a thread owns 4 positions
+// 256 apart so that the statistics' cross-lane reductions are amortised.  Bound by the 517 MB output write.
+constexpr int kC1fQ = 4, kC1fP = 256 * kC1fQ, kC1fWin = (kC1fP - 1) * 5 + 15;
+__global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ out, float* __restrict__ spart, int Lin, int Lout, int pad) {
+    __shared__ float sw[kC1fWin + 1];
+    const int b = blockIdx.y, p0 = blockIdx.x * kC1fP, tid = threadIdx.x;
+    const int x0 = p0 * 5 - pad;
+    for (int i = tid; i < kC1fWin; i += 256) {
+        const int x = x0 + i;
+        const float v = wav[(size_t)b * Lin + min(max(x, 0), Lin - 1)];
+        sw[i] = (x >= 0 && x < Lin) ? v : 0.f;
+    }
+    __syncthreads();
+    // thread tid owns positions p0 + tid + 256 q: every store instruction of a wave covers 64 consecutive positions
+    float win[kC1fQ][15];
+    bool valid[kC1fQ];
+    int nv = 0;                                                      // valid positions of this WAVE (uniform)
+    const int wv = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < kC1fQ; ++q) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) win[q][k] = sw[(tid + 256 * q) * 5 + k];
+        valid[q] = p0 + tid + 256 * q < Lout;
+        nv += min(64, max(0, Lout - (p0 + 256 * q + 64 * wv)));
+    }
+    const int np = gridDim.x * 4;
+#pragma unroll 2
+    for (int co = 0; co < 32; ++co) {
+        float v[kC1fQ];
+        float s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < kC1fQ; ++q) {
+            v[q] = bias[co];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) v[q] = fmaf(w[co * 15 + k], win[q][k], v[q]);
+            if (valid[q]) {
+                out[((size_t)b * 32 + co) * Lout + p0 + tid + 256 * q] = v[q];
+                s1 += v[q];
+            }
+        }
+        if (spart) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) s1 += __shfl_xor(s1, o);
+            const float mean = nv > 0 ? s1 / (float)nv : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < kC1fQ; ++q) {
+                const float d = valid[q] ? v[q] - mean : 0.f;
+                m2 = fmaf(d, d, m2);
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) m2 += __shfl_xor(m2, o);
+            if ((tid & 63) == 0) {
+                float* sp = spart + (((size_t)b * 32 + co) * np + blockIdx.x * 4 + wv) * 3;
+                sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
+            }
+        }
+    }
+}
+
+hipError_t launch_conv1_fwd(const float* wav, const float* w, const float* bias, float* out, float* out_stats, float* spart, int B, int Lin,
+                            int Lout, int pad, hipStream_t st) {
+    if (out_stats && !spart) return hipErrorInvalidValue;
+    dim3 grid((Lout + kC1fP - 1) / kC1fP, B);
+    hipLaunchKernelGGL(k_conv1_fwd, grid, dim3(256), 0, st, wav, w, bias, out, out_stats ? spart : nullptr, Lin, Lout, pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !out_stats) return e;
+    return launch_stats_merge(spart, out_stats, B * 32, (int)grid.x * 4, st);
 }
 
 }  // namespace ls

@@ -104,12 +104,13 @@ hipError_t init_seq_kernels();
 hipError_t launch_step_seq(Variant v, const StepArgs& a, int batch, hipStream_t st);
 
 // ---- once-per-call kernels (ls_prepare.hip) ------------------------------------------------
-hipError_t launch_conv1d(const float* in, const float* stats, const float* w, const float* bias, float* out,
-                         int B, int Cin, int Cout, int Lin, int Lout, int stride, int pad, hipStream_t st);
-// stride-6 layers on MFMA (ls_conv.hip); wimg = per-lane operand image built by ls_api.cpp
-hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* wimg, const float* bias, float* out, int B,
-                              int Cin, int Cout, int Lin, int Lout, hipStream_t st);
-hipError_t launch_instnorm_stats(const float* x, float* stats, int rows, int L, hipStream_t st);
+// stride-6 layers on MFMA (ls_conv.hip); wimg = per-lane operand image.  out_stats != null: the InstanceNorm statistics of
+// the output are produced by the same pass (spart: workspace, B*Cout*ceil(Lout/64)*12 floats)
+hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* wimg, const float* bias, float* out, float* out_stats,
+                              float* spart, int B, int Cin, int Cout, int Lin, int Lout, hipStream_t st);
+// conv1 (Cin = 1, k 15, stride 5) + output statistics in one pass (spart: B*32*ceil(Lout/256)*12 floats)
+hipError_t launch_conv1_fwd(const float* wav, const float* w, const float* bias, float* out, float* out_stats, float* spart, int B, int Lin,
+                            int Lout, int pad, hipStream_t st);
 // C[M][N] = act(A[M][K] . W[N][K]^T + bias) (+ R): fp32 MFMA GEMM (ls_gemm.hip); act 3 = exact GELU
 hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                           float* C, int ldc, int M, int N, int K, int act, hipStream_t st);

@@ -11,132 +11,7 @@ namespace ls {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// ---------------------------------------------------------------------------------------------
-// Direct Conv1d, kernel 15.  Workgroup = (64 output positions) x (32 output channels) of one sample;
-// lane = position, wave = 8 output channels.  Input window + weight slab are staged in LDS per chunk
-// of input channels; the previous layer's InstanceNorm + LeakyReLU(0.3) is applied while staging
-// (stats = per-(sample,channel) {mean, rstd}), so normalised activations are never written to HBM.
-// ---------------------------------------------------------------------------------------------
-constexpr int kConvK = 15;
-constexpr int kConvTP = 64;
-constexpr int kConvTC = 32;
-constexpr int kConvCI = 16;   // input channels per LDS chunk
-
-template <int STRIDE>
-__global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ in, const float* __restrict__ stats,
-                                                const float* __restrict__ w, const float* __restrict__ bias,
-                                                float* __restrict__ out, int Cin, int Cout, int Lin, int Lout,
-                                                int pad) {
-    constexpr int WIN = (kConvTP - 1) * STRIDE + kConvK;          // input window per tile
-    constexpr int WINP = WIN + 1;
-    __shared__ float sIn[kConvCI * WINP];
-    __shared__ __attribute__((aligned(16))) float sW[kConvCI * kConvK * kConvTC];   // [ci*15+k][32 channels]
-
-    const int b = blockIdx.z;
-    const int co0 = blockIdx.y * kConvTC;
-    const int p0 = blockIdx.x * kConvTP;
-    const int tid = threadIdx.x;
-    const int p = tid & 63;
-    const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);      // channels co0 + 8*cg .. +7
-    const int in0 = p0 * STRIDE - pad;
-
-    float acc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-
-    for (int ci0 = 0; ci0 < Cin; ci0 += kConvCI) {
-        const int nci = (Cin - ci0 < kConvCI) ? Cin - ci0 : kConvCI;
-        __syncthreads();
-        for (int idx = tid; idx < nci * WIN; idx += 256) {
-            const int ci = idx / WIN, o = idx - ci * WIN;
-            const int gi = in0 + o;
-            float v = 0.f;
-            if (gi >= 0 && gi < Lin) {
-                v = in[((size_t)b * Cin + ci0 + ci) * Lin + gi];
-                if (stats) {   // InstanceNorm1d(affine=False, eps 1e-5, biased var) + LeakyReLU(0.3), audio_enc.py:10-11
-                    const float m = stats[((size_t)b * Cin + ci0 + ci) * 2], r = stats[((size_t)b * Cin + ci0 + ci) * 2 + 1];
-                    v = (v - m) * r;
-                    v = v >= 0.f ? v : 0.3f * v;
-                }
-            }
-            sIn[ci * WINP + o] = v;
-        }
-        for (int idx = tid; idx < nci * kConvK * kConvTC; idx += 256) {
-            const int c = idx & (kConvTC - 1), ck = idx / kConvTC;     // ck = ci*15 + k
-            const int ci = ck / kConvK, k = ck - ci * kConvK;
-            float v = 0.f;
-            if (co0 + c < Cout) v = w[((size_t)(co0 + c) * Cin + ci0 + ci) * kConvK + k];
-            sW[ck * kConvTC + c] = v;
-        }
-        __syncthreads();
-        for (int ci = 0; ci < nci; ++ci) {
-#pragma unroll
-            for (int k = 0; k < kConvK; ++k) {
-                const float v = sIn[ci * WINP + p * STRIDE + k];
-                const f4 w0 = *reinterpret_cast<const f4*>(&sW[(ci * kConvK + k) * kConvTC + cg * 8]);
-                const f4 w1 = *reinterpret_cast<const f4*>(&sW[(ci * kConvK + k) * kConvTC + cg * 8 + 4]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[c] = fmaf(v, w0[c], acc[c]);
-                    acc[4 + c] = fmaf(v, w1[c], acc[4 + c]);
-                }
-            }
-        }
-    }
-    if (p0 + p < Lout) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int co = co0 + cg * 8 + c;
-            if (co < Cout) out[((size_t)b * Cout + co) * Lout + p0 + p] = acc[c] + bias[co];
-        }
-    }
-}
-
-hipError_t launch_conv1d(const float* in, const float* stats, const float* w, const float* bias, float* out,
-                         int B, int Cin, int Cout, int Lin, int Lout, int stride, int pad, hipStream_t st) {
-    dim3 grid((Lout + kConvTP - 1) / kConvTP, (Cout + kConvTC - 1) / kConvTC, B);
-    if (stride == 5)
-        hipLaunchKernelGGL(k_conv1d<5>, grid, dim3(256), 0, st, in, stats, w, bias, out, Cin, Cout, Lin, Lout, pad);
-    else if (stride == 6)
-        hipLaunchKernelGGL(k_conv1d<6>, grid, dim3(256), 0, st, in, stats, w, bias, out, Cin, Cout, Lin, Lout, pad);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-// per-row mean and 1/sqrt(biased var + 1e-5) over L (two-pass, like torch's InstanceNorm on fp32)
-__global__ __launch_bounds__(256) void k_instnorm_stats(const float* __restrict__ x, float* __restrict__ stats, int L) {
-    __shared__ float red[4];
-    const size_t rowi = blockIdx.x;
-    const float* xr = x + rowi * L;
-    const int tid = threadIdx.x;
-    auto block_sum = [&](float v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = v;
-        __syncthreads();
-        return (red[0] + red[1]) + (red[2] + red[3]);
-    };
-    float s = 0.f;
-    for (int i = tid; i < L; i += 256) s += xr[i];
-    const float mean = block_sum(s) / (float)L;
-    float q = 0.f;
-    for (int i = tid; i < L; i += 256) {
-        const float d = xr[i] - mean;
-        q += d * d;
-    }
-    const float var = block_sum(q) / (float)L;
-    if (tid == 0) {
-        stats[rowi * 2] = mean;
-        stats[rowi * 2 + 1] = 1.0f / sqrtf(var + 1e-5f);
-    }
-}
-
-hipError_t launch_instnorm_stats(const float* x, float* stats, int rows, int L, hipStream_t st) {
-    hipLaunchKernelGGL(k_instnorm_stats, dim3(rows), dim3(256), 0, st, x, stats, L);
-    return hipGetLastError();
-}
+// (the WavEncoder convolutions and their fused InstanceNorm statistics live in ls_conv.hip)
 
 __global__ void k_gather_rows(const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out,
                               int rows, int width, int table_rows) {

@@ -168,6 +168,10 @@ int ensure_batch(ls_trainer* h, int B) {
     }
     const size_t c1need = (size_t)B * ((L[1] + 255) / 256) * 480;
     if (c1need > colmax) colmax = c1need;
+    for (int i = 0; i < 3; ++i) {       // InstanceNorm partials of the forward convs
+        const size_t need = (size_t)B * kCout[i] * ((L[i + 1] + 63) / 64) * 4 * 3;
+        if (need > colmax) colmax = need;
+    }
     HIPCHK(h, E(h->col, colmax));
     h->ws_floats = (size_t)48 << 20;
     HIPCHK(h, E(h->ws, h->ws_floats));
@@ -197,14 +201,13 @@ static hipError_t colsum_to(ls_trainer* h, const float* in, int ri, long long ro
 static int train_forward(ls_trainer* h, const TrainDims& d) {
     TRAIN_LOCALS(h, d);
     // WavEncoder (audio_enc.py:9-25): raw conv outputs + InstanceNorm statistics are kept for the backward
-    HIPCHK(h, launch_conv1d(h->audio.f(), nullptr, P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), B, 1, kCout[0], L[0], L[1], kStride[0],
-                            kPad[0], st));
-    HIPCHK(h, launch_instnorm_stats(h->c[0].f(), h->st[0].f(), B * kCout[0], L[1], st));
+    // (the column buffer is free during the forward: it serves as the statistics-partials workspace)
+    HIPCHK(h, launch_conv1_fwd(h->audio.f(), P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), h->st[0].f(), h->col.f(), B, L[0], L[1],
+                               kPad[0], st));
     for (int i = 1; i < 4; ++i) {
         HIPCHK(h, launch_build_conv_img(P(h, ck(i, "weight")), h->img[i].f(), kCin[i], kCout[i], st));
-        HIPCHK(h, launch_conv1d_mfma(h->c[i - 1].f(), h->st[i - 1].f(), h->img[i].f(), P(h, ck(i, "bias")), h->c[i].f(), B, kCin[i], kCout[i], L[i],
-                                     L[i + 1], st));
-        if (i < 3) HIPCHK(h, launch_instnorm_stats(h->c[i].f(), h->st[i].f(), B * kCout[i], L[i + 1], st));
+        HIPCHK(h, launch_conv1d_mfma(h->c[i - 1].f(), h->st[i - 1].f(), h->img[i].f(), P(h, ck(i, "bias")), h->c[i].f(), i < 3 ? h->st[i].f() : nullptr,
+                                     h->col.f(), B, kCin[i], kCout[i], L[i], L[i + 1], st));
     }
     HIPCHK(h, launch_build_feat_train(h->x_start.f(), h->noise.f(), h->origin_x.f(), h->c[3].f(), h->drop.f(), h->ca.f(), h->cb.f(), h->feat.f(),
                                       h->x_t.f(), d, h->cfg.model.n_pre_seq, st));
@@ -628,6 +631,13 @@ int ls_train_read(ls_trainer* h, const char* what, float* out, size_t n) {
     else if (w == "z_logvar") { src = h->lv.f(); need = B * kD; }
     else if (w == "emb") { src = h->emb.f(); need = B * kD; }
     else if (w == "x_last") { src = h->xcur.f(); need = B * d.S * kD; }
+    else if (w.size() == 2 && w[0] == 'c' && w[1] >= '1' && w[1] <= '4') {          // raw conv outputs [B][Cout][L]
+        const int i = w[1] - '1';
+        src = h->c[i].f(); need = B * kCout[i] * h->convL[i + 1];
+    } else if (w.size() == 3 && w[0] == 's' && w[1] == 't' && w[2] >= '1' && w[2] <= '3') {   // (mean, rstd) per (sample, channel)
+        const int i = w[2] - '1';
+        src = h->st[i].f(); need = B * kCout[i] * 2;
+    }
     else return fail(h, LS_EINVAL, "ls_train_read: unknown tensor '%s'", what);
     if (n != need) return fail(h, LS_EINVAL, "ls_train_read: '%s' has %zu elements, buffer has %zu", what, need, n);
     HIPCHK(h, hipSetDevice(h->cfg.model.device));

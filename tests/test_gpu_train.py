@@ -50,15 +50,24 @@ def test_forward_backward_matches_oracle_and_fixture(dataset):
     assert np.abs(out - oout).max() < 1e-3
     g = tr.grads()
     assert sorted(g) == sorted(ograds)
+    # LeakyReLU' is discontinuous: an InstanceNorm output within a few ulp of 0 may get either slope depending on the last
+    # bit of the channel mean.  Conv weights upstream of such an element (layer j and below) are compared in relative L2.
+    import torch
+    margins = tro.leaky_kink_margins(oracle.P, torch.from_numpy(y["audio_input"]))
+    exposed = {f"audio_encoder.feat_extractor.{idx}.weight" for j, idx in enumerate((0, 3, 6)) if min(margins[j:]) < 2e-6}
+    print(f"[{dataset}] min |normalised activation| per layer: {margins}; kink-exposed tensors: {sorted(exposed)}")
     worst = 0.0
     for k in g:
         if k in NULL_GRAD:
             assert np.abs(g[k]).max() < 1e-5, k
             continue
+        if k in exposed:
+            assert np.linalg.norm(g[k] - ograds[k]) <= 2e-2 * np.linalg.norm(ograds[k]), k
+            continue
         rel = np.abs(g[k] - ograds[k]).max() / (np.abs(ograds[k]).max() + 1e-12)
         worst = max(worst, rel)
         assert rel < 2e-4, (k, rel)
-        if f"g_{k}_full" in gold:                      # reference gradients stored in full for the small tensors
+        if f"g_{k}_full" in gold and k not in exposed:   # reference gradients stored in full for the small tensors
             ref = gold[f"g_{k}_full"]
             assert np.abs(g[k] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, k
     print(f"[{dataset}] worst relative gradient error {worst:.2e}")
@@ -247,3 +256,31 @@ def test_full_batch_gradient_is_deterministic_and_equals_mean_of_half_batches():
         a, b = g_full_np[o:o + n], g_mean_np[o:o + n]
         assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max() + 1e-9, k
     assert np.isfinite(g_full_np).all()
+
+
+def test_gradients_strict_on_a_batch_without_kink_proximal_activations():
+    """Same comparison with EVERY tensor held to the strict max-abs bound, on a (deterministically searched) 2-sample batch
+    whose normalised activations all stay >= 3e-6 away from the LeakyReLU kink, so that no slope is ambiguous."""
+    import torch
+    cfg, sd, tr = make("ted")
+    oracle = tro.TrainOracle(sd, cfg.n_prefix_tokens)
+    Bs = 2
+    chosen = None
+    for step in range(40):
+        x_start, y, noise, drop, eps = synth.make_train_batch(cfg, Bs, step)
+        if min(tro.leaky_kink_margins(oracle.P, torch.from_numpy(y["audio_input"]))) >= 3e-6:
+            chosen = step
+            break
+    assert chosen is not None, "no kink-free batch among 40 candidates"
+    t = np.array([17, 803])
+    tr.forward_backward(x_start, t, noise, y, drop, eps)
+    _, _, ograds, _ = oracle.forward_backward(x_start, t, noise, y, drop, eps)
+    g = tr.grads()
+    worst = 0.0
+    for k in g:
+        if k in NULL_GRAD:
+            continue
+        rel = np.abs(g[k] - ograds[k]).max() / (np.abs(ograds[k]).max() + 1e-12)
+        worst = max(worst, rel)
+        assert rel < 2e-4, (k, rel, chosen)
+    print(f"kink-free batch = step {chosen}; worst relative gradient error {worst:.2e}")
