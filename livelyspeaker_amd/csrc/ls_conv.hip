@@ -494,13 +494,15 @@ __global__ __launch_bounds__(256) void k_in_finalize(float* __restrict__ dc, con
 }
 
 hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
-                             const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, hipStream_t st) {
+                             const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, bool finalize,
+                             int* nslot, hipStream_t st) {
     if (Cin % 32 || Cout % kDgCo) return hipErrorInvalidValue;
     const int nq = (Lx + 5) / 6;
     dim3 grid((nq + kDgQT - 1) / kDgQT, Cin / 32, B);
+    if (nslot) *nslot = (int)grid.x * 2;
     hipLaunchKernelGGL(k_conv_dgrad, grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, dc_out, partial, Cin, Cout, Lx, Lout);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || !finalize) return e;
     hipLaunchKernelGGL(k_in_finalize, dim3(B * Cin), dim3(256), 0, st, dc_out, craw, stats, partial, (int)grid.x * 2, Lx);
     return hipGetLastError();
 }

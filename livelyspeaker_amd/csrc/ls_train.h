@@ -78,17 +78,19 @@ hipError_t launch_scale_rows(float* x, const float* drop, int B, int per_sample,
 // ---- audio encoder backward ----
 hipError_t launch_im2col(const float* in, const float* stats, float* col, int B, int Cin, int Lin, int Lout, int stride, int pad,
                          hipStream_t st);
-// partial[(b, chunk)][480]; *nchunk = chunks per sample
-hipError_t launch_conv1_wgrad(const float* dc, const float* wav, float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk,
-                              hipStream_t st);
+// conv1 weight gradient with the InstanceNorm backward of its output applied on the fly (dy + row partials from
+// launch_conv_dgrad(..., finalize = false)); partial[(b, chunk)][480]; *nchunk = chunks per sample
+hipError_t launch_conv1_wgrad(const float* dy, const float* craw, const float* stats, const float* rowpart, int nslot, const float* wav,
+                              float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk, hipStream_t st);
 // implicit-GEMM weight gradient of a stride-6 conv layer (ls_conv.hip); partial[ngroups][Cout][Cin*15]
 hipError_t launch_conv_wgrad(const float* dc, const float* in, const float* stats, float* partial, int B, int Cin, int Cout, int Lin, int Lout,
                              int spw, int* ngroups, hipStream_t st);
 // implicit-GEMM data gradient + LeakyReLU' + InstanceNorm backward of a stride-6 conv layer (ls_conv.hip)
 hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
+// finalize = false leaves dy in dc_out and the per-row partial sums in partial[row][*nslot][2] for a fused consumer
 hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
-                             const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, hipStream_t st);
-hipError_t launch_rowsum_bcl(const float* dc, float* partial, int B, int C, int L, hipStream_t st);
+                             const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, bool finalize,
+                             int* nslot, hipStream_t st);
 hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
 // ---- optimiser ----
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,

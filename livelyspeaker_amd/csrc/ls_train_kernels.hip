@@ -517,20 +517,42 @@ hipError_t launch_im2col(const float* in, const float* stats, float* col, int B,
 
 // conv1 (Cin = 1, k 15, stride 5, pad 1600) weight gradient without an im2col: workgroup = (256-position chunk, sample),
 // thread (co, k) accumulates sum_p dC1[b][co][p] * wav[b][5p + k - 1600] from LDS; partial[(b, chunk)][co*15 + k].
+// dC1 is never materialised: k_conv_dgrad left dy = dAct * lrelu'(y) and per-row partial sums of dy and dy*y, and the
+// InstanceNorm backward d c1 = rstd * (dy - mean(dy) - y * mean(dy*y)) is applied here while the tile is staged
+// (saves one read-modify-write pass over the 517 MB tensor).
 constexpr int kC1P = 256, kC1Ld = kC1P + 4;
-__global__ __launch_bounds__(512) void k_conv1_wgrad(const float* __restrict__ dc, const float* __restrict__ wav, float* __restrict__ partial,
-                                                     int Lin, int Lout, int stride, int pad) {
+__global__ __launch_bounds__(512) void k_conv1_wgrad(const float* __restrict__ dy, const float* __restrict__ craw, const float* __restrict__ stats,
+                                                     const float* __restrict__ rowpart, int nslot, const float* __restrict__ wav,
+                                                     float* __restrict__ partial, int Lin, int Lout, int stride, int pad) {
     __shared__ __attribute__((aligned(16))) float dcs[32 * kC1Ld];
     __shared__ float wavs[kC1P * 5 + 16];
+    __shared__ float rowc[32][4];                        // mean, rstd, mean(dy), mean(dy*y) of the 32 (b, co) rows
     const int b = blockIdx.y, p0 = blockIdx.x * kC1P, tid = threadIdx.x;
-    for (int i = tid; i < 32 * kC1P; i += 512) {
-        const int co = i / kC1P, p = i % kC1P;
-        dcs[co * kC1Ld + p] = p0 + p < Lout ? dc[((size_t)b * 32 + co) * Lout + p0 + p] : 0.f;
+    if (tid < 32) {
+        const size_t row = (size_t)b * 32 + tid;
+        float a = 0.f, c2 = 0.f;
+        for (int i = 0; i < nslot; ++i) {                // fixed order
+            a += rowpart[(row * nslot + i) * 2];
+            c2 += rowpart[(row * nslot + i) * 2 + 1];
+        }
+        rowc[tid][0] = stats[row * 2];
+        rowc[tid][1] = stats[row * 2 + 1];
+        rowc[tid][2] = a / (float)Lout;
+        rowc[tid][3] = c2 / (float)Lout;
     }
     const int x0 = p0 * stride - pad;
     for (int i = tid; i < kC1P * 5 + 16; i += 512) {
         const int x = x0 + i;
-        wavs[i] = (x >= 0 && x < Lin) ? wav[(size_t)b * Lin + x] : 0.f;
+        const float v = wav[(size_t)b * Lin + min(max(x, 0), Lin - 1)];
+        wavs[i] = (x >= 0 && x < Lin) ? v : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * kC1P; i += 512) {
+        const int co = i / kC1P, p = i % kC1P;
+        const size_t o = ((size_t)b * 32 + co) * Lout + min(p0 + p, Lout - 1);
+        const float y = (craw[o] - rowc[co][0]) * rowc[co][1];
+        const float v = rowc[co][1] * (dy[o] - rowc[co][2] - y * rowc[co][3]);
+        dcs[co * kC1Ld + p] = p0 + p < Lout ? v : 0.f;
     }
     __syncthreads();
     if (tid < 480) {
@@ -548,26 +570,12 @@ __global__ __launch_bounds__(512) void k_conv1_wgrad(const float* __restrict__ d
     }
 }
 
-hipError_t launch_conv1_wgrad(const float* dc, const float* wav, float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk,
-                              hipStream_t st) {
+hipError_t launch_conv1_wgrad(const float* dy, const float* craw, const float* stats, const float* rowpart, int nslot, const float* wav,
+                              float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk, hipStream_t st) {
     if (stride != 5) return hipErrorInvalidValue;
     const int nc = (Lout + kC1P - 1) / kC1P;
     *nchunk = nc;
-    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nc, B), dim3(512), 0, st, dc, wav, partial, Lin, Lout, stride, pad);
-    return hipGetLastError();
-}
-
-// partial[b][c] = sum_x dc[b][c][x]  (-> conv bias gradient after a reduce over b)
-__global__ __launch_bounds__(64) void k_rowsum_bcl(const float* __restrict__ dc, float* __restrict__ partial, int L) {
-    const size_t row = blockIdx.x;
-    float s = 0.f;
-    for (int x = threadIdx.x; x < L; x += 64) s += dc[row * L + x];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) partial[row] = s;
-}
-
-hipError_t launch_rowsum_bcl(const float* dc, float* partial, int B, int C, int L, hipStream_t st) {
-    hipLaunchKernelGGL(k_rowsum_bcl, dim3(B * C), dim3(64), 0, st, dc, partial, L);
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nc, B), dim3(512), 0, st, dy, craw, stats, rowpart, nslot, wav, partial, Lin, Lout, stride, pad);
     return hipGetLastError();
 }
 
