@@ -15,7 +15,6 @@ import sys
 import time
 from types import SimpleNamespace
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -5,7 +5,6 @@ call.  Here both passes are rows of the same workgroup inside one launch of the 
 lerp ``out_u + scale * (out_c - out_u)`` is applied in its epilogue."""
 from __future__ import annotations
 
-import torch
 import torch.nn as nn
 
 

@@ -1,8 +1,9 @@
-import sys, time, os
-sys.path.insert(0, "/root/repo")
-import numpy as np, torch
+import sys, time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from types import SimpleNamespace
-from livelyspeaker_amd import synth, _lib
+from livelyspeaker_amd import synth
 from livelyspeaker_amd.model_util import create_model_and_diffusion
 from livelyspeaker_amd.train_loop import TrainLoop
 cfg = synth.TED; B = 512; dev = "cuda:0"
