@@ -284,3 +284,19 @@ def test_gradients_strict_on_a_batch_without_kink_proximal_activations():
         worst = max(worst, rel)
         assert rel < 2e-4, (k, rel, chosen)
     print(f"kink-free batch = step {chosen}; worst relative gradient error {worst:.2e}")
+
+
+def test_batch_size_may_change_between_steps():
+    """The last batch of an epoch is smaller and buffers grow on demand: results must not depend on the call history."""
+    import torch
+    cfg, sd, tr = make("ted")
+    _, _, fresh = make("ted")
+    x, y, noise, drop, eps = synth.make_train_batch(cfg, 6, 2)
+    t = np.array([3, 999, 500, 0, 42, 77])
+    sub = lambda s: (x[s], t[s], noise[s], {k: v[s] for k, v in y.items()}, drop[s], eps[s])
+    tr.forward_backward(*sub(slice(0, 2)))             # small first (allocates for 2) ...
+    tr.forward_backward(*sub(slice(0, 6)))             # ... grow to 6 ...
+    tr.forward_backward(*sub(slice(2, 5)))             # ... shrink to 3
+    a = tr.grad.clone()
+    fresh.forward_backward(*sub(slice(2, 5)))
+    assert torch.equal(a, fresh.grad)
