@@ -86,6 +86,14 @@ struct StepArgs {
     float c0, c1, c2, c3, c4;
     // DDPM: x' = c0*x0 + c1*x_t + nz*c2*noise
     // DDIM: eps = (c0*x_t - x0)/c1 ; x' = x0*c2 + c3*eps + nz*c4*noise
+    // ---- training-forward variant (k_step<..., TRAIN = 1>, ls_train_api.cpp): a workgroup holds samples 2b (rows 0..S-1) and
+    // 2b+1 (rows S..2S-1) of a single pass and writes every tensor the backward needs straight from registers.
+    // All are [L][tr_B*S][512] (stats [L][tr_B*S][2]); temb/temb_stride give one timestep-embedding row per SAMPLE.
+    const float* tr_x0;      // [tr_B*S][512] token sequences entering layer 0
+    float* tr_x1; float* tr_u1; float* tr_a1; float* tr_x2; float* tr_u2; float* tr_a2;
+    float* tr_s1; float* tr_s2;
+    float* tr_xout;          // [tr_B*S][512] output of the last layer
+    int tr_B;
     float* trace;            // [B][L+1][2S][512] or null
     unsigned long long* prof;  // profiling only (env LS_PROF): [8 waves][kProfPoints] s_memtime stamps of workgroup prof_wg
     int prof_wg;
@@ -97,6 +105,8 @@ enum Variant { kTED = 0, kBEAT = 1 };
 
 // prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
 hipError_t launch_step(Variant v, int prec, const StepArgs& a, int batch, hipStream_t st);
+// training forward of the mixer: ceil(tr_B / 2) workgroups (ls_step.hip, TRAIN variant)
+hipError_t launch_train_mixer_fwd(Variant v, const StepArgs& a, hipStream_t st);
 size_t step_lds_bytes(Variant v);
 hipError_t init_step_kernels();
 hipError_t init_seq_kernels();

@@ -44,8 +44,9 @@ __host__ __device__ constexpr bool tokmix_needed32(int S, int t, int ks) {
     return !(32 * ks + 31 < src_lo || 32 * ks > src_hi);
 }
 
-template <int S, int NPRE, int JF, int PREC>
+template <int S, int NPRE, int JF, int PREC, int TRAIN = 0>
 __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
+    static_assert(!TRAIN || PREC == 0, "the training forward is fp32");
     constexpr int R = 2 * S;                 // packed rows: [cond tokens | uncond tokens]
     constexpr int KXQ = (JF + 15) / 16;      // 16-wide k groups of the x_t part of input_mapping
     constexpr int KXP = KXQ * 16;
@@ -100,6 +101,25 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 
     f4 X[kCB][kNT];
 
+    // TRAIN: global row (sample * S + token) of this lane's row of tile t, or -1 when the row is padding / past the batch
+    auto grow_of = [&](int t) -> int {
+        const int r = 16 * t + s16;
+        if (r >= R) return -1;
+        const int sq = r >= S ? 1 : 0;
+        const int sample = 2 * b + sq;
+        return sample < a.tr_B ? sample * S + (r - sq * S) : -1;
+    };
+    auto store_rows = [&](float* base, int l) {                 // X (residual layout) -> [L][tr_B*S][512]
+        float* dst = base + (size_t)l * a.tr_B * S * kD;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            const int gr = grow_of(t);
+            if (gr >= 0)
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) *reinterpret_cast<f4*>(dst + (size_t)gr * kD + chw + 16 * cb) = X[cb][t];
+        }
+    };
+
     // debug-only phase stamps (LS_PROF): lane 0 of every wave of one workgroup records s_memtime
     auto stamp = [&](int idx) {
         if (a.prof && b == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
@@ -107,7 +127,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     stamp(0);
 
     // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
-    {
+    if constexpr (TRAIN) {
+        // training forward: the token sequences were assembled by the batch-level kernels (input_mapping GEMM, style /
+        // emotion tokens); load this workgroup's two samples into the residual layout
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            const int gr = grow_of(t);
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+                X[cb][t] = gr >= 0 ? *reinterpret_cast<const f4*>(a.tr_x0 + (size_t)gr * kD + chw + 16 * cb) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
         // Base value of every row first (its loads overlap the x_t staging below): frame tokens start from the
         // per-call static projection, prefix tokens from the style sample / emotion embedding.  The x_t columns of
         // input_mapping are then accumulated ONTO these by using them as the MFMA C operand.
@@ -207,7 +237,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     // cross-lane exchanges, across the 8 waves through LDS -- which is as cancellation-free as two-pass but needs
     // ONE workgroup barrier per LayerNorm instead of two.
     float mean[kNT], rstd[kNT];
-    auto ln_stats = [&]() {
+    auto ln_stats = [&](float* gstats) {
+        (void)gstats;
         if (a.ablate & 4) {
 #pragma unroll
             for (int t = 0; t < kNT; ++t) { mean[t] = 0.f; rstd[t] = 1.f; }
@@ -261,12 +292,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             }
             mean[t] = mt;
             rstd[t] = rsqrtf((m2s + 64.0f * dd) * (1.0f / kD) + 1e-5f);
+            if constexpr (TRAIN) {                        // (mean, rstd) of every row, kept for the LayerNorm backward
+                const int gr = grow_of(t);
+                if (w == 0 && g == 0 && gr >= 0) *reinterpret_cast<f2*>(gstats + (size_t)gr * 2) = (f2){mean[t], rstd[t]};
+            }
         }
     };
     // write the normalised operand of this lane's channels into the LDS buffer: LN1 applies alpha/beta here
     // (2 FMAs per element); LN2's alpha/beta are folded into the channel-mix weights/bias on the host
     // (W' = W.diag(alpha), b' = b + W.beta), so its operand is just (x - mean) * rstd: 1 FMA per element.
-    auto ln_store = [&](const float* alpha, const float* beta) {
+    auto ln_store = [&](const float* alpha, const float* beta, float* gout) {
+        (void)gout;
         float nmr[kNT];
 #pragma unroll
         for (int t = 0; t < kNT; ++t) nmr[t] = -mean[t] * rstd[t];
@@ -323,6 +359,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         *reinterpret_cast<bf4*>(&Ul[row_of(t) * kUStride + chw + 16 * cb]) = lo;
                     } else {
                         *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                        if constexpr (TRAIN) {            // the normalised operand is also an input of the weight gradients
+                            const int gr = grow_of(t);
+                            if (gr >= 0) *reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb) = u;
+                        }
                     }
                 }
         }
@@ -331,7 +371,18 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
     for (int l = 0; l < a.layers; ++l) {
         fresh();
-        {   // x = x + emb  (emb re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
+        if constexpr (TRAIN) {
+            // every sample has its own diffusion timestep: the two halves of the workgroup add different embedding rows
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                const int sample = min(2 * b + (row_of(t) >= S ? 1 : 0), a.tr_B - 1);
+                const float* te = a.temb + (size_t)sample * a.temb_stride + chw;
+                if (valid_of(t))
+#pragma unroll
+                    for (int cb = 0; cb < kCB; ++cb) X[cb][t] += *reinterpret_cast<const f4*>(te + 16 * cb);
+            }
+            store_rows(a.tr_x1, l);
+        } else {   // x = x + emb  (emb re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
             const float* te = a.temb + (size_t)b * a.temb_stride + chw;
             f4 e[kCB];
 #pragma unroll
@@ -343,10 +394,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     if (valid_of(t)) X[cb][t] += e[cb];
         }
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
-        ln_stats();
+        ln_stats(TRAIN ? a.tr_s1 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(2 + 8 * l);
         fresh();
-        ln_store(a.W->ln1a + l * kD, a.W->ln1b + l * kD);
+        ln_store(a.W->ln1a + l * kD, a.W->ln1b + l * kD, TRAIN ? a.tr_u1 + (size_t)l * a.tr_B * S * kD : nullptr);
         // no workgroup barrier here: token mixing contracts over ROWS, so wave w only reads back the 64 channel columns
         // it has just written itself (LDS operations of one wave execute in order); the LN statistics barrier above
         // already ordered these stores after every wave's reads of the previous operand.
@@ -420,6 +471,14 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     }
                 }
                 if (valid_of(t)) {
+                    if constexpr (TRAIN) {                // pre-activation of the token-mixing conv, for SiLU'
+                        const int gr = grow_of(t);
+                        if (gr >= 0) {
+                            float* dst = a.tr_a1 + ((size_t)l * a.tr_B * S + gr) * kD + chw;
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) *reinterpret_cast<f4*>(dst + 16 * cb) = acc[cb];
+                        }
+                    }
 #pragma unroll
                     for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
@@ -427,12 +486,16 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 }
             }
         }
+        if constexpr (TRAIN) store_rows(a.tr_x2, l);
         stamp(4 + 8 * l);
         fresh();
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
-        ln_stats();
+        ln_stats(TRAIN ? a.tr_s2 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(5 + 8 * l);      // its two barriers also order every wave's token-mix reads before the stores below
-        ln_store(nullptr, nullptr);
+        if constexpr (TRAIN)   // training keeps LN2's affine explicit (alpha2 / beta2 get their own gradients)
+            ln_store(a.W->ln2a + l * kD, a.W->ln2b + l * kD, a.tr_u2 + (size_t)l * a.tr_B * S * kD);
+        else
+            ln_store(nullptr, nullptr, nullptr);
         __syncthreads();
         stamp(6 + 8 * l);
         if constexpr (PREC == 1) {
@@ -614,11 +677,19 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * cb);
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t) {
+                    if constexpr (TRAIN) {                // pre-activation of the channel-mixing linear
+                        const int gr = grow_of(t);
+                        if (gr >= 0) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = acc[c2][t];
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) X[cb][t][j] = silu_acc(acc[c2][t][j], X[cb][t][j]);
                 }
                 if (s16 < NREM) {
                     const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
+                    if constexpr (TRAIN) {
+                        const int gr = grow_of(kFullTiles);
+                        if (gr >= 0) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = rv + bc;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) X[cb][kFullTiles][j] = silu_acc(rv[j] + bc[j], X[cb][kFullTiles][j]);
                 }
@@ -631,6 +702,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         dump_trace(l + 1);
     }
 
+    if constexpr (TRAIN) {         // poseFinal, the losses and everything else downstream are batch-level kernels
+        store_rows(a.tr_xout, 0);
+        return;
+    }
     // ================= OutputProcess.poseFinal (RAG.py:205-211) ====================================
     stamp(2 + 8 * a.layers);
     fresh();
@@ -774,14 +849,24 @@ size_t step_lds_bytes(Variant v) {
 
 // Opt in to >64 KiB dynamic LDS once per process (must happen outside stream capture).
 hipError_t init_step_kernels() {
-    const void* ks[4] = {reinterpret_cast<const void*>(k_step<35, 1, 27, 0>), reinterpret_cast<const void*>(k_step<35, 1, 27, 1>),
-                         reinterpret_cast<const void*>(k_step<36, 2, 282, 0>), reinterpret_cast<const void*>(k_step<36, 2, 282, 1>)};
-    for (int i = 0; i < 4; ++i) {
+    const void* ks[6] = {reinterpret_cast<const void*>(k_step<35, 1, 27, 0>), reinterpret_cast<const void*>(k_step<35, 1, 27, 1>),
+                         reinterpret_cast<const void*>(k_step<35, 1, 27, 0, 1>),
+                         reinterpret_cast<const void*>(k_step<36, 2, 282, 0>), reinterpret_cast<const void*>(k_step<36, 2, 282, 1>),
+                         reinterpret_cast<const void*>(k_step<36, 2, 282, 0, 1>)};
+    for (int i = 0; i < 6; ++i) {
         hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)step_lds_bytes(i < 2 ? kTED : kBEAT));
+                                           (int)step_lds_bytes(i < 3 ? kTED : kBEAT));
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t launch_train_mixer_fwd(Variant v, const StepArgs& a, hipStream_t st) {
+    const size_t lds = step_lds_bytes(v);
+    const int wgs = (a.tr_B + 1) / 2;
+    if (v == kTED) hipLaunchKernelGGL((k_step<35, 1, 27, 0, 1>), dim3(wgs), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((k_step<36, 2, 282, 0, 1>), dim3(wgs), dim3(512), lds, st, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_step(Variant v, int prec, const StepArgs& a, int batch, hipStream_t st) {

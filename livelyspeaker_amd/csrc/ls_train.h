@@ -51,15 +51,19 @@ struct TrainDims { int B, S, T, NPRE, JF, KF, KFP, D, L; };   // KF = 2*JF+1+256
 // ---- forward ----
 hipError_t launch_build_feat_train(const float* x_start, const float* noise, const float* origin_x, const float* c4, const float* drop,
                                    const float* ca, const float* cb, float* feat, float* x_t, TrainDims d, int n_pre_seq, hipStream_t st);
-hipError_t launch_ln_fwd(const float* xin, const float* emb, int S, float* x1, float* u, float* stats, const float* alpha,
-                         const float* beta, int rows, hipStream_t st);
-hipError_t launch_tokmix_fwd(const float* u, const float* x1, const float* wt, const float* bt, float* a1, float* x2, int B, int S,
-                             hipStream_t st);
 hipError_t launch_style_fwd(const float* mu, const float* lv, const float* eps, const float* emo_w, const int64_t* emo, int emo_stride,
                             float* x0, float* kld_partial, int B, int S, int NPRE, hipStream_t st);
 hipError_t launch_loss(const float* out, const float* x_start, float* dout, float* partial, TrainDims d, float lambda_vel, hipStream_t st);
 hipError_t launch_finish_terms(const float* loss_partial, int n_loss, const float* kld_partial, int n_kld, float* terms, TrainDims d,
                                float lambda_vel, float kld_weight, hipStream_t st);
+// mixer weight images for the fused training forward (k_step TRAIN variant): flat-parameter offsets in, images out
+struct TrainImgArgs {
+    const float* P;
+    long long base, lstride, o_a1, o_b1, o_wt, o_bt, o_a2, o_b2, o_w, o_b;     // layer 0 base, per-layer stride, offsets inside a layer
+    int L, S, MK;
+    float* wch; float* bch; float* ww; float* btok; float* l1a; float* l1b; float* l2a; float* l2b;
+};
+hipError_t launch_build_train_images(const TrainImgArgs& a, hipStream_t st);
 // ---- backward ----
 hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, float* partial, int rows, int nwaves, hipStream_t st);
 hipError_t launch_ln_bwd(const float* du, const float* x, const float* stats, const float* alpha, float* g, float* partial, int rows,

@@ -63,7 +63,9 @@ struct ls_trainer {
     int capB = 0;
     Buf x_start, noise, drop, eps, audio, origin_x, vid, emo, ca, cb, tidx;
     Buf c[4], st[3], img[4], dimg[4], feat, x_t, zc, mu, lv, pe_rows, pre1, hid, emb, xcur;
-    std::vector<Buf> X1, A1, X2, A2, U1, U2, S1, S2;
+    Buf X1, A1, X2, A2, U1, U2, S1, S2;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward
+    Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw;    // mixer weight images + the DevWeights block k_step reads
+    TrainImgArgs img_args{};
     Buf out, dout, lossp, kldp, terms, G, T1, T2, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dc[3], ws;
     size_t ws_floats = 0;
     int B = 0;
@@ -147,14 +149,8 @@ int ensure_batch(ls_trainer* h, int B) {
     HIPCHK(h, E(h->zc, (size_t)B * kSpk)); HIPCHK(h, E(h->dzc, (size_t)B * kSpk));
     for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));
     for (Buf* b : {&h->xcur, &h->G, &h->T1, &h->T2}) HIPCHK(h, E(*b, R * kD));
-    for (auto* v : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2}) {
-        v->resize(d0.L);
-        for (auto& b : *v) HIPCHK(h, E(b, R * kD));
-    }
-    for (auto* v : {&h->S1, &h->S2}) {
-        v->resize(d0.L);
-        for (auto& b : *v) HIPCHK(h, E(b, R * 2));
-    }
+    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2}) HIPCHK(h, E(*b, (size_t)d0.L * R * kD));
+    for (Buf* b : {&h->S1, &h->S2}) HIPCHK(h, E(*b, (size_t)d0.L * R * 2));
     HIPCHK(h, E(h->out, (size_t)B * d0.T * d0.JF)); HIPCHK(h, E(h->dout, (size_t)B * d0.T * d0.JF));
     HIPCHK(h, E(h->lossp, 2 * ((size_t)B * d0.JF / 256 + 2))); HIPCHK(h, E(h->kldp, B)); HIPCHK(h, E(h->terms, 8));
     HIPCHK(h, E(h->part, (size_t)kNW * 2 * kD + (size_t)B * 128 + 4096 * 512 + (size_t)B * 32 * 2 * 2 * ((L[1] + 5) / 6 / 64 + 1)));
@@ -178,6 +174,10 @@ int ensure_batch(ls_trainer* h, int B) {
     h->capB = B;
     return LS_OK;
 }
+
+// layer l of a saved-activation family [L][R][512] / statistics [L][R][2]
+static inline float* lay(const Buf& b, int l, int R) { return b.f() + (size_t)l * R * kD; }
+static inline float* lay2(const Buf& b, int l, int R) { return b.f() + (size_t)l * R * 2; }
 
 // locals shared by the stages of one step
 #define TRAIN_LOCALS(h, d)                                                                                   \
@@ -240,16 +240,20 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         b2.bias = P(h, "backbone.embed_timestep.time_embed.2.bias");
         HIPCHK(h, launch_gemm_tr(b2, true, true, 1, st));
     }
-    for (int l = 0; l < d.L; ++l) {   // MLPblock.forward (mlp_module.py:67-74)
-        HIPCHK(h, launch_ln_fwd(h->xcur.f(), h->emb.f(), S, h->X1[l].f(), h->U1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")),
-                                P(h, lk(l, "block1.0.beta")), R, st));
-        HIPCHK(h, launch_tokmix_fwd(h->U1[l].f(), h->X1[l].f(), P(h, lk(l, "block1.1.weight")), P(h, lk(l, "block1.1.bias")), h->A1[l].f(),
-                                    h->X2[l].f(), B, S, st));
-        HIPCHK(h, launch_ln_fwd(h->X2[l].f(), nullptr, S, nullptr, h->U2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")),
-                                P(h, lk(l, "block2.0.beta")), R, st));
-        GemmArgs a = gemm(op_rows(h->U2[l].f(), kD, R, kD), op_rows(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->xcur.f(), kD, R, kD, kD);
-        a.bias = P(h, lk(l, "block2.1.bias")); a.Cpre = h->A2[l].f(); a.act = 1; a.R = h->X2[l].f();
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+    {   // TransMLP: all 8 MLPblocks (mlp_module.py:67-91) in ONE launch of the fused kernel the sampler uses (ls_step.hip,
+        // TRAIN variant): a workgroup keeps two samples' residual streams in registers and writes X1 / U1 / A1 / X2 / U2 / A2
+        // and the LayerNorm statistics of every layer for the backward; the last layer's output lands back in xcur.
+        h->img_args.P = h->P.f();
+        HIPCHK(h, launch_build_train_images(h->img_args, st));
+        StepArgs a{};
+        a.temb = h->emb.f(); a.temb_stride = kD;
+        a.W = static_cast<const DevWeights*>(h->tdevw.p);
+        a.layers = d.L;
+        a.sampler = kNone;
+        a.tr_x0 = h->xcur.f(); a.tr_xout = h->xcur.f(); a.tr_B = B;
+        a.tr_x1 = h->X1.f(); a.tr_u1 = h->U1.f(); a.tr_a1 = h->A1.f(); a.tr_x2 = h->X2.f(); a.tr_u2 = h->U2.f(); a.tr_a2 = h->A2.f();
+        a.tr_s1 = h->S1.f(); a.tr_s2 = h->S2.f();
+        HIPCHK(h, launch_train_mixer_fwd(d.NPRE == 2 ? kBEAT : kTED, a, st));
     }
     {   // OutputProcess.poseFinal on the frame rows (RAG.py:128-129, 205-211)
         GemmArgs a = gemm(gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
@@ -279,22 +283,22 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
     }
     for (int l = d.L - 1; l >= 0; --l) {
         // block2: x3 = x2 + SiLU(LN2(x2) Wch^T + b)
-        HIPCHK(h, launch_silu_bwd_colsum(h->G.f(), h->A2[l].f(), h->T1.f(), part, R, kNW, st));
+        HIPCHK(h, launch_silu_bwd_colsum(h->G.f(), lay(h->A2, l, R), h->T1.f(), part, R, kNW, st));
         HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, lk(l, "block2.1.bias")), 0, st));
-        HIPCHK(h, wgrad(h, op_cols(h->T1.f(), kD, kD, R), op_cols(h->U2[l].f(), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")), kD,
+        HIPCHK(h, wgrad(h, op_cols(h->T1.f(), kD, kD, R), op_cols(lay(h->U2, l, R), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")), kD,
                         kD, kD, R));
         {
             GemmArgs a = gemm(op_rows(h->T1.f(), kD, R, kD), op_cols(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->T2.f(), kD, R, kD, kD);
             HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
         }
-        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X2[l].f(), h->S2[l].f(), P(h, lk(l, "block2.0.alpha")), h->G.f(), part, R, kNW, st));
+        HIPCHK(h, launch_ln_bwd(h->T2.f(), lay(h->X2, l, R), lay2(h->S2, l, R), P(h, lk(l, "block2.0.alpha")), h->G.f(), part, R, kNW, st));
         // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
         HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
         // block1: x2 = x1 + SiLU(Wt LN1(x1) + bt)
-        HIPCHK(h, launch_tokmix_bwd(h->G.f(), h->A1[l].f(), h->U1[l].f(), P(h, lk(l, "block1.1.weight")), h->T2.f(), h->pw.f(), h->pb.f(), B, S, st));
+        HIPCHK(h, launch_tokmix_bwd(h->G.f(), lay(h->A1, l, R), lay(h->U1, l, R), P(h, lk(l, "block1.1.weight")), h->T2.f(), h->pw.f(), h->pb.f(), B, S, st));
         HIPCHK(h, launch_partial_reduce(h->pw.f(), B * 4, (long long)S * S, S * S, Gr(h, grad, lk(l, "block1.1.weight")), 0, st));
         HIPCHK(h, launch_partial_reduce(h->pb.f(), B * 4, S, S, Gr(h, grad, lk(l, "block1.1.bias")), 0, st));
-        HIPCHK(h, launch_ln_bwd(h->T2.f(), h->X1[l].f(), h->S1[l].f(), P(h, lk(l, "block1.0.alpha")), h->G.f(), part, R, kNW, st));
+        HIPCHK(h, launch_ln_bwd(h->T2.f(), lay(h->X1, l, R), lay2(h->S1, l, R), P(h, lk(l, "block1.0.alpha")), h->G.f(), part, R, kNW, st));
         // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
         HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
         HIPCHK(h, launch_tok_sum(h->G.f(), h->demb.f(), B, S, l != d.L - 1, st));
@@ -455,6 +459,30 @@ int ls_train_create(const ls_train_config* cfg, ls_trainer** out) {
         if ((e = h->img[i].ensure((size_t)kCout[i] * kCin[i] * 15 * 4)) != hipSuccess) return bail("hipMalloc(img)", e);
         if ((e = h->dimg[i].ensure((size_t)kCout[i] * kCin[i] * 16 * 4)) != hipSuccess) return bail("hipMalloc(dimg)", e);
     }
+    {   // mixer weight images of the fused training forward (rebuilt from the master parameters every step)
+        const int MK = (2 * d.S + 3) / 4;
+        const size_t nimg[8] = {(size_t)d.L * kD * kD, (size_t)d.L * kD, (size_t)d.L * 5 * MK * 64, (size_t)d.L * 80,
+                                (size_t)d.L * kD, (size_t)d.L * kD, (size_t)d.L * kD, (size_t)d.L * kD};
+        Buf* ib[8] = {&h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a, &h->tl2b};
+        for (int i = 0; i < 8; ++i)
+            if ((e = ib[i]->ensure(nimg[i] * 4)) != hipSuccess) return bail("hipMalloc(train images)", e);
+        DevWeights dw{};
+        dw.wch_img = h->twch.f(); dw.bch = h->tbch.f(); dw.ww_img = h->tww.f(); dw.btok_rows = h->tbtok.f();
+        dw.ln1a = h->tl1a.f(); dw.ln1b = h->tl1b.f(); dw.ln2a = h->tl2a.f(); dw.ln2b = h->tl2b.f();
+        if ((e = h->tdevw.ensure(sizeof dw)) != hipSuccess) return bail("hipMalloc(DevWeights)", e);
+        if ((e = hipMemcpy(h->tdevw.p, &dw, sizeof dw, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(DevWeights)", e);
+        auto off = [&](int l, const char* sfx) { return h->table[h->index.at(lk(l, sfx))].off; };
+        TrainImgArgs& ia = h->img_args;
+        ia.base = off(0, "block1.0.alpha");
+        ia.lstride = d.L > 1 ? off(1, "block1.0.alpha") - ia.base : 0;
+        ia.o_a1 = 0; ia.o_b1 = off(0, "block1.0.beta") - ia.base; ia.o_wt = off(0, "block1.1.weight") - ia.base;
+        ia.o_bt = off(0, "block1.1.bias") - ia.base; ia.o_a2 = off(0, "block2.0.alpha") - ia.base; ia.o_b2 = off(0, "block2.0.beta") - ia.base;
+        ia.o_w = off(0, "block2.1.weight") - ia.base; ia.o_b = off(0, "block2.1.bias") - ia.base;
+        ia.L = d.L; ia.S = d.S; ia.MK = MK;
+        ia.wch = h->twch.f(); ia.bch = h->tbch.f(); ia.ww = h->tww.f(); ia.btok = h->tbtok.f();
+        ia.l1a = h->tl1a.f(); ia.l1b = h->tl1b.f(); ia.l2a = h->tl2a.f(); ia.l2b = h->tl2b.f();
+        if ((e = init_step_kernels()) != hipSuccess) return bail("hipFuncSetAttribute(k_step)", e);
+    }
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("sync", e);
     *out = h;
     return LS_OK;
@@ -470,7 +498,9 @@ void ls_train_destroy(ls_trainer* h) {
                              &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->col, &h->ws};
     for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
-    for (auto* v : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->S1, &h->S2}) for (auto& b : *v) all.push_back(&b);
+    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->S1, &h->S2, &h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a,
+                   &h->tl2b, &h->tdevw})
+        all.push_back(b);
     for (Buf* b : all) b->release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -57,45 +57,6 @@ hipError_t launch_build_feat_train(const float* x_start, const float* noise, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LN_spatial forward (mlp_module.py:21-35), optionally preceded by the timestep-embedding add (MLPblock.forward :68-69)
-__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ xin, const float* __restrict__ emb, int S,
-                                                float* __restrict__ x1, float* __restrict__ u, float* __restrict__ stats,
-                                                const float* __restrict__ alpha, const float* __restrict__ beta, int rows) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const f4* xr = reinterpret_cast<const f4*>(xin + (size_t)row * kDm);
-    f4 a = xr[lane], b = xr[64 + lane];
-    if (emb) {
-        const f4* er = reinterpret_cast<const f4*>(emb + (size_t)(row / S) * kDm);
-        a += er[lane];
-        b += er[64 + lane];
-        f4* o = reinterpret_cast<f4*>(x1 + (size_t)row * kDm);
-        o[lane] = a;
-        o[64 + lane] = b;
-    }
-    const float mean = wave_sum((a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3])) * (1.0f / kDm);
-    const f4 da = a - mean, db = b - mean;
-    const float var = wave_sum((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3]) + (db[0] * db[0] + db[1] * db[1]) +
-                               (db[2] * db[2] + db[3] * db[3])) * (1.0f / kDm);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    const f4* al = reinterpret_cast<const f4*>(alpha);
-    const f4* be = reinterpret_cast<const f4*>(beta);
-    f4* uo = reinterpret_cast<f4*>(u + (size_t)row * kDm);
-    uo[lane] = da * rstd * al[lane] + be[lane];
-    uo[64 + lane] = db * rstd * al[64 + lane] + be[64 + lane];
-    if (lane == 0) {
-        stats[(size_t)row * 2] = mean;
-        stats[(size_t)row * 2 + 1] = rstd;
-    }
-}
-
-hipError_t launch_ln_fwd(const float* xin, const float* emb, int S, float* x1, float* u, float* stats, const float* alpha,
-                         const float* beta, int rows, hipStream_t st) {
-    hipLaunchKernelGGL(k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, st, xin, emb, S, x1, u, stats, alpha, beta, rows);
-    return hipGetLastError();
-}
-
 // LN_spatial backward: g[row] += rstd * (gy - mean(gy) - xhat * mean(gy * xhat)), gy = du * alpha; per-wave partial
 // column sums of du*xhat (-> d alpha) and du (-> d beta) in partial[wave][2][512]
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ stats,
@@ -163,43 +124,10 @@ hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Token mixing (Conv1d(S,S,1) over the token axis, mlp_module.py:51-55): a1[b][s'][c] = bt[s'] + sum_s wt[s'][s] u[b][s][c];
-// x2 = x1 + SiLU(a1).  Workgroup = (sample, 128-channel slab); every thread register-tiles 4 outputs so that each pair of
-// LDS operand reads feeds 4 FMAs (the kernels are LDS-bandwidth bound).
+// Token mixing (Conv1d(S,S,1) over the token axis, mlp_module.py:51-55), backward.  (The forward runs inside the fused
+// training-forward kernel, ls_step.hip TRAIN variant.)  Workgroup = (sample, 128-channel slab); every thread register-tiles
+// its outputs so that each pair of LDS operand reads feeds 4 FMAs (the kernel is LDS-bandwidth bound).
 constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36, kTokWs = kTokMaxS + 4;     // ws rows padded to 40 (float4 reads)
-
-__global__ __launch_bounds__(256) void k_tokmix_fwd(const float* __restrict__ u, const float* __restrict__ x1, const float* __restrict__ wt,
-                                                    const float* __restrict__ bt, float* __restrict__ a1, float* __restrict__ x2, int S) {
-    __shared__ float us[kTokMaxS * kTokLd];
-    __shared__ __attribute__((aligned(16))) float wsT[kTokMaxS * kTokWs];       // wsT[s][s'] = wt[s'][s]
-    const int b = blockIdx.x, c0 = blockIdx.y * kTokC, tid = threadIdx.x;
-    for (int i = tid; i < S * kTokC; i += 256) us[(i / kTokC) * kTokLd + (i % kTokC)] = u[((size_t)b * S + i / kTokC) * kDm + c0 + (i % kTokC)];
-    for (int i = tid; i < kTokMaxS * kTokWs; i += 256) {
-        const int s = i / kTokWs, sp = i % kTokWs;
-        wsT[i] = (s < S && sp < S) ? wt[sp * S + s] : 0.f;
-    }
-    __syncthreads();
-    const int c = tid & (kTokC - 1);
-    for (int sp0 = 4 * (tid >> 7); sp0 < S; sp0 += 8) {          // 4 output tokens sp0..sp0+3 per thread
-        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < S; ++s) acc += *reinterpret_cast<const f4*>(&wsT[s * kTokWs + sp0]) * us[s * kTokLd + c];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (sp0 + e >= S) break;
-            const float v = acc[e] + bt[sp0 + e];
-            const size_t o = ((size_t)b * S + sp0 + e) * kDm + c0 + c;
-            a1[o] = v;
-            x2[o] = x1[o] + silu_f_(v);
-        }
-    }
-}
-
-hipError_t launch_tokmix_fwd(const float* u, const float* x1, const float* wt, const float* bt, float* a1, float* x2, int B, int S,
-                             hipStream_t st) {
-    if (S > kTokMaxS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tokmix_fwd, dim3(B, kDm / kTokC), dim3(256), 0, st, u, x1, wt, bt, a1, x2, S);
-    return hipGetLastError();
-}
 
 // backward: da = g * silu'(a1); du[b][s][c] = sum_s' wt[s'][s] da[s'][c]; per-workgroup partials
 // pw[(b,slab)][s'][s] = sum_c da[s'][c] u1[s][c], pb[(b,slab)][s'] = sum_c da[s'][c]
@@ -596,6 +524,50 @@ __global__ void k_build_conv_img(const float* __restrict__ w, float* __restrict_
 hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st) {
     const size_t total = (size_t)Cout * Cin * 15;
     hipLaunchKernelGGL(k_build_conv_img, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, img, Cin, Cout);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-lane MFMA operand images of the mixer weights for the fused training forward (k_step TRAIN variant), rebuilt from
+// the flat master parameters after every optimiser step.  Same layouts as ls_api.cpp build_images, except that LN2's
+// affine is NOT folded into the channel-mix weights (alpha2 / beta2 are trained):
+//   wch[l][w][p][q][c2][lane][j] = W_l[n = 64w + 16(2p+c2) + (lane&15)][k = 16q + 4(lane>>4) + j]
+//   ww[l][t][m][lane] = blockdiag(Wt_l, Wt_l)[r = 16t + (lane&15)][r' = 4m + (lane>>4)],  btok[l][r] = bt_l[r % S]
+__global__ void k_build_train_images(const TrainImgArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int R = 2 * a.S;
+    if (i < (size_t)a.L * kDm * kDm) {
+        const int j = (int)(i & 3), lane = (int)((i >> 2) & 63), c2 = (int)((i >> 8) & 1), q = (int)((i >> 9) & 31);
+        const int p = (int)((i >> 14) & 1), w = (int)((i >> 15) & 7), l = (int)(i >> 18);
+        const int n = 64 * w + 16 * (2 * p + c2) + (lane & 15), k = 16 * q + 4 * (lane >> 4) + j;
+        a.wch[i] = a.P[a.base + (long long)l * a.lstride + a.o_w + (long long)n * kDm + k];
+    }
+    if (i < (size_t)a.L * 5 * a.MK * 64) {
+        const int lane = (int)(i & 63);
+        size_t rr = i >> 6;
+        const int m = (int)(rr % a.MK); rr /= a.MK;
+        const int t = (int)(rr % 5), l = (int)(rr / 5);
+        const int r = 16 * t + (lane & 15), rp = 4 * m + (lane >> 4);
+        float v = 0.f;
+        if (r < R && rp < R && r / a.S == rp / a.S) v = a.P[a.base + (long long)l * a.lstride + a.o_wt + (long long)(r % a.S) * a.S + (rp % a.S)];
+        a.ww[i] = v;
+    }
+    if (i < (size_t)a.L * 80) {
+        const int l = (int)(i / 80), r = (int)(i % 80);
+        a.btok[i] = r < R ? a.P[a.base + (long long)l * a.lstride + a.o_bt + (r % a.S)] : 0.f;
+    }
+    if (i < (size_t)a.L * kDm) {
+        const int l = (int)(i / kDm), c = (int)(i % kDm);
+        const long long lb = a.base + (long long)l * a.lstride;
+        a.bch[i] = a.P[lb + a.o_b + c];
+        a.l1a[i] = a.P[lb + a.o_a1 + c]; a.l1b[i] = a.P[lb + a.o_b1 + c];
+        a.l2a[i] = a.P[lb + a.o_a2 + c]; a.l2b[i] = a.P[lb + a.o_b2 + c];
+    }
+}
+
+hipError_t launch_build_train_images(const TrainImgArgs& a, hipStream_t st) {
+    const size_t total = (size_t)a.L * kDm * kDm;
+    hipLaunchKernelGGL(k_build_train_images, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
