@@ -25,25 +25,6 @@
 
 namespace ls {
 
-__host__ __device__ constexpr bool tokmix_needed(int S, int t, int m) {
-    const int R = 2 * S;
-    const int r_lo = 16 * t;
-    if (r_lo >= R) return false;
-    const int r_hi = (16 * t + 15 < R - 1) ? 16 * t + 15 : R - 1;
-    const int src_lo = (r_lo / S) * S, src_hi = (r_hi / S + 1) * S - 1;
-    return !(4 * m + 3 < src_lo || 4 * m > src_hi);
-}
-
-// same for the bf16 token-mix MFMA, whose k step covers 32 source rows
-__host__ __device__ constexpr bool tokmix_needed32(int S, int t, int ks) {
-    const int R = 2 * S;
-    const int r_lo = 16 * t;
-    if (r_lo >= R) return false;
-    const int r_hi = (16 * t + 15 < R - 1) ? 16 * t + 15 : R - 1;
-    const int src_lo = (r_lo / S) * S, src_hi = (r_hi / S + 1) * S - 1;
-    return !(32 * ks + 31 < src_lo || 32 * ks > src_hi);
-}
-
 template <int S, int NPRE, int JF, int PREC, int TRAIN = 0>
 __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     static_assert(!TRAIN || PREC == 0, "the training forward is fp32");

@@ -31,4 +31,24 @@ __device__ __forceinline__ gf4p g4(const float* p) { return (gf4p)(const f4*)p; 
 __device__ __forceinline__ gfp g1(const float* p) { return (gfp)p; }
 
 
+// which (tile, k step) pairs of the block-diagonal token-mixing GEMM touch a non-zero block
+__host__ __device__ constexpr bool tokmix_needed(int S, int t, int m) {
+    const int R = 2 * S;
+    const int r_lo = 16 * t;
+    if (r_lo >= R) return false;
+    const int r_hi = (16 * t + 15 < R - 1) ? 16 * t + 15 : R - 1;
+    const int src_lo = (r_lo / S) * S, src_hi = (r_hi / S + 1) * S - 1;
+    return !(4 * m + 3 < src_lo || 4 * m > src_hi);
+}
+
+// same for the bf16 token-mix MFMA, whose k step covers 32 source rows
+__host__ __device__ constexpr bool tokmix_needed32(int S, int t, int ks) {
+    const int R = 2 * S;
+    const int r_lo = 16 * t;
+    if (r_lo >= R) return false;
+    const int r_hi = (16 * t + 15 < R - 1) ? 16 * t + 15 : R - 1;
+    const int src_lo = (r_lo / S) * S, src_hi = (r_hi / S + 1) * S - 1;
+    return !(32 * ks + 31 < src_lo || 32 * ks > src_hi);
+}
+
 }  // namespace ls

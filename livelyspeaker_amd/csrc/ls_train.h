@@ -62,8 +62,22 @@ struct TrainImgArgs {
     long long base, lstride, o_a1, o_b1, o_wt, o_bt, o_a2, o_b2, o_w, o_b;     // layer 0 base, per-layer stride, offsets inside a layer
     int L, S, MK;
     float* wch; float* bch; float* ww; float* btok; float* l1a; float* l1b; float* l2a; float* l2b;
+    float* wchT; float* wwT;      // transposed images for the fused backward (dU = dA . W)
 };
 hipError_t launch_build_train_images(const TrainImgArgs& a, hipStream_t st);
+// fused mixer backward (ls_train_bwd.hip): saved activations in, dA2 / dA1 (weight-gradient operands) and partials out
+struct MixerBwdArgs {
+    float* g;                 // [B*S][512] in: d loss / d mixer output; out: d loss / d token sequences entering layer 0
+    const float* a2; const float* a1; const float* x2; const float* x1; const float* s2; const float* s1;   // [L][B*S][512 | 2]
+    float* da2; float* da1;   // [L][B*S][512]
+    float* scratch;           // [workgroups][2S][512]
+    float* colpart;           // [workgroups][L][5][512]: d bias(block2), d alpha2, d beta2, d alpha1, d beta1 partial column sums
+    float* dembp;             // [L][B][512] per-layer d(timestep embedding)
+    const float* wchT_img; const float* wwT_img; const float* ln2a; const float* ln1a;   // images / [L][512]
+    int B, layers;
+};
+hipError_t init_mixer_bwd();
+hipError_t launch_mixer_bwd(Variant v, const MixerBwdArgs& a, hipStream_t st);
 // ---- backward ----
 hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, float* partial, int rows, int nwaves, hipStream_t st);
 hipError_t launch_ln_bwd(const float* du, const float* x, const float* stats, const float* alpha, float* g, float* partial, int rows,

@@ -63,8 +63,8 @@ struct ls_trainer {
     int capB = 0;
     Buf x_start, noise, drop, eps, audio, origin_x, vid, emo, ca, cb, tidx;
     Buf c[4], st[3], img[4], dimg[4], feat, x_t, zc, mu, lv, pe_rows, pre1, hid, emb, xcur;
-    Buf X1, A1, X2, A2, U1, U2, S1, S2;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward
-    Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw;    // mixer weight images + the DevWeights block k_step reads
+    Buf X1, A1, X2, A2, U1, U2, S1, S2, dA2, dA1, colpart, dembp;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward
+    Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw, twchT, twwT;    // mixer weight images + the DevWeights block k_step reads
     TrainImgArgs img_args{};
     Buf out, dout, lossp, kldp, terms, G, T1, T2, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dc[3], ws;
     size_t ws_floats = 0;
@@ -148,8 +148,10 @@ int ensure_batch(ls_trainer* h, int B) {
     HIPCHK(h, E(h->feat, (size_t)B * d0.T * d0.KFP));
     HIPCHK(h, E(h->zc, (size_t)B * kSpk)); HIPCHK(h, E(h->dzc, (size_t)B * kSpk));
     for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));
-    for (Buf* b : {&h->xcur, &h->G, &h->T1, &h->T2}) HIPCHK(h, E(*b, R * kD));
-    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2}) HIPCHK(h, E(*b, (size_t)d0.L * R * kD));
+    for (Buf* b : {&h->xcur, &h->G, &h->T2}) HIPCHK(h, E(*b, R * kD));
+    HIPCHK(h, E(h->T1, (size_t)((B + 1) / 2) * 2 * d0.S * kD));      // gy slabs of the fused mixer backward
+    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->dA2, &h->dA1}) HIPCHK(h, E(*b, (size_t)d0.L * R * kD));
+    HIPCHK(h, E(h->colpart, (size_t)((B + 1) / 2) * d0.L * 5 * kD)); HIPCHK(h, E(h->dembp, (size_t)d0.L * B * kD));
     for (Buf* b : {&h->S1, &h->S2}) HIPCHK(h, E(*b, (size_t)d0.L * R * 2));
     HIPCHK(h, E(h->out, (size_t)B * d0.T * d0.JF)); HIPCHK(h, E(h->dout, (size_t)B * d0.T * d0.JF));
     HIPCHK(h, E(h->lossp, 2 * ((size_t)B * d0.JF / 256 + 2))); HIPCHK(h, E(h->kldp, B)); HIPCHK(h, E(h->terms, 8));
@@ -281,28 +283,34 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
         a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
         HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
     }
+    // All 8 MLPblocks backward in ONE launch (ls_train_bwd.hip): G stays in registers across the layers; the kernel leaves
+    // dA2 / dA1 for the batch-level weight-gradient products below, per-workgroup partial column sums for the bias and
+    // LayerNorm parameters, the per-layer d(timestep embedding) and, in G, the gradient of the layer-0 input.
+    const int nwg = (B + 1) / 2;
+    {
+        MixerBwdArgs a{};
+        a.g = h->G.f();
+        a.a2 = h->A2.f(); a.a1 = h->A1.f(); a.x2 = h->X2.f(); a.x1 = h->X1.f(); a.s2 = h->S2.f(); a.s1 = h->S1.f();
+        a.da2 = h->dA2.f(); a.da1 = h->dA1.f(); a.scratch = h->T1.f(); a.colpart = h->colpart.f(); a.dembp = h->dembp.f();
+        a.wchT_img = h->twchT.f(); a.wwT_img = h->twwT.f(); a.ln2a = h->tl2a.f(); a.ln1a = h->tl1a.f();
+        a.B = B; a.layers = d.L;
+        HIPCHK(h, launch_mixer_bwd(d.NPRE == 2 ? kBEAT : kTED, a, st));
+    }
+    const long long cps = (long long)d.L * 5 * kD;          // stride between workgroups in colpart
     for (int l = d.L - 1; l >= 0; --l) {
-        // block2: x3 = x2 + SiLU(LN2(x2) Wch^T + b)
-        HIPCHK(h, launch_silu_bwd_colsum(h->G.f(), lay(h->A2, l, R), h->T1.f(), part, R, kNW, st));
-        HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, lk(l, "block2.1.bias")), 0, st));
-        HIPCHK(h, wgrad(h, op_cols(h->T1.f(), kD, kD, R), op_cols(lay(h->U2, l, R), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")), kD,
-                        kD, kD, R));
-        {
-            GemmArgs a = gemm(op_rows(h->T1.f(), kD, R, kD), op_cols(P(h, lk(l, "block2.1.weight")), kD, kD, kD), h->T2.f(), kD, R, kD, kD);
-            HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
-        }
-        HIPCHK(h, launch_ln_bwd(h->T2.f(), lay(h->X2, l, R), lay2(h->S2, l, R), P(h, lk(l, "block2.0.alpha")), h->G.f(), part, R, kNW, st));
-        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
-        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
-        // block1: x2 = x1 + SiLU(Wt LN1(x1) + bt)
-        HIPCHK(h, launch_tokmix_bwd(h->G.f(), lay(h->A1, l, R), lay(h->U1, l, R), P(h, lk(l, "block1.1.weight")), h->T2.f(), h->pw.f(), h->pb.f(), B, S, st));
+        const float* cp = h->colpart.f() + (size_t)l * 5 * kD;
+        HIPCHK(h, launch_partial_reduce(cp, nwg, cps, kD, Gr(h, grad, lk(l, "block2.1.bias")), 0, st));
+        // alpha and beta are adjacent in the flat layout and in colpart: one reduce writes both
+        HIPCHK(h, launch_partial_reduce(cp + kD, nwg, cps, 2 * kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
+        HIPCHK(h, launch_partial_reduce(cp + 3 * kD, nwg, cps, 2 * kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
+        HIPCHK(h, wgrad(h, op_cols(lay(h->dA2, l, R), kD, kD, R), op_cols(lay(h->U2, l, R), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")),
+                        kD, kD, kD, R));
+        // token weights: dWt[s'][s] = sum_{b,c} dA1[b][s'][c] U1[b][s][c], d bt[s'] = sum_{b,c} dA1[b][s'][c]
+        HIPCHK(h, launch_tokmix_bwd(lay(h->dA1, l, R), nullptr, lay(h->U1, l, R), nullptr, nullptr, h->pw.f(), h->pb.f(), B, S, st));
         HIPCHK(h, launch_partial_reduce(h->pw.f(), B * 4, (long long)S * S, S * S, Gr(h, grad, lk(l, "block1.1.weight")), 0, st));
         HIPCHK(h, launch_partial_reduce(h->pb.f(), B * 4, S, S, Gr(h, grad, lk(l, "block1.1.bias")), 0, st));
-        HIPCHK(h, launch_ln_bwd(h->T2.f(), lay(h->X1, l, R), lay2(h->S1, l, R), P(h, lk(l, "block1.0.alpha")), h->G.f(), part, R, kNW, st));
-        // alpha and beta are adjacent in the flat layout: one reduce writes both ([wave][d alpha 512 | d beta 512])
-        HIPCHK(h, launch_partial_reduce(part, kNW, 2 * kD, 2 * kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
-        HIPCHK(h, launch_tok_sum(h->G.f(), h->demb.f(), B, S, l != d.L - 1, st));
     }
+    HIPCHK(h, launch_partial_reduce(h->dembp.f(), d.L, (long long)B * kD, B * kD, h->demb.f(), 0, st));
     return LS_OK;
 }
 
@@ -481,7 +489,9 @@ int ls_train_create(const ls_train_config* cfg, ls_trainer** out) {
         ia.L = d.L; ia.S = d.S; ia.MK = MK;
         ia.wch = h->twch.f(); ia.bch = h->tbch.f(); ia.ww = h->tww.f(); ia.btok = h->tbtok.f();
         ia.l1a = h->tl1a.f(); ia.l1b = h->tl1b.f(); ia.l2a = h->tl2a.f(); ia.l2b = h->tl2b.f();
-        if ((e = init_step_kernels()) != hipSuccess) return bail("hipFuncSetAttribute(k_step)", e);
+        if ((e = h->twchT.ensure(nimg[0] * 4)) != hipSuccess || (e = h->twwT.ensure(nimg[2] * 4)) != hipSuccess) return bail("hipMalloc(transposed images)", e);
+        ia.wchT = h->twchT.f(); ia.wwT = h->twwT.f();
+        if ((e = init_step_kernels()) != hipSuccess || (e = init_mixer_bwd()) != hipSuccess) return bail("hipFuncSetAttribute", e);
     }
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("sync", e);
     *out = h;
@@ -499,7 +509,7 @@ void ls_train_destroy(ls_trainer* h) {
     for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
     for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->S1, &h->S2, &h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a,
-                   &h->tl2b, &h->tdevw})
+                   &h->tl2b, &h->tdevw, &h->twchT, &h->twwT, &h->dA2, &h->dA1, &h->colpart, &h->dembp})
         all.push_back(b);
     for (Buf* b : all) b->release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);

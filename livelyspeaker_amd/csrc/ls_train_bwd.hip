@@ -1,0 +1,389 @@
+// Fused backward of the mixer (8 MLPblocks, mlp_module.py:37-91) for the training step, the mirror image of the fused
+// training forward (k_step TRAIN variant, ls_step.hip): one 512-thread workgroup holds TWO samples of the batch (70 | 72
+// rows), the gradient of the residual stream G stays in registers in the MFMA C/D layout for all layers (wave w owns
+// channels [64w, 64w+64)), and per layer, last to first:
+//   1. dA2 = G * SiLU'(A2)                         -> global (operand of the batch-level weight-gradient GEMM) and LDS
+//   2. dU2 = dA2 . Wch          (v_mfma_f32_16x16x4_f32 against the TRANSPOSED weight image; ragged rows on FMAs / 4x4x1 MFMAs)
+//   3. LayerNorm-2 backward: G += rstd * (gy - mean(gy) - xhat * mean(gy * xhat)), gy = dU2 * alpha2; row means via one
+//      cross-wave LDS exchange; d alpha2 / d beta2 / d bias as per-workgroup partial column sums
+//   4. dA1 = G * SiLU'(A1)                         -> global (operand of the token-weight gradient) and LDS (wave-private columns)
+//   5. dU1 = blockdiag(Wt, Wt)^T . dA1   (token mixing on MFMA with the transposed block-diagonal image)
+//   6. LayerNorm-1 backward as in 3; per-sample sum over tokens of G -> d(timestep embedding) partial of this layer
+// gy makes one round trip through a per-workgroup scratch slab in global memory (L2-resident) because the row means are
+// only known after the whole row has been produced.  Everything the kernel sums is reduced in a fixed order (registers,
+// cross-lane butterflies, LDS in wave order): the step stays bit-reproducible.
+#include "ls_internal.h"
+#include "ls_step_common.h"
+#include "ls_train.h"
+
+namespace ls {
+
+template <int S>
+__global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
+    constexpr int R = 2 * S;
+    constexpr int MK = (R + 3) / 4;
+    constexpr int kFullTiles = 4;
+    constexpr int NREM = R - 16 * kFullTiles;
+    constexpr bool kRemMfma = (NREM % 4 == 0);
+    constexpr int NRG = kRemMfma ? NREM / 4 : 1;
+    constexpr int NRV = kRemMfma ? 1 : NREM;
+    static_assert(NREM > 0 && NREM <= 16 && R <= 16 * kNT, "row tiling");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* psum = smem;                      // [8 waves][80 rows] (s1, s2) pairs of the LayerNorm-backward row sums
+    float* U = smem + 2 * kWaves * 16 * kNT; // [R][520] fp32 MFMA operand (dA2, then dA1)
+    float* REM = U + R * kUStride;           // [8 waves][2][NREM][16] remainder-row patch
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int s16 = lane & 15, g = lane >> 4, chw = 64 * w + 4 * g;
+    auto fresh = [&]() {                     // keeps per-lane addresses phase-local (see ls_step.hip)
+        asm volatile("" : "+v"(lane));
+        s16 = lane & 15;
+        g = lane >> 4;
+        chw = 64 * w + 4 * g;
+    };
+    auto row_of = [&](int t) { return 16 * t + s16; };
+    auto grow_of = [&](int t) -> int {       // global row (sample * S + token) or -1 for padding / past the batch
+        const int r = 16 * t + s16;
+        if (r >= R) return -1;
+        const int sq = r >= S ? 1 : 0;
+        const int sample = 2 * b + sq;
+        return sample < a.B ? sample * S + (r - sq * S) : -1;
+    };
+    const size_t LR = (size_t)a.B * S;       // rows per layer of the saved activations
+
+    f4 G[kCB][kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+        const int gr = grow_of(t);
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb)
+            G[cb][t] = gr >= 0 ? *reinterpret_cast<const f4*>(a.g + (size_t)gr * kD + chw + 16 * cb) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    float* scratch = a.scratch + (size_t)b * R * kD;       // this workgroup's gy slab [R][512]
+    f2* pst = reinterpret_cast<f2*>(psum);
+
+    // finish a LayerNorm backward: cross-wave row sums of (gy, gy*xhat), then G += rstd * (gy - m1 - xhat * m2)
+    auto ln_bwd_finish = [&](float (&s1)[kNT], float (&s2)[kNT], const float* xsaved, const float* stats) {
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            float u = s1[t], v = s2[t];
+            u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+            u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+            if (g == 0) pst[w * 80 + 16 * t + s16] = (f2){u, v};
+        }
+        __syncthreads();
+        float m1[kNT], m2[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) {
+                const f2 pp = pst[ww * 80 + 16 * t + s16];
+                u += pp.x;
+                v += pp.y;
+            }
+            m1[t] = u * (1.0f / kD);
+            m2[t] = v * (1.0f / kD);
+        }
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            const int gr = grow_of(t);
+            if (gr >= 0) {
+                const f2 st = *reinterpret_cast<const f2*>(stats + (size_t)gr * 2);
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) {
+                    const f4 gy = *reinterpret_cast<const f4*>(scratch + (size_t)row_of(t) * kD + chw + 16 * cb);
+                    const f4 x = *reinterpret_cast<const f4*>(xsaved + (size_t)gr * kD + chw + 16 * cb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xh = (x[j] - st.x) * st.y;
+                        G[cb][t][j] += st.y * (gy[j] - m1[t] - xh * m2[t]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                      // psum and the scratch slab may be rewritten
+    };
+    // consume one (tile, channel block) of dU: gy -> scratch, row partial sums, LayerNorm-parameter partial column sums
+    auto ln_bwd_tile = [&](const f4 du, int t, int cb, const float* xsaved, const float* stats, const float* alpha, float& s1, float& s2,
+                           f4& pa, f4& pb) {
+        const int gr = grow_of(t);
+        if (gr < 0) return;
+        const f2 st = *reinterpret_cast<const f2*>(stats + (size_t)gr * 2);
+        const f4 x = *reinterpret_cast<const f4*>(xsaved + (size_t)gr * kD + chw + 16 * cb);
+        const f4 al = *g4(alpha + chw + 16 * cb);
+        f4 gy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (x[j] - st.x) * st.y;
+            gy[j] = du[j] * al[j];
+            s1 += gy[j];
+            s2 = fmaf(gy[j], xh, s2);
+            pa[j] = fmaf(du[j], xh, pa[j]);
+            pb[j] += du[j];
+        }
+        *reinterpret_cast<f4*>(scratch + (size_t)row_of(t) * kD + chw + 16 * cb) = gy;
+    };
+    // column partials of this workgroup: sum over the 16 row lanes, lanes s16 == 0 write [wg][layer][which][512]
+    auto write_colpart = [&](f4 v, int l, int which, int cb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v[j] += __shfl_xor(v[j], o);
+        if (s16 == 0) *reinterpret_cast<f4*>(a.colpart + (((size_t)b * a.layers + l) * 5 + which) * kD + chw + 16 * cb) = v;
+    };
+
+    for (int l = a.layers - 1; l >= 0; --l) {
+        fresh();
+        // ---- 1. dA2 = G * SiLU'(A2): weight-gradient operand + MFMA operand; its column sums are d bias -------------
+        {
+            const float* A2 = a.a2 + (size_t)l * LR * kD;
+            float* dA2 = a.da2 + (size_t)l * LR * kD;
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                f4 pbias = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    if (16 * t + s16 >= R) continue;
+                    const int gr = grow_of(t);
+                    f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+                    if (gr >= 0) {
+                        const f4 av = *reinterpret_cast<const f4*>(A2 + (size_t)gr * kD + chw + 16 * cb);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av[j] * -1.4426950408889634f));
+                            d[j] = G[cb][t][j] * (sg * (1.0f + av[j] * (1.0f - sg)));
+                        }
+                        *reinterpret_cast<f4*>(dA2 + (size_t)gr * kD + chw + 16 * cb) = d;
+                        pbias += d;
+                    }
+                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = d;
+                }
+                write_colpart(pbias, l, 0, cb);
+            }
+        }
+        __syncthreads();
+        // ---- 2./3. dU2 = dA2 . Wch (transposed image) and the LayerNorm-2 backward -------------------------------
+        float s1[kNT], s2[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+        const float* X2 = a.x2 + (size_t)l * LR * kD;
+        const float* S2 = a.s2 + (size_t)l * LR * 2;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            fresh();
+            f4 acc[2][kFullTiles];
+            float racc[2][NRV];
+            f4 racc4[2][NRG];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+                for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < NRV; ++r) racc[c2][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < NRG; ++r) racc4[c2][r] = (f4){0.f, 0.f, 0.f, 0.f};
+            }
+            gf4p wp = g4(a.wchT_img) + ((size_t)((l * kWaves + w) * 2 + p) * 32) * 2 * 64 + lane;
+            const float* ub = U + s16 * kUStride + 4 * g;
+            const float* ur = U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g;
+            f4 An[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
+#pragma unroll 2
+            for (int q = 0; q < 32; ++q) {
+                f4 A[2], Bv[kFullTiles], Ur[kRemMfma ? NRG : NRV];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
+                {
+                    const int qn = (q + 1 < 32) ? q + 1 : 31;
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[(qn * 2 + c2) * 64];
+                }
+#pragma unroll
+                for (int t = 0; t < kFullTiles; ++t) Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
+#pragma unroll
+                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r)
+                    Ur[r] = *reinterpret_cast<const f4*>(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        if constexpr (kRemMfma) {
+#pragma unroll
+                            for (int r = 0; r < NRG; ++r)
+                                racc4[c2][r] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[c2][j], Ur[r][j], racc4[c2][r], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NRV; ++r) racc[c2][r] = fmaf(A[c2][j], Ur[r][j], racc[c2][r]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fresh();
+            float* rem = REM + w * (2 * NREM * 16);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                if constexpr (kRemMfma) {
+#pragma unroll
+                    for (int r = 0; r < NRG; ++r) {
+                        f4 v = racc4[c2][r];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] += __shfl_xor(v[i], 16);
+                            v[i] += __shfl_xor(v[i], 32);
+                        }
+                        if (g == 0) *reinterpret_cast<f4*>(&rem[(c2 * NREM + 4 * r + (lane & 3)) * 16 + 4 * (s16 >> 2)]) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NRV; ++r) {
+                        float v = racc[c2][r];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        if (g == 0) rem[(c2 * NREM + r) * 16 + s16] = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int cb = 2 * p + c2;
+                f4 pa = (f4){0.f, 0.f, 0.f, 0.f}, pb = pa;
+#pragma unroll
+                for (int t = 0; t < kFullTiles; ++t) ln_bwd_tile(acc[c2][t], t, cb, X2, S2, a.ln2a + l * kD, s1[t], s2[t], pa, pb);
+                if (s16 < NREM) {
+                    const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
+                    ln_bwd_tile(rv, kFullTiles, cb, X2, S2, a.ln2a + l * kD, s1[kFullTiles], s2[kFullTiles], pa, pb);
+                }
+                write_colpart(pa, l, 1, cb);
+                write_colpart(pb, l, 2, cb);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        ln_bwd_finish(s1, s2, X2, S2);
+        fresh();
+        // ---- 4. dA1 = G * SiLU'(A1): token-weight-gradient operand + wave-private columns of the MFMA operand ------
+        {
+            const float* A1 = a.a1 + (size_t)l * LR * kD;
+            float* dA1 = a.da1 + (size_t)l * LR * kD;
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    if (16 * t + s16 >= R) continue;
+                    const int gr = grow_of(t);
+                    f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+                    if (gr >= 0) {
+                        const f4 av = *reinterpret_cast<const f4*>(A1 + (size_t)gr * kD + chw + 16 * cb);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av[j] * -1.4426950408889634f));
+                            d[j] = G[cb][t][j] * (sg * (1.0f + av[j] * (1.0f - sg)));
+                        }
+                        *reinterpret_cast<f4*>(dA1 + (size_t)gr * kD + chw + 16 * cb) = d;
+                    }
+                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = d;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();      // token mixing contracts over rows: a wave reads back only its own columns
+        fresh();
+        // ---- 5./6. dU1 = WW^T . dA1 and the LayerNorm-1 backward ----------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+        const float* X1 = a.x1 + (size_t)l * LR * kD;
+        const float* S1 = a.s1 + (size_t)l * LR * 2;
+        {
+            gfp wwp = g1(a.wwT_img) + (size_t)l * kNT * MK * 64 + lane;
+            const float* up = U + 64 * w + s16;
+            f4 pa[kCB], pb[kCB];
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) { pa[cb] = (f4){0.f, 0.f, 0.f, 0.f}; pb[cb] = pa[cb]; }
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                float Bt[MK];
+#pragma unroll
+                for (int m = 0; m < MK; ++m)
+                    if (tokmix_needed(S, t, m)) Bt[m] = wwp[(t * MK + m) * 64];
+                f4 acc[kCB];
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MK; ++m) {
+                    if (tokmix_needed(S, t, m)) {
+                        const int srow = (4 * m + 3 < R || 4 * m + g < R) ? 4 * m + g : R - 1;
+#pragma unroll
+                        for (int cb = 0; cb < kCB; ++cb) acc[cb] = MFMA(up[srow * kUStride + 16 * cb], Bt[m], acc[cb]);
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) ln_bwd_tile(acc[cb], t, cb, X1, S1, a.ln1a + l * kD, s1[t], s2[t], pa[cb], pb[cb]);
+            }
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                write_colpart(pa[cb], l, 3, cb);
+                write_colpart(pb[cb], l, 4, cb);
+            }
+        }
+        ln_bwd_finish(s1, s2, X1, S1);
+        // d(timestep embedding): x1 = x0 + emb broadcast over the tokens -> per-sample sum over tokens of G, per layer
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb) {
+            f4 h0 = (f4){0.f, 0.f, 0.f, 0.f}, h1 = h0;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                const int r = 16 * t + s16;
+                if (r < S) h0 += G[cb][t];
+                else if (r < R) h1 += G[cb][t];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    h0[j] += __shfl_xor(h0[j], o);
+                    h1[j] += __shfl_xor(h1[j], o);
+                }
+            if (s16 == 0) {
+                float* dst = a.dembp + ((size_t)l * a.B + 2 * b) * kD + chw + 16 * cb;
+                *reinterpret_cast<f4*>(dst) = h0;
+                if (2 * b + 1 < a.B) *reinterpret_cast<f4*>(dst + kD) = h1;
+            }
+        }
+    }
+    // gradient with respect to the token sequences entering layer 0
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+        const int gr = grow_of(t);
+        if (gr >= 0)
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) *reinterpret_cast<f4*>(a.g + (size_t)gr * kD + chw + 16 * cb) = G[cb][t];
+    }
+}
+
+hipError_t init_mixer_bwd() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mixer_bwd<35>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)step_lds_bytes(kTED));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_mixer_bwd<36>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)step_lds_bytes(kBEAT));
+}
+
+hipError_t launch_mixer_bwd(Variant v, const MixerBwdArgs& a, hipStream_t st) {
+    const int wgs = (a.B + 1) / 2;
+    if (v == kTED) hipLaunchKernelGGL(k_mixer_bwd<35>, dim3(wgs), dim3(512), step_lds_bytes(kTED), st, a);
+    else hipLaunchKernelGGL(k_mixer_bwd<36>, dim3(wgs), dim3(512), step_lds_bytes(kBEAT), st, a);
+    return hipGetLastError();
+}
+
+}  // namespace ls

@@ -129,7 +129,8 @@ hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, 
 // its outputs so that each pair of LDS operand reads feeds 4 FMAs (the kernel is LDS-bandwidth bound).
 constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36, kTokWs = kTokMaxS + 4;     // ws rows padded to 40 (float4 reads)
 
-// backward: da = g * silu'(a1); du[b][s][c] = sum_s' wt[s'][s] da[s'][c]; per-workgroup partials
+// backward: da = g * silu'(a1) (a1 == null: g already is da); du[b][s][c] = sum_s' wt[s'][s] da[s'][c] (du == null: skipped, the
+// fused mixer backward computes it); per-workgroup partials
 // pw[(b,slab)][s'][s] = sum_c da[s'][c] u1[s][c], pb[(b,slab)][s'] = sum_c da[s'][c]
 __global__ __launch_bounds__(256) void k_tokmix_bwd(const float* __restrict__ g, const float* __restrict__ a1, const float* __restrict__ u1,
                                                     const float* __restrict__ wt, float* __restrict__ du, float* __restrict__ pw,
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void k_tokmix_bwd(const float* __restrict__ g,
         float dv = 0.f, uv = 0.f;
         if (r < S) {
             const size_t o = ((size_t)b * S + r) * kDm + c0 + cc;
-            dv = g[o] * silu_grad(a1[o]);
+            dv = a1 ? g[o] * silu_grad(a1[o]) : g[o];
             uv = u1[o];
         }
         das[r * kTokLd + cc] = dv;                       // rows S..S+3 are zero so that the 4-wide tiles below need no masks
@@ -151,10 +152,11 @@ __global__ __launch_bounds__(256) void k_tokmix_bwd(const float* __restrict__ g,
     }
     for (int i = tid; i < kTokMaxS * kTokWs; i += 256) {
         const int sp = i / kTokWs, s = i % kTokWs;
-        ws[i] = (sp < S && s < S) ? wt[sp * S + s] : 0.f;
+        ws[i] = (wt && sp < S && s < S) ? wt[sp * S + s] : 0.f;
     }
     __syncthreads();
     const int c = tid & (kTokC - 1);
+    if (du)
     for (int s0 = 4 * (tid >> 7); s0 < S; s0 += 8) {              // du for 4 tokens s0..s0+3
         f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
         for (int sp = 0; sp < S; ++sp) acc += *reinterpret_cast<const f4*>(&ws[sp * kTokWs + s0]) * das[sp * kTokLd + c];
@@ -541,6 +543,7 @@ __global__ void k_build_train_images(const TrainImgArgs a) {
         const int p = (int)((i >> 14) & 1), w = (int)((i >> 15) & 7), l = (int)(i >> 18);
         const int n = 64 * w + 16 * (2 * p + c2) + (lane & 15), k = 16 * q + 4 * (lane >> 4) + j;
         a.wch[i] = a.P[a.base + (long long)l * a.lstride + a.o_w + (long long)n * kDm + k];
+        a.wchT[i] = a.P[a.base + (long long)l * a.lstride + a.o_w + (long long)k * kDm + n];       // operand of dU = dA . W
     }
     if (i < (size_t)a.L * 5 * a.MK * 64) {
         const int lane = (int)(i & 63);
@@ -549,8 +552,13 @@ __global__ void k_build_train_images(const TrainImgArgs a) {
         const int t = (int)(rr % 5), l = (int)(rr / 5);
         const int r = 16 * t + (lane & 15), rp = 4 * m + (lane >> 4);
         float v = 0.f;
-        if (r < R && rp < R && r / a.S == rp / a.S) v = a.P[a.base + (long long)l * a.lstride + a.o_wt + (long long)(r % a.S) * a.S + (rp % a.S)];
+        float vT = 0.f;
+        if (r < R && rp < R && r / a.S == rp / a.S) {
+            v = a.P[a.base + (long long)l * a.lstride + a.o_wt + (long long)(r % a.S) * a.S + (rp % a.S)];
+            vT = a.P[a.base + (long long)l * a.lstride + a.o_wt + (long long)(rp % a.S) * a.S + (r % a.S)];
+        }
         a.ww[i] = v;
+        a.wwT[i] = vT;
     }
     if (i < (size_t)a.L * 80) {
         const int l = (int)(i / 80), r = (int)(i % 80);
