@@ -53,6 +53,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         const int sample = 2 * b + sq;
         return sample < a.B ? sample * S + (r - sq * S) : -1;
     };
+    auto growc_of = [&](int t) -> int { const int gr = grow_of(t); return gr >= 0 ? gr : 0; };   // clamped: loads stay branch-free
     const size_t LR = (size_t)a.B * S;       // rows per layer of the saved activations
 
     f4 G[kCB][kNT];
@@ -91,31 +92,30 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         }
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
-            const int gr = grow_of(t);
-            if (gr >= 0) {
-                const f2 st = *reinterpret_cast<const f2*>(stats + (size_t)gr * 2);
+            // all loads of the tile first, from clamped rows (a guarded load would serialise behind its own s_waitcnt)
+            const int gr = grow_of(t), grc = growc_of(t), rl = min(row_of(t), R - 1);
+            const f2 st = *reinterpret_cast<const f2*>(stats + (size_t)grc * 2);
+            f4 gy[kCB], x[kCB];
 #pragma unroll
-                for (int cb = 0; cb < kCB; ++cb) {
-                    const f4 gy = *reinterpret_cast<const f4*>(scratch + (size_t)row_of(t) * kD + chw + 16 * cb);
-                    const f4 x = *reinterpret_cast<const f4*>(xsaved + (size_t)gr * kD + chw + 16 * cb);
+            for (int cb = 0; cb < kCB; ++cb) {
+                gy[cb] = *reinterpret_cast<const f4*>(scratch + (size_t)rl * kD + chw + 16 * cb);
+                x[cb] = *reinterpret_cast<const f4*>(xsaved + (size_t)grc * kD + chw + 16 * cb);
+            }
+            if (gr >= 0) {
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float xh = (x[j] - st.x) * st.y;
-                        G[cb][t][j] += st.y * (gy[j] - m1[t] - xh * m2[t]);
+                        const float xh = (x[cb][j] - st.x) * st.y;
+                        G[cb][t][j] += st.y * (gy[cb][j] - m1[t] - xh * m2[t]);
                     }
-                }
             }
         }
         __syncthreads();                      // psum and the scratch slab may be rewritten
     };
     // consume one (tile, channel block) of dU: gy -> scratch, row partial sums, LayerNorm-parameter partial column sums
-    auto ln_bwd_tile = [&](const f4 du, int t, int cb, const float* xsaved, const float* stats, const float* alpha, float& s1, float& s2,
-                           f4& pa, f4& pb) {
-        const int gr = grow_of(t);
-        if (gr < 0) return;
-        const f2 st = *reinterpret_cast<const f2*>(stats + (size_t)gr * 2);
-        const f4 x = *reinterpret_cast<const f4*>(xsaved + (size_t)gr * kD + chw + 16 * cb);
-        const f4 al = *g4(alpha + chw + 16 * cb);
+    auto ln_bwd_tile = [&](const f4 du, int t, int cb, const f4 x, const f2 st, const f4 al, float& s1, float& s2, f4& pa, f4& pb) {
+        if (grow_of(t) < 0) return;
         f4 gy;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -146,13 +146,16 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) {
                 f4 pbias = (f4){0.f, 0.f, 0.f, 0.f};
+                f4 avs[kNT];
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) avs[t] = *reinterpret_cast<const f4*>(A2 + (size_t)growc_of(t) * kD + chw + 16 * cb);
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
                     if (16 * t + s16 >= R) continue;
                     const int gr = grow_of(t);
                     f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+                    const f4 av = avs[t];
                     if (gr >= 0) {
-                        const f4 av = *reinterpret_cast<const f4*>(A2 + (size_t)gr * kD + chw + 16 * cb);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av[j] * -1.4426950408889634f));
@@ -173,6 +176,9 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         for (int t = 0; t < kNT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
         const float* X2 = a.x2 + (size_t)l * LR * kD;
         const float* S2 = a.s2 + (size_t)l * LR * 2;
+        f2 st2[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) st2[t] = *reinterpret_cast<const f2*>(S2 + (size_t)growc_of(t) * 2);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             fresh();
@@ -261,11 +267,15 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int cb = 2 * p + c2;
                 f4 pa = (f4){0.f, 0.f, 0.f, 0.f}, pb = pa;
+                const f4 al = *g4(a.ln2a + l * kD + chw + 16 * cb);
+                f4 xs[kNT];
 #pragma unroll
-                for (int t = 0; t < kFullTiles; ++t) ln_bwd_tile(acc[c2][t], t, cb, X2, S2, a.ln2a + l * kD, s1[t], s2[t], pa, pb);
+                for (int t = 0; t < kNT; ++t) xs[t] = *reinterpret_cast<const f4*>(X2 + (size_t)growc_of(t) * kD + chw + 16 * cb);
+#pragma unroll
+                for (int t = 0; t < kFullTiles; ++t) ln_bwd_tile(acc[c2][t], t, cb, xs[t], st2[t], al, s1[t], s2[t], pa, pb);
                 if (s16 < NREM) {
                     const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
-                    ln_bwd_tile(rv, kFullTiles, cb, X2, S2, a.ln2a + l * kD, s1[kFullTiles], s2[kFullTiles], pa, pb);
+                    ln_bwd_tile(rv, kFullTiles, cb, xs[kFullTiles], st2[kFullTiles], al, s1[kFullTiles], s2[kFullTiles], pa, pb);
                 }
                 write_colpart(pa, l, 1, cb);
                 write_colpart(pb, l, 2, cb);
@@ -279,14 +289,17 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
             const float* A1 = a.a1 + (size_t)l * LR * kD;
             float* dA1 = a.da1 + (size_t)l * LR * kD;
 #pragma unroll
-            for (int cb = 0; cb < kCB; ++cb)
+            for (int cb = 0; cb < kCB; ++cb) {
+                f4 avs[kNT];
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) avs[t] = *reinterpret_cast<const f4*>(A1 + (size_t)growc_of(t) * kD + chw + 16 * cb);
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
                     if (16 * t + s16 >= R) continue;
                     const int gr = grow_of(t);
                     f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+                    const f4 av = avs[t];
                     if (gr >= 0) {
-                        const f4 av = *reinterpret_cast<const f4*>(A1 + (size_t)gr * kD + chw + 16 * cb);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av[j] * -1.4426950408889634f));
@@ -296,6 +309,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                     }
                     *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = d;
                 }
+            }
         }
         __builtin_amdgcn_wave_barrier();      // token mixing contracts over rows: a wave reads back only its own columns
         fresh();
@@ -327,8 +341,13 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                         for (int cb = 0; cb < kCB; ++cb) acc[cb] = MFMA(up[srow * kUStride + 16 * cb], Bt[m], acc[cb]);
                     }
                 }
+                const f2 st1 = *reinterpret_cast<const f2*>(S1 + (size_t)growc_of(t) * 2);
+                f4 xs[kCB];
 #pragma unroll
-                for (int cb = 0; cb < kCB; ++cb) ln_bwd_tile(acc[cb], t, cb, X1, S1, a.ln1a + l * kD, s1[t], s2[t], pa[cb], pb[cb]);
+                for (int cb = 0; cb < kCB; ++cb) xs[cb] = *reinterpret_cast<const f4*>(X1 + (size_t)growc_of(t) * kD + chw + 16 * cb);
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb)
+                    ln_bwd_tile(acc[cb], t, cb, xs[cb], st1, *g4(a.ln1a + l * kD + chw + 16 * cb), s1[t], s2[t], pa[cb], pb[cb]);
             }
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) {
