@@ -36,32 +36,45 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ i
     for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
     const int lbase = g * kCvWinP + (16 * w + s16) * kCvS;     // + (4*cig)*WinP + k per step
 
+    // Software pipeline: the raw input window of chunk c+1 (25 values per thread, 16 threads per input channel, clamped
+    // addresses so the loads are branch-free and in flight together) is fetched while chunk c is multiplied, and the
+    // weight operand of tap k+1 (L2) while tap k is multiplied.
+    constexpr int NV = (kCvWin + 15) / 16;
+    float vals[NV], vm = 0.f, vr = 1.f;
+    const int validw = Lin - in0;                                       // >= 1 for every tile that has an output position
+    auto fetch = [&](int c) {
+        const size_t row = (size_t)b * Cin + c * kCvCI + (tid >> 4);
+        vm = stats[row * 2];                                            // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
+        vr = stats[row * 2 + 1];
+        const float* src = in + row * Lin + in0;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) vals[q] = src[min((tid & 15) + 16 * q, validw - 1)];
+    };
+    fetch(0);
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
-        {   // 16 threads per input channel; clamped addresses keep the 25 loads branch-free and in flight together
-            const int ci = tid >> 4;
-            const size_t row = (size_t)b * Cin + c * kCvCI + ci;
-            const float m = stats[row * 2], r = stats[row * 2 + 1];         // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
-            const float* src = in + row * Lin + in0;
-            const int valid = Lin - in0;                                    // >= 1 for every tile that has an output position
-            float vals[(kCvWin + 15) / 16];
 #pragma unroll
-            for (int q = 0; q < (kCvWin + 15) / 16; ++q) vals[q] = src[min((tid & 15) + 16 * q, valid - 1)];
-#pragma unroll
-            for (int q = 0; q < (kCvWin + 15) / 16; ++q) {
-                const int o = (tid & 15) + 16 * q;
-                float v = (vals[q] - m) * r;
-                v = v >= 0.f ? v : 0.3f * v;
-                if (o < kCvWin) sIn[ci * kCvWinP + o] = o < valid ? v : 0.f;
-            }
+        for (int q = 0; q < NV; ++q) {
+            const int o = (tid & 15) + 16 * q;
+            float v = (vals[q] - vm) * vr;
+            v = v >= 0.f ? v : 0.3f * v;
+            if (o < kCvWin) sIn[(tid >> 4) * kCvWinP + o] = o < validw ? v : 0.f;
         }
         __syncthreads();
+        if (c + 1 < nchunk) fetch(c + 1);
         const f4* wp = reinterpret_cast<const f4*>(wimg) + ((size_t)(blockIdx.y * 4) * nchunk + c) * kCvK * 64 + lane;
+        f4 An[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) An[t] = wp[((size_t)t * nchunk * kCvK) * 64];
 #pragma unroll
         for (int k = 0; k < kCvK; ++k) {
             f4 A[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) A[t] = wp[((size_t)t * nchunk * kCvK + k) * 64];
+            for (int t = 0; t < 4; ++t) A[t] = An[t];
+            if (k + 1 < kCvK) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) An[t] = wp[((size_t)t * nchunk * kCvK + k + 1) * 64];
+            }
 #pragma unroll
             for (int cig = 0; cig < 4; ++cig) {
                 const float Bv = sIn[lbase + (4 * cig) * kCvWinP + k];
