@@ -156,7 +156,7 @@ int ensure_batch(ls_trainer* h, int B) {
     HIPCHK(h, E(h->out, (size_t)B * d0.T * d0.JF)); HIPCHK(h, E(h->dout, (size_t)B * d0.T * d0.JF));
     HIPCHK(h, E(h->lossp, 2 * ((size_t)B * d0.JF / 256 + 2))); HIPCHK(h, E(h->kldp, B)); HIPCHK(h, E(h->terms, 8));
     HIPCHK(h, E(h->part, (size_t)kNW * 2 * kD + (size_t)B * 128 + 4096 * 512 + (size_t)B * 32 * 2 * 2 * ((L[1] + 5) / 6 / 64 + 1)));
-    HIPCHK(h, E(h->pw, (size_t)B * 4 * d0.S * d0.S)); HIPCHK(h, E(h->pb, (size_t)B * 4 * d0.S));
+    HIPCHK(h, E(h->pw, (size_t)d0.L * B * 4 * d0.S * d0.S)); HIPCHK(h, E(h->pb, (size_t)d0.L * B * 4 * d0.S));
     HIPCHK(h, E(h->dAf, (size_t)B * d0.T * kAud));
     // col: conv4's im2col [B*34][1920] and the partial-sum workspace of the implicit-GEMM weight gradients
     size_t colmax = (size_t)B * L[4] * kCin[3] * 15;
@@ -296,20 +296,20 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
         a.B = B; a.layers = d.L;
         HIPCHK(h, launch_mixer_bwd(d.NPRE == 2 ? kBEAT : kTED, a, st));
     }
-    const long long cps = (long long)d.L * 5 * kD;          // stride between workgroups in colpart
-    for (int l = d.L - 1; l >= 0; --l) {
-        const float* cp = h->colpart.f() + (size_t)l * 5 * kD;
-        HIPCHK(h, launch_partial_reduce(cp, nwg, cps, kD, Gr(h, grad, lk(l, "block2.1.bias")), 0, st));
-        // alpha and beta are adjacent in the flat layout and in colpart: one reduce writes both
-        HIPCHK(h, launch_partial_reduce(cp + kD, nwg, cps, 2 * kD, Gr(h, grad, lk(l, "block2.0.alpha")), 0, st));
-        HIPCHK(h, launch_partial_reduce(cp + 3 * kD, nwg, cps, 2 * kD, Gr(h, grad, lk(l, "block1.0.alpha")), 0, st));
+    // per-workgroup partial column sums -> bias / LayerNorm-parameter gradients of ALL layers, one launch per family
+    // (alpha and beta are adjacent both in colpart and in the flat layout; the per-layer stride of the flat layout is constant)
+    const long long cps = (long long)d.L * 5 * kD, ls = h->img_args.lstride;
+    float* g0 = grad + h->img_args.base;
+    HIPCHK(h, launch_partial_reduce_groups(h->colpart.f(), nwg, cps, kD, g0 + h->img_args.o_b, d.L, 5 * kD, ls, st));
+    HIPCHK(h, launch_partial_reduce_groups(h->colpart.f() + kD, nwg, cps, 2 * kD, g0 + h->img_args.o_a2, d.L, 5 * kD, ls, st));
+    HIPCHK(h, launch_partial_reduce_groups(h->colpart.f() + 3 * kD, nwg, cps, 2 * kD, g0 + h->img_args.o_a1, d.L, 5 * kD, ls, st));
+    // token weights of all layers: dWt[s'][s] = sum_{b,c} dA1[b][s'][c] U1[b][s][c], d bt[s'] = sum_{b,c} dA1[b][s'][c]
+    HIPCHK(h, launch_tokmix_wgrad(h->dA1.f(), h->U1.f(), h->pw.f(), h->pb.f(), B, S, d.L, st));
+    HIPCHK(h, launch_partial_reduce_groups(h->pw.f(), B * 4, (long long)S * S, S * S, g0 + h->img_args.o_wt, d.L, (long long)B * 4 * S * S, ls, st));
+    HIPCHK(h, launch_partial_reduce_groups(h->pb.f(), B * 4, S, S, g0 + h->img_args.o_bt, d.L, (long long)B * 4 * S, ls, st));
+    for (int l = d.L - 1; l >= 0; --l)
         HIPCHK(h, wgrad(h, op_cols(lay(h->dA2, l, R), kD, kD, R), op_cols(lay(h->U2, l, R), kD, kD, R), false, false, Gr(h, grad, lk(l, "block2.1.weight")),
                         kD, kD, kD, R));
-        // token weights: dWt[s'][s] = sum_{b,c} dA1[b][s'][c] U1[b][s][c], d bt[s'] = sum_{b,c} dA1[b][s'][c]
-        HIPCHK(h, launch_tokmix_bwd(lay(h->dA1, l, R), nullptr, lay(h->U1, l, R), nullptr, nullptr, h->pw.f(), h->pb.f(), B, S, st));
-        HIPCHK(h, launch_partial_reduce(h->pw.f(), B * 4, (long long)S * S, S * S, Gr(h, grad, lk(l, "block1.1.weight")), 0, st));
-        HIPCHK(h, launch_partial_reduce(h->pb.f(), B * 4, S, S, Gr(h, grad, lk(l, "block1.1.bias")), 0, st));
-    }
     HIPCHK(h, launch_partial_reduce(h->dembp.f(), d.L, (long long)B * kD, B * kD, h->demb.f(), 0, st));
     return LS_OK;
 }

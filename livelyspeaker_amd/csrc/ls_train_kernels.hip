@@ -127,45 +127,26 @@ hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, 
 // Token mixing (Conv1d(S,S,1) over the token axis, mlp_module.py:51-55), backward.  (The forward runs inside the fused
 // training-forward kernel, ls_step.hip TRAIN variant.)  Workgroup = (sample, 128-channel slab); every thread register-tiles
 // its outputs so that each pair of LDS operand reads feeds 4 FMAs (the kernel is LDS-bandwidth bound).
-constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36, kTokWs = kTokMaxS + 4;     // ws rows padded to 40 (float4 reads)
+constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36;
 
-// backward: da = g * silu'(a1) (a1 == null: g already is da); du[b][s][c] = sum_s' wt[s'][s] da[s'][c] (du == null: skipped, the
-// fused mixer backward computes it); per-workgroup partials
-// pw[(b,slab)][s'][s] = sum_c da[s'][c] u1[s][c], pb[(b,slab)][s'] = sum_c da[s'][c]
-__global__ __launch_bounds__(256) void k_tokmix_bwd(const float* __restrict__ g, const float* __restrict__ a1, const float* __restrict__ u1,
-                                                    const float* __restrict__ wt, float* __restrict__ du, float* __restrict__ pw,
-                                                    float* __restrict__ pb, int S) {
+// Token-weight gradient of every layer in one launch (grid.z = layer): per (sample, 128-channel slab) workgroup
+//   pw[l][(b,slab)][s'][s] = sum_c dA1[l][b][s'][c] U1[l][b][s][c],   pb[l][(b,slab)][s'] = sum_c dA1[l][b][s'][c]
+// (dA1 comes from the fused mixer backward).  2 x 4 register tile per thread: 6 LDS reads per 8 FMAs.
+__global__ __launch_bounds__(256) void k_tokmix_wgrad(const float* __restrict__ da, const float* __restrict__ u1, float* __restrict__ pw,
+                                                      float* __restrict__ pb, int S, int B) {
     __shared__ float das[(kTokMaxS + 4) * kTokLd];
     __shared__ float us[(kTokMaxS + 4) * kTokLd];
-    __shared__ __attribute__((aligned(16))) float ws[kTokMaxS * kTokWs];        // ws[s'][s] = wt[s'][s], rows padded
-    const int b = blockIdx.x, c0 = blockIdx.y * kTokC, tid = threadIdx.x;
+    const int b = blockIdx.x, c0 = blockIdx.y * kTokC, l = blockIdx.z, tid = threadIdx.x;
+    const size_t lbase = (size_t)l * B * S * kDm;
     for (int i = tid; i < (kTokMaxS + 4) * kTokC; i += 256) {
         const int r = i / kTokC, cc = i % kTokC;
-        float dv = 0.f, uv = 0.f;
-        if (r < S) {
-            const size_t o = ((size_t)b * S + r) * kDm + c0 + cc;
-            dv = a1 ? g[o] * silu_grad(a1[o]) : g[o];
-            uv = u1[o];
-        }
-        das[r * kTokLd + cc] = dv;                       // rows S..S+3 are zero so that the 4-wide tiles below need no masks
-        us[r * kTokLd + cc] = uv;
-    }
-    for (int i = tid; i < kTokMaxS * kTokWs; i += 256) {
-        const int sp = i / kTokWs, s = i % kTokWs;
-        ws[i] = (wt && sp < S && s < S) ? wt[sp * S + s] : 0.f;
+        const size_t o = lbase + ((size_t)b * S + min(r, S - 1)) * kDm + c0 + cc;        // clamped address, branch-free loads
+        const float dv = da[o], uv = u1[o];
+        das[r * kTokLd + cc] = r < S ? dv : 0.f;          // rows S..S+3 are zero so that the 4-wide tiles below need no masks
+        us[r * kTokLd + cc] = r < S ? uv : 0.f;
     }
     __syncthreads();
-    const int c = tid & (kTokC - 1);
-    if (du)
-    for (int s0 = 4 * (tid >> 7); s0 < S; s0 += 8) {              // du for 4 tokens s0..s0+3
-        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < S; ++sp) acc += *reinterpret_cast<const f4*>(&ws[sp * kTokWs + s0]) * das[sp * kTokLd + c];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (s0 + e < S) du[((size_t)b * S + s0 + e) * kDm + c0 + c] = acc[e];
-    }
-    // weight-gradient partial: 2 x 4 register tile per thread, 6 LDS reads per 8 FMAs
-    const size_t blk = (size_t)b * gridDim.y + blockIdx.y;
+    const size_t blk = ((size_t)l * B + b) * gridDim.y + blockIdx.y;
     const int nsp = (S + 1) / 2, ns4 = (S + 3) / 4;
     for (int o = tid; o < nsp * ns4; o += 256) {
         const int sp = 2 * (o / ns4), s = 4 * (o % ns4);
@@ -193,20 +174,22 @@ __global__ __launch_bounds__(256) void k_tokmix_bwd(const float* __restrict__ g,
     }
 }
 
-hipError_t launch_tokmix_bwd(const float* g, const float* a1, const float* u1, const float* wt, float* du, float* pw, float* pb, int B,
-                             int S, hipStream_t st) {
+hipError_t launch_tokmix_wgrad(const float* da, const float* u1, float* pw, float* pb, int B, int S, int layers, hipStream_t st) {
     if (S > kTokMaxS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tokmix_bwd, dim3(B, kDm / kTokC), dim3(256), 0, st, g, a1, u1, wt, du, pw, pb, S);
+    hipLaunchKernelGGL(k_tokmix_wgrad, dim3(B, kDm / kTokC, layers), dim3(256), 0, st, da, u1, pw, pb, S, B);
     return hipGetLastError();
 }
 
 // out[c] (+)= sum_{i<n} partial[i*stride + c] in a fixed order (deterministic): block = 64 columns x 16 index lanes,
 // lane q sums i = q, q+16, ... with four independent accumulators, the 16 lanes are then combined through LDS in order.
+// blockIdx.y selects an independent group (e.g. a layer): partial += y * pgstride, out += y * ogstride.
 __global__ __launch_bounds__(1024) void k_partial_reduce(const float* __restrict__ partial, int n, long long stride, int cols,
-                                                         float* __restrict__ out, int accumulate) {
+                                                         float* __restrict__ out, int accumulate, long long pgstride, long long ogstride) {
     __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    partial += (size_t)blockIdx.y * pgstride;
+    out += (size_t)blockIdx.y * ogstride;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < cols) {
         int i = q;
@@ -229,7 +212,13 @@ __global__ __launch_bounds__(1024) void k_partial_reduce(const float* __restrict
 }
 
 hipError_t launch_partial_reduce(const float* partial, int n, long long stride, int cols, float* out, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(k_partial_reduce, dim3((cols + 63) / 64), dim3(1024), 0, st, partial, n, stride, cols, out, accumulate);
+    hipLaunchKernelGGL(k_partial_reduce, dim3((cols + 63) / 64), dim3(1024), 0, st, partial, n, stride, cols, out, accumulate, 0LL, 0LL);
+    return hipGetLastError();
+}
+
+hipError_t launch_partial_reduce_groups(const float* partial, int n, long long stride, int cols, float* out, int groups, long long pgstride,
+                                        long long ogstride, hipStream_t st) {
+    hipLaunchKernelGGL(k_partial_reduce, dim3((cols + 63) / 64, groups), dim3(1024), 0, st, partial, n, stride, cols, out, 0, pgstride, ogstride);
     return hipGetLastError();
 }
 
