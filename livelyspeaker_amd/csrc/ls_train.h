@@ -80,8 +80,6 @@ hipError_t init_mixer_bwd();
 hipError_t launch_mixer_bwd(Variant v, const MixerBwdArgs& a, hipStream_t st);
 // ---- backward ----
 hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, float* partial, int rows, int nwaves, hipStream_t st);
-hipError_t launch_ln_bwd(const float* du, const float* x, const float* stats, const float* alpha, float* g, float* partial, int rows,
-                         int nwaves, hipStream_t st);
 // token-weight gradient partials of all layers: pw[L][B*4][S*S], pb[L][B*4][S]
 hipError_t launch_tokmix_wgrad(const float* da, const float* u1, float* pw, float* pb, int B, int S, int layers, hipStream_t st);
 hipError_t launch_partial_reduce(const float* partial, int n, long long stride, int cols, float* out, int accumulate, hipStream_t st);
@@ -90,7 +88,6 @@ hipError_t launch_partial_reduce_groups(const float* partial, int n, long long s
                                         long long ogstride, hipStream_t st);
 // partial[nblk][cols]; follow with launch_partial_reduce(partial, nblk, cols, cols, ...)
 hipError_t launch_colsum(const float* in, int ri, long long ro, long long rs, int rows, int cols, float* partial, int nblk, hipStream_t st);
-hipError_t launch_tok_sum(const float* g, float* demb, int B, int S, int accumulate, hipStream_t st);
 hipError_t launch_style_bwd(const float* g0, const float* mu, const float* lv, const float* eps, float* dmu, float* dlv, int B, int S,
                             float kld_weight, hipStream_t st);
 hipError_t launch_scatter_rows(const float* src, long long src_stride, const int64_t* idx, int idx_stride, int n, int cols, float* table,

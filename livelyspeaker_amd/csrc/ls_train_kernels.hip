@@ -1,7 +1,7 @@
-// Non-GEMM kernels of the training step: q_sample + feature build, LN_spatial forward/backward,
-// token-mixing forward/backward, reparameterisation + KLD, Huber / velocity losses and their gradient, conv1's weight
-// gradient, deterministic partial-sum reductions (no float atomics), AdamW.  All fp32.  Row kernels give one 64-lane
-// wave a 512-channel row (2 float4 per lane).
+// Batch-level non-GEMM kernels of the training step (the mixer itself runs in the fused kernels of
+// ls_step.hip / ls_train_bwd.hip): q_sample + feature build, token-weight gradients, reparameterisation + KLD, Huber /
+// velocity losses and their gradient, conv1's weight gradient, mixer weight images, deterministic partial-sum reductions
+// (no float atomics), AdamW.  All fp32.
 #include "ls_internal.h"
 #include "ls_train.h"
 
@@ -57,43 +57,6 @@ hipError_t launch_build_feat_train(const float* x_start, const float* noise, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LN_spatial backward: g[row] += rstd * (gy - mean(gy) - xhat * mean(gy * xhat)), gy = du * alpha; per-wave partial
-// column sums of du*xhat (-> d alpha) and du (-> d beta) in partial[wave][2][512]
-__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ stats,
-                                                const float* __restrict__ alpha, float* __restrict__ g, float* __restrict__ partial,
-                                                int rows, int nwaves) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const f4* al = reinterpret_cast<const f4*>(alpha);
-    const f4 al0 = al[lane], al1 = al[64 + lane];
-    f4 sa0 = (f4){0.f, 0.f, 0.f, 0.f}, sa1 = sa0, sb0 = sa0, sb1 = sa0;
-    for (int row = gw; row < rows; row += nwaves) {
-        const f4* dr = reinterpret_cast<const f4*>(du + (size_t)row * kDm);
-        const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * kDm);
-        const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
-        const f4 d0 = dr[lane], d1 = dr[64 + lane];
-        const f4 h0 = (xr[lane] - mean) * rstd, h1 = (xr[64 + lane] - mean) * rstd;
-        const f4 y0 = d0 * al0, y1 = d1 * al1;
-        const float m1 = wave_sum((y0[0] + y0[1]) + (y0[2] + y0[3]) + (y1[0] + y1[1]) + (y1[2] + y1[3])) * (1.0f / kDm);
-        const f4 p0 = y0 * h0, p1 = y1 * h1;
-        const float m2 = wave_sum((p0[0] + p0[1]) + (p0[2] + p0[3]) + (p1[0] + p1[1]) + (p1[2] + p1[3])) * (1.0f / kDm);
-        f4* gr = reinterpret_cast<f4*>(g + (size_t)row * kDm);
-        gr[lane] += (y0 - m1 - h0 * m2) * rstd;
-        gr[64 + lane] += (y1 - m1 - h1 * m2) * rstd;
-        sa0 += d0 * h0; sa1 += d1 * h1;
-        sb0 += d0; sb1 += d1;
-    }
-    f4* po = reinterpret_cast<f4*>(partial + (size_t)gw * 2 * kDm);
-    po[lane] = sa0; po[64 + lane] = sa1;
-    po[128 + lane] = sb0; po[192 + lane] = sb1;
-}
-
-hipError_t launch_ln_bwd(const float* du, const float* x, const float* stats, const float* alpha, float* g, float* partial, int rows,
-                         int nwaves, hipStream_t st) {
-    hipLaunchKernelGGL(k_ln_bwd, dim3(nwaves / 4), dim3(256), 0, st, du, x, stats, alpha, g, partial, rows, nwaves);
-    return hipGetLastError();
-}
-
 // da = g * silu'(apre); per-wave partial column sums of da in partial[wave][512] (-> bias gradient)
 __global__ __launch_bounds__(256) void k_silu_bwd_colsum(const float* __restrict__ g, const float* __restrict__ apre,
                                                          float* __restrict__ da, float* __restrict__ partial, int rows, int nwaves) {
@@ -240,20 +203,6 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ in, in
 hipError_t launch_colsum(const float* in, int ri, long long ro, long long rs, int rows, int cols, float* partial, int nblk, hipStream_t st) {
     const int rpb = (rows + nblk - 1) / nblk;
     hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64, nblk), dim3(256), 0, st, in, ri, ro, rs, rows, cols, partial, rpb);
-    return hipGetLastError();
-}
-
-// demb[b][c] (+)= sum_s g[b][s][c]   (x = x + emb broadcast over tokens, mlp_module.py:68-69)
-__global__ void k_tok_sum(const float* __restrict__ g, float* __restrict__ demb, int S, int accumulate) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    float s = 0.f;
-    for (int t = 0; t < S; ++t) s += g[((size_t)b * S + t) * kDm + c];
-    const size_t o = (size_t)b * kDm + c;
-    demb[o] = accumulate ? demb[o] + s : s;
-}
-
-hipError_t launch_tok_sum(const float* g, float* demb, int B, int S, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(k_tok_sum, dim3(B), dim3(kDm), 0, st, g, demb, S, accumulate);
     return hipGetLastError();
 }
 
