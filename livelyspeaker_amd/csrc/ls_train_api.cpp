@@ -124,6 +124,19 @@ GemmArgs gemm(GemmOperand A, GemmOperand B, float* C, long long ldc, int M, int 
     return a;
 }
 
+// GEMM launch that splits K when the output has too few 128x128 tiles to fill the chip and the epilogue allows it
+// (bias and accumulation are applied by the split-K reduction; activation / pre-activation copy / residual are not)
+hipError_t gemm_run(ls_trainer* h, GemmArgs a, bool a_k, bool b_k) {
+    int s = 1;
+    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (!a.act && !a.Cpre && !a.R && tiles < 128 && h->ws.p) {
+        a.ws = h->ws.f(); a.ws_floats = h->ws_floats;
+        s = splits_for(a.M, a.N, a.K);
+        while (s > 1 && (size_t)s * a.M * a.N > h->ws_floats) --s;
+    }
+    return launch_gemm_tr(a, a_k, b_k, s, h->stream);
+}
+
 // weight gradient: C[n_out][n_in] = sum over rows of dY(:, n_out) * X(:, n_in); split over the row index
 hipError_t wgrad(ls_trainer* h, GemmOperand dy_cols, GemmOperand x_cols, bool a_k, bool b_k, float* C, long long ldc, int M, int N, int K) {
     GemmArgs a = gemm(dy_cols, x_cols, C, ldc, M, N, K);
@@ -218,7 +231,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
                           h->xcur.f() + (size_t)d.NPRE * kD, kD, BT, kD, d.KF);
         a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
         a.bias = P(h, "input_mapping.bias");
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, true));
     }
     HIPCHK(h, launch_gather_rows(P(h, "speaker_embedding.weight"), reinterpret_cast<const int64_t*>(h->vid.p), h->zc.f(), B, kSpk,
                                  h->cfg.model.n_speakers, st));
@@ -226,7 +239,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         GemmArgs a = gemm(op_rows(h->zc.f(), kSpk, B, kSpk), op_rows(P(h, k ? "speaker_logvar.weight" : "speaker_mu.weight"), kSpk, kD, kSpk),
                           k ? h->lv.f() : h->mu.f(), kD, B, kD, kSpk);
         a.bias = P(h, k ? "speaker_logvar.bias" : "speaker_mu.bias");
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, true));
     }
     HIPCHK(h, launch_style_fwd(h->mu.f(), h->lv.f(), h->eps.f(), d.NPRE == 2 ? P(h, "emotion_embedding.weight") : nullptr,
                                reinterpret_cast<const int64_t*>(h->emo.p), T, h->xcur.f(), h->kldp.f(), B, S, d.NPRE, st));
@@ -236,11 +249,11 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         GemmArgs a = gemm(op_rows(h->pe_rows.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.0.weight"), kD, kD, kD), h->hid.f(),
                           kD, B, kD, kD);
         a.bias = P(h, "backbone.embed_timestep.time_embed.0.bias"); a.Cpre = h->pre1.f(); a.act = 1;
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, true));
         GemmArgs b2 = gemm(op_rows(h->hid.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.2.weight"), kD, kD, kD), h->emb.f(), kD,
                            B, kD, kD);
         b2.bias = P(h, "backbone.embed_timestep.time_embed.2.bias");
-        HIPCHK(h, launch_gemm_tr(b2, true, true, 1, st));
+        HIPCHK(h, gemm_run(h, b2, true, true));
     }
     {   // TransMLP: all 8 MLPblocks (mlp_module.py:67-91) in ONE launch of the fused kernel the sampler uses (ls_step.hip,
         // TRAIN variant): a workgroup keeps two samples' residual streams in registers and writes X1 / U1 / A1 / X2 / U2 / A2
@@ -261,7 +274,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         GemmArgs a = gemm(gemm_operand(h->xcur.f() + (size_t)d.NPRE * kD, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
                           op_rows(P(h, "output_process.poseFinal.weight"), kD, JF, kD), h->out.f(), JF, BT, JF, kD);
         a.bias = P(h, "output_process.poseFinal.bias");
-        HIPCHK(h, launch_gemm_tr(a, true, true, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, true));
     }
     const int nlb = (B * JF + 255) / 256;
     HIPCHK(h, launch_loss(h->out.f(), h->x_start.f(), h->dout.f(), h->lossp.f(), d, h->cfg.lambda_vel, st));
@@ -281,7 +294,7 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
         GemmArgs a = gemm(op_rows(h->dout.f(), JF, BT, JF), op_cols(P(h, "output_process.poseFinal.weight"), kD, kD, JF),
                           h->G.f() + (size_t)d.NPRE * kD, kD, BT, kD, JF);
         a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, false));
     }
     // All 8 MLPblocks backward in ONE launch (ls_train_bwd.hip): G stays in registers across the layers; the kernel leaves
     // dA2 / dA1 for the batch-level weight-gradient products below, per-workgroup partial column sums for the bias and
@@ -326,7 +339,7 @@ static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad)
         HIPCHK(h, colsum_to(h, dz, INT_MAX, 0, kD, B, kD, Gr(h, grad, k ? "speaker_logvar.bias" : "speaker_mu.bias")));
         GemmArgs a = gemm(op_rows(dz, kD, B, kD), op_cols(P(h, wk), kSpk, kSpk, kD), h->dzc.f(), kSpk, B, kSpk, kD);
         a.accumulate = k;
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, false));
     }
     HIPCHK(h, launch_scatter_rows(h->dzc.f(), kSpk, reinterpret_cast<const int64_t*>(h->vid.p), 1, B, kSpk, Gr(h, grad, "speaker_embedding.weight"), st));
     if (d.NPRE == 2)
@@ -341,7 +354,7 @@ static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad)
         GemmArgs a = gemm(gemm_operand(dH, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
                           gemm_operand(P(h, "input_mapping.weight") + 2 * JF + 1, INT_MAX, 0, 1, INT_MAX, 0, d.KF, false, kAud, kD), h->dAf.f(), kAud,
                           BT, kAud, kD);
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, false));
         HIPCHK(h, launch_scale_rows(h->dAf.f(), h->drop.f(), B, T * kAud, st));
     }
     // TimestepEmbedder
@@ -351,7 +364,7 @@ static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad)
         HIPCHK(h, wgrad(h, op_cols(h->demb.f(), kD, kD, B), op_cols(h->hid.f(), kD, kD, B), false, false, Gr(h, grad, w2), kD, kD, kD, B));
         HIPCHK(h, colsum_to(h, h->demb.f(), INT_MAX, 0, kD, B, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.2.bias")));
         GemmArgs a = gemm(op_rows(h->demb.f(), kD, B, kD), op_cols(P(h, w2), kD, kD, kD), h->dhid.f(), kD, B, kD, kD);
-        HIPCHK(h, launch_gemm_tr(a, true, false, 1, st));
+        HIPCHK(h, gemm_run(h, a, true, false));
         HIPCHK(h, launch_silu_bwd_colsum(h->dhid.f(), h->pre1.f(), h->dhid.f(), part, B, kNW, st));
         HIPCHK(h, launch_partial_reduce(part, kNW, kD, kD, Gr(h, grad, "backbone.embed_timestep.time_embed.0.bias"), 0, st));
         HIPCHK(h, wgrad(h, op_cols(h->dhid.f(), kD, kD, B), op_cols(h->pe_rows.f(), kD, kD, B), false, false, Gr(h, grad, w0), kD, kD, kD, B));
