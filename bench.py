@@ -25,12 +25,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_RESULT_OUT = sys.stdout        # replaced by a private duplicate of fd 1 when run as a script (_reserve_stdout)
 
 FLOP_PER_SAMPLE_STEP = {"ted": 317_431_808, "beat": 362_496_000}     # BASELINE.md section 3 (CFG: 2 forwards, hoisted form)
 MFMA_F32_PEAK_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # HBM bytes per k_step launch from rocprofv3 PMC passes (profiles/r01b_kernel_trace_and_pmc.md): 2*FETCH_SIZE + WRITE_SIZE
 # (KiB -> B, with the guide's gfx950 FETCH_SIZE correction); measured for the default workload only.
-PMC_TRAFFIC_BYTES = {("ted", 512): 218_940_170}      # profiles/r01e_final_kernel_trace_and_pmc.md
+PMC_TRAFFIC_BYTES = {("ted", 512): 218_940_170}      # profiles/r01e_final_kernel_trace_and_pmc.md (PMC section)
 
 
 def parse():
@@ -167,7 +168,9 @@ def _train_schedule(a):
 
 
 def main():
+    global _RESULT_OUT
     a = parse()
+    _RESULT_OUT = _reserve_stdout()
     import torch
     import torch.distributed as dist
     from livelyspeaker_amd import synth
@@ -312,10 +315,20 @@ def main():
             rec["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, a)
-        print(json.dumps(rec), flush=True)
+        _RESULT_OUT.write(json.dumps(rec) + "\n")
+        _RESULT_OUT.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _reserve_stdout():
+    """Keep stdout for the ONE JSON line: libraries below us write there too (RCCL prints a version banner at communicator
+    creation), so fd 1 is pointed at stderr for the run and the result goes to a private duplicate of the original stdout."""
+    sys.stdout.flush()
+    out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return out
 
 
 if __name__ == "__main__":

@@ -208,3 +208,24 @@ def test_uniform_sampler_replays_numpy_choice_stream():
 def test_parse_resume_step_from_filename():
     from livelyspeaker_amd.train_loop import parse_resume_step_from_filename as f
     assert f("save/x/model000012345.pt") == 12345 and f("nothing.pt") == 0 and f("modelabc.pt") == 0
+
+
+def test_bench_stdout_carries_only_the_result_line():
+    """bench.py promises ONE JSON line on stdout; libraries under it (RCCL's version banner) write to fd 1 too, so the
+    run points fd 1 at stderr and keeps a private duplicate for the result."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent(f'''
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        out = bench._reserve_stdout()
+        os.write(1, b"banner written to fd 1 by a library\\n")
+        print("python-level noise")
+        out.write('{{"ok": 1}}\\n'); out.flush()
+    ''')
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"ok": 1}\n'
+    assert "banner written to fd 1" in r.stderr and "python-level noise" in r.stderr
