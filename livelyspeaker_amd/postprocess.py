@@ -22,6 +22,7 @@ TED_BEAT_THRES = 0.03
 TED_DIR_VEC_PAIRS = [(0, 1, 0.26), (1, 2, 0.18), (2, 3, 0.14), (1, 4, 0.22), (4, 5, 0.36), (5, 6, 0.33), (1, 7, 0.22),
                      (7, 8, 0.36), (8, 9, 0.33)]
 TED_FPS = 15.0
+TED_BEAT_SIGMA = 0.1          # test_RAG_ted.py:33
 
 
 def ted_post_config() -> "_lib.LsPostConfig":
@@ -60,3 +61,32 @@ def ted_postprocess(sample, device: int = 0, want_pose: bool = True) -> dict:
     beats = [[float(t) / TED_FPS for t in np.nonzero(mask_np[b])[0]] for b in range(B)]
     return {"aligned_motions": aligned, "pose": pose, "angle_diff": diff,
             "beat_mask": mask.bool() if m.on_device else mask.astype(bool), "motion_beat_times": beats}
+
+
+class BeatConsistency:
+    """Running beat-alignment (BC) score over clips, as the evaluation loop accumulates it (test_RAG_ted.py:113-127): for every
+    audio onset, exp(-min_m (onset - m)^2 / (2 sigma^2)) over the clip's motion beats; clips without a motion beat contribute
+    nothing (not even their onsets).  Audio onset times are an INPUT here: the reference gets them from
+    librosa.onset.onset_detect, a third-party package that is not part of this path."""
+
+    def __init__(self, sigma: float = TED_BEAT_SIGMA):
+        self.sigma = float(sigma)
+        self.align_sum = 0.0
+        self.num_beats = 0
+        self.motion_beats_sum = 0
+
+    def push(self, motion_beat_times, audio_beat_times):
+        """Both arguments: one sequence of times (seconds) per clip."""
+        if len(motion_beat_times) != len(audio_beat_times):
+            raise ValueError("one list of motion beats and one list of audio onsets per clip")
+        for mb, ab in zip(motion_beat_times, audio_beat_times):
+            self.motion_beats_sum += len(mb)
+            if len(mb) == 0:
+                continue
+            mb = np.asarray(mb, np.float64)
+            for a in np.asarray(ab, np.float64).reshape(-1):
+                self.align_sum += float(np.exp(-np.min((a - mb) ** 2) / (2.0 * self.sigma * self.sigma)))
+            self.num_beats += len(ab)
+
+    def score(self) -> float:
+        return self.align_sum / self.num_beats

@@ -46,3 +46,29 @@ def test_hip_post_vs_reference_fixture(g9):
     assert rb["aligned_motions"].is_cuda and tuple(rb["pose"].shape) == (512, 34, 10, 3)
     assert np.array_equal(rb["angle_diff"][:4].cpu().numpy(), r["angle_diff"])
     assert np.array_equal(rb["beat_mask"][508:].cpu().numpy(), r["beat_mask"])
+
+
+def test_beat_consistency_accumulation():
+    """BC score accumulation of the evaluation loop (test_RAG_ted.py:113-127), restated here in its literal loop form."""
+    import math
+    from livelyspeaker_amd.postprocess import BeatConsistency
+    rng = np.random.Generator(np.random.PCG64(5))
+    motion = [sorted((rng.integers(2, 33, size=n) / 15.0).tolist()) for n in (3, 0, 1, 6)]
+    audio = [np.sort(rng.uniform(0, 2.2, size=n)) for n in (4, 5, 0, 7)]
+    bc = BeatConsistency()
+    bc.push(motion[:2], audio[:2])
+    bc.push(motion[2:], audio[2:])
+    sigma, total, nb, nm = 0.1, 0.0, 0, 0
+    for mb, ab in zip(motion, audio):
+        nm += len(mb)
+        if len(mb) == 0:
+            continue
+        s = 0
+        for a in ab:
+            s += np.power(math.e, -np.min(np.power((a - np.asarray(mb)), 2)) / (2 * sigma * sigma))
+        total += s
+        nb += len(ab)
+    assert bc.motion_beats_sum == nm and bc.num_beats == nb
+    assert abs(bc.score() - total / nb) < 1e-12
+    with pytest.raises(ValueError):
+        bc.push(motion[:1], audio[:2])
