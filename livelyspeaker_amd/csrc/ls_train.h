@@ -26,8 +26,12 @@ struct GemmArgs {
     int act;                 // 0 none, 1 SiLU
     int accumulate;          // C += result
     int M, N, K, kchunk;
-    float* ws;               // split-K workspace
+    float* ws;               // split-K workspace [batch][split][M][N]
     size_t ws_floats;
+    // batched form: blockIdx.z = batch * splits + split; problem b reads A.p + b*bsA, B.p + b*bsB and writes C + b*bsC
+    // (bias / Cpre / R are not batched: they must be null when nbatch > 1)
+    int nbatch, splits;
+    long long bsA, bsB, bsC;
 };
 
 inline GemmOperand gemm_operand(const float* p, int ri, long long ro, long long rs, int ki, long long ko, long long ks, bool kcontig,

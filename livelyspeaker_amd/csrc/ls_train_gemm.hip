@@ -73,6 +73,16 @@ __device__ __forceinline__ void fetch(f4 (&v)[4], const GemmOperand& o, const si
     }
 }
 
+// The same for the common case -- full 128-row tile, whole K tiles, float4-legal, single-level reduction index: four
+// unconditional loads off one running pointer (`at` already includes the thread's k position; it advances by one K tile per
+// iteration).  The general fetch above costs ~450 executed VALU/SALU instructions per K tile (bounds tests, two-level index
+// arithmetic), which on gfx950 come straight out of the fp32 MFMA issue time.
+template <bool KC>
+__device__ __forceinline__ void fetch_fast(f4 (&v)[4], const float* at, const size_t (&roff)[4], long long ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f4*>(KC ? at + roff[i] : at + (long long)(8 * i) * ks);
+}
+
 // registers -> LDS: K-contiguous operands as [row][k] (stride 36), row-contiguous ones as [k][row] (stride 132)
 template <bool KC>
 __device__ __forceinline__ void put(float* s, const f4 (&v)[4], int tid) {
@@ -103,8 +113,8 @@ __device__ __forceinline__ f4 frag(const float* s, int row, int kk, int g) {
     return v;
 }
 
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 3) void k_gemm_tr(const GemmArgs a) {
+template <bool AK, bool BK, bool FAST>
+__global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     constexpr int SA = AK ? kTM * kLdK : kTK * kLdR;
     constexpr int SB = BK ? kTM * kLdK : kTK * kLdR;
     __shared__ __attribute__((aligned(16))) float sA[SA];
@@ -112,10 +122,14 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTM;
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int m0 = by * kTM, n0 = bx * kTM;
     const int s16 = lane & 15, g = lane >> 4;
-    const int z = blockIdx.z;
+    const int zb = bz / a.splits, z = bz - zb * a.splits;     // (problem of the batch, K split)
     const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    a.A.p += (size_t)zb * a.bsA;
+    a.B.p += (size_t)zb * a.bsB;
+    a.C += (size_t)zb * a.bsC;
 
     f4 acc[4][4];                                   // [n tile][m tile]
 #pragma unroll
@@ -127,35 +141,76 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(const GemmArgs a) {
     row_offsets<AK>(a.A, roffA, m0, a.M, tid);
     row_offsets<BK>(a.B, roffB, n0, a.N, tid);
     f4 ra[4], rb[4];
-    fetch<AK>(ra, a.A, roffA, m0, a.M, kbeg, kend, tid);
-    fetch<BK>(rb, a.B, roffB, n0, a.N, kbeg, kend, tid);
+    // FAST: running pointers of this thread's share of the current K tile
+    const float* pa = nullptr;
+    const float* pb = nullptr;
+    if (FAST) {
+        pa = AK ? a.A.p + kbeg + (tid & 7) * 4 : a.A.p + roffA[0] + (long long)(kbeg + (tid >> 5)) * a.A.ks;
+        pb = BK ? a.B.p + kbeg + (tid & 7) * 4 : a.B.p + roffB[0] + (long long)(kbeg + (tid >> 5)) * a.B.ks;
+        fetch_fast<AK>(ra, pa, roffA, a.A.ks);
+        fetch_fast<BK>(rb, pb, roffB, a.B.ks);
+    } else {
+        fetch<AK>(ra, a.A, roffA, m0, a.M, kbeg, kend, tid);
+        fetch<BK>(rb, a.B, roffB, n0, a.N, kbeg, kend, tid);
+    }
     for (int k0 = kbeg; k0 < kend; k0 += kTK) {
         __syncthreads();
         put<AK>(sA, ra, tid);
         put<BK>(sB, rb, tid);
         __syncthreads();
-        if (k0 + kTK < kend) {              // next tile's global loads overlap this tile's MFMAs
+        if (FAST) {                         // next tile's global loads overlap this tile's MFMAs; the last iteration re-reads its
+            const long long adv = k0 + kTK < kend ? kTK : 0;          // own tile instead of branching around the loads
+            pa += AK ? adv : adv * a.A.ks;
+            pb += BK ? adv : adv * a.B.ks;
+            fetch_fast<AK>(ra, pa, roffA, a.A.ks);
+            fetch_fast<BK>(rb, pb, roffB, a.B.ks);
+            __builtin_amdgcn_sched_barrier(0);      // or the scheduler sinks these loads below the MFMAs, right in front of their use
+        } else if (k0 + kTK < kend) {
             fetch<AK>(ra, a.A, roffA, m0, a.M, k0 + kTK, kend, tid);
             fetch<BK>(rb, a.B, roffB, n0, a.N, k0 + kTK, kend, tid);
         }
+        if (FAST) {
+            // fragment loads run one step ahead of the MFMAs that use them (8 steps per K tile: 2 k-halves x 4 n tiles): the fast
+            // staging path leaves the registers for a second A set and a second B fragment at 3 waves / SIMD
+            f4 af[2][4], bf[2];
 #pragma unroll
-        for (int kk = 0; kk < kTK / 16; ++kk) {
-            f4 af[4];
+            for (int j = 0; j < 4; ++j) af[0][j] = frag<AK>(sA, wm * 64 + 16 * j + s16, 0, g);
+            bf[0] = frag<BK>(sB, wn * 64 + s16, 0, g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = frag<AK>(sA, wm * 64 + 16 * j + s16, kk, g);
+            for (int st = 0; st < 8; ++st) {
+                const int kk = st >> 2, i = st & 3;
+                if (st + 1 < 8) bf[(st + 1) & 1] = frag<BK>(sB, wn * 64 + 16 * ((st + 1) & 3) + s16, (st + 1) >> 2, g);
+                if (st == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {       // one B fragment live at a time keeps the kernel at 3 waves / SIMD
-                const f4 bf = frag<BK>(sB, wn * 64 + 16 * i + s16, kk, g);
+                    for (int j = 0; j < 4; ++j) af[1][j] = frag<AK>(sA, wm * 64 + 16 * j + s16, 1, g);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // pins [LDS reads of the next step][MFMAs of this step]
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(bf[e], af[j][e], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(bf[st & 1][e], af[kk][j][e], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < kTK / 16; ++kk) {
+                f4 af[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[j] = frag<AK>(sA, wm * 64 + 16 * j + s16, kk, g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {       // one B fragment live at a time keeps the kernel at 3 waves / SIMD
+                    const f4 bf = frag<BK>(sB, wn * 64 + 16 * i + s16, kk, g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(bf[e], af[j][e], acc[i][j]);
+                }
             }
         }
     }
     // lane (m = s16 of m tile j, g) holds n = n0 + wn*64 + 16*i + 4*g + {0..3}
-    const bool partial = gridDim.z > 1;
-    float* Cz = partial ? a.ws + (size_t)z * a.M * a.N : nullptr;
+    const bool partial = a.splits > 1;
+    float* Cz = partial ? a.ws + (size_t)bz * a.M * a.N : nullptr;
     const bool cvec = a.cns == 1 && (a.crs & 3) == 0 && (a.cri == INT_MAX || (a.cro & 3) == 0) && ((uintptr_t)a.C & 15) == 0 &&
                       (!a.Cpre || ((uintptr_t)a.Cpre & 15) == 0) && (!a.R || ((uintptr_t)a.R & 15) == 0) &&
                       (!a.bias || ((uintptr_t)a.bias & 15) == 0);
@@ -211,12 +266,14 @@ __global__ void k_splitk_reduce(const GemmArgs a, int Z) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)a.M * a.N) return;
     const int m = (int)(i / a.N), n = (int)(i % a.N);
+    const float* ws = a.ws + (size_t)blockIdx.y * Z * a.M * a.N;          // blockIdx.y: problem of the batch
+    float* C = a.C + (size_t)blockIdx.y * a.bsC;
     float v = 0.f;
-    for (int z = 0; z < Z; ++z) v += a.ws[(size_t)z * a.M * a.N + i];
+    for (int z = 0; z < Z; ++z) v += ws[(size_t)z * a.M * a.N + i];
     if (a.bias) v += a.bias[n];
     const size_t co = (size_t)(m / a.cri) * a.cro + (size_t)(m % a.cri) * a.crs + (size_t)n * a.cns;
-    if (a.accumulate) v += a.C[co];
-    a.C[co] = v;
+    if (a.accumulate) v += C[co];
+    C[co] = v;
 }
 
 hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits, hipStream_t st) {
@@ -225,17 +282,28 @@ hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits
     int kchunk = ((a.K + splits - 1) / splits + kTK - 1) / kTK * kTK;
     splits = (a.K + kchunk - 1) / kchunk;
     a.kchunk = kchunk;
-    if (splits > 1 && (!a.ws || (size_t)splits * a.M * a.N > a.ws_floats)) return hipErrorInvalidValue;
+    a.splits = splits;
+    if (a.nbatch < 1) a.nbatch = 1;
+    if (a.nbatch > 1 && (a.bias || a.Cpre || a.R)) return hipErrorInvalidValue;
+    if (splits > 1 && (!a.ws || (size_t)a.nbatch * splits * a.M * a.N > a.ws_floats)) return hipErrorInvalidValue;
     if (splits > 1 && (a.Cpre || a.R || a.act)) return hipErrorInvalidValue;
-    dim3 grid((a.N + kTM - 1) / kTM, (a.M + kTM - 1) / kTM, splits);
-    if (a_kcontig && b_kcontig) hipLaunchKernelGGL((k_gemm_tr<true, true>), grid, dim3(256), 0, st, a);
-    else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((k_gemm_tr<true, false>), grid, dim3(256), 0, st, a);
-    else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((k_gemm_tr<false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm_tr<false, false>), grid, dim3(256), 0, st, a);
+    dim3 grid((a.N + kTM - 1) / kTM, (a.M + kTM - 1) / kTM, a.nbatch * splits);
+    // fast staging path: full tiles, whole K tiles in every split, float4-legal operands with a single-level reduction index
+    const bool fast = a.M % kTM == 0 && a.N % kTM == 0 && a.K % kTK == 0 && a.A.vec && a.B.vec && a.A.ki == INT_MAX && a.B.ki == INT_MAX;
+#define LS_GEMM_LAUNCH(AKV, BKV)                                                                             \
+    do {                                                                                                     \
+        if (fast) hipLaunchKernelGGL((k_gemm_tr<AKV, BKV, true>), grid, dim3(256), 0, st, a);                \
+        else hipLaunchKernelGGL((k_gemm_tr<AKV, BKV, false>), grid, dim3(256), 0, st, a);                    \
+    } while (0)
+    if (a_kcontig && b_kcontig) LS_GEMM_LAUNCH(true, true);
+    else if (a_kcontig && !b_kcontig) LS_GEMM_LAUNCH(true, false);
+    else if (!a_kcontig && b_kcontig) LS_GEMM_LAUNCH(false, true);
+    else LS_GEMM_LAUNCH(false, false);
+#undef LS_GEMM_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splits == 1) return e;
     const size_t n = (size_t)a.M * a.N;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, splits);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), a.nbatch), dim3(256), 0, st, a, splits);
     return hipGetLastError();
 }
 

@@ -16,6 +16,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 cfg = synth.CONFIGS[ds]
 eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
 eng.load_state_dict(synth.make_state_dict(cfg))
+if os.environ.get("LS_PROF_PRECISION"):
+    eng.set_precision(os.environ["LS_PROF_PRECISION"])
 eng.set_schedule(orc.Schedule(8, ""))
 eng.prepare(synth.make_cond(cfg, B))
 for _ in range(2):
