@@ -366,6 +366,7 @@ hipError_t launch_conv_wgrad(const float* dc, const float* in, const float* stat
 namespace ls {
 
 constexpr int kDgQT = 64, kDgDld = kDgQT + 4, kDgCo = 64;
+constexpr int kDgEpS = 6 * kDgQT + 4;            // row stride of the epilogue tile [32][6*64] in LDS
 
 __global__ void k_build_dgrad_img(const float* __restrict__ w, float* __restrict__ img, int Cin, int Cout) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,7 +395,8 @@ hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout,
 __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc_in, long long sb, long long sc, long long sp,
                                                     const float* __restrict__ wimg, const float* __restrict__ craw, const float* __restrict__ stats,
                                                     float* __restrict__ dc_out, float* __restrict__ partial, int Cin, int Cout, int Lx, int Lout) {
-    __shared__ float dcs[kDgCo * kDgDld];
+    __shared__ __attribute__((aligned(16))) float smem[32 * kDgEpS > kDgCo * kDgDld ? 32 * kDgEpS : kDgCo * kDgDld];
+    float* dcs = smem;                 // main loop: dC [64 co][66 q + pad]; epilogue: dAct tile [32 ci][384 x + pad]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
@@ -412,12 +414,24 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
 
     for (int cc = 0; cc < Cout / kDgCo; ++cc) {
         __syncthreads();
-        for (int idx = tid; idx < kDgCo * (kDgQT + 2); idx += 256) {
-            const int co = idx / (kDgQT + 2), jj = idx - co * (kDgQT + 2);
-            const int p = q0 - 2 + jj;
-            const int pc = min(max(p, 0), Lout - 1);                  // clamped address: branch-free load
-            const float v = dc_in[(size_t)b * sb + (size_t)(cc * kDgCo + co) * sc + (size_t)pc * sp];
-            dcs[co * kDgDld + jj] = (p >= 0 && p < Lout) ? v : 0.f;
+        {
+            // all of this thread's loads first (clamped addresses: branch-free, in flight together), then the LDS writes
+            constexpr int kN = kDgCo * (kDgQT + 2), kPer = (kN + 255) / 256;
+            float v[kPer];
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int idx = min(tid + 256 * i, kN - 1);
+                const int co = idx / (kDgQT + 2), jj = idx - co * (kDgQT + 2);
+                const int pc = min(max(q0 - 2 + jj, 0), Lout - 1);
+                v[i] = dc_in[(size_t)b * sb + (size_t)(cc * kDgCo + co) * sc + (size_t)pc * sp];
+            }
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int idx = tid + 256 * i;
+                const int co = idx / (kDgQT + 2), jj = idx - co * (kDgQT + 2);
+                const int p = q0 - 2 + jj;
+                if (idx < kN) dcs[co * kDgDld + jj] = (p >= 0 && p < Lout) ? v[i] : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll 2
@@ -439,50 +453,58 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
             }
         }
     }
-    // epilogue: lane (q = s16, g) holds input channels ci0 + 16 cit + 4 g + e
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    float mean[4], rstd[4];
-    size_t rowoff[4];
+    // Epilogue.  A lane's accumulators are 6 consecutive x of 4 channels (x = 6 q + r), 24 B apart from the next lane's: written
+    // straight to HBM that is 48 scattered dword stores per lane (rocprofv3: 953 MB written for a 517 MB tensor, 35 % MFMA
+    // busy, 62 % of wave time in s_waitcnt).  The tile goes through LDS instead ([32 channels][384 x], reusing the operand
+    // buffer) and every wave then streams whole channel rows: coalesced c_raw loads and dy stores, one (sum dy, sum dy*y) pair
+    // per row and workgroup.
+    __syncthreads();
+    float* ep = smem;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const size_t row = (size_t)b * Cin + ci0 + 16 * cit + 4 * g + e;
-        mean[e] = stats[row * 2];
-        rstd[e] = stats[row * 2 + 1];
-        rowoff[e] = row * Lx;
-    }
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = q0 + 32 * qh + 16 * qt + s16;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const int x = 6 * q + r;
-            if (x < Lx) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float y = (craw[rowoff[e] + x] - mean[e]) * rstd[e];
-                    const float dy = y >= 0.f ? acc[qt][r][e] : 0.3f * acc[qt][r][e];
-                    dc_out[rowoff[e] + x] = dy;
-                    s1[e] += dy;
-                    s2[e] += dy * y;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            s1[e] += __shfl_xor(s1[e], o);
-            s2[e] += __shfl_xor(s2[e], o);
-        }
-    }
-    if (s16 == 0) {
-        const int nslot = gridDim.x * 2, slot = blockIdx.x * 2 + qh;
+    for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const size_t row = (size_t)b * Cin + ci0 + 16 * cit + 4 * g + e;
-            partial[(row * nslot + slot) * 2] = s1[e];
-            partial[(row * nslot + slot) * 2 + 1] = s2[e];
+            float* dst = ep + (16 * cit + 4 * g + e) * kDgEpS + 6 * (32 * qh + 16 * qt + s16);
+#pragma unroll
+            for (int r2 = 0; r2 < 3; ++r2) *reinterpret_cast<float2*>(dst + 2 * r2) = make_float2(acc[qt][2 * r2][e], acc[qt][2 * r2 + 1][e]);
+        }
+    __syncthreads();
+    const int x0 = 6 * q0, nx = min(6 * kDgQT, Lx - x0);                  // valid x of this tile (>= 1)
+    const int nslot = gridDim.x * 2;
+    float cv[8][6];                                                      // the accumulators are dead: their registers hold the c_raw tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float* cr = craw + ((size_t)b * Cin + ci0 + w + 4 * i) * Lx + x0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cv[i][k] = cr[min(lane + 64 * k, nx - 1)];   // clamped: 48 branch-free loads in flight together
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = w + 4 * i;
+        const size_t row = (size_t)b * Cin + ci0 + c;
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        float* dst = dc_out + row * Lx + x0;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int xl = lane + 64 * k;
+            const float y = (cv[i][k] - mean) * rstd;
+            const float av = ep[c * kDgEpS + xl];
+            const float dy = y >= 0.f ? av : 0.3f * av;
+            if (xl < nx) {
+                dst[xl] = dy;
+                s1 += dy;
+                s2 += dy * y;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (lane == 0) {                                                 // slot layout kept for the consumers: 2 per position tile
+            float* pp = partial + (row * nslot + blockIdx.x * 2) * 2;
+            pp[0] = s1; pp[1] = s2; pp[2] = 0.f; pp[3] = 0.f;
         }
     }
 }
