@@ -7,6 +7,7 @@
 // operand W[co][ci0+g][k] is pre-permuted on the host into per-lane order (one float4 = 4 consecutive MFMA steps).
 // Workgroup = 64 positions x 64 output channels of one sample: wave w owns 16 positions and 4 channel tiles.
 #include "ls_internal.h"
+#include "ls_lanes.h"
 #include "ls_train.h"
 
 namespace ls {
@@ -96,14 +97,10 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ i
                 // InstanceNorm statistics of this wave's 16 positions (lanes sharing g), two-pass inside the tile:
                 // (count, mean, M2) per (sample, channel, position tile); k_stats_merge combines them (Chan et al.)
                 const int nv = min(16, max(0, Lout - (p0 + 16 * w)));
-                float s1 = valid ? v : 0.f;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) s1 += __shfl_xor(s1, o);
+                const float s1 = row16_sum(valid ? v : 0.f);
                 const float mean = nv > 0 ? s1 / (float)nv : 0.f;
                 const float d = valid ? v - mean : 0.f;
-                float m2 = d * d;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
+                const float m2 = row16_sum(d * d);
                 if (s16 == 0) {
                     float* sp = spart + (((size_t)b * Cout + co) * (gridDim.x * 4) + blockIdx.x * 4 + w) * 3;
                     sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
@@ -204,8 +201,7 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ wav
             }
         }
         if (spart) {
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) s1 += __shfl_xor(s1, o);
+            s1 = wave_sum(s1);
             const float mean = nv > 0 ? s1 / (float)nv : 0.f;
             float m2 = 0.f;
 #pragma unroll
@@ -213,8 +209,7 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ wav
                 const float d = valid[q] ? v[q] - mean : 0.f;
                 m2 = fmaf(d, d, m2);
             }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) m2 += __shfl_xor(m2, o);
+            m2 = wave_sum(m2);
             if ((tid & 63) == 0) {
                 float* sp = spart + (((size_t)b * 32 + co) * np + blockIdx.x * 4 + wv) * 3;
                 sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
@@ -497,11 +492,8 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
                 s2 += dy * y;
             }
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            s1 += __shfl_xor(s1, o);
-            s2 += __shfl_xor(s2, o);
-        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
         if (lane == 0) {                                                 // slot layout kept for the consumers: 2 per position tile
             float* pp = partial + (row * nslot + blockIdx.x * 2) * 2;
             pp[0] = s1; pp[1] = s2; pp[2] = 0.f; pp[3] = 0.f;

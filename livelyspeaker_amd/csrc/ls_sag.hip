@@ -4,6 +4,7 @@
 // FFN 512-1024-512 with exact GELU); finallayer -> [B, J, F, T].  Runs once per batch (it produces init_image for
 // the RAG refine loop), so the small kernels here are plain VALU; the linears use the fp32 MFMA GEMM (ls_gemm.hip).
 #include "ls_internal.h"
+#include "ls_lanes.h"
 
 namespace ls {
 
@@ -84,14 +85,12 @@ __global__ __launch_bounds__(256) void k_layernorm512(const float* __restrict__ 
         v1 += br[lane + 64];
     }
     float s = (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum(s);
     const float mean = s * (1.0f / kD);
     float q = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const float a = v0[e] - mean, c = v1[e] - mean; q += a * a + c * c; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_sum(q);
     const float rstd = 1.0f / sqrtf(q * (1.0f / kD) + 1e-5f);
     const f4* wr = reinterpret_cast<const f4*>(w);
     const f4* be = reinterpret_cast<const f4*>(beta);

@@ -22,6 +22,7 @@
 //   * token mixing (Conv1d(S,S,1) over the token axis) is a second small MFMA GEMM against a
 //     block-diagonal [R x R] operand; its output lands directly in the residual layout.
 #include "ls_step_common.h"
+#include "ls_lanes.h"
 
 namespace ls {
 
@@ -239,17 +240,22 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     const float d = X[cb][t][j] - m;
                     m2 = fmaf(d, d, m2);
                 }
-            {   // merge with the lane group 16 lanes away (16 + 16 values), then 32 lanes away (32 + 32)
-                const float mo = __shfl_xor(m, 16), m2o = __shfl_xor(m2, 16);
-                const float d = mo - m;
-                m2 = (m2 + m2o) + d * d * 8.0f;
-                m = 0.5f * (m + mo);
+            {   // merge with the lane group 16 lanes away (16 + 16 values), then 32 lanes away (32 + 32); the update is symmetric
+                // in the pair, so both members of the v_permlane swap are used as they come (no select, no LDS round trip)
+                float ma, mb, qa, qb;
+                xor16_pair(m, ma, mb);
+                xor16_pair(m2, qa, qb);
+                const float d = mb - ma;
+                m2 = (qa + qb) + d * d * 8.0f;
+                m = 0.5f * (ma + mb);
             }
             {
-                const float mo = __shfl_xor(m, 32), m2o = __shfl_xor(m2, 32);
-                const float d = mo - m;
-                m2 = (m2 + m2o) + d * d * 16.0f;
-                m = 0.5f * (m + mo);
+                float ma, mb, qa, qb;
+                xor32_pair(m, ma, mb);
+                xor32_pair(m2, qa, qb);
+                const float d = mb - ma;
+                m2 = (qa + qb) + d * d * 16.0f;
+                m = 0.5f * (ma + mb);
             }
             if (g == 0) pst[w * 80 + 16 * t + s16] = (f2){m, m2};
         }
@@ -635,8 +641,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         f4 v = racc4[c2][r];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            v[i] += __shfl_xor(v[i], 16);
-                            v[i] += __shfl_xor(v[i], 32);
+                            v[i] = xor32_sum(xor16_sum(v[i]));
                         }
                         // lane (block = lane>>2, row = lane&3) holds channels 4*(s16>>2)..+3 of row 4r + (lane&3)
                         if (g == 0) *reinterpret_cast<f4*>(&rem[(c2 * NREM + 4 * r + (lane & 3)) * 16 + 4 * (s16 >> 2)]) = v;
@@ -645,8 +650,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                     for (int r = 0; r < NRV; ++r) {
                         float v = racc[c2][r];
-                        v += __shfl_xor(v, 16);
-                        v += __shfl_xor(v, 32);
+                        v = xor32_sum(xor16_sum(v));
                         if (g == 0) rem[(c2 * NREM + r) * 16 + s16] = v;
                     }
                 }

@@ -15,6 +15,7 @@
 #include "ls_internal.h"
 #include "ls_step_common.h"
 #include "ls_train.h"
+#include "ls_lanes.h"
 
 namespace ls {
 
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
             float u = s1[t], v = s2[t];
-            u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
-            u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+            u = xor32_sum(xor16_sum(u));
+            v = xor32_sum(xor16_sum(v));
             if (g == 0) pst[w * 80 + 16 * t + s16] = (f2){u, v};
         }
         __syncthreads();
@@ -131,9 +132,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
     // column partials of this workgroup: sum over the 16 row lanes, lanes s16 == 0 write [wg][layer][which][512]
     auto write_colpart = [&](f4 v, int l, int which, int cb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) v[j] += __shfl_xor(v[j], o);
+        for (int j = 0; j < 4; ++j) v[j] = row16_sum(v[j]);
         if (s16 == 0) *reinterpret_cast<f4*>(a.colpart + (((size_t)b * a.layers + l) * 5 + which) * kD + chw + 16 * cb) = v;
     };
 
@@ -247,8 +246,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                         f4 v = racc4[c2][r];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            v[i] += __shfl_xor(v[i], 16);
-                            v[i] += __shfl_xor(v[i], 32);
+                            v[i] = xor32_sum(xor16_sum(v[i]));
                         }
                         if (g == 0) *reinterpret_cast<f4*>(&rem[(c2 * NREM + 4 * r + (lane & 3)) * 16 + 4 * (s16 >> 2)]) = v;
                     }
@@ -256,8 +254,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
 #pragma unroll
                     for (int r = 0; r < NRV; ++r) {
                         float v = racc[c2][r];
-                        v += __shfl_xor(v, 16);
-                        v += __shfl_xor(v, 32);
+                        v = xor32_sum(xor16_sum(v));
                         if (g == 0) rem[(c2 * NREM + r) * 16 + s16] = v;
                     }
                 }
@@ -367,12 +364,10 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                 else if (r < R) h1 += G[cb][t];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    h0[j] += __shfl_xor(h0[j], o);
-                    h1[j] += __shfl_xor(h1[j], o);
-                }
+            for (int j = 0; j < 4; ++j) {
+                h0[j] = row16_sum(h0[j]);
+                h1[j] = row16_sum(h1[j]);
+            }
             if (s16 == 0) {
                 float* dst = a.dembp + ((size_t)l * a.B + 2 * b) * kD + chw + 16 * cb;
                 *reinterpret_cast<f4*>(dst) = h0;

@@ -4,17 +4,13 @@
 // (no float atomics), AdamW.  All fp32.
 #include "ls_internal.h"
 #include "ls_train.h"
+#include "ls_lanes.h"
 
 namespace ls {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kDm = 512;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 __device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + expf(-a)); }
 __device__ __forceinline__ float silu_f_(float a) { return a * sigmoidf_(a); }
 __device__ __forceinline__ float silu_grad(float a) {
