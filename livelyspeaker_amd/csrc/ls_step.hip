@@ -288,7 +288,9 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     // write the normalised operand of this lane's channels into the LDS buffer: LN1 applies alpha/beta here
     // (2 FMAs per element); LN2's alpha/beta are folded into the channel-mix weights/bias on the host
     // (W' = W.diag(alpha), b' = b + W.beta), so its operand is just (x - mean) * rstd: 1 FMA per element.
-    auto ln_store = [&](const float* alpha, const float* beta, float* gout) {
+    // alv/bev: LN1's alpha/beta of this lane's channels, loaded by the caller BEFORE the statistics (a load per channel block
+    // here cost four serialised L2 round trips per layer); alpha == nullptr: LN2, affine folded into the weights
+    auto ln_store = [&](const float* alpha, const f4 (&alv)[kCB], const f4 (&bev)[kCB], float* gout) {
         (void)gout;
         float nmr[kNT];
 #pragma unroll
@@ -297,8 +299,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         for (int cb = 0; cb < kCB; ++cb) {
             f4 al, be;
             if (alpha) {
-                al = *g4(alpha + chw + 16 * cb);
-                be = *g4(beta + chw + 16 * cb);
+                al = alv[cb];
+                be = bev[cb];
             }
 #pragma unroll
             for (int t = 0; t < kNT; ++t)
@@ -381,10 +383,16 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     if (valid_of(t)) X[cb][t] += e[cb];
         }
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
+        f4 alv[kCB], bev[kCB];                      // LN1 affine: in flight during the statistics and their barrier
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb) {
+            alv[cb] = *g4(a.W->ln1a + l * kD + chw + 16 * cb);
+            bev[cb] = *g4(a.W->ln1b + l * kD + chw + 16 * cb);
+        }
         ln_stats(TRAIN ? a.tr_s1 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(2 + 8 * l);
         fresh();
-        ln_store(a.W->ln1a + l * kD, a.W->ln1b + l * kD, TRAIN ? a.tr_u1 + (size_t)l * a.tr_B * S * kD : nullptr);
+        ln_store(a.W->ln1a + l * kD, alv, bev, TRAIN ? a.tr_u1 + (size_t)l * a.tr_B * S * kD : nullptr);
         // no workgroup barrier here: token mixing contracts over ROWS, so wave w only reads back the 64 channel columns
         // it has just written itself (LDS operations of one wave execute in order); the LN statistics barrier above
         // already ordered these stores after every wave's reads of the previous operand.
@@ -477,12 +485,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         stamp(4 + 8 * l);
         fresh();
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
+        f4 alv2[kCB], bev2[kCB];
+        if constexpr (TRAIN) {   // training keeps LN2's affine explicit (alpha2 / beta2 get their own gradients)
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                alv2[cb] = *g4(a.W->ln2a + l * kD + chw + 16 * cb);
+                bev2[cb] = *g4(a.W->ln2b + l * kD + chw + 16 * cb);
+            }
+        }
         ln_stats(TRAIN ? a.tr_s2 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(5 + 8 * l);      // its two barriers also order every wave's token-mix reads before the stores below
-        if constexpr (TRAIN)   // training keeps LN2's affine explicit (alpha2 / beta2 get their own gradients)
-            ln_store(a.W->ln2a + l * kD, a.W->ln2b + l * kD, a.tr_u2 + (size_t)l * a.tr_B * S * kD);
-        else
-            ln_store(nullptr, nullptr, nullptr);
+        ln_store(TRAIN ? a.W->ln2a : nullptr, alv2, bev2, TRAIN ? a.tr_u2 + (size_t)l * a.tr_B * S * kD : nullptr);
         __syncthreads();
         stamp(6 + 8 * l);
         if constexpr (PREC == 1) {
@@ -565,9 +578,11 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             f4 acc[2][kFullTiles];
             float racc[2][NRV];
             f4 racc4[2][NRG];
+            f4 bcv[2];                                    // Linear bias (+ W.beta of LN2); kept for the ragged rows' epilogue
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
-                const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));   // Linear bias (+ W.beta of LN2)
+                const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));
+                bcv[c2] = bc;
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = bc;
 #pragma unroll
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int cb = 2 * p + c2;
-                const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * cb);
+                const f4 bc = bcv[c2];
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t) {
                     if constexpr (TRAIN) {                // pre-activation of the channel-mixing linear
