@@ -5,6 +5,8 @@
 """
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -14,8 +16,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libls_hip.so")
 SOURCES = ["ls_api.cpp", "ls_sag_api.cpp", "ls_step.hip", "ls_step_seq.hip", "ls_prepare.hip", "ls_gemm.hip", "ls_sag.hip", "ls_post.hip", "ls_conv.hip", "ls_train_api.cpp", "ls_train_gemm.hip", "ls_train_kernels.hip", "ls_train_bwd.hip", "ls_eval.hip"]
-HEADERS = [os.path.join(CSRC, "ls_internal.h"), os.path.join(CSRC, "ls_philox.h"), os.path.join(CSRC, "ls_step_common.h"),
-           os.path.join(ROOT, "include", "ls_hip.h")]
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "ls_hip.h")]
+STAMP = LIB + ".srchash"          # hash of the sources the library was built from (travels with it; git-ignored)
 
 
 def hipcc_path() -> str:
@@ -25,9 +27,22 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
 
 
+def source_hash() -> str:
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
+    """Content-based when the build left its stamp (file times do not survive every copy of the tree); mtimes otherwise."""
     if not os.path.exists(LIB):
         return True
+    if os.path.exists(STAMP):
+        with open(STAMP) as f:
+            return f.read().strip() != source_hash()
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
@@ -42,13 +57,21 @@ def build_library(force: bool = False, verbose: bool = False, defines=(), out: s
     # the scalar form next to MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    tmp = f"{LIB}.tmp{os.getpid()}"              # several ranks may find the library stale at once: private temp, atomic rename
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
+    digest = source_hash()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
+    if out is None and not defines:
+        with open(STAMP + f".tmp{os.getpid()}", "w") as f:
+            f.write(digest + "\n")
+        os.replace(STAMP + f".tmp{os.getpid()}", STAMP)
     return LIB
 
 
