@@ -89,8 +89,10 @@ struct StepArgs {
     // ---- training-forward variant (k_step<..., TRAIN = 1>, ls_train_api.cpp): a workgroup holds samples 2b (rows 0..S-1) and
     // 2b+1 (rows S..2S-1) of a single pass and writes every tensor the backward needs straight from registers.
     // All are [L][tr_B*S][512] (stats [L][tr_B*S][2]); temb/temb_stride give one timestep-embedding row per SAMPLE.
+    // tr_x1 / tr_x2: the NORMALISED inputs x-hat = (x - mean) * rstd of LayerNorm 1 / 2 (pre-affine); tr_a1 / tr_a2: the
+    // pre-activations of the two mixes; tr_s1 / tr_s2: (mean, rstd).
     const float* tr_x0;      // [tr_B*S][512] token sequences entering layer 0
-    float* tr_x1; float* tr_u1; float* tr_a1; float* tr_x2; float* tr_u2; float* tr_a2;
+    float* tr_x1; float* tr_a1; float* tr_x2; float* tr_a2;
     float* tr_s1; float* tr_s2;
     float* tr_xout;          // [tr_B*S][512] output of the last layer
     int tr_B;

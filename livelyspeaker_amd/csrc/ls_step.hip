@@ -314,9 +314,14 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 } else if (valid_of(t)) {
                     f4 u;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        u[j] = fmaf(X[cb][t][j], rstd[t], nmr[t]);
-                        if (alpha) u[j] = fmaf(u[j], al[j], be[j]);
+                    for (int j = 0; j < 4; ++j) u[j] = fmaf(X[cb][t][j], rstd[t], nmr[t]);
+                    if constexpr (TRAIN) {                // x-hat is what the backward needs (LayerNorm backward directly; the
+                        const int gr = grow_of(t);        // weight gradients rebuild U = alpha * x-hat + beta from it)
+                        if (gr >= 0) *reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb) = u;
+                    }
+                    if (alpha) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) u[j] = fmaf(u[j], al[j], be[j]);
                     }
                     if (PREC == 1 && alpha) {
                         // token-mix operand, bf16x3: the contraction runs over ROWS, so the MFMA A operand needs 8
@@ -348,10 +353,6 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         *reinterpret_cast<bf4*>(&Ul[row_of(t) * kUStride + chw + 16 * cb]) = lo;
                     } else {
                         *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
-                        if constexpr (TRAIN) {            // the normalised operand is also an input of the weight gradients
-                            const int gr = grow_of(t);
-                            if (gr >= 0) *reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb) = u;
-                        }
                     }
                 }
         }
@@ -370,7 +371,6 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                     for (int cb = 0; cb < kCB; ++cb) X[cb][t] += *reinterpret_cast<const f4*>(te + 16 * cb);
             }
-            store_rows(a.tr_x1, l);
         } else {   // x = x + emb  (emb re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
             const float* te = a.temb + (size_t)b * a.temb_stride + chw;
             f4 e[kCB];
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         ln_stats(TRAIN ? a.tr_s1 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(2 + 8 * l);
         fresh();
-        ln_store(a.W->ln1a + l * kD, alv, bev, TRAIN ? a.tr_u1 + (size_t)l * a.tr_B * S * kD : nullptr);
+        ln_store(a.W->ln1a + l * kD, alv, bev, TRAIN ? a.tr_x1 + (size_t)l * a.tr_B * S * kD : nullptr);
         // no workgroup barrier here: token mixing contracts over ROWS, so wave w only reads back the 64 channel columns
         // it has just written itself (LDS operations of one wave execute in order); the LN statistics barrier above
         // already ordered these stores after every wave's reads of the previous operand.
@@ -481,7 +481,6 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 }
             }
         }
-        if constexpr (TRAIN) store_rows(a.tr_x2, l);
         stamp(4 + 8 * l);
         fresh();
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
@@ -495,7 +494,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         }
         ln_stats(TRAIN ? a.tr_s2 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(5 + 8 * l);      // its two barriers also order every wave's token-mix reads before the stores below
-        ln_store(TRAIN ? a.W->ln2a : nullptr, alv2, bev2, TRAIN ? a.tr_u2 + (size_t)l * a.tr_B * S * kD : nullptr);
+        ln_store(TRAIN ? a.W->ln2a : nullptr, alv2, bev2, TRAIN ? a.tr_x2 + (size_t)l * a.tr_B * S * kD : nullptr);
         __syncthreads();
         stamp(6 + 8 * l);
         if constexpr (PREC == 1) {

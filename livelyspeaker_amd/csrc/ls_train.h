@@ -72,7 +72,7 @@ hipError_t launch_build_train_images(const TrainImgArgs& a, hipStream_t st);
 // fused mixer backward (ls_train_bwd.hip): saved activations in, dA2 / dA1 (weight-gradient operands) and partials out
 struct MixerBwdArgs {
     float* g;                 // [B*S][512] in: d loss / d mixer output; out: d loss / d token sequences entering layer 0
-    const float* a2; const float* a1; const float* x2; const float* x1; const float* s2; const float* s1;   // [L][B*S][512 | 2]
+    const float* a2; const float* a1; const float* x2; const float* x1; const float* s2; const float* s1;   // [L][B*S][512 | 2]; x1 / x2 = x-hat
     float* da2; float* da1;   // [L][B*S][512]
     float* scratch;           // [workgroups][2S][512]
     float* colpart;           // [workgroups][L][5][512]: d bias(block2), d alpha2, d beta2, d alpha1, d beta1 partial column sums
@@ -84,8 +84,11 @@ hipError_t init_mixer_bwd();
 hipError_t launch_mixer_bwd(Variant v, const MixerBwdArgs& a, hipStream_t st);
 // ---- backward ----
 hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, float* partial, int rows, int nwaves, hipStream_t st);
-// token-weight gradient partials of all layers: pw[L][B*4][S*S], pb[L][B*4][S]
-hipError_t launch_tokmix_wgrad(const float* da, const float* u1, float* pw, float* pb, int B, int S, int layers, hipStream_t st);
+// token-weight gradient partials of all layers: pw[L][B*4][S*S], pb[L][B*4][S]; xh1 = saved x-hat of LayerNorm 1, l1a / l1b [L][512]
+hipError_t launch_tokmix_wgrad(const float* da, const float* xh1, const float* l1a, const float* l1b, float* pw, float* pb, int B, int S,
+                               int layers, hipStream_t st);
+// dW[l][o][i] = dW[l][o][i] * alpha2[l][i] + beta2[l][i] * db[l][o] (dW came from the product with x-hat instead of U2)
+hipError_t launch_wch_affine(float* dw, const float* db, const float* l2a, const float* l2b, long long lstride, int layers, hipStream_t st);
 hipError_t launch_partial_reduce(const float* partial, int n, long long stride, int cols, float* out, int accumulate, hipStream_t st);
 // the same for `groups` independent (partial, out) pairs in one launch: group y reads partial + y*pgstride, writes out + y*ogstride
 hipError_t launch_partial_reduce_groups(const float* partial, int n, long long stride, int cols, float* out, int groups, long long pgstride,

@@ -63,7 +63,7 @@ struct ls_trainer {
     int capB = 0;
     Buf x_start, noise, drop, eps, audio, origin_x, vid, emo, ca, cb, tidx;
     Buf c[4], st[3], img[4], dimg[4], feat, x_t, zc, mu, lv, pe_rows, pre1, hid, emb, xcur;
-    Buf X1, A1, X2, A2, U1, U2, S1, S2, dA2, dA1, colpart, dembp;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward
+    Buf X1, A1, X2, A2, S1, S2, dA2, dA1, colpart, dembp;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward; X1 / X2 hold x-hat
     Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw, twchT, twwT;    // mixer weight images + the DevWeights block k_step reads
     TrainImgArgs img_args{};
     Buf out, dout, lossp, kldp, terms, G, T1, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dc[3], ws;
@@ -178,7 +178,7 @@ int ensure_batch(ls_trainer* h, int B) {
     for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));
     for (Buf* b : {&h->xcur, &h->G}) HIPCHK(h, E(*b, R * kD));
     HIPCHK(h, E(h->T1, (size_t)((B + 1) / 2) * 2 * d0.S * kD));      // gy slabs of the fused mixer backward
-    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->dA2, &h->dA1}) HIPCHK(h, E(*b, (size_t)d0.L * R * kD));
+    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->dA2, &h->dA1}) HIPCHK(h, E(*b, (size_t)d0.L * R * kD));
     HIPCHK(h, E(h->colpart, (size_t)((B + 1) / 2) * d0.L * 5 * kD)); HIPCHK(h, E(h->dembp, (size_t)d0.L * B * kD));
     for (Buf* b : {&h->S1, &h->S2}) HIPCHK(h, E(*b, (size_t)d0.L * R * 2));
     HIPCHK(h, E(h->out, (size_t)B * d0.T * d0.JF)); HIPCHK(h, E(h->dout, (size_t)B * d0.T * d0.JF));
@@ -271,7 +271,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         HIPCHK(h, gemm_run(h, b2, true, true));
     }
     {   // TransMLP: all 8 MLPblocks (mlp_module.py:67-91) in ONE launch of the fused kernel the sampler uses (ls_step.hip,
-        // TRAIN variant): a workgroup keeps two samples' residual streams in registers and writes X1 / U1 / A1 / X2 / U2 / A2
+        // TRAIN variant): a workgroup keeps two samples' residual streams in registers and writes x-hat1 / A1 / x-hat2 / A2
         // and the LayerNorm statistics of every layer for the backward; the last layer's output lands back in xcur.
         h->img_args.P = h->P.f();
         HIPCHK(h, launch_build_train_images(h->img_args, st));
@@ -281,7 +281,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         a.layers = d.L;
         a.sampler = kNone;
         a.tr_x0 = h->xcur.f(); a.tr_xout = h->xcur.f(); a.tr_B = B;
-        a.tr_x1 = h->X1.f(); a.tr_u1 = h->U1.f(); a.tr_a1 = h->A1.f(); a.tr_x2 = h->X2.f(); a.tr_u2 = h->U2.f(); a.tr_a2 = h->A2.f();
+        a.tr_x1 = h->X1.f(); a.tr_a1 = h->A1.f(); a.tr_x2 = h->X2.f(); a.tr_a2 = h->A2.f();
         a.tr_s1 = h->S1.f(); a.tr_s2 = h->S2.f();
         HIPCHK(h, launch_train_mixer_fwd(d.NPRE == 2 ? kBEAT : kTED, a, st));
     }
@@ -332,12 +332,14 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
     HIPCHK(h, launch_partial_reduce_groups(h->colpart.f() + kD, nwg, cps, 2 * kD, g0 + h->img_args.o_a2, d.L, 5 * kD, ls, st));
     HIPCHK(h, launch_partial_reduce_groups(h->colpart.f() + 3 * kD, nwg, cps, 2 * kD, g0 + h->img_args.o_a1, d.L, 5 * kD, ls, st));
     // token weights of all layers: dWt[s'][s] = sum_{b,c} dA1[b][s'][c] U1[b][s][c], d bt[s'] = sum_{b,c} dA1[b][s'][c]
-    HIPCHK(h, launch_tokmix_wgrad(h->dA1.f(), h->U1.f(), h->pw.f(), h->pb.f(), B, S, d.L, st));
+    HIPCHK(h, launch_tokmix_wgrad(h->dA1.f(), h->X1.f(), h->tl1a.f(), h->tl1b.f(), h->pw.f(), h->pb.f(), B, S, d.L, st));
     HIPCHK(h, launch_partial_reduce_groups(h->pw.f(), B * 4, (long long)S * S, S * S, g0 + h->img_args.o_wt, d.L, (long long)B * 4 * S * S, ls, st));
     HIPCHK(h, launch_partial_reduce_groups(h->pb.f(), B * 4, S, S, g0 + h->img_args.o_bt, d.L, (long long)B * 4 * S, ls, st));
-    // channel-mix weight gradients of all layers: dW[l] = dA2[l]^T U2[l]
-    HIPCHK(h, wgrad_batched(h, op_cols(lay(h->dA2, 0, R), kD, kD, R), op_cols(lay(h->U2, 0, R), kD, kD, R), g0 + h->img_args.o_w, kD, kD, kD, R, d.L,
+    // channel-mix weight gradients of all layers: dW[l] = dA2[l]^T U2[l] with U2 = alpha2 * x-hat2 + beta2: the product runs on the saved
+    // x-hat2 and the affine is applied to the 512 x 512 result (the bias gradients d b = colsum(dA2) were reduced above)
+    HIPCHK(h, wgrad_batched(h, op_cols(lay(h->dA2, 0, R), kD, kD, R), op_cols(lay(h->X2, 0, R), kD, kD, R), g0 + h->img_args.o_w, kD, kD, kD, R, d.L,
                             (long long)R * kD, (long long)R * kD, ls));
+    HIPCHK(h, launch_wch_affine(g0 + h->img_args.o_w, g0 + h->img_args.o_b, h->tl2a.f(), h->tl2b.f(), ls, d.L, st));
     HIPCHK(h, launch_partial_reduce(h->dembp.f(), d.L, (long long)B * kD, B * kD, h->demb.f(), 0, st));
     return LS_OK;
 }
@@ -536,7 +538,7 @@ void ls_train_destroy(ls_trainer* h) {
                              &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->col, &h->ws};
     for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
-    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->U1, &h->U2, &h->S1, &h->S2, &h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a,
+    for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->S1, &h->S2, &h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a,
                    &h->tl2b, &h->tdevw, &h->twchT, &h->twwT, &h->dA2, &h->dA1, &h->colpart, &h->dembp})
         all.push_back(b);
     for (Buf* b : all) b->release();

@@ -107,8 +107,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                 for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float xh = (x[cb][j] - st.x) * st.y;
-                        G[cb][t][j] += st.y * (gy[cb][j] - m1[t] - xh * m2[t]);
+                        G[cb][t][j] += st.y * (gy[cb][j] - m1[t] - x[cb][j] * m2[t]);      // x: saved x-hat
                     }
             }
         }
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         f4 gy;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float xh = (x[j] - st.x) * st.y;
+            const float xh = x[j];                // the forward saved x-hat itself
             gy[j] = du[j] * al[j];
             s1 += gy[j];
             s2 = fmaf(gy[j], xh, s2);

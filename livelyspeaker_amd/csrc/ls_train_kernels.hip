@@ -91,8 +91,9 @@ constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36;
 // Token-weight gradient of every layer in one launch (grid.z = layer): per (sample, 128-channel slab) workgroup
 //   pw[l][(b,slab)][s'][s] = sum_c dA1[l][b][s'][c] U1[l][b][s][c],   pb[l][(b,slab)][s'] = sum_c dA1[l][b][s'][c]
 // (dA1 comes from the fused mixer backward).  2 x 4 register tile per thread: 6 LDS reads per 8 FMAs.
-__global__ __launch_bounds__(256) void k_tokmix_wgrad(const float* __restrict__ da, const float* __restrict__ u1, float* __restrict__ pw,
-                                                      float* __restrict__ pb, int S, int B) {
+// xh1 is the saved x-hat of LayerNorm 1; the operand U1 = alpha1 * x-hat + beta1 is rebuilt while it is staged.
+__global__ __launch_bounds__(256) void k_tokmix_wgrad(const float* __restrict__ da, const float* __restrict__ xh1, const float* __restrict__ l1a,
+                                                      const float* __restrict__ l1b, float* __restrict__ pw, float* __restrict__ pb, int S, int B) {
     __shared__ float das[(kTokMaxS + 4) * kTokLd];
     __shared__ float us[(kTokMaxS + 4) * kTokLd];
     const int b = blockIdx.x, c0 = blockIdx.y * kTokC, l = blockIdx.z, tid = threadIdx.x;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void k_tokmix_wgrad(const float* __restrict__ 
     for (int i = tid; i < (kTokMaxS + 4) * kTokC; i += 256) {
         const int r = i / kTokC, cc = i % kTokC;
         const size_t o = lbase + ((size_t)b * S + min(r, S - 1)) * kDm + c0 + cc;        // clamped address, branch-free loads
-        const float dv = da[o], uv = u1[o];
+        const float dv = da[o], uv = fmaf(xh1[o], l1a[l * kDm + c0 + cc], l1b[l * kDm + c0 + cc]);
         das[r * kTokLd + cc] = r < S ? dv : 0.f;          // rows S..S+3 are zero so that the 4-wide tiles below need no masks
         us[r * kTokLd + cc] = r < S ? uv : 0.f;
     }
@@ -133,9 +134,26 @@ __global__ __launch_bounds__(256) void k_tokmix_wgrad(const float* __restrict__ 
     }
 }
 
-hipError_t launch_tokmix_wgrad(const float* da, const float* u1, float* pw, float* pb, int B, int S, int layers, hipStream_t st) {
+hipError_t launch_tokmix_wgrad(const float* da, const float* xh1, const float* l1a, const float* l1b, float* pw, float* pb, int B, int S,
+                               int layers, hipStream_t st) {
     if (S > kTokMaxS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tokmix_wgrad, dim3(B, kDm / kTokC, layers), dim3(256), 0, st, da, u1, pw, pb, S, B);
+    hipLaunchKernelGGL(k_tokmix_wgrad, dim3(B, kDm / kTokC, layers), dim3(256), 0, st, da, xh1, l1a, l1b, pw, pb, S, B);
+    return hipGetLastError();
+}
+
+// Channel-mix weight gradient from the product with x-hat: the forward operand was U2 = alpha2 * x-hat2 + beta2, so
+//   dW[o][i] = sum_r dA2[r][o] U2[r][i] = alpha2[i] * (dA2^T x-hat2)[o][i] + beta2[i] * db[o],   db[o] = sum_r dA2[r][o] (the bias gradient).
+// One thread per element of [L][512][512]; dw / db are addressed through the flat gradient array (per-layer stride lstride).
+__global__ __launch_bounds__(256) void k_wch_affine(float* __restrict__ dw, const float* __restrict__ db, const float* __restrict__ l2a,
+                                                    const float* __restrict__ l2b, long long lstride) {
+    const int l = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;       // e = o * 512 + i
+    const int o = e >> 9, i = e & 511;
+    float* p = dw + (size_t)l * lstride + e;
+    *p = fmaf(*p, l2a[l * kDm + i], l2b[l * kDm + i] * db[(size_t)l * lstride + o]);
+}
+
+hipError_t launch_wch_affine(float* dw, const float* db, const float* l2a, const float* l2b, long long lstride, int layers, hipStream_t st) {
+    hipLaunchKernelGGL(k_wch_affine, dim3(kDm * kDm / 256, layers), dim3(256), 0, st, dw, db, l2a, l2b, lstride);
     return hipGetLastError();
 }
 
