@@ -74,7 +74,6 @@ struct MixerBwdArgs {
     float* g;                 // [B*S][512] in: d loss / d mixer output; out: d loss / d token sequences entering layer 0
     const float* a2; const float* a1; const float* x2; const float* x1; const float* s2; const float* s1;   // [L][B*S][512 | 2]; x1 / x2 = x-hat
     float* da2; float* da1;   // [L][B*S][512]
-    float* scratch;           // [workgroups][2S][512]
     float* colpart;           // [workgroups][L][5][512]: d bias(block2), d alpha2, d beta2, d alpha1, d beta1 partial column sums
     float* dembp;             // [L][B][512] per-layer d(timestep embedding)
     const float* wchT_img; const float* wwT_img; const float* ln2a; const float* ln1a;   // images / [L][512]

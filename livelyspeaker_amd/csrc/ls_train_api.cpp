@@ -66,7 +66,7 @@ struct ls_trainer {
     Buf X1, A1, X2, A2, S1, S2, dA2, dA1, colpart, dembp;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward; X1 / X2 hold x-hat
     Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw, twchT, twwT;    // mixer weight images + the DevWeights block k_step reads
     TrainImgArgs img_args{};
-    Buf out, dout, lossp, kldp, terms, G, T1, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dc[3], ws;
+    Buf out, dout, lossp, kldp, terms, G, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dc[3], ws;
     size_t ws_floats = 0;
     int B = 0;
     bool have_forward = false;
@@ -177,7 +177,6 @@ int ensure_batch(ls_trainer* h, int B) {
     HIPCHK(h, E(h->zc, (size_t)B * kSpk)); HIPCHK(h, E(h->dzc, (size_t)B * kSpk));
     for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));
     for (Buf* b : {&h->xcur, &h->G}) HIPCHK(h, E(*b, R * kD));
-    HIPCHK(h, E(h->T1, (size_t)((B + 1) / 2) * 2 * d0.S * kD));      // gy slabs of the fused mixer backward
     for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->dA2, &h->dA1}) HIPCHK(h, E(*b, (size_t)d0.L * R * kD));
     HIPCHK(h, E(h->colpart, (size_t)((B + 1) / 2) * d0.L * 5 * kD)); HIPCHK(h, E(h->dembp, (size_t)d0.L * B * kD));
     for (Buf* b : {&h->S1, &h->S2}) HIPCHK(h, E(*b, (size_t)d0.L * R * 2));
@@ -319,7 +318,7 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
         MixerBwdArgs a{};
         a.g = h->G.f();
         a.a2 = h->A2.f(); a.a1 = h->A1.f(); a.x2 = h->X2.f(); a.x1 = h->X1.f(); a.s2 = h->S2.f(); a.s1 = h->S1.f();
-        a.da2 = h->dA2.f(); a.da1 = h->dA1.f(); a.scratch = h->T1.f(); a.colpart = h->colpart.f(); a.dembp = h->dembp.f();
+        a.da2 = h->dA2.f(); a.da1 = h->dA1.f(); a.colpart = h->colpart.f(); a.dembp = h->dembp.f();
         a.wchT_img = h->twchT.f(); a.wwT_img = h->twwT.f(); a.ln2a = h->tl2a.f(); a.ln1a = h->tl1a.f();
         a.B = B; a.layers = d.L;
         HIPCHK(h, launch_mixer_bwd(d.NPRE == 2 ? kBEAT : kTED, a, st));
@@ -534,7 +533,7 @@ void ls_train_destroy(ls_trainer* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo,
                              &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
-                             &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->T1, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
+                             &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
                              &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->col, &h->ws};
     for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }

@@ -9,8 +9,8 @@
 //   4. dA1 = G * SiLU'(A1)                         -> global (operand of the token-weight gradient) and LDS (wave-private columns)
 //   5. dU1 = blockdiag(Wt, Wt)^T . dA1   (token mixing on MFMA with the transposed block-diagonal image)
 //   6. LayerNorm-1 backward as in 3; per-sample sum over tokens of G -> d(timestep embedding) partial of this layer
-// gy makes one round trip through a per-workgroup scratch slab in global memory (L2-resident) because the row means are
-// only known after the whole row has been produced.  Everything the kernel sums is reduced in a fixed order (registers,
+// The row means are only known after the whole row has been produced, so the update is applied in two parts (rstd * gy at once,
+// the mean terms afterwards from the saved x-hat) and gy never leaves the registers.  Everything the kernel sums is reduced in a fixed order (registers,
 // cross-lane butterflies, LDS in wave order): the step stays bit-reproducible.
 #include "ls_internal.h"
 #include "ls_step_common.h"
@@ -65,10 +65,12 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         for (int cb = 0; cb < kCB; ++cb)
             G[cb][t] = gr >= 0 ? *reinterpret_cast<const f4*>(a.g + (size_t)gr * kD + chw + 16 * cb) : (f4){0.f, 0.f, 0.f, 0.f};
     }
-    float* scratch = a.scratch + (size_t)b * R * kD;       // this workgroup's gy slab [R][512]
     f2* pst = reinterpret_cast<f2*>(psum);
 
-    // finish a LayerNorm backward: cross-wave row sums of (gy, gy*xhat), then G += rstd * (gy - m1 - xhat * m2)
+    // LayerNorm backward, G += rstd * (gy - m1 - xhat * m2) with gy = dU * alpha and the row means m1 = mean(gy), m2 = mean(gy * xhat),
+    // in two parts so that gy never leaves the registers: ln_bwd_tile adds rstd * gy as soon as the MFMAs deliver dU; once the
+    // cross-wave row sums are known, ln_bwd_finish subtracts rstd * (m1 + xhat * m2), which needs only the saved x-hat again.
+    // (A gy slab per workgroup in global memory, written by the tiles and re-read here, was 1.2 GB of traffic per step.)
     auto ln_bwd_finish = [&](float (&s1)[kNT], float (&s2)[kNT], const float* xsaved, const float* stats) {
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
@@ -94,26 +96,22 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
             // all loads of the tile first, from clamped rows (a guarded load would serialise behind its own s_waitcnt)
-            const int gr = grow_of(t), grc = growc_of(t), rl = min(row_of(t), R - 1);
+            const int gr = grow_of(t), grc = growc_of(t);
             const f2 st = *reinterpret_cast<const f2*>(stats + (size_t)grc * 2);
-            f4 gy[kCB], x[kCB];
+            f4 x[kCB];
 #pragma unroll
-            for (int cb = 0; cb < kCB; ++cb) {
-                gy[cb] = *reinterpret_cast<const f4*>(scratch + (size_t)rl * kD + chw + 16 * cb);
-                x[cb] = *reinterpret_cast<const f4*>(xsaved + (size_t)grc * kD + chw + 16 * cb);
-            }
+            for (int cb = 0; cb < kCB; ++cb) x[cb] = *reinterpret_cast<const f4*>(xsaved + (size_t)grc * kD + chw + 16 * cb);
             if (gr >= 0) {
+                const float c1 = st.y * m1[t], c2 = st.y * m2[t];
 #pragma unroll
                 for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        G[cb][t][j] += st.y * (gy[cb][j] - m1[t] - x[cb][j] * m2[t]);      // x: saved x-hat
-                    }
+                    for (int j = 0; j < 4; ++j) G[cb][t][j] -= fmaf(x[cb][j], c2, c1);      // x: saved x-hat
             }
         }
-        __syncthreads();                      // psum and the scratch slab may be rewritten
+        __syncthreads();                      // psum may be rewritten
     };
-    // consume one (tile, channel block) of dU: gy -> scratch, row partial sums, LayerNorm-parameter partial column sums
+    // consume one (tile, channel block) of dU: G += rstd * gy, row partial sums, LayerNorm-parameter partial column sums
     auto ln_bwd_tile = [&](const f4 du, int t, int cb, const f4 x, const f2 st, const f4 al, float& s1, float& s2, f4& pa, f4& pb) {
         if (grow_of(t) < 0) return;
         f4 gy;
@@ -125,8 +123,8 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
             s2 = fmaf(gy[j], xh, s2);
             pa[j] = fmaf(du[j], xh, pa[j]);
             pb[j] += du[j];
+            G[cb][t][j] = fmaf(st.y, gy[j], G[cb][t][j]);
         }
-        *reinterpret_cast<f4*>(scratch + (size_t)row_of(t) * kD + chw + 16 * cb) = gy;
     };
     // column partials of this workgroup: sum over the 16 row lanes, lanes s16 == 0 write [wg][layer][which][512]
     auto write_colpart = [&](f4 v, int l, int which, int cb) {
