@@ -139,18 +139,22 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         {
             const float* A2 = a.a2 + (size_t)l * LR * kD;
             float* dA2 = a.da2 + (size_t)l * LR * kD;
+            // the whole A2 tile of this lane first (20 float4 in flight together; no MFMA accumulators are live here): one memory
+            // round trip per phase instead of one per channel block
+            f4 avs[kCB][kNT];
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) avs[cb][t] = *reinterpret_cast<const f4*>(A2 + (size_t)growc_of(t) * kD + chw + 16 * cb);
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) {
                 f4 pbias = (f4){0.f, 0.f, 0.f, 0.f};
-                f4 avs[kNT];
-#pragma unroll
-                for (int t = 0; t < kNT; ++t) avs[t] = *reinterpret_cast<const f4*>(A2 + (size_t)growc_of(t) * kD + chw + 16 * cb);
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
                     if (16 * t + s16 >= R) continue;
                     const int gr = grow_of(t);
                     f4 d = (f4){0.f, 0.f, 0.f, 0.f};
-                    const f4 av = avs[t];
+                    const f4 av = avs[cb][t];
                     if (gr >= 0) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -282,17 +286,19 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         {
             const float* A1 = a.a1 + (size_t)l * LR * kD;
             float* dA1 = a.da1 + (size_t)l * LR * kD;
+            f4 avs[kCB][kNT];                 // as in step 1: the whole A1 tile in flight together
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) avs[cb][t] = *reinterpret_cast<const f4*>(A1 + (size_t)growc_of(t) * kD + chw + 16 * cb);
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) {
-                f4 avs[kNT];
-#pragma unroll
-                for (int t = 0; t < kNT; ++t) avs[t] = *reinterpret_cast<const f4*>(A1 + (size_t)growc_of(t) * kD + chw + 16 * cb);
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
                     if (16 * t + s16 >= R) continue;
                     const int gr = grow_of(t);
                     f4 d = (f4){0.f, 0.f, 0.f, 0.f};
-                    const f4 av = avs[t];
+                    const f4 av = avs[cb][t];
                     if (gr >= 0) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -324,6 +330,15 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MK; ++m)
                     if (tokmix_needed(S, t, m)) Bt[m] = wwp[(t * MK + m) * 64];
+                // what the LayerNorm backward of this tile needs: issued before the tile's MFMAs, pinned there
+                const f2 st1 = *reinterpret_cast<const f2*>(S1 + (size_t)growc_of(t) * 2);
+                f4 xs[kCB], al1[kCB];
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) {
+                    xs[cb] = *reinterpret_cast<const f4*>(X1 + (size_t)growc_of(t) * kD + chw + 16 * cb);
+                    al1[cb] = *g4(a.ln1a + l * kD + chw + 16 * cb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 f4 acc[kCB];
 #pragma unroll
                 for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -335,13 +350,9 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                         for (int cb = 0; cb < kCB; ++cb) acc[cb] = MFMA(up[srow * kUStride + 16 * cb], Bt[m], acc[cb]);
                     }
                 }
-                const f2 st1 = *reinterpret_cast<const f2*>(S1 + (size_t)growc_of(t) * 2);
-                f4 xs[kCB];
-#pragma unroll
-                for (int cb = 0; cb < kCB; ++cb) xs[cb] = *reinterpret_cast<const f4*>(X1 + (size_t)growc_of(t) * kD + chw + 16 * cb);
 #pragma unroll
                 for (int cb = 0; cb < kCB; ++cb)
-                    ln_bwd_tile(acc[cb], t, cb, xs[cb], st1, *g4(a.ln1a + l * kD + chw + 16 * cb), s1[t], s2[t], pa[cb], pb[cb]);
+                    ln_bwd_tile(acc[cb], t, cb, xs[cb], st1, al1[cb], s1[t], s2[t], pa[cb], pb[cb]);
             }
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) {
