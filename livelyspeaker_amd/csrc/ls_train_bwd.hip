@@ -238,6 +238,14 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             fresh();
+            // LayerNorm-2 backward inputs of both channel blocks of this pass: in flight during the remainder-row reduction below
+            f4 xs2[2][kNT], al2[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                al2[c2] = *g4(a.ln2a + l * kD + chw + 16 * (2 * p + c2));
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) xs2[c2][t] = *reinterpret_cast<const f4*>(X2 + (size_t)growc_of(t) * kD + chw + 16 * (2 * p + c2));
+            }
             float* rem = REM + w * (2 * NREM * 16);
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
@@ -265,15 +273,12 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int cb = 2 * p + c2;
                 f4 pa = (f4){0.f, 0.f, 0.f, 0.f}, pb = pa;
-                const f4 al = *g4(a.ln2a + l * kD + chw + 16 * cb);
-                f4 xs[kNT];
+                const f4 al = al2[c2];
 #pragma unroll
-                for (int t = 0; t < kNT; ++t) xs[t] = *reinterpret_cast<const f4*>(X2 + (size_t)growc_of(t) * kD + chw + 16 * cb);
-#pragma unroll
-                for (int t = 0; t < kFullTiles; ++t) ln_bwd_tile(acc[c2][t], t, cb, xs[t], st2[t], al, s1[t], s2[t], pa, pb);
+                for (int t = 0; t < kFullTiles; ++t) ln_bwd_tile(acc[c2][t], t, cb, xs2[c2][t], st2[t], al, s1[t], s2[t], pa, pb);
                 if (s16 < NREM) {
                     const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
-                    ln_bwd_tile(rv, kFullTiles, cb, xs[kFullTiles], st2[kFullTiles], al, s1[kFullTiles], s2[kFullTiles], pa, pb);
+                    ln_bwd_tile(rv, kFullTiles, cb, xs2[c2][kFullTiles], st2[kFullTiles], al, s1[kFullTiles], s2[kFullTiles], pa, pb);
                 }
                 write_colpart(pa, l, 1, cb);
                 write_colpart(pb, l, 2, cb);
