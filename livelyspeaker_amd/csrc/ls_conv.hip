@@ -86,19 +86,23 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ i
     }
     const int p = p0 + 16 * w + s16;
     const bool valid = p < Lout;
+    f4 bv[4];                                   // all bias values first: a load per (t, j) inside the loop below was 16 serialised L2 round trips
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const f4*>(bias + co0 + 16 * t + 4 * g);
+    const int nv = min(16, max(0, Lout - (p0 + 16 * w)));
+    const float inv_nv = nv > 0 ? 1.0f / (float)nv : 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int co = co0 + 16 * t + 4 * g + j;
-            const float v = acc[t][j] + bias[co];
+            const float v = acc[t][j] + bv[t][j];
             if (valid) out[((size_t)b * Cout + co) * Lout + p] = v;
             if (spart) {
                 // InstanceNorm statistics of this wave's 16 positions (lanes sharing g), two-pass inside the tile:
                 // (count, mean, M2) per (sample, channel, position tile); k_stats_merge combines them (Chan et al.)
-                const int nv = min(16, max(0, Lout - (p0 + 16 * w)));
                 const float s1 = row16_sum(valid ? v : 0.f);
-                const float mean = nv > 0 ? s1 / (float)nv : 0.f;
+                const float mean = s1 * inv_nv;
                 const float d = valid ? v - mean : 0.f;
                 const float m2 = row16_sum(d * d);
                 if (s16 == 0) {

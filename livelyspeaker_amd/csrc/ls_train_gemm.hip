@@ -214,15 +214,21 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     const bool cvec = a.cns == 1 && (a.crs & 3) == 0 && (a.cri == INT_MAX || (a.cro & 3) == 0) && ((uintptr_t)a.C & 15) == 0 &&
                       (!a.Cpre || ((uintptr_t)a.Cpre & 15) == 0) && (!a.R || ((uintptr_t)a.R & 15) == 0) &&
                       (!a.bias || ((uintptr_t)a.bias & 15) == 0);
+    // FAST tiles are full: no bounds tests (each one is a branch that also serialises the loads behind it), bias fetched once
+    f4 biasv[4];
+    if (FAST && a.bias && !partial) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) biasv[i] = *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + 16 * j + s16;
-        if (m >= a.M) continue;
+        if (!FAST && m >= a.M) continue;
         const size_t crow = partial ? (size_t)m * a.N : lvl(m, a.cri, a.cro, a.crs);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn * 64 + 16 * i + 4 * g;
-            if (n >= a.N) continue;
+            if (!FAST && n >= a.N) continue;
             f4 v = acc[i][j];
             if (partial) {
                 if ((a.N & 3) == 0) *reinterpret_cast<f4*>(&Cz[crow + n]) = v;
@@ -232,9 +238,9 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
                 }
                 continue;
             }
-            if (cvec && n + 3 < a.N) {
+            if (cvec && (FAST || n + 3 < a.N)) {
                 const size_t co = crow + n;
-                if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
+                if (a.bias) v += FAST ? biasv[i] : *reinterpret_cast<const f4*>(a.bias + n);
                 if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co) = v;
                 if (a.act == 1) {
 #pragma unroll
