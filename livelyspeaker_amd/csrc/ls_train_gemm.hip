@@ -22,6 +22,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTM = 128, kTK = 32, kLdK = kTK + 4, kLdR = kTM + 4;
 
+// epilogue activations: 0 none, 1 SiLU, 2 exp(0.5 y) (std from log-variance), 3 exact GELU (F.gelu default)
+__device__ __forceinline__ float gemm_act(float v, int act) {
+    if (act == 1) return v / (1.0f + expf(-v));
+    if (act == 2) return expf(0.5f * v);
+    if (act == 3) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
 // two-level index -> offset; the single-level case (inner extent INT_MAX) skips the integer division
 __device__ __forceinline__ size_t lvl(int i, int inner, long long so, long long si) {
     if (inner == INT_MAX) return (size_t)i * si;
@@ -242,9 +250,9 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
                 const size_t co = crow + n;
                 if (a.bias) v += FAST ? biasv[i] : *reinterpret_cast<const f4*>(a.bias + n);
                 if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co) = v;
-                if (a.act == 1) {
+                if (a.act) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+                    for (int e = 0; e < 4; ++e) v[e] = gemm_act(v[e], a.act);
                 }
                 if (a.R) v += *reinterpret_cast<const f4*>(a.R + co);
                 if (a.accumulate) v += *reinterpret_cast<const f4*>(a.C + co);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
                     if (a.bias) x += a.bias[n + e];
                     const size_t co = crow + (size_t)(n + e) * a.cns;
                     if (a.Cpre) a.Cpre[co] = x;
-                    if (a.act == 1) x = x / (1.0f + expf(-x));
+                    x = gemm_act(x, a.act);
                     if (a.R) x += a.R[co];
                     if (a.accumulate) x += a.C[co];
                     a.C[co] = x;
