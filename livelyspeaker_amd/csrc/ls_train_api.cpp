@@ -23,16 +23,21 @@ namespace {
 std::string g_train_create_error;
 
 struct Buf {
-    void* p = nullptr;
+    void* p = nullptr;       // what the kernels read: the buffer's own allocation, or a caller's device tensor for the duration of a call
+    void* own = nullptr;
     size_t bytes = 0;
     hipError_t ensure(size_t n) {
-        if (n <= bytes) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
+        if (n > bytes) {
+            if (own) { hipError_t e = hipFree(own); if (e != hipSuccess) return e; own = nullptr; bytes = 0; }
+            hipError_t e = hipMalloc(&own, n);
+            if (e != hipSuccess) return e;
+            bytes = n;
+        }
+        p = own;
+        return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void alias(const void* q) { p = const_cast<void*>(q); }
+    void release() { if (own) (void)hipFree(own); p = own = nullptr; bytes = 0; }
     float* f() const { return static_cast<float*>(p); }
 };
 
@@ -102,7 +107,10 @@ float* Gr(ls_trainer* h, float* grad, const std::string& key) { return grad + h-
 std::string lk(int l, const char* s) { return "backbone.mlps." + std::to_string(l) + "." + s; }
 std::string ck(int i, const char* s) { return "audio_encoder.feat_extractor." + std::to_string(kKey[i]) + "." + s; }
 
+// Batch inputs: host arrays are copied in; device tensors are read in place (the call is synchronous, the caller's tensors outlive it,
+// and no kernel writes them) -- ten device-to-device copies per step otherwise, the 74 MB waveform among them.
 int ingest(ls_trainer* h, Buf& dst, const void* src, size_t bytes, bool on_device) {
+    if (on_device && bytes && ((uintptr_t)src & 15) == 0) { dst.alias(src); return LS_OK; }       // (an unaligned view is copied)
     HIPCHK(h, dst.ensure(bytes ? bytes : 4));
     if (bytes) HIPCHK(h, hipMemcpyAsync(dst.p, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     return LS_OK;
