@@ -83,9 +83,10 @@ hipError_t init_mixer_bwd();
 hipError_t launch_mixer_bwd(Variant v, const MixerBwdArgs& a, hipStream_t st);
 // ---- backward ----
 hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, float* partial, int rows, int nwaves, hipStream_t st);
-// token-weight gradient partials of all layers: pw[L][B*4][S*S], pb[L][B*4][S]; xh1 = saved x-hat of LayerNorm 1, l1a / l1b [L][512]
+// token-weight gradient partials of all layers (MFMA): pw[L][*ngroups][S*S], pb[L][*ngroups][S]; xh1 = saved x-hat of LayerNorm 1,
+// l1a / l1b [L][512]
 hipError_t launch_tokmix_wgrad(const float* da, const float* xh1, const float* l1a, const float* l1b, float* pw, float* pb, int B, int S,
-                               int layers, hipStream_t st);
+                               int layers, int* ngroups, hipStream_t st);
 // dW[l][o][i] = dW[l][o][i] * alpha2[l][i] + beta2[l][i] * db[l][o] (dW came from the product with x-hat instead of U2)
 hipError_t launch_wch_affine(float* dw, const float* db, const float* l2a, const float* l2b, long long lstride, int layers, hipStream_t st);
 hipError_t launch_partial_reduce(const float* partial, int n, long long stride, int cols, float* out, int accumulate, hipStream_t st);

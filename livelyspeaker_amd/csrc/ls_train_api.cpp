@@ -339,9 +339,10 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
     HIPCHK(h, launch_partial_reduce_groups(h->colpart.f() + kD, nwg, cps, 2 * kD, g0 + h->img_args.o_a2, d.L, 5 * kD, ls, st));
     HIPCHK(h, launch_partial_reduce_groups(h->colpart.f() + 3 * kD, nwg, cps, 2 * kD, g0 + h->img_args.o_a1, d.L, 5 * kD, ls, st));
     // token weights of all layers: dWt[s'][s] = sum_{b,c} dA1[b][s'][c] U1[b][s][c], d bt[s'] = sum_{b,c} dA1[b][s'][c]
-    HIPCHK(h, launch_tokmix_wgrad(h->dA1.f(), h->X1.f(), h->tl1a.f(), h->tl1b.f(), h->pw.f(), h->pb.f(), B, S, d.L, st));
-    HIPCHK(h, launch_partial_reduce_groups(h->pw.f(), B * 4, (long long)S * S, S * S, g0 + h->img_args.o_wt, d.L, (long long)B * 4 * S * S, ls, st));
-    HIPCHK(h, launch_partial_reduce_groups(h->pb.f(), B * 4, S, S, g0 + h->img_args.o_bt, d.L, (long long)B * 4 * S, ls, st));
+    int ntw = 0;
+    HIPCHK(h, launch_tokmix_wgrad(h->dA1.f(), h->X1.f(), h->tl1a.f(), h->tl1b.f(), h->pw.f(), h->pb.f(), B, S, d.L, &ntw, st));
+    HIPCHK(h, launch_partial_reduce_groups(h->pw.f(), ntw, (long long)S * S, S * S, g0 + h->img_args.o_wt, d.L, (long long)ntw * S * S, ls, st));
+    HIPCHK(h, launch_partial_reduce_groups(h->pb.f(), ntw, S, S, g0 + h->img_args.o_bt, d.L, (long long)ntw * S, ls, st));
     // channel-mix weight gradients of all layers: dW[l] = dA2[l]^T U2[l] with U2 = alpha2 * x-hat2 + beta2: the product runs on the saved
     // x-hat2 and the affine is applied to the 512 x 512 result (the bias gradients d b = colsum(dA2) were reduced above)
     HIPCHK(h, wgrad_batched(h, op_cols(lay(h->dA2, 0, R), kD, kD, R), op_cols(lay(h->X2, 0, R), kD, kD, R), g0 + h->img_args.o_w, kD, kD, kD, R, d.L,

@@ -83,61 +83,97 @@ hipError_t launch_silu_bwd_colsum(const float* g, const float* apre, float* da, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Token mixing (Conv1d(S,S,1) over the token axis, mlp_module.py:51-55), backward.  (The forward runs inside the fused
-// training-forward kernel, ls_step.hip TRAIN variant.)  Workgroup = (sample, 128-channel slab); every thread register-tiles
-// its outputs so that each pair of LDS operand reads feeds 4 FMAs (the kernel is LDS-bandwidth bound).
-constexpr int kTokC = 128, kTokLd = kTokC + 1, kTokMaxS = 36;
+// Token mixing (Conv1d(S,S,1) over the token axis, mlp_module.py:51-55), backward.  (The forward and the data gradient run inside
+// the fused mixer kernels.)  Token-weight gradient of every layer in one launch, on the matrix cores:
+//   dWt[l][s'][s] = sum_{b,c} dA1[l][b][s'][c] U1[l][b][s][c],   d bt[l][s'] = sum_{b,c} dA1[l][b][s'][c],   U1 = alpha1 * x-hat1 + beta1
+// Per sample this is a 35 x 35 (36 x 36) product over K = 512 channels: M = s' and N = s are padded to 3 tiles of 16, both operands
+// are read straight from global memory as float4s in the k-permuted order the contraction allows (lane (row, g) holds channels
+// 16q + 4g + e for MFMA step e), U1 is rebuilt from the saved x-hat on the way, and the first padding row of the N operand is set
+// to ones so that column S of the product IS the bias gradient.  A wave accumulates kTokSpv samples in its 9 accumulators; the four
+// waves of a workgroup are then summed through LDS in wave order (deterministic) into one partial per workgroup:
+//   pw[l][wg][s'][s], pb[l][wg][s'].
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int kTokSpv = 2, kTokMaxS = 47;            // samples per wave; S + 1 <= 48 (three tiles incl. the ones row)
 
-// Token-weight gradient of every layer in one launch (grid.z = layer): per (sample, 128-channel slab) workgroup
-//   pw[l][(b,slab)][s'][s] = sum_c dA1[l][b][s'][c] U1[l][b][s][c],   pb[l][(b,slab)][s'] = sum_c dA1[l][b][s'][c]
-// (dA1 comes from the fused mixer backward).  2 x 4 register tile per thread: 6 LDS reads per 8 FMAs.
-// xh1 is the saved x-hat of LayerNorm 1; the operand U1 = alpha1 * x-hat + beta1 is rebuilt while it is staged.
 __global__ __launch_bounds__(256) void k_tokmix_wgrad(const float* __restrict__ da, const float* __restrict__ xh1, const float* __restrict__ l1a,
                                                       const float* __restrict__ l1b, float* __restrict__ pw, float* __restrict__ pb, int S, int B) {
-    __shared__ float das[(kTokMaxS + 4) * kTokLd];
-    __shared__ float us[(kTokMaxS + 4) * kTokLd];
-    const int b = blockIdx.x, c0 = blockIdx.y * kTokC, l = blockIdx.z, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float red[4][9][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
+    const int l = blockIdx.y;
     const size_t lbase = (size_t)l * B * S * kDm;
-    for (int i = tid; i < (kTokMaxS + 4) * kTokC; i += 256) {
-        const int r = i / kTokC, cc = i % kTokC;
-        const size_t o = lbase + ((size_t)b * S + min(r, S - 1)) * kDm + c0 + cc;        // clamped address, branch-free loads
-        const float dv = da[o], uv = fmaf(xh1[o], l1a[l * kDm + c0 + cc], l1b[l * kDm + c0 + cc]);
-        das[r * kTokLd + cc] = r < S ? dv : 0.f;          // rows S..S+3 are zero so that the 4-wide tiles below need no masks
-        us[r * kTokLd + cc] = r < S ? uv : 0.f;
-    }
-    __syncthreads();
-    const size_t blk = ((size_t)l * B + b) * gridDim.y + blockIdx.y;
-    const int nsp = (S + 1) / 2, ns4 = (S + 3) / 4;
-    for (int o = tid; o < nsp * ns4; o += 256) {
-        const int sp = 2 * (o / ns4), s = 4 * (o % ns4);
-        float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int cc = 0; cc < kTokC; ++cc) {
-            const float d0 = das[sp * kTokLd + cc], d1 = das[(sp + 1) * kTokLd + cc];
+    f4v acc[3][3];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float uv = us[(s + e) * kTokLd + cc];
-                r0[e] = fmaf(d0, uv, r0[e]);
-                r1[e] = fmaf(d1, uv, r1[e]);
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+    int rowc[3];
+    float vmask[3], ones[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int r = 16 * t + s16;
+        rowc[t] = min(r, S - 1);                       // clamped row: the loads stay branch-free
+        vmask[t] = r < S ? 1.f : 0.f;
+        ones[t] = r == S ? 1.f : 0.f;                  // N operand: row S is all ones -> column S of the product = sum_c dA1
+    }
+    const float* al = l1a + l * kDm + 4 * g;
+    const float* be = l1b + l * kDm + 4 * g;
+    for (int i = 0; i < kTokSpv; ++i) {
+        const int b = (blockIdx.x * 4 + w) * kTokSpv + i;
+        if (b >= B) break;                             // wave-uniform
+        const float* dab = da + lbase + (size_t)b * S * kDm + 4 * g;
+        const float* xhb = xh1 + lbase + (size_t)b * S * kDm + 4 * g;
+#pragma unroll 2
+        for (int q = 0; q < kDm / 16; ++q) {
+            const f4v a4 = *reinterpret_cast<const f4v*>(al + 16 * q), b4 = *reinterpret_cast<const f4v*>(be + 16 * q);
+            f4v A[3], Bm[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                A[t] = *reinterpret_cast<const f4v*>(dab + (size_t)rowc[t] * kDm + 16 * q);
+                Bm[t] = *reinterpret_cast<const f4v*>(xhb + (size_t)rowc[t] * kDm + 16 * q);
             }
-        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (s + e >= S) break;
-            pw[blk * S * S + (size_t)sp * S + s + e] = r0[e];
-            if (sp + 1 < S) pw[blk * S * S + (size_t)(sp + 1) * S + s + e] = r1[e];
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    A[t][e] *= vmask[t];
+                    Bm[t][e] = fmaf(fmaf(Bm[t][e], a4[e], b4[e]), vmask[t], ones[t]);
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][e], Bm[nt][e], acc[mt][nt], 0, 0, 0);
         }
     }
-    for (int sp = tid; sp < S; sp += 256) {
-        float acc = 0.f;
-        for (int cc = 0; cc < kTokC; ++cc) acc += das[sp * kTokLd + cc];
-        pb[blk * S + sp] = acc;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) *reinterpret_cast<f4v*>(&red[w][3 * mt + nt][lane][0]) = acc[mt][nt];
+    __syncthreads();
+    // lane (s16, g) of tile (mt, nt), register r: s' = 16 mt + 4 g + r, s = 16 nt + s16
+    const size_t blk = (size_t)l * gridDim.x + blockIdx.x;
+    for (int o = tid; o < 9 * 256; o += 256) {
+        const int tile = o >> 8, ln = (o >> 2) & 63, r = o & 3;
+        const float v = ((red[0][tile][ln][r] + red[1][tile][ln][r]) + red[2][tile][ln][r]) + red[3][tile][ln][r];
+        const int sp = 16 * (tile / 3) + 4 * (ln >> 4) + r, sc = 16 * (tile % 3) + (ln & 15);
+        if (sp < S) {
+            if (sc < S) pw[blk * S * S + (size_t)sp * S + sc] = v;
+            else if (sc == S) pb[blk * S + sp] = v;
+        }
     }
 }
 
+// *ngroups = partials per layer written (pw[L][*ngroups][S*S], pb[L][*ngroups][S])
 hipError_t launch_tokmix_wgrad(const float* da, const float* xh1, const float* l1a, const float* l1b, float* pw, float* pb, int B, int S,
-                               int layers, hipStream_t st) {
+                               int layers, int* ngroups, hipStream_t st) {
     if (S > kTokMaxS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tokmix_wgrad, dim3(B, kDm / kTokC, layers), dim3(256), 0, st, da, xh1, l1a, l1b, pw, pb, S, B);
+    const int nwg = (B + 4 * kTokSpv - 1) / (4 * kTokSpv);
+    *ngroups = nwg;
+    hipLaunchKernelGGL(k_tokmix_wgrad, dim3(nwg, layers), dim3(256), 0, st, da, xh1, l1a, l1b, pw, pb, S, B);
     return hipGetLastError();
 }
 
