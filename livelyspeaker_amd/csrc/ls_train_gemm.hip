@@ -283,6 +283,7 @@ __global__ void k_splitk_reduce(const GemmArgs a, int Z) {
     const float* ws = a.ws + (size_t)blockIdx.y * Z * a.M * a.N;          // blockIdx.y: problem of the batch
     float* C = a.C + (size_t)blockIdx.y * a.bsC;
     float v = 0.f;
+#pragma unroll 8                                    // independent loads in flight; the sum keeps its z order
     for (int z = 0; z < Z; ++z) v += ws[(size_t)z * a.M * a.N + i];
     if (a.bias) v += a.bias[n];
     const size_t co = (size_t)(m / a.cri) * a.cro + (size_t)(m % a.cri) * a.crs + (size_t)n * a.cns;

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(1024) void k_partial_reduce(const float* __restrict
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < cols) {
         int i = q;
+#pragma unroll 4                                    // 16 loads in flight per lane: these launches are pure latency
         for (; i + 48 < n; i += 64) {
             s0 += partial[(size_t)i * stride + c];
             s1 += partial[(size_t)(i + 16) * stride + c];
