@@ -27,6 +27,21 @@ __device__ __forceinline__ float wave_sum(float v) {
            __int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48));
 }
 
+// maximum over the whole wave (wave-uniform result)
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = dpp_max<0xB1>(v);
+    v = dpp_max<0x4E>(v);
+    v = dpp_max<0x141>(v);
+    v = dpp_max<0x140>(v);
+    const int i = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+}
+
 // v + v[lane ^ 32] / v + v[lane ^ 16] with gfx950's v_permlane32_swap / v_permlane16_swap (VALU, no LDS round trip):
 // swap(a, b) exchanges the upper half (odd rows) of a with the lower half (even rows) of b; with a = b = v the two results
 // hold v's lower and upper halves (even and odd rows) broadcast over the pair, so their sum is the xor-exchange sum.

@@ -30,44 +30,96 @@ __global__ void k_sag_queries(const float* __restrict__ x, const float* __restri
     }
 }
 
-// nn.MultiheadAttention self-attention of one (sample, head): softmax(q k^T / sqrt(hd)) v over the T=34 queries.
-// qkv rows are [q | k | v] of width 3*D (in_proj of the packed weight).
+// nn.MultiheadAttention self-attention of one (sample, head): softmax(q k^T / sqrt(hd)) v over the T = 34 queries -- the only
+// QK^T / softmax / attn.V in the model (motionclip_module.py:98-183).  qkv rows are [q | k | v] of width 3*D (packed in_proj).
+// Workgroup = (sample, head), 4 waves.  Q (pre-scaled), K, V [34][HD] are staged in LDS with row stride HD + 4 (conflict-free
+// ds_read_b128); both contractions run on v_mfma_f32_16x16x4_f32 with T padded to 3 tiles of 16 (rows past 33 are clamped on the
+// read and never stored / masked):
+//   scores = Q K^T : 3 x 3 tiles, K-dim = HD in the k-permuted float4 order (lane (row, g) holds d = 16q + 4g + e for step e)
+//   softmax        : one wave per query row, lane = key; row max and row sum are wavefront reductions (DPP / readlane)
+//   out = P V      : 3 x (HD/16) tiles, K-dim = 36 keys (P's columns 34, 35 are written as zero)
 template <int HD>
 __global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__ qkv, float* __restrict__ out, int D) {
-    __shared__ float sq[kT][HD + 1], sk[kT][HD + 1], sv[kT][HD + 1], sp[kT][kT + 1];
-    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < kT * HD; i += 256) {
-        const int t = i / HD, d = i % HD;
-        const float* row = qkv + (size_t)(b * kT + t) * 3 * D + h * HD + d;
-        sq[t][d] = row[0];
-        sk[t][d] = row[D];
-        sv[t][d] = row[2 * D];
-    }
-    __syncthreads();
+    constexpr int LQ = HD + 4, LP = 37, KP = 36;
+    __shared__ __attribute__((aligned(16))) float sq[kT * LQ], sk[kT * LQ], sv[kT * LQ];
+    __shared__ float sp[kT * LP];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
     const float scale = rsqrtf((float)HD);
-    for (int i = tid; i < kT * kT; i += 256) {
-        const int a = i / kT, c = i % kT;
-        float s = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < HD; ++d) s = fmaf(sq[a][d] * scale, sk[c][d], s);      // torch scales q before q.k^T
-        sp[a][c] = s;
+    {
+        // all of this thread's loads first (float4, clamped index: branch-free and in flight together), then the LDS writes
+        constexpr int kF4 = kT * HD / 4, kPer = (kF4 + 255) / 256;
+        f4 vq[kPer], vk[kPer], vv[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = min(tid + 256 * j, kF4 - 1), t = idx / (HD / 4), d4 = idx % (HD / 4);
+            const float* row = qkv + (size_t)(b * kT + t) * 3 * D + h * HD + 4 * d4;
+            vq[j] = *reinterpret_cast<const f4*>(row);
+            vk[j] = *reinterpret_cast<const f4*>(row + D);
+            vv[j] = *reinterpret_cast<const f4*>(row + 2 * D);
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = tid + 256 * j, t = idx / (HD / 4), d = 4 * (idx % (HD / 4));
+            if (idx < kF4) {
+                *reinterpret_cast<f4*>(&sq[t * LQ + d]) = vq[j] * scale;      // torch scales q before q.k^T
+                *reinterpret_cast<f4*>(&sk[t * LQ + d]) = vk[j];
+                *reinterpret_cast<f4*>(&sv[t * LQ + d]) = vv[j];
+            }
+        }
     }
     __syncthreads();
-    if (tid < kT) {
-        float m = -INFINITY;
-        for (int c = 0; c < kT; ++c) m = fmaxf(m, sp[tid][c]);
-        float sum = 0.f;
-        for (int c = 0; c < kT; ++c) { const float e = expf(sp[tid][c] - m); sp[tid][c] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int c = 0; c < kT; ++c) sp[tid][c] *= inv;
+    // ---- scores: tile (mt, nt) = w, w + 4, w + 8 of the 3 x 3 grid; lane holds S[a = 16 mt + 4 g + r][c = 16 nt + s16]
+    for (int tile = w; tile < 9; tile += 4) {
+        const int mt = tile / 3, nt = tile % 3;
+        const float* qa = sq + min(16 * mt + s16, kT - 1) * LQ + 4 * g;
+        const float* kb = sk + min(16 * nt + s16, kT - 1) * LQ + 4 * g;
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < HD / 16; ++q) {
+            const f4 av = *reinterpret_cast<const f4*>(qa + 16 * q), bv = *reinterpret_cast<const f4*>(kb + 16 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+        }
+        const int c = 16 * nt + s16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 16 * mt + 4 * g + r;
+            if (a < kT && c < kT) sp[a * LP + c] = acc[r];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < kT * HD; i += 256) {
-        const int t = i / HD, d = i % HD;
-        float o = 0.f;
-#pragma unroll 2
-        for (int c = 0; c < kT; ++c) o = fmaf(sp[t][c], sv[c][d], o);
-        out[(size_t)(b * kT + t) * D + h * HD + d] = o;
+    // ---- softmax over the keys of each query row: one wave per row, lane = key
+    for (int a = w; a < kT; a += 4) {
+        const float v = lane < kT ? sp[a * LP + lane] : -INFINITY;
+        const float m = wave_max(v);
+        const float e = lane < kT ? expf(v - m) : 0.f;
+        const float inv = 1.0f / wave_sum(e);
+        if (lane < KP) sp[a * LP + lane] = e * inv;                       // columns 34, 35: zero (K padding of the P.V product)
+    }
+    __syncthreads();
+    // ---- out = P V: wave w owns feature tiles 2w, 2w + 1 ... of HD / 16; lane holds O[a = 16 mt + 4 g + r][d = 16 nt + s16]
+    for (int nt = w; nt < HD / 16; nt += 4) {
+        f4 acc[3];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) acc[mt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KP / 4; ++ks) {
+            const float bv = sv[min(4 * ks + g, kT - 1) * LQ + 16 * nt + s16];    // rows 34, 35 meet P's zero columns
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                const float av = sp[min(16 * mt + s16, kT - 1) * LP + 4 * ks + g];
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * mt + 4 * g + r;
+                if (a < kT) out[(size_t)(b * kT + a) * D + h * HD + 16 * nt + s16] = acc[mt][r];
+            }
     }
 }
 
@@ -99,19 +151,31 @@ __global__ __launch_bounds__(256) void k_layernorm512(const float* __restrict__ 
     yr[lane + 64] = (v1 - mean) * rstd * wr[lane + 64] + be[lane + 64];
 }
 
-// finallayer + "zero for padded area" + permute to [B, J*F, T] (motionclip_module.py:172-176)
-__global__ void k_sag_final(const float* __restrict__ xh, const float* __restrict__ wf, const float* __restrict__ bf,
-                            const unsigned char* __restrict__ mask, float* __restrict__ out, int JF, int D) {
-    extern __shared__ float sx[];
-    const int r = blockIdx.x, b = r / kT, f = r % kT;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) sx[d] = xh[(size_t)r * D + d];
-    __syncthreads();
+// finallayer + "zero for padded area" + permute to [B, J*F, T] (motionclip_module.py:172-176).  One wave per row: lane l holds
+// channels 8l .. 8l+7 of the row, every output feature is a coalesced read of its weight row and a wave-wide sum.  (One thread per
+// output feature walking its own weight row -- 27 strided streams per workgroup -- took 154 us at B = 512; this takes ~20.)
+__global__ __launch_bounds__(256) void k_sag_final(const float* __restrict__ xh, const float* __restrict__ wf, const float* __restrict__ bf,
+                                                   const unsigned char* __restrict__ mask, float* __restrict__ out, int rows, int JF, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;                                        // wave-uniform
+    const int b = r / kT, f = r % kT;
     const bool keep = mask ? mask[r] != 0 : true;
-    for (int c = threadIdx.x; c < JF; c += blockDim.x) {
-        float v = bf[c];
-        const float* w = wf + (size_t)c * D;
-        for (int d = 0; d < D; ++d) v = fmaf(w[d], sx[d], v);
-        out[((size_t)b * JF + c) * kT + f] = keep ? v : 0.f;
+    float acc_mine = 0.f;                                         // lane c ends up holding output feature c (JF <= 64 per pass)
+    for (int c0 = 0; c0 < JF; c0 += 64) {
+        for (int c = c0; c < min(JF, c0 + 64); ++c) {
+            float p = 0.f;
+            for (int d = 8 * lane; d < D; d += 512) {
+                const f4 x0 = *reinterpret_cast<const f4*>(xh + (size_t)r * D + d), x1 = *reinterpret_cast<const f4*>(xh + (size_t)r * D + d + 4);
+                const f4 w0 = *reinterpret_cast<const f4*>(wf + (size_t)c * D + d), w1 = *reinterpret_cast<const f4*>(wf + (size_t)c * D + d + 4);
+                p += (x0[0] * w0[0] + x0[1] * w0[1]) + (x0[2] * w0[2] + x0[3] * w0[3]) + (x1[0] * w1[0] + x1[1] * w1[1]) +
+                     (x1[2] * w1[2] + x1[3] * w1[3]);
+            }
+            const float v = wave_sum(p) + bf[c];
+            if (lane == c - c0) acc_mine = v;
+        }
+        const int c = c0 + lane;
+        if (c < JF) out[((size_t)b * JF + c) * kT + f] = keep ? acc_mine : 0.f;
     }
 }
 
@@ -132,7 +196,8 @@ hipError_t launch_layernorm512(const float* x, const float* bc, const float* w, 
 }
 hipError_t launch_sag_final(const float* xh, const float* wf, const float* bf, const unsigned char* mask, float* out, int B,
                             int JF, int D, hipStream_t st) {
-    hipLaunchKernelGGL(k_sag_final, dim3(B * kT), dim3(64), D * sizeof(float), st, xh, wf, bf, mask, out, JF, D);
+    if (D % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sag_final, dim3((B * kT + 3) / 4), dim3(256), 0, st, xh, wf, bf, mask, out, B * kT, JF, D);
     return hipGetLastError();
 }
 

@@ -13,17 +13,19 @@ __global__ void k(const float* x, float* o) {
     o[192 + l] = ls::xor16_sum(v) - (v + __shfl_xor(v, 16));
     o[256 + l] = ls::xor32_get(v, l) - __shfl_xor(v, 32);
     o[320 + l] = ls::xor16_get(v, l) - __shfl_xor(v, 16);
+    float mx = v; for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    o[384 + l] = ls::wave_max(v) - mx;
 }
 int main() {
-    float hx[64], ho[384], *dx, *dout;
+    float hx[64], ho[448], *dx, *dout;
     for (int i = 0; i < 64; ++i) hx[i] = (float)(i * i % 37) + 0.25f * i;      // exactly representable, sums exact
     hipMalloc(&dx, sizeof(hx)); hipMalloc(&dout, sizeof(ho));
     hipMemcpy(dx, hx, sizeof(hx), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dx, dout);
     hipMemcpy(ho, dout, sizeof(ho), hipMemcpyDeviceToHost);
-    const char* names[6] = {"row16_sum", "wave_sum", "xor32_sum", "xor16_sum", "xor32_get", "xor16_get"};
+    const char* names[7] = {"row16_sum", "wave_sum", "xor32_sum", "xor16_sum", "xor32_get", "xor16_get", "wave_max"};
     int bad = 0;
-    for (int t = 0; t < 6; ++t) {
+    for (int t = 0; t < 7; ++t) {
         float m = 0; for (int i = 0; i < 64; ++i) m = fmaxf(m, fabsf(ho[64 * t + i]));
         printf("%s max |diff| = %g\n", names[t], m);
         bad += m != 0.f;
