@@ -438,8 +438,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     if (valid_of(t)) {
 #pragma unroll
                         for (int cb = 0; cb < kCB; ++cb)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) X[cb][t][j] = silu_acc(acc[cb][j], X[cb][t][j]);
+                            X[cb][t] = silu_acc4(acc[cb], X[cb][t]);
                     }
                 }
             }
@@ -476,8 +475,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     }
 #pragma unroll
                     for (int cb = 0; cb < kCB; ++cb)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) X[cb][t][j] = silu_acc(acc[cb][j], X[cb][t][j]);
+                        X[cb][t] = silu_acc4(acc[cb], X[cb][t]);
                 }
             }
         }
@@ -560,8 +558,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                     for (int t = 0; t < kNT; ++t)
                         if (valid_of(t)) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) X[2 * p + c2][t][j] = silu_acc(acc[c2][t][j], X[2 * p + c2][t][j]);
+                            X[2 * p + c2][t] = silu_acc4(acc[c2][t], X[2 * p + c2][t]);
                         }
                 if (p == 0) stamp(7 + 8 * l);
             }
@@ -680,8 +677,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         const int gr = grow_of(t);
                         if (gr >= 0) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = acc[c2][t];
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) X[cb][t][j] = silu_acc(acc[c2][t][j], X[cb][t][j]);
+                    X[cb][t] = silu_acc4(acc[c2][t], X[cb][t]);
                 }
                 if (s16 < NREM) {
                     const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
@@ -689,8 +685,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         const int gr = grow_of(kFullTiles);
                         if (gr >= 0) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = rv + bc;
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) X[cb][kFullTiles][j] = silu_acc(rv[j] + bc[j], X[cb][kFullTiles][j]);
+                    X[cb][kFullTiles] = silu_acc4(rv + bc, X[cb][kFullTiles]);
                 }
             }
             __builtin_amdgcn_wave_barrier();

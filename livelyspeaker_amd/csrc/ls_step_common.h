@@ -21,6 +21,25 @@ __device__ __forceinline__ float silu_acc(float v, float r) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
     return fmaf(v, s, r);
 }
+// the same for a float4 of accumulators: the three non-transcendental operations as packed f32 (v_pk_mul / v_pk_add / v_pk_fma:
+// two elements per issue) -- these epilogues run after the MFMA loop, where packed math is not the anti-lever it is next to MFMAs
+__device__ __forceinline__ f4 silu_acc4(f4 v, f4 r) {
+#ifdef LS_SILU_SCALAR
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = silu_acc(v[j], r[j]);
+    return o;
+#else
+    const f2 c = (f2){-1.4426950408889634f, -1.4426950408889634f}, one = (f2){1.0f, 1.0f};
+    f2 v0 = (f2){v[0], v[1]}, v1 = (f2){v[2], v[3]};
+    f2 t0 = v0 * c, t1 = v1 * c;
+    f2 e0 = (f2){__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])}, e1 = (f2){__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])};
+    e0 = e0 + one; e1 = e1 + one;
+    const f2 s0 = (f2){__builtin_amdgcn_rcpf(e0[0]), __builtin_amdgcn_rcpf(e0[1])}, s1 = (f2){__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
+    const f2 o0 = __builtin_elementwise_fma(v0, s0, (f2){r[0], r[1]}), o1 = __builtin_elementwise_fma(v1, s1, (f2){r[2], r[3]});
+    return (f4){o0[0], o0[1], o1[0], o1[1]};
+#endif
+}
 
 // Pointers fetched from the DevWeights block are generic to the compiler; cast them to the global
 // address space so loads are global_load (vmcnt only) instead of flat_load (vmcnt AND lgkmcnt, which
