@@ -229,17 +229,20 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         f2* pst = reinterpret_cast<f2*>(psum);            // [8 waves][80 rows] (mean, M2) of 64 channels
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
-            float s = 0.f;
+            // both passes as float4 arithmetic (packed f32: two elements per issue); four interleaved partial sums per pass
+            f4 sv = X[0][t];
 #pragma unroll
-            for (int cb = 0; cb < kCB; ++cb) s += (X[cb][t][0] + X[cb][t][1]) + (X[cb][t][2] + X[cb][t][3]);
-            float m = s * (1.0f / 16.0f), m2 = 0.f;
+            for (int cb = 1; cb < kCB; ++cb) sv += X[cb][t];
+            const float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+            float m = s * (1.0f / 16.0f);
+            const f4 mv = (f4){m, m, m, m};
+            f4 qv = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int cb = 0; cb < kCB; ++cb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = X[cb][t][j] - m;
-                    m2 = fmaf(d, d, m2);
-                }
+            for (int cb = 0; cb < kCB; ++cb) {
+                const f4 d = X[cb][t] - mv;
+                qv = __builtin_elementwise_fma(d, d, qv);
+            }
+            float m2 = (qv[0] + qv[1]) + (qv[2] + qv[3]);
             {   // merge with the lane group 16 lanes away (16 + 16 values), then 32 lanes away (32 + 32); the update is symmetric
                 // in the pair, so both members of the v_permlane swap are used as they come (no select, no LDS round trip)
                 float ma, mb, qa, qb;
@@ -312,17 +315,13 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { Th[o + 32 * j] = (__bf16)0.f; Tl[o + 32 * j] = (__bf16)0.f; }
                 } else if (valid_of(t)) {
-                    f4 u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) u[j] = fmaf(X[cb][t][j], rstd[t], nmr[t]);
+                    const f4 rs = (f4){rstd[t], rstd[t], rstd[t], rstd[t]}, nm = (f4){nmr[t], nmr[t], nmr[t], nmr[t]};
+                    f4 u = __builtin_elementwise_fma(X[cb][t], rs, nm);          // packed f32
                     if constexpr (TRAIN) {                // x-hat is what the backward needs (LayerNorm backward directly; the
                         const int gr = grow_of(t);        // weight gradients rebuild U = alpha * x-hat + beta from it)
                         if (gr >= 0) *reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb) = u;
                     }
-                    if (alpha) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) u[j] = fmaf(u[j], al[j], be[j]);
-                    }
+                    if (alpha) u = __builtin_elementwise_fma(u, al, be);
                     if (PREC == 1 && alpha) {
                         // token-mix operand, bf16x3: the contraction runs over ROWS, so the MFMA A operand needs 8
                         // consecutive source rows of one channel in 16 contiguous bytes: UT[row/8][channel][row%8]
