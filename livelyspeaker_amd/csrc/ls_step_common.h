@@ -41,6 +41,21 @@ __device__ __forceinline__ f4 silu_acc4(f4 v, f4 r) {
 #endif
 }
 
+// g * SiLU'(a) for a float4, SiLU'(a) = s (1 + a (1 - s)), s = sigmoid(a); non-transcendental operations as packed f32
+__device__ __forceinline__ f4 silu_grad4(f4 a, f4 g) {
+    const f4 c = (f4){-1.4426950408889634f, -1.4426950408889634f, -1.4426950408889634f, -1.4426950408889634f};
+    const f4 one = (f4){1.0f, 1.0f, 1.0f, 1.0f};
+    const f4 t = a * c;
+    f4 e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(t[j]);
+    e = e + one;
+    f4 sg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sg[j] = __builtin_amdgcn_rcpf(e[j]);
+    return g * (sg * __builtin_elementwise_fma(a, one - sg, one));
+}
+
 // Pointers fetched from the DevWeights block are generic to the compiler; cast them to the global
 // address space so loads are global_load (vmcnt only) instead of flat_load (vmcnt AND lgkmcnt, which
 // would make every LDS wait in the GEMM loops also wait for the weight prefetch).

@@ -156,11 +156,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                     f4 d = (f4){0.f, 0.f, 0.f, 0.f};
                     const f4 av = avs[cb][t];
                     if (gr >= 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av[j] * -1.4426950408889634f));
-                            d[j] = G[cb][t][j] * (sg * (1.0f + av[j] * (1.0f - sg)));
-                        }
+                        d = silu_grad4(av, G[cb][t]);
                         *reinterpret_cast<f4*>(dA2 + (size_t)gr * kD + chw + 16 * cb) = d;
                         pbias += d;
                     }
@@ -305,11 +301,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                     f4 d = (f4){0.f, 0.f, 0.f, 0.f};
                     const f4 av = avs[cb][t];
                     if (gr >= 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av[j] * -1.4426950408889634f));
-                            d[j] = G[cb][t][j] * (sg * (1.0f + av[j] * (1.0f - sg)));
-                        }
+                        d = silu_grad4(av, G[cb][t]);
                         *reinterpret_cast<f4*>(dA1 + (size_t)gr * kD + chw + 16 * cb) = d;
                     }
                     *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = d;
