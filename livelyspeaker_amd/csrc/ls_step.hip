@@ -266,20 +266,22 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
             f2 pw[kWaves];
-            float ms = 0.f, m2s = 0.f;
+            f2 acc2 = (f2){0.f, 0.f};                     // (sum of means, sum of M2): packed f32 adds
 #pragma unroll
             for (int ww = 0; ww < kWaves; ++ww) {
                 pw[ww] = pst[ww * 80 + 16 * t + s16];
-                ms += pw[ww].x;
-                m2s += pw[ww].y;
+                acc2 += pw[ww];
             }
+            const float ms = acc2.x, m2s = acc2.y;
             const float mt = ms * (1.0f / kWaves);
-            float dd = 0.f;
+            const f2 mt2 = (f2){mt, mt};
+            f2 dd2 = (f2){0.f, 0.f};                      // squared mean deviations, two waves per packed FMA
 #pragma unroll
-            for (int ww = 0; ww < kWaves; ++ww) {
-                const float d = pw[ww].x - mt;
-                dd = fmaf(d, d, dd);
+            for (int ww = 0; ww < kWaves; ww += 2) {
+                const f2 d = (f2){pw[ww].x, pw[ww + 1].x} - mt2;
+                dd2 = __builtin_elementwise_fma(d, d, dd2);
             }
+            const float dd = dd2.x + dd2.y;
             mean[t] = mt;
             rstd[t] = rsqrtf((m2s + 64.0f * dd) * (1.0f / kD) + 1e-5f);
             if constexpr (TRAIN) {                        // (mean, rstd) of every row, kept for the LayerNorm backward
