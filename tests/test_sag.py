@@ -65,6 +65,54 @@ def test_hip_decoder_vs_golden_and_oracle(g6):
         eng.close()
 
 
+# ---- BEAT twin (scripts_beat/model/motionclip_module.py:98-183: 47 joints x 6 features, mapping = Linear(283, 512)) ----
+@pytest.fixture(scope="module")
+def g6_beat():
+    return np.load(os.path.join(GOLDEN, "sag_beat_golden.npz"))
+
+
+def _inputs_beat(B=6):
+    return synth.make_cond(synth.BEAT, B)["origin_x"], synth.make_text_features(B)
+
+
+def test_oracle_matches_reference_fixture_beat(g6_beat):
+    from oracle import rag_oracle as orc
+    x, z = _inputs_beat()
+    oracle = orc.SagDecoderOracle(synth.make_sag_state_dict(synth.BEAT), njoints=synth.BEAT.njoints, nfeats=synth.BEAT.nfeats)
+    assert max_abs(oracle.decode(x, z, None), g6_beat["G6_sag_all"]) < 2e-5
+    assert max_abs(oracle.decode(x, z, g6_beat["G6_mask_ragged"]), g6_beat["G6_sag_ragged"]) < 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_decoder_vs_golden_beat(g6_beat):
+    import torch
+    from livelyspeaker_amd import _lib
+    from livelyspeaker_amd.motionclip_module import Decoder_TRANSFORMER
+    cfg = synth.BEAT
+    sd = synth.make_sag_state_dict(cfg)
+    x, z = _inputs_beat()
+    eng = _lib.SagEngine(cfg.njoints, cfg.nfeats)
+    try:
+        eng.load_state_dict(sd)
+        d_all = max_abs(eng.decode(x, z), g6_beat["G6_sag_all"])
+        out = eng.decode(x, z, g6_beat["G6_mask_ragged"])
+        d_rag = max_abs(out, g6_beat["G6_sag_ragged"])
+        print(f"BEAT SAG decoder vs reference: all {d_all:.3e} ragged {d_rag:.3e}")
+        assert d_all < 1e-4 and d_rag < 1e-4
+        assert float(np.abs(out[4, :, :, 20:]).max()) == 0.0
+    finally:
+        eng.close()
+    # the drop-in module with the variant's constructor arguments (mapping must come out as Linear(283, 512))
+    dec = Decoder_TRANSFORMER(njoints=cfg.njoints, nfeats=cfg.nfeats, latent_dim=512, n_pre_poses=4, use_style=False)
+    assert tuple(dec.mapping.weight.shape) == (512, 283)
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    dec = dec.to("cuda:0").eval()
+    batch = {"x": torch.from_numpy(x).to("cuda:0"), "mask": torch.from_numpy(g6_beat["G6_mask_ragged"]).to("cuda:0"),
+             "z": torch.from_numpy(z).to("cuda:0")}
+    got = dec(batch)["output"].cpu().numpy()
+    assert max_abs(got, g6_beat["G6_sag_ragged"]) < 1e-4
+
+
 @pytest.mark.gpu
 def test_livelyspeaker_pipeline_dropin(g6):
     """test_LivelySpeaker_ted.py:77-113 end to end: SAG.decoder(batch) -> init_image -> ddim100, skip 80 refine."""
