@@ -230,6 +230,12 @@ typedef struct ls_post_config {
 int ls_ted_post(int device, int on_device, int batch, const ls_post_config* c, const float* sample, float* aligned,
                 float* pose, float* angle_diff, unsigned char* beat_mask);
 
+/* BEAT twin of the caller plumbing (scripts_beat/test_RAG_beat.py:86, 101): the sampled tensor [B,J,6,34] in the reference layout
+ * -> decoded_motions [B,34,J*6] (`.permute(0, 3, 1, 2).reshape(tar_pose.shape)`) and pred_euler [B,34,J*3] in degrees
+ * (`matrix_to_euler_angles(rotation_6d_to_matrix(.), "XYZ") / pi * 180`, scripts_beat/dataloaders/rot_utils.py:218-257, 513-534:
+ * Gram-Schmidt on the two 3-vectors, then (atan2(-m12, m22), asin(m02), atan2(-m01, m00))).  Either output may be NULL. */
+int ls_beat_post(int device, int on_device, int batch, int njoints, const float* sample, float* decoded, float* euler_deg);
+
 /* ---- training step ----------------------------------------------------------------
  * One optimisation step of the RAG denoiser as TrainLoop.run_step runs it (scripts/train_utils/train_loop.py:146-186):
  *   x_t = q_sample(x_start, t, noise)                                  gaussian_diffusion.py:1281-1282

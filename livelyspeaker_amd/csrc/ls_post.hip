@@ -130,3 +130,69 @@ extern "C" int ls_ted_post(int device, int on_device, int batch, const ls_post_c
     }
     return e == hipSuccess ? LS_OK : LS_EHIP;
 }
+
+// ---- BEAT: rot6d -> rotation matrix -> Euler XYZ (degrees), plus the [B,J,6,T] -> [B,T,J*6] layout change --------------------
+namespace ls {
+
+__global__ __launch_bounds__(256) void k_beat_post(const float* __restrict__ sample, float* __restrict__ decoded, float* __restrict__ euler,
+                                                   int J, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // one thread per (b, t, joint)
+    if (i >= total) return;
+    const int j = (int)(i % J);
+    const size_t bt = i / J;
+    const int t = (int)(bt % kT);
+    const size_t b = bt / kT;
+    float d6[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) d6[f] = sample[((b * J + j) * 6 + f) * kT + t];
+    if (decoded) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) decoded[(bt * J + j) * 6 + f] = d6[f];
+    }
+    if (!euler) return;
+    // rotation_6d_to_matrix (rot_utils.py:529-534): b1 = normalize(a1), b2 = normalize(a2 - (b1.a2) b1), b3 = b1 x b2; rows of M
+    const float n1 = fmaxf(sqrtf(d6[0] * d6[0] + d6[1] * d6[1] + d6[2] * d6[2]), 1e-12f);      // F.normalize: x / max(|x|, eps)
+    const float b1x = d6[0] / n1, b1y = d6[1] / n1, b1z = d6[2] / n1;
+    const float dt = b1x * d6[3] + b1y * d6[4] + b1z * d6[5];
+    float b2x = d6[3] - dt * b1x, b2y = d6[4] - dt * b1y, b2z = d6[5] - dt * b1z;
+    const float n2 = fmaxf(sqrtf(b2x * b2x + b2y * b2y + b2z * b2z), 1e-12f);
+    b2x /= n2; b2y /= n2; b2z /= n2;
+    const float b3z = b1x * b2y - b1y * b2x;                           // only m22 of the third row is needed
+    // matrix_to_euler_angles(M, "XYZ") (rot_utils.py:238-257): (atan2(-m12, m22), asin(m02), atan2(-m01, m00))
+    const float k = 57.29577951308232f;                                // / pi * 180
+    float* o = euler + (bt * J + j) * 3;
+    o[0] = atan2f(-b2z, b3z) * k;
+    o[1] = asinf(b1z) * k;
+    o[2] = atan2f(-b1y, b1x) * k;
+}
+
+}  // namespace ls
+
+extern "C" int ls_beat_post(int device, int on_device, int batch, int njoints, const float* sample, float* decoded, float* euler_deg) {
+    using namespace ls;
+    if (!sample || batch < 1 || njoints < 1) return LS_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return LS_EHIP;
+    const size_t n_in = (size_t)batch * njoints * 6 * kT, n_eu = (size_t)batch * kT * njoints * 3, total = (size_t)batch * kT * njoints;
+    float *d_in = nullptr, *d_dec = nullptr, *d_eu = nullptr;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    if (on_device) {
+        d_in = const_cast<float*>(sample); d_dec = decoded; d_eu = euler_deg;
+    } else {
+        chk(hipMalloc(&d_in, n_in * 4));
+        if (decoded) chk(hipMalloc(&d_dec, n_in * 4));
+        if (euler_deg) chk(hipMalloc(&d_eu, n_eu * 4));
+        if (e == hipSuccess) chk(hipMemcpy(d_in, sample, n_in * 4, hipMemcpyHostToDevice));
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_beat_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, d_in, d_dec, d_eu, njoints, total);
+        chk(hipGetLastError());
+        chk(hipDeviceSynchronize());
+    }
+    if (!on_device) {
+        if (e == hipSuccess && decoded) chk(hipMemcpy(decoded, d_dec, n_in * 4, hipMemcpyDeviceToHost));
+        if (e == hipSuccess && euler_deg) chk(hipMemcpy(euler_deg, d_eu, n_eu * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_in); if (d_dec) (void)hipFree(d_dec); if (d_eu) (void)hipFree(d_eu);
+    }
+    return e == hipSuccess ? LS_OK : LS_EHIP;
+}

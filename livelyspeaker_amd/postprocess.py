@@ -63,6 +63,24 @@ def ted_postprocess(sample, device: int = 0, want_pose: bool = True) -> dict:
             "beat_mask": mask.bool() if m.on_device else mask.astype(bool), "motion_beat_times": beats}
 
 
+def beat_postprocess(sample, device: int = 0, want_euler: bool = True) -> dict:
+    """BEAT caller plumbing (scripts_beat/test_RAG_beat.py:86, 101).  sample: [B, 47, 6, 34] (numpy, CPU tensor or CUDA tensor as
+    returned by the sampler).  Returns decoded_motions [B, 34, 282] (the rot6d pose sequence the evaluator and the metrics
+    consume) and pred_euler [B, 34, 141]: Euler XYZ angles in degrees of every joint (rot_utils.matrix_to_euler_angles(
+    rot_utils.rotation_6d_to_matrix(.), "XYZ") / pi * 180).  Audio onsets / the alignment score stay with the caller."""
+    lib = _lib.load_library()
+    m = _lib._Marshal(device, sample)
+    B, J = int(sample.shape[0]), int(sample.shape[1])
+    if tuple(sample.shape[2:]) != (6, 34):
+        raise ValueError(f"expected [B, J, 6, 34], got {tuple(sample.shape)}")
+    dec, p_dec = m.out((B, 34, J * 6))
+    eul, p_eul = m.out((B, 34, J * 3)) if want_euler else (None, None)
+    rc = lib.ls_beat_post(device, int(m.on_device), B, J, m.f32(sample, (B, J, 6, 34)), p_dec, p_eul)
+    if rc != 0:
+        raise _lib.EngineError(f"ls_beat_post failed ({rc})")
+    return {"decoded_motions": dec, "pred_euler": eul}
+
+
 class BeatConsistency:
     """Running beat-alignment (BC) score over clips, as the evaluation loop accumulates it (test_RAG_ted.py:113-127): for every
     audio onset, exp(-min_m (onset - m)^2 / (2 sigma^2)) over the clip's motion beats; clips without a motion beat contribute

@@ -394,6 +394,24 @@ class SagDecoderOracle:
         return np.ascontiguousarray(out.reshape(B, self.T, self.J, self.Fe).transpose(0, 2, 3, 1))
 
 
+# --------------------------------------------------------------------------- caller plumbing, BEAT twin
+def beat_post(sample):
+    """scripts_beat/test_RAG_beat.py:86 (layout) and :101 (rot6d -> matrix -> Euler XYZ in degrees) restated:
+    rotation_6d_to_matrix (scripts_beat/dataloaders/rot_utils.py:529-534) and matrix_to_euler_angles(., "XYZ") (:238-257)."""
+    x = np.asarray(sample, dtype=F32)
+    B, J, _, T = x.shape
+    dec = np.ascontiguousarray(x.transpose(0, 3, 1, 2).reshape(B, T, J * 6))
+    d6 = dec.reshape(B, T, J, 6)
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = a1 / np.maximum(np.sqrt((a1 * a1).sum(-1, keepdims=True, dtype=F32)), F32(1e-12))
+    b2 = a2 - (b1 * a2).sum(-1, keepdims=True, dtype=F32) * b1
+    b2 = b2 / np.maximum(np.sqrt((b2 * b2).sum(-1, keepdims=True, dtype=F32)), F32(1e-12))
+    b3z = b1[..., 0] * b2[..., 1] - b1[..., 1] * b2[..., 0]
+    k = F32(180.0 / math.pi)
+    eul = np.stack((np.arctan2(-b2[..., 2], b3z), np.arcsin(b1[..., 2]), np.arctan2(-b1[..., 1], b1[..., 0])), axis=-1).astype(F32) * k
+    return {"decoded_motions": dec, "pred_euler": eul.reshape(B, T, J * 3).astype(F32)}
+
+
 # --------------------------------------------------------------------------- caller plumbing (SURVEY.md section 8f-2)
 def ted_post(sample, mean_dir_vec, angle_pairs, change_angle, thres, dir_vec_pairs):
     """scripts/test_RAG_ted.py:84-111 and convert_dir_vec_to_pose (scripts/utils/data_utils.py:77-97) restated."""

@@ -72,3 +72,43 @@ def test_beat_consistency_accumulation():
     assert abs(bc.score() - total / nb) < 1e-12
     with pytest.raises(ValueError):
         bc.push(motion[:1], audio[:2])
+
+
+# ---- BEAT twin: layout change + rot6d -> matrix -> Euler XYZ in degrees (scripts_beat/test_RAG_beat.py:86, 101) --------------------
+@pytest.fixture(scope="module")
+def g10():
+    return np.load(os.path.join(GOLDEN, "post_beat_golden.npz"))
+
+
+def _beat_sample():
+    return np.load(os.path.join(GOLDEN, "beat_golden.npz"))["G3_ddpm50_final"]
+
+
+def _circ_deg(a, b):
+    """largest angular distance in degrees (atan2 wraps at +-180)"""
+    return float(np.abs((np.asarray(a, np.float64) - np.asarray(b, np.float64) + 180.0) % 360.0 - 180.0).max())
+
+
+def test_beat_oracle_matches_reference_fixture(g10):
+    from oracle import rag_oracle as orc
+    o = orc.beat_post(_beat_sample())
+    assert np.array_equal(o["decoded_motions"], g10["G10_decoded"])
+    assert _circ_deg(o["pred_euler"], g10["G10_euler"]) < 5e-3         # asin / atan2 near their singular points amplify fp32 rounding
+
+
+@pytest.mark.gpu
+def test_hip_beat_post_vs_reference_fixture(g10):
+    import torch
+    s = _beat_sample()
+    r = pp.beat_postprocess(s)
+    assert np.array_equal(r["decoded_motions"], g10["G10_decoded"])
+    d = _circ_deg(r["pred_euler"], g10["G10_euler"])
+    print("BEAT euler max circular |d| (deg) =", d)
+    assert d < 5e-3
+    big = torch.from_numpy(np.tile(s, (64, 1, 1, 1))).cuda()            # the callers' batch (256), device-resident
+    rb = pp.beat_postprocess(big)
+    assert rb["pred_euler"].is_cuda and tuple(rb["pred_euler"].shape) == (256, 34, 141)
+    assert np.array_equal(rb["pred_euler"][252:].cpu().numpy(), r["pred_euler"])
+    assert np.array_equal(rb["decoded_motions"][:4].cpu().numpy(), r["decoded_motions"])
+    with pytest.raises(ValueError):
+        pp.beat_postprocess(np.zeros((2, 47, 3, 34), np.float32))
