@@ -5,7 +5,7 @@
 // 16 input channels: the four K entries of one MFMA are 4 consecutive input channels at the same tap k, so lane
 // (position p, g) reads lds[(ci0+g)][p*6 + k] = lane base + compile-time offset (no per-lane div/mod), and the weight
 // operand W[co][ci0+g][k] is pre-permuted on the host into per-lane order (one float4 = 4 consecutive MFMA steps).
-// Workgroup = 64 positions x 64 output channels of one sample: wave w owns 16 channels and the 4 position tiles.
+// Workgroup = 64 positions x 64 output channels of one sample; 4 consumer waves (16 channels x the 4 position tiles each) + 4 producer waves.
 #include "ls_internal.h"
 #include "ls_lanes.h"
 #include "ls_train.h"
@@ -21,51 +21,59 @@ constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the
 
 // wimg: [co tile (Cout/16)][chunk (Cin/16)][step4 (15)][lane 64][4]: element e of step4 q is MFMA step s = 4q+e,
 //       tap k = s / 4 ... see build_conv_image() in ls_api.cpp: step s -> (k = s / 4, cig = s % 4), ci = 4*cig + g
-__global__ __launch_bounds__(256, 3) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
-                                                     const float* __restrict__ wimg, const float* __restrict__ bias,
-                                                     float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout) {
-    __shared__ float sIn[kCvCI * kCvWinP];
+// Producer / consumer workgroup (512 threads): waves 0-3 only multiply (wave w = channel tile w x the four position tiles:
+// one float4 of weights per tap feeds 16 MFMAs; activations from LDS, weights from L2), waves 4-7 only stage -- they fetch the
+// NEXT chunk's raw input window (25 values per thread, clamped addresses: branch-free and in flight together), apply the
+// previous layer's InstanceNorm + LeakyReLU and write it to the other half of a double-buffered LDS window while the consumers
+// run the current chunk's 240 MFMAs.  One workgroup barrier per chunk.  (As a single-role 256-thread kernel the memory side
+// alone took 276 us and the MFMA side alone 336 us for conv2, and they overlapped poorly: 515 us; this form: 476 us.)
+__global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
+                                                        const float* __restrict__ wimg, const float* __restrict__ bias,
+                                                        float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout) {
+    __shared__ float sIn[2][kCvCI * kCvWinP];
     const int b = blockIdx.z, co0 = blockIdx.y * kCvTC, p0 = blockIdx.x * kCvTP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s16 = lane & 15, g = lane >> 4;
     const int nchunk = Cin / kCvCI;
     const int in0 = p0 * kCvS;
-
-    // Wave w owns channel tile w (16 output channels) for all four 16-position tiles: one float4 of weights per tap feeds 16 MFMAs
-    // and the activations come from LDS.  (With the roles swapped every wave of the workgroup streamed the same 4 KB of weights per
-    // tap from L2; measured 3-4 % slower.)
+    const int validw = Lin - in0;                                       // >= 1 for every tile that has an output position
+    constexpr int NV = (kCvWin + 15) / 16;
+    if (w >= 4) {
+        // ---------------- producers
+        const int pt = tid - 256;
+        auto stage = [&](int c, float* dst) {
+            const size_t row = (size_t)b * Cin + c * kCvCI + (pt >> 4);
+            const float vm = stats[row * 2], vr = stats[row * 2 + 1];   // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
+            const float* src = in + row * Lin + in0;
+            float vals[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) vals[q] = src[min((pt & 15) + 16 * q, validw - 1)];      // clamped: branch-free, in flight together
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int o = (pt & 15) + 16 * q;
+                float v = (vals[q] - vm) * vr;
+                v = v >= 0.f ? v : 0.3f * v;
+                if (o < kCvWin) dst[(pt >> 4) * kCvWinP + o] = o < validw ? v : 0.f;
+            }
+        };
+        stage(0, sIn[0]);
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) stage(c + 1, sIn[(c + 1) & 1]);
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------- consumers
+    const int s16 = lane & 15, g = lane >> 4;
     f4 acc[4];                                                 // [position tile]
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
     const int lbase = g * kCvWinP + s16 * kCvS;                // + (4*cig)*WinP + 16*pt*S + k per step
-
-    // Software pipeline: the raw input window of chunk c+1 (25 values per thread, 16 threads per input channel, clamped
-    // addresses so the loads are branch-free and in flight together) is fetched while chunk c is multiplied, and the
-    // weight operand of tap k+1 (L2) while tap k is multiplied.
-    constexpr int NV = (kCvWin + 15) / 16;
-    float vals[NV], vm = 0.f, vr = 1.f;
-    const int validw = Lin - in0;                                       // >= 1 for every tile that has an output position
-    auto fetch = [&](int c) {
-        const size_t row = (size_t)b * Cin + c * kCvCI + (tid >> 4);
-        vm = stats[row * 2];                                            // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
-        vr = stats[row * 2 + 1];
-        const float* src = in + row * Lin + in0;
-#pragma unroll
-        for (int q = 0; q < NV; ++q) vals[q] = src[min((tid & 15) + 16 * q, validw - 1)];
-    };
-    fetch(0);
+    const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
+    __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const int o = (tid & 15) + 16 * q;
-            float v = (vals[q] - vm) * vr;
-            v = v >= 0.f ? v : 0.3f * v;
-            if (o < kCvWin) sIn[(tid >> 4) * kCvWinP + o] = o < validw ? v : 0.f;
-        }
-        __syncthreads();
-        if (c + 1 < nchunk) fetch(c + 1);
+        const float* sb = sIn[c & 1];
         const f4* wp = reinterpret_cast<const f4*>(wimg) + ((size_t)(blockIdx.y * 4 + w) * nchunk + c) * kCvK * 64 + lane;
         f4 An = wp[0];
 #pragma unroll
@@ -76,14 +84,13 @@ __global__ __launch_bounds__(256, 3) void k_conv1d_mfma(const float* __restrict_
             for (int cig = 0; cig < 4; ++cig) {
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) {
-                    const float Bv = sIn[lbase + (4 * cig) * kCvWinP + 16 * pt * kCvS + k];
+                    const float Bv = sb[lbase + (4 * cig) * kCvWinP + 16 * pt * kCvS + k];
                     acc[pt] = MFMA(A[cig], Bv, acc[pt]);
                 }
             }
         }
+        __syncthreads();
     }
-    // lane (s16, g) holds channels co0 + 16 w + 4 g + j of positions p0 + 16 pt + s16
-    const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
         const int p = p0 + 16 * pt + s16;
@@ -96,8 +103,6 @@ __global__ __launch_bounds__(256, 3) void k_conv1d_mfma(const float* __restrict_
             const float v = acc[pt][j] + bv[j];
             if (valid) out[((size_t)b * Cout + co) * Lout + p] = v;
             if (spart) {
-                // InstanceNorm statistics of 16 positions (lanes sharing g), two-pass inside the tile:
-                // (count, mean, M2) per (sample, channel, 16-position tile); k_stats_merge combines them (Chan et al.)
                 const float s1 = row16_sum(valid ? v : 0.f);
                 const float mean = s1 * inv_nv;
                 const float d = valid ? v - mean : 0.f;
@@ -153,7 +158,7 @@ hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* 
                               float* spart, int B, int Cin, int Cout, int Lin, int Lout, hipStream_t st) {
     if (Cin % kCvCI || Cout % kCvTC || !stats || (out_stats && !spart)) return hipErrorInvalidValue;
     dim3 grid((Lout + kCvTP - 1) / kCvTP, Cout / kCvTC, B);
-    hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(256), 0, st, in, stats, wimg, bias, out, out_stats ? spart : nullptr, Cin, Cout, Lin, Lout);
+    hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(512), 0, st, in, stats, wimg, bias, out, out_stats ? spart : nullptr, Cin, Cout, Lin, Lout);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !out_stats) return e;
     return launch_stats_merge(spart, out_stats, B * Cout, (int)grid.x * 4, st);
