@@ -85,17 +85,17 @@ __device__ __forceinline__ void fetch(f4 (&v)[4], const GemmOperand& o, const si
 // unconditional loads off one running pointer (`at` already includes the thread's k position; it advances by one K tile per
 // iteration).  The general fetch above costs ~450 executed VALU/SALU instructions per K tile (bounds tests, two-level index
 // arithmetic), which on gfx950 come straight out of the fp32 MFMA issue time.
-template <bool KC>
+template <bool KC, int NI = 4>
 __device__ __forceinline__ void fetch_fast(f4 (&v)[4], const float* at, const size_t (&roff)[4], long long ks) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f4*>(KC ? at + roff[i] : at + (long long)(8 * i) * ks);
+    for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const f4*>(KC ? at + roff[i] : at + (long long)(8 * i) * ks);
 }
 
 // registers -> LDS: K-contiguous operands as [row][k] (stride 36), row-contiguous ones as [k][row] (stride 132)
-template <bool KC>
+template <bool KC, int NI = 4>
 __device__ __forceinline__ void put(float* s, const f4 (&v)[4], int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         if (KC) *reinterpret_cast<f4*>(&s[((tid >> 3) + 32 * i) * kLdK + (tid & 7) * 4]) = v[i];
         else *reinterpret_cast<f4*>(&s[((tid >> 5) + 8 * i) * kLdR + (tid & 31) * 4]) = v[i];
     }
@@ -121,9 +121,14 @@ __device__ __forceinline__ f4 frag(const float* s, int row, int kk, int g) {
     return v;
 }
 
-template <bool AK, bool BK, bool FAST>
+// MT: 16-row m tiles per wave -> 128 (MT = 4) or 64 (MT = 2) rows of A per workgroup.  The 64-row tile exists for products whose
+// 128 x 128 tile count fills the chip badly (e.g. 544 tiles on 768 workgroup slots: one CU in eight runs three tiles while the
+// others run two); only the K-contiguous fast path is instantiated with it.
+template <bool AK, bool BK, bool FAST, int MT = 4>
 __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
-    constexpr int SA = AK ? kTM * kLdK : kTK * kLdR;
+    static_assert(MT == 4 || (MT == 2 && AK && FAST), "64-row tiles: K-contiguous A on the fast path only");
+    constexpr int BM = 32 * MT;
+    constexpr int SA = AK ? BM * kLdK : kTK * kLdR;
     constexpr int SB = BK ? kTM * kLdK : kTK * kLdR;
     __shared__ __attribute__((aligned(16))) float sA[SA];
     __shared__ __attribute__((aligned(16))) float sB[SB];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    const int m0 = by * kTM, n0 = bx * kTM;
+    const int m0 = by * BM, n0 = bx * kTM;
     const int s16 = lane & 15, g = lane >> 4;
     const int zb = bz / a.splits, z = bz - zb * a.splits;     // (problem of the batch, K split)
     const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
@@ -139,11 +144,11 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     a.B.p += (size_t)zb * a.bsB;
     a.C += (size_t)zb * a.bsC;
 
-    f4 acc[4][4];                                   // [n tile][m tile]
+    f4 acc[4][MT];                                  // [n tile][m tile]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
     size_t roffA[4], roffB[4];
     row_offsets<AK>(a.A, roffA, m0, a.M, tid);
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     if (FAST) {
         pa = AK ? a.A.p + kbeg + (tid & 7) * 4 : a.A.p + roffA[0] + (long long)(kbeg + (tid >> 5)) * a.A.ks;
         pb = BK ? a.B.p + kbeg + (tid & 7) * 4 : a.B.p + roffB[0] + (long long)(kbeg + (tid >> 5)) * a.B.ks;
-        fetch_fast<AK>(ra, pa, roffA, a.A.ks);
+        fetch_fast<AK, MT>(ra, pa, roffA, a.A.ks);
         fetch_fast<BK>(rb, pb, roffB, a.B.ks);
     } else {
         fetch<AK>(ra, a.A, roffA, m0, a.M, kbeg, kend, tid);
@@ -163,14 +168,14 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     }
     for (int k0 = kbeg; k0 < kend; k0 += kTK) {
         __syncthreads();
-        put<AK>(sA, ra, tid);
+        put<AK, MT>(sA, ra, tid);
         put<BK>(sB, rb, tid);
         __syncthreads();
         if (FAST) {                         // next tile's global loads overlap this tile's MFMAs; the last iteration re-reads its
             const long long adv = k0 + kTK < kend ? kTK : 0;          // own tile instead of branching around the loads
             pa += AK ? adv : adv * a.A.ks;
             pb += BK ? adv : adv * a.B.ks;
-            fetch_fast<AK>(ra, pa, roffA, a.A.ks);
+            fetch_fast<AK, MT>(ra, pa, roffA, a.A.ks);
             fetch_fast<BK>(rb, pb, roffB, a.B.ks);
             __builtin_amdgcn_sched_barrier(0);      // or the scheduler sinks these loads below the MFMAs, right in front of their use
         } else if (k0 + kTK < kend) {
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
         if (FAST) {
             // fragment loads run one step ahead of the MFMAs that use them (8 steps per K tile: 2 k-halves x 4 n tiles): the fast
             // staging path leaves the registers for a second A set and a second B fragment at 3 waves / SIMD
-            f4 af[2][4], bf[2];
+            f4 af[2][MT], bf[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[0][j] = frag<AK>(sA, wm * 64 + 16 * j + s16, 0, g);
+            for (int j = 0; j < MT; ++j) af[0][j] = frag<AK>(sA, wm * 16 * MT + 16 * j + s16, 0, g);
             bf[0] = frag<BK>(sB, wn * 64 + s16, 0, g);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
@@ -190,28 +195,28 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
                 if (st + 1 < 8) bf[(st + 1) & 1] = frag<BK>(sB, wn * 64 + 16 * ((st + 1) & 3) + s16, (st + 1) >> 2, g);
                 if (st == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) af[1][j] = frag<AK>(sA, wm * 64 + 16 * j + s16, 1, g);
+                    for (int j = 0; j < MT; ++j) af[1][j] = frag<AK>(sA, wm * 16 * MT + 16 * j + s16, 1, g);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // pins [LDS reads of the next step][MFMAs of this step]
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(bf[st & 1][e], af[kk][j][e], acc[i][j]);
+                    for (int j = 0; j < MT; ++j) acc[i][j] = MFMA(bf[st & 1][e], af[kk][j][e], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
             for (int kk = 0; kk < kTK / 16; ++kk) {
-                f4 af[4];
+                f4 af[MT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = frag<AK>(sA, wm * 64 + 16 * j + s16, kk, g);
+                for (int j = 0; j < MT; ++j) af[j] = frag<AK>(sA, wm * 16 * MT + 16 * j + s16, kk, g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {       // one B fragment live at a time keeps the kernel at 3 waves / SIMD
                     const f4 bf = frag<BK>(sB, wn * 64 + 16 * i + s16, kk, g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] = MFMA(bf[e], af[j][e], acc[i][j]);
+                        for (int j = 0; j < MT; ++j) acc[i][j] = MFMA(bf[e], af[j][e], acc[i][j]);
                 }
             }
         }
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
         for (int i = 0; i < 4; ++i) biasv[i] = *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + 16 * j + s16;
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * 16 * MT + 16 * j + s16;
         if (!FAST && m >= a.M) continue;
         const size_t crow = partial ? (size_t)m * a.N : lvl(m, a.cri, a.cro, a.crs);
 #pragma unroll
@@ -305,16 +310,26 @@ hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits
     dim3 grid((a.N + kTM - 1) / kTM, (a.M + kTM - 1) / kTM, a.nbatch * splits);
     // fast staging path: full tiles, whole K tiles in every split, float4-legal operands with a single-level reduction index
     const bool fast = a.M % kTM == 0 && a.N % kTM == 0 && a.K % kTK == 0 && a.A.vec && a.B.vec && a.A.ki == INT_MAX && a.B.ki == INT_MAX;
+    // 64-row tiles when they balance the 256 CUs better: every CU works through ceil(workgroups / 256) tiles (co-resident ones share
+    // its matrix pipes), so the efficiency of a grid is (workgroups / 256) / ceil(workgroups / 256) -- 544 tiles: 0.71, 1088 half tiles: 0.85
+    auto balance = [](long long wgs) { const double per = (double)wgs / 256.0; return per / (double)((wgs + 255) / 256); };
+    const long long t128 = (long long)grid.x * grid.y * grid.z;
+    const bool half = fast && a_kcontig && b_kcontig && balance(2 * t128) > balance(t128) + 0.05;
+    if (half) {
+        grid.y *= 2;
+        hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2>), grid, dim3(256), 0, st, a);
+    } else {
 #define LS_GEMM_LAUNCH(AKV, BKV)                                                                             \
     do {                                                                                                     \
         if (fast) hipLaunchKernelGGL((k_gemm_tr<AKV, BKV, true>), grid, dim3(256), 0, st, a);                \
         else hipLaunchKernelGGL((k_gemm_tr<AKV, BKV, false>), grid, dim3(256), 0, st, a);                    \
     } while (0)
-    if (a_kcontig && b_kcontig) LS_GEMM_LAUNCH(true, true);
-    else if (a_kcontig && !b_kcontig) LS_GEMM_LAUNCH(true, false);
-    else if (!a_kcontig && b_kcontig) LS_GEMM_LAUNCH(false, true);
-    else LS_GEMM_LAUNCH(false, false);
+        if (a_kcontig && b_kcontig) LS_GEMM_LAUNCH(true, true);
+        else if (a_kcontig && !b_kcontig) LS_GEMM_LAUNCH(true, false);
+        else if (!a_kcontig && b_kcontig) LS_GEMM_LAUNCH(false, true);
+        else LS_GEMM_LAUNCH(false, false);
 #undef LS_GEMM_LAUNCH
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splits == 1) return e;
     const size_t n = (size_t)a.M * a.N;
