@@ -58,7 +58,7 @@ float bf16_to_f32(unsigned short h) {
 struct ls_handle {
     ls_config cfg{};
     Variant var = kTED;
-    int JF = 0, S = 0, R = 0, NOB = 0, KXQ = 0, MK = 0, KIN = 0, KF = 0;
+    int JF = 0, S = 0, R = 0, NOB = 0, KXQ = 0, MK = 0, KIN = 0, KF = 0, KFP = 0;      // KFP: KF padded to the GEMM's K tile
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -73,7 +73,7 @@ struct ls_handle {
     DevBuf winx_seq_img, wch_seq_hi_img, wch_seq_lo_img, ww_seq_hi_img, ww_seq_lo_img, btok_seq, wout_hi_img, wout_lo_img, out_raw;
     DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
     DevBuf conv_img[4];     // MFMA operand images of the stride-6 conv layers (ls_conv.hip)
-    DevBuf conv_w[4], conv_b[4], win_full, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
+    DevBuf conv_w[4], conv_b[4], win_full, win_pad, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
     DevBuf te_w0, te_b0, te_w2, te_b2, pe;
 
     // schedule
@@ -365,6 +365,13 @@ int build_images(ls_handle* h) {
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
     UP(win_full, *Win); UP(win_bias, *bin);
+    {   // the static columns JF.. of input_mapping as their own [512][KFP] matrix (zero-padded to a whole number of K tiles and
+        // 16-byte-aligned rows): the once-per-call projection then takes the GEMM's fast path
+        std::vector<float> wp((size_t)D * h->KFP, 0.f);
+        for (int n = 0; n < D; ++n)
+            for (int k = 0; k < h->KF; ++k) wp[(size_t)n * h->KFP + k] = (*Win)[(size_t)n * KIN + JF + k];
+        UP(win_pad, wp);
+    }
     // raw weights used by the once-per-call kernels
     for (int i = 0; i < 4; ++i) {
         snprintf(key, sizeof key, "audio_encoder.feat_extractor.%d.weight", kConvKey[i]);
@@ -554,6 +561,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     h->MK = (h->R + 3) / 4;
     h->KIN = 2 * JF + 1 + kAudioFeat;
     h->KF = JF + 1 + kAudioFeat;
+    h->KFP = (h->KF + 31) / 32 * 32;
     memcpy(h->convL, convL, sizeof convL);
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -582,7 +590,7 @@ void ls_destroy(ls_handle* h) {
     free_graph(h);
     DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->ww_hi_img, &h->ww_lo_img, &h->winx_seq_img, &h->wch_seq_hi_img,
                      &h->wch_seq_lo_img, &h->ww_seq_hi_img, &h->ww_seq_lo_img, &h->btok_seq, &h->wout_hi_img, &h->wout_lo_img, &h->out_raw, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
-                     &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
+                     &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_pad, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
                      &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
@@ -700,14 +708,14 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
         in = outs[i]->f();
     }
     // ---- static part of input_mapping (RAG.py:110-114): columns JF.. of W_in act on [prefix poses | bit | audio]
-    const int KF = h->KF, KIN = h->KIN;
-    HIPCHK(h, h->feat_c.ensure((size_t)B * kT * KF * sizeof(float)));
-    HIPCHK(h, h->feat_u.ensure((size_t)B * kT * KF * sizeof(float)));
+    const int KFP = h->KFP;
+    HIPCHK(h, h->feat_c.ensure((size_t)B * kT * KFP * sizeof(float)));
+    HIPCHK(h, h->feat_u.ensure((size_t)B * kT * KFP * sizeof(float)));
     HIPCHK(h, h->static_c.ensure((size_t)B * kT * kD * sizeof(float)));
     HIPCHK(h, h->static_u.ensure((size_t)B * kT * kD * sizeof(float)));
-    HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_c.f(), h->feat_u.f(), B, JF, h->cfg.n_pre_seq, st));
-    HIPCHK(h, launch_gemm_nt(h->feat_c.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), nullptr, 0, h->static_c.f(), kD, B * kT, kD, KF, 0, st));
-    HIPCHK(h, launch_gemm_nt(h->feat_u.f(), KF, h->win_full.f() + JF, KIN, h->win_bias.f(), nullptr, 0, h->static_u.f(), kD, B * kT, kD, KF, 0, st));
+    HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_c.f(), h->feat_u.f(), B, JF, KFP, h->cfg.n_pre_seq, st));
+    HIPCHK(h, launch_gemm_nt(h->feat_c.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_c.f(), kD, B * kT, kD, KFP, 0, st));
+    HIPCHK(h, launch_gemm_nt(h->feat_u.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_u.f(), kD, B * kT, kD, KFP, 0, st));
     // ---- speaker style (RAG.py:116-119): z = Embedding[vid]; mu, logvar = Linear(z); std = exp(0.5*logvar)
     HIPCHK(h, h->z.ensure((size_t)B * 256 * sizeof(float)));
     HIPCHK(h, h->z_mu.ensure((size_t)B * kD * sizeof(float)));

@@ -129,7 +129,7 @@ hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, cons
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int rows, int width,
                               int table_rows, hipStream_t st);
 hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
-                              int B, int JF, int n_pre_seq, hipStream_t st);
+                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st);
 hipError_t launch_to_internal(const float* src_bjft, float* dst_btc, int B, int JF, hipStream_t st);
 hipError_t launch_from_internal(const float* src_btc, float* dst_bjft, int B, int JF, hipStream_t st);
 hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size_t n, float a, float b,

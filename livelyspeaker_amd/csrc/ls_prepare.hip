@@ -31,20 +31,22 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out
 // InputProcess features without the x_t columns (RAG.py:110-112, 184-192):
 // row (b,f) = [origin_x[b,:,f] if f < n_pre_seq else 0 | indicator bit | audio feature (cond) or 0 (uncond)]
 __global__ void k_build_feats(const float* __restrict__ origin_x, const float* __restrict__ conv4,
-                              float* __restrict__ feat_c, float* __restrict__ feat_u, int JF, int n_pre_seq) {
+                              float* __restrict__ feat_c, float* __restrict__ feat_u, int JF, int KFP, int n_pre_seq) {
     const int b = blockIdx.x / kT, f = blockIdx.x % kT;
     const int KF = JF + 1 + kAudioFeat;
-    float* fc = feat_c + (size_t)blockIdx.x * KF;
-    float* fu = feat_u + (size_t)blockIdx.x * KF;
-    for (int c = threadIdx.x; c < KF; c += blockDim.x) {
+    float* fc = feat_c + (size_t)blockIdx.x * KFP;          // rows padded with zeros to KFP (a whole number of GEMM K tiles)
+    float* fu = feat_u + (size_t)blockIdx.x * KFP;
+    for (int c = threadIdx.x; c < KFP; c += blockDim.x) {
         float vc, vu;
         if (c < JF) {
             vc = vu = (f < n_pre_seq) ? origin_x[((size_t)b * JF + c) * kT + f] : 0.f;
         } else if (c == JF) {
             vc = vu = (f < n_pre_seq) ? 1.f : 0.f;
-        } else {
+        } else if (c < KF) {
             vc = conv4[((size_t)b * kAudioFeat + (c - JF - 1)) * kT + f];
             vu = 0.f;                                                   // mask_cond(force_mask), RAG.py:82-83
+        } else {
+            vc = vu = 0.f;
         }
         fc[c] = vc;
         fu[c] = vu;
@@ -52,8 +54,8 @@ __global__ void k_build_feats(const float* __restrict__ origin_x, const float* _
 }
 
 hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
-                              int B, int JF, int n_pre_seq, hipStream_t st) {
-    hipLaunchKernelGGL(k_build_feats, dim3(B * kT), dim3(256), 0, st, origin_x, conv4, feat_c, feat_u, JF, n_pre_seq);
+                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_feats, dim3(B * kT), dim3(256), 0, st, origin_x, conv4, feat_c, feat_u, JF, KFP, n_pre_seq);
     return hipGetLastError();
 }
 
