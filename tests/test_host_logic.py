@@ -229,3 +229,19 @@ def test_bench_stdout_carries_only_the_result_line():
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"ok": 1}\n'
     assert "banner written to fd 1" in r.stderr and "python-level noise" in r.stderr
+
+
+def test_build_staleness_is_content_based(tmp_path, monkeypatch):
+    """The library is rebuilt when its sources changed, judged by the content hash the build leaves beside it (file times do not
+    survive every copy of the tree); without the stamp the check falls back to modification times."""
+    from livelyspeaker_amd import build as b
+    if not os.path.exists(b.LIB):
+        pytest.skip("library not built")
+    stamp = tmp_path / "libls_hip.so.srchash"
+    monkeypatch.setattr(b, "STAMP", str(stamp))
+    stamp.write_text(b.source_hash() + "\n")
+    assert not b.is_stale()
+    stamp.write_text("0" * 64 + "\n")
+    assert b.is_stale()
+    stamp.unlink()
+    assert b.is_stale() == any(os.path.getmtime(d) > os.path.getmtime(b.LIB) for d in [os.path.join(b.CSRC, s) for s in b.SOURCES] + b.HEADERS)
