@@ -48,25 +48,62 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _object_for(hipcc, src, flags, objdir):
+    """Compile one source to a cached object: the key covers the source, every header and the flags."""
+    h = hashlib.sha256(" ".join(flags).encode())
+    for path in [os.path.join(CSRC, src)] + HEADERS:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    obj = os.path.join(objdir, f"{os.path.splitext(src)[0]}.{h.hexdigest()[:16]}.o")
+    if os.path.exists(obj):
+        return obj, None
+    tmp = f"{obj}.tmp{os.getpid()}"
+    res = subprocess.run([hipcc, "-c"] + flags + [os.path.join(CSRC, src), "-o", tmp], capture_output=True, text=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        return None, f"{src}:\n{res.stdout}{res.stderr}"
+    os.replace(tmp, obj)
+    for stale in glob.glob(os.path.join(objdir, f"{os.path.splitext(src)[0]}.*.o")):     # one cached object per source
+        if stale != obj:
+            os.remove(stale)
+    return obj, None
+
+
 def build_library(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
-    """defines/out: build an A/B variant (e.g. defines=['LS_GRP=2'], out='build/variants/grp2.so')."""
+    """Compile every source for gfx950 (one hipcc per file, in parallel, objects cached under build/obj) and link the
+    shared library.  defines/out: build an A/B or debug variant (e.g. defines=['LS_DEBUG'], out='build/variants/debug.so');
+    force=True ignores the object cache."""
+    from concurrent.futures import ThreadPoolExecutor
     LIB = out or globals()['LIB']
     if not force and out is None and not is_stale():
         return LIB
+    hipcc = hipcc_path()
     # -fno-slp-vectorize: SLP packs adjacent scalar f32 FMAs into v_pk_fma_f32 + v_mov shuffles, which is slower than
     # the scalar form next to MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
+             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
+    objdir = os.path.join(ROOT, "build", "obj" + ("-" + hashlib.sha256(" ".join(defines).encode()).hexdigest()[:8] if defines else ""))
+    os.makedirs(objdir, exist_ok=True)
+    if force:
+        for o in glob.glob(os.path.join(objdir, "*.o")):
+            os.remove(o)
+    digest = source_hash()
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(lambda s: _object_for(hipcc, s, flags, objdir), SOURCES))
+    errors = [e for _, e in results if e]
+    if errors:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(errors))
     tmp = f"{LIB}.tmp{os.getpid()}"              # several ranks may find the library stale at once: private temp, atomic rename
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    digest = source_hash()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB)
     if out is None and not defines:
         with open(STAMP + f".tmp{os.getpid()}", "w") as f:
