@@ -8,13 +8,22 @@ Philox noise; conditioning tensors are already resident in HBM when the timed re
 
   python bench.py [--gpus N --steps K --warmup W]             # N=1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W               # N>1: one rank per GPU, batch sharded, weak scaling
+         bench.py --gpus N --steps K --warmup W               # N>1: one rank per GPU over RCCL
+  ... bench.py --gpus N --global-batch 4096                   # STRONG scaling (BASELINE configs[3]): one global batch sharded
+                                                              # over the ranks, result all-gathered inside the timed region
 
-Rank 0 prints ONE JSON line (see the driver contract in the task statement) with two extra objects:
-"roofline" (fused step kernel vs the gfx950 FP32-matrix MFMA peak; duration from HIP events on the engine's
-own stream) and "cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample).
+Default is weak scaling (512 clips per GPU, no data-path collective).  Rank 0 prints ONE JSON line (driver contract) with,
+besides the contract's keys:
+  "roofline"       fused step kernel vs the gfx950 FP32-matrix MFMA peak; duration from HIP events on the engine's own stream
+  "parity_in_run"  two samples of the FIRST TIMED call replayed through the CPU oracle on the restated Philox noise
+  "single_pass"    the guidance-scale-1 workload (uncond pass legitimately skipped), own FLOP count -- never mixed into `value`
+  "livelyspeaker"  BASELINE configs[2] as the reference runs it: SAG decode + ddim100 / skip 80 refine, own roofline
+  "shard_check"    the config-4 premise on hardware: every rank re-generates ANOTHER rank's shard via sample_offset
+  "split_precision", "train_step"   secondary legs
+  "cpu_baseline"   torch-CPU port of the reference algorithm timed on this box's host cores (bounded sample)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,11 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 _RESULT_OUT = sys.stdout        # replaced by a private duplicate of fd 1 when run as a script (_reserve_stdout)
 
-FLOP_PER_SAMPLE_STEP = {"ted": 317_431_808, "beat": 362_496_000}     # BASELINE.md section 3 (CFG: 2 forwards, hoisted form)
+# BASELINE.md section 3 / SURVEY.md 8(d): hoisted form, 2 FLOPs per MAC.  CFG = two forwards per sample per step.
+FLOP_PER_FORWARD = {"ted": 158_715_904, "beat": 181_248_000}
 MFMA_F32_PEAK_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-# HBM bytes per k_step launch from rocprofv3 PMC passes (profiles/r01b_kernel_trace_and_pmc.md): 2*FETCH_SIZE + WRITE_SIZE
-# (KiB -> B, with the guide's gfx950 FETCH_SIZE correction); measured for the default workload only.
-PMC_TRAFFIC_BYTES = {("ted", 512): 218_940_170}      # profiles/r01e_final_kernel_trace_and_pmc.md (PMC section)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "k_step_traffic.json")   # rocprofv3 PMC passes, keyed to the kernel source
 
 
 def parse():
@@ -40,18 +48,22 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dataset", default="ted", choices=["ted", "beat"])
-    ap.add_argument("--batch", type=int, default=512, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="clips per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total clips, sharded over the ranks")
     ap.add_argument("--diffusion-steps", type=int, default=1000)
     ap.add_argument("--respacing", default="", help="'' = DDPM over all steps, 'ddim100' = DDIM")
     ap.add_argument("--skip", type=int, default=0)
     ap.add_argument("--scale", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of the first timed call")
+    ap.add_argument("--parity-samples", type=int, default=2)
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no single-pass / LivelySpeaker / bf16x3 / train legs")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--train-leg", action="store_true", help="also time the training step (default on at 1 GPU; at N>1 it "
-                    "adds the RCCL gradient all-reduce, the build's only collective)")
+                    "adds the RCCL gradient all-reduce, the build's only per-step collective)")
     ap.add_argument("--no-train-leg", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x3_perpass"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32 = exact (headline); bf16x3 = opt-in split-precision channel mixing")
     return ap.parse_args()
 
@@ -63,47 +75,96 @@ def mk_args(cfg, steps):
                            lambda_rcxyz=0.0, lambda_fc=0.0, njoints=cfg.njoints)
 
 
+def pmc_traffic(dataset, B):
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes -- only if they were taken on THIS kernel source
+    (the file stores the hash of ls_step_kernel.h it was measured on); otherwise null rather than a stale constant."""
+    try:
+        rec = json.load(open(PMC_TRAFFIC_FILE))
+        src = open(os.path.join(ROOT, "livelyspeaker_amd", "csrc", "ls_step_kernel.h"), "rb").read()
+        ent = rec["entries"].get(f"{dataset}:{B}")
+        if ent and ent["kernel_source_sha256"] == hashlib.sha256(src).hexdigest():
+            return ent["bytes_per_launch"], ent["source"]
+        return None, f"{os.path.relpath(PMC_TRAFFIC_FILE, ROOT)} has no entry for this kernel source (re-profile)"
+    except Exception as e:
+        return None, f"unavailable: {e!r}"[:120]
+
+
 def cpu_baseline(cfg, args):
-    """CPU oracle (numpy port of the reference algorithm) on a bounded sample, extrapolated linearly in the
-    number of (homogeneous) diffusion steps.  Reported next to the GPU number; it is not the target."""
+    """SURVEY.md 8(d) "CPU baseline timing": the torch-CPU port of the reference algorithm (oracle/rag_torch_cpu.py, pinned to
+    reference-generated fixtures) on this box's host cores.  Steps are homogeneous, so >= 20 hoisted steps at the headline batch
+    are timed (after one warm-up step) and scaled linearly; the reference-faithful mode (audio encoder re-run in both passes of
+    every step, as the reference does) is timed separately; plus one full config-1 loop (B=4, 50-step DDPM).  Reported next to
+    the GPU number; it is a baseline, not the target."""
+    import torch
     from livelyspeaker_amd import synth
     from oracle import rag_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    Bc, n_h, n_f = 64, 12, 2
-    sd = synth.make_state_dict(cfg)
-    oracle = orc.RagOracle(sd, cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
-    sch = orc.Schedule(args.diffusion_steps, args.respacing)
-    y = synth.make_cond(cfg, Bc, scale=args.scale)
-    tape = synth.NoiseTape(cfg, Bc, max(n_h, n_f))
+    from oracle.rag_torch_cpu import TorchCpuSampler
+    threads = torch.get_num_threads()
+    port = TorchCpuSampler(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    B, n_h, n_f = args.batch, 20, 2
     ddim = args.respacing.startswith("ddim")
+    sch = orc.Schedule(args.diffusion_steps, args.respacing)
+    y = port._y(synth.make_cond(cfg, B, scale=args.scale))
+    tape = synth.NoiseTape(cfg, B, n_h + 1)
+    port.sample_loop(sch, y, tape.x_init, tape.eps, tape.noise, ddim=ddim, hoisted=True, max_steps=1)       # warm-up (oneDNN primitives)
     t0 = time.perf_counter()
-    oracle.prepare(y)
+    port.prepare(y)
     t_prep = time.perf_counter() - t0
     t0 = time.perf_counter()
-    orc.sample_loop(oracle, sch, y, tape.x_init, tape.eps, tape.noise, ddim=ddim, hoisted=True, max_steps=n_h)
-    t_h = (time.perf_counter() - t0 - 0.0) / n_h            # includes one more prepare; subtract below
-    t_h = max(t_h - t_prep / n_h, 1e-9)
+    port.sample_loop(sch, y, tape.x_init, tape.eps, tape.noise, ddim=ddim, hoisted=True, max_steps=n_h)
+    t_h = max((time.perf_counter() - t0 - t_prep) / n_h, 1e-9)                                               # the loop re-runs prepare once
+    port.sample_loop(sch, y, tape.x_init, tape.eps, tape.noise, ddim=ddim, hoisted=False, max_steps=1)       # warm-up
     t0 = time.perf_counter()
-    orc.sample_loop(oracle, sch, y, tape.x_init, tape.eps, tape.noise, ddim=ddim, hoisted=False, max_steps=n_f)
+    port.sample_loop(sch, y, tape.x_init, tape.eps, tape.noise, ddim=ddim, hoisted=False, max_steps=n_f)
     t_f = (time.perf_counter() - t0) / n_f
+    c1 = synth.TED if cfg.name == "ted" else cfg
+    sch1 = orc.Schedule(50, "")
+    tape1 = synth.NoiseTape(c1, 4, 50)
+    y1 = port._y(synth.make_cond(c1, 4, scale=1.5))
+    port.sample_loop(sch1, y1, tape1.x_init, tape1.eps, tape1.noise, hoisted=False, max_steps=2)
+    t0 = time.perf_counter()
+    port.sample_loop(sch1, y1, tape1.x_init, tape1.eps, tape1.noise, hoisted=False)
+    t_c1 = time.perf_counter() - t0
     n_exec = sch.num_timesteps - args.skip
-    frames = Bc * cfg.nframes
-    return {"value": round(frames / (t_prep + n_exec * t_h), 3), "unit": "pose-frames/s", "cores": int(cores),
-            "kind": "port",
-            "sample": f"numpy oracle, B={Bc}: 1 prepare + {n_h} hoisted steps ({t_h * 1e3:.1f} ms/step) extrapolated to "
-                      f"{n_exec} steps; reference-faithful mode (audio encoder re-run 2x/step) {n_f} steps "
-                      f"({t_f * 1e3:.1f} ms/step)",
-            "reference_faithful_value": round(frames / (n_exec * t_f), 3)}
+    frames = B * cfg.nframes
+    return {"value": round(frames / (t_prep + n_exec * t_h), 3), "unit": "pose-frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"torch-CPU port (oracle/rag_torch_cpu.py), torch.get_num_threads()={threads}, B={B}: 1 prepare ({t_prep:.2f} s) + "
+                      f"{n_h} hoisted steps ({t_h * 1e3:.0f} ms/step) scaled to {n_exec} steps; reference-faithful mode (audio encoder "
+                      f"re-run 2x/step) {n_f} steps at {t_f * 1e3:.0f} ms/step; full config-1 loop (B=4, 50-step DDPM, faithful) {t_c1:.2f} s. "
+                      f"The REAL reference measured in the build container (8 threads, SURVEY.md [probe]): 6.04 s/step at B=512 = "
+                      f"2.9 pose-frames/s, config 1 in 1.64 s",
+            "hoisted_ms_per_step": round(t_h * 1e3, 1), "reference_faithful_ms_per_step": round(t_f * 1e3, 1),
+            "reference_faithful_value": round(frames / (n_exec * t_f), 3), "config1_loop_s": round(t_c1, 3),
+            "reference_probe_8_threads": {"s_per_step_b512": 6.04, "pose_frames_per_s": 2.9, "config1_loop_s": 1.64}}
+
+
+def parity_in_run(cfg, a, out_first, seed, sample_offset, y_np, n_pick):
+    """Replay `n_pick` samples of the first TIMED call (same Philox seed / global sample indices, every diffusion step) through
+    the CPU oracle fed with the numpy restatement of the device RNG, and return max|hip - oracle| (contract: 1e-3)."""
+    from livelyspeaker_amd import synth
+    from oracle import philox_oracle as po
+    from oracle import rag_oracle as orc
+    B = out_first.shape[0]
+    pick = np.unique(np.linspace(0, B - 1, n_pick).round().astype(int))
+    sch = orc.Schedule(a.diffusion_steps, a.respacing)
+    n_exec = sch.num_timesteps - a.skip
+    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    t0 = time.perf_counter()
+    gidx = sample_offset + pick
+    eps, noise = po.step_tapes(seed, gidx, n_exec, (cfg.njoints, cfg.nfeats, cfg.nframes))
+    x_T = po.x_init(seed, gidx, cfg.jf, cfg.nframes, (cfg.njoints, cfg.nfeats))
+    want = orc.sample_loop(oracle, sch, {k: v[pick] for k, v in y_np.items()}, x_T, eps, noise, ddim=a.respacing.startswith("ddim"),
+                           skip_timesteps=a.skip)
+    d = float(np.abs(out_first[pick].astype(np.float64) - want).max())
+    return {"max_abs_diff": float(f"{d:.3e}"), "tolerance": 3e-4, "contract": 1e-3, "ok": bool(d <= 3e-4),
+            "samples": [int(p) for p in pick], "steps_replayed": n_exec,
+            "what": "first timed call (Philox noise, hipGraph) vs oracle/rag_oracle.py on oracle/philox_oracle.py's restated noise",
+            "oracle_seconds": round(time.perf_counter() - t0, 1)}
 
 
 def train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence):
     """Time TrainLoop.run_step-equivalent work: forward + losses + backward (ls_train_forward_backward), gradient
     all-reduce over the ranks (RCCL, only when world > 1), AdamW.  Batch per GPU = --batch (reference default 512)."""
-    import numpy as np
     import torch
     from livelyspeaker_amd import _lib, synth
     from livelyspeaker_amd.train_loop import allreduce_mean_
@@ -162,9 +223,67 @@ def train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence):
 
 def _train_schedule(a):
     from livelyspeaker_amd.model_util import create_gaussian_diffusion
-    from types import SimpleNamespace
     return create_gaussian_diffusion(SimpleNamespace(diffusion_steps=1000, noise_schedule="cosine", sigma_small=True, lambda_vel=1.0,
                                                      lambda_rcxyz=0.0, lambda_fc=0.0), "")
+
+
+def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3):
+    """BASELINE configs[2] as the reference runs it (scripts/test_LivelySpeaker_ted.py:85-113): SAG decoder on a synthetic CLIP text
+    feature -> init_image -> CFG RAG refine with ddim100, skip_timesteps=80 (20 steps), guidance 2.5.  Own roofline object."""
+    import torch
+    from livelyspeaker_amd import synth
+    from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
+    from livelyspeaker_amd.model_util import create_model_and_diffusion
+    from livelyspeaker_amd.motionclip_module import Decoder_TRANSFORMER
+    model, diffusion = create_model_and_diffusion(mk_args(cfg, 1000), "ddim100", dataset="ted")
+    model.load_state_dict(model_sd, strict=False)
+    model.to(dev)
+    model.eval()
+    model.cache_conditioning = False
+    cfgm = ClassifierFreeSampleModel(model)
+    diffusion.noise_source = "philox"
+    sag = Decoder_TRANSFORMER(latent_dim=512, n_pre_poses=4, use_style=False)
+    sag.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_sag_state_dict(cfg).items()}, strict=False)
+    sag.to(dev)
+    sag.eval()
+    y_np = synth.make_cond(cfg, B, scale=2.5)
+    y = {k: torch.from_numpy(v).to(dev) for k, v in y_np.items()}
+    batch = {"x": y["origin_x"].clone(), "mask": torch.ones(B, 34, device=dev).bool(),
+             "z": torch.from_numpy(synth.make_text_features(B)).to(dev)}
+
+    def call():
+        decoded = sag(batch)["output"]
+        return diffusion.ddim_sample_loop(cfgm, (B, cfg.njoints, cfg.nfeats, cfg.nframes), clip_denoised=False, model_kwargs={"y": y},
+                                          skip_timesteps=80, init_image=decoded, progress=False, dump_steps=None, noise=None,
+                                          const_noise=False)
+    call()
+    eng, seng = model.engine(), sag.engine()
+    fence()
+    t0 = time.perf_counter()
+    loop_ms = prep_ms = 0.0
+    launches = 0
+    for _ in range(reps):
+        out = call()
+        tm = eng.timing()
+        loop_ms += tm["loop_ms"]
+        prep_ms += tm["prepare_ms"]
+        launches += tm["n_step_launches"]
+    fence()
+    el = (time.perf_counter() - t0) / reps
+    assert bool(torch.isfinite(out).all())
+    kernel_ms = loop_ms / max(launches, 1)
+    ach = 2 * FLOP_PER_FORWARD["ted"] * B / (kernel_ms * 1e-3) / 1e12
+    sag_ms = getattr(seng, "last_decode_ms", lambda: None)()
+    return {"workload": f"TED LivelySpeaker: SAG decode (synthetic CLIP text feature) + CFG RAG refine, ddim100 with skip_timesteps=80 "
+                        f"(20 DDIM steps, what scripts/test_LivelySpeaker_ted.py runs), batch {B}, guidance 2.5, Philox noise",
+            "value": round(B * cfg.nframes / el, 1), "unit": "pose-frames/s", "ms_per_call": round(el * 1e3, 3),
+            "sag_decode_ms": None if sag_ms is None else round(sag_ms, 3), "prepare_ms": round(prep_ms / reps, 3),
+            "refine_loop_ms": round(loop_ms / reps, 3), "denoise_steps": 20,
+            "full_100_steps_note": "BASELINE words it as '100 DDIM steps'; `--respacing ddim100` runs that variant as the headline workload",
+            "roofline": {"bound": "mfma", "kernel": "ls::k_step", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(kernel_ms, 4),
+                         "call_frac": round((2 * FLOP_PER_FORWARD["ted"] * B * 20 / 1e12 / MFMA_F32_PEAK_TFLOPS) / (el * 1e3) * 1e3, 4),
+                         "call_frac_note": "k_step FLOPs of the 20 steps at the MFMA peak / whole-call wall time (SAG + prepare + loop + host)"}}
 
 
 def main():
@@ -173,7 +292,7 @@ def main():
     _RESULT_OUT = _reserve_stdout()
     import torch
     import torch.distributed as dist
-    from livelyspeaker_amd import synth
+    from livelyspeaker_amd import shard, synth
     from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
     from livelyspeaker_amd.model_util import create_model_and_diffusion
 
@@ -192,13 +311,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = synth.CONFIGS[a.dataset]
-    B = a.batch
+    strong = a.global_batch > 0
+    if strong:
+        first, B = shard.shard_range(a.global_batch, world, rank)
+        if a.global_batch % world:
+            raise SystemExit("--global-batch must be divisible by the number of ranks")
+    else:
+        first, B = rank * a.batch, a.batch
+    total = a.global_batch if strong else world * B
     model, diffusion = create_model_and_diffusion(mk_args(cfg, a.diffusion_steps), a.respacing, dataset=a.dataset)
     # random-init weights of the architecture, re-drawn with non-degenerate scale (the reference's own init
     # zeroes the channel-mix weights); rank 0's copy is broadcast over RCCL so all ranks agree.
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=synth.SEED_WEIGHTS + (0 if rank == 0 else 1)).items()}
     if use_dist:
-        from livelyspeaker_amd import shard
         sd = shard.broadcast_state_dict(sd, dev)
     model.load_state_dict(sd, strict=False)
     model.to(dev)
@@ -208,113 +333,197 @@ def main():
     cfgm = ClassifierFreeSampleModel(model)
     diffusion.noise_source = "philox"
     diffusion.use_graph = not a.no_graph
-    diffusion.sample_offset = rank * B      # Philox streams keyed by the global sample index (shard-invariant)
+    diffusion.sample_offset = first         # Philox streams keyed by the global sample index (shard-invariant)
 
-    y_np = synth.make_cond(cfg, B, scale=a.scale, seed=synth.SEED_COND + rank)
+    # conditioning of the global batch = concatenation of per-shard draws (seed = SEED_COND + shard index), so any rank can
+    # rebuild any shard; shard r of the strong-scaling run IS the batch rank r of the weak-scaling run would hold
+    def cond_of(shard_index, scale):
+        return synth.make_cond(cfg, B, scale=scale, seed=synth.SEED_COND + shard_index)
+
+    y_np = cond_of(rank, a.scale)
     y = {k: torch.from_numpy(v).to(dev) for k, v in y_np.items()}
     shape = (B, cfg.njoints, cfg.nfeats, cfg.nframes)
     ddim = a.respacing.startswith("ddim")
     fn = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
 
-    def one_call():
-        return fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=a.skip, init_image=None,
-                  progress=False, dump_steps=None, noise=None, const_noise=False)
+    def one_call(yy=None):
+        local_out = fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": yy or y}, skip_timesteps=a.skip, init_image=None,
+                       progress=False, dump_steps=None, noise=None, const_noise=False)
+        if strong:
+            return local_out, shard.gather_samples(local_out, total)       # all_gather_into_tensor over RCCL, inside the timed region
+        return local_out, None
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.manual_seed(233)
-    out = None
+    def timed(n, yy=None):
+        """n calls bracketed by barrier + synchronize; max over ranks.  Returns (elapsed, loop_ms, launches, prep_ms, first_out, seed)."""
+        loop_ms, launches, prep_ms, first_out, seed, gathered = 0.0, 0, 0.0, None, None, None
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n):
+            out, gathered = one_call(yy)
+            tm = eng.timing()
+            loop_ms += tm["loop_ms"]
+            launches += tm["n_step_launches"]
+            prep_ms += tm["prepare_ms"]
+            if i == 0:
+                first_out, seed = out, diffusion.last_philox_seed
+        fence()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, loop_ms, launches, prep_ms, first_out, seed, gathered
+
+    torch.manual_seed(233)                  # every rank draws the same Philox key per call
     for _ in range(a.warmup):
-        out = one_call()
+        one_call()
     eng = model.engine()
-    loop_ms, launches, prep_ms = 0.0, 0, 0.0
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = one_call()
-        tm = eng.timing()
-        loop_ms += tm["loop_ms"]
-        launches += tm["n_step_launches"]
-        prep_ms += tm["prepare_ms"]
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert out is not None and bool(torch.isfinite(out).all()), "non-finite samples"
+    elapsed, loop_ms, launches, prep_ms, first_out, first_seed, gathered = timed(a.steps)
+    assert first_out is not None and bool(torch.isfinite(first_out).all()), "non-finite samples"
+    single_pass_main = bool(eng.timing()["single_pass"])
+
+    # the config-4 premise, on hardware: rank r re-generates the shard of rank (r+1) % world on ITS OWN GPU from the same Philox key
+    # with sample_offset, and compares it with what that rank produced (strong mode: the gathered tensor; weak mode: a P2P-free
+    # all_gather of the per-rank results).  Bitwise equality expected: the streams depend on the global index only.
+    shard_check = None
+    if use_dist or strong:
+        nb = (rank + 1) % world
+        nb_first = shard.shard_range(total, world, nb)[0] if strong else nb * B
+        mine = first_out
+        allr = shard.gather_samples(mine, world * B) if not strong else None
+        y_nb = {k: torch.from_numpy(v).to(dev) for k, v in cond_of(nb, a.scale).items()}
+        diffusion.sample_offset, diffusion.philox_seed = nb_first, first_seed
+        redo = fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": y_nb}, skip_timesteps=a.skip, init_image=None, progress=False,
+                  dump_steps=None, noise=None, const_noise=False)
+        diffusion.sample_offset, diffusion.philox_seed = first, None
+        if strong:      # `gathered` is the last timed call's; re-run the first call's seed for a like-for-like global tensor
+            diffusion.philox_seed = first_seed
+            ref_global = shard.gather_samples(fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=a.skip,
+                                                 init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False), total)
+            diffusion.philox_seed = None
+        else:
+            ref_global = allr
+        theirs = ref_global[nb * B:(nb + 1) * B]
+        stats = torch.stack([(redo - theirs).abs().max().double(), redo.double().abs().sum(), theirs.double().abs().sum()])
+        mx = stats[:1].clone()
+        sums = stats[1:].clone()
+        if use_dist:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        shard_check = {"rccl_ranks": dist.get_world_size() if use_dist else 1,
+                       "what": "every rank re-generated the NEXT rank's shard on its own GPU via sample_offset (same Philox key, that "
+                               "shard's conditioning) and compared it with what that rank produced",
+                       "max_abs_diff": float(mx.item()), "bitwise_equal": bool(mx.item() == 0.0),
+                       "checksum_recomputed": float(sums[0].item()), "checksum_sharded": float(sums[1].item())}
+
+    extra = not a.no_extra_legs and a.precision == "fp32"
+
+    # Secondary object: guidance scale 1 (what the reference's callers run): the uncond pass is legitimately skipped
+    single = None
+    if extra and a.scale != 1.0:
+        y1 = dict(y, scale=torch.ones(B, device=dev))
+        one_call(y1)
+        n1 = max(1, min(a.steps, 2))
+        e1, l1, k1, _, o1, _, _ = timed(n1, y1)
+        assert bool(eng.timing()["single_pass"]) and bool(torch.isfinite(o1).all())
+        km = l1 / max(k1, 1)
+        ach1 = FLOP_PER_FORWARD[a.dataset] * B / (km * 1e-3) / 1e12
+        single = {"workload": "same as the headline but guidance scale 1.0 (scripts/test_RAG_ted.py:183): out_u + 1*(out_c - out_u) = out_c, "
+                              "so ONE forward per sample per step (two samples per workgroup); never mixed into `value`",
+                  "value": round(total * cfg.nframes * n1 / e1, 2), "unit": "pose-frames/s", "ms_per_call": round(e1 / n1 * 1e3, 3),
+                  "flop_per_sample_step": FLOP_PER_FORWARD[a.dataset],
+                  "roofline": {"bound": "mfma", "achieved": round(ach1, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach1 / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(km, 4)},
+                  "parity": "reference fixture G11 (scale 1, both passes evaluated by the reference) <= 3e-4, tests/test_gpu_singlepass.py"}
 
     # Secondary leg (never the headline `value`): the opt-in bf16x3 split-precision mode, same workload, same run.
     split = None
-    if a.precision == "fp32" and not a.no_split_leg:
+    if extra and not a.no_split_leg:
         model.precision = "bf16x3"
         one_call()
-        fence()
-        t1 = time.perf_counter()
         n2 = max(1, min(a.steps, 2))
-        l2, k2 = 0.0, 0
-        for _ in range(n2):
-            one_call()
-            tm = eng.timing()
-            l2 += tm["loop_ms"]
-            k2 += tm["n_step_launches"]
-        fence()
-        e2 = time.perf_counter() - t1
-        if use_dist:
-            t = torch.tensor([e2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
+        e2, l2, k2, _, _, _, _ = timed(n2)
         split = {"mode": "bf16x3: channel/token mixing as 3 bf16 MFMAs per fp32 product (hi.hi+hi.lo+lo.hi), fp32 accumulate",
-                 "value": round(world * B * cfg.nframes * n2 / e2, 2), "unit": "pose-frames/s",
+                 "value": round(total * cfg.nframes * n2 / e2, 2), "unit": "pose-frames/s",
                  "kernel_ms": round(l2 / max(k2, 1), 4),
                  "parity": "max-abs vs reference golden after 1000 DDPM steps 3.5e-5 (contract 1e-3), tests/test_gpu_edge.py",
                  "note": "opt-in (RAG.precision / ls_set_precision); the headline value above is the exact-fp32 path"}
         model.precision = "fp32"
 
+    lively = None
+    if extra and a.dataset == "ted" and world == 1:
+        try:
+            lively = livelyspeaker_leg(cfg, sd, dev, B, fence)
+        except Exception as e:                      # never let a secondary leg take the headline line down
+            lively = {"error": repr(e)[:300]}
+
     # Secondary leg: one optimisation step of the denoiser (SURVEY.md section 8 f-3), data-parallel over the ranks.
     train = None
-    if (a.train_leg or world == 1) and not a.no_train_leg and a.precision == "fp32":
+    if extra and (a.train_leg or world == 1) and not a.no_train_leg and not strong:
         try:
             train = train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence)
-        except Exception as e:                      # never let the secondary leg take the headline line down
+        except Exception as e:
             train = {"error": repr(e)[:300]}
 
     if rank == 0:
-        frames = world * B * cfg.nframes * a.steps
+        frames = total * cfg.nframes * a.steps
         n_exec = diffusion.num_timesteps - a.skip
         kernel_ms = loop_ms / max(launches, 1)
-        achieved = FLOP_PER_SAMPLE_STEP[a.dataset] * B / (kernel_ms * 1e-3) / 1e12
+        passes = 1 if single_pass_main else 2
+        flop_launch = passes * FLOP_PER_FORWARD[a.dataset] * B
+        achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
         # fp32: FP32-matrix MFMA peak.  bf16x3: three bf16 MFMAs per algorithmic product -> dense bf16 peak / 3.
         peak = MFMA_F32_PEAK_TFLOPS if a.precision == "fp32" else round(2500.0 / 3.0, 1)
+        traffic, traffic_src = pmc_traffic(a.dataset, B)
         rec = {
             "metric": "pose-frames/sec denoised", "value": round(frames / elapsed, 2), "unit": "pose-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "fp32" else "bf16x3 split (fp32 accumulate) for channel mixing, f32 elsewhere",
             "data": "synthetic",
             "config": {"workload": f"{a.dataset.upper()} RAG, batch {B} x {cfg.nframes} frames per GPU, "
                                    f"{n_exec}-step {'DDIM' if ddim else 'DDPM'} ({a.diffusion_steps} diffusion steps"
-                                   f"{', respacing ' + a.respacing if a.respacing else ''}), CFG scale {a.scale}, "
+                                   f"{', respacing ' + a.respacing if a.respacing else ''}), CFG scale {a.scale}"
+                                   f"{' (single pass: every scale is 1)' if single_pass_main else ''}, "
                                    f"random-init weights + synthetic audio/speaker/prefix-pose conditioning, Philox noise on device",
-                       "global_batch": world * B, "frames": cfg.nframes, "denoise_steps": n_exec,
-                       "guidance_scale": a.scale, "parallelism": f"batch-sharded x{world}, no per-step collective",
+                       "global_batch": total, "frames": cfg.nframes, "denoise_steps": n_exec,
+                       "guidance_scale": a.scale,
+                       "parallelism": (f"global batch {total} sharded x{world}, all_gather of the result in the timed region" if strong
+                                       else f"batch-sharded x{world}, no per-step collective"),
                        "hipgraph": bool(diffusion.use_graph)},
             "roofline": {"bound": "mfma", "kernel": "ls::k_step (fused CFG denoiser + sampler update, 1 launch/step)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         "traffic": PMC_TRAFFIC_BYTES.get((a.dataset, B)), "traffic_unit": "B/launch (rocprofv3 PMC, profiles/)",
-                         "kernel_ms": round(kernel_ms, 4), "flop_per_launch": FLOP_PER_SAMPLE_STEP[a.dataset] * B,
+                         "traffic": traffic, "traffic_unit": "B/launch (rocprofv3 PMC)", "traffic_source": traffic_src,
+                         "kernel_ms": round(kernel_ms, 4), "flop_per_launch": flop_launch,
                          "prepare_ms_per_call": round(prep_ms / a.steps, 3)},
         }
+        if shard_check is not None:
+            rec["shard_check"] = shard_check
+            rec["rccl_ranks"] = shard_check["rccl_ranks"]
+        if not a.no_parity:
+            try:
+                rec["parity_in_run"] = parity_in_run(cfg, a, first_out.detach().cpu().numpy(), first_seed, first, y_np, a.parity_samples)
+            except Exception as e:
+                rec["parity_in_run"] = {"error": repr(e)[:300]}
+        if single is not None:
+            rec["single_pass"] = single
+        if lively is not None:
+            rec["livelyspeaker"] = lively
         if split is not None:
             rec["split_precision"] = split
         if train is not None:
             rec["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(cfg, a)
+            try:
+                rec["cpu_baseline"] = cpu_baseline(cfg, a)
+            except Exception as e:
+                rec["cpu_baseline"] = {"error": repr(e)[:300]}
         _RESULT_OUT.write(json.dumps(rec) + "\n")
         _RESULT_OUT.flush()
     if use_dist:

@@ -42,8 +42,7 @@ enum { LS_NOISE_TAPE = 0, LS_NOISE_PHILOX = 1 };
 /* Arithmetic of the channel-mixing GEMM (92 % of the FLOPs). FP32 (default): v_mfma_f32_16x16x4_f32, exact fp32
  * products.  BF16X3 (opt-in): each fp32 operand split into bf16 hi+lo, three v_mfma_f32_16x16x32_bf16 per product
  * (hi.hi + hi.lo + lo.hi, fp32 accumulate): ~2^-16 relative product error, parity-gated at the 1e-3 contract. */
-enum { LS_PRECISION_FP32 = 0, LS_PRECISION_BF16X3 = 1,
-       LS_PRECISION_BF16X3_PERPASS = 2 /* same arithmetic, one workgroup per CFG pass; slower, kept as A/B reference */ };
+enum { LS_PRECISION_FP32 = 0, LS_PRECISION_BF16X3 = 1 };
 
 typedef struct ls_handle ls_handle;
 
@@ -90,7 +89,8 @@ typedef struct ls_cond {
     const float* audio_input;   /* [B, audio_len]                                  */
     const float* origin_x;      /* [B, J, F, T]; frames >= n_pre_seq are ignored   */
     const int64_t* vid_indices; /* [B] < n_speakers                                */
-    const int64_t* emo;         /* [B] emotion id of frame 0, or NULL (TED)        */
+    const int64_t* emo;         /* [B, T] emotion ids as the callers hold y['emo'] (frame 0 is read,
+                                   scripts_beat/model/RAG.py:125), or NULL (TED); same shape as ls_train_batch.emo */
     const float* scale;         /* [B] guidance scale (cfg_sampler.py:31)          */
 } ls_cond;
 
@@ -103,7 +103,8 @@ typedef struct ls_sample_args {
     int32_t on_device;
     int32_t use_graph;          /* 1: capture the step loop in a hipGraph and replay */
     int32_t clip_denoised;      /* clamp pred_xstart to [-1,1] (callers pass False)  */
-    int32_t reserved;
+    int32_t two_pass_always;    /* 0: when every scale == 1 the uncond pass is skipped (out_u + 1*(out_c - out_u) = out_c,
+                                   cfg_sampler.py:31; the callers run guidance_param = 1); 1: always evaluate both passes */
     float eta;                  /* DDIM eta (callers never pass it: 0)              */
     int32_t n_dump;             /* dump_steps (DDPM only, :660-671)                 */
     const int32_t* dump_steps;  /* executed-step counters (0 = first executed step), host memory */
@@ -139,7 +140,7 @@ typedef struct ls_step_args {
     int32_t on_device;
     float eta;
     int32_t clip_denoised;
-    int32_t reserved;
+    int32_t two_pass_always;    /* as in ls_sample_args                             */
     const float* x;             /* [B,J,F,T]                                        */
     const float* eps_cond;
     const float* eps_uncond;
@@ -154,6 +155,7 @@ typedef struct ls_timing {
     float total_ms;             /* last ls_sample incl. layout conversion and copies */
     int32_t n_step_launches;
     int32_t graph_replayed;     /* 1 if the loop ran as a hipGraph replay           */
+    int32_t single_pass;        /* 1 if the loop ran the single-pass (scale == 1) kernel */
 } ls_timing;
 
 int ls_abi_version(void);

@@ -43,7 +43,7 @@ class LsCond(C.Structure):
 class LsSampleArgs(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("noise_mode", C.c_int32), ("skip_timesteps", C.c_int32),
                 ("const_noise", C.c_int32), ("on_device", C.c_int32), ("use_graph", C.c_int32),
-                ("clip_denoised", C.c_int32), ("reserved", C.c_int32), ("eta", C.c_float), ("n_dump", C.c_int32), ("dump_steps", c_i32p), ("dump_out", C.c_void_p),
+                ("clip_denoised", C.c_int32), ("two_pass_always", C.c_int32), ("eta", C.c_float), ("n_dump", C.c_int32), ("dump_steps", c_i32p), ("dump_out", C.c_void_p),
                 ("x_init", C.c_void_p), ("init_image", C.c_void_p), ("eps_tape", C.c_void_p),
                 ("noise_tape", C.c_void_p), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
                 ("out", C.c_void_p)]
@@ -57,7 +57,7 @@ class LsForwardArgs(C.Structure):
 
 class LsStepArgs(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("index", C.c_int32), ("on_device", C.c_int32), ("eta", C.c_float),
-                ("clip_denoised", C.c_int32), ("reserved", C.c_int32), ("x", C.c_void_p), ("eps_cond", C.c_void_p), ("eps_uncond", C.c_void_p), ("noise", C.c_void_p),
+                ("clip_denoised", C.c_int32), ("two_pass_always", C.c_int32), ("x", C.c_void_p), ("eps_cond", C.c_void_p), ("eps_uncond", C.c_void_p), ("noise", C.c_void_p),
                 ("sample", C.c_void_p), ("pred_xstart", C.c_void_p)]
 
 
@@ -75,7 +75,7 @@ class LsPostConfig(C.Structure):
 
 class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32)]
+                ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32), ("single_pass", C.c_int32)]
 
 
 class LsTrainConfig(C.Structure):
@@ -113,8 +113,20 @@ class EngineError(RuntimeError):
     pass
 
 
+_lib_override = None
+
+
+def use_library(path: str) -> None:
+    """Developer tooling only (tools/ab_variants.py, tools/phase_profile.py): bind an alternative build of the library.
+    Must be called, in code, before the first engine is created; no environment variable selects the binary."""
+    global _lib_override
+    if _lib is not None:
+        raise EngineError("use_library() must be called before the library is loaded")
+    _lib_override = os.path.abspath(path)
+
+
 def library_path() -> str:
-    return os.environ.get("LS_LIB", _build.LIB)     # LS_LIB: A/B-test an alternative build (tools/ab_variants.py)
+    return _lib_override or _build.LIB
 
 
 def load_library(build_if_missing: bool = True):
@@ -130,7 +142,7 @@ def load_library(build_if_missing: bool = True):
     except Exception:
         pass
     path = library_path()
-    if build_if_missing and "LS_LIB" not in os.environ and _build.is_stale():
+    if build_if_missing and _lib_override is None and _build.is_stale():
         try:
             _build.build_library()
         except Exception as e:      # no hipcc on this box: fall through to whatever .so travelled here
@@ -221,7 +233,6 @@ class _Marshal:
             import torch
             self.torch = torch
             self.dev = torch.device("cuda", device_index)
-            torch.cuda.current_stream(self.dev).synchronize()   # inputs were produced on torch's stream
 
     def f32(self, a, shape=None):
         return self._conv(a, np.float32, shape)
@@ -246,6 +257,13 @@ class _Marshal:
             assert tuple(n.shape) == tuple(shape), (n.shape, tuple(shape))
         self.keep.append(n)
         return n.ctypes.data_as(C.c_void_p)
+
+    def ready(self):
+        """Call right before the ABI call.  The engine's streams are non-blocking (nothing orders them against torch's), and the
+        inputs -- as well as the dtype / contiguity conversions `_conv` may have just enqueued (e.g. the strided `emo[:, 0]` of
+        the BEAT callers) -- were produced on torch's current stream: finish that stream first."""
+        if self.on_device:
+            self.torch.cuda.current_stream(self.dev).synchronize()
 
     def out(self, shape):
         """(object, pointer) for an fp32 output of this call."""
@@ -302,7 +320,7 @@ class Engine:
 
     def set_precision(self, mode):
         """'fp32' (exact, default) or 'bf16x3' (split-precision channel mixing on the bf16 matrix cores)."""
-        code = {"fp32": 0, "bf16x3": 1, "bf16x3_perpass": 2}.get(mode, mode)
+        code = {"fp32": 0, "bf16x3": 1}.get(mode, mode)
         self._check(self.lib.ls_set_precision(self.h, int(code)), "ls_set_precision")
         self.precision = mode
 
@@ -330,13 +348,14 @@ class Engine:
     # ---- per call --------------------------------------------------------------------------------
     def prepare(self, y: dict):
         emo = y.get("emo") if self.cfg.n_prefix_tokens == 2 else None
-        if emo is not None and getattr(emo, "ndim", 1) == 2:
-            emo = emo[:, 0]                                    # y['emo'][:,0], scripts_beat/model/RAG.py:125
+        if emo is not None and getattr(emo, "ndim", 2) == 1:   # a bare [B] id vector: broadcast to the callers' [B, T] form
+            emo = emo[:, None].repeat(1, self.T) if hasattr(emo, "repeat") and not isinstance(emo, np.ndarray) else np.repeat(np.asarray(emo)[:, None], self.T, 1)
         m = _Marshal(self.device, y["audio_input"], y["origin_x"], y["vid_indices"], y["scale"], emo)
         B = int(y["audio_input"].shape[0])
         c = LsCond(B, int(m.on_device), m.f32(y["audio_input"], (B, self.cfg.audio_len)),
                    m.f32(y["origin_x"], (B, self.J, self.F, self.T)), m.i64(y["vid_indices"], (B,)),
-                   m.i64(emo, (B,)), m.f32(y["scale"], (B,)))
+                   m.i64(emo, (B, self.T)), m.f32(y["scale"], (B,)))
+        m.ready()
         self._check(self.lib.ls_prepare(self.h, C.byref(c)), "ls_prepare")
         self.batch = B
 
@@ -354,22 +373,24 @@ class Engine:
         tr, ptr = m.out((B, self.layers + 1, 2 * self.S, D)) if trace else (None, None)
         a = LsForwardArgs(int(m.on_device), 0, m.f32(x, self._xshape()), m.i64(t, (B,)), m.f32(eps_c, (B, D)),
                           m.f32(eps_u, (B, D)), poc, pou, pog, ptr)
+        m.ready()
         self._check(self.lib.ls_forward(self.h, C.byref(a)), "ls_forward")
         return (oc, ou, og, tr) if trace else (oc, ou, og)
 
-    def step(self, sampler, index, x, eps_c, eps_u, noise, eta=0.0, clip_denoised=False):
+    def step(self, sampler, index, x, eps_c, eps_u, noise, eta=0.0, clip_denoised=False, two_pass_always=False):
         m = _Marshal(self.device, x, eps_c, eps_u, noise)
         B, D = self.batch, self.D
         out, pout = m.out(self._xshape())
         x0, px0 = m.out(self._xshape())
-        a = LsStepArgs(sampler, index, int(m.on_device), eta, int(clip_denoised), 0, m.f32(x, self._xshape()),
+        a = LsStepArgs(sampler, index, int(m.on_device), eta, int(clip_denoised), int(two_pass_always), m.f32(x, self._xshape()),
                        m.f32(eps_c.reshape(B, D)), m.f32(eps_u.reshape(B, D)), m.f32(noise, self._xshape()), pout, px0)
+        m.ready()
         self._check(self.lib.ls_step(self.h, C.byref(a)), "ls_step")
         return out, x0
 
     def sample(self, sampler=LS_SAMPLER_DDPM, x_init=None, eps_tape=None, noise_tape=None, init_image=None,
                skip_timesteps=0, eta=0.0, const_noise=False, dump_steps=None, philox_seed=None, sample_offset=0,
-               use_graph=True, clip_denoised=False, device_out=False):
+               use_graph=True, clip_denoised=False, device_out=False, two_pass_always=False):
         """Run the whole loop. TAPE mode when tapes are given, PHILOX mode when ``philox_seed`` is.
         Outputs are torch CUDA tensors if any input is one (or ``device_out``), else numpy."""
         members = [x_init, eps_tape, noise_tape, init_image]
@@ -380,6 +401,7 @@ class Engine:
         a = LsSampleArgs()
         a.sampler, a.skip_timesteps, a.const_noise, a.on_device = sampler, skip_timesteps, int(const_noise), int(m.on_device)
         a.use_graph, a.eta, a.clip_denoised = int(use_graph), eta, int(clip_denoised)
+        a.two_pass_always = int(two_pass_always)
         n_exec = self.n_steps - skip_timesteps
         if philox_seed is None:
             a.noise_mode = LS_NOISE_TAPE
@@ -397,6 +419,7 @@ class Engine:
             dumps, a.dump_out = m.out((len(ds),) + self._xshape())
             a.n_dump, a.dump_steps = len(ds), ds.ctypes.data_as(c_i32p)
             m.keep.append(ds)
+        m.ready()
         self._check(self.lib.ls_sample(self.h, C.byref(a)), "ls_sample")
         return (out, dumps) if dump_steps else out
 
@@ -404,6 +427,7 @@ class Engine:
         m = _Marshal(self.device, x_start, noise)
         out, pout = m.out(tuple(x_start.shape))
         n = int(np.prod(x_start.shape))
+        m.ready()
         self._check(self.lib.ls_q_sample(self.h, index, int(m.on_device), n, m.f32(x_start), m.f32(noise), pout), "ls_q_sample")
         return out
 
@@ -477,6 +501,7 @@ class SagEngine:
                 a = np.ascontiguousarray(a, dtype=np.uint8)
                 m.keep.append(a)
                 pmask = a.ctypes.data_as(C.c_void_p)
+        m.ready()
         self._check(self.lib.ls_sag_decode(self.h, B, int(m.on_device), m.f32(x, (B, self.J, self.F, self.T)),
                                            m.f32(z, (B, self.D)), pmask, pout), "ls_sag_decode")
         return out
@@ -560,6 +585,7 @@ class Trainer:
                           m.f32(y["audio_input"]), m.f32(y["origin_x"], xs), m.i64(y["vid_indices"], (B,)),
                           m.i64(y["emo"], (B, self.T)) if self.n_prefix == 2 else None)
         terms = LsTrainTerms()
+        m.ready()
         torch.cuda.current_stream(self.grad.device).synchronize()
         self._check(self.lib.ls_train_forward_backward(self.h, C.byref(tb), C.c_void_p(self.grad.data_ptr()), C.byref(terms)),
                     "ls_train_forward_backward")
@@ -635,5 +661,6 @@ class EvalEngine:
         m = _Marshal(self.device, poses)
         B = int(poses.shape[0])
         out, pout = m.out((B, self.base))
+        m.ready()
         self._check(self.lib.ls_eval_features(self.h, B, int(m.on_device), m.f32(poses, (B, self.T, self.pose_dim)), pout), "ls_eval_features")
         return out

@@ -70,7 +70,6 @@ struct ls_handle {
 
     // device weights
     DevBuf wch_hi_img, wch_lo_img, ww_hi_img, ww_lo_img;
-    DevBuf winx_seq_img, wch_seq_hi_img, wch_seq_lo_img, ww_seq_hi_img, ww_seq_lo_img, btok_seq, wout_hi_img, wout_lo_img, out_raw;
     DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
     DevBuf conv_img[4];     // MFMA operand images of the stride-6 conv layers (ls_conv.hip)
     DevBuf conv_w[4], conv_b[4], win_full, win_pad, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
@@ -88,6 +87,7 @@ struct ls_handle {
     // per-call state
     int B = 0;              // prepared batch
     bool prepared = false;
+    bool all_scale_one = false;   // every y['scale'] == 1: the CFG combination equals the cond output -> single-pass kernel
     DevBuf audio, origin_x, vid, emo, scale;
     DevBuf c1, c2, c3, c4, st1, st2, st3, feat_c, feat_u, static_c, static_u, z, z_mu, z_logvar, z_std, emo_tok;
     DevBuf audio_feat, spart;
@@ -101,16 +101,18 @@ struct ls_handle {
 
     ls_timing timing{};
     CallParams call_host{0, 0};
+    int precision = 0;      // 0 exact fp32 MFMA, 1 bf16x3 split-precision channel mixing (ls_set_precision)
+#ifdef LS_DEBUG             // profiling variant of the library only (build_library(defines=['LS_DEBUG'])); never in the shipped .so
     DevBuf prof;
     bool prof_on = false;   // LS_PROF=<workgroup index>: in-kernel s_memtime phase stamps, read with ls_read("prof")
     int prof_wg = 0;
-    int precision = 0;      // 0 exact fp32 MFMA, 1 bf16x3 split-precision channel mixing (ls_set_precision)
-    int ablate = 0;         // LS_ABLATE (profiling only; results are wrong when non-zero)
+    int ablate = 0;         // LS_ABLATE (results are wrong when non-zero)
+#endif
 };
 
 namespace {
 
-hipError_t run_step(ls_handle* h, StepArgs& s, int B, hipStream_t st);
+hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st);
 
 int fail(ls_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -175,8 +177,6 @@ int build_images(ls_handle* h) {
         l2a((size_t)L * D), l2b((size_t)L * D), ww((size_t)L * kNT * MK * 64), bt((size_t)L * 80, 0.f);
     std::vector<unsigned short> wch_hi((size_t)L * D * D), wch_lo((size_t)L * D * D);
     const int KS = (R + 31) / 32;
-    std::vector<unsigned short> wcs_hi((size_t)L * D * D), wcs_lo((size_t)L * D * D), wws_hi((size_t)L * 3 * 2 * 64 * 8), wws_lo((size_t)L * 3 * 2 * 64 * 8);
-    std::vector<float> bts((size_t)L * 48, 0.f);
     std::vector<unsigned short> wwh((size_t)L * kNT * KS * 64 * 8), wwl((size_t)L * kNT * KS * 64 * 8);
     char key[160];
     for (int l = 0; l < L; ++l) {
@@ -219,34 +219,6 @@ int build_images(ls_handle* h) {
                                     wch_lo[oh] = f32_to_bf16(v - bf16_to_f32(hi));
                                     ++oh;
                                 }
-        }
-        {   // per-pass variant: [l][w4][p][q16][c4][lane][8],  n = 128w + 16(4p+c) + (lane&15)
-            size_t oh = (size_t)l * D * D;
-            for (int w = 0; w < 4; ++w)
-                for (int p = 0; p < 2; ++p)
-                    for (int q = 0; q < 16; ++q)
-                        for (int c = 0; c < 4; ++c)
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int e = 0; e < 8; ++e) {
-                                    const int n = 128 * w + 16 * (4 * p + c) + (lane & 15);
-                                    const int k = 32 * q + 8 * (lane >> 4) + e;
-                                    const float v = (*W)[(size_t)n * D + k] * (*a2)[k];
-                                    const unsigned short hi = f32_to_bf16(v);
-                                    wcs_hi[oh] = hi;
-                                    wcs_lo[oh] = f32_to_bf16(v - bf16_to_f32(hi));
-                                    ++oh;
-                                }
-            for (int t = 0; t < 3; ++t)
-                for (int ks = 0; ks < 2; ++ks)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 8; ++e) {
-                            const int r = 16 * t + (lane & 15), rp = 32 * ks + 8 * (lane >> 4) + e;
-                            const float v = (r < S && rp < S) ? (*Wt)[(size_t)r * S + rp] : 0.f;
-                            const size_t o = ((((size_t)l * 3 + t) * 2 + ks) * 64 + lane) * 8 + e;
-                            wws_hi[o] = f32_to_bf16(v);
-                            wws_lo[o] = f32_to_bf16(v - bf16_to_f32(wws_hi[o]));
-                        }
-            for (int r = 0; r < S; ++r) bts[(size_t)l * 48 + r] = (*b1)[r];
         }
         for (int n = 0; n < D; ++n) {                                                    // b' = b + W . beta2
             double acc = (*b2)[n];
@@ -309,34 +281,6 @@ int build_images(ls_handle* h) {
                     }
         for (int c = 0; c < JF; ++c) bout[c] = (*bo)[c];
     }
-    // per-pass variant: x_t columns of input_mapping [w4][h][q][c4][lane][4] and poseFinal as bf16 hi/lo [ob][q16][lane][8]
-    std::vector<float> winxs((size_t)4 * 2 * KXQ * 4 * 64 * 4);
-    std::vector<unsigned short> wo_hi((size_t)NOB * 16 * 64 * 8), wo_lo((size_t)NOB * 16 * 64 * 8);
-    {
-        size_t o = 0;
-        for (int w = 0; w < 4; ++w)
-            for (int hh = 0; hh < 2; ++hh)
-                for (int q = 0; q < KXQ; ++q)
-                    for (int c = 0; c < 4; ++c)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 4; ++j) {
-                                const int n = 128 * w + 16 * (4 * hh + c) + (lane & 15);
-                                const int k = 16 * q + 4 * (lane >> 4) + j;
-                                winxs[o++] = k < JF ? (*Win)[(size_t)n * KIN + k] : 0.f;
-                            }
-        o = 0;
-        for (int ob = 0; ob < NOB; ++ob)
-            for (int q = 0; q < 16; ++q)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 8; ++e) {
-                        const int c = 16 * ob + (lane & 15);
-                        const int k = 32 * q + 8 * (lane >> 4) + e;
-                        const float v = c < JF ? (*Wout)[(size_t)c * D + k] : 0.f;
-                        wo_hi[o] = f32_to_bf16(v);
-                        wo_lo[o] = f32_to_bf16(v - bf16_to_f32(wo_hi[o]));
-                        ++o;
-                    }
-    }
     // wout_reg_img[w][ob][cb][lane][j] = Wout[c = 16ob + (lane&15)][k = 64w + 16cb + 4(lane>>4) + j]: the k order in which
     // wave w's residual registers X[cb][.][j] present the hidden state as an MFMA B operand
     std::vector<float> woutr((size_t)kWaves * NOB * kCB * 64 * 4);
@@ -358,10 +302,6 @@ int build_images(ls_handle* h) {
     if ((rc = upload(h, h->wch_lo_img, wch_lo.data(), wch_lo.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->ww_hi_img, wwh.data(), wwh.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->ww_lo_img, wwl.data(), wwl.size() * sizeof(unsigned short))) != LS_OK) return rc;
-#define UPS(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof((vec)[0]))) != LS_OK) return rc
-    UPS(winx_seq_img, winxs); UPS(wch_seq_hi_img, wcs_hi); UPS(wch_seq_lo_img, wcs_lo); UPS(ww_seq_hi_img, wws_hi);
-    UPS(ww_seq_lo_img, wws_lo); UPS(btok_seq, bts); UPS(wout_hi_img, wo_hi); UPS(wout_lo_img, wo_lo);
-#undef UPS
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
     UP(win_full, *Win); UP(win_bias, *bin);
@@ -433,14 +373,6 @@ int build_images(ls_handle* h) {
     dw.wch_lo_img = static_cast<const unsigned short*>(h->wch_lo_img.p);
     dw.ww_hi_img = static_cast<const unsigned short*>(h->ww_hi_img.p);
     dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
-    dw.winx_seq_img = h->winx_seq_img.f();
-    dw.wch_seq_hi_img = static_cast<const unsigned short*>(h->wch_seq_hi_img.p);
-    dw.wch_seq_lo_img = static_cast<const unsigned short*>(h->wch_seq_lo_img.p);
-    dw.ww_seq_hi_img = static_cast<const unsigned short*>(h->ww_seq_hi_img.p);
-    dw.ww_seq_lo_img = static_cast<const unsigned short*>(h->ww_seq_lo_img.p);
-    dw.btok_seq = h->btok_seq.f();
-    dw.wout_hi_img = static_cast<const unsigned short*>(h->wout_hi_img.p);
-    dw.wout_lo_img = static_cast<const unsigned short*>(h->wout_lo_img.p);
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
     dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
     dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
@@ -471,15 +403,11 @@ int ensure_temb_table(ls_handle* h) {
     return LS_OK;
 }
 
-// precision 0: exact fp32 (k_step<..,0>); 1: bf16x3 inside the same one-workgroup-per-sample kernel (k_step<..,1>);
-// 2: bf16x3 with one workgroup per CFG pass (k_seq + k_cfg_update) -- measured SLOWER (0.84 vs 0.67 ms/step at B=512:
-// every workgroup streams the whole 1 MB/layer of hi+lo weights for 48 rows instead of 80), kept as an A/B reference
-hipError_t run_step(ls_handle* h, StepArgs& s, int B, hipStream_t st) {
-    if (h->precision == 2) {
-        s.out_raw = h->out_raw.f();
-        return launch_step_seq(h->var, s, B, st);
-    }
-    return launch_step(h->var, h->precision == 1 ? 1 : 0, s, B, st);
+// precision 0: exact fp32 (k_step<..,0>); 1: bf16x3 inside the same one-workgroup-per-sample kernel (k_step<..,1>)
+// pair: the single-pass variant (two samples' cond pass per workgroup), legal when every guidance scale is 1
+hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
+    s.batch = B;
+    return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
 }
 
 void fill_common(ls_handle* h, StepArgs& a) {
@@ -492,9 +420,11 @@ void fill_common(ls_handle* h, StepArgs& a) {
     a.W = static_cast<const DevWeights*>(h->devw.p);
     a.layers = h->cfg.layers;
     a.sampler = kNone;
+#ifdef LS_DEBUG
     a.ablate = h->ablate;
     a.prof = h->prof_on ? static_cast<unsigned long long*>(h->prof.p) : nullptr;
     a.prof_wg = h->prof_wg;
+#endif
 }
 
 // per-step scalars, cast fp64 -> fp32 exactly like _extract_into_tensor (gaussian_diffusion.py:1651-1664)
@@ -550,8 +480,10 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (e != hipSuccess) return fail(nullptr, LS_EHIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
     ls_handle* h = new ls_handle();
     h->cfg = *cfg;
+#ifdef LS_DEBUG
     if (const char* ab = getenv("LS_ABLATE")) h->ablate = atoi(ab);
     if (const char* pr = getenv("LS_PROF")) { h->prof_on = true; h->prof_wg = atoi(pr); }
+#endif
     h->var = var;
     h->JF = JF;
     h->S = kT + cfg->n_prefix_tokens;
@@ -569,14 +501,14 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
-    e = init_seq_kernels();
-    if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(seq kernel LDS): %s", hipGetErrorString(e)); }
     e = init_step_kernels();
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
+#ifdef LS_DEBUG
     if (h->prof_on) {
         std::vector<unsigned long long> z((size_t)kWaves * kProfPoints, 0ull);
         if (upload(h, h->prof, z.data(), z.size() * sizeof(unsigned long long)) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
     }
+#endif
     CallParams cp{0, 0};
     if (upload(h, h->callp, &cp, sizeof cp) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
     *out = h;
@@ -588,16 +520,18 @@ void ls_destroy(ls_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graph(h);
-    DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->ww_hi_img, &h->ww_lo_img, &h->winx_seq_img, &h->wch_seq_hi_img,
-                     &h->wch_seq_lo_img, &h->ww_seq_hi_img, &h->ww_seq_lo_img, &h->btok_seq, &h->wout_hi_img, &h->wout_lo_img, &h->out_raw, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
+    DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->ww_hi_img, &h->ww_lo_img, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
                      &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_pad, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
                      &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
-                     &h->callp, &h->eps_tape, &h->noise_tape, &h->prof};
+                     &h->callp, &h->eps_tape, &h->noise_tape};
     for (DevBuf* d : all) d->release();
+#ifdef LS_DEBUG
+    h->prof.release();
+#endif
     for (int i = 0; i < 4; ++i) { h->conv_w[i].release(); h->conv_b[i].release(); h->conv_img[i].release(); }
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -628,7 +562,7 @@ int ls_commit_weights(ls_handle* h) {
 
 int ls_set_precision(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
-    if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3 && mode != LS_PRECISION_BF16X3_PERPASS)
+    if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3)
         return fail(h, LS_EINVAL, "unknown precision mode %d", mode);
     if (mode != h->precision) free_graph(h);
     h->precision = mode;
@@ -674,7 +608,15 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     if ((rc = ingest(h, h->origin_x, c->origin_x, (size_t)B * JF * kT * sizeof(float), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->vid, c->vid_indices, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->scale, c->scale, (size_t)B * sizeof(float), od)) != LS_OK) return rc;
-    if (c->emo && (rc = ingest(h, h->emo, c->emo, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
+    if (c->emo && (rc = ingest(h, h->emo, c->emo, (size_t)B * kT * sizeof(int64_t), od)) != LS_OK) return rc;
+    {   // guidance scale 1 for the whole batch (what the reference's callers run: test_RAG_ted.py:183): out_u + 1 * (out_c - out_u)
+        // is out_c, so the sampling loop may skip the uncond pass (ls_sample_args.two_pass_always keeps both)
+        std::vector<float> sc((size_t)B);
+        if (od) HIPCHK(h, hipMemcpy(sc.data(), c->scale, (size_t)B * sizeof(float), hipMemcpyDeviceToHost));
+        else memcpy(sc.data(), c->scale, (size_t)B * sizeof(float));
+        h->all_scale_one = true;
+        for (float v : sc) if (v != 1.0f) { h->all_scale_one = false; break; }
+    }
 
     // ---- WavEncoder (audio_enc.py:6-25): conv -> [IN + LReLU fused into the next conv's staging] x3 -> conv
     const int* Lc = h->convL;
@@ -727,9 +669,8 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), nullptr, 0, h->z_std.f(), kD, B, kD, 256, 2, st));
     if (h->cfg.n_prefix_tokens == 2) {   // scripts_beat/model/RAG.py:125
         HIPCHK(h, h->emo_tok.ensure((size_t)B * kD * sizeof(float)));
-        HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st));
+        HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, kT));   // y['emo'][:, 0]
     }
-    { const void* old_raw = h->out_raw.p; HIPCHK(h, h->out_raw.ensure((size_t)B * 2 * kT * JF * sizeof(float))); if (old_raw != h->out_raw.p) free_graph(h); }
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipEventElapsedTime(&h->timing.prepare_ms, h->ev[0], h->ev[1]));
@@ -767,7 +708,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
         HIPCHK(h, h->trace.ensure((size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float)));
         s.trace = h->trace.f();
     }
-    HIPCHK(h, run_step(h, s, B, st));
+    HIPCHK(h, run_step(h, s, B, false, st));      // model(x, t, y) parity entry: both passes always
     float* outs[3] = {a->out_cond, a->out_uncond, a->out_cfg};
     const float* srcs[3] = {h->fwd_c.f(), h->fwd_u.f(), h->fwd_cfg.f()};
     for (int i = 0; i < 3; ++i) {
@@ -809,7 +750,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
     s.noise = h->noise.f();
     s.temb = h->temb.f() + (size_t)a->index * kD; s.temb_stride = 0;
-    HIPCHK(h, run_step(h, s, B, st));
+    HIPCHK(h, run_step(h, s, B, h->all_scale_one && !a->two_pass_always, st));
     HIPCHK(h, launch_from_internal(h->xb.f(), h->xio.f(), B, JF, st));
     if ((rc = egress(h, a->sample, h->xio.f(), nx, od)) != LS_OK) return rc;
     if (a->pred_xstart) {
@@ -897,11 +838,14 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     }
 
     // ---- the loop: for i = T-1-skip ... 0 (gaussian_diffusion.py:724-743 / :994-1014) ----------------
-    char keybuf[256];
+    const bool pair = h->all_scale_one && !a->two_pass_always;
+    std::string key;
     {
-        int off = snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u d%d", h->precision, B, a->sampler, (double)a->eta,
-                           a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, a->n_dump);
-        for (int d = 0; d < a->n_dump && off < (int)sizeof keybuf - 12; ++d) off += snprintf(keybuf + off, sizeof keybuf - off, ",%d", a->dump_steps[d]);
+        char keybuf[256];
+        snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d", h->precision, B, a->sampler, (double)a->eta,
+                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump);
+        key = keybuf;
+        for (int d = 0; d < a->n_dump; ++d) key += "," + std::to_string(a->dump_steps[d]);      // the whole list, however long
     }
     auto enqueue_loop = [&]() -> int {
         for (int k = 0; k < n_exec; ++k) {
@@ -922,14 +866,14 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
             }
             for (int d = 0; d < a->n_dump; ++d)
                 if (a->dump_steps[d] == k) s.x0_out = h->dump.f() + (size_t)d * nelem;
-            HIPCHK(h, run_step(h, s, B, st));
+            HIPCHK(h, run_step(h, s, B, pair, st));
         }
         return LS_OK;
     };
     h->timing.graph_replayed = 0;
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     if (a->use_graph) {
-        if (!h->graph_exec || h->graph_key != keybuf) {
+        if (!h->graph_exec || h->graph_key != key) {
             free_graph(h);
             HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             rc = enqueue_loop();
@@ -939,7 +883,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
             if (e != hipSuccess) return fail(h, LS_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
             h->graph = g;
             HIPCHK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
-            h->graph_key = keybuf;
+            h->graph_key = key;
             HIPCHK(h, hipEventRecord(h->ev[1], st));    // exclude capture/instantiate from loop_ms
         } else {
             h->timing.graph_replayed = 1;
@@ -961,6 +905,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
     HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
     h->timing.n_step_launches = n_exec;
+    h->timing.single_pass = pair ? 1 : 0;
     return LS_OK;
 }
 
@@ -987,6 +932,7 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
     const float* src = nullptr;
     size_t cnt = 0;
     const size_t B = (size_t)h->B;
+#ifdef LS_DEBUG
     if (n == "prof") {
         if (!h->prof_on) return fail(h, LS_ESTATE, "LS_PROF not set");
         cnt = (size_t)kWaves * kProfPoints * 2;     // 64-bit stamps as pairs of 32-bit words
@@ -994,6 +940,7 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
         HIPCHK(h, hipMemcpy(host_out, h->prof.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
         return (long long)cnt;
     }
+#endif
     if (n == "temb") {
         if (!h->have_sched || !h->committed) return fail(h, LS_ESTATE, "temb needs weights and schedule");
         int rc = ensure_temb_table(h);

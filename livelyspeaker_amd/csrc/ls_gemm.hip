@@ -1,13 +1,344 @@
-// nn.Linear-shaped products of the once-per-call stage and the SAG decoder:
-//     C[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] ) (+ R[m][n])          (y = x W^T + b)
-// They run on the strided fp32 MFMA GEMM of ls_train_gemm.hip (both operands K-contiguous): 128x128 tiles of
-// v_mfma_f32_16x16x4_f32, register-prefetch software pipeline, and -- for full tiles with float4-legal operands, which is every
-// SAG-decoder product at the callers' batch -- its fast staging path.
+// Strided fp32 MFMA GEMM for the training step (forward, data-gradient and weight-gradient products):
+//     C[m][n] (+)= act( sum_k A(m,k) * B(n,k) + bias[n] )
+// A(m,k) and B(n,k) are addressed through two-level strides on both the row and the reduction index
+//     off(m,k) = (m / ri) * ro + (m % ri) * rs  +  (k / ki) * ko + (k % ki) * ks
+// so nn.Linear forward (A = X[m][k], B = W[n][k]), dX = dY W (B = W read down its columns), dW = dY^T X (both operands
+// read down their columns, reduction over the batch rows) and the [B][C][L] conv tensors all run on the same kernel
+// without materialised transposes.  The template flag says which index is contiguous in memory for each operand, which
+// decides how threads are laid over the tile when it is staged (coalesced global reads) and how it sits in LDS:
+//   K-contiguous operand: LDS [row][k] (stride 36), MFMA operand = one ds_read_b128;
+//   row-contiguous operand: LDS [k][row] (stride 132), staged with float4 writes, MFMA operand = 4 ds_read_b32.
+// The next K tile is fetched into registers while the current one is multiplied (software pipelining).
+// v_mfma_f32_16x16x4_f32, 128x128 tile / 256 threads, K chunk 32, same transposed accumulator form as the step kernel.
+// Split-K (gridDim.z > 1) writes partial tiles to a workspace which k_splitk_reduce sums in a fixed order
+// (deterministic: no float atomics anywhere in the training step).
 #include "ls_internal.h"
 #include "ls_train.h"
 
 namespace ls {
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int kTM = 128, kTK = 32, kLdK = kTK + 4, kLdR = kTM + 4;
+
+// epilogue activations: 0 none, 1 SiLU, 2 exp(0.5 y) (std from log-variance), 3 exact GELU (F.gelu default)
+__device__ __forceinline__ float gemm_act(float v, int act) {
+    if (act == 1) return v / (1.0f + expf(-v));
+    if (act == 2) return expf(0.5f * v);
+    if (act == 3) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
+// two-level index -> offset; the single-level case (inner extent INT_MAX) skips the integer division
+__device__ __forceinline__ size_t lvl(int i, int inner, long long so, long long si) {
+    if (inner == INT_MAX) return (size_t)i * si;
+    return (size_t)(i / inner) * so + (size_t)(i % inner) * si;
+}
+
+// Fetch this thread's share of a 128 x 32 operand tile into registers (global loads only; they stay in flight while the
+// previous tile is multiplied).  KC: threads adjacent along k (operand is k-contiguous); otherwise adjacent along rows.
+// roff[]: the thread's row offsets, computed once per kernel.
+template <bool KC>
+__device__ __forceinline__ void fetch(f4 (&v)[4], const GemmOperand& o, const size_t (&roff)[4], int r0, int R, int k0, int k1, int tid) {
+    if (KC) {
+        const int c4 = (tid & 7) * 4, k = k0 + c4;
+        size_t koff[4];
+        const bool vec = o.vec && k + 3 < k1;
+        if (vec) koff[0] = lvl(k, o.ki, o.ko, o.ks);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) koff[e] = lvl(k + e, o.ki, o.ko, o.ks);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            v[i] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (r0 + r < R) {
+                if (vec) v[i] = *reinterpret_cast<const f4*>(o.p + roff[i] + koff[0]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (k + e < k1) v[i][e] = o.p[roff[i] + koff[e]];
+                }
+            }
+        }
+    } else {
+        const int r4 = (tid & 31) * 4;
+        const bool vec = o.vec && r0 + r4 + 3 < R;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (tid >> 5) + 8 * i;
+            v[i] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (k < k1) {
+                const size_t koff = lvl(k, o.ki, o.ko, o.ks);
+                if (vec) v[i] = *reinterpret_cast<const f4*>(o.p + roff[0] + koff);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (r0 + r4 + e < R) v[i][e] = o.p[roff[e] + koff];
+                }
+            }
+        }
+    }
+}
+
+// The same for the common case -- full 128-row tile, whole K tiles, float4-legal, single-level reduction index: four
+// unconditional loads off one running pointer (`at` already includes the thread's k position; it advances by one K tile per
+// iteration).  The general fetch above costs ~450 executed VALU/SALU instructions per K tile (bounds tests, two-level index
+// arithmetic), which on gfx950 come straight out of the fp32 MFMA issue time.
+template <bool KC, int NI = 4>
+__device__ __forceinline__ void fetch_fast(f4 (&v)[4], const float* at, const size_t (&roff)[4], long long ks) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const f4*>(KC ? at + roff[i] : at + (long long)(8 * i) * ks);
+}
+
+// registers -> LDS: K-contiguous operands as [row][k] (stride 36), row-contiguous ones as [k][row] (stride 132)
+template <bool KC, int NI = 4>
+__device__ __forceinline__ void put(float* s, const f4 (&v)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (KC) *reinterpret_cast<f4*>(&s[((tid >> 3) + 32 * i) * kLdK + (tid & 7) * 4]) = v[i];
+        else *reinterpret_cast<f4*>(&s[((tid >> 5) + 8 * i) * kLdR + (tid & 31) * 4]) = v[i];
+    }
+}
+
+// per-thread row offsets of the tile rows this thread stages (KC: rows (tid>>3) + 32 i; else rows 4 (tid&31) + e)
+template <bool KC>
+__device__ __forceinline__ void row_offsets(const GemmOperand& o, size_t (&roff)[4], int r0, int R, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + (KC ? (tid >> 3) + 32 * i : (tid & 31) * 4 + i);
+        if (r >= R) r = R - 1;
+        roff[i] = lvl(r, o.ri, o.ro, o.rs);
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ f4 frag(const float* s, int row, int kk, int g) {
+    if (KC) return *reinterpret_cast<const f4*>(&s[row * kLdK + 16 * kk + 4 * g]);
+    f4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = s[(16 * kk + 4 * g + e) * kLdR + row];
+    return v;
+}
+
+// MT: 16-row m tiles per wave -> 128 (MT = 4) or 64 (MT = 2) rows of A per workgroup.  The 64-row tile exists for products whose
+// 128 x 128 tile count fills the chip badly (e.g. 544 tiles on 768 workgroup slots: one CU in eight runs three tiles while the
+// others run two); only the K-contiguous fast path is instantiated with it.
+template <bool AK, bool BK, bool FAST, int MT = 4>
+__global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
+    static_assert(MT == 4 || (MT == 2 && AK && FAST), "64-row tiles: K-contiguous A on the fast path only");
+    constexpr int BM = 32 * MT;
+    constexpr int SA = AK ? BM * kLdK : kTK * kLdR;
+    constexpr int SB = BK ? kTM * kLdK : kTK * kLdR;
+    __shared__ __attribute__((aligned(16))) float sA[SA];
+    __shared__ __attribute__((aligned(16))) float sB[SB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int m0 = by * BM, n0 = bx * kTM;
+    const int s16 = lane & 15, g = lane >> 4;
+    const int zb = bz / a.splits, z = bz - zb * a.splits;     // (problem of the batch, K split)
+    const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    a.A.p += (size_t)zb * a.bsA;
+    a.B.p += (size_t)zb * a.bsB;
+    a.C += (size_t)zb * a.bsC;
+
+    f4 acc[4][MT];                                  // [n tile][m tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    size_t roffA[4], roffB[4];
+    row_offsets<AK>(a.A, roffA, m0, a.M, tid);
+    row_offsets<BK>(a.B, roffB, n0, a.N, tid);
+    f4 ra[4], rb[4];
+    // FAST: running pointers of this thread's share of the current K tile
+    const float* pa = nullptr;
+    const float* pb = nullptr;
+    if (FAST) {
+        pa = AK ? a.A.p + kbeg + (tid & 7) * 4 : a.A.p + roffA[0] + (long long)(kbeg + (tid >> 5)) * a.A.ks;
+        pb = BK ? a.B.p + kbeg + (tid & 7) * 4 : a.B.p + roffB[0] + (long long)(kbeg + (tid >> 5)) * a.B.ks;
+        fetch_fast<AK, MT>(ra, pa, roffA, a.A.ks);
+        fetch_fast<BK>(rb, pb, roffB, a.B.ks);
+    } else {
+        fetch<AK>(ra, a.A, roffA, m0, a.M, kbeg, kend, tid);
+        fetch<BK>(rb, a.B, roffB, n0, a.N, kbeg, kend, tid);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += kTK) {
+        __syncthreads();
+        put<AK, MT>(sA, ra, tid);
+        put<BK>(sB, rb, tid);
+        __syncthreads();
+        if (FAST) {                         // next tile's global loads overlap this tile's MFMAs; the last iteration re-reads its
+            const long long adv = k0 + kTK < kend ? kTK : 0;          // own tile instead of branching around the loads
+            pa += AK ? adv : adv * a.A.ks;
+            pb += BK ? adv : adv * a.B.ks;
+            fetch_fast<AK, MT>(ra, pa, roffA, a.A.ks);
+            fetch_fast<BK>(rb, pb, roffB, a.B.ks);
+            __builtin_amdgcn_sched_barrier(0);      // or the scheduler sinks these loads below the MFMAs, right in front of their use
+        } else if (k0 + kTK < kend) {
+            fetch<AK>(ra, a.A, roffA, m0, a.M, k0 + kTK, kend, tid);
+            fetch<BK>(rb, a.B, roffB, n0, a.N, k0 + kTK, kend, tid);
+        }
+        if (FAST) {
+            // fragment loads run one step ahead of the MFMAs that use them (8 steps per K tile: 2 k-halves x 4 n tiles): the fast
+            // staging path leaves the registers for a second A set and a second B fragment at 3 waves / SIMD
+            f4 af[2][MT], bf[2];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) af[0][j] = frag<AK>(sA, wm * 16 * MT + 16 * j + s16, 0, g);
+            bf[0] = frag<BK>(sB, wn * 64 + s16, 0, g);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int kk = st >> 2, i = st & 3;
+                if (st + 1 < 8) bf[(st + 1) & 1] = frag<BK>(sB, wn * 64 + 16 * ((st + 1) & 3) + s16, (st + 1) >> 2, g);
+                if (st == 0) {
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) af[1][j] = frag<AK>(sA, wm * 16 * MT + 16 * j + s16, 1, g);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // pins [LDS reads of the next step][MFMAs of this step]
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) acc[i][j] = MFMA(bf[st & 1][e], af[kk][j][e], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < kTK / 16; ++kk) {
+                f4 af[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) af[j] = frag<AK>(sA, wm * 16 * MT + 16 * j + s16, kk, g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {       // one B fragment live at a time keeps the kernel at 3 waves / SIMD
+                    const f4 bf = frag<BK>(sB, wn * 64 + 16 * i + s16, kk, g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j) acc[i][j] = MFMA(bf[e], af[j][e], acc[i][j]);
+                }
+            }
+        }
+    }
+    // lane (m = s16 of m tile j, g) holds n = n0 + wn*64 + 16*i + 4*g + {0..3}
+    const bool partial = a.splits > 1;
+    float* Cz = partial ? a.ws + (size_t)bz * a.M * a.N : nullptr;
+    const bool cvec = a.cns == 1 && (a.crs & 3) == 0 && (a.cri == INT_MAX || (a.cro & 3) == 0) && ((uintptr_t)a.C & 15) == 0 &&
+                      (!a.Cpre || ((uintptr_t)a.Cpre & 15) == 0) && (!a.R || ((uintptr_t)a.R & 15) == 0) &&
+                      (!a.bias || ((uintptr_t)a.bias & 15) == 0);
+    // FAST tiles are full: no bounds tests (each one is a branch that also serialises the loads behind it), bias fetched once
+    f4 biasv[4];
+    if (FAST && a.bias && !partial) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) biasv[i] = *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * 16 * MT + 16 * j + s16;
+        if (!FAST && m >= a.M) continue;
+        const size_t crow = partial ? (size_t)m * a.N : lvl(m, a.cri, a.cro, a.crs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + 16 * i + 4 * g;
+            if (!FAST && n >= a.N) continue;
+            f4 v = acc[i][j];
+            if (partial) {
+                if ((a.N & 3) == 0) *reinterpret_cast<f4*>(&Cz[crow + n]) = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < a.N) Cz[crow + n + e] = v[e];
+                }
+                continue;
+            }
+            if (cvec && (FAST || n + 3 < a.N)) {
+                const size_t co = crow + n;
+                if (a.bias) v += FAST ? biasv[i] : *reinterpret_cast<const f4*>(a.bias + n);
+                if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co) = v;
+                if (a.act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gemm_act(v[e], a.act);
+                }
+                if (a.R) v += *reinterpret_cast<const f4*>(a.R + co);
+                if (a.accumulate) v += *reinterpret_cast<const f4*>(a.C + co);
+                *reinterpret_cast<f4*>(a.C + co) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= a.N) continue;
+                    float x = v[e];
+                    if (a.bias) x += a.bias[n + e];
+                    const size_t co = crow + (size_t)(n + e) * a.cns;
+                    if (a.Cpre) a.Cpre[co] = x;
+                    x = gemm_act(x, a.act);
+                    if (a.R) x += a.R[co];
+                    if (a.accumulate) x += a.C[co];
+                    a.C[co] = x;
+                }
+            }
+        }
+    }
+}
+
+// C[m][n] (+)= sum_z ws[z][m][n] (+ bias); fixed summation order
+__global__ void k_splitk_reduce(const GemmArgs a, int Z) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)a.M * a.N) return;
+    const int m = (int)(i / a.N), n = (int)(i % a.N);
+    const float* ws = a.ws + (size_t)blockIdx.y * Z * a.M * a.N;          // blockIdx.y: problem of the batch
+    float* C = a.C + (size_t)blockIdx.y * a.bsC;
+    float v = 0.f;
+#pragma unroll 8                                    // independent loads in flight; the sum keeps its z order
+    for (int z = 0; z < Z; ++z) v += ws[(size_t)z * a.M * a.N + i];
+    if (a.bias) v += a.bias[n];
+    const size_t co = (size_t)(m / a.cri) * a.cro + (size_t)(m % a.cri) * a.crs + (size_t)n * a.cns;
+    if (a.accumulate) v += C[co];
+    C[co] = v;
+}
+
+hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits, hipStream_t st) {
+    if (splits < 1) splits = 1;
+    // chunk is a multiple of the K tile so that every split starts on a tile boundary
+    int kchunk = ((a.K + splits - 1) / splits + kTK - 1) / kTK * kTK;
+    splits = (a.K + kchunk - 1) / kchunk;
+    a.kchunk = kchunk;
+    a.splits = splits;
+    if (a.nbatch < 1) a.nbatch = 1;
+    if (a.nbatch > 1 && (a.bias || a.Cpre || a.R)) return hipErrorInvalidValue;
+    if (splits > 1 && (!a.ws || (size_t)a.nbatch * splits * a.M * a.N > a.ws_floats)) return hipErrorInvalidValue;
+    if (splits > 1 && (a.Cpre || a.R || a.act)) return hipErrorInvalidValue;
+    dim3 grid((a.N + kTM - 1) / kTM, (a.M + kTM - 1) / kTM, a.nbatch * splits);
+    // fast staging path: full tiles, whole K tiles in every split, float4-legal operands with a single-level reduction index
+    const bool fast = a.M % kTM == 0 && a.N % kTM == 0 && a.K % kTK == 0 && a.A.vec && a.B.vec && a.A.ki == INT_MAX && a.B.ki == INT_MAX;
+    // 64-row tiles when they balance the 256 CUs better: every CU works through ceil(workgroups / 256) tiles (co-resident ones share
+    // its matrix pipes), so the efficiency of a grid is (workgroups / 256) / ceil(workgroups / 256) -- 544 tiles: 0.71, 1088 half tiles: 0.85
+    auto balance = [](long long wgs) { const double per = (double)wgs / 256.0; return per / (double)((wgs + 255) / 256); };
+    const long long t128 = (long long)grid.x * grid.y * grid.z;
+    const bool half = fast && a_kcontig && b_kcontig && balance(2 * t128) > balance(t128) + 0.05;
+    if (half) {
+        grid.y *= 2;
+        hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2>), grid, dim3(256), 0, st, a);
+    } else {
+#define LS_GEMM_LAUNCH(AKV, BKV)                                                                             \
+    do {                                                                                                     \
+        if (fast) hipLaunchKernelGGL((k_gemm_tr<AKV, BKV, true>), grid, dim3(256), 0, st, a);                \
+        else hipLaunchKernelGGL((k_gemm_tr<AKV, BKV, false>), grid, dim3(256), 0, st, a);                    \
+    } while (0)
+        if (a_kcontig && b_kcontig) LS_GEMM_LAUNCH(true, true);
+        else if (a_kcontig && !b_kcontig) LS_GEMM_LAUNCH(true, false);
+        else if (!a_kcontig && b_kcontig) LS_GEMM_LAUNCH(false, true);
+        else LS_GEMM_LAUNCH(false, false);
+#undef LS_GEMM_LAUNCH
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || splits == 1) return e;
+    const size_t n = (size_t)a.M * a.N;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), a.nbatch), dim3(256), 0, st, a, splits);
+    return hipGetLastError();
+}
+
+// nn.Linear-shaped entry (y = x W^T + b) used by the sampler's once-per-call stage, the SAG decoder and the FGD evaluator:
+//     C[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] ) (+ R[m][n]),   both operands K-contiguous
 // act: 0 none, 1 SiLU, 2 exp(0.5 y), 3 exact GELU (F.gelu default, nn.TransformerDecoderLayer activation="gelu")
 hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                           float* C, int ldc, int M, int N, int K, int act, hipStream_t st) {

@@ -34,15 +34,6 @@ struct DevWeights {
     const unsigned short* wch_lo_img;
     const unsigned short* ww_hi_img;   // [L][5][KS][64][8]  block-diagonal token weights, bf16 hi / lo planes
     const unsigned short* ww_lo_img;
-    // per-pass variant (ls_step_seq.hip: 4 waves x 128 channels, one sequence = 3 token tiles)
-    const float* winx_seq_img;            // [4][2 halves][KXQ][4 cb][64][4]
-    const unsigned short* wch_seq_hi_img; // [L][4][2 passes][16 q][4 cb][64][8]
-    const unsigned short* wch_seq_lo_img;
-    const unsigned short* ww_seq_hi_img;  // [L][3][2][64][8]   Wt (single sequence), bf16 hi / lo
-    const unsigned short* ww_seq_lo_img;
-    const float* btok_seq;                // [L][48]
-    const unsigned short* wout_hi_img;    // [NOB][16 q][64][8]  poseFinal, bf16 hi / lo
-    const unsigned short* wout_lo_img;
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
     const float* btok_rows;  // [L][80]
@@ -60,7 +51,6 @@ struct StepArgs {
     float* x0_out;       // pred_xstart (CFG-combined)    (nullable)
     float* fwd_c;        // raw cond / uncond model outputs (nullable)
     float* fwd_u;
-    float* out_raw;      // per-pass variant: raw model outputs [B][2 passes][T][JF] handed to k_cfg_update
     // prepared conditioning
     const float* static_c;   // [B][T][512]  W_in[:,JF:] . [prefix poses | bit | audio] + b
     const float* static_u;   // same with the audio term masked
@@ -79,6 +69,7 @@ struct StepArgs {
     unsigned step_id;        // Philox stream selector
     const struct DevWeights* W;   // weight images (device memory, constant per model)
     int layers;
+    int batch;               // samples in this launch (PAIR variant: two per workgroup, the last one may be single)
     // sampler update
     int sampler;             // SamplerKind
     int t_nonzero;           // 1[t != 0]
@@ -97,23 +88,29 @@ struct StepArgs {
     float* tr_xout;          // [tr_B*S][512] output of the last layer
     int tr_B;
     float* trace;            // [B][L+1][2S][512] or null
-    unsigned long long* prof;  // profiling only (env LS_PROF): [8 waves][kProfPoints] s_memtime stamps of workgroup prof_wg
+#ifdef LS_DEBUG
+    // Profiling builds only (tools/phase_profile.py, tools/ab_variants.py compile their own -DLS_DEBUG variant of the library):
+    // the shipped library has neither the fields nor the code that reads them, so no environment variable can change its results.
+    unsigned long long* prof;  // [8 waves][kProfPoints] s_memtime stamps of workgroup prof_wg (env LS_PROF)
     int prof_wg;
-    int ablate;              // profiling only (env LS_ABLATE): 1 skip channel-mix MFMAs, 2 skip token-mix, 4 skip LN stats
+    int ablate;              // env LS_ABLATE: 1 skip channel-mix MFMAs, 2 skip token-mix, 4 skip LN stats (results are wrong)
+#endif
 };
 
 // dataset variant of the compiled kernel
 enum Variant { kTED = 0, kBEAT = 1 };
 
 // prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
-hipError_t launch_step(Variant v, int prec, const StepArgs& a, int batch, hipStream_t st);
+// pair: 0 = CFG (cond + uncond pass of one sample per workgroup), 1 = single pass (guidance scale 1: two samples per workgroup)
+hipError_t launch_step(Variant v, int prec, int pair, const StepArgs& a, int batch, hipStream_t st);
+hipError_t launch_step_ted(int prec, int pair, const StepArgs& a, int batch, hipStream_t st);     // ls_step.hip
+hipError_t launch_step_beat(int prec, int pair, const StepArgs& a, int batch, hipStream_t st);    // ls_step_beat.hip
+hipError_t init_step_kernels_ted();
+hipError_t init_step_kernels_beat();
 // training forward of the mixer: ceil(tr_B / 2) workgroups (ls_step.hip, TRAIN variant)
 hipError_t launch_train_mixer_fwd(Variant v, const StepArgs& a, hipStream_t st);
 size_t step_lds_bytes(Variant v);
 hipError_t init_step_kernels();
-hipError_t init_seq_kernels();
-// bf16x3, one workgroup per CFG pass + CFG/sampler-update kernel (ls_step_seq.hip)
-hipError_t launch_step_seq(Variant v, const StepArgs& a, int batch, hipStream_t st);
 
 // ---- once-per-call kernels (ls_prepare.hip) ------------------------------------------------
 // stride-6 layers on MFMA (ls_conv.hip); wimg = per-lane operand image.  out_stats != null: the InstanceNorm statistics of
@@ -126,8 +123,9 @@ hipError_t launch_conv1_fwd(const float* wav, const float* w, const float* bias,
 // C[M][N] = act(A[M][K] . W[N][K]^T + bias) (+ R): fp32 MFMA GEMM (ls_gemm.hip); act 3 = exact GELU
 hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                           float* C, int ldc, int M, int N, int K, int act, hipStream_t st);
+// out[r] = table[idx[r * idx_stride]] (rows clamped into the table)
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int rows, int width,
-                              int table_rows, hipStream_t st);
+                              int table_rows, hipStream_t st, int idx_stride = 1);
 hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
                               int B, int JF, int KFP, int n_pre_seq, hipStream_t st);
 hipError_t launch_to_internal(const float* src_bjft, float* dst_btc, int B, int JF, hipStream_t st);

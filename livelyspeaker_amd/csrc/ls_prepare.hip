@@ -14,17 +14,17 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // (the WavEncoder convolutions and their fused InstanceNorm statistics live in ls_conv.hip)
 
 __global__ void k_gather_rows(const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out,
-                              int rows, int width, int table_rows) {
+                              int rows, int width, int table_rows, int idx_stride) {
     const int r = blockIdx.x;
-    long long i = idx[r];
+    long long i = idx[(size_t)r * idx_stride];
     if (i < 0) i = 0;
     if (i >= table_rows) i = table_rows - 1;
     for (int c = threadIdx.x; c < width; c += blockDim.x) out[(size_t)r * width + c] = table[(size_t)i * width + c];
 }
 
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int rows, int width,
-                              int table_rows, hipStream_t st) {
-    hipLaunchKernelGGL(k_gather_rows, dim3(rows), dim3(256), 0, st, table, idx, out, rows, width, table_rows);
+                              int table_rows, hipStream_t st, int idx_stride) {
+    hipLaunchKernelGGL(k_gather_rows, dim3(rows), dim3(256), 0, st, table, idx, out, rows, width, table_rows, idx_stride);
     return hipGetLastError();
 }
 

@@ -1,5 +1,4 @@
-// Device-side helpers shared by the step kernels (ls_step.hip: one workgroup per sample; ls_step_seq.hip: one
-// workgroup per CFG pass).
+// Device-side helpers of the fused step kernel (ls_step.hip) and the training backward (ls_train_bwd.hip).
 #pragma once
 #include "ls_internal.h"
 #include "ls_philox.h"
@@ -13,6 +12,13 @@ typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) bf8* gbf8p;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ablation switches exist in -DLS_DEBUG builds only; in the shipped library the test is a compile-time false
+#ifdef LS_DEBUG
+#define LS_ABLATED(args, bit) (((args).ablate & (bit)) != 0)
+#else
+#define LS_ABLATED(args, bit) false
+#endif
 
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp), far inside the 1e-3 parity budget.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

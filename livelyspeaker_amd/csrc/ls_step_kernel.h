@@ -1,0 +1,863 @@
+// Fused diffusion-step kernel for gfx950 (MI355X): ONE launch = one p_sample / ddim_sample step of the
+// CFG-wrapped RAG denoiser for the whole batch.  Replaces, per step, the ~230 eager aten ops of
+//   ClassifierFreeSampleModel.forward   scripts/model/cfg_sampler.py:24-31
+//   RAG.forward                         scripts/model/RAG.py:98-133
+//   TransMLP / MLPblock / LN_spatial    scripts/model/mlp_module.py:21-91
+//   OutputProcess                       scripts/model/RAG.py:205-211
+//   p_mean_variance / p_sample / ddim_sample   scripts/diffusion/gaussian_diffusion.py:284-399, 507-558, 745-798
+//
+// Mapping:
+//   * one workgroup (8 waves, 512 threads) owns ONE sample: the cond and uncond passes are packed as
+//     R = 2*S rows (70 TED / 72 BEAT) -> 5 token tiles of 16, so the CFG lerp and the sampler update fuse
+//     into the same launch and nothing but x_t (3.7 KB) round-trips through HBM between steps.
+//   * every contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32; bf16/fp16 inputs fail the 1e-3
+//     parity budget) in the TRANSPOSED form D[channel][token]: channels on the
+//     MFMA M axis, tokens on N.  The MFMA C/D layout (lane&15 = token, 4*(lane>>4)+reg = channel) is then
+//     ALSO the layout of the residual stream, which therefore lives in registers for the whole forward:
+//     wave w owns channels [64w, 64w+64) of all 80 rows = 80 VGPRs.
+//   * the normalised operand (LN1(x) for token mixing, LN2(x) for channel mixing) is staged in LDS as
+//     U[row][k] with row stride 520 floats: lane (token, g) fetches k = 16q+4g..+3 with one conflict-free
+//     ds_read_b128 and feeds 4 consecutive MFMAs; the weight operand uses the same k permutation and is
+//     pre-swizzled on the host so each wave-instruction reads 1 KiB contiguous from L2.
+//   * token mixing (Conv1d(S,S,1) over the token axis) is a second small MFMA GEMM against a
+//     block-diagonal [R x R] operand; its output lands directly in the residual layout.
+#pragma once
+#include "ls_step_common.h"
+#include "ls_lanes.h"
+
+namespace ls {
+
+// PAIR = 1: single-pass sampling for guidance scale 1 (out_u + 1 * (out_c - out_u) = out_c, cfg_sampler.py:31, and the callers
+// run guidance_param = 1: test_RAG_ted.py:183): the 2S rows hold the COND pass of TWO samples (2b, 2b+1) instead of the cond and
+// uncond passes of one -- the same block-diagonal token mixing, half the work per sample.
+template <int S, int NPRE, int JF, int PREC, int TRAIN = 0, int PAIR = 0>
+__global__ __launch_bounds__(512) void k_step(const StepArgs a) {
+    static_assert(!TRAIN || PREC == 0, "the training forward is fp32");
+    static_assert(!(TRAIN && PAIR), "PAIR is a sampling variant");
+    constexpr int R = 2 * S;                 // packed rows: [cond tokens | uncond tokens]  (PAIR: [sample 2b | sample 2b+1])
+    constexpr int KXQ = (JF + 15) / 16;      // 16-wide k groups of the x_t part of input_mapping
+    constexpr int KXP = KXQ * 16;
+    constexpr int NOB = (JF + 15) / 16;      // 16-wide output blocks of poseFinal
+    constexpr int OSTR = NOB * 16 + 4;
+    constexpr int MK = (R + 3) / 4;          // k steps of the token-mix GEMM
+    constexpr int NU = NOB * kNT;            // output-projection work units
+    constexpr int MAXU = (NU + kWaves - 1) / kWaves;
+    constexpr int kFullTiles = 4;            // token tiles whose 16 rows are all real
+    constexpr int NREM = R - 16 * kFullTiles;  // rows of the ragged last tile (6 TED / 8 BEAT)
+    // Ragged rows: scalar FMAs (TED, 6 rows) or v_mfma_f32_4x4x1_16b row groups (BEAT, 8 rows = 2 full groups).
+    // Measured on MI355X: the 4x4x1 MFMA issues in 16 cycles = 16 MAC/cycle, the same rate as a wave64 v_fma_f32,
+    // so it only pays when no group is padded (BEAT 0.898 -> 0.867 ms/step: fewer LDS reads; TED 1.494 -> 1.518).
+    constexpr bool kRemMfma = (NREM % 4 == 0);
+    constexpr int NRG = kRemMfma ? NREM / 4 : 1;   // 4-row groups (MFMA path)
+    constexpr int NRV = kRemMfma ? 1 : NREM;       // rows (VALU path)
+    constexpr int NG = (R + 7) / 8;            // 8-row groups of the transposed bf16 operand of token mixing
+    constexpr int KS = (R + 31) / 32;          // k steps (32 source rows) of the bf16 token-mix MFMA
+    constexpr int kGrpStride = kD * 8 + 16;    // bf16 per 8-row group (+32 B so the two row halves of a tile miss each other's banks)
+    static_assert(2 * NG * kGrpStride * 2 <= (R * kUStride + kWaves * 2 * NREM * 16) * 4, "bf16 token-mix planes must fit U + REM");
+    static_assert(NREM > 0 && NREM <= 16, "ragged tile");
+    static_assert(R <= 16 * kNT, "rows must fit the token tiles");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* psum = smem;                      // [8][80] (mean, M2) pairs of the LayerNorm merge
+    float* U = smem + 2 * kWaves * 16 * kNT; // [R][520] fp32 operand / two bf16 planes (bf16x3 mode)
+    float* REM = U + R * kUStride;           // [8 waves][2][NREM][16] remainder-row patch (fp32 mode)
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int s16 = lane & 15;
+    int g = lane >> 4;
+    int chw = 64 * w + 4 * g;                // + 16*cb + j  = this lane's channels
+    // Register-pressure control: the residual stream (80 VGPRs) must stay in registers for the whole forward.
+    // Left alone, LICM hoists every per-lane address of every phase out of the layer loop and keeps ~100 of them
+    // live across the MFMA loops, which pushes X into scratch (each LayerNorm then reloads it with ~50 serialized
+    // scratch_load + s_waitcnt pairs).  Laundering the lane id at phase boundaries makes those addresses
+    // phase-local: 3 VALU ops to recompute instead of a register held for the whole kernel.
+    auto fresh = [&]() {
+        asm volatile("" : "+v"(lane));
+        s16 = lane & 15;
+        g = lane >> 4;
+        chw = 64 * w + 4 * g;
+    };
+
+    // Row metadata is recomputed where needed (tiles 0..3 are always fully valid; only tile 4 is ragged).
+    auto row_of = [&](int t) { return 16 * t + s16; };
+    auto valid_of = [&](int t) { return (16 * t + 15 < R) ? true : (16 * t + s16 < R); };
+    auto rowc_of = [&](int t) { const int r = 16 * t + s16; return (16 * t + 15 < R || r < R) ? r : R - 1; };
+
+    f4 X[kCB][kNT];
+
+    // TRAIN: global row (sample * S + token) of this lane's row of tile t, or -1 when the row is padding / past the batch
+    auto grow_of = [&](int t) -> int {
+        const int r = 16 * t + s16;
+        if (r >= R) return -1;
+        const int sq = r >= S ? 1 : 0;
+        const int sample = 2 * b + sq;
+        return sample < a.tr_B ? sample * S + (r - sq * S) : -1;
+    };
+    auto store_rows = [&](float* base, int l) {                 // X (residual layout) -> [L][tr_B*S][512]
+        float* dst = base + (size_t)l * a.tr_B * S * kD;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            const int gr = grow_of(t);
+            if (gr >= 0)
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) *reinterpret_cast<f4*>(dst + (size_t)gr * kD + chw + 16 * cb) = X[cb][t];
+        }
+    };
+
+    // phase stamps, -DLS_DEBUG builds only (tools/phase_profile.py): lane 0 of every wave of one workgroup records s_memtime
+    auto stamp = [&](int idx) {
+#ifdef LS_DEBUG
+        if (a.prof && b == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
+#else
+        (void)idx;
+#endif
+    };
+    stamp(0);
+
+    // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
+    if constexpr (TRAIN) {
+        // training forward: the token sequences were assembled by the batch-level kernels (input_mapping GEMM, style /
+        // emotion tokens); load this workgroup's two samples into the residual layout
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            const int gr = grow_of(t);
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+                X[cb][t] = gr >= 0 ? *reinterpret_cast<const f4*>(a.tr_x0 + (size_t)gr * kD + chw + 16 * cb) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        // Base value of every row first (its loads overlap the x_t staging below): frame tokens start from the
+        // per-call static projection, prefix tokens from the style sample / emotion embedding.  The x_t columns of
+        // input_mapping are then accumulated ONTO these by using them as the MFMA C operand.
+        // sm(sq): the sample whose pass occupies row half sq.  CFG: both halves are sample b (cond | uncond).  PAIR: samples
+        // 2b and 2b+1, cond pass both; with an odd batch the last workgroup computes its last sample twice and stores it once.
+        auto sm = [&](int sq) -> int { return PAIR ? min(2 * b + sq, a.batch - 1) : b; };
+        const unsigned long long goff = a.call ? a.call->sample_offset : 0ull;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            const int rc = rowc_of(t);
+            const int sq = rc >= S ? 1 : 0;
+            const int tk = rc - sq * S;
+            const int smp = sm(sq);
+            const bool unc = !PAIR && sq;
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                const int ch = chw + 16 * cb;
+                f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+                if (valid_of(t)) {
+                    if (tk >= NPRE) {
+                        const float* st = (unc ? a.static_u : a.static_c) + ((size_t)smp * kT + (tk - NPRE)) * kD + ch;
+                        v = *reinterpret_cast<const f4*>(st);
+                    } else if (tk == 0) {
+                        // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
+                        const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)smp * kD + ch);
+                        const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)smp * kD + ch);
+                        f4 e;
+                        const float* ep = unc ? a.eps_u : a.eps_c;
+                        if (ep) {
+                            e = *reinterpret_cast<const f4*>(ep + (size_t)smp * kD + ch);
+                        } else {
+                            float z[4];            // this lane's 4 consecutive channels = one Philox block
+                            philox_normal4(a.call, goff + (unsigned long long)smp, a.step_id, unc ? 2u : 1u, (unsigned)(ch >> 2), z);
+                            e = (f4){z[0], z[1], z[2], z[3]};
+                        }
+                        v = mu + e * sd;
+                    } else {
+                        // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
+                        v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)smp * kD + ch);
+                    }
+                }
+                X[cb][t] = v;
+            }
+        }
+        for (int idx = tid; idx < R * KXP; idx += 512) {
+            const int r = idx / KXP, k = idx - r * KXP;
+            const int sq = r >= S ? 1 : 0;
+            const int tk = r - sq * S;
+            float v = 0.f;
+            if (tk >= NPRE && k < JF) v = a.x_in[(size_t)sm(sq) * kT * JF + (tk - NPRE) * JF + k];
+            U[r * kUStride + k] = v;
+        }
+        __syncthreads();
+        fresh();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f4 acc[2][kNT];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) acc[c2][t] = X[2 * p + c2][t];
+            gf4p wp = g4(a.W->winx_img) + (size_t)(w * 2 + p) * KXQ * 2 * 64 + lane;
+#pragma unroll 2
+            for (int q = 0; q < KXQ; ++q) {
+                f4 A[2], Bv[kNT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = wp[(q * 2 + c2) * 64];
+#pragma unroll
+                for (int t = 0; t < kNT; ++t)
+                    Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t)
+                    X[2 * p + c2][t] = valid_of(t) ? acc[c2][t] : (f4){0.f, 0.f, 0.f, 0.f};   // pad rows stay zero
+        }
+    }
+
+    auto dump_trace = [&](int stage) {
+        if (!a.trace) return;
+        float* tr = a.trace + ((size_t)b * (a.layers + 1) + stage) * R * kD;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+            if (valid_of(t))
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb)
+                    *reinterpret_cast<f4*>(tr + (size_t)row_of(t) * kD + chw + 16 * cb) = X[cb][t];
+    };
+    dump_trace(0);
+    stamp(1);
+
+    // LN_spatial statistics over the 512 channels of each row (mlp_module.py:29-33).  The reference is two-pass
+    // (mean, then centred biased variance).  Here every lane does the two passes over its own 16 channels and the
+    // (mean, M2) pairs are merged pairwise with Chan's parallel-variance update -- across the 4 lane groups with two
+    // cross-lane exchanges, across the 8 waves through LDS -- which is as cancellation-free as two-pass but needs
+    // ONE workgroup barrier per LayerNorm instead of two.
+    float mean[kNT], rstd[kNT];
+    auto ln_stats = [&](float* gstats) {
+        (void)gstats;
+        if (LS_ABLATED(a, 4)) {
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) { mean[t] = 0.f; rstd[t] = 1.f; }
+            return;
+        }
+        f2* pst = reinterpret_cast<f2*>(psum);            // [8 waves][80 rows] (mean, M2) of 64 channels
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            // both passes as float4 arithmetic (packed f32: two elements per issue); four interleaved partial sums per pass
+            f4 sv = X[0][t];
+#pragma unroll
+            for (int cb = 1; cb < kCB; ++cb) sv += X[cb][t];
+            const float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+            float m = s * (1.0f / 16.0f);
+            const f4 mv = (f4){m, m, m, m};
+            f4 qv = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                const f4 d = X[cb][t] - mv;
+                qv = __builtin_elementwise_fma(d, d, qv);
+            }
+            float m2 = (qv[0] + qv[1]) + (qv[2] + qv[3]);
+            {   // merge with the lane group 16 lanes away (16 + 16 values), then 32 lanes away (32 + 32); the update is symmetric
+                // in the pair, so both members of the v_permlane swap are used as they come (no select, no LDS round trip)
+                float ma, mb, qa, qb;
+                xor16_pair(m, ma, mb);
+                xor16_pair(m2, qa, qb);
+                const float d = mb - ma;
+                m2 = (qa + qb) + d * d * 8.0f;
+                m = 0.5f * (ma + mb);
+            }
+            {
+                float ma, mb, qa, qb;
+                xor32_pair(m, ma, mb);
+                xor32_pair(m2, qa, qb);
+                const float d = mb - ma;
+                m2 = (qa + qb) + d * d * 16.0f;
+                m = 0.5f * (ma + mb);
+            }
+            if (g == 0) pst[w * 80 + 16 * t + s16] = (f2){m, m2};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+            f2 pw[kWaves];
+            f2 acc2 = (f2){0.f, 0.f};                     // (sum of means, sum of M2): packed f32 adds
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) {
+                pw[ww] = pst[ww * 80 + 16 * t + s16];
+                acc2 += pw[ww];
+            }
+            const float ms = acc2.x, m2s = acc2.y;
+            const float mt = ms * (1.0f / kWaves);
+            const f2 mt2 = (f2){mt, mt};
+            f2 dd2 = (f2){0.f, 0.f};                      // squared mean deviations, two waves per packed FMA
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ww += 2) {
+                const f2 d = (f2){pw[ww].x, pw[ww + 1].x} - mt2;
+                dd2 = __builtin_elementwise_fma(d, d, dd2);
+            }
+            const float dd = dd2.x + dd2.y;
+            mean[t] = mt;
+            rstd[t] = rsqrtf((m2s + 64.0f * dd) * (1.0f / kD) + 1e-5f);
+            if constexpr (TRAIN) {                        // (mean, rstd) of every row, kept for the LayerNorm backward
+                const int gr = grow_of(t);
+                if (w == 0 && g == 0 && gr >= 0) *reinterpret_cast<f2*>(gstats + (size_t)gr * 2) = (f2){mean[t], rstd[t]};
+            }
+        }
+    };
+    // write the normalised operand of this lane's channels into the LDS buffer: LN1 applies alpha/beta here
+    // (2 FMAs per element); LN2's alpha/beta are folded into the channel-mix weights/bias on the host
+    // (W' = W.diag(alpha), b' = b + W.beta), so its operand is just (x - mean) * rstd: 1 FMA per element.
+    // alv/bev: LN1's alpha/beta of this lane's channels, loaded by the caller BEFORE the statistics (a load per channel block
+    // here cost four serialised L2 round trips per layer); alpha == nullptr: LN2, affine folded into the weights
+    auto ln_store = [&](const float* alpha, const f4 (&alv)[kCB], const f4 (&bev)[kCB], float* gout) {
+        (void)gout;
+        float nmr[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) nmr[t] = -mean[t] * rstd[t];
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb) {
+            f4 al, be;
+            if (alpha) {
+                al = alv[cb];
+                be = bev[cb];
+            }
+#pragma unroll
+            for (int t = 0; t < kNT; ++t)
+                if (PREC == 1 && alpha && !valid_of(t) && row_of(t) < 8 * NG) {
+                    __bf16* Th = reinterpret_cast<__bf16*>(U);
+                    __bf16* Tl = Th + NG * kGrpStride;
+                    const int r = row_of(t);
+                    const int o = (r >> 3) * kGrpStride + (64 * w + 16 * cb + g) * 8 + (r & 7);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { Th[o + 32 * j] = (__bf16)0.f; Tl[o + 32 * j] = (__bf16)0.f; }
+                } else if (valid_of(t)) {
+                    const f4 rs = (f4){rstd[t], rstd[t], rstd[t], rstd[t]}, nm = (f4){nmr[t], nmr[t], nmr[t], nmr[t]};
+                    f4 u = __builtin_elementwise_fma(X[cb][t], rs, nm);          // packed f32
+                    if constexpr (TRAIN) {                // x-hat is what the backward needs (LayerNorm backward directly; the
+                        const int gr = grow_of(t);        // weight gradients rebuild U = alpha * x-hat + beta from it)
+                        if (gr >= 0) *reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb) = u;
+                    }
+                    if (alpha) u = __builtin_elementwise_fma(u, al, be);
+                    if (PREC == 1 && alpha) {
+                        // token-mix operand, bf16x3: the contraction runs over ROWS, so the MFMA A operand needs 8
+                        // consecutive source rows of one channel in 16 contiguous bytes: UT[row/8][channel][row%8]
+                        // slot of channel (g, j) inside its 16-channel block is 4*j + g (bit-fields swapped), so the four lane
+                        // groups of one ds_write_b16 hit four different 16-byte slots instead of two
+                        __bf16* Th = reinterpret_cast<__bf16*>(U);
+                        __bf16* Tl = Th + NG * kGrpStride;
+                        const int r = row_of(t);
+                        const int o = (r >> 3) * kGrpStride + (64 * w + 16 * cb + g) * 8 + (r & 7);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const __bf16 hi = (__bf16)u[j];
+                            Th[o + 32 * j] = hi;
+                            Tl[o + 32 * j] = (__bf16)(u[j] - (float)hi);
+                        }
+                    } else if (PREC == 1 && !alpha) {
+                        // bf16x3 operand: u = hi + lo (+ O(2^-17 |u|)), hi = bf16_rne(u), lo = bf16_rne(u - hi);
+                        // two bf16 planes [R][520] in the space of the fp32 buffer
+                        __bf16* Uh = reinterpret_cast<__bf16*>(U);
+                        __bf16* Ul = Uh + R * kUStride;
+                        bf4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            hi[j] = (__bf16)u[j];
+                            lo[j] = (__bf16)(u[j] - (float)hi[j]);
+                        }
+                        *reinterpret_cast<bf4*>(&Uh[row_of(t) * kUStride + chw + 16 * cb]) = hi;
+                        *reinterpret_cast<bf4*>(&Ul[row_of(t) * kUStride + chw + 16 * cb]) = lo;
+                    } else {
+                        *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                    }
+                }
+        }
+    };
+
+    // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
+    for (int l = 0; l < a.layers; ++l) {
+        fresh();
+        if constexpr (TRAIN) {
+            // every sample has its own diffusion timestep: the two halves of the workgroup add different embedding rows
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                const int sample = min(2 * b + (row_of(t) >= S ? 1 : 0), a.tr_B - 1);
+                const float* te = a.temb + (size_t)sample * a.temb_stride + chw;
+                if (valid_of(t))
+#pragma unroll
+                    for (int cb = 0; cb < kCB; ++cb) X[cb][t] += *reinterpret_cast<const f4*>(te + 16 * cb);
+            }
+        } else {   // x = x + emb  (emb re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
+            const float* te = a.temb + (size_t)b * a.temb_stride + chw;
+            f4 e[kCB];
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) e[cb] = *reinterpret_cast<const f4*>(te + 16 * cb);
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t)
+                    if (valid_of(t)) X[cb][t] += e[cb];
+        }
+        // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
+        f4 alv[kCB], bev[kCB];                      // LN1 affine: in flight during the statistics and their barrier
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb) {
+            alv[cb] = *g4(a.W->ln1a + l * kD + chw + 16 * cb);
+            bev[cb] = *g4(a.W->ln1b + l * kD + chw + 16 * cb);
+        }
+        ln_stats(TRAIN ? a.tr_s1 + (size_t)l * a.tr_B * S * 2 : nullptr);
+        stamp(2 + 8 * l);
+        fresh();
+        ln_store(a.W->ln1a + l * kD, alv, bev, TRAIN ? a.tr_x1 + (size_t)l * a.tr_B * S * kD : nullptr);
+        // no workgroup barrier here: token mixing contracts over ROWS, so wave w only reads back the 64 channel columns
+        // it has just written itself (LDS operations of one wave execute in order); the LN statistics barrier above
+        // already ordered these stores after every wave's reads of the previous operand.
+        __builtin_amdgcn_wave_barrier();
+        stamp(3 + 8 * l);
+        fresh();
+        // out[d][r] = sum_r' u[r'][d] * WW[r][r']  as D[channel][row]: A = u^T from LDS, B = the block-diagonal
+        // token weights (same for every workgroup, L1/L2 resident).  Tile by tile so only 18 B + 16 acc
+        // registers are live; the k range of a tile covers just the sequence(s) whose rows it holds.
+        if constexpr (PREC == 1) {
+            if (!LS_ABLATED(a, 2)) {
+                const __bf16* Th = reinterpret_cast<const __bf16*>(U);
+                const __bf16* Tl = Th + NG * kGrpStride;
+                const int slot = ((s16 & 3) << 2) | (s16 >> 2);      // channel i = 4g'+j' of a block lives in slot 4j'+g'
+                gbf8p wwh = (gbf8p)(const bf8*)(a.W->ww_hi_img) + (size_t)l * kNT * KS * 64 + lane;
+                gbf8p wwl = (gbf8p)(const bf8*)(a.W->ww_lo_img) + (size_t)l * kNT * KS * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    const float bt = valid_of(t) ? g1(a.W->btok_rows)[l * 80 + row_of(t)] : 0.f;
+                    f4 acc[kCB];
+#pragma unroll
+                    for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){bt, bt, bt, bt};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (tokmix_needed32(S, t, ks)) {
+                            const bf8 Bh = wwh[(t * KS + ks) * 64], Bl = wwl[(t * KS + ks) * 64];
+                            const int grp = (4 * ks + 3 < NG || 4 * ks + g < NG) ? 4 * ks + g : NG - 1;   // clamp: weights are 0 there
+                            const int ao = grp * kGrpStride + (64 * w + slot) * 8;
+                            bf8 Ah[kCB], Al[kCB];
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) {
+                                Ah[cb] = *reinterpret_cast<const bf8*>(Th + ao + 16 * cb * 8);
+                                Al[cb] = *reinterpret_cast<const bf8*>(Tl + ao + 16 * cb * 8);
+                            }
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[cb], Bh, acc[cb], 0, 0, 0);
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[cb], Bl, acc[cb], 0, 0, 0);
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[cb], Bh, acc[cb], 0, 0, 0);
+                        }
+                    }
+                    if (valid_of(t)) {
+#pragma unroll
+                        for (int cb = 0; cb < kCB; ++cb)
+                            X[cb][t] = silu_acc4(acc[cb], X[cb][t]);
+                    }
+                }
+            }
+        } else if (!LS_ABLATED(a, 2)) {
+            gfp wwp = g1(a.W->ww_img) + (size_t)l * kNT * MK * 64 + lane;
+            const float* up = U + 64 * w + s16;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                float Bt[MK];
+#pragma unroll
+                for (int m = 0; m < MK; ++m)
+                    if (tokmix_needed(S, t, m)) Bt[m] = wwp[(t * MK + m) * 64];
+                const float bt = valid_of(t) ? g1(a.W->btok_rows)[l * 80 + row_of(t)] : 0.f;    // Conv1d bias of this row
+                f4 acc[kCB];
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb) acc[cb] = (f4){bt, bt, bt, bt};
+#pragma unroll
+                for (int m = 0; m < MK; ++m) {
+                    if (tokmix_needed(S, t, m)) {
+                        const int srow = (4 * m + 3 < R || 4 * m + g < R) ? 4 * m + g : R - 1;
+#pragma unroll
+                        for (int cb = 0; cb < kCB; ++cb)
+                            acc[cb] = MFMA(up[srow * kUStride + 16 * cb], Bt[m], acc[cb]);
+                    }
+                }
+                if (valid_of(t)) {
+                    if constexpr (TRAIN) {                // pre-activation of the token-mixing conv, for SiLU'
+                        const int gr = grow_of(t);
+                        if (gr >= 0) {
+                            float* dst = a.tr_a1 + ((size_t)l * a.tr_B * S + gr) * kD + chw;
+#pragma unroll
+                            for (int cb = 0; cb < kCB; ++cb) *reinterpret_cast<f4*>(dst + 16 * cb) = acc[cb];
+                        }
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < kCB; ++cb)
+                        X[cb][t] = silu_acc4(acc[cb], X[cb][t]);
+                }
+            }
+        }
+        stamp(4 + 8 * l);
+        fresh();
+        // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
+        f4 alv2[kCB], bev2[kCB];
+        if constexpr (TRAIN) {   // training keeps LN2's affine explicit (alpha2 / beta2 get their own gradients)
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                alv2[cb] = *g4(a.W->ln2a + l * kD + chw + 16 * cb);
+                bev2[cb] = *g4(a.W->ln2b + l * kD + chw + 16 * cb);
+            }
+        }
+        ln_stats(TRAIN ? a.tr_s2 + (size_t)l * a.tr_B * S * 2 : nullptr);
+        stamp(5 + 8 * l);      // its two barriers also order every wave's token-mix reads before the stores below
+        ln_store(TRAIN ? a.W->ln2a : nullptr, alv2, bev2, TRAIN ? a.tr_x2 + (size_t)l * a.tr_B * S * kD : nullptr);
+        __syncthreads();
+        stamp(6 + 8 * l);
+        if constexpr (PREC == 1) {
+            // ---- bf16x3 split precision: W'.u ~= hi_w.hi_u + hi_w.lo_u + lo_w.hi_u on v_mfma_f32_16x16x32_bf16 (fp32
+            // accumulate; bf16 x bf16 products are exact in fp32; the dropped lo.lo term and the split residuals are
+            // O(2^-16) relative).  These MFMAs run on the bf16 matrix cores, which do NOT share lanes with the fp32
+            // VALU work of the other phases, and all 5 token tiles are cheap enough to run padded.
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fresh();
+                f4 acc[2][kNT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t) acc[c2][t] = bc;
+                }
+                const size_t wofs = ((size_t)((l * kWaves + w) * 2 + p) * 16) * 2 * 64 + lane;
+                gbf8p wh = (gbf8p)(const bf8*)(a.W->wch_hi_img) + wofs;
+                gbf8p wl = (gbf8p)(const bf8*)(a.W->wch_lo_img) + wofs;
+                const __bf16* Uh = reinterpret_cast<const __bf16*>(U);
+                const __bf16* Ul = Uh + R * kUStride;
+                int rofs[kNT];
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) rofs[t] = rowc_of(t) * kUStride + 8 * g;
+                bf8 Ahn[2], Aln[2];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) { Ahn[c2] = wh[c2 * 64]; Aln[c2] = wl[c2 * 64]; }
+                if (!LS_ABLATED(a, 1))
+#pragma unroll 2
+                for (int q = 0; q < 16; ++q) {
+                    bf8 Ah[2], Al[2], Bh[kNT], Bl[kNT];
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) { Ah[c2] = Ahn[c2]; Al[c2] = Aln[c2]; }
+                    const int qn = (q + 1 < 16) ? q + 1 : 15;
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) { Ahn[c2] = wh[(qn * 2 + c2) * 64]; Aln[c2] = wl[(qn * 2 + c2) * 64]; }
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t) {
+                        Bh[t] = *reinterpret_cast<const bf8*>(Uh + rofs[t] + 32 * q);
+                        Bl[t] = *reinterpret_cast<const bf8*>(Ul + rofs[t] + 32 * q);
+                    }
+                    // term-major order: 10 independent accumulators between two MFMAs on the same one
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t)
+                            acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[t], acc[c2][t], 0, 0, 0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t)
+                            acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[t], acc[c2][t], 0, 0, 0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kNT; ++t)
+                            acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[t], acc[c2][t], 0, 0, 0);
+                }
+                fresh();
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t)
+                        if (valid_of(t)) {
+                            X[2 * p + c2][t] = silu_acc4(acc[c2][t], X[2 * p + c2][t]);
+                        }
+                if (p == 0) stamp(7 + 8 * l);
+            }
+        } else {
+        // Rows 64..R-1 (6 of the 16 rows of tile 4) would waste 62 % of a fifth MFMA tile = 20 % of all channel-mix
+        // MFMAs.  They are computed instead on the VALU pipe, in the shadow of the MFMAs of tiles 0..3, from the
+        // same A-operand registers: lane (n, g) accumulates W[n][k(g)] * U[row][k(g)] over its k subset, the four
+        // lane groups are summed with two cross-lane adds, and a 6 KB per-wave LDS patch turns [channel-lane][row]
+        // into the residual layout [row-lane][channel-reg].
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            fresh();
+            f4 acc[2][kFullTiles];
+            float racc[2][NRV];
+            f4 racc4[2][NRG];
+            f4 bcv[2];                                    // Linear bias (+ W.beta of LN2); kept for the ragged rows' epilogue
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));
+                bcv[c2] = bc;
+#pragma unroll
+                for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = bc;
+#pragma unroll
+                for (int r = 0; r < NRV; ++r) racc[c2][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < NRG; ++r) racc4[c2][r] = (f4){0.f, 0.f, 0.f, 0.f};
+            }
+            gf4p wp = g4(a.W->wch_img) + ((size_t)((l * kWaves + w) * 2 + p) * 32) * 2 * 64 + lane;
+            const float* ub = U + s16 * kUStride + 4 * g;                 // tile t: + 16*t*kUStride
+            // VALU path: remainder row r at + r*kUStride (all lanes the same row); MFMA path: lane's row (lane&3) of group rg at + 4*rg*kUStride
+            const float* ur = U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g;
+            f4 An[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
+            if (!LS_ABLATED(a, 1))
+#pragma unroll 2
+            for (int q = 0; q < 32; ++q) {
+                f4 A[2], Bv[kFullTiles], Ur[kRemMfma ? NRG : NRV];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
+                {
+                    const int qn = (q + 1 < 32) ? q + 1 : 31;       // branch-free prefetch (last one re-reads q=31)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[(qn * 2 + c2) * 64];
+                }
+#pragma unroll
+                for (int t = 0; t < kFullTiles; ++t)
+                    Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
+#pragma unroll
+                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r)
+                    Ur[r] = *reinterpret_cast<const f4*>(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
+                // Per k: [8 MFMAs][2*NREM scalar FMAs], order pinned.  A/B-tested on MI355X (tools/ab_variants.py, ms/step
+                // at B=512): this 1.513 | [32 MFMA][8*NREM FMA] 1.526 | compiler's own order 1.627 (it hoists the FMAs
+                // next to their ds_reads and stalls) | fine 2:3 interleave 1.646 | 5th MFMA tile instead of FMAs 1.645.
+                // fp32 MFMA and fp32 VALU share the SIMD's FMA lanes on gfx950 (removing the FMAs saves exactly their
+                // issue time), so the gain is the padding saved (6 rows of work instead of 16), not overlap; v_pk_fma_f32,
+                // v_mfma_f32_4x4x1_16b (16 cycles/issue: 1.518 with rows padded to 8)
+                // and s_setprio alternation between the two waves of a SIMD were measured and do not help.
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        if constexpr (kRemMfma) {
+                            // block (g, n>>2) = {4 channels} x {4 rows} over the lane's own k subset: the A operand is the
+                            // same register the 16x16x4 MFMAs use
+#pragma unroll
+                            for (int r = 0; r < NRG; ++r)
+                                racc4[c2][r] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[c2][j], Ur[r][j], racc4[c2][r], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NRV; ++r) racc[c2][r] = fmaf(A[c2][j], Ur[r][j], racc[c2][r]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fresh();
+            // remainder rows: sum the 4 k-subsets, then [channel-lane][row] -> [row-lane][channel-reg] through LDS
+            float* rem = REM + w * (2 * NREM * 16);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                if constexpr (kRemMfma) {
+#pragma unroll
+                    for (int r = 0; r < NRG; ++r) {
+                        f4 v = racc4[c2][r];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = xor32_sum(xor16_sum(v[i]));
+                        }
+                        // lane (block = lane>>2, row = lane&3) holds channels 4*(s16>>2)..+3 of row 4r + (lane&3)
+                        if (g == 0) *reinterpret_cast<f4*>(&rem[(c2 * NREM + 4 * r + (lane & 3)) * 16 + 4 * (s16 >> 2)]) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NRV; ++r) {
+                        float v = racc[c2][r];
+                        v = xor32_sum(xor16_sum(v));
+                        if (g == 0) rem[(c2 * NREM + r) * 16 + s16] = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int cb = 2 * p + c2;
+                const f4 bc = bcv[c2];
+#pragma unroll
+                for (int t = 0; t < kFullTiles; ++t) {
+                    if constexpr (TRAIN) {                // pre-activation of the channel-mixing linear
+                        const int gr = grow_of(t);
+                        if (gr >= 0) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = acc[c2][t];
+                    }
+                    X[cb][t] = silu_acc4(acc[c2][t], X[cb][t]);
+                }
+                if (s16 < NREM) {
+                    const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
+                    if constexpr (TRAIN) {
+                        const int gr = grow_of(kFullTiles);
+                        if (gr >= 0) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = rv + bc;
+                    }
+                    X[cb][kFullTiles] = silu_acc4(rv + bc, X[cb][kFullTiles]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (p == 0) stamp(7 + 8 * l);
+        }
+        }
+        stamp(9 + 8 * l);
+        dump_trace(l + 1);
+    }
+
+    if constexpr (TRAIN) {         // poseFinal, the losses and everything else downstream are batch-level kernels
+        store_rows(a.tr_xout, 0);
+        return;
+    }
+    // ================= OutputProcess.poseFinal (RAG.py:205-211) ====================================
+    stamp(2 + 8 * a.layers);
+    fresh();
+    __syncthreads();                       // every wave is done reading the last LN2 operand: U is free
+    constexpr bool kOutFromRegs = (NOB <= 2);
+    constexpr int OROWS = kOutFromRegs ? kWaves * R : R;      // rows of the OUT / partial buffer overlaid on U
+    static_assert(OROWS * OSTR <= R * kUStride, "OUT overlay must fit the operand buffer");
+    float* OUT = U;
+    if constexpr (kOutFromRegs) {
+        // Narrow output (TED, 27 features): every wave contracts over ITS OWN 64 channels straight from the residual
+        // registers (the residual layout is a valid MFMA B operand; the weight image carries the matching k
+        // permutation), writes a [R][32] partial, and the 8 partials are summed in the epilogue below.  No x -> LDS
+        // round trip, no latency-bound k loop on two waves.
+        f4 acc[NOB][kNT];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) acc[ob][t] = (f4){0.f, 0.f, 0.f, 0.f};
+        gf4p wr = g4(a.W->wout_reg_img) + (size_t)w * NOB * kCB * 64 + lane;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                const f4 A = wr[(ob * kCB + cb) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < kNT; ++t) acc[ob][t] = MFMA(A[j], X[cb][t][j], acc[ob][t]);
+            }
+        stamp(3 + 8 * a.layers);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int t = 0; t < kNT; ++t)
+                if (valid_of(t))
+                    *reinterpret_cast<f4*>(&OUT[(w * R + row_of(t)) * OSTR + 16 * ob + 4 * g]) = acc[ob][t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+            if (valid_of(t))
+#pragma unroll
+                for (int cb = 0; cb < kCB; ++cb)
+                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = X[cb][t];
+        __syncthreads();
+        f4 res[MAXU];
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = w + kWaves * i;      // wave-uniform
+            res[i] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (u < NU) {
+                const int ob = u / kNT, t = u - ob * kNT;
+                const int rc = (16 * t + s16 < R) ? 16 * t + s16 : R - 1;
+                gf4p wp = g4(a.W->wout_img) + (size_t)ob * 32 * 64 + lane;
+                const float* up = &U[rc * kUStride + 4 * g];
+                f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll 4
+                for (int q = 0; q < 32; ++q) {
+                    const f4 A = wp[q * 64];
+                    const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * q);
+                    a0 = MFMA(A[0], Bv[0], a0);
+                    a1 = MFMA(A[1], Bv[1], a1);
+                    a0 = MFMA(A[2], Bv[2], a0);
+                    a1 = MFMA(A[3], Bv[3], a1);
+                }
+                res[i] = a0 + a1;
+            }
+        }
+        stamp(3 + 8 * a.layers);
+        fresh();
+        __syncthreads();                       // operand buffer is free: overlay OUT[row][c]
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = w + kWaves * i;
+            if (u < NU) {
+                const int ob = u / kNT, t = u - ob * kNT;
+                const int r = 16 * t + s16;
+                if (r < R) *reinterpret_cast<f4*>(&OUT[r * OSTR + 16 * ob + 4 * g]) = res[i];
+            }
+        }
+    }
+    __syncthreads();
+    auto out_at = [&](int r, int c) {
+        if constexpr (kOutFromRegs) {
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) v += OUT[(ww * R + r) * OSTR + c];
+            return v;
+        } else {
+            return OUT[r * OSTR + c];
+        }
+    };
+
+    // ====== CFG lerp (cfg_sampler.py:31) + posterior / DDIM update (gaussian_diffusion.py:260-282,
+    //        507-558, 745-798), written back in the internal [B][T][JF] layout ======================
+    {
+        const float sc = (!PAIR && a.scale) ? a.scale[b] : 1.0f;
+        const unsigned long long goff = a.call ? a.call->sample_offset : 0ull;
+        for (int idx0 = tid; idx0 < (PAIR ? 2 : 1) * kT * JF; idx0 += 512) {
+            const int sq = (PAIR && idx0 >= kT * JF) ? 1 : 0;
+            const int idx = idx0 - sq * kT * JF;
+            const int smp = PAIR ? 2 * b + sq : b;
+            if (PAIR && smp >= a.batch) break;
+            const size_t base = (size_t)smp * kT * JF;
+            const unsigned long long gidx = goff + (unsigned long long)smp;
+            const int f = idx / JF, c = idx - f * JF;
+            const float bo = g1(a.W->bout)[c];
+            float x0;
+            if constexpr (PAIR) {
+                x0 = out_at(sq * S + NPRE + f, c) + bo;           // scale == 1: the CFG combination is the cond output
+            } else {
+                const float oc = out_at(NPRE + f, c) + bo;
+                const float ou = out_at(S + NPRE + f, c) + bo;
+                if (a.fwd_c) a.fwd_c[base + idx] = oc;
+                if (a.fwd_u) a.fwd_u[base + idx] = ou;
+                x0 = ou + sc * (oc - ou);
+            }
+            if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (a.x0_out) a.x0_out[base + idx] = x0;
+            if (a.sampler != kNone) {
+                const float xt = a.x_in[base + idx];
+                float nz = 0.f;
+                if (a.t_nonzero) {
+                    if (a.noise) {
+                        const size_t bn = a.const_noise ? 0 : (size_t)smp;
+                        nz = a.noise[(bn * JF + c) * kT + f];
+                    } else {
+                        nz = philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(c * kT + f));
+                    }
+                }
+                float xn;
+                if (a.sampler == kDDPM) {
+                    xn = a.c0 * x0 + a.c1 * xt;
+                    if (a.t_nonzero) xn += a.c2 * nz;
+                } else {
+                    const float eps = (a.c0 * xt - x0) / a.c1;
+                    xn = x0 * a.c2 + a.c3 * eps;
+                    if (a.t_nonzero) xn += a.c4 * nz;
+                }
+                a.x_out[base + idx] = xn;
+            }
+        }
+    }
+    stamp(4 + 8 * a.layers);
+}
+
+}  // namespace ls

@@ -1,5 +1,5 @@
 // Training-step internals: strided GEMM arguments and kernel launchers shared by
-// ls_train_gemm.hip, ls_train_kernels.hip and ls_train_api.cpp.
+// ls_gemm.hip, ls_train_kernels.hip and ls_train_api.cpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <climits>

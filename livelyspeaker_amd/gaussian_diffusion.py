@@ -85,6 +85,8 @@ class GaussianDiffusion:
 
     noise_source = "torch_cpu"      # or "philox"
     use_graph = True
+    philox_seed = None              # philox mode: None = draw the key from torch's generator per call
+    last_philox_seed = None
 
     def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False,
                  lambda_rcxyz=0., lambda_vel=0., lambda_pose=1., lambda_orient=1., lambda_loc=1.,
@@ -210,13 +212,21 @@ class GaussianDiffusion:
             x_init = th.randn(*shape)
             if const_noise:
                 x_init = x_init[[0]].repeat(B, 1, 1, 1)
+        # the reference appends pred_xstart whenever the loop counter is `in dump_steps` (gaussian_diffusion.py:660-671): execution
+        # order, duplicates and out-of-range entries have no effect
+        want_dumps = dump_steps is not None
+        dump_steps = sorted({int(d) for d in dump_steps if 0 <= int(d) < n_exec}) if dump_steps else None
         kw = dict(sampler=sampler, x_init=x_init, init_image=init_image, skip_timesteps=skip_timesteps, eta=eta,
-                  const_noise=const_noise, dump_steps=list(dump_steps) if dump_steps else None,
+                  const_noise=const_noise, dump_steps=dump_steps or None,
                   use_graph=self.use_graph, clip_denoised=clip_denoised)
         if philox:
             if const_noise:
                 raise NotImplementedError("const_noise needs noise_source='torch_cpu'")
-            kw["philox_seed"] = int(th.randint(0, 2 ** 62, (1,)).item())
+            # one 62-bit key per call from torch's generator (torch.manual_seed reproduces a run); `philox_seed` pins it
+            # instead (replaying a call, e.g. a shard of a multi-GPU batch on another GPU); the key used is kept for checkers
+            drawn = int(th.randint(0, 2 ** 62, (1,)).item())
+            self.last_philox_seed = drawn if self.philox_seed is None else int(self.philox_seed)
+            kw["philox_seed"] = self.last_philox_seed
             kw["sample_offset"] = int(getattr(self, "sample_offset", 0))
         else:
             eps = th.empty(n_exec, 2, B, eng.D)
@@ -234,8 +244,8 @@ class GaussianDiffusion:
             kw["eps_tape"], kw["noise_tape"] = eps, nz
         kw["device_out"] = th.device(device).type == "cuda"
         res = eng.sample(**kw)
-        if dump_steps:
-            return [_as_tensor(d, device).clone() for d in res[1]]
+        if want_dumps:
+            return [_as_tensor(d, device).clone() for d in res[1]] if dump_steps else []
         return _as_tensor(res, device)
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,

@@ -104,8 +104,17 @@ class TrainLoop:
 
     def _load_optimizer_state(self):
         path = os.path.join(os.path.dirname(self.resume_checkpoint), f"opt{self.resume_step:09}.pt")
+        lr = None
         if os.path.exists(path):
-            self.trainer.load_optimizer_state(torch.load(path, map_location="cpu"))
+            st, lr = unpack_optimizer_state(self.model, torch.load(path, map_location="cpu"))
+            if st["exp_avg"]:
+                self.trainer.load_optimizer_state(st)
+        # opt.load_state_dict restores the annealed lr of the last executed step through param_groups (train_loop.py:96-104);
+        # without an optimizer file, recompute what _anneal_lr left there: step index resume_step - 1
+        if lr is not None:
+            self.cur_lr = lr
+        elif self.lr_anneal_steps:
+            self.cur_lr = self.lr * (1 - (self.resume_step - 1) / self.lr_anneal_steps)
 
     def sync_model(self):
         """Copy the trained master parameters back into ``self.model`` (so sampling / state_dict() see them)."""
@@ -168,14 +177,69 @@ class TrainLoop:
         return f"model{(self.step + self.resume_step):09d}.pt"
 
     def save(self):
+        """model%09d.pt / opt%09d.pt in the REFERENCE's formats (train_loop.py:203-227), so either side can resume the other's run:
+        the model file is ``master_params_to_state_dict`` (every state-dict entry incl. the ``*.pe`` buffers, trained values under
+        the parameter keys); the optimizer file is ``torch.optim.AdamW.state_dict()`` (state[i] in parameter order + param_groups
+        with the current, possibly annealed, lr)."""
         if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
             return
-        sd = {k: torch.from_numpy(v) for k, v in self.trainer.state_dict().items()}
         os.makedirs(self.save_dir, exist_ok=True)
-        torch.save(sd, os.path.join(self.save_dir, self.ckpt_file_name()))
-        st = self.trainer.optimizer_state()                     # tensors only, so torch.load(weights_only=True) accepts the file
-        st = {"step": st["step"], **{n: {k: torch.from_numpy(v) for k, v in st[n].items()} for n in ("exp_avg", "exp_avg_sq")}}
-        torch.save(st, os.path.join(self.save_dir, f"opt{(self.step + self.resume_step):09d}.pt"))
+        torch.save(pack_model_checkpoint(self.model, self.trainer.state_dict()), os.path.join(self.save_dir, self.ckpt_file_name()))
+        torch.save(pack_optimizer_state(self.model, self.trainer.optimizer_state(), self.cur_lr, self.weight_decay),
+                   os.path.join(self.save_dir, f"opt{(self.step + self.resume_step):09d}.pt"))
+
+
+def _param_keys(model):
+    """Parameter keys in optimizer order = ``model.parameters()`` order without CLIP (train_loop.py:57-59, fp16_util.py:140-150)."""
+    return [k for k, _ in model.named_parameters() if not k.startswith("clip_model.")]
+
+
+def pack_model_checkpoint(model, trained: dict) -> dict:
+    """What ``MixedPrecisionTrainer.master_params_to_state_dict`` + ``save_checkpoint`` write (fp16_util.py:189-196,
+    train_loop.py:204-216): ``model.state_dict()`` with the trained values substituted, CLIP weights dropped."""
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.startswith("clip_model."):
+            continue
+        sd[k] = (torch.as_tensor(trained[k]).reshape(v.shape).to(v.dtype) if k in trained else v.detach().cpu()).clone()
+    return sd
+
+
+def pack_optimizer_state(model, opt: dict, lr: float, weight_decay: float) -> dict:
+    """``torch.optim.AdamW.state_dict()`` layout from the engine's {'step', 'exp_avg', 'exp_avg_sq'} (keys = state-dict names)."""
+    keys = _param_keys(model)
+    shapes = dict(model.named_parameters())
+    state = {}
+    if opt["step"] > 0:
+        for i, k in enumerate(keys):
+            state[i] = {"step": torch.tensor(float(opt["step"])),
+                        "exp_avg": torch.as_tensor(opt["exp_avg"][k]).reshape(shapes[k].shape).clone(),
+                        "exp_avg_sq": torch.as_tensor(opt["exp_avg_sq"][k]).reshape(shapes[k].shape).clone()}
+    group = {"lr": float(lr), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": float(weight_decay), "amsgrad": False,
+             "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(keys)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def unpack_optimizer_state(model, st: dict):
+    """Either layout -> ({'step', 'exp_avg', 'exp_avg_sq'}, lr or None): torch's AdamW state_dict (what the reference writes) or
+    this package's round-1 files ({'step', 'exp_avg': {key: tensor}, 'exp_avg_sq': {...}})."""
+    if "param_groups" not in st:
+        return {"step": int(st["step"]), "exp_avg": dict(st["exp_avg"]), "exp_avg_sq": dict(st["exp_avg_sq"])}, None
+    keys = _param_keys(model)
+    group = st["param_groups"][0]
+    order = list(group["params"])
+    if len(order) != len(keys):
+        raise ValueError(f"optimizer file holds {len(order)} parameters, the model has {len(keys)}")
+    out = {"step": 0, "exp_avg": {}, "exp_avg_sq": {}}
+    for pos, pid in enumerate(order):
+        ent = st["state"].get(pid)
+        if ent is None:
+            continue
+        out["step"] = int(float(ent["step"]))
+        out["exp_avg"][keys[pos]] = ent["exp_avg"]
+        out["exp_avg_sq"][keys[pos]] = ent["exp_avg_sq"]
+    return out, float(group["lr"])
 
 
 def parse_resume_step_from_filename(filename):

@@ -320,3 +320,40 @@ def test_philox_noise_is_standard_normal(big):
     b = eng.philox_x_init(256, seed=7, sample_offset=256)
     assert np.array_equal(b, a[256:].astype(np.float32))          # stream follows the global sample index
     assert not np.array_equal(eng.philox_x_init(256, seed=8, sample_offset=256), b)
+
+
+def test_conditioning_cache_hits_on_repeated_calls_and_dumps_follow_execution_order(monkeypatch):
+    """Step-by-step callers (model(x, t, y) / p_sample per step) must pay the once-per-call stage once: RAG.py:110's in-place
+    zeroing of origin_x must not invalidate the cache key on every call.  Also: dump_steps come back in execution order, with
+    out-of-range entries dropped, like the reference's `if i in dump_steps: dump.append(...)` (gaussian_diffusion.py:660-671)."""
+    import torch
+    from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
+    from livelyspeaker_amd.model_util import create_model_and_diffusion
+    cfg = synth.TED
+    model, diffusion = create_model_and_diffusion(_mk_args(cfg, 8), "")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}, strict=False)
+    model.to("cuda:0")
+    model.eval()
+    w = ClassifierFreeSampleModel(model)
+    y = {k: torch.from_numpy(v).to("cuda:0") for k, v in synth.make_cond(cfg, 4).items()}
+    assert bool((y["origin_x"][..., 4:] != 0).any())
+    eng = model.engine()
+    calls = []
+    real = eng.prepare
+    monkeypatch.setattr(eng, "prepare", lambda yy: (calls.append(1), real(yy))[1])
+    x = torch.randn(4, 9, 3, 34, device="cuda:0")
+    torch.manual_seed(1)
+    for i in (7, 6, 5):
+        x = diffusion.p_sample(w, x, torch.full((4,), i), clip_denoised=False, model_kwargs={"y": y})["sample"]
+    model(x, torch.full((4,), 3, device="cuda:0"), y=y)
+    assert len(calls) == 1, calls
+    assert not bool((y["origin_x"][..., 4:] != 0).any())                   # the reference's in-place side effect is kept
+    y["audio_input"].mul_(0.5)                                              # an in-place edit of the conditioning is noticed
+    model(x, torch.full((4,), 3, device="cuda:0"), y=y)
+    assert len(calls) == 2
+    torch.manual_seed(2)
+    a = diffusion.p_sample_loop(w, (4, 9, 3, 34), clip_denoised=False, model_kwargs={"y": y}, dump_steps=[5, 0, 99, 5, 2])
+    torch.manual_seed(2)
+    b = diffusion.p_sample_loop(w, (4, 9, 3, 34), clip_denoised=False, model_kwargs={"y": y}, dump_steps=[0, 2, 5])
+    assert len(a) == 3 and all(torch.equal(p, q) for p, q in zip(a, b))
+    assert diffusion.p_sample_loop(w, (4, 9, 3, 34), clip_denoised=False, model_kwargs={"y": y}, dump_steps=[]) == []

@@ -58,3 +58,34 @@ def test_livelyspeaker_pipeline_matches_chained_oracles():
     ofeat = evo.pose_encoder(synth.make_embedding_net_state_dict(27, 32), opost["aligned"])
     assert np.abs(feat - ofeat).max() < 2e-3 * max(1.0, float(np.abs(ofeat).max()))
     assert real.shape == (B, 34, 27)
+
+
+def test_bench_strong_scaling_path_under_torch_distributed_run(tmp_path):
+    """BASELINE configs[3]'s code path end to end on ONE rank: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1
+    --global-batch G` (RCCL process group, shard + all_gather inside the timed region, shard cross-check, in-run parity), next to
+    the plain weak-scaling invocation of the same workload: one JSON line each, values within a few percent."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--diffusion-steps", "100", "--no-cpu-baseline", "--no-extra-legs"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r1 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", "29611", os.path.join(root, "bench.py"), "--global-batch", "512"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    lines = [l for l in r1.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r1.stdout
+    strong = json.loads(lines[0])
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    weak = json.loads([l for l in r2.stdout.splitlines() if l.strip()][0])
+    print("strong:", strong["value"], strong["shard_check"], strong["parity_in_run"])
+    print("weak:  ", weak["value"], weak["parity_in_run"])
+    assert strong["scaling"] == "strong" and weak["scaling"] == "weak"
+    assert strong["rccl_ranks"] == 1 and strong["shard_check"]["bitwise_equal"]
+    assert strong["shard_check"]["checksum_recomputed"] == strong["shard_check"]["checksum_sharded"]
+    assert strong["parity_in_run"]["ok"] and weak["parity_in_run"]["ok"]
+    assert strong["config"]["global_batch"] == 512 and weak["config"]["global_batch"] == 512
+    assert abs(strong["value"] / weak["value"] - 1) < 0.05           # 100-step calls (150 ms): the gather and host jitter are visible

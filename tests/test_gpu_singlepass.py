@@ -1,0 +1,111 @@
+"""Single-pass sampling (guidance scale 1): when every y['scale'] == 1 the CFG combination out_u + 1 * (out_c - out_u) is the
+cond output (scripts/model/cfg_sampler.py:31), the callers run exactly that (scripts/test_RAG_ted.py:183,
+scripts_beat/test_RAG_beat.py:193), and the engine packs the cond pass of TWO samples into the workgroup that otherwise holds
+the cond + uncond pass of one.  Checked against fixtures G11 produced by the reference itself (which evaluates both passes),
+the CPU oracle, and the engine's own two-pass kernel."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, max_abs
+from livelyspeaker_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL_LOOP = 3e-4
+
+
+@pytest.fixture(scope="module")
+def golden_r2():
+    return {ds: np.load(os.path.join(GOLDEN, f"{ds}_golden_r2.npz")) for ds in ("ted", "beat")}
+
+
+def _engine(ds):
+    from livelyspeaker_amd import _lib
+    cfg = synth.CONFIGS[ds]
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
+    eng.load_state_dict(synth.make_state_dict(cfg))
+    return cfg, eng
+
+
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_scale1_loops_vs_reference_fixture(ds, golden_r2):
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg, eng = _engine(ds)
+    g = golden_r2[ds]
+    try:
+        B = 5                                            # odd: the last workgroup holds one sample
+        y = synth.make_cond(cfg, B, scale=1.0)
+        eng.prepare(y)
+        for key, steps, resp, ddim, skip, use_init in (("G11_scale1_ddpm50_B5_final", 50, "", False, 0, False),
+                                                       ("G11_scale1_ddim100_skip80_B5_final", 1000, "ddim100", True, 80, True)):
+            sch = orc.Schedule(steps, resp)
+            eng.set_schedule(sch)
+            tape = synth.NoiseTape(cfg, B, sch.num_timesteps - skip)
+            kw = dict(sampler=_lib.LS_SAMPLER_DDIM if ddim else _lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps,
+                      noise_tape=tape.noise, skip_timesteps=skip, init_image=synth.make_init_image(cfg, B) if use_init else None)
+            one = eng.sample(**kw)
+            assert eng.timing()["single_pass"] == 1
+            two = eng.sample(two_pass_always=True, **kw)
+            assert eng.timing()["single_pass"] == 0
+            d1, d2, d12 = max_abs(one, g[key]), max_abs(two, g[key]), max_abs(one, two)
+            print(f"{ds} {key}: single-pass vs reference {d1:.3e}, two-pass vs reference {d2:.3e}, single vs two {d12:.3e}")
+            assert d1 < TOL_LOOP and d2 < TOL_LOOP and d12 < 1e-4
+    finally:
+        eng.close()
+
+
+def test_single_pass_is_selected_only_when_every_scale_is_one():
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg, eng = _engine("ted")
+    try:
+        B = 6
+        eng.set_schedule(orc.Schedule(4, ""))
+        tape = synth.NoiseTape(cfg, B, 4)
+        y = synth.make_cond(cfg, B, scale=1.0)
+        y["scale"][3] = 1.5
+        eng.prepare(y)
+        mixed = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise)
+        assert eng.timing()["single_pass"] == 0
+        oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+        want = orc.sample_loop(oracle, orc.Schedule(4, ""), y, tape.x_init, tape.eps, tape.noise)
+        assert max_abs(mixed, want) < TOL_LOOP
+        # single steps take the same route (ls_step)
+        y1 = synth.make_cond(cfg, B, scale=1.0)
+        eng.prepare(y1)
+        a, a0 = eng.step(_lib.LS_SAMPLER_DDPM, 2, tape.x_init, tape.eps[0, 0], tape.eps[0, 1], tape.noise[0])
+        b, b0 = eng.step(_lib.LS_SAMPLER_DDPM, 2, tape.x_init, tape.eps[0, 0], tape.eps[0, 1], tape.noise[0], two_pass_always=True)
+        assert max_abs(a, b) < 1e-5 and max_abs(a0, b0) < 1e-5
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("B", [512, 511, 1])
+def test_single_pass_full_batch_vs_two_pass_and_oracle(B):
+    """Headline batch (even), odd and degenerate sizes in the throughput mode (Philox noise, hipGraph)."""
+    from livelyspeaker_amd import _lib
+    from oracle import philox_oracle as po
+    from oracle import rag_oracle as orc
+    cfg, eng = _engine("ted")
+    try:
+        steps, seed, off = 24, 77, 1000
+        y = synth.make_cond(cfg, B, scale=1.0)
+        sch = orc.Schedule(steps, "")
+        eng.set_schedule(sch)
+        eng.prepare(y)
+        one = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=off)
+        assert eng.timing()["single_pass"] == 1
+        two = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=off, two_pass_always=True)
+        d12 = max_abs(one, two)
+        pick = np.unique(np.array([0, B // 2, B - 1]))
+        eps, noise = po.step_tapes(seed, off + pick, steps, (cfg.njoints, cfg.nfeats, cfg.nframes))
+        x_T = po.x_init(seed, off + pick, cfg.jf, cfg.nframes, (cfg.njoints, cfg.nfeats))
+        oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+        want = orc.sample_loop(oracle, sch, {k: v[pick] for k, v in y.items()}, x_T, eps, noise)
+        d = max_abs(one[pick], want)
+        print(f"B={B}: single vs two-pass {d12:.3e}; single vs oracle (samples {pick.tolist()}) {d:.3e}")
+        assert d12 < 1e-4 and d < TOL_LOOP
+    finally:
+        eng.close()

@@ -136,7 +136,7 @@ def test_train_argument_errors():
 
 # ---------------------------------------------------------------------------------------------------------------
 # Host mirror: TrainLoop drop-in (scripts/train_utils/train_loop.py) driving the engine
-def _loop_fixture(tmp_path, steps_data, resume=""):
+def _loop_fixture(tmp_path, steps_data, resume="", lr_anneal_steps=0):
     import torch
     from types import SimpleNamespace
     from livelyspeaker_amd.model_util import create_model_and_diffusion
@@ -149,7 +149,7 @@ def _loop_fixture(tmp_path, steps_data, resume=""):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}, strict=False)
     model.to("cuda:0")
     model.train()
-    targs = SimpleNamespace(batch_size=B, lr=1e-4, weight_decay=0.0, lr_anneal_steps=0, log_interval=1000, save_interval=1000,
+    targs = SimpleNamespace(batch_size=B, lr=1e-4, weight_decay=0.0, lr_anneal_steps=lr_anneal_steps, log_interval=1000, save_interval=1000,
                             resume_checkpoint=resume, epochs=1, save_dir=str(tmp_path), overwrite=True, dataset="ted")
     return cfg, model, diffusion, TrainLoop(targs, None, model, diffusion, steps_data)
 
@@ -197,7 +197,10 @@ def test_trainloop_reproduces_oracle_trajectory_with_reference_draw_order():
     assert np.abs(w - synth.make_state_dict(cfg)["output_process.poseFinal.weight"]).max() > 1e-5     # it did train
 
 
-def test_trainloop_checkpoint_resume_is_bit_identical(tmp_path):
+@pytest.mark.parametrize("anneal", [0, 10])
+def test_trainloop_checkpoint_resume_is_bit_identical(tmp_path, anneal):
+    """Also with lr annealing on: the resumed run must continue with the annealed lr of the last executed step (restored from
+    the optimizer file's param_groups like opt.load_state_dict does, train_loop.py:96-104), not restart at args.lr."""
     import torch
     cfg = synth.CONFIGS["ted"]
 
@@ -207,19 +210,24 @@ def test_trainloop_checkpoint_resume_is_bit_identical(tmp_path):
             loop.step += 1
 
     np.random.seed(3); torch.manual_seed(3)
-    _, _, _, full = _loop_fixture(tmp_path / "full", None)
+    _, _, _, full = _loop_fixture(tmp_path / "full", None, lr_anneal_steps=anneal)
     run(full, _batches(cfg, 4))
     ref = full.trainer.state_dict()
 
     np.random.seed(3); torch.manual_seed(3)
-    _, _, _, first = _loop_fixture(tmp_path / "ck", None)
+    _, _, _, first = _loop_fixture(tmp_path / "ck", None, lr_anneal_steps=anneal)
     run(first, _batches(cfg, 2))
     first.save()
     ck = os.path.join(str(tmp_path / "ck"), "model000000002.pt")
     assert os.path.exists(ck) and os.path.exists(os.path.join(str(tmp_path / "ck"), "opt000000002.pt"))
     rng_np, rng_t = np.random.get_state(), torch.get_rng_state()
-    _, _, _, second = _loop_fixture(tmp_path / "ck", None, resume=ck)
+    saved = torch.load(ck, map_location="cpu")
+    assert sum(k.endswith(".pe") for k in saved) == 3                 # the reference's loader requires the buffers
+    osd = torch.load(os.path.join(str(tmp_path / "ck"), "opt000000002.pt"), map_location="cpu")
+    assert set(osd) == {"state", "param_groups"} and len(osd["state"]) == len(osd["param_groups"][0]["params"])
+    _, _, _, second = _loop_fixture(tmp_path / "ck", None, resume=ck, lr_anneal_steps=anneal)
     assert second.resume_step == 2 and second.trainer.optimizer_state()["step"] == 2
+    assert second.cur_lr == first.cur_lr
     np.random.set_state(rng_np); torch.set_rng_state(rng_t)
     run(second, _batches(cfg, 2, start=2))
     got = second.trainer.state_dict()

@@ -87,6 +87,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.ls_abi_version() == 1
 
 
+def test_shipped_library_has_no_debug_switches():
+    """Ablation / phase-stamp code exists only in -DLS_DEBUG variants built by tools/: the shipped binary reads no LS_*
+    environment variable (an env var must never be able to make the product fast and wrong), and the Python loader has
+    no environment override of which binary it binds."""
+    blob = open(_lib.library_path(), "rb").read()
+    for name in (b"LS_ABLATE", b"LS_PROF", b"LS_LIB"):
+        assert name not in blob, name
+    assert b"getenv" not in blob
+    src = open(os.path.join(ROOT, "livelyspeaker_amd", "_lib.py")).read()
+    assert "os.environ" not in src
+    for f in ("ls_api.cpp", "ls_sag_api.cpp", "ls_train_api.cpp"):
+        text = open(os.path.join(ROOT, "livelyspeaker_amd", "csrc", f)).read()
+        for m in re.finditer(r"getenv", text):
+            before = text[:m.start()]
+            assert before.rfind("#ifdef LS_DEBUG") > before.rfind("#endif"), f"{f}: getenv outside an LS_DEBUG block"
+
+
 def test_abi_struct_sizes_match_header_layout():
     assert ctypes.sizeof(_lib.LsConfig) == 48
     assert ctypes.sizeof(_lib.LsSchedule) == 8 + 10 * 8
@@ -94,7 +111,7 @@ def test_abi_struct_sizes_match_header_layout():
     assert ctypes.sizeof(_lib.LsSampleArgs) == 40 + 2 * 8 + 4 * 8 + 2 * 8 + 8
     assert ctypes.sizeof(_lib.LsForwardArgs) == 8 + 8 * 8
     assert ctypes.sizeof(_lib.LsStepArgs) == 24 + 6 * 8
-    assert ctypes.sizeof(_lib.LsTiming) == 20
+    assert ctypes.sizeof(_lib.LsTiming) == 24
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
@@ -245,3 +262,72 @@ def test_build_staleness_is_content_based(tmp_path, monkeypatch):
     assert b.is_stale()
     stamp.unlink()
     assert b.is_stale() == any(os.path.getmtime(d) > os.path.getmtime(b.LIB) for d in [os.path.join(b.CSRC, s) for s in b.SOURCES] + b.HEADERS)
+
+
+def test_checkpoint_files_interchange_with_the_reference(tmp_path):
+    """model%09d.pt must pass the reference's `load_model_wo_clip` (no unexpected keys, only clip_model.* may be missing) and
+    opt%09d.pt must load into a `torch.optim.AdamW` over the reference model's parameters; and a file written by the reference's
+    optimizer must load back into the engine's layout.  Runs the reference's own loader when /root/reference is present (build
+    container); the layout checks against the mirror model run everywhere."""
+    import subprocess
+    import sys
+    from livelyspeaker_amd import synth, train_loop as tl
+    from livelyspeaker_amd.model_util import create_model_and_diffusion
+    cfg = synth.TED
+    model, _ = create_model_and_diffusion(_mk_args_local(cfg), "")
+    trained = {k: v + 1.0 for k, v in synth.make_state_dict(cfg).items()}
+    keys = tl._param_keys(model)
+    g = np.random.Generator(np.random.PCG64(11))
+    opt = {"step": 7, "exp_avg": {k: g.standard_normal(dict(model.named_parameters())[k].numel()).astype(np.float32) for k in keys},
+           "exp_avg_sq": {k: np.abs(g.standard_normal(dict(model.named_parameters())[k].numel())).astype(np.float32) for k in keys}}
+    msd = tl.pack_model_checkpoint(model, trained)
+    assert list(msd) == [k for k in model.state_dict() if not k.startswith("clip_model.")]
+    assert sum(k.endswith(".pe") for k in msd) == 3                      # the three PositionalEncoding buffers travel too
+    assert torch.equal(msd["input_mapping.weight"], torch.from_numpy(trained["input_mapping.weight"]))
+    ost = tl.pack_optimizer_state(model, opt, lr=3e-5, weight_decay=0.01)
+    ref_opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    ref_opt.load_state_dict(ost)                                          # torch's own loader accepts the layout
+    assert ref_opt.param_groups[0]["lr"] == 3e-5 and ref_opt.param_groups[0]["weight_decay"] == 0.01
+    back, lr = tl.unpack_optimizer_state(model, ref_opt.state_dict())     # ... and what torch writes loads back
+    assert lr == 3e-5 and back["step"] == 7
+    for k in keys:
+        assert np.array_equal(np.asarray(back["exp_avg"][k]).ravel(), opt["exp_avg"][k])
+        assert np.array_equal(np.asarray(back["exp_avg_sq"][k]).ravel(), opt["exp_avg_sq"][k])
+    old, lr_old = tl.unpack_optimizer_state(model, {"step": 3, "exp_avg": {"a": 1}, "exp_avg_sq": {"a": 2}})   # round-1 layout
+    assert old["step"] == 3 and lr_old is None
+    if not os.path.isdir("/root/reference/scripts"):
+        return
+    torch.save(msd, tmp_path / "model000000007.pt")
+    torch.save(ost, tmp_path / "opt000000007.pt")
+    code = f'''
+import sys, types, torch
+sys.dont_write_bytecode = True
+sys.modules["clip"] = types.ModuleType("clip")
+sys.path.insert(0, "/root/reference/scripts")
+from types import SimpleNamespace
+from mdm_utils.model_util import create_model_and_diffusion, load_model_wo_clip
+args = SimpleNamespace(mdm_condm="text", latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1, arch="trans_enc", emb_trans_dec=False,
+    dataset="humanml", lang_model=None, mlpact="silu", diffusion_steps=1000, noise_schedule="cosine", sigma_small=True, lambda_vel=1.0,
+    lambda_rcxyz=0.0, lambda_fc=0.0)
+model, _ = create_model_and_diffusion(args, "")
+load_model_wo_clip(model, torch.load(r"{tmp_path}/model000000007.pt", map_location="cpu"))        # asserts on unexpected / missing keys
+opt = torch.optim.AdamW(model.parameters_wo_clip() if hasattr(model, "parameters_wo_clip") else model.parameters(), lr=1e-4, weight_decay=0.0)
+opt.load_state_dict(torch.load(r"{tmp_path}/opt000000007.pt", map_location="cpu"))
+names = [k for k, _ in model.named_parameters()]
+assert float(opt.state[model.get_parameter(names[0])]["step"]) == 7.0
+assert tuple(opt.state[model.get_parameter("input_mapping.weight")]["exp_avg"].shape) == (512, 311)
+torch.save(opt.state_dict(), r"{tmp_path}/ref_opt.pt")
+print("REFERENCE-LOADER-OK", len(names))
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REFERENCE-LOADER-OK" in r.stdout, r.stderr[-2000:]
+    assert int(r.stdout.split("REFERENCE-LOADER-OK")[1].split()[0]) == len(keys)       # same parameter list, same order
+    back2, _ = tl.unpack_optimizer_state(model, torch.load(tmp_path / "ref_opt.pt", map_location="cpu"))
+    assert np.array_equal(np.asarray(back2["exp_avg"]["speaker_mu.bias"]).ravel(), opt["exp_avg"]["speaker_mu.bias"])
+
+
+def _mk_args_local(cfg):
+    from types import SimpleNamespace
+    return SimpleNamespace(mdm_condm="text", latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1, arch="trans_enc",
+                           emb_trans_dec=False, dataset="humanml", lang_model=None, mlpact="silu", diffusion_steps=1000,
+                           noise_schedule="cosine", sigma_small=True, lambda_vel=1.0, lambda_rcxyz=0.0, lambda_fc=0.0, njoints=cfg.njoints)

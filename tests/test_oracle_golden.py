@@ -103,3 +103,54 @@ def test_ted_dump_steps_and_full_ddim(golden):
 
 def test_ted_1000_step_ddpm(golden):
     assert max_abs(_loop("ted", 1000, "", False, 0, False), golden["ted"]["G5_ddpm1000_final"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# the torch-CPU port that bench.py's cpu_baseline leg times (oracle/rag_torch_cpu.py): both of its modes against the
+# reference-generated fixtures, so the number timed on the GPU box's host cores is the reference's arithmetic
+@pytest.mark.parametrize("ds,hoisted", [("ted", True), ("ted", False), ("beat", True)])
+def test_torch_cpu_port_vs_reference_fixtures(golden, ds, hoisted):
+    from oracle.rag_torch_cpu import TorchCpuSampler
+    cfg = synth.CONFIGS[ds]
+    g = golden[ds]
+    port = TorchCpuSampler(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    y = synth.make_cond(cfg, 4)
+    sch = orc.Schedule(50, "")
+    tape = synth.NoiseTape(cfg, 4, 50)
+    out = port.sample_loop(sch, y, tape.x_init, tape.eps, tape.noise, hoisted=hoisted)
+    assert max_abs(out, g["G3_ddpm50_final"]) < TOL                      # config 1: B=4, 50-step DDPM, CFG 1.5
+    if hoisted:
+        sch = orc.Schedule(1000, "ddim100")
+        tape = synth.NoiseTape(cfg, 4, 20)
+        out = port.sample_loop(sch, y, tape.x_init, tape.eps, tape.noise, ddim=True, skip_timesteps=80,
+                               init_image=synth.make_init_image(cfg, 4))
+        assert max_abs(out, g["G4_ddim100_skip80_final"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# round-2 fixtures (tests/golden/make_golden_r2.py): guidance scale 1 with an odd batch, BEAT at TED's depth
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_scale1_loops(ds):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, f"{ds}_golden_r2.npz"))
+    cfg, oracle = _oracle(ds)
+    y = synth.make_cond(cfg, 5, scale=1.0)
+    sch = orc.Schedule(50, "")
+    tape = synth.NoiseTape(cfg, 5, 50)
+    out = orc.sample_loop(oracle, sch, y, tape.x_init, tape.eps, tape.noise)
+    assert max_abs(out, g["G11_scale1_ddpm50_B5_final"]) < TOL
+    sch = orc.Schedule(1000, "ddim100")
+    tape = synth.NoiseTape(cfg, 5, 20)
+    out = orc.sample_loop(oracle, sch, y, tape.x_init, tape.eps, tape.noise, ddim=True, skip_timesteps=80,
+                          init_image=synth.make_init_image(cfg, 5))
+    assert max_abs(out, g["G11_scale1_ddim100_skip80_B5_final"]) < TOL
+
+
+def test_beat_full_ddim100():
+    """(the 1000-step BEAT fixture G12 is checked against the oracle when it is generated and against the HIP path on the GPU;
+    replaying it here would add a minute to the CPU suite)"""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "beat_golden_r2.npz"))
+    assert max_abs(_loop("beat", 1000, "ddim100", True, 0, False), g["G13_ddim100_full_final"]) < TOL

@@ -24,6 +24,7 @@ sys.path.insert(0, %r)
 from livelyspeaker_amd import _lib, synth
 from oracle import rag_oracle as orc
 ds, B, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+_lib.use_library(sys.argv[4])
 cfg = synth.CONFIGS[ds]
 eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
 eng.load_state_dict(synth.make_state_dict(cfg))
@@ -56,8 +57,7 @@ def run(ds="ted", B=512, steps=40, rounds=3):
     chk = {}
     for _ in range(rounds):
         for lib in libs:
-            env = dict(os.environ, LS_LIB=lib)
-            out = subprocess.run([sys.executable, "-c", CHILD, ds, str(B), str(steps)], env=env, capture_output=True, text=True)
+            out = subprocess.run([sys.executable, "-c", CHILD, ds, str(B), str(steps), lib], capture_output=True, text=True)
             name = os.path.basename(lib)[:-3]
             try:
                 r = json.loads(out.stdout.strip().splitlines()[-1])

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""In-kernel phase profile of ls::k_step (debug aid): LS_PROF=<workgroup> makes lane 0 of each wave of that
-workgroup record s_memtime at phase boundaries.  Prints mean cycles per phase (over waves and layers)."""
+"""In-kernel phase profile of ls::k_step (debug aid).  Uses a -DLS_DEBUG build of the library (variants/debug.so; build it in
+the container with `python tools/phase_profile.py build`, it travels to the GPU box): there LS_PROF=<workgroup> makes lane 0
+of each wave of that workgroup record s_memtime at phase boundaries.  The shipped library has no such code.
+Prints mean cycles per phase (over waves and layers)."""
 import os
 import sys
 
@@ -9,7 +11,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("LS_PROF", "300")
 from livelyspeaker_amd import _lib, synth          # noqa: E402
+from livelyspeaker_amd import build as _build      # noqa: E402
 from oracle import rag_oracle as orc               # noqa: E402
+
+DEBUG_LIB = os.path.join(_build.ROOT, "variants", "debug.so")
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    os.makedirs(os.path.dirname(DEBUG_LIB), exist_ok=True)
+    print(_build.build_library(defines=["LS_DEBUG"], out=DEBUG_LIB))
+    sys.exit(0)
+_lib.use_library(DEBUG_LIB)
 
 ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
