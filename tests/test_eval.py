@@ -67,3 +67,34 @@ def test_embedding_space_evaluator_dropin_reproduces_reference_scores():
     torch.manual_seed(4)
     div = ev.get_diversity_scores()
     assert abs(div - float(g["ted_diversity"])) < 1e-4 * float(g["ted_diversity"])
+
+
+def test_streaming_statistics_and_eigh_frechet_match_the_reference_scores():
+    """The drop-in's own statistics (batch-wise parallel-variance accumulation; Tr sqrt(S1 S2) from two symmetric
+    eigendecompositions) against the scores the reference's evaluator produced for the same features (fixture), against the
+    scipy-sqrtm restatement, and on degenerate inputs."""
+    from livelyspeaker_amd import ted_evaluator as te
+    g = np.load(os.path.join(GOLD, "eval_ted_golden.npz"))
+    gen, real = g["ted_gen_feat"], g["ted_real_feat"]
+    mg, mr = te._Moments(), te._Moments()
+    for i in range(0, len(gen), 64):                     # ragged last batch on purpose
+        mg.add(gen[i:i + 37]); mg.add(gen[i + 37:i + 64])
+        mr.add(real[i:i + 64])
+    assert mg.n == len(gen) and np.allclose(mg.mean, gen.mean(0, dtype=np.float64), atol=1e-12)
+    assert np.allclose(mg.covariance(), np.cov(gen.astype(np.float64), rowvar=False), rtol=1e-10, atol=1e-12)
+    fd = te.EmbeddingSpaceEvaluator.calculate_frechet_distance(mg.mean, mg.covariance(), mr.mean, mr.covariance())
+    # the reference takes the means with np.mean on float32 features (float32 result, ~1e-7 relative) and feeds them to
+    # ||mu1 - mu2||^2; the accumulation here is float64 throughout, so agreement is at that level, not at float64 round-off
+    assert abs(fd - float(g["ted_frechet"])) < 2e-6 * float(g["ted_frechet"])
+    want64 = evo.calculate_frechet_distance(gen.mean(0, dtype=np.float64), np.cov(gen, rowvar=False), real.mean(0, dtype=np.float64),
+                                            np.cov(real, rowvar=False))
+    assert abs(fd - want64) < 1e-9 * want64              # same inputs in float64: eigh route == scipy sqrtm route
+    rng = np.random.Generator(np.random.PCG64(2))
+    for n, d in ((40, 6), (5, 9)):                       # second case: rank-deficient covariances (fewer samples than dims)
+        a, b = rng.standard_normal((n, d)), rng.standard_normal((n, d)) * 0.5 + 0.3
+        want = evo.calculate_frechet_distance(a.mean(0), np.cov(a, rowvar=False), b.mean(0), np.cov(b, rowvar=False))
+        got = te.EmbeddingSpaceEvaluator.calculate_frechet_distance(a.mean(0), np.cov(a, rowvar=False), b.mean(0), np.cov(b, rowvar=False))
+        assert abs(got - want) < 1e-6 * max(1.0, abs(want)), (n, d, got, want)
+    same = te.EmbeddingSpaceEvaluator.calculate_frechet_distance(mg.mean, mg.covariance(), mg.mean, mg.covariance())
+    assert abs(same) < 1e-9
+    assert te.EmbeddingSpaceEvaluator.calculate_frechet_distance([np.nan, 0.0], np.eye(2), [0.0, 0.0], np.eye(2)) == float("inf")
