@@ -290,7 +290,7 @@ def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3):
     assert bool(torch.isfinite(out).all())
     kernel_ms = loop_ms / max(launches, 1)
     ach = 2 * FLOP_PER_FORWARD["ted"] * B / (kernel_ms * 1e-3) / 1e12
-    sag_ms = getattr(seng, "last_decode_ms", lambda: None)()
+    sag_ms = seng.last_decode_ms()
     return {"workload": f"TED LivelySpeaker: SAG decode (synthetic CLIP text feature) + CFG RAG refine, ddim100 with skip_timesteps=80 "
                         f"(20 DDIM steps, what scripts/test_LivelySpeaker_ted.py runs), batch {B}, guidance 2.5, Philox noise",
             "value": round(B * cfg.nframes / el, 1), "unit": "pose-frames/s", "ms_per_call": round(el * 1e3, 3),

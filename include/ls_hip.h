@@ -212,6 +212,7 @@ int ls_sag_commit_weights(ls_sag* h);
  * -> batch['output'] [B,J,F,T] */
 int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask,
                   float* out);
+float ls_sag_last_decode_ms(const ls_sag* h);   /* GPU time of the last ls_sag_decode (HIP events on the handle's stream) */
 
 /* ---- caller-side post-processing of sampled clips ---------------------------------
  * scripts/test_RAG_ted.py:84-111 (layout change, mean add, per-bone normalisation, joint-angle change curve, motion

@@ -100,7 +100,7 @@ class LsEvalConfig(C.Structure):
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
            "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
-           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_ted_post", "ls_beat_post",
+           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
            "ls_train_adamw", "ls_train_read", "ls_train_get_moment", "ls_train_set_moment", "ls_train_get_step", "ls_train_set_step",
@@ -179,6 +179,8 @@ def load_library(build_if_missing: bool = True):
     lib.ls_sag_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     lib.ls_sag_commit_weights.argtypes = [C.c_void_p]
     lib.ls_sag_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ls_sag_last_decode_ms.argtypes = [C.c_void_p]
+    lib.ls_sag_last_decode_ms.restype = C.c_float
     lib.ls_ted_post.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(LsPostConfig), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]
     lib.ls_beat_post.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -485,6 +487,9 @@ class SagEngine:
             a = _np32(v)
             self._check(self.lib.ls_sag_set_weight(self.h, k.encode(), a.ctypes.data_as(c_f32p), a.size), f"ls_sag_set_weight({k})")
         self._check(self.lib.ls_sag_commit_weights(self.h), "ls_sag_commit_weights")
+
+    def last_decode_ms(self) -> float:
+        return float(self.lib.ls_sag_last_decode_ms(self.h))
 
     def decode(self, x, z, mask=None):
         m = _Marshal(self.device, x, z, mask)

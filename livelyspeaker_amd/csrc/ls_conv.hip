@@ -116,6 +116,100 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
     }
 }
 
+// The same implicit GEMM for a SHORT output (the last encoder layer: 34 positions from 217 inputs).  With one sample per workgroup
+// the 34 positions fill 34 of the 64 columns of the tile above (conv4 ran at 0.36 of the MFMA peak, its matrix pipe as busy as
+// conv3's for 63 % of the FLOPs -- profiles/r02a).  Here the N axis enumerates (sample, position) pairs of NS samples: NS = 4 gives
+// 136 columns = 8.5 tiles of 16 -> 9 tiles, 94 % useful.  A lane's activation address is per-lane data anyway (base + compile-time
+// tap / channel offsets), so columns that straddle two samples cost nothing.  Same producer / consumer split, same weight image.
+template <int NS, int NPT>
+__global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ in, const float* __restrict__ stats,
+                                                         const float* __restrict__ wimg, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int Cin, int Cout, int Lin, int Lout, int B, int winp) {
+    extern __shared__ float sIn[];                             // [2][NS][16][winp]
+    const int b0 = blockIdx.z * NS, co0 = blockIdx.y * kCvTC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunk = Cin / kCvCI;
+    const int wn = (Lout - 1) * kCvS + kCvK;                   // input samples a row of the window holds (<= Lin)
+    const int bufsz = NS * kCvCI * winp;
+    if (w >= 4) {
+        // ---------------- producers: 16 threads per row, 16 rows per pass, NS passes per chunk
+        const int pt = tid - 256;
+        constexpr int NQ = 15;                                 // 16-wide groups of a window row: wn <= 35 * 6 + 15 = 225
+        auto stage = [&](int c, float* dst) {
+            float vals[NS][NQ], vm[NS], vr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {                     // every load of the chunk first (clamped addresses: branch-free, in flight together)
+                const int b = min(b0 + s, B - 1);                               // past the batch: staged but never stored
+                const size_t row = (size_t)b * Cin + c * kCvCI + (pt >> 4);
+                vm[s] = stats[row * 2]; vr[s] = stats[row * 2 + 1];             // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
+                const float* src = in + row * Lin;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) vals[s][q] = src[min((pt & 15) + 16 * q, Lin - 1)];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float* d = dst + (s * kCvCI + (pt >> 4)) * winp;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int o = (pt & 15) + 16 * q;
+                    float v = (vals[s][q] - vm[s]) * vr[s];
+                    v = v >= 0.f ? v : 0.3f * v;
+                    if (o < wn) d[o] = v;
+                }
+            }
+        };
+        stage(0, sIn);
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) stage(c + 1, sIn + ((c + 1) & 1) * bufsz);
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------- consumers: wave w = channel tile w x all NPT column tiles
+    const int s16 = lane & 15, g = lane >> 4;
+    f4 acc[NPT];
+    int lb[NPT];                                               // lane's window base per column tile
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+        const int j = min(16 * t + s16, NS * Lout - 1);
+        const int s = j / Lout, p = j - s * Lout;
+        lb[t] = (s * kCvCI + g) * winp + p * kCvS;
+    }
+    const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const float* sb = sIn + (c & 1) * bufsz;
+        const f4* wp = reinterpret_cast<const f4*>(wimg) + ((size_t)(blockIdx.y * 4 + w) * nchunk + c) * kCvK * 64 + lane;
+        f4 An = wp[0];
+#pragma unroll
+        for (int k = 0; k < kCvK; ++k) {
+            const f4 A = An;
+            if (k + 1 < kCvK) An = wp[(k + 1) * 64];
+#pragma unroll
+            for (int cig = 0; cig < 4; ++cig) {
+#pragma unroll
+                for (int t = 0; t < NPT; ++t) {
+                    const float Bv = sb[lb[t] + (4 * cig) * winp + k];
+                    acc[t] = MFMA(A[cig], Bv, acc[t]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int j = 16 * t + s16;
+        const int s = j / Lout, p = j - s * Lout;
+        if (j < NS * Lout && b0 + s < B) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[((size_t)(b0 + s) * Cout + co0 + 16 * w + 4 * g + e) * Lout + p] = acc[t][e] + bv[e];
+        }
+    }
+}
+
 // stats[row] = (mean, 1/sqrt(biased var + 1e-5)) from np partial (count, mean, M2) triples per row, merged in index order
 // with the parallel-variance update (Chan, Golub, LeVeque): exact-arithmetic equivalent of the two-pass statistics.
 __global__ __launch_bounds__(256) void k_stats_merge(const float* __restrict__ spart, float* __restrict__ stats, int rows, int np) {
@@ -157,6 +251,23 @@ hipError_t launch_stats_merge(const float* spart, float* stats, int rows, int np
 hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* wimg, const float* bias, float* out, float* out_stats,
                               float* spart, int B, int Cin, int Cout, int Lin, int Lout, hipStream_t st) {
     if (Cin % kCvCI || Cout % kCvTC || !stats || (out_stats && !spart)) return hipErrorInvalidValue;
+    if (!out_stats && Lout <= 36 && (Lout - 1) * kCvS + kCvK <= Lin) {
+        // short output without statistics (conv4: 34 positions): columns = (sample, position) pairs of 4 samples, 9 tiles
+        constexpr int NS = 4, NPT = 9;
+        const int winp = ((Lout - 1) * kCvS + kCvK) | 1;                  // odd row stride: the 4 lane groups (channels) hit different banks
+        const size_t lds = (size_t)2 * NS * kCvCI * winp * sizeof(float);
+        static bool attr_set = false;                                     // > 64 KiB of dynamic LDS needs the opt-in, once per process
+        if (!attr_set) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1d_short<NS, NPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (ea != hipSuccess) return ea;
+            attr_set = true;
+        }
+        if (NS * Lout <= 16 * NPT && lds <= 160 * 1024) {
+            hipLaunchKernelGGL((k_conv1d_short<NS, NPT>), dim3(1, Cout / kCvTC, (B + NS - 1) / NS), dim3(512), lds, st, in, stats, wimg, bias, out,
+                               Cin, Cout, Lin, Lout, B, winp);
+            return hipGetLastError();
+        }
+    }
     dim3 grid((Lout + kCvTP - 1) / kCvTP, Cout / kCvTC, B);
     hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(512), 0, st, in, stats, wimg, bias, out, out_stats ? spart : nullptr, Cin, Cout, Lin, Lout);
     hipError_t e = hipGetLastError();

@@ -140,7 +140,8 @@ hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipS
 hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bmap, const float* pe, float* q, int B,
                               int JF, int n_pre, int D, hipStream_t st);
 hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, int D, hipStream_t st);
-hipError_t launch_layernorm512(const float* x, const float* bc, const float* w, const float* beta, float* y, int rows,
+// y = LayerNorm(x (+ bc[row / T], rows of bc bc_stride floats apart))
+hipError_t launch_layernorm512(const float* x, const float* bc, int bc_stride, const float* w, const float* beta, float* y, int rows,
                                hipStream_t st);
 hipError_t launch_sag_final(const float* xh, const float* wf, const float* bf, const unsigned char* mask, float* out, int B,
                             int JF, int D, hipStream_t st);

@@ -32,25 +32,28 @@ __global__ void k_sag_queries(const float* __restrict__ x, const float* __restri
 
 // nn.MultiheadAttention self-attention of one (sample, head): softmax(q k^T / sqrt(hd)) v over the T = 34 queries -- the only
 // QK^T / softmax / attn.V in the model (motionclip_module.py:98-183).  qkv rows are [q | k | v] of width 3*D (packed in_proj).
-// Workgroup = (sample, head), 4 waves.  Q (pre-scaled), K, V [34][HD] are staged in LDS with row stride HD + 4 (conflict-free
+// Workgroup = one sample, 4 waves, looping over its heads: the NEXT head's Q / K / V are fetched into registers while the current
+// head is computed (as one workgroup per (sample, head) the kernel was a chain of latencies -- global load, LDS, three barriers --
+// repeated over four rounds of 512 resident workgroups: 46 us at B = 512 for 2.4 MFLOP and 52 KB per pair).  Q (pre-scaled), K, V
+// [34][HD] are staged in LDS with row stride HD + 4 (conflict-free
 // ds_read_b128); both contractions run on v_mfma_f32_16x16x4_f32 with T padded to 3 tiles of 16 (rows past 33 are clamped on the
 // read and never stored / masked):
 //   scores = Q K^T : 3 x 3 tiles, K-dim = HD in the k-permuted float4 order (lane (row, g) holds d = 16q + 4g + e for step e)
 //   softmax        : one wave per query row, lane = key; row max and row sum are wavefront reductions (DPP / readlane)
 //   out = P V      : 3 x (HD/16) tiles, K-dim = 36 keys (P's columns 34, 35 are written as zero)
 template <int HD>
-__global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__ qkv, float* __restrict__ out, int D) {
+__global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__ qkv, float* __restrict__ out, int D, int heads) {
     constexpr int LQ = HD + 4, LP = 37, KP = 36;
     __shared__ __attribute__((aligned(16))) float sq[kT * LQ], sk[kT * LQ], sv[kT * LQ];
     __shared__ float sp[kT * LP];
-    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
     const float scale = rsqrtf((float)HD);
-    {
-        // all of this thread's loads first (float4, clamped index: branch-free and in flight together), then the LDS writes
-        constexpr int kF4 = kT * HD / 4, kPer = (kF4 + 255) / 256;
-        f4 vq[kPer], vk[kPer], vv[kPer];
+    constexpr int kF4 = kT * HD / 4, kPer = (kF4 + 255) / 256;
+    f4 vq[kPer], vk[kPer], vv[kPer];
+    // this thread's share of one head's Q / K / V: float4 loads with a clamped index (branch-free, all in flight together)
+    auto fetch = [&](int h) {
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int idx = min(tid + 256 * j, kF4 - 1), t = idx / (HD / 4), d4 = idx % (HD / 4);
@@ -59,6 +62,10 @@ __global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__
             vk[j] = *reinterpret_cast<const f4*>(row + D);
             vv[j] = *reinterpret_cast<const f4*>(row + 2 * D);
         }
+    };
+    fetch(0);
+    for (int h = 0; h < heads; ++h) {
+        if (h) __syncthreads();                                   // the previous head's P.V is done reading sv / sp
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int idx = tid + 256 * j, t = idx / (HD / 4), d = 4 * (idx % (HD / 4));
@@ -68,63 +75,64 @@ __global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__
                 *reinterpret_cast<f4*>(&sv[t * LQ + d]) = vv[j];
             }
         }
-    }
-    __syncthreads();
-    // ---- scores: tile (mt, nt) = w, w + 4, w + 8 of the 3 x 3 grid; lane holds S[a = 16 mt + 4 g + r][c = 16 nt + s16]
-    for (int tile = w; tile < 9; tile += 4) {
-        const int mt = tile / 3, nt = tile % 3;
-        const float* qa = sq + min(16 * mt + s16, kT - 1) * LQ + 4 * g;
-        const float* kb = sk + min(16 * nt + s16, kT - 1) * LQ + 4 * g;
-        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (h + 1 < heads) fetch(h + 1);                          // in flight during this head's scores / softmax / P.V
+        // ---- scores: tile (mt, nt) = w, w + 4, w + 8 of the 3 x 3 grid; lane holds S[a = 16 mt + 4 g + r][c = 16 nt + s16]
+        for (int tile = w; tile < 9; tile += 4) {
+            const int mt = tile / 3, nt = tile % 3;
+            const float* qa = sq + min(16 * mt + s16, kT - 1) * LQ + 4 * g;
+            const float* kb = sk + min(16 * nt + s16, kT - 1) * LQ + 4 * g;
+            f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < HD / 16; ++q) {
-            const f4 av = *reinterpret_cast<const f4*>(qa + 16 * q), bv = *reinterpret_cast<const f4*>(kb + 16 * q);
+            for (int q = 0; q < HD / 16; ++q) {
+                const f4 av = *reinterpret_cast<const f4*>(qa + 16 * q), bv = *reinterpret_cast<const f4*>(kb + 16 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
-        }
-        const int c = 16 * nt + s16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int a = 16 * mt + 4 * g + r;
-            if (a < kT && c < kT) sp[a * LP + c] = acc[r];
-        }
-    }
-    __syncthreads();
-    // ---- softmax over the keys of each query row: one wave per row, lane = key
-    for (int a = w; a < kT; a += 4) {
-        const float v = lane < kT ? sp[a * LP + lane] : -INFINITY;
-        const float m = wave_max(v);
-        const float e = lane < kT ? expf(v - m) : 0.f;
-        const float inv = 1.0f / wave_sum(e);
-        if (lane < KP) sp[a * LP + lane] = e * inv;                       // columns 34, 35: zero (K padding of the P.V product)
-    }
-    __syncthreads();
-    // ---- out = P V: wave w owns feature tiles 2w, 2w + 1 ... of HD / 16; lane holds O[a = 16 mt + 4 g + r][d = 16 nt + s16]
-    for (int nt = w; nt < HD / 16; nt += 4) {
-        f4 acc[3];
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) acc[mt] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KP / 4; ++ks) {
-            const float bv = sv[min(4 * ks + g, kT - 1) * LQ + 16 * nt + s16];    // rows 34, 35 meet P's zero columns
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt) {
-                const float av = sp[min(16 * mt + s16, kT - 1) * LP + 4 * ks + g];
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
+            const int c = 16 * nt + s16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a = 16 * mt + 4 * g + r;
-                if (a < kT) out[(size_t)(b * kT + a) * D + h * HD + 16 * nt + s16] = acc[mt][r];
+                if (a < kT && c < kT) sp[a * LP + c] = acc[r];
             }
+        }
+        __syncthreads();
+        // ---- softmax over the keys of each query row: one wave per row, lane = key
+        for (int a = w; a < kT; a += 4) {
+            const float v = lane < kT ? sp[a * LP + lane] : -INFINITY;
+            const float m = wave_max(v);
+            const float e = lane < kT ? expf(v - m) : 0.f;
+            const float inv = 1.0f / wave_sum(e);
+            if (lane < KP) sp[a * LP + lane] = e * inv;                   // columns 34, 35: zero (K padding of the P.V product)
+        }
+        __syncthreads();
+        // ---- out = P V: wave w owns feature tiles w, w + 4 of HD / 16; lane holds O[a = 16 mt + 4 g + r][d = 16 nt + s16]
+        for (int nt = w; nt < HD / 16; nt += 4) {
+            f4 acc[3];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) acc[mt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KP / 4; ++ks) {
+                const float bv = sv[min(4 * ks + g, kT - 1) * LQ + 16 * nt + s16];    // rows 34, 35 meet P's zero columns
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    const float av = sp[min(16 * mt + s16, kT - 1) * LP + 4 * ks + g];
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = 16 * mt + 4 * g + r;
+                    if (a < kT) out[(size_t)(b * kT + a) * D + h * HD + 16 * nt + s16] = acc[mt][r];
+                }
+        }
     }
 }
 
 // y = LayerNorm(x (+ bc[b])) * w + beta, eps 1e-5, biased variance (nn.LayerNorm); one wave per row of D = 512
-__global__ __launch_bounds__(256) void k_layernorm512(const float* __restrict__ x, const float* __restrict__ bc,
+__global__ __launch_bounds__(256) void k_layernorm512(const float* __restrict__ x, const float* __restrict__ bc, int bc_stride,
                                                       const float* __restrict__ w, const float* __restrict__ beta,
                                                       float* __restrict__ y, int rows) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void k_layernorm512(const float* __restrict__ 
     const f4* xr = reinterpret_cast<const f4*>(x + (size_t)r * kD);
     f4 v0 = xr[lane], v1 = xr[lane + 64];
     if (bc) {
-        const f4* br = reinterpret_cast<const f4*>(bc + (size_t)(r / kT) * kD);
+        const f4* br = reinterpret_cast<const f4*>(bc + (size_t)(r / kT) * bc_stride);
         v0 += br[lane];
         v1 += br[lane + 64];
     }
@@ -151,31 +159,60 @@ __global__ __launch_bounds__(256) void k_layernorm512(const float* __restrict__ 
     yr[lane + 64] = (v1 - mean) * rstd * wr[lane + 64] + be[lane + 64];
 }
 
-// finallayer + "zero for padded area" + permute to [B, J*F, T] (motionclip_module.py:172-176).  One wave per row: lane l holds
-// channels 8l .. 8l+7 of the row, every output feature is a coalesced read of its weight row and a wave-wide sum.  (One thread per
-// output feature walking its own weight row -- 27 strided streams per workgroup -- took 154 us at B = 512; this takes ~20.)
+// finallayer + "zero for padded area" + permute to [B, J*F, T] (motionclip_module.py:172-176) on v_mfma_f32_16x16x4_f32.
+// Workgroup = one sample: out[c][f] = sum_d W[c][d] x[f][d] as D[feature tile][frame tile] (NCT x 3 tiles of 16), both operands
+// read straight from global memory in the k-permuted float4 order (lane (row, g) holds d = 16q + 4g .. +3: one float4 = 4 MFMA
+// steps).  Each of the 4 waves contracts over its own quarter of D (its loads are issued together), the partial tiles are summed
+// through LDS, and the [c][f] result leaves in the reference layout with coalesced stores along f.
+// (History at B = 512: one thread per output feature 154 us; one wave per row with wave-wide sums 70 us; this form: see profiles/.)
 __global__ __launch_bounds__(256) void k_sag_final(const float* __restrict__ xh, const float* __restrict__ wf, const float* __restrict__ bf,
-                                                   const unsigned char* __restrict__ mask, float* __restrict__ out, int rows, int JF, int D) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;                                        // wave-uniform
-    const int b = r / kT, f = r % kT;
-    const bool keep = mask ? mask[r] != 0 : true;
-    float acc_mine = 0.f;                                         // lane c ends up holding output feature c (JF <= 64 per pass)
-    for (int c0 = 0; c0 < JF; c0 += 64) {
-        for (int c = c0; c < min(JF, c0 + 64); ++c) {
-            float p = 0.f;
-            for (int d = 8 * lane; d < D; d += 512) {
-                const f4 x0 = *reinterpret_cast<const f4*>(xh + (size_t)r * D + d), x1 = *reinterpret_cast<const f4*>(xh + (size_t)r * D + d + 4);
-                const f4 w0 = *reinterpret_cast<const f4*>(wf + (size_t)c * D + d), w1 = *reinterpret_cast<const f4*>(wf + (size_t)c * D + d + 4);
-                p += (x0[0] * w0[0] + x0[1] * w0[1]) + (x0[2] * w0[2] + x0[3] * w0[3]) + (x1[0] * w1[0] + x1[1] * w1[1]) +
-                     (x1[2] * w1[2] + x1[3] * w1[3]);
-            }
-            const float v = wave_sum(p) + bf[c];
-            if (lane == c - c0) acc_mine = v;
+                                                   const unsigned char* __restrict__ mask, float* __restrict__ out, int JF, int D) {
+    constexpr int NCT = 2, NFT = 3;                               // 32 features x 48 (34) frames per pass
+    __shared__ float part[4][NCT * NFT][4][64];                   // [wave][tile][reg][lane]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
+    const int kq = D / 64;                                        // 16-wide k groups per wave (D = 512: 8)
+    const float* xb = xh + (size_t)b * kT * D + (size_t)w * (D / 4) + 4 * g;
+    for (int c0 = 0; c0 < JF; c0 += 16 * NCT) {                   // TED: one pass (27 features); BEAT: nine (282)
+        f4 acc[NCT][NFT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) acc[ct][ft] = (f4){0.f, 0.f, 0.f, 0.f};
+        const float* wb = wf + (size_t)w * (D / 4) + 4 * g;
+        for (int q = 0; q < kq; ++q) {
+            f4 A[NCT], Bv[NFT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) A[ct] = *reinterpret_cast<const f4*>(wb + (size_t)min(c0 + 16 * ct + s16, JF - 1) * D + 16 * q);
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) Bv[ft] = *reinterpret_cast<const f4*>(xb + (size_t)min(16 * ft + s16, kT - 1) * D + 16 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int ft = 0; ft < NFT; ++ft) acc[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ct][e], Bv[ft][e], acc[ct][ft], 0, 0, 0);
         }
-        const int c = c0 + lane;
-        if (c < JF) out[((size_t)b * JF + c) * kT + f] = keep ? acc_mine : 0.f;
+        __syncthreads();                                          // the previous pass's readers are done with `part`
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[w][ct * NFT + ft][r][lane] = acc[ct][ft][r];
+        __syncthreads();
+        // tile (ct, ft), register r of lane (s16, g): feature c = c0 + 16 ct + 4 g + r, frame f = 16 ft + s16
+        for (int idx = tid; idx < NCT * NFT * 256; idx += 256) {
+            const int tile = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
+            const int ct = tile / NFT, ft = tile - ct * NFT;
+            const int c = c0 + 16 * ct + 4 * (ln >> 4) + r, f = 16 * ft + (ln & 15);
+            if (c < JF && f < kT) {
+                const float v = ((part[0][tile][r][ln] + part[1][tile][r][ln]) + (part[2][tile][r][ln] + part[3][tile][r][ln])) + bf[c];
+                const bool keep = mask ? mask[b * kT + f] != 0 : true;
+                out[((size_t)b * JF + c) * kT + f] = keep ? v : 0.f;
+            }
+        }
     }
 }
 
@@ -186,18 +223,18 @@ hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bm
 }
 hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, int D, hipStream_t st) {
     if (D / heads != 128) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_sag_attention<128>), dim3(B, heads), dim3(256), 0, st, qkv, out, D);
+    hipLaunchKernelGGL((k_sag_attention<128>), dim3(B), dim3(256), 0, st, qkv, out, D, heads);
     return hipGetLastError();
 }
-hipError_t launch_layernorm512(const float* x, const float* bc, const float* w, const float* beta, float* y, int rows,
+hipError_t launch_layernorm512(const float* x, const float* bc, int bc_stride, const float* w, const float* beta, float* y, int rows,
                                hipStream_t st) {
-    hipLaunchKernelGGL(k_layernorm512, dim3((rows + 3) / 4), dim3(256), 0, st, x, bc, w, beta, y, rows);
+    hipLaunchKernelGGL(k_layernorm512, dim3((rows + 3) / 4), dim3(256), 0, st, x, bc, bc_stride, w, beta, y, rows);
     return hipGetLastError();
 }
 hipError_t launch_sag_final(const float* xh, const float* wf, const float* bf, const unsigned char* mask, float* out, int B,
                             int JF, int D, hipStream_t st) {
-    if (D % 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_sag_final, dim3((B * kT + 3) / 4), dim3(256), 0, st, xh, wf, bf, mask, out, B * kT, JF, D);
+    if (D % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sag_final, dim3(B), dim3(256), 0, st, xh, wf, bf, mask, out, JF, D);
     return hipGetLastError();
 }
 

@@ -38,7 +38,10 @@ struct ls_sag {
     std::map<std::string, std::vector<float>> w;
     std::map<std::string, Buf> dw;      // device copies under the same keys
     bool committed = false;
-    Buf pe, xin, zin, mask, q, qkv, attn, t1, x1, cav, ca, x2, hid, t3, out;
+    Buf pe, xin, zin, mask, q, qkv, attn, t1, x1, ca, x2, hid, t3, out;
+    Buf wcross, bcross;      // cross-attention of ALL layers as one [L*D][D] matrix (see ls_sag_commit_weights)
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    float last_ms = 0.f;
 };
 
 namespace {
@@ -79,6 +82,8 @@ int ls_sag_create(const ls_sag_config* cfg, ls_sag** out) {
     h->JF = cfg->njoints * cfg->nfeats;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return sfail(nullptr, LS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    for (auto& ev : h->ev)
+        if (hipEventCreate(&ev) != hipSuccess) { delete h; return sfail(nullptr, LS_EHIP, "hipEventCreate failed"); }
     // PositionalEncoding rows 0..T-1 (motionclip_module.py:11-28), fp32 like the torch buffer
     std::vector<float> pe((size_t)kT * kD);
     const float cexp = (float)(-std::log(10000.0) / kD);
@@ -103,8 +108,10 @@ void ls_sag_destroy(ls_sag* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->dw) kv.second.release();
-    Buf* all[] = {&h->pe, &h->xin, &h->zin, &h->mask, &h->q, &h->qkv, &h->attn, &h->t1, &h->x1, &h->cav, &h->ca, &h->x2, &h->hid, &h->t3, &h->out};
+    Buf* all[] = {&h->pe, &h->xin, &h->zin, &h->mask, &h->q, &h->qkv, &h->attn, &h->t1, &h->x1, &h->ca, &h->x2, &h->hid, &h->t3, &h->out,
+                  &h->wcross, &h->bcross};
     for (Buf* b : all) b->release();
+    for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -151,6 +158,38 @@ int ls_sag_commit_weights(ls_sag* h) {
     if ((rc = need("finallayer.bias", JF)) != LS_OK) return rc;
     if ((rc = need("mapping.weight", (size_t)D * (JF + 1))) != LS_OK) return rc;   // :133  Linear(28,512)
     if ((rc = need("mapping.bias", D)) != LS_OK) return rc;
+    {   // Cross-attention to a memory of length 1 (the CLIP text feature): softmax over one key is 1, so every layer adds
+        //     out_proj(v_proj(z)) = (W_out W_v) z + (W_out b_v + b_out)
+        // to each of its rows -- a per-sample vector that depends on z only.  The products W_out W_v are formed here once (in double),
+        // for all layers stacked as one [L*D][D] matrix, so a decode needs ONE small GEMM instead of two per layer.
+        const int L = h->cfg.num_layers;
+        std::vector<float> wc((size_t)L * D * D), bc((size_t)L * D);
+        std::vector<double> row(D);
+        for (int l = 0; l < L; ++l) {
+            snprintf(key, sizeof key, "seqTransDecoder.layers.%d.", l);
+            const std::string P(key);
+            const float* Wv = h->w[P + "multihead_attn.in_proj_weight"].data() + (size_t)2 * D * D;     // rows 2D..3D of in_proj: v_proj
+            const float* bv = h->w[P + "multihead_attn.in_proj_bias"].data() + 2 * D;
+            const float* Wo = h->w[P + "multihead_attn.out_proj.weight"].data();
+            const float* bo = h->w[P + "multihead_attn.out_proj.bias"].data();
+            for (int i = 0; i < D; ++i) {
+                std::fill(row.begin(), row.end(), 0.0);
+                double bacc = bo[i];
+                for (int j = 0; j < D; ++j) {
+                    const double wij = Wo[(size_t)i * D + j];
+                    const float* wvj = Wv + (size_t)j * D;
+                    for (int k = 0; k < D; ++k) row[k] += wij * (double)wvj[k];
+                    bacc += wij * (double)bv[j];
+                }
+                for (int k = 0; k < D; ++k) wc[((size_t)l * D + i) * D + k] = (float)row[k];
+                bc[(size_t)l * D + i] = (float)bacc;
+            }
+        }
+        SCHK(h, h->wcross.ensure(wc.size() * sizeof(float)));
+        SCHK(h, h->bcross.ensure(bc.size() * sizeof(float)));
+        SCHK(h, hipMemcpy(h->wcross.p, wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice));
+        SCHK(h, hipMemcpy(h->bcross.p, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     h->committed = true;
     return LS_OK;
 }
@@ -177,8 +216,12 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
     SCHK(h, h->q.ensure(nm)); SCHK(h, h->qkv.ensure(3 * nm)); SCHK(h, h->attn.ensure(nm)); SCHK(h, h->t1.ensure(nm));
     SCHK(h, h->x1.ensure(nm)); SCHK(h, h->x2.ensure(nm)); SCHK(h, h->t3.ensure(nm));
     SCHK(h, h->hid.ensure((size_t)M * FF * sizeof(float)));
-    SCHK(h, h->cav.ensure((size_t)B * D * sizeof(float))); SCHK(h, h->ca.ensure((size_t)B * D * sizeof(float)));
+    const int LD = h->cfg.num_layers * D;
+    SCHK(h, h->ca.ensure((size_t)B * LD * sizeof(float)));
     auto W = [&](const std::string& k) { return h->dw[k].f(); };
+    SCHK(h, hipEventRecord(h->ev[0], st));
+    // cross-attention terms of all layers: ca[b][l*D + i] = (W_out_l W_v_l) z_b + (W_out_l b_v_l + b_out_l)
+    SCHK(h, launch_gemm_nt(h->zin.f(), D, h->wcross.f(), D, h->bcross.f(), nullptr, 0, h->ca.f(), LD, B, LD, D, 0, st));
     SCHK(h, launch_sag_queries(h->xin.f(), W("mapping.weight"), W("mapping.bias"), h->pe.f(), h->q.f(), B, JF, h->cfg.n_pre_poses, D, st));
     float* xcur = h->q.f();
     char pre[96];
@@ -189,21 +232,23 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
         SCHK(h, launch_gemm_nt(xcur, D, W(P + "self_attn.in_proj_weight"), D, W(P + "self_attn.in_proj_bias"), nullptr, 0, h->qkv.f(), 3 * D, M, 3 * D, D, 0, st));
         SCHK(h, launch_sag_attention(h->qkv.f(), h->attn.f(), B, H, D, st));
         SCHK(h, launch_gemm_nt(h->attn.f(), D, W(P + "self_attn.out_proj.weight"), D, W(P + "self_attn.out_proj.bias"), xcur, D, h->t1.f(), D, M, D, D, 0, st));
-        SCHK(h, launch_layernorm512(h->t1.f(), nullptr, W(P + "norm1.weight"), W(P + "norm1.bias"), h->x1.f(), M, st));
-        // cross-attention to a memory of length 1: softmax over one key is 1, so the block adds out_proj(v_proj(z))
-        SCHK(h, launch_gemm_nt(h->zin.f(), D, W(P + "multihead_attn.in_proj_weight") + (size_t)2 * D * D, D, W(P + "multihead_attn.in_proj_bias") + 2 * D, nullptr, 0, h->cav.f(), D, B, D, D, 0, st));
-        SCHK(h, launch_gemm_nt(h->cav.f(), D, W(P + "multihead_attn.out_proj.weight"), D, W(P + "multihead_attn.out_proj.bias"), nullptr, 0, h->ca.f(), D, B, D, D, 0, st));
-        SCHK(h, launch_layernorm512(h->x1.f(), h->ca.f(), W(P + "norm2.weight"), W(P + "norm2.bias"), h->x2.f(), M, st));
+        SCHK(h, launch_layernorm512(h->t1.f(), nullptr, 0, W(P + "norm1.weight"), W(P + "norm1.bias"), h->x1.f(), M, st));
+        // cross-attention block: x = norm2(x + ca_l[b])  (the per-sample vector computed above)
+        SCHK(h, launch_layernorm512(h->x1.f(), h->ca.f() + (size_t)l * D, LD, W(P + "norm2.weight"), W(P + "norm2.bias"), h->x2.f(), M, st));
         // feed-forward: x = norm3(x + linear2(gelu(linear1(x))))
         SCHK(h, launch_gemm_nt(h->x2.f(), D, W(P + "linear1.weight"), D, W(P + "linear1.bias"), nullptr, 0, h->hid.f(), FF, M, FF, D, 3, st));
         SCHK(h, launch_gemm_nt(h->hid.f(), FF, W(P + "linear2.weight"), FF, W(P + "linear2.bias"), h->x2.f(), D, h->t3.f(), D, M, D, FF, 0, st));
-        SCHK(h, launch_layernorm512(h->t3.f(), nullptr, W(P + "norm3.weight"), W(P + "norm3.bias"), h->q.f(), M, st));
+        SCHK(h, launch_layernorm512(h->t3.f(), nullptr, 0, W(P + "norm3.weight"), W(P + "norm3.bias"), h->q.f(), M, st));
         xcur = h->q.f();
     }
     SCHK(h, launch_sag_final(xcur, W("finallayer.weight"), W("finallayer.bias"), dmask, h->out.f(), B, JF, D, st));
+    SCHK(h, hipEventRecord(h->ev[1], st));
     SCHK(h, hipMemcpyAsync(out, h->out.p, nx, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     SCHK(h, hipStreamSynchronize(st));
+    SCHK(h, hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
     return LS_OK;
 }
+
+float ls_sag_last_decode_ms(const ls_sag* h) { return h ? h->last_ms : -1.f; }
 
 }  // extern "C"
