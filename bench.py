@@ -37,7 +37,9 @@ sys.path.insert(0, ROOT)
 _RESULT_OUT = sys.stdout        # replaced by a private duplicate of fd 1 when run as a script (_reserve_stdout)
 
 # BASELINE.md section 3 / SURVEY.md 8(d): hoisted form, 2 FLOPs per MAC.  CFG = two forwards per sample per step.
-FLOP_PER_FORWARD = {"ted": 158_715_904, "beat": 181_248_000}
+FLOP_PER_FORWARD = {"ted": 158_715_904, "beat": 181_248_000,
+                    # synthetic 150-frame BEAT variant (S = 152): 2 x 43 315 200 (x_t in / poseFinal) + 8 x (23 658 496 token + 79 691 776 channel)
+                    "beat150": 913_432_576}
 MFMA_F32_PEAK_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "k_step_traffic.json")   # rocprofv3 PMC passes, keyed to the kernel source
 
@@ -47,7 +49,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dataset", default="ted", choices=["ted", "beat"])
+    ap.add_argument("--dataset", default="ted", choices=["ted", "beat", "beat150"],
+                    help="beat150 = SYNTHETIC long-sequence variant (configs[4] as worded; perf-only, no parity claim vs the reference)")
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total clips, sharded over the ranks")
     ap.add_argument("--diffusion-steps", type=int, default=1000)
@@ -165,7 +168,7 @@ def parity_in_run(cfg, a, out_first, seed, sample_offset, y_np, n_pick):
     pick = np.unique(np.linspace(0, B - 1, n_pick).round().astype(int))
     sch = orc.Schedule(a.diffusion_steps, a.respacing)
     n_exec = sch.num_timesteps - a.skip
-    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, nframes=cfg.nframes)
     t0 = time.perf_counter()
     gidx = sample_offset + pick
     eps, noise = po.step_tapes(seed, gidx, n_exec, (cfg.njoints, cfg.nfeats, cfg.nframes))
@@ -502,7 +505,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "fp32" else "bf16x3 split (fp32 accumulate) for channel mixing, f32 elsewhere",
-            "data": "synthetic",
+            "data": "synthetic" if a.dataset != "beat150" else "synthetic (shape too: 150 frames, which the reference cannot run -- no parity claim)",
             "config": {"workload": f"{a.dataset.upper()} RAG, batch {B} x {cfg.nframes} frames per GPU, "
                                    f"{n_exec}-step {'DDIM' if ddim else 'DDPM'} ({a.diffusion_steps} diffusion steps"
                                    f"{', respacing ' + a.respacing if a.respacing else ''}), CFG scale {a.scale}"
@@ -513,7 +516,9 @@ def main():
                        "parallelism": (f"global batch {total} sharded x{world}, all_gather of the result in the timed region" if strong
                                        else f"batch-sharded x{world}, no per-step collective"),
                        "hipgraph": bool(diffusion.use_graph)},
-            "roofline": {"bound": "mfma", "kernel": "ls::k_step (fused CFG denoiser + sampler update, 1 launch/step)",
+            "roofline": {"bound": "mfma", "kernel": ("ls::k_step (fused CFG denoiser + sampler update, 1 launch/step)" if a.dataset != "beat150" else
+                                                     "long-sequence step: 36 launches/step (GEMMs on ls::k_gemm_tr + LayerNorm / assemble / update kernels); "
+                                                     "achieved = algorithmic FLOPs / mean step time"),
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_unit": "B/launch (rocprofv3 PMC)", "traffic_source": traffic_src,

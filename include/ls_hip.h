@@ -51,12 +51,14 @@ typedef struct ls_handle ls_handle;
 typedef struct ls_config {
     int32_t njoints;          /* 9 (TED) | 47 (BEAT)                               */
     int32_t nfeats;           /* 3 | 6                                             */
-    int32_t nframes;          /* 34 (the token-mixing conv fixes it)               */
+    int32_t nframes;          /* 34 = the reference's (token-mixing conv fixes it): fused step kernel.  Any other
+                                 value selects the synthetic long-sequence path (e.g. 150 frames, BASELINE configs[4]'s
+                                 wording; the reference cannot run it -- perf-only, checked against this repo's oracle) */
     int32_t n_prefix_tokens;  /* 1 = [style] | 2 = [style, emotion]                */
     int32_t n_pre_seq;        /* 4 prefix poses (RAG.py:70)                        */
     int32_t latent_dim;       /* 512                                               */
     int32_t layers;           /* 8                                                 */
-    int32_t audio_len;        /* 36267 | 36266 raw samples -> 34 audio frames      */
+    int32_t audio_len;        /* 36267 | 36266 raw samples -> 34 audio frames (must yield nframes) */
     int32_t n_speakers;       /* 1400 (RAG.py:65)                                  */
     int32_t n_emotions;       /* 0 | 8                                             */
     int32_t device;           /* HIP device ordinal                                */

@@ -59,6 +59,11 @@ struct ls_handle {
     ls_config cfg{};
     Variant var = kTED;
     int JF = 0, S = 0, R = 0, NOB = 0, KXQ = 0, MK = 0, KIN = 0, KF = 0, KFP = 0;      // KFP: KF padded to the GEMM's K tile
+    int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
+    bool fused = true;
+    int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection, row stride of the output buffer)
+    DevBuf lw_wt, lw_bt, lw_wc, lw_bc, lw_winx, lw_wout;     // long path: row-major weights
+    DevBuf lx_proj, lx_X, lx_U, lx_OUT;                      // long path: workspaces
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -169,8 +174,8 @@ void free_graph(ls_handle* h) {
     h->graph_key.clear();
 }
 
-// Build the device images whose element order is the per-lane MFMA operand order of ls_step.hip.
-int build_images(ls_handle* h) {
+// Device images whose element order is the per-lane MFMA operand order of the fused step kernel (ls_step_kernel.h).
+int build_fused_images(ls_handle* h) {
     const int L = h->cfg.layers, S = h->S, R = h->R, JF = h->JF, D = kD;
     const int MK = h->MK, KXQ = h->KXQ, NOB = h->NOB, KIN = h->KIN;
     std::vector<float> wch((size_t)L * D * D), bch((size_t)L * D), l1a((size_t)L * D), l1b((size_t)L * D),
@@ -304,6 +309,32 @@ int build_images(ls_handle* h) {
     if ((rc = upload(h, h->ww_lo_img, wwl.data(), wwl.size() * sizeof(unsigned short))) != LS_OK) return rc;
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
+#undef UP
+    DevWeights dw{};
+    dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
+    dw.wch_hi_img = static_cast<const unsigned short*>(h->wch_hi_img.p);
+    dw.wch_lo_img = static_cast<const unsigned short*>(h->wch_lo_img.p);
+    dw.ww_hi_img = static_cast<const unsigned short*>(h->ww_hi_img.p);
+    dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
+    dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
+    dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
+    dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
+    if ((rc = upload(h, h->devw, &dw, sizeof dw)) != LS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return LS_OK;
+}
+
+
+// Weights of the once-per-call stage (audio encoder, static input projection, speaker style, timestep embedder): the same for the
+// fused (34-frame) and the long-sequence path.
+int build_shared_weights(ls_handle* h) {
+    const int JF = h->JF, D = kD, KIN = h->KIN;
+    char key[160];
+    int rc;
+    const auto* Win = find_w(h, "input_mapping.weight", (size_t)D * KIN);        // RAG.py:62
+    const auto* bin = find_w(h, "input_mapping.bias", D);
+    if (!Win || !bin) return LS_ESTATE;
+#define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
     UP(win_full, *Win); UP(win_bias, *bin);
     {   // the static columns JF.. of input_mapping as their own [512][KFP] matrix (zero-padded to a whole number of K tiles and
         // 16-byte-aligned rows): the once-per-call projection then takes the GEMM's fast path
@@ -367,16 +398,54 @@ int build_images(ls_handle* h) {
         }
         if ((rc = upload(h, h->pe, pe.data(), pe.size() * sizeof(float))) != LS_OK) return rc;
     }
-    DevWeights dw{};
-    dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
-    dw.wch_hi_img = static_cast<const unsigned short*>(h->wch_hi_img.p);
-    dw.wch_lo_img = static_cast<const unsigned short*>(h->wch_lo_img.p);
-    dw.ww_hi_img = static_cast<const unsigned short*>(h->ww_hi_img.p);
-    dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
-    dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
-    dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
-    dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
-    if ((rc = upload(h, h->devw, &dw, sizeof dw)) != LS_OK) return rc;
+    return LS_OK;
+}
+
+// Long-sequence path (nframes != 34, ls_long.hip): plain row-major weights for the batch-level kernels.
+int build_long_weights(ls_handle* h) {
+    const int L = h->cfg.layers, S = h->S, JF = h->JF, D = kD, KIN = h->KIN, JFP = h->JFP;
+    std::vector<float> wt((size_t)L * S * S), bt((size_t)L * S), wc((size_t)L * D * D), bc((size_t)L * D), l1a((size_t)L * D), l1b((size_t)L * D),
+        l2a((size_t)L * D), l2b((size_t)L * D);
+    char key[160];
+    for (int l = 0; l < L; ++l) {
+        auto K = [&](const char* suffix) { snprintf(key, sizeof key, "backbone.mlps.%d.%s", l, suffix); return std::string(key); };
+        const auto* W = find_w(h, K("block2.1.weight"), (size_t)D * D);
+        const auto* b2 = find_w(h, K("block2.1.bias"), D);
+        const auto* Wt = find_w(h, K("block1.1.weight"), (size_t)S * S);
+        const auto* b1 = find_w(h, K("block1.1.bias"), S);
+        const auto* a1 = find_w(h, K("block1.0.alpha"), D);
+        const auto* be1 = find_w(h, K("block1.0.beta"), D);
+        const auto* a2 = find_w(h, K("block2.0.alpha"), D);
+        const auto* be2 = find_w(h, K("block2.0.beta"), D);
+        if (!W || !b2 || !Wt || !b1 || !a1 || !be1 || !a2 || !be2) return LS_ESTATE;
+        memcpy(&wc[(size_t)l * D * D], W->data(), (size_t)D * D * sizeof(float));
+        memcpy(&bc[(size_t)l * D], b2->data(), D * sizeof(float));
+        memcpy(&wt[(size_t)l * S * S], Wt->data(), (size_t)S * S * sizeof(float));
+        memcpy(&bt[(size_t)l * S], b1->data(), S * sizeof(float));
+        memcpy(&l1a[(size_t)l * D], a1->data(), D * sizeof(float));
+        memcpy(&l1b[(size_t)l * D], be1->data(), D * sizeof(float));
+        memcpy(&l2a[(size_t)l * D], a2->data(), D * sizeof(float));
+        memcpy(&l2b[(size_t)l * D], be2->data(), D * sizeof(float));
+    }
+    const auto* Win = find_w(h, "input_mapping.weight", (size_t)D * KIN);
+    const auto* Wout = find_w(h, "output_process.poseFinal.weight", (size_t)JF * D);
+    const auto* bo = find_w(h, "output_process.poseFinal.bias", JF);
+    if (!Win || !Wout || !bo) return LS_ESTATE;
+    std::vector<float> winx((size_t)D * JFP, 0.f);                                      // x_t columns, K padded to whole GEMM tiles
+    for (int n = 0; n < D; ++n)
+        for (int k = 0; k < JF; ++k) winx[(size_t)n * JFP + k] = (*Win)[(size_t)n * KIN + k];
+    int rc;
+#define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
+    UP(lw_wt, wt); UP(lw_bt, bt); UP(lw_wc, wc); UP(lw_bc, bc); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
+    UP(lw_winx, winx); UP(lw_wout, *Wout); UP(bout, *bo);
+#undef UP
+    return LS_OK;
+}
+
+int build_images(ls_handle* h) {
+    int rc = h->fused ? build_fused_images(h) : build_long_weights(h);
+    if (rc != LS_OK) return rc;
+    if ((rc = build_shared_weights(h)) != LS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return LS_OK;
 }
@@ -407,7 +476,20 @@ int ensure_temb_table(ls_handle* h) {
 // pair: the single-pass variant (two samples' cond pass per workgroup), legal when every guidance scale is 1
 hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
     s.batch = B;
-    return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
+    if (h->fused) return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
+    // long-sequence path: the same step from batch-level kernels (both passes always; exact fp32 only)
+    LongStepArgs a{};
+    a.B = B; a.T = h->T; a.S = h->S; a.npre = h->cfg.n_prefix_tokens; a.JF = h->JF; a.JFP = h->JFP; a.ldo = h->JFP; a.layers = h->cfg.layers;
+    a.x_in = s.x_in; a.x_out = s.x_out; a.x0_out = s.x0_out; a.fwd_c = s.fwd_c; a.fwd_u = s.fwd_u;
+    a.static_c = s.static_c; a.static_u = s.static_u; a.z_mu = s.z_mu; a.z_std = s.z_std; a.emo_tok = s.emo_tok; a.scale = s.scale;
+    a.temb = s.temb;
+    a.eps_c = s.eps_c; a.eps_u = s.eps_u; a.noise = s.noise; a.const_noise = s.const_noise; a.call = s.call; a.step_id = s.step_id;
+    a.winx = h->lw_winx.f(); a.ln1a = h->ln1a.f(); a.ln1b = h->ln1b.f(); a.ln2a = h->ln2a.f(); a.ln2b = h->ln2b.f();
+    a.wt = h->lw_wt.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
+    a.xproj = h->lx_proj.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
+    a.sampler = s.sampler; a.t_nonzero = s.t_nonzero; a.clip_denoised = s.clip_denoised;
+    a.c0 = s.c0; a.c1 = s.c1; a.c2 = s.c2; a.c3 = s.c3; a.c4 = s.c4;
+    return launch_step_long(a, st);
 }
 
 void fill_common(ls_handle* h, StepArgs& a) {
@@ -459,7 +541,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (!cfg || !out) return fail(nullptr, LS_EINVAL, "ls_create: null argument");
     *out = nullptr;
     if (cfg->latent_dim != kD) return fail(nullptr, LS_EUNSUPPORTED, "latent_dim must be %d", kD);
-    if (cfg->nframes != kT) return fail(nullptr, LS_EUNSUPPORTED, "nframes must be %d", kT);
+    if (cfg->nframes < cfg->n_pre_seq || cfg->nframes < 1 || cfg->nframes > 4096) return fail(nullptr, LS_EINVAL, "nframes out of range");
     const int JF = cfg->njoints * cfg->nfeats;
     Variant var;
     if (JF == 27 && cfg->n_prefix_tokens == 1) var = kTED;
@@ -475,7 +557,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
         L = (L + 2 * kConvPad[i] - 15) / kConvStride[i] + 1;
         convL[i + 1] = L;
     }
-    if (L != kT) return fail(nullptr, LS_EINVAL, "audio_len %d yields %d audio frames, need %d", cfg->audio_len, L, kT);
+    if (L != cfg->nframes) return fail(nullptr, LS_EINVAL, "audio_len %d yields %d audio frames, need %d", cfg->audio_len, L, cfg->nframes);
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail(nullptr, LS_EHIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
     ls_handle* h = new ls_handle();
@@ -486,7 +568,10 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
 #endif
     h->var = var;
     h->JF = JF;
-    h->S = kT + cfg->n_prefix_tokens;
+    h->T = cfg->nframes;
+    h->fused = cfg->nframes == kT;          // the reference's 34 frames: fused step kernel; otherwise the long-sequence path
+    h->JFP = (JF + 31) / 32 * 32;
+    h->S = h->T + cfg->n_prefix_tokens;
     h->R = 2 * h->S;
     h->NOB = (JF + 15) / 16;
     h->KXQ = (JF + 15) / 16;
@@ -527,7 +612,8 @@ void ls_destroy(ls_handle* h) {
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
-                     &h->callp, &h->eps_tape, &h->noise_tape};
+                     &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_winx, &h->lw_wout,
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -564,6 +650,7 @@ int ls_set_precision(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
     if (mode != LS_PRECISION_FP32 && mode != LS_PRECISION_BF16X3)
         return fail(h, LS_EINVAL, "unknown precision mode %d", mode);
+    if (!h->fused && mode != LS_PRECISION_FP32) return fail(h, LS_EUNSUPPORTED, "the long-sequence path (nframes != %d) is exact fp32 only", kT);
     if (mode != h->precision) free_graph(h);
     h->precision = mode;
     return LS_OK;
@@ -605,10 +692,10 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     int rc;
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     if ((rc = ingest(h, h->audio, c->audio_input, (size_t)B * AL * sizeof(float), od)) != LS_OK) return rc;
-    if ((rc = ingest(h, h->origin_x, c->origin_x, (size_t)B * JF * kT * sizeof(float), od)) != LS_OK) return rc;
+    if ((rc = ingest(h, h->origin_x, c->origin_x, (size_t)B * JF * h->T * sizeof(float), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->vid, c->vid_indices, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->scale, c->scale, (size_t)B * sizeof(float), od)) != LS_OK) return rc;
-    if (c->emo && (rc = ingest(h, h->emo, c->emo, (size_t)B * kT * sizeof(int64_t), od)) != LS_OK) return rc;
+    if (c->emo && (rc = ingest(h, h->emo, c->emo, (size_t)B * h->T * sizeof(int64_t), od)) != LS_OK) return rc;
     {   // guidance scale 1 for the whole batch (what the reference's callers run: test_RAG_ted.py:183): out_u + 1 * (out_c - out_u)
         // is out_c, so the sampling loop may skip the uncond pass (ls_sample_args.two_pass_always keeps both)
         std::vector<float> sc((size_t)B);
@@ -651,13 +738,13 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     }
     // ---- static part of input_mapping (RAG.py:110-114): columns JF.. of W_in act on [prefix poses | bit | audio]
     const int KFP = h->KFP;
-    HIPCHK(h, h->feat_c.ensure((size_t)B * kT * KFP * sizeof(float)));
-    HIPCHK(h, h->feat_u.ensure((size_t)B * kT * KFP * sizeof(float)));
-    HIPCHK(h, h->static_c.ensure((size_t)B * kT * kD * sizeof(float)));
-    HIPCHK(h, h->static_u.ensure((size_t)B * kT * kD * sizeof(float)));
-    HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_c.f(), h->feat_u.f(), B, JF, KFP, h->cfg.n_pre_seq, st));
-    HIPCHK(h, launch_gemm_nt(h->feat_c.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_c.f(), kD, B * kT, kD, KFP, 0, st));
-    HIPCHK(h, launch_gemm_nt(h->feat_u.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_u.f(), kD, B * kT, kD, KFP, 0, st));
+    HIPCHK(h, h->feat_c.ensure((size_t)B * h->T * KFP * sizeof(float)));
+    HIPCHK(h, h->feat_u.ensure((size_t)B * h->T * KFP * sizeof(float)));
+    HIPCHK(h, h->static_c.ensure((size_t)B * h->T * kD * sizeof(float)));
+    HIPCHK(h, h->static_u.ensure((size_t)B * h->T * kD * sizeof(float)));
+    HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_c.f(), h->feat_u.f(), B, JF, KFP, h->cfg.n_pre_seq, st, h->T));
+    HIPCHK(h, launch_gemm_nt(h->feat_c.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_c.f(), kD, B * h->T, kD, KFP, 0, st));
+    HIPCHK(h, launch_gemm_nt(h->feat_u.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_u.f(), kD, B * h->T, kD, KFP, 0, st));
     // ---- speaker style (RAG.py:116-119): z = Embedding[vid]; mu, logvar = Linear(z); std = exp(0.5*logvar)
     HIPCHK(h, h->z.ensure((size_t)B * 256 * sizeof(float)));
     HIPCHK(h, h->z_mu.ensure((size_t)B * kD * sizeof(float)));
@@ -669,7 +756,16 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), nullptr, 0, h->z_std.f(), kD, B, kD, 256, 2, st));
     if (h->cfg.n_prefix_tokens == 2) {   // scripts_beat/model/RAG.py:125
         HIPCHK(h, h->emo_tok.ensure((size_t)B * kD * sizeof(float)));
-        HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, kT));   // y['emo'][:, 0]
+        HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, h->T));   // y['emo'][:, 0]
+    }
+    if (!h->fused) {        // workspaces of the long-sequence path: token sequences of both passes, their LayerNorm'd copy, poseFinal output
+        const void* old[4] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p};
+        const size_t rows = (size_t)2 * B * h->S;
+        HIPCHK(h, h->lx_proj.ensure((size_t)B * h->T * kD * sizeof(float)));
+        HIPCHK(h, h->lx_X.ensure(rows * kD * sizeof(float)));
+        HIPCHK(h, h->lx_U.ensure(rows * kD * sizeof(float)));
+        HIPCHK(h, h->lx_OUT.ensure(rows * h->JFP * sizeof(float)));
+        if (old[0] != h->lx_proj.p || old[1] != h->lx_X.p || old[2] != h->lx_U.p || old[3] != h->lx_OUT.p) free_graph(h);
     }
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     HIPCHK(h, hipStreamSynchronize(st));
@@ -686,12 +782,12 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
     if (!a->x || !a->timesteps || !a->eps_cond || !a->eps_uncond) return fail(h, LS_EINVAL, "ls_forward: null input");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int B = h->B, JF = h->JF, od = a->on_device;
-    const size_t nx = (size_t)B * JF * kT * sizeof(float);
+    const size_t nx = (size_t)B * JF * h->T * sizeof(float);
     hipStream_t st = h->stream;
     int rc;
     if ((rc = ingest(h, h->xio, a->x, nx, od)) != LS_OK) return rc;
     HIPCHK(h, h->xa.ensure(nx));
-    HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st));
+    HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st, h->T));
     HIPCHK(h, h->eps.ensure((size_t)2 * B * kD * sizeof(float)));
     HIPCHK(h, hipMemcpyAsync(h->eps.f(), a->eps_cond, (size_t)B * kD * sizeof(float), od ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->eps.f() + (size_t)B * kD, a->eps_uncond, (size_t)B * kD * sizeof(float), od ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
@@ -704,6 +800,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
     s.fwd_c = h->fwd_c.f(); s.fwd_u = h->fwd_u.f(); s.x0_out = h->fwd_cfg.f();
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
     s.temb = h->tfwd.f(); s.temb_stride = kD;
+    if (a->trace && !h->fused) return fail(h, LS_EUNSUPPORTED, "the residual-stream trace is an output of the fused step kernel only");
     if (a->trace) {
         HIPCHK(h, h->trace.ensure((size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float)));
         s.trace = h->trace.f();
@@ -713,7 +810,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
     const float* srcs[3] = {h->fwd_c.f(), h->fwd_u.f(), h->fwd_cfg.f()};
     for (int i = 0; i < 3; ++i) {
         if (!outs[i]) continue;
-        HIPCHK(h, launch_from_internal(srcs[i], h->xio.f(), B, JF, st));
+        HIPCHK(h, launch_from_internal(srcs[i], h->xio.f(), B, JF, st, h->T));
         if ((rc = egress(h, outs[i], h->xio.f(), nx, od)) != LS_OK) return rc;
     }
     if (a->trace && (rc = egress(h, a->trace, h->trace.f(), (size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float), od)) != LS_OK) return rc;
@@ -730,13 +827,13 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     if (a->sampler != LS_SAMPLER_DDPM && a->sampler != LS_SAMPLER_DDIM) return fail(h, LS_EINVAL, "bad sampler");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int B = h->B, JF = h->JF, od = a->on_device;
-    const size_t nx = (size_t)B * JF * kT * sizeof(float);
+    const size_t nx = (size_t)B * JF * h->T * sizeof(float);
     hipStream_t st = h->stream;
     int rc;
     if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
     if ((rc = ingest(h, h->xio, a->x, nx, od)) != LS_OK) return rc;
     HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->fwd_cfg.ensure(nx));
-    HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st));
+    HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st, h->T));
     HIPCHK(h, h->eps.ensure((size_t)2 * B * kD * sizeof(float)));
     const hipMemcpyKind kind = od ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIPCHK(h, hipMemcpyAsync(h->eps.f(), a->eps_cond, (size_t)B * kD * sizeof(float), kind, st));
@@ -750,11 +847,11 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
     s.noise = h->noise.f();
     s.temb = h->temb.f() + (size_t)a->index * kD; s.temb_stride = 0;
-    HIPCHK(h, run_step(h, s, B, h->all_scale_one && !a->two_pass_always, st));
-    HIPCHK(h, launch_from_internal(h->xb.f(), h->xio.f(), B, JF, st));
+    HIPCHK(h, run_step(h, s, B, h->fused && h->all_scale_one && !a->two_pass_always, st));
+    HIPCHK(h, launch_from_internal(h->xb.f(), h->xio.f(), B, JF, st, h->T));
     if ((rc = egress(h, a->sample, h->xio.f(), nx, od)) != LS_OK) return rc;
     if (a->pred_xstart) {
-        HIPCHK(h, launch_from_internal(h->fwd_cfg.f(), h->xio.f(), B, JF, st));
+        HIPCHK(h, launch_from_internal(h->fwd_cfg.f(), h->xio.f(), B, JF, st, h->T));
         if ((rc = egress(h, a->pred_xstart, h->xio.f(), nx, od)) != LS_OK) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(st));
@@ -797,7 +894,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int B = h->B, JF = h->JF, od = a->on_device;
     const int n_exec = h->n_steps - a->skip_timesteps;
-    const size_t nelem = (size_t)B * JF * kT;
+    const size_t nelem = (size_t)B * JF * h->T;
     const size_t nx = nelem * sizeof(float);
     hipStream_t st = h->stream;
     int rc;
@@ -810,16 +907,16 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     // x_T (gaussian_diffusion.py:700-707 / :972-977)
     if (a->x_init) {
         if ((rc = ingest(h, h->xio, a->x_init, nx, od)) != LS_OK) return rc;
-        HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st));
+        HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st, h->T));
     } else {
-        HIPCHK(h, launch_randn_fill(h->xa.f(), B, JF, static_cast<const CallParams*>(h->callp.p), 0u, st));
+        HIPCHK(h, launch_randn_fill(h->xa.f(), B, JF, static_cast<const CallParams*>(h->callp.p), 0u, st, h->T));
     }
     // init_image -> q_sample at the first executed index (:709-716 / :979-986)
     const int first_index = n_exec - 1;
     if (a->init_image || a->skip_timesteps > 0) {
         if (a->init_image) {
             if ((rc = ingest(h, h->xio, a->init_image, nx, od)) != LS_OK) return rc;
-            HIPCHK(h, launch_to_internal(h->xio.f(), h->xtmp.f(), B, JF, st));
+            HIPCHK(h, launch_to_internal(h->xio.f(), h->xtmp.f(), B, JF, st, h->T));
         } else {
             HIPCHK(h, hipMemsetAsync(h->xtmp.p, 0, nx, st));
         }
@@ -838,7 +935,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     }
 
     // ---- the loop: for i = T-1-skip ... 0 (gaussian_diffusion.py:724-743 / :994-1014) ----------------
-    const bool pair = h->all_scale_one && !a->two_pass_always;
+    const bool pair = h->fused && h->all_scale_one && !a->two_pass_always;
     std::string key;
     {
         char keybuf[256];
@@ -894,10 +991,10 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     }
     HIPCHK(h, hipEventRecord(h->ev[2], st));
     const float* final_x = (n_exec & 1) ? h->xb.f() : h->xa.f();
-    HIPCHK(h, launch_from_internal(final_x, h->xio.f(), B, JF, st));
+    HIPCHK(h, launch_from_internal(final_x, h->xio.f(), B, JF, st, h->T));
     if ((rc = egress(h, a->out, h->xio.f(), nx, od)) != LS_OK) return rc;
     for (int d = 0; d < a->n_dump; ++d) {
-        HIPCHK(h, launch_from_internal(h->dump.f() + (size_t)d * nelem, h->xio.f(), B, JF, st));
+        HIPCHK(h, launch_from_internal(h->dump.f() + (size_t)d * nelem, h->xio.f(), B, JF, st, h->T));
         if ((rc = egress(h, a->dump_out + (size_t)d * nelem, h->xio.f(), nx, od)) != LS_OK) return rc;
     }
     HIPCHK(h, hipEventRecord(h->ev[3], st));
@@ -912,13 +1009,13 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
 int ls_philox_x_init(ls_handle* h, int batch, uint64_t seed, uint64_t sample_offset, int on_device, float* out) {
     if (!h || !out || batch < 1) return fail(h, LS_EINVAL, "ls_philox_x_init: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    const size_t nx = (size_t)batch * h->JF * kT * sizeof(float);
+    const size_t nx = (size_t)batch * h->JF * h->T * sizeof(float);
     HIPCHK(h, h->xtmp.ensure(nx));
     HIPCHK(h, h->xio.ensure(nx));
     h->call_host = CallParams{seed, sample_offset};
     HIPCHK(h, hipMemcpyAsync(h->callp.p, &h->call_host, sizeof(CallParams), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, launch_randn_fill(h->xtmp.f(), batch, h->JF, static_cast<const CallParams*>(h->callp.p), 0u, h->stream));
-    HIPCHK(h, launch_from_internal(h->xtmp.f(), h->xio.f(), batch, h->JF, h->stream));
+    HIPCHK(h, launch_randn_fill(h->xtmp.f(), batch, h->JF, static_cast<const CallParams*>(h->callp.p), 0u, h->stream, h->T));
+    HIPCHK(h, launch_from_internal(h->xtmp.f(), h->xio.f(), batch, h->JF, h->stream, h->T));
     int rc = egress(h, out, h->xio.f(), nx, on_device);
     if (rc != LS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -949,11 +1046,11 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
     } else {
         if (!h->prepared) return fail(h, LS_ESTATE, "ls_read('%s') before ls_prepare", name);
         if (n == "audio_feat") {
-            HIPCHK(h, h->audio_feat.ensure(B * kT * kAudioFeat * sizeof(float)));
-            HIPCHK(h, launch_transpose_feat(h->c4.f(), h->audio_feat.f(), (int)B, h->stream));
-            src = h->audio_feat.f(); cnt = B * kT * kAudioFeat;
-        } else if (n == "static_c") { src = h->static_c.f(); cnt = B * kT * kD; }
-        else if (n == "static_u") { src = h->static_u.f(); cnt = B * kT * kD; }
+            HIPCHK(h, h->audio_feat.ensure(B * h->T * kAudioFeat * sizeof(float)));
+            HIPCHK(h, launch_transpose_feat(h->c4.f(), h->audio_feat.f(), (int)B, h->stream, h->T));
+            src = h->audio_feat.f(); cnt = B * h->T * kAudioFeat;
+        } else if (n == "static_c") { src = h->static_c.f(); cnt = B * h->T * kD; }
+        else if (n == "static_u") { src = h->static_u.f(); cnt = B * h->T * kD; }
         else if (n == "z_mu") { src = h->z_mu.f(); cnt = B * kD; }
         else if (n == "z_logvar") { src = h->z_logvar.f(); cnt = B * kD; }
         else if (n == "z_std") { src = h->z_std.f(); cnt = B * kD; }

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     a.A.p += (size_t)zb * a.bsA;
     a.B.p += (size_t)zb * a.bsB;
     a.C += (size_t)zb * a.bsC;
+    if (a.R) a.R += (size_t)zb * a.bsC;             // the residual and the pre-activation copy share C's addressing, batch stride included;
+    if (a.Cpre) a.Cpre += (size_t)zb * a.bsC;       // the bias is shared by the problems of a batch
 
     f4 acc[4][MT];                                  // [n tile][m tile]
 #pragma unroll
@@ -304,7 +306,6 @@ hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits
     a.kchunk = kchunk;
     a.splits = splits;
     if (a.nbatch < 1) a.nbatch = 1;
-    if (a.nbatch > 1 && (a.bias || a.Cpre || a.R)) return hipErrorInvalidValue;
     if (splits > 1 && (!a.ws || (size_t)a.nbatch * splits * a.M * a.N > a.ws_floats)) return hipErrorInvalidValue;
     if (splits > 1 && (a.Cpre || a.R || a.act)) return hipErrorInvalidValue;
     dim3 grid((a.N + kTM - 1) / kTM, (a.M + kTM - 1) / kTM, a.nbatch * splits);

@@ -100,6 +100,29 @@ struct StepArgs {
 // dataset variant of the compiled kernel
 enum Variant { kTED = 0, kBEAT = 1 };
 
+// Arguments of one diffusion step of the long-sequence path (ls_long.hip): same roles as StepArgs, plus the batch-level workspaces.
+struct LongStepArgs {
+    int B, T, S, npre, JF, JFP, ldo, layers;
+    const float* x_in; float* x_out; float* x0_out; float* fwd_c; float* fwd_u;      // internal layout [B][T][JF]
+    const float* static_c; const float* static_u; const float* z_mu; const float* z_std; const float* emo_tok; const float* scale;
+    const float* temb;                     // one row (the timestep is uniform over the batch in sampling)
+    const float* eps_c; const float* eps_u; const float* noise; int const_noise;
+    const CallParams* call; unsigned step_id;
+    // weights (row-major, as in the state dict)
+    const float* winx;                     // [512][JFP]  x_t columns of input_mapping
+    const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;      // [L][512]
+    const float* wt; const float* bt;      // [L][S][S], [L][S]   token-mixing Conv1d(S, S, 1)
+    const float* wc; const float* bc;      // [L][512][512], [L][512]
+    const float* wout; const float* bout;  // [JF][512], [JF]
+    // workspaces
+    float* xproj;                          // [B*T][512]
+    float* X; float* U;                    // [2*B*S][512]
+    float* OUT;                            // [2*B*S][ldo]
+    int sampler, t_nonzero, clip_denoised;
+    float c0, c1, c2, c3, c4;
+};
+hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st);
+
 // prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
 // pair: 0 = CFG (cond + uncond pass of one sample per workgroup), 1 = single pass (guidance scale 1: two samples per workgroup)
 hipError_t launch_step(Variant v, int prec, int pair, const StepArgs& a, int batch, hipStream_t st);
@@ -127,14 +150,14 @@ hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, cons
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int rows, int width,
                               int table_rows, hipStream_t st, int idx_stride = 1);
 hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
-                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st);
-hipError_t launch_to_internal(const float* src_bjft, float* dst_btc, int B, int JF, hipStream_t st);
-hipError_t launch_from_internal(const float* src_btc, float* dst_bjft, int B, int JF, hipStream_t st);
+                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st, int T = kT);
+hipError_t launch_to_internal(const float* src_bjft, float* dst_btc, int B, int JF, hipStream_t st, int T = kT);
+hipError_t launch_from_internal(const float* src_btc, float* dst_bjft, int B, int JF, hipStream_t st, int T = kT);
 hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size_t n, float a, float b,
                            hipStream_t st);
 hipError_t launch_randn_fill(float* out_btc, int B, int JF, const CallParams* call, unsigned stream_id,
-                             hipStream_t st);
-hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipStream_t st);
+                             hipStream_t st, int T = kT);
+hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipStream_t st, int T = kT);
 
 // ---- SAG decoder kernels (ls_sag.hip) ----------------------------------------------------------
 hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bmap, const float* pe, float* q, int B,

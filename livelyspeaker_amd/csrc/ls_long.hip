@@ -1,0 +1,141 @@
+// Long-sequence variant of the diffusion step (nframes != 34), built from batch-level kernels.
+//
+// BASELINE.json configs[4] words the BEAT workload as "256 x 150 frames".  The reference cannot run that: RAG's token-mixing
+// Conv1d fixes the sequence at 34 frames + prefix tokens (scripts_beat/model/RAG.py:56, 119-126) and its audio encoder yields 149
+// frames for the 160 000-sample clips.  SURVEY.md 8(d) "Config 5" therefore allows a SYNTHETIC, perf-only variant (S = 152 tokens,
+// audio length chosen so the encoder yields 150 frames) with no parity claim against the reference; it is checked against this
+// repository's own CPU oracle, which is generic in the frame count.
+//
+// The fused kernel (ls_step_kernel.h) keeps a sample's whole [2S][512] operand in one CU's LDS; at S = 152 that is 632 KB, so this
+// path runs the same arithmetic as separate launches over ALL rows of the batch (row r = (pass, sample, token); pass 0 = cond,
+// 1 = uncond):
+//   k_long_assemble   token sequences: style / emotion tokens + static projection + x_t projection        (RAG.py:110-126)
+//   per layer:  k_long_addemb_ln (x += emb; u = LN1(x)) -> token mixing as a batched GEMM per sequence, written transposed
+//               (x += SiLU(Wt u + bt)) -> k_layernorm512 (u = LN2(x)) -> channel mixing GEMM (x += SiLU(u Wc^T + bc))
+//   poseFinal GEMM -> k_long_update (CFG lerp + DDPM / DDIM update + noise)                 (cfg_sampler.py:31, gaussian_diffusion.py)
+// All products run on the fp32 MFMA GEMM k_gemm_tr (ls_gemm.hip).
+#include "ls_internal.h"
+#include "ls_lanes.h"
+#include "ls_philox.h"
+#include "ls_train.h"
+
+namespace ls {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// X[(p*B + b)*S + s][:] : s = 0 style token (mu + eps * std), s = 1 emotion token (two-prefix variants), else frame t = s - NPRE:
+// xproj[b*T + t] + static_{c|u}[b*T + t].  One 128-thread workgroup per row (one float4 per thread).
+__global__ __launch_bounds__(128) void k_long_assemble(const LongStepArgs a) {
+    const int r = blockIdx.x, s = r % a.S, pb = r / a.S, b = pb % a.B, p = pb / a.B;
+    const int ch = 4 * threadIdx.x;
+    f4 v;
+    if (s >= a.npre) {
+        const size_t fr = ((size_t)b * a.T + (s - a.npre)) * kD + ch;
+        v = *reinterpret_cast<const f4*>(a.xproj + fr) + *reinterpret_cast<const f4*>((p ? a.static_u : a.static_c) + fr);
+    } else if (s == 0) {
+        const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + ch), sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + ch);
+        f4 e;
+        const float* ep = p ? a.eps_u : a.eps_c;
+        if (ep) e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + ch);
+        else {
+            float z[4];
+            philox_normal4(a.call, a.call->sample_offset + (unsigned long long)b, a.step_id, 1u + p, (unsigned)(ch >> 2), z);
+            e = (f4){z[0], z[1], z[2], z[3]};
+        }
+        v = mu + e * sd;
+    } else {
+        v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);
+    }
+    *reinterpret_cast<f4*>(a.X + (size_t)r * kD + ch) = v;
+}
+
+// x += emb (the timestep embedding is re-added at the input of every block, mlp_module.py:68-69); u = LN_spatial(x) * alpha + beta
+// (mlp_module.py:29-35: biased variance over the 512 channels, eps 1e-5).  One wave per row.
+__global__ __launch_bounds__(256) void k_long_addemb_ln(float* __restrict__ x, const float* __restrict__ emb, const float* __restrict__ alpha,
+                                                        const float* __restrict__ beta, float* __restrict__ u, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    f4* xr = reinterpret_cast<f4*>(x + (size_t)r * kD);
+    const f4* er = reinterpret_cast<const f4*>(emb);
+    const f4 v0 = xr[lane] + er[lane], v1 = xr[lane + 64] + er[lane + 64];
+    xr[lane] = v0;
+    xr[lane + 64] = v1;
+    float s = (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+    const float mean = wave_sum(s) * (1.0f / kD);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float c0 = v0[e] - mean, c1 = v1[e] - mean; q += c0 * c0 + c1 * c1; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kD) + 1e-5f);
+    const f4* al = reinterpret_cast<const f4*>(alpha);
+    const f4* be = reinterpret_cast<const f4*>(beta);
+    f4* ur = reinterpret_cast<f4*>(u + (size_t)r * kD);
+    ur[lane] = (v0 - mean) * rstd * al[lane] + be[lane];
+    ur[lane + 64] = (v1 - mean) * rstd * al[lane + 64] + be[lane + 64];
+}
+
+// CFG combination + sampler update, element (b, t, c) of the internal [B][T][JF] layout; OUT rows are (pass, b, token) x ldo
+__global__ __launch_bounds__(256) void k_long_update(const LongStepArgs a) {
+    const int b = blockIdx.y;
+    const int TJ = a.T * a.JF;
+    const float sc = a.scale ? a.scale[b] : 1.0f;
+    const unsigned long long gidx = a.call->sample_offset + (unsigned long long)b;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < TJ; idx += gridDim.x * 256) {
+        const int f = idx / a.JF, c = idx - f * a.JF;
+        const float bo = a.bout[c];
+        const float oc = a.OUT[((size_t)(0 * a.B + b) * a.S + a.npre + f) * a.ldo + c] + bo;
+        const float ou = a.OUT[((size_t)(1 * a.B + b) * a.S + a.npre + f) * a.ldo + c] + bo;
+        const size_t base = (size_t)b * TJ;
+        if (a.fwd_c) a.fwd_c[base + idx] = oc;
+        if (a.fwd_u) a.fwd_u[base + idx] = ou;
+        float x0 = ou + sc * (oc - ou);
+        if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        if (a.x0_out) a.x0_out[base + idx] = x0;
+        if (a.sampler == kNone) continue;
+        const float xt = a.x_in[base + idx];
+        float nz = 0.f;
+        if (a.t_nonzero) {
+            if (a.noise) nz = a.noise[((size_t)(a.const_noise ? 0 : b) * a.JF + c) * a.T + f];
+            else nz = philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(c * a.T + f));
+        }
+        float xn;
+        if (a.sampler == kDDPM) {
+            xn = a.c0 * x0 + a.c1 * xt;
+            if (a.t_nonzero) xn += a.c2 * nz;
+        } else {
+            const float eps = (a.c0 * xt - x0) / a.c1;
+            xn = x0 * a.c2 + a.c3 * eps;
+            if (a.t_nonzero) xn += a.c4 * nz;
+        }
+        a.x_out[base + idx] = xn;
+    }
+}
+
+hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
+    const int rows = 2 * a.B * a.S, D = kD;
+    hipError_t e;
+    // x_t columns of input_mapping: xproj[B*T][512] = x_t[B*T][JF] . Win[:, :JF]^T   (K padded with zero columns of the weight)
+    if ((e = launch_gemm_nt(a.x_in, a.JF, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, a.B * a.T, D, a.JF, 0, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a);
+    for (int l = 0; l < a.layers; ++l) {
+        hipLaunchKernelGGL(k_long_addemb_ln, dim3((rows + 3) / 4), dim3(256), 0, st, a.X, a.temb, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.U, rows);
+        {   // token mixing, one problem per sequence: C'[channel][token] = sum_k U[k][channel] Wt[token][k] + bt[token], stored at
+            // X[token][channel] (crs = 1, cns = 512): the Conv1d bias is per output TOKEN, which is the GEMM's per-column bias in this form
+            GemmArgs g{};
+            g.A = op_cols(a.U, D, D, a.S);                               // operand row = channel, reduction index = token (stride 512)
+            g.B = op_rows(a.wt + (size_t)l * a.S * a.S, a.S, a.S, a.S);
+            g.C = a.X; g.cri = INT_MAX; g.cro = 0; g.crs = 1; g.cns = D;
+            g.bias = a.bt + (size_t)l * a.S; g.R = a.X; g.act = 1;
+            g.M = D; g.N = a.S; g.K = a.S;
+            g.nbatch = 2 * a.B; g.bsA = (long long)a.S * D; g.bsB = 0; g.bsC = (long long)a.S * D;
+            if ((e = launch_gemm_tr(g, false, true, 1, st)) != hipSuccess) return e;
+        }
+        if ((e = launch_layernorm512(a.X, nullptr, 0, a.ln2a + (size_t)l * D, a.ln2b + (size_t)l * D, a.U, rows, st)) != hipSuccess) return e;
+        if ((e = launch_gemm_nt(a.U, D, a.wc + (size_t)l * D * D, D, a.bc + (size_t)l * D, a.X, D, a.X, D, rows, D, D, 1, st)) != hipSuccess) return e;
+    }
+    if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, rows, a.JF, D, 0, st)) != hipSuccess) return e;
+    const int TJ = a.T * a.JF;
+    hipLaunchKernelGGL(k_long_update, dim3((TJ + 1023) / 1024, a.B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace ls

@@ -31,19 +31,19 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out
 // InputProcess features without the x_t columns (RAG.py:110-112, 184-192):
 // row (b,f) = [origin_x[b,:,f] if f < n_pre_seq else 0 | indicator bit | audio feature (cond) or 0 (uncond)]
 __global__ void k_build_feats(const float* __restrict__ origin_x, const float* __restrict__ conv4,
-                              float* __restrict__ feat_c, float* __restrict__ feat_u, int JF, int KFP, int n_pre_seq) {
-    const int b = blockIdx.x / kT, f = blockIdx.x % kT;
+                              float* __restrict__ feat_c, float* __restrict__ feat_u, int JF, int KFP, int n_pre_seq, int T) {
+    const int b = blockIdx.x / T, f = blockIdx.x % T;
     const int KF = JF + 1 + kAudioFeat;
     float* fc = feat_c + (size_t)blockIdx.x * KFP;          // rows padded with zeros to KFP (a whole number of GEMM K tiles)
     float* fu = feat_u + (size_t)blockIdx.x * KFP;
     for (int c = threadIdx.x; c < KFP; c += blockDim.x) {
         float vc, vu;
         if (c < JF) {
-            vc = vu = (f < n_pre_seq) ? origin_x[((size_t)b * JF + c) * kT + f] : 0.f;
+            vc = vu = (f < n_pre_seq) ? origin_x[((size_t)b * JF + c) * T + f] : 0.f;
         } else if (c == JF) {
             vc = vu = (f < n_pre_seq) ? 1.f : 0.f;
         } else if (c < KF) {
-            vc = conv4[((size_t)b * kAudioFeat + (c - JF - 1)) * kT + f];
+            vc = conv4[((size_t)b * kAudioFeat + (c - JF - 1)) * T + f];
             vu = 0.f;                                                   // mask_cond(force_mask), RAG.py:82-83
         } else {
             vc = vu = 0.f;
@@ -54,45 +54,45 @@ __global__ void k_build_feats(const float* __restrict__ origin_x, const float* _
 }
 
 hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
-                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st) {
-    hipLaunchKernelGGL(k_build_feats, dim3(B * kT), dim3(256), 0, st, origin_x, conv4, feat_c, feat_u, JF, KFP, n_pre_seq);
+                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st, int T) {
+    hipLaunchKernelGGL(k_build_feats, dim3(B * T), dim3(256), 0, st, origin_x, conv4, feat_c, feat_u, JF, KFP, n_pre_seq, T);
     return hipGetLastError();
 }
 
 // [B][JF][T] (reference [B,J,F,T]) <-> internal [B][T][JF]
-__global__ void k_to_internal(const float* __restrict__ src, float* __restrict__ dst, int JF) {
+__global__ void k_to_internal(const float* __restrict__ src, float* __restrict__ dst, int JF, int T) {
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < kT * JF; i += blockDim.x) {
+    for (int i = threadIdx.x; i < T * JF; i += blockDim.x) {
         const int f = i / JF, c = i - f * JF;
-        dst[(size_t)b * kT * JF + i] = src[((size_t)b * JF + c) * kT + f];
+        dst[(size_t)b * T * JF + i] = src[((size_t)b * JF + c) * T + f];
     }
 }
-__global__ void k_from_internal(const float* __restrict__ src, float* __restrict__ dst, int JF) {
+__global__ void k_from_internal(const float* __restrict__ src, float* __restrict__ dst, int JF, int T) {
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < kT * JF; i += blockDim.x) {
-        const int c = i / kT, f = i - c * kT;
-        dst[(size_t)b * kT * JF + i] = src[((size_t)b * kT + f) * JF + c];
+    for (int i = threadIdx.x; i < T * JF; i += blockDim.x) {
+        const int c = i / T, f = i - c * T;
+        dst[(size_t)b * T * JF + i] = src[((size_t)b * T + f) * JF + c];
     }
 }
-hipError_t launch_to_internal(const float* s, float* d, int B, int JF, hipStream_t st) {
-    hipLaunchKernelGGL(k_to_internal, dim3(B), dim3(256), 0, st, s, d, JF);
+hipError_t launch_to_internal(const float* s, float* d, int B, int JF, hipStream_t st, int T) {
+    hipLaunchKernelGGL(k_to_internal, dim3(B), dim3(256), 0, st, s, d, JF, T);
     return hipGetLastError();
 }
-hipError_t launch_from_internal(const float* s, float* d, int B, int JF, hipStream_t st) {
-    hipLaunchKernelGGL(k_from_internal, dim3(B), dim3(256), 0, st, s, d, JF);
+hipError_t launch_from_internal(const float* s, float* d, int B, int JF, hipStream_t st, int T) {
+    hipLaunchKernelGGL(k_from_internal, dim3(B), dim3(256), 0, st, s, d, JF, T);
     return hipGetLastError();
 }
 
 // conv4 [B][256][T] -> audio feature [B][T][256] (audio_enc.py:25 transpose), for ls_read("audio_feat")
-__global__ void k_transpose_feat(const float* __restrict__ conv4, float* __restrict__ out) {
+__global__ void k_transpose_feat(const float* __restrict__ conv4, float* __restrict__ out, int T) {
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < kT * kAudioFeat; i += blockDim.x) {
+    for (int i = threadIdx.x; i < T * kAudioFeat; i += blockDim.x) {
         const int f = i / kAudioFeat, c = i - f * kAudioFeat;
-        out[(size_t)b * kT * kAudioFeat + i] = conv4[((size_t)b * kAudioFeat + c) * kT + f];
+        out[(size_t)b * T * kAudioFeat + i] = conv4[((size_t)b * kAudioFeat + c) * T + f];
     }
 }
-hipError_t launch_transpose_feat(const float* conv4, float* out, int B, hipStream_t st) {
-    hipLaunchKernelGGL(k_transpose_feat, dim3(B), dim3(256), 0, st, conv4, out);
+hipError_t launch_transpose_feat(const float* conv4, float* out, int B, hipStream_t st, int T) {
+    hipLaunchKernelGGL(k_transpose_feat, dim3(B), dim3(256), 0, st, conv4, out, T);
     return hipGetLastError();
 }
 
@@ -110,16 +110,16 @@ hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size
 }
 
 // Philox x_T (perf mode): element index follows the reference layout (c*T+f) so it is layout independent.
-__global__ void k_randn_fill(float* __restrict__ out, int JF, const CallParams* __restrict__ call, unsigned stream_id) {
+__global__ void k_randn_fill(float* __restrict__ out, int JF, const CallParams* __restrict__ call, unsigned stream_id, int T) {
     const int b = blockIdx.x;
     const unsigned long long gidx = call->sample_offset + (unsigned long long)b;
-    for (int i = threadIdx.x; i < kT * JF; i += blockDim.x) {
+    for (int i = threadIdx.x; i < T * JF; i += blockDim.x) {
         const int f = i / JF, c = i - f * JF;
-        out[(size_t)b * kT * JF + i] = philox_normal(call, gidx, 0xFFFFFFu, stream_id, (unsigned)(c * kT + f));
+        out[(size_t)b * T * JF + i] = philox_normal(call, gidx, 0xFFFFFFu, stream_id, (unsigned)(c * T + f));
     }
 }
-hipError_t launch_randn_fill(float* out, int B, int JF, const CallParams* call, unsigned stream_id, hipStream_t st) {
-    hipLaunchKernelGGL(k_randn_fill, dim3(B), dim3(256), 0, st, out, JF, call, stream_id);
+hipError_t launch_randn_fill(float* out, int B, int JF, const CallParams* call, unsigned stream_id, hipStream_t st, int T) {
+    hipLaunchKernelGGL(k_randn_fill, dim3(B), dim3(256), 0, st, out, JF, call, stream_id, T);
     return hipGetLastError();
 }
 

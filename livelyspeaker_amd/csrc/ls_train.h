@@ -29,7 +29,7 @@ struct GemmArgs {
     float* ws;               // split-K workspace [batch][split][M][N]
     size_t ws_floats;
     // batched form: blockIdx.z = batch * splits + split; problem b reads A.p + b*bsA, B.p + b*bsB and writes C + b*bsC
-    // (bias / Cpre / R are not batched: they must be null when nbatch > 1)
+    // (Cpre / R follow C's batch stride; the bias is shared by all problems of the batch)
     int nbatch, splits;
     long long bsA, bsB, bsC;
 };

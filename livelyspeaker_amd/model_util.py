@@ -17,8 +17,10 @@ def load_model_wo_clip(model, state_dict):
 
 
 def get_model_args(args, dataset="ted"):
-    beat = dataset == "beat"
-    return {'modeltype': '', 'njoints': args.njoints if beat else 9, 'nfeats': 6 if beat else 3, 'num_actions': 1370,
+    """dataset: "ted" | "beat" (the reference's two factories) | "beat150" (synthetic long-sequence BEAT variant, perf-only)."""
+    beat = dataset in ("beat", "beat150")
+    extra = {'nframes': 150, 'audio_len': 160745} if dataset == "beat150" else {}
+    return {**extra, 'modeltype': '', 'njoints': args.njoints if beat else 9, 'nfeats': 6 if beat else 3, 'num_actions': 1370,
             'translation': True, 'pose_rep': 'rot6d', 'glob': True, 'glob_rot': True,
             'latent_dim': args.latent_dim, 'ff_size': 1024 if beat else args.ff_size, 'num_layers': args.layers,
             'num_heads': 4, 'dropout': 0.1, 'activation': "gelu", 'data_rep': 'vec_dir', 'cond_mode': args.mdm_condm,

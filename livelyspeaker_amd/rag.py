@@ -82,7 +82,7 @@ class RAG(nn.Module):
     def __init__(self, modeltype, njoints, nfeats, num_actions, translation, pose_rep, glob, glob_rot,
                  latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1, ablation=None,
                  activation="gelu", legacy=False, data_rep='rot6d', clip_dim=512, arch='trans_enc', mlpact='silu',
-                 n_prefix_tokens=1, n_emotions=8, **kargs):
+                 n_prefix_tokens=1, n_emotions=8, nframes=34, audio_len=None, **kargs):
         super().__init__()
         self.legacy, self.modeltype, self.njoints, self.nfeats = legacy, modeltype, njoints, nfeats
         self.num_actions, self.data_rep, self.pose_rep = num_actions, data_rep, pose_rep
@@ -97,7 +97,10 @@ class RAG(nn.Module):
         if mlpact != 'silu':
             raise NotImplementedError("the gfx950 step kernel fuses SiLU (parser default, parser_util.py:92)")
         self.n_prefix_tokens = n_prefix_tokens
-        self.nframes = 34
+        #: 34 in the reference (the token-mixing conv fixes it).  Any other value builds the SYNTHETIC long-sequence variant
+        #: (perf-only; the reference cannot run it) with `audio_len` raw samples chosen so the conv stack yields `nframes` frames.
+        self.nframes = int(nframes)
+        self.audio_len = int(audio_len) if audio_len is not None else self.AUDIO_LEN[n_prefix_tokens]
         seq_len = self.nframes + n_prefix_tokens                 # 35 (RAG.py:56) | 36 (scripts_beat/model/RAG.py:56)
 
         # --- parameter holders, constructed in the reference's order (RAG.py:56-77) ---------------------
@@ -157,7 +160,7 @@ class RAG(nn.Module):
         di = self._device_index()
         if self._engine is None or self._engine.device != di:
             self._engine = _lib.Engine(self.njoints, self.nfeats, self.n_prefix_tokens,
-                                       self.AUDIO_LEN[self.n_prefix_tokens], n_emotions=self.n_emotions,
+                                       self.audio_len, n_emotions=self.n_emotions,
                                        nframes=self.nframes, n_pre_seq=self.n_pre_seq, latent_dim=self.latent_dim,
                                        layers=self.num_layers, n_speakers=1400, device=di)
             self._weights_dirty = True

@@ -56,7 +56,11 @@ class PathConfig:
 TED = PathConfig("ted", njoints=9, nfeats=3, n_prefix_tokens=1, audio_len=36267)
 BEAT = PathConfig("beat", njoints=47, nfeats=6, n_prefix_tokens=2, audio_len=36266,
                   n_emotions=8)
-CONFIGS = {"ted": TED, "beat": BEAT}
+# SYNTHETIC long-sequence variant (BASELINE configs[4]'s "150 frames" wording, SURVEY.md 8d "Config 5"): the reference cannot run it
+# (its token-mixing conv fixes 34 frames, its audio encoder yields 149 frames for 160 000 samples); 160 745 samples is the clip length
+# for which the conv stack yields exactly 150 frames (-> 32787 -> 5463 -> 909 -> 150).  Perf-only; checked against this repo's oracle.
+BEAT150 = PathConfig("beat150", njoints=47, nfeats=6, nframes=150, n_prefix_tokens=2, audio_len=160745, n_emotions=8)
+CONFIGS = {"ted": TED, "beat": BEAT, "beat150": BEAT150}
 
 AUDIO_CONV = [(1, 32, 5, 1600), (32, 64, 6, 0), (64, 128, 6, 0), (128, 256, 6, 0)]  # (cin,cout,stride,pad), k=15
 AUDIO_KERNEL = 15
@@ -128,7 +132,7 @@ def make_cond(cfg: PathConfig, batch: int, seed: int = SEED_COND, scale: float =
     g = _rng(seed)
     audio = _f32(0.1 * g.standard_normal((total, cfg.audio_len)))
     origin_x = _f32(0.3 * g.standard_normal((total, cfg.njoints, cfg.nfeats, cfg.nframes)))
-    n_vid = 1370 if cfg.name == "ted" else 30
+    n_vid = 1370 if cfg.name == "ted" else 30          # speakers: TED 1370, BEAT 30
     vid = g.integers(0, n_vid, size=(total,)).astype(np.int64)
     sl = slice(first_sample, first_sample + batch)
     y = {"audio_input": audio[sl].copy(), "origin_x": origin_x[sl].copy(),

@@ -50,8 +50,8 @@ class TorchCpuSampler:
 
     # ---- hoisted --------------------------------------------------------------------------------------------------------
     def prepare(self, y):
-        P, B, T = self.P, y["audio_input"].shape[0], 34
-        af = wav_encoder(P, y["audio_input"])                                           # [B, 34, 256]
+        P, B, T = self.P, y["audio_input"].shape[0], y["origin_x"].shape[-1]
+        af = wav_encoder(P, y["audio_input"])                                           # [B, T, 256]
         ox = y["origin_x"].clone()
         ox[..., self.n_pre_seq:] = 0
         pre = ox.permute(0, 3, 1, 2).reshape(B, T, self.JF)
@@ -74,8 +74,8 @@ class TorchCpuSampler:
 
     def cfg_forward_hoisted(self, x, temb, y, eps_c, eps_u):
         """Both CFG passes as one [2B, S, 512] batch; temb [512] (the timestep is uniform over the batch in sampling)."""
-        P, pr, B = self.P, self.prep, x.shape[0]
-        xt = x.permute(0, 3, 1, 2).reshape(B, 34, self.JF)
+        P, pr, B, T = self.P, self.prep, x.shape[0], x.shape[-1]
+        xt = x.permute(0, 3, 1, 2).reshape(B, T, self.JF)
         h = F.linear(xt, P["input_mapping.weight"][:, :self.JF])                          # x_t columns only
         h = torch.cat([h, h], 0) + pr["static"]
         style = torch.cat([pr["mu"] + eps_c.view(B, 512) * pr["std"], pr["mu"] + eps_u.view(B, 512) * pr["std"]], 0)[:, None]
@@ -89,7 +89,7 @@ class TorchCpuSampler:
             u = ln_spatial(xs, P[p + "block2.0.alpha"], P[p + "block2.0.beta"])
             xs = xs + F.silu(F.linear(u, P[p + "block2.1.weight"], P[p + "block2.1.bias"]))
         out = F.linear(xs[:, self.npt:], P["output_process.poseFinal.weight"], P["output_process.poseFinal.bias"])
-        out = out.reshape(2 * B, 34, self.J, self.Fd).permute(0, 2, 3, 1)
+        out = out.reshape(2 * B, T, self.J, self.Fd).permute(0, 2, 3, 1)
         return out[B:] + y["scale"].view(-1, 1, 1, 1) * (out[:B] - out[B:])
 
     # ---- loop (gaussian_diffusion.py:608-743 / 895-1014) ---------------------------------------------------------------------
