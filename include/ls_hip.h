@@ -189,6 +189,14 @@ int ls_philox_x_init(ls_handle* h, int batch, uint64_t seed, uint64_t sample_off
  * "audio_feat" [B,T,256], "static_c"/"static_u" [B,T,D], "z_mu"/"z_logvar"/"z_std" [B,D],
  * "temb" [n_steps,D].  Returns the element count, or a negative error. */
 long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capacity);
+
+/* Multi-GPU sharding of one batch (the reference's dist_util.py:18-41 is a stub): the path has no
+ * per-step exchange, so a C-ABI integrator shards by (1) splitting the batch contiguously with ls_shard_range, (2) giving every
+ * rank's handle the same weights (broadcast them with whatever communicator the host application has -- RCCL ncclBroadcast of
+ * the arrays passed to ls_set_weight), (3) passing ls_sample_args.sample_offset = first so the PHILOX streams follow the global
+ * sample index (results do not depend on the GPU count), (4) gathering the [count, J, F, T] outputs.  livelyspeaker_amd/shard.py
+ * is that recipe over torch.distributed.  Rank r of `world` owns samples [first, first + count). */
+int ls_shard_range(int64_t total, int32_t world, int32_t rank, int64_t* first, int64_t* count);
 int ls_get_timing(const ls_handle* h, ls_timing* out);
 int ls_synchronize(ls_handle* h);
 

@@ -1062,6 +1062,14 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
     return (long long)cnt;
 }
 
+int ls_shard_range(int64_t total, int32_t world, int32_t rank, int64_t* first, int64_t* count) {
+    if (total < 0 || world < 1 || rank < 0 || rank >= world || !first || !count) return LS_EINVAL;
+    const int64_t base = total / world, extra = total % world;
+    *count = base + (rank < extra ? 1 : 0);
+    *first = (int64_t)rank * base + (rank < extra ? rank : extra);
+    return LS_OK;
+}
+
 int ls_get_timing(const ls_handle* h, ls_timing* out) {
     if (!h || !out) return LS_EINVAL;
     *out = h->timing;

@@ -29,19 +29,26 @@ constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the
 // alone took 276 us and the MFMA side alone 336 us for conv2, and they overlapped poorly: 515 us; this form: 476 us.)
 __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
                                                         const float* __restrict__ wimg, const float* __restrict__ bias,
-                                                        float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout) {
+                                                        float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout,
+                                                        int ntile, int tpw) {
+    // A workgroup walks `tpw` consecutive 64-position tiles of one (sample, 64-channel group): the (tile, chunk) stages form ONE
+    // pipeline, so the producers' first fetch and the consumers' epilogue of a tile are hidden behind neighbouring stages instead of
+    // being paid once per 480 MFMAs (conv2 as one tile per workgroup: matrix pipe 59 % busy, profiles/r02a).
     __shared__ float sIn[2][kCvCI * kCvWinP];
-    const int b = blockIdx.z, co0 = blockIdx.y * kCvTC, p0 = blockIdx.x * kCvTP;
+    const int b = blockIdx.z, co0 = blockIdx.y * kCvTC;
+    const int t0 = blockIdx.x * tpw, t1 = min(ntile, t0 + tpw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = Cin / kCvCI;
-    const int in0 = p0 * kCvS;
-    const int validw = Lin - in0;                                       // >= 1 for every tile that has an output position
+    const int nstage = (t1 - t0) * nchunk;
     constexpr int NV = (kCvWin + 15) / 16;
     if (w >= 4) {
         // ---------------- producers
         const int pt = tid - 256;
-        auto stage = [&](int c, float* dst) {
+        auto stage = [&](int sidx, float* dst) {
+            const int tl = sidx / nchunk, c = sidx - tl * nchunk;
+            const int in0 = (t0 + tl) * kCvTP * kCvS;
+            const int validw = Lin - in0;                                   // >= 1 for every tile that has an output position
             const size_t row = (size_t)b * Cin + c * kCvCI + (pt >> 4);
             const float vm = stats[row * 2], vr = stats[row * 2 + 1];   // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
             const float* src = in + row * Lin + in0;
@@ -58,58 +65,73 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
         };
         stage(0, sIn[0]);
         __syncthreads();
-        for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nchunk) stage(c + 1, sIn[(c + 1) & 1]);
+        for (int sidx = 0; sidx < nstage; ++sidx) {
+            if (sidx + 1 < nstage) stage(sidx + 1, sIn[(sidx + 1) & 1]);
             __syncthreads();
         }
         return;
     }
     // ---------------- consumers
     const int s16 = lane & 15, g = lane >> 4;
-    f4 acc[4];                                                 // [position tile]
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
     const int lbase = g * kCvWinP + s16 * kCvS;                // + (4*cig)*WinP + 16*pt*S + k per step
     const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
+    constexpr int kWPre = 3, kWRing = 5;                       // taps in flight; ring size (15 taps per chunk = 3 turns of the ring:
+    static_assert(kCvK % kWRing == 0 && kWPre < kWRing, "ring positions must line up across chunks");   // positions repeat per chunk)
+    f4 ring[kWRing];
+    const f4* wbase = reinterpret_cast<const f4*>(wimg) + (size_t)(blockIdx.y * 4 + w) * nchunk * kCvK * 64 + lane;
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const float* sb = sIn[c & 1];
-        const f4* wp = reinterpret_cast<const f4*>(wimg) + ((size_t)(blockIdx.y * 4 + w) * nchunk + c) * kCvK * 64 + lane;
-        f4 An = wp[0];
+    int sidx = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        const int p0 = tile * kCvTP;
+        f4 acc[4];                                             // [position tile]
 #pragma unroll
-        for (int k = 0; k < kCvK; ++k) {
-            const f4 A = An;
-            if (k + 1 < kCvK) An = wp[(k + 1) * 64];
+        for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunk; ++c, ++sidx) {
+            const float* sb = sIn[sidx & 1];
+            // weight operand: a ring of kWPre taps in flight (one float4 per tap = 16 MFMAs = 512 issue cycles; an L2 round trip under
+            // load is longer than that, so a distance of one tap stalled every tap); the ring runs on into the next chunk's image
+            const f4* wp = wbase + (size_t)c * kCvK * 64;
+            const f4* wpn = wbase + (size_t)((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 64;      // next stage's chunk (same tile or the next)
+            if (sidx == 0) {
 #pragma unroll
-            for (int cig = 0; cig < 4; ++cig) {
+                for (int k = 0; k < kWPre; ++k) ring[k] = wp[k * 64];
+            }
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
-                    const float Bv = sb[lbase + (4 * cig) * kCvWinP + 16 * pt * kCvS + k];
-                    acc[pt] = MFMA(A[cig], Bv, acc[pt]);
+            for (int k = 0; k < kCvK; ++k) {
+                const f4 A = ring[k % kWRing];
+                ring[(k + kWPre) % kWRing] = (k + kWPre < kCvK) ? wp[(k + kWPre) * 64] : wpn[(k + kWPre - kCvK) * 64];
+#pragma unroll
+                for (int cig = 0; cig < 4; ++cig) {
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) {
+                        const float Bv = sb[lbase + (4 * cig) * kCvWinP + 16 * pt * kCvS + k];
+                        acc[pt] = MFMA(A[cig], Bv, acc[pt]);
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+        // epilogue of this tile (registers -> global only): runs while the producers stage the next tile's second chunk
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int p = p0 + 16 * pt + s16;
-        const bool valid = p < Lout;
-        const int nv = min(16, max(0, Lout - (p0 + 16 * pt)));
-        const float inv_nv = nv > 0 ? 1.0f / (float)nv : 0.f;
+        for (int pt = 0; pt < 4; ++pt) {
+            const int p = p0 + 16 * pt + s16;
+            const bool valid = p < Lout;
+            const int nv = min(16, max(0, Lout - (p0 + 16 * pt)));
+            const float inv_nv = nv > 0 ? 1.0f / (float)nv : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int co = co0 + 16 * w + 4 * g + j;
-            const float v = acc[pt][j] + bv[j];
-            if (valid) out[((size_t)b * Cout + co) * Lout + p] = v;
-            if (spart) {
-                const float s1 = row16_sum(valid ? v : 0.f);
-                const float mean = s1 * inv_nv;
-                const float d = valid ? v - mean : 0.f;
-                const float m2 = row16_sum(d * d);
-                if (s16 == 0) {
-                    float* sp = spart + (((size_t)b * Cout + co) * (gridDim.x * 4) + blockIdx.x * 4 + pt) * 3;
-                    sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + 16 * w + 4 * g + j;
+                const float v = acc[pt][j] + bv[j];
+                if (valid) out[((size_t)b * Cout + co) * Lout + p] = v;
+                if (spart) {
+                    const float s1 = row16_sum(valid ? v : 0.f);
+                    const float mean = s1 * inv_nv;
+                    const float d = valid ? v - mean : 0.f;
+                    const float m2 = row16_sum(d * d);
+                    if (s16 == 0) {
+                        float* sp = spart + (((size_t)b * Cout + co) * (ntile * 4) + tile * 4 + pt) * 3;
+                        sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
+                    }
                 }
             }
         }
@@ -180,14 +202,19 @@ __global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ 
     }
     const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
     __syncthreads();
+    constexpr int kWPre = 3, kWRing = 5;                       // weight taps in flight (see k_conv1d_mfma)
+    f4 ring[kWRing];
+    const f4* wbase = reinterpret_cast<const f4*>(wimg) + (size_t)(blockIdx.y * 4 + w) * nchunk * kCvK * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < kWPre; ++k) ring[k] = wbase[k * 64];
     for (int c = 0; c < nchunk; ++c) {
         const float* sb = sIn + (c & 1) * bufsz;
-        const f4* wp = reinterpret_cast<const f4*>(wimg) + ((size_t)(blockIdx.y * 4 + w) * nchunk + c) * kCvK * 64 + lane;
-        f4 An = wp[0];
+        const f4* wp = wbase + (size_t)c * kCvK * 64;
+        const f4* wpn = wbase + (size_t)((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 64;
 #pragma unroll
         for (int k = 0; k < kCvK; ++k) {
-            const f4 A = An;
-            if (k + 1 < kCvK) An = wp[(k + 1) * 64];
+            const f4 A = ring[k % kWRing];
+            ring[(k + kWPre) % kWRing] = (k + kWPre < kCvK) ? wp[(k + kWPre) * 64] : wpn[(k + kWPre - kCvK) * 64];
 #pragma unroll
             for (int cig = 0; cig < 4; ++cig) {
 #pragma unroll
@@ -268,11 +295,15 @@ hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* 
             return hipGetLastError();
         }
     }
-    dim3 grid((Lout + kCvTP - 1) / kCvTP, Cout / kCvTC, B);
-    hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(512), 0, st, in, stats, wimg, bias, out, out_stats ? spart : nullptr, Cin, Cout, Lin, Lout);
+    const int ntile = (Lout + kCvTP - 1) / kCvTP;
+    // tiles per workgroup: the whole row when that still leaves >= 2 workgroups per CU; otherwise split rows until it does
+    int tpw = ntile;
+    while (tpw > 1 && (long long)((ntile + tpw - 1) / tpw) * (Cout / kCvTC) * B < 512) tpw = (tpw + 1) / 2;
+    dim3 grid((ntile + tpw - 1) / tpw, Cout / kCvTC, B);
+    hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(512), 0, st, in, stats, wimg, bias, out, out_stats ? spart : nullptr, Cin, Cout, Lin, Lout, ntile, tpw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !out_stats) return e;
-    return launch_stats_merge(spart, out_stats, B * Cout, (int)grid.x * 4, st);
+    return launch_stats_merge(spart, out_stats, B * Cout, ntile * 4, st);
 }
 
 // conv1 (audio_enc.py:10): Conv1d(1, 32, 15, stride 5, padding 1600) on the raw waveform + the InstanceNorm statistics of

@@ -104,6 +104,21 @@ def test_shipped_library_has_no_debug_switches():
             assert before.rfind("#ifdef LS_DEBUG") > before.rfind("#endif"), f"{f}: getenv outside an LS_DEBUG block"
 
 
+def test_abi_shard_range_matches_the_python_shard_layer():
+    from livelyspeaker_amd import shard
+    lib = ctypes.CDLL(_lib.library_path())
+    lib.ls_shard_range.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    f, c = ctypes.c_int64(), ctypes.c_int64()
+    for total, world in ((4096, 8), (513, 8), (5, 8), (0, 3), (7, 1)):
+        seen = 0
+        for r in range(world):
+            assert lib.ls_shard_range(total, world, r, ctypes.byref(f), ctypes.byref(c)) == 0
+            assert (f.value, c.value) == shard.shard_range(total, world, r) and f.value == seen
+            seen += c.value
+        assert seen == total
+    assert lib.ls_shard_range(8, 2, 2, ctypes.byref(f), ctypes.byref(c)) < 0 and lib.ls_shard_range(8, 0, 0, ctypes.byref(f), ctypes.byref(c)) < 0
+
+
 def test_abi_struct_sizes_match_header_layout():
     assert ctypes.sizeof(_lib.LsConfig) == 48
     assert ctypes.sizeof(_lib.LsSchedule) == 8 + 10 * 8
