@@ -32,8 +32,12 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
                                                         float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout,
                                                         int ntile, int tpw) {
     // A workgroup walks `tpw` consecutive 64-position tiles of one (sample, 64-channel group): the (tile, chunk) stages form ONE
-    // pipeline, so the producers' first fetch and the consumers' epilogue of a tile are hidden behind neighbouring stages instead of
-    // being paid once per 480 MFMAs (conv2 as one tile per workgroup: matrix pipe 59 % busy, profiles/r02a).
+    // pipeline, so the producers' first fetch and the consumers' epilogue of a tile overlap neighbouring stages.
+    // Measured on MI355X at B = 512 (profiles/r02b): conv2 505 -> 499 us, conv3 347 -> 338 us with this and the weight ring below --
+    // and 502 us with the producers additionally software-pipelined two stages deep (raw loads given two stage-times to land; not
+    // kept).  So neither the per-tile prologue, nor the weight fetch, nor the activation fetch latency sets the 12 us stage time
+    // (8 us of it is MFMA issue of the two co-resident workgroups): what remains is the producers' normalisation arithmetic and LDS
+    // writes, which on gfx950 issue on the same SIMD ports as the fp32 MFMAs of the consumer waves they share a SIMD with.
     __shared__ float sIn[2][kCvCI * kCvWinP];
     const int b = blockIdx.z, co0 = blockIdx.y * kCvTC;
     const int t0 = blockIdx.x * tpw, t1 = min(ntile, t0 + tpw);
