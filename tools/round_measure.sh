@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): the round's measurement set.  Everything lands under gpurun_out/$1/.
+out="gpurun_out/$1"; mkdir -p "$out"
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; tail -3 "$out/pytest_gpu.log"
+python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "default rc=$?"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 1 --global-batch 512 \
+    --no-extra-legs --no-cpu-baseline > "$out/bench_strong_n1.json" 2> "$out/bench_strong_n1.err"; echo "strong rc=$?"
+python bench.py --dataset beat --batch 256 --no-extra-legs --no-cpu-baseline > "$out/bench_beat256.json" 2> "$out/bench_beat256.err"; echo "beat rc=$?"
+python bench.py --dataset beat150 --batch 32 --no-extra-legs --no-cpu-baseline --steps 2 > "$out/bench_beat150_b32.json" 2> "$out/bench_beat150_b32.err"; echo "beat150/32 rc=$?"
+python bench.py --dataset beat150 --batch 256 --no-extra-legs --no-cpu-baseline --steps 1 --diffusion-steps 200 > "$out/bench_beat150_b256.json" 2> "$out/bench_beat150_b256.err"; echo "beat150/256 rc=$?"
+python bench.py --respacing ddim100 --no-extra-legs --no-cpu-baseline --steps 5 > "$out/bench_ddim100_full.json" 2> "$out/bench_ddim100_full.err"; echo "ddim100 rc=$?"
+python bench.py --batch 4 --diffusion-steps 50 --no-extra-legs --no-cpu-baseline --steps 20 > "$out/bench_config1_shape.json" 2> "$out/bench_config1.err"; echo "config1 rc=$?"
+python bench.py --scale 1.0 --no-extra-legs --no-cpu-baseline > "$out/bench_scale1.json" 2> "$out/bench_scale1.err"; echo "scale1 rc=$?"
+rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs > "$out/kt_bench.json" 2> "$out/kt.log"
+python profiles/summarize_rocprof.py "$(ls $out/kt/*.db | head -1)" "kernel trace of bench.py --steps 1 --warmup 1 (headline workload)" "$out/kt_bench.json" > "$out/kt_bench.md"
+python profiles/dispatch_summary.py "$(ls $out/kt/*.db | head -1)" "ls::" > "$out/kt_dispatch.md"
+tools/prof_call.sh "$out/lively" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE" -- python examples/livelyspeaker_ted.py 512
+tools/prof_call.sh "$out/long" "" -- python bench.py --dataset beat150 --batch 32 --no-extra-legs --no-cpu-baseline --no-parity --steps 1 --warmup 1 --diffusion-steps 20
+rm -rf "$out"/kt "$out"/*/kt "$out"/*/pmc_*/
+for f in "$out"/bench_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    r = json.load(open(sys.argv[1]))
+    print(sys.argv[1].split("/")[-1], r["value"], r["ms_per_step"], r["roofline"]["kernel_ms"], r["roofline"]["frac"], (r.get("parity_in_run") or {}).get("max_abs_diff"), (r.get("shard_check") or {}).get("bitwise_equal"))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+done
