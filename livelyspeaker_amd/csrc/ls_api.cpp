@@ -62,8 +62,8 @@ struct ls_handle {
     int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
     bool fused = true;
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection, row stride of the output buffer)
-    DevBuf lw_wt, lw_bt, lw_wc, lw_bc, lw_winx, lw_wout;     // long path: row-major weights
-    DevBuf lx_proj, lx_X, lx_U, lx_OUT;                      // long path: workspaces
+    DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160)
+    DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_stats;            // long path: workspaces
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -436,6 +436,14 @@ int build_long_weights(ls_handle* h) {
         for (int k = 0; k < JF; ++k) winx[(size_t)n * JFP + k] = (*Win)[(size_t)n * KIN + k];
     int rc;
 #define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
+    if (S <= 160) {                                                                     // operand image of the fused token-mixing kernel
+        std::vector<float> wtp((size_t)L * 160 * 160, 0.f);
+        for (int l = 0; l < L; ++l)
+            for (int r = 0; r < S; ++r) memcpy(&wtp[((size_t)l * 160 + r) * 160], &wt[((size_t)l * S + r) * S], S * sizeof(float));
+        UP(lw_wtp, wtp);
+    } else {
+        h->lw_wtp.release();
+    }
     UP(lw_wt, wt); UP(lw_bt, bt); UP(lw_wc, wc); UP(lw_bc, bc); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(lw_winx, winx); UP(lw_wout, *Wout); UP(bout, *bo);
 #undef UP
@@ -485,7 +493,7 @@ hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st)
     a.temb = s.temb;
     a.eps_c = s.eps_c; a.eps_u = s.eps_u; a.noise = s.noise; a.const_noise = s.const_noise; a.call = s.call; a.step_id = s.step_id;
     a.winx = h->lw_winx.f(); a.ln1a = h->ln1a.f(); a.ln1b = h->ln1b.f(); a.ln2a = h->ln2a.f(); a.ln2b = h->ln2b.f();
-    a.wt = h->lw_wt.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
+    a.wt = h->lw_wt.f(); a.wtp = h->lw_wtp.f(); a.stats = h->lx_stats.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
     a.xproj = h->lx_proj.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
     a.sampler = s.sampler; a.t_nonzero = s.t_nonzero; a.clip_denoised = s.clip_denoised;
     a.c0 = s.c0; a.c1 = s.c1; a.c2 = s.c2; a.c3 = s.c3; a.c4 = s.c4;
@@ -612,7 +620,7 @@ void ls_destroy(ls_handle* h) {
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
-                     &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_winx, &h->lw_wout,
+                     &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_stats, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_winx, &h->lw_wout,
                      &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
@@ -765,6 +773,7 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
         HIPCHK(h, h->lx_X.ensure(rows * kD * sizeof(float)));
         HIPCHK(h, h->lx_U.ensure(rows * kD * sizeof(float)));
         HIPCHK(h, h->lx_OUT.ensure(rows * h->JFP * sizeof(float)));
+        { const void* os = h->lx_stats.p; HIPCHK(h, h->lx_stats.ensure(rows * 2 * sizeof(float))); if (os != h->lx_stats.p) free_graph(h); }
         if (old[0] != h->lx_proj.p || old[1] != h->lx_X.p || old[2] != h->lx_U.p || old[3] != h->lx_OUT.p) free_graph(h);
     }
     HIPCHK(h, hipEventRecord(h->ev[1], st));

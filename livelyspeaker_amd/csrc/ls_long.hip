@@ -10,8 +10,9 @@
 // path runs the same arithmetic as separate launches over ALL rows of the batch (row r = (pass, sample, token); pass 0 = cond,
 // 1 = uncond):
 //   k_long_assemble   token sequences: style / emotion tokens + static projection + x_t projection        (RAG.py:110-126)
-//   per layer:  k_long_addemb_ln (x += emb; u = LN1(x)) -> token mixing as a batched GEMM per sequence, written transposed
-//               (x += SiLU(Wt u + bt)) -> k_layernorm512 (u = LN2(x)) -> channel mixing GEMM (x += SiLU(u Wc^T + bc))
+//   per layer:  k_long_addemb_stats (x += emb; row statistics) -> k_long_tokmix (LN1 applied while staging, Wt in LDS, MFMA,
+//               x += SiLU(Wt u + bt) in place)  [S > 160: k_long_addemb_ln + a batched, transposed GEMM per sequence]
+//               -> k_layernorm512 (u = LN2(x)) -> channel mixing GEMM (x += SiLU(u Wc^T + bc))
 //   poseFinal GEMM -> k_long_update (CFG lerp + DDPM / DDIM update + noise)                 (cfg_sampler.py:31, gaussian_diffusion.py)
 // All products run on the fp32 MFMA GEMM k_gemm_tr (ls_gemm.hip).
 #include "ls_internal.h"
@@ -73,6 +74,120 @@ __global__ __launch_bounds__(256) void k_long_addemb_ln(float* __restrict__ x, c
     ur[lane + 64] = (v1 - mean) * rstd * al[lane + 64] + be[lane + 64];
 }
 
+// x += emb; stats[row] = (mean, rstd) of LN_spatial over the 512 channels -- the normalisation itself is applied by the consumer
+// (k_long_tokmix) while it stages its operand, so no normalised copy of the activations is written.  One wave per row.
+__global__ __launch_bounds__(256) void k_long_addemb_stats(float* __restrict__ x, const float* __restrict__ emb, float* __restrict__ stats, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    f4* xr = reinterpret_cast<f4*>(x + (size_t)r * kD);
+    const f4* er = reinterpret_cast<const f4*>(emb);
+    const f4 v0 = xr[lane] + er[lane], v1 = xr[lane + 64] + er[lane + 64];
+    xr[lane] = v0;
+    xr[lane + 64] = v1;
+    const float s = (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+    const float mean = wave_sum(s) * (1.0f / kD);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float c0 = v0[e] - mean, c1 = v1[e] - mean; q += c0 * c0 + c1 * c1; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kD) + 1e-5f);
+    if (lane == 0) { stats[2 * (size_t)r] = mean; stats[2 * (size_t)r + 1] = rstd; }
+}
+
+// Token mixing of one sequence (Conv1d(S, S, 1) over the token axis, mlp_module.py:51-55, 70-71), fused with LN1 and the SiLU +
+// residual:   x[t][c] += SiLU( sum_k Wt[t][k] * LN1(x)[k][c] + bt[t] )
+// Workgroup = (sequence, 128-channel quarter), 4 waves.  Wt (zero-padded to [KPAD][KPAD] on the host) is staged in LDS ONCE and
+// serves both 64-channel slabs of the quarter; per slab the operand LN1(x)[k][64] is staged (normalised with the row statistics of
+// k_long_addemb_stats and alpha / beta on the way in), then D[token tile][channel tile] runs on v_mfma_f32_16x16x4_f32: wave w owns
+// channel tile w of the slab and all token tiles, A = Wt rows (ds_read_b128 in the k-permuted order, row stride KPAD + 4:
+// conflict-free), B = the operand column (4 ds_read_b32 per 4 k-steps, shared by every token tile).  The result goes back into x in
+// place (a slab's columns are touched by this workgroup only).
+template <int KPAD>
+__global__ __launch_bounds__(256) void k_long_tokmix(float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wtp,
+                                                     const float* __restrict__ bt, const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                     int S) {
+    constexpr int LW = KPAD + 4, LU = 64 + 4, NMT = KPAD / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sW = lds;                   // [KPAD][LW]
+    float* sU = lds + KPAD * LW;       // [KPAD][LU]  (rows >= S are zero)
+    const int seq = blockIdx.x, quarter = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
+    float* xs = x + (size_t)seq * S * kD;
+    const float* st = stats + (size_t)seq * S * 2;
+    {   // Wt image -> LDS.  All of a thread's loads are issued before its first LDS write (a load -> write loop runs one L2 round trip
+        // per iteration: 25 of them in a row were 37 of this kernel's 50 us)
+        constexpr int NW = KPAD * (KPAD / 4) / 256;
+        static_assert(KPAD * (KPAD / 4) % 256 == 0, "whole float4 rounds");
+        f4 tw[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) tw[j] = *reinterpret_cast<const f4*>(wtp + (size_t)(tid + 256 * j) * 4);     // the image is dense [KPAD][KPAD]
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + 256 * j, r = i / (KPAD / 4), c4 = i - r * (KPAD / 4);
+            *reinterpret_cast<f4*>(&sW[r * LW + 4 * c4]) = tw[j];
+        }
+    }
+    for (int slab = 0; slab < 2; ++slab) {
+        const int c0 = quarter * 128 + slab * 64;
+        if (slab) __syncthreads();                                            // the previous slab's MFMAs are done with sU
+        {   // operand slab: LN1 applied on the way in; loads first (clamped rows: branch-free), then the LDS writes
+            constexpr int NU = KPAD * 16 / 256;
+            const int c4 = tid & 15;
+            const f4 al = *reinterpret_cast<const f4*>(alpha + c0 + 4 * c4), be = *reinterpret_cast<const f4*>(beta + c0 + 4 * c4);
+            f4 xv[NU];
+            float mu[NU], rs[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const int r = min((tid >> 4) + 16 * j, S - 1);
+                xv[j] = *reinterpret_cast<const f4*>(xs + (size_t)r * kD + c0 + 4 * c4);
+                mu[j] = st[2 * r]; rs[j] = st[2 * r + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const int r = (tid >> 4) + 16 * j;
+                const f4 v = (xv[j] - mu[j]) * rs[j] * al + be;
+                *reinterpret_cast<f4*>(&sU[r * LU + 4 * c4]) = r < S ? v : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+        f4 acc[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) acc[mt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int q = 0; q < KPAD / 16; ++q) {
+            float Bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bv[e] = sU[(16 * q + 4 * g + e) * LU + 16 * w + s16];
+            f4 A[NMT];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) A[mt] = *reinterpret_cast<const f4*>(&sW[(16 * mt + s16) * LW + 16 * q + 4 * g]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)                       // k-step outer: consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][e], Bv[e], acc[mt], 0, 0, 0);
+        }
+        // lane (s16, g) holds D[token = 16 mt + 4 g + r][channel = c0 + 16 w + s16].  All residual loads first, then the stores:
+        // written as `*p = *p + f(acc)` per element the compiler must keep every load behind the previous store (it cannot prove the
+        // addresses distinct), which serialises 40 L2 round trips per lane.
+        float res[NMT][4];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = min(16 * mt + 4 * g + r, S - 1);
+                res[mt][r] = xs[(size_t)t * kD + c0 + 16 * w + s16];
+            }
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * mt + 4 * g + r;
+                const float v = acc[mt][r] + bt[min(t, S - 1)];
+                if (t < S) xs[(size_t)t * kD + c0 + 16 * w + s16] = res[mt][r] + v / (1.0f + __expf(-v));
+            }
+    }
+}
+
 // CFG combination + sampler update, element (b, t, c) of the internal [B][T][JF] layout; OUT rows are (pass, b, token) x ldo
 __global__ __launch_bounds__(256) void k_long_update(const LongStepArgs a) {
     const int b = blockIdx.y;
@@ -116,7 +231,23 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     // x_t columns of input_mapping: xproj[B*T][512] = x_t[B*T][JF] . Win[:, :JF]^T   (K padded with zero columns of the weight)
     if ((e = launch_gemm_nt(a.x_in, a.JF, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, a.B * a.T, D, a.JF, 0, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a);
+    // fused token mixing needs S <= 160 (its Wt image and operand slab live in LDS); longer sequences take the batched-GEMM form
+    constexpr int kTokPad = 160;
+    const bool fused_tok = a.wtp != nullptr && a.S <= kTokPad;
+    const size_t tok_lds = (size_t)(kTokPad * (kTokPad + 4) + kTokPad * 68) * sizeof(float);
+    if (fused_tok) {
+        static bool attr_set = false;                                          // > 64 KiB of dynamic LDS: opt in once per process
+        if (!attr_set) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_long_tokmix<kTokPad>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tok_lds)) != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
     for (int l = 0; l < a.layers; ++l) {
+        if (fused_tok) {
+            hipLaunchKernelGGL(k_long_addemb_stats, dim3((rows + 3) / 4), dim3(256), 0, st, a.X, a.temb, a.stats, rows);
+            hipLaunchKernelGGL((k_long_tokmix<kTokPad>), dim3(2 * a.B, 4), dim3(256), tok_lds, st, a.X, a.stats, a.wtp + (size_t)l * kTokPad * kTokPad,
+                               a.bt + (size_t)l * a.S, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.S);
+        } else {
         hipLaunchKernelGGL(k_long_addemb_ln, dim3((rows + 3) / 4), dim3(256), 0, st, a.X, a.temb, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.U, rows);
         {   // token mixing, one problem per sequence: C'[channel][token] = sum_k U[k][channel] Wt[token][k] + bt[token], stored at
             // X[token][channel] (crs = 1, cns = 512): the Conv1d bias is per output TOKEN, which is the GEMM's per-column bias in this form
@@ -128,6 +259,7 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
             g.M = D; g.N = a.S; g.K = a.S;
             g.nbatch = 2 * a.B; g.bsA = (long long)a.S * D; g.bsB = 0; g.bsC = (long long)a.S * D;
             if ((e = launch_gemm_tr(g, false, true, 1, st)) != hipSuccess) return e;
+        }
         }
         if ((e = launch_layernorm512(a.X, nullptr, 0, a.ln2a + (size_t)l * D, a.ln2b + (size_t)l * D, a.U, rows, st)) != hipSuccess) return e;
         if ((e = launch_gemm_nt(a.U, D, a.wc + (size_t)l * D * D, D, a.bc + (size_t)l * D, a.X, D, a.X, D, rows, D, D, 1, st)) != hipSuccess) return e;

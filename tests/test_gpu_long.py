@@ -84,3 +84,30 @@ def test_long_philox_mode_and_limits(long_ctx):
     assert max_abs(got, want) < TOL
     with pytest.raises(L.EngineError, match="fp32 only"):
         eng.set_precision("bf16x3")
+
+
+def test_sequences_longer_than_the_fused_token_mixing_limit_take_the_gemm_form():
+    """S > 160 tokens: the token-mixing operand no longer fits the fused kernel's LDS budget, so the step falls back to LayerNorm +
+    a batched, transposed GEMM per sequence.  TED layout with 200 frames (214 745 samples -> 43 587 -> 7 263 -> 1 209 -> 200)."""
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg = synth.PathConfig("ted200", njoints=9, nfeats=3, nframes=200, n_prefix_tokens=1, audio_len=214745)
+    assert synth.audio_lengths(cfg.audio_len)[-1] == 200
+    sd = synth.make_state_dict(cfg)
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, nframes=cfg.nframes)
+    try:
+        eng.load_state_dict(sd)
+        oracle = orc.RagOracle(sd, cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, nframes=cfg.nframes)
+        B, steps = 2, 4
+        y = synth.make_cond(cfg, B)
+        sch = orc.Schedule(steps, "")
+        eng.set_schedule(sch)
+        eng.prepare(y)
+        tape = synth.NoiseTape(cfg, B, steps)
+        got = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise)
+        want = orc.sample_loop(oracle, sch, y, tape.x_init, tape.eps, tape.noise)
+        d = max_abs(got, want)
+        print(f"200-frame TED-layout loop (GEMM-form token mixing): max|hip - oracle| = {d:.3e}")
+        assert d < TOL
+    finally:
+        eng.close()
