@@ -150,3 +150,25 @@ def test_beat_long_loops_vs_reference_fixtures(key, steps, resp, ddim):
         assert d < TOL_LOOP
     finally:
         eng.close()
+
+
+def test_config4_global_batch_4096_equals_eight_shards_of_512():
+    """BASELINE configs[3]: one global batch of 4096 clips == eight shards of 512 generated with sample_offset (what the eight
+    ranks of a node run; here one GPU plays every rank in turn), bit for bit -- 12 DDPM steps, Philox noise, hipGraph."""
+    from livelyspeaker_amd import _lib
+    cfg, eng = _engine("ted")
+    orc, _ = _oracle(cfg)
+    try:
+        G, W, steps, seed = 4096, 8, 12, 8675309
+        y = synth.make_cond(cfg, G)
+        eng.set_schedule(orc.Schedule(steps, ""))
+        eng.prepare(y)
+        whole = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=0)
+        assert whole.shape[0] == G and np.isfinite(whole).all()
+        for r in range(W):
+            sl = slice(r * G // W, (r + 1) * G // W)
+            eng.prepare({k: v[sl] for k, v in y.items()})
+            part = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=sl.start)
+            assert np.array_equal(part, whole[sl]), f"shard {r} differs from the global batch"
+    finally:
+        eng.close()
