@@ -233,3 +233,63 @@ def test_bf16x3_mode_meets_the_parity_contract(ds, mode, golden):
         assert max_abs(out, g["G3_ddpm50_final"]) < 3e-4        # switching back restores the exact path
     finally:
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BEAT edge cases (round 1 covered them for TED only) and the single-pass variant at degenerate sizes
+@pytest.mark.parametrize("B,scale", [(1, 1.5), (3, 1.5), (1, 1.0), (7, 1.0)])
+def test_beat_ragged_batches_both_step_variants_vs_oracle(B, scale):
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg = synth.BEAT
+    sd = synth.make_state_dict(cfg)
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
+    try:
+        eng.load_state_dict(sd)
+        oracle = orc.RagOracle(sd, cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+        sch = orc.Schedule(1000, "ddim100")
+        skip = 94
+        y = synth.make_cond(cfg, B, seed=21 + B, scale=scale)
+        tape = synth.NoiseTape(cfg, B, sch.num_timesteps - skip, seed=9 + B)
+        init = synth.make_init_image(cfg, B)
+        eng.set_schedule(sch)
+        eng.prepare(y)
+        got = eng.sample(sampler=_lib.LS_SAMPLER_DDIM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise, skip_timesteps=skip,
+                         init_image=init, eta=0.3)
+        assert eng.timing()["single_pass"] == int(scale == 1.0)
+        want = orc.sample_loop(oracle, sch, y, tape.x_init, tape.eps, tape.noise, ddim=True, skip_timesteps=skip, init_image=init, eta=0.3)
+        d = max_abs(got, want)
+        print(f"BEAT B={B} scale={scale}: max|hip - oracle| = {d:.3e}")
+        assert d < TOL
+    finally:
+        eng.close()
+
+
+def test_emo_accepts_the_callers_frame_tensor_and_a_bare_id_vector():
+    """y['emo'] is [B, T] in the reference's callers (frame 0 is read, scripts_beat/model/RAG.py:125); the ABI takes that shape for
+    sampling and training alike.  A bare [B] vector is broadcast by the Python layer; a strided CUDA view takes the device path."""
+    import torch
+    from livelyspeaker_amd import _lib
+    cfg = synth.BEAT
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
+    try:
+        eng.load_state_dict(synth.make_state_dict(cfg))
+        from oracle import rag_oracle as orc
+        eng.set_schedule(orc.Schedule(3, ""))
+        y = synth.make_cond(cfg, 4)
+        tape = synth.NoiseTape(cfg, 4, 3)
+        kw = dict(sampler=_lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise)
+        eng.prepare(y)
+        a = eng.sample(**kw)
+        eng.prepare(dict(y, emo=y["emo"][:, 0].copy()))                                   # bare [B]
+        assert np.array_equal(a, eng.sample(**kw))
+        wide = torch.from_numpy(np.repeat(y["emo"], 2, axis=1)).cuda()[:, ::2]            # non-contiguous CUDA view of the same ids
+        yc = {k: torch.from_numpy(v).cuda() for k, v in y.items()}
+        yc["emo"] = wide
+        eng.prepare(yc)
+        assert np.array_equal(a, eng.sample(**kw))
+        y2 = dict(y, emo=(y["emo"] + 1) % 8)
+        eng.prepare(y2)
+        assert not np.array_equal(a, eng.sample(**kw))                                    # the token really depends on it
+    finally:
+        eng.close()
