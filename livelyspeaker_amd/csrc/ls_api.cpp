@@ -77,7 +77,8 @@ struct ls_handle {
     DevBuf wch_hi_img, wch_lo_img, ww_hi_img, ww_lo_img;
     DevBuf wch_img, bch, ln1a, ln1b, ln2a, ln2b, ww_img, btok_rows, winx_img, wout_img, wout_reg_img, bout, devw;
     DevBuf conv_img[4];     // MFMA operand images of the stride-6 conv layers (ls_conv.hip)
-    DevBuf conv_w[4], conv_b[4], win_full, win_pad, win_bias, spk_emb, mu_w, mu_b, lv_w, lv_b, emo_emb;
+    DevBuf conv_w[4], conv_b[4], win_full, win_pre, win_aud, win_bias, spk_emb, ml_w, ml_b, emo_emb;
+    int KPP = 0;            // prefix-pose + bit columns of input_mapping, padded to the GEMM's K tile
     DevBuf te_w0, te_b0, te_w2, te_b2, pe;
 
     // schedule
@@ -94,7 +95,7 @@ struct ls_handle {
     bool prepared = false;
     bool all_scale_one = false;   // every y['scale'] == 1: the CFG combination equals the cond output -> single-pass kernel
     DevBuf audio, origin_x, vid, emo, scale;
-    DevBuf c1, c2, c3, c4, st1, st2, st3, feat_c, feat_u, static_c, static_u, z, z_mu, z_logvar, z_std, emo_tok;
+    DevBuf c1, c2, c3, c4, st1, st2, st3, feat_c, feat_u, static_c, static_u, z, z_ml, z_mu, z_logvar, z_std, emo_tok;
     DevBuf audio_feat, spart;
     DevBuf xa, xb, xtmp, xio, fwd_c, fwd_u, fwd_cfg, eps, noise, tfwd, tfwd_tmp, tidx, dump, trace, callp;
     DevBuf eps_tape, noise_tape;
@@ -336,12 +337,15 @@ int build_shared_weights(ls_handle* h) {
     if (!Win || !bin) return LS_ESTATE;
 #define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
     UP(win_full, *Win); UP(win_bias, *bin);
-    {   // the static columns JF.. of input_mapping as their own [512][KFP] matrix (zero-padded to a whole number of K tiles and
-        // 16-byte-aligned rows): the once-per-call projection then takes the GEMM's fast path
-        std::vector<float> wp((size_t)D * h->KFP, 0.f);
-        for (int n = 0; n < D; ++n)
-            for (int k = 0; k < h->KF; ++k) wp[(size_t)n * h->KFP + k] = (*Win)[(size_t)n * KIN + JF + k];
-        UP(win_pad, wp);
+    {   // the static columns JF.. of input_mapping, split by the features they multiply: [prefix poses | bit] (shared by both CFG
+        // passes; zero-padded to a whole number of K tiles so the projection takes the GEMM's fast path) and the 256 audio columns
+        // (cond pass only)
+        std::vector<float> wp((size_t)D * h->KPP, 0.f), wa((size_t)D * kAudioFeat);
+        for (int n = 0; n < D; ++n) {
+            for (int k = 0; k < JF + 1; ++k) wp[(size_t)n * h->KPP + k] = (*Win)[(size_t)n * KIN + JF + k];
+            for (int k = 0; k < kAudioFeat; ++k) wa[(size_t)n * kAudioFeat + k] = (*Win)[(size_t)n * KIN + 2 * JF + 1 + k];
+        }
+        UP(win_pre, wp); UP(win_aud, wa);
     }
     // raw weights used by the once-per-call kernels
     for (int i = 0; i < 4; ++i) {
@@ -377,7 +381,13 @@ int build_shared_weights(ls_handle* h) {
     const auto* t2w = find_w(h, "backbone.embed_timestep.time_embed.2.weight", (size_t)D * D);
     const auto* t2b = find_w(h, "backbone.embed_timestep.time_embed.2.bias", D);
     if (!se || !mw || !mb || !lw || !lb || !t0w || !t0b || !t2w || !t2b) return LS_ESTATE;
-    UP(spk_emb, *se); UP(mu_w, *mw); UP(mu_b, *mb); UP(lv_w, *lw); UP(lv_b, *lb);
+    UP(spk_emb, *se);
+    {   // speaker_mu and speaker_logvar as ONE [1024][256] projection (rows 0..511 mu, 512..1023 logvar): one launch instead of three
+        std::vector<float> w2(mw->begin(), mw->end()), b2(mb->begin(), mb->end());
+        w2.insert(w2.end(), lw->begin(), lw->end());
+        b2.insert(b2.end(), lb->begin(), lb->end());
+        UP(ml_w, w2); UP(ml_b, b2);
+    }
     UP(te_w0, *t0w); UP(te_b0, *t0b); UP(te_w2, *t2w); UP(te_b2, *t2b);
     if (h->cfg.n_emotions > 0) {
         const auto* ee = find_w(h, "emotion_embedding.weight", (size_t)h->cfg.n_emotions * D);   // scripts_beat/model/RAG.py:72
@@ -587,6 +597,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     h->KIN = 2 * JF + 1 + kAudioFeat;
     h->KF = JF + 1 + kAudioFeat;
     h->KFP = (h->KF + 31) / 32 * 32;
+    h->KPP = (JF + 1 + 31) / 32 * 32;
     memcpy(h->convL, convL, sizeof convL);
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -614,10 +625,10 @@ void ls_destroy(ls_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graph(h);
     DevBuf* all[] = {&h->wch_hi_img, &h->wch_lo_img, &h->ww_hi_img, &h->ww_lo_img, &h->wch_img, &h->bch, &h->ln1a, &h->ln1b, &h->ln2a, &h->ln2b, &h->ww_img, &h->btok_rows, &h->winx_img,
-                     &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_pad, &h->win_bias, &h->spk_emb, &h->mu_w, &h->mu_b, &h->lv_w,
-                     &h->lv_b, &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
+                     &h->wout_img, &h->wout_reg_img, &h->bout, &h->devw, &h->win_full, &h->win_pre, &h->win_aud, &h->win_bias, &h->spk_emb, &h->ml_w, &h->ml_b,
+                     &h->emo_emb, &h->te_w0, &h->te_b0, &h->te_w2, &h->te_b2, &h->pe, &h->temb, &h->temb_tmp,
                      &h->tmap_dev, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->scale, &h->c1, &h->c2, &h->c3, &h->c4,
-                     &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_mu,
+                     &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_ml, &h->z_mu,
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_stats, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_winx, &h->lw_wout,
@@ -745,23 +756,24 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
         in = outs[i]->f();
     }
     // ---- static part of input_mapping (RAG.py:110-114): columns JF.. of W_in act on [prefix poses | bit | audio]
-    const int KFP = h->KFP;
-    HIPCHK(h, h->feat_c.ensure((size_t)B * h->T * KFP * sizeof(float)));
-    HIPCHK(h, h->feat_u.ensure((size_t)B * h->T * KFP * sizeof(float)));
+    const int KPP = h->KPP;
+    HIPCHK(h, h->feat_c.ensure((size_t)B * h->T * kAudioFeat * sizeof(float)));       // audio features [B*T][256]
+    HIPCHK(h, h->feat_u.ensure((size_t)B * h->T * KPP * sizeof(float)));              // [prefix poses | bit | pad]
     HIPCHK(h, h->static_c.ensure((size_t)B * h->T * kD * sizeof(float)));
     HIPCHK(h, h->static_u.ensure((size_t)B * h->T * kD * sizeof(float)));
-    HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_c.f(), h->feat_u.f(), B, JF, KFP, h->cfg.n_pre_seq, st, h->T));
-    HIPCHK(h, launch_gemm_nt(h->feat_c.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_c.f(), kD, B * h->T, kD, KFP, 0, st));
-    HIPCHK(h, launch_gemm_nt(h->feat_u.f(), KFP, h->win_pad.f(), KFP, h->win_bias.f(), nullptr, 0, h->static_u.f(), kD, B * h->T, kD, KFP, 0, st));
+    HIPCHK(h, launch_build_feats(h->origin_x.f(), h->c4.f(), h->feat_u.f(), h->feat_c.f(), B, JF, KPP, h->cfg.n_pre_seq, st, h->T));
+    // static_u = [prefix poses | bit] . Wpre^T + b;  static_c = static_u + audio . Waud^T  (K = KPP + 256 instead of 2 x that)
+    HIPCHK(h, launch_gemm_nt(h->feat_u.f(), KPP, h->win_pre.f(), KPP, h->win_bias.f(), nullptr, 0, h->static_u.f(), kD, B * h->T, kD, KPP, 0, st));
+    HIPCHK(h, launch_gemm_nt(h->feat_c.f(), kAudioFeat, h->win_aud.f(), kAudioFeat, nullptr, h->static_u.f(), kD, h->static_c.f(), kD, B * h->T, kD, kAudioFeat, 0, st));
     // ---- speaker style (RAG.py:116-119): z = Embedding[vid]; mu, logvar = Linear(z); std = exp(0.5*logvar)
     HIPCHK(h, h->z.ensure((size_t)B * 256 * sizeof(float)));
     HIPCHK(h, h->z_mu.ensure((size_t)B * kD * sizeof(float)));
     HIPCHK(h, h->z_logvar.ensure((size_t)B * kD * sizeof(float)));
     HIPCHK(h, h->z_std.ensure((size_t)B * kD * sizeof(float)));
     HIPCHK(h, launch_gather_rows(h->spk_emb.f(), static_cast<const int64_t*>(h->vid.p), h->z.f(), B, 256, h->cfg.n_speakers, st));
-    HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->mu_w.f(), 256, h->mu_b.f(), nullptr, 0, h->z_mu.f(), kD, B, kD, 256, 0, st));
-    HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), nullptr, 0, h->z_logvar.f(), kD, B, kD, 256, 0, st));
-    HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->lv_w.f(), 256, h->lv_b.f(), nullptr, 0, h->z_std.f(), kD, B, kD, 256, 2, st));
+    HIPCHK(h, h->z_ml.ensure((size_t)B * 2 * kD * sizeof(float)));
+    HIPCHK(h, launch_gemm_nt(h->z.f(), 256, h->ml_w.f(), 256, h->ml_b.f(), nullptr, 0, h->z_ml.f(), 2 * kD, B, 2 * kD, 256, 0, st));
+    HIPCHK(h, launch_split_style(h->z_ml.f(), h->z_mu.f(), h->z_logvar.f(), h->z_std.f(), B, st));
     if (h->cfg.n_prefix_tokens == 2) {   // scripts_beat/model/RAG.py:125
         HIPCHK(h, h->emo_tok.ensure((size_t)B * kD * sizeof(float)));
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, h->T));   // y['emo'][:, 0]

@@ -151,8 +151,10 @@ hipError_t launch_gemm_nt(const float* A, int lda, const float* W, int ldw, cons
 // out[r] = table[idx[r * idx_stride]] (rows clamped into the table)
 hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int rows, int width,
                               int table_rows, hipStream_t st, int idx_stride = 1);
-hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
-                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st, int T = kT);
+// feat_p [B*T][KPP] = [prefix poses | bit | pad], feat_a [B*T][256] = audio feature (see ls_prepare.hip)
+hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_p, float* feat_a,
+                              int B, int JF, int KPP, int n_pre_seq, hipStream_t st, int T = kT);
+hipError_t launch_split_style(const float* ml, float* mu, float* lv, float* sd, int B, hipStream_t st);
 hipError_t launch_to_internal(const float* src_bjft, float* dst_btc, int B, int JF, hipStream_t st, int T = kT);
 hipError_t launch_from_internal(const float* src_btc, float* dst_bjft, int B, int JF, hipStream_t st, int T = kT);
 hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size_t n, float a, float b,

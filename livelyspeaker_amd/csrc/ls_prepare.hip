@@ -28,34 +28,41 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out
     return hipGetLastError();
 }
 
-// InputProcess features without the x_t columns (RAG.py:110-112, 184-192):
-// row (b,f) = [origin_x[b,:,f] if f < n_pre_seq else 0 | indicator bit | audio feature (cond) or 0 (uncond)]
+// InputProcess features without the x_t columns (RAG.py:110-112, 184-192), split by what they multiply:
+//   feat_p[(b,f)] = [origin_x[b,:,f] if f < n_pre_seq else 0 | indicator bit | 0 pad]   (KPP columns: shared by both CFG passes)
+//   feat_a[(b,f)] = audio feature conv4[b,:,f]                                          (256 columns: the cond pass only)
+// so that static_u = feat_p . Wpre^T + b  and  static_c = static_u + feat_a . Waud^T  (mask_cond zeroes the audio term of the uncond
+// pass, RAG.py:82-83): K = KPP + 256 in total instead of 2 x (KPP + 256).
 __global__ void k_build_feats(const float* __restrict__ origin_x, const float* __restrict__ conv4,
-                              float* __restrict__ feat_c, float* __restrict__ feat_u, int JF, int KFP, int n_pre_seq, int T) {
+                              float* __restrict__ feat_p, float* __restrict__ feat_a, int JF, int KPP, int n_pre_seq, int T) {
     const int b = blockIdx.x / T, f = blockIdx.x % T;
-    const int KF = JF + 1 + kAudioFeat;
-    float* fc = feat_c + (size_t)blockIdx.x * KFP;          // rows padded with zeros to KFP (a whole number of GEMM K tiles)
-    float* fu = feat_u + (size_t)blockIdx.x * KFP;
-    for (int c = threadIdx.x; c < KFP; c += blockDim.x) {
-        float vc, vu;
-        if (c < JF) {
-            vc = vu = (f < n_pre_seq) ? origin_x[((size_t)b * JF + c) * T + f] : 0.f;
-        } else if (c == JF) {
-            vc = vu = (f < n_pre_seq) ? 1.f : 0.f;
-        } else if (c < KF) {
-            vc = conv4[((size_t)b * kAudioFeat + (c - JF - 1)) * T + f];
-            vu = 0.f;                                                   // mask_cond(force_mask), RAG.py:82-83
-        } else {
-            vc = vu = 0.f;
-        }
-        fc[c] = vc;
-        fu[c] = vu;
+    float* fp = feat_p + (size_t)blockIdx.x * KPP;
+    float* fa = feat_a + (size_t)blockIdx.x * kAudioFeat;
+    for (int c = threadIdx.x; c < KPP; c += blockDim.x) {
+        float v = 0.f;
+        if (f < n_pre_seq) v = c < JF ? origin_x[((size_t)b * JF + c) * T + f] : (c == JF ? 1.f : 0.f);
+        fp[c] = v;
     }
+    for (int c = threadIdx.x; c < kAudioFeat; c += blockDim.x) fa[c] = conv4[((size_t)b * kAudioFeat + c) * T + f];
 }
 
-hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_c, float* feat_u,
-                              int B, int JF, int KFP, int n_pre_seq, hipStream_t st, int T) {
-    hipLaunchKernelGGL(k_build_feats, dim3(B * T), dim3(256), 0, st, origin_x, conv4, feat_c, feat_u, JF, KFP, n_pre_seq, T);
+hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_p, float* feat_a,
+                              int B, int JF, int KPP, int n_pre_seq, hipStream_t st, int T) {
+    hipLaunchKernelGGL(k_build_feats, dim3(B * T), dim3(256), 0, st, origin_x, conv4, feat_p, feat_a, JF, KPP, n_pre_seq, T);
+    return hipGetLastError();
+}
+
+// speaker style (RAG.py:116-119): [mu | logvar] rows of the fused projection -> z_mu, z_logvar, z_std = exp(0.5 logvar)
+__global__ void k_split_style(const float* __restrict__ ml, float* __restrict__ mu, float* __restrict__ lv, float* __restrict__ sd, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / kD, c = i - b * kD;
+    const float m = ml[(size_t)b * 2 * kD + c], l = ml[(size_t)b * 2 * kD + kD + c];
+    mu[i] = m; lv[i] = l; sd[i] = expf(0.5f * l);
+}
+hipError_t launch_split_style(const float* ml, float* mu, float* lv, float* sd, int B, hipStream_t st) {
+    const int n = B * kD;
+    hipLaunchKernelGGL(k_split_style, dim3((n + 255) / 256), dim3(256), 0, st, ml, mu, lv, sd, n);
     return hipGetLastError();
 }
 
