@@ -36,8 +36,10 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
     // Measured on MI355X at B = 512 (profiles/r02b): conv2 505 -> 499 us, conv3 347 -> 338 us with this and the weight ring below --
     // and 502 us with the producers additionally software-pipelined two stages deep (raw loads given two stage-times to land; not
     // kept).  So neither the per-tile prologue, nor the weight fetch, nor the activation fetch latency sets the 12 us stage time
-    // (8 us of it is MFMA issue of the two co-resident workgroups): what remains is the producers' normalisation arithmetic and LDS
-    // writes, which on gfx950 issue on the same SIMD ports as the fp32 MFMAs of the consumer waves they share a SIMD with.
+    // (8 us of it is MFMA issue of the two co-resident workgroups).  Cutting the producers' arithmetic from 10 to 4 VALU operations
+    // per element on interior tiles (no clamp, no tail mask, max() for the LeakyReLU) changed nothing either (496 us): the producer
+    // side is not the limiter in any of its aspects; the consumers' loop -- one LDS operand read per MFMA, 50 % of the LDS pipe
+    // with two workgroups per CU -- sets the pace at 59 % matrix-pipe occupancy.
     __shared__ float sIn[2][kCvCI * kCvWinP];
     const int b = blockIdx.z, co0 = blockIdx.y * kCvTC;
     const int t0 = blockIdx.x * tpw, t1 = min(ntile, t0 + tpw);
