@@ -111,3 +111,23 @@ def test_sequences_longer_than_the_fused_token_mixing_limit_take_the_gemm_form()
         assert d < TOL
     finally:
         eng.close()
+
+
+def test_long_single_steps_vs_oracle(long_ctx):
+    """ls_step (p_sample / ddim_sample one step at a time, what a step-by-step caller uses) on the long-sequence path."""
+    cfg, eng, orc, oracle, L = (long_ctx[k] for k in ("cfg", "eng", "orc", "oracle", "L"))
+    B = 2
+    y = synth.make_cond(cfg, B)
+    g = np.random.Generator(np.random.PCG64(77))
+    x = g.standard_normal((B, cfg.njoints, cfg.nfeats, cfg.nframes)).astype(np.float32)
+    eps = g.standard_normal((2, B, 512)).astype(np.float32)
+    noise = g.standard_normal(x.shape).astype(np.float32)
+    oracle.prepare(y)
+    for name, resp, sampler, idx in (("p", "", L.LS_SAMPLER_DDPM, 40), ("ddim", "ddim100", L.LS_SAMPLER_DDIM, 0)):
+        sch = orc.Schedule(1000 if resp else 50, resp)
+        eng.set_schedule(sch)
+        eng.prepare(y)
+        out, x0 = eng.step(sampler, idx, x, eps[0], eps[1], noise)
+        w0 = oracle.cfg_forward(x, np.full((B,), sch.timestep_map[idx]), y, eps[0], eps[1])
+        want = orc.p_sample_update(sch, x, w0, idx, noise) if name == "p" else orc.ddim_update(sch, x, w0, idx, noise)
+        assert max_abs(x0, w0) < TOL and max_abs(out, want) < TOL, name
