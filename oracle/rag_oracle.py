@@ -2,7 +2,7 @@
 
 A plain numpy (fp32) restatement of the reference's algorithm for the path named in
 BASELINE.json. Only ``tests/``, ``__graft_entry__.smoke()``
-and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product package
+and ``bench.py``'s checker legs (``cpu_baseline``, ``parity_in_run``) may import this module; the product package
 ``livelyspeaker_amd`` never does (it fails loudly if the HIP library is missing).
 
 Parity pin: the reference has no golden vectors of its own.  This oracle
