@@ -413,34 +413,15 @@ def main():
     shard_check = None
     if use_dist or strong:
         try:
-            nb = (rank + 1) % world
-            nb_first = shard.shard_range(total, world, nb)[0] if strong else nb * B
-            mine = first_out
-            allr = shard.gather_samples(mine, world * B) if not strong else None
-            y_nb = {k: torch.from_numpy(v).to(dev) for k, v in cond_of(nb, a.scale).items()}
-            diffusion.sample_offset, diffusion.philox_seed = nb_first, first_seed
-            redo = fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": y_nb}, skip_timesteps=a.skip, init_image=None, progress=False,
-                      dump_steps=None, noise=None, const_noise=False)
-            diffusion.sample_offset, diffusion.philox_seed = first, None
-            if strong:      # `gathered` is the last timed call's; re-run the first call's seed for a like-for-like global tensor
-                diffusion.philox_seed = first_seed
-                ref_global = shard.gather_samples(fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=a.skip,
-                                                     init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False), total)
-                diffusion.philox_seed = None
-            else:
-                ref_global = allr
-            theirs = ref_global[nb * B:(nb + 1) * B]
-            stats = torch.stack([(redo - theirs).abs().max().double(), redo.double().abs().sum(), theirs.double().abs().sum()])
-            mx = stats[:1].clone()
-            sums = stats[1:].clone()
-            if use_dist:
-                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-            shard_check = {"rccl_ranks": dist.get_world_size() if use_dist else 1,
-                           "what": "every rank re-generated the NEXT rank's shard on its own GPU via sample_offset (same Philox key, that "
-                                   "shard's conditioning) and compared it with what that rank produced",
-                           "max_abs_diff": float(mx.item()), "bitwise_equal": bool(mx.item() == 0.0),
-                           "checksum_recomputed": float(sums[0].item()), "checksum_sharded": float(sums[1].item())}
+            def regenerate(first_idx, count, shard_index):
+                y_sh = {k: torch.from_numpy(v).to(dev) for k, v in cond_of(shard_index, a.scale).items()}
+                diffusion.sample_offset, diffusion.philox_seed = first_idx, first_seed
+                try:
+                    return fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": y_sh}, skip_timesteps=a.skip, init_image=None,
+                              progress=False, dump_steps=None, noise=None, const_noise=False)
+                finally:
+                    diffusion.sample_offset, diffusion.philox_seed = first, None
+            shard_check = shard.cross_check(regenerate, first_out, total, equal_shards_of=B)
 
         except Exception as e:          # symmetric on every rank (same code path); never take the headline line down
             shard_check = {"error": repr(e)[:300], "rccl_ranks": dist.get_world_size() if use_dist else 1}

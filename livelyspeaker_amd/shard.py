@@ -94,3 +94,34 @@ def sample_sharded(sample_fn, model, global_shape, y_global: dict, diffusion=Non
             kwargs[name] = kwargs[name][first:first + count]
     local = sample_fn(model, (count,) + tuple(global_shape[1:]), model_kwargs={"y": y_local}, **kwargs)
     return gather_samples(local, total)
+
+
+def cross_check(generate, mine: torch.Tensor, total: int, *, equal_shards_of: int | None = None) -> dict:
+    """The "N GPUs == one GPU" premise checked instead of assumed: every rank re-generates the NEXT rank's shard by itself --
+    ``generate(first, count, shard_index)`` must produce the samples of global indices [first, first + count) from scratch on this
+    rank (that shard's conditioning, the same Philox key, ``sample_offset = first``) -- and compares it with what that rank produced
+    (``mine`` = this rank's own shard, gathered over the group).  Returns the max-abs difference (all-reduced MAX) and both checksums
+    (all-reduced SUM); identical streams give exactly 0.  Works on one rank too (a replay check).  Collective: every rank must call
+    it.  ``equal_shards_of``: per-rank shard size when shards are defined by rank (weak scaling) rather than by ``shard_range``."""
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if on else 1
+    rank = dist.get_rank() if on else 0
+    nb = (rank + 1) % world
+    if equal_shards_of is not None:
+        spans = [(r * equal_shards_of, equal_shards_of) for r in range(world)]
+    else:
+        spans = [shard_range(total, world, r) for r in range(world)]
+    whole = gather_samples(mine, total)
+    first, count = spans[nb]
+    redo = generate(first, count, nb)
+    theirs = whole[first:first + count]
+    stats = torch.stack([(redo - theirs).abs().max().double(), redo.double().abs().sum(), theirs.double().abs().sum()])
+    mx, sums = stats[:1].clone(), stats[1:].clone()
+    if on:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return {"rccl_ranks": world,
+            "what": "every rank re-generated the NEXT rank's shard on its own GPU via sample_offset (same Philox key, that shard's "
+                    "conditioning) and compared it with what that rank produced",
+            "max_abs_diff": float(mx.item()), "bitwise_equal": bool(mx.item() == 0.0),
+            "checksum_recomputed": float(sums[0].item()), "checksum_sharded": float(sums[1].item())}

@@ -159,3 +159,52 @@ def test_world2_data_parallel_gradient_equals_full_batch_gradient():
         p.join(timeout=120)
     assert status == "ok", val
     assert val < 1e-5, val
+
+
+# ---- bench.py's shard cross-check (shard.cross_check), world 2 over gloo with a stand-in generator ------------------------------
+def _xcheck_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from livelyspeaker_amd import shard
+        B = 3
+
+        def gen(first, count, shard_index):          # what a Philox-keyed sampler is: a pure function of the global sample index
+            idx = torch.arange(first, first + count, dtype=torch.float32)
+            return (torch.sin(idx * 12.9898)[:, None, None, None] * torch.ones(count, 2, 3, 4) + shard_index * 0.0).contiguous()
+
+        mine = gen(rank * B, B, rank)
+        ok = shard.cross_check(gen, mine, world * B, equal_shards_of=B)
+        bad_mine = mine + (1e-3 if rank == 1 else 0.0)                  # rank 1 "computes something else"
+        bad = shard.cross_check(gen, bad_mine, world * B, equal_shards_of=B)
+        ragged = shard.cross_check(lambda f, c, s: gen(f, c, s), gen(*shard.shard_range(5, world, rank), rank), 5)      # 3 + 2 samples
+        q.put((rank, (ok, bad, ragged)))
+    except Exception as e:
+        import traceback
+        q.put((rank, RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_shard_cross_check():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xcheck_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for v in results.values():
+        if isinstance(v, Exception):
+            raise v
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok, bad, ragged = results[rank]
+        assert ok["rccl_ranks"] == 2 and ok["bitwise_equal"] and ok["max_abs_diff"] == 0.0
+        assert ok["checksum_recomputed"] == ok["checksum_sharded"]
+        assert not bad["bitwise_equal"] and abs(bad["max_abs_diff"] - 1e-3) < 1e-6          # seen by EVERY rank (all-reduced)
+        assert ragged["bitwise_equal"]
+    assert results[0][0] == results[1][0]
