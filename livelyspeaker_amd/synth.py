@@ -274,3 +274,11 @@ class NoiseTape:
             out.append(self.eps[i, 1][:, None, :])
             out.append(self.noise[i])
         return out
+
+
+def schedule(diffusion_steps: int, timestep_respacing: str = ""):
+    """The product's own schedule object (SpacedDiffusion tables) for tools and examples that drive the engine directly."""
+    from types import SimpleNamespace
+    from .model_util import create_gaussian_diffusion
+    return create_gaussian_diffusion(SimpleNamespace(diffusion_steps=diffusion_steps, noise_schedule="cosine", sigma_small=True,
+                                                     lambda_vel=1.0, lambda_rcxyz=0.0, lambda_fc=0.0), timestep_respacing)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Debug helper: per-parameter gradient error of the HIP training step vs the torch-CPU oracle (GPU box)."""
+"""Debug helper (test infrastructure, run by hand on the GPU box): per-parameter gradient error of the HIP training step vs the
+torch-CPU oracle.  Lives under tests/ because only tests/, smoke() and bench.py's checker legs may use oracle/."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

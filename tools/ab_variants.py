@@ -22,14 +22,13 @@ CHILD = r'''
 import os, sys, json
 sys.path.insert(0, %r)
 from livelyspeaker_amd import _lib, synth
-from oracle import rag_oracle as orc
 ds, B, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 _lib.use_library(sys.argv[4])
 cfg = synth.CONFIGS[ds]
 eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
 eng.load_state_dict(synth.make_state_dict(cfg))
 if os.environ.get("LS_PRECISION"): eng.set_precision(os.environ["LS_PRECISION"])
-eng.set_schedule(orc.Schedule(steps, ""))
+eng.set_schedule(synth.schedule(steps))
 eng.prepare(synth.make_cond(cfg, B))
 ts = []
 for i in range(4):

@@ -12,7 +12,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("LS_PROF", "300")
 from livelyspeaker_amd import _lib, synth          # noqa: E402
 from livelyspeaker_amd import build as _build      # noqa: E402
-from oracle import rag_oracle as orc               # noqa: E402
 
 DEBUG_LIB = os.path.join(_build.ROOT, "variants", "debug.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
@@ -28,7 +27,7 @@ eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n
 eng.load_state_dict(synth.make_state_dict(cfg))
 if os.environ.get("LS_PROF_PRECISION"):
     eng.set_precision(os.environ["LS_PROF_PRECISION"])
-eng.set_schedule(orc.Schedule(8, ""))
+eng.set_schedule(synth.schedule(8))
 eng.prepare(synth.make_cond(cfg, B))
 for _ in range(2):
     eng.sample(sampler=0, philox_seed=1)

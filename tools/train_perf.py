@@ -5,7 +5,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from livelyspeaker_amd import _lib, synth
-from oracle import rag_oracle as orc
 
 ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
@@ -13,7 +12,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 cfg = synth.CONFIGS[ds]
 tr = _lib.Trainer(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
 tr.load_state_dict(synth.make_state_dict(cfg))
-tr.set_schedule(orc.Schedule(1000, ""))
+tr.set_schedule(synth.schedule(1000))
 x_start, y, noise, drop, eps = synth.make_train_batch(cfg, B, 0)
 dev = torch.device("cuda", 0)
 tod = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
