@@ -18,6 +18,7 @@ besides the contract's keys:
   "parity_in_run"  two samples of the FIRST TIMED call replayed through the CPU oracle on the restated Philox noise
   "single_pass"    the guidance-scale-1 workload (uncond pass legitimately skipped), own FLOP count -- never mixed into `value`
   "livelyspeaker"  BASELINE configs[2] as the reference runs it: SAG decode + ddim100 / skip 80 refine, own roofline
+  "configs4_beat"  BASELINE configs[4]: BEAT at 34 frames (B=256) and the SYNTHETIC 150-frame variant (B=32), own rooflines
   "shard_check"    the config-4 premise on hardware: every rank re-generates ANOTHER rank's shard via sample_offset
   "split_precision", "train_step"   secondary legs
   "cpu_baseline"   torch-CPU port of the reference algorithm timed on this box's host cores (bounded sample)
@@ -306,6 +307,45 @@ def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3):
                          "call_frac_note": "k_step FLOPs of the 20 steps at the MFMA peak / whole-call wall time (SAG + prepare + loop + host)"}}
 
 
+def other_config_leg(dataset, B, dev, fence, steps=1000):
+    """One more BASELINE config measured in the same run, compactly: a fresh model of that dataset, one warm-up and one timed
+    `p_sample_loop` call (1000-step DDPM, CFG 1.5, Philox noise), own FLOP count.  `beat150` is the SYNTHETIC 150-frame variant."""
+    import torch
+    from livelyspeaker_amd import synth
+    from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
+    from livelyspeaker_amd.model_util import create_model_and_diffusion
+    cfg = synth.CONFIGS[dataset]
+    model, diffusion = create_model_and_diffusion(mk_args(cfg, steps), "", dataset=dataset)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}, strict=False)
+    model.to(dev)
+    model.eval()
+    model.cache_conditioning = False
+    cfgm = ClassifierFreeSampleModel(model)
+    diffusion.noise_source = "philox"
+    y = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_cond(cfg, B, scale=1.5).items()}
+    shape = (B, cfg.njoints, cfg.nfeats, cfg.nframes)
+    call = lambda: diffusion.p_sample_loop(cfgm, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
+                                           progress=False, dump_steps=None, noise=None, const_noise=False)
+    call()
+    fence()
+    t0 = time.perf_counter()
+    out = call()
+    fence()
+    el = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    tm = model.engine().timing()
+    km = tm["loop_ms"] / max(tm["n_step_launches"], 1)
+    ach = 2 * FLOP_PER_FORWARD[dataset] * B / (km * 1e-3) / 1e12
+    model.engine().close()
+    return {"workload": f"{dataset.upper()} RAG, batch {B} x {cfg.nframes} frames, {steps}-step DDPM, CFG 1.5, Philox noise"
+                        + (" -- SYNTHETIC shape (150 frames: the reference cannot run it), perf-only, no parity claim vs the reference"
+                           if dataset == "beat150" else ""),
+            "value": round(B * cfg.nframes / el, 1), "unit": "pose-frames/s", "ms_per_call": round(el * 1e3, 2),
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "step_ms": round(km, 4),
+                         "flop_per_sample_step": 2 * FLOP_PER_FORWARD[dataset]}}
+
+
 def main():
     global _RESULT_OUT
     a = parse()
@@ -468,6 +508,17 @@ def main():
         except Exception as e:                      # never let a secondary leg take the headline line down
             lively = {"error": repr(e)[:300]}
 
+    # BASELINE configs[4] in the same run (1 GPU only): BEAT at the reference's 34 frames with the whole 256-clip job on this GPU, and the
+    # synthetic 150-frame variant at one GPU's share (256 / 8 = 32 clips)
+    others = None
+    if extra and a.dataset == "ted" and world == 1:
+        others = {}
+        for name, ds, bb in (("beat_34_frames_b256", "beat", 256), ("beat150_synthetic_b32", "beat150", 32)):
+            try:
+                others[name] = other_config_leg(ds, bb, dev, fence)
+            except Exception as e:
+                others[name] = {"error": repr(e)[:300]}
+
     # Secondary leg: one optimisation step of the denoiser, data-parallel over the ranks.
     train = None
     if extra and (a.train_leg or world == 1) and not a.no_train_leg and not strong:
@@ -523,6 +574,8 @@ def main():
             rec["single_pass"] = single
         if lively is not None:
             rec["livelyspeaker"] = lively
+        if others is not None:
+            rec["configs4_beat"] = others
         if split is not None:
             rec["split_precision"] = split
         if train is not None:
