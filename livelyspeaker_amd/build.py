@@ -71,7 +71,7 @@ def _object_for(hipcc, src, flags, objdir):
     return obj, None
 
 
-def build_library(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
+def build_library(force: bool = False, verbose: bool = False, defines=(), out: str = None, extra_flags=()) -> str:
     """Compile every source for gfx950 (one hipcc per file, in parallel, objects cached under build/obj) and link the
     shared library.  defines/out: build an A/B or debug variant (e.g. defines=['LS_DEBUG'], out='build/variants/debug.so');
     force=True ignores the object cache."""
@@ -83,8 +83,9 @@ def build_library(force: bool = False, verbose: bool = False, defines=(), out: s
     # -fno-slp-vectorize: SLP packs adjacent scalar f32 FMAs into v_pk_fma_f32 + v_mov shuffles, which is slower than
     # the scalar form next to MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
-             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
-    objdir = os.path.join(ROOT, "build", "obj" + ("-" + hashlib.sha256(" ".join(defines).encode()).hexdigest()[:8] if defines else ""))
+             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines] + list(extra_flags)
+    variant = list(defines) + list(extra_flags)
+    objdir = os.path.join(ROOT, "build", "obj" + ("-" + hashlib.sha256(" ".join(variant).encode()).hexdigest()[:8] if variant else ""))
     os.makedirs(objdir, exist_ok=True)
     if force:
         for o in glob.glob(os.path.join(objdir, "*.o")):
@@ -105,7 +106,7 @@ def build_library(force: bool = False, verbose: bool = False, defines=(), out: s
             os.remove(tmp)
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB)
-    if out is None and not defines:
+    if out is None and not defines and not extra_flags:
         with open(STAMP + f".tmp{os.getpid()}", "w") as f:
             f.write(digest + "\n")
         os.replace(STAMP + f".tmp{os.getpid()}", STAMP)

@@ -46,7 +46,9 @@ def build(specs):
     for spec in specs:
         name, _, defs = spec.partition("=")
         out = os.path.join(VDIR, name + ".so")
-        b.build_library(force=True, defines=[d for d in defs.split(",") if d], out=out)
+        items = [d for d in defs.split(",") if d]          # NAME=DEF1,DEF2,@-mllvm,@-some-flag : '@' items are raw compiler flags
+        b.build_library(force=True, defines=[d for d in items if not d.startswith("@")], out=out,
+                        extra_flags=[d[1:] for d in items if d.startswith("@")])
         print("built", out)
 
 
