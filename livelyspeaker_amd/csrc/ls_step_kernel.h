@@ -173,6 +173,38 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 X[cb][t] = v;
             }
         }
+        constexpr int NIT = (R * KXP + 511) / 512;                   // x_t values per thread: 5 (TED) | 41 (BEAT)
+        if constexpr (NIT > 8) {
+            // Wide feature vectors (BEAT, 282): the thread's loads first (clamped address + select: branch-free, in flight together),
+            // then the LDS writes, in blocks of 14 so the registers stay bounded -- as a load -> write loop every iteration paid its own
+            // L2 round trip, 41 in a row.  Same-box A/B (tools/ab_variants.py, 5 rounds): BEAT 0.8508 -> 0.8477 ms/step.  TED (5
+            // iterations) keeps the loop: the same change there measured 1.4334 -> 1.4373.
+            constexpr int CH = 14;
+#pragma unroll
+            for (int it0 = 0; it0 < NIT; it0 += CH) {
+                float xv[CH];
+#pragma unroll
+                for (int itl = 0; itl < CH; ++itl) {
+                    if (it0 + itl >= NIT) break;
+                    const int idx = min(tid + 512 * (it0 + itl), R * KXP - 1);
+                    const int r = idx / KXP, k = idx - r * KXP;
+                    const int sq = r >= S ? 1 : 0;
+                    const int tk = r - sq * S;
+                    const bool live = tk >= NPRE && k < JF;
+                    xv[itl] = a.x_in[(size_t)sm(sq) * kT * JF + (live ? (tk - NPRE) * JF + k : 0)];
+                    if (!live) xv[itl] = 0.f;
+                }
+#pragma unroll
+                for (int itl = 0; itl < CH; ++itl) {
+                    if (it0 + itl >= NIT) break;
+                    const int idx = tid + 512 * (it0 + itl);
+                    if (idx < R * KXP) {
+                        const int r = idx / KXP;
+                        U[r * kUStride + (idx - r * KXP)] = xv[itl];
+                    }
+                }
+            }
+        } else
         for (int idx = tid; idx < R * KXP; idx += 512) {
             const int r = idx / KXP, k = idx - r * KXP;
             const int sq = r >= S ? 1 : 0;
