@@ -222,12 +222,13 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) acc[c2][t] = X[2 * p + c2][t];
-            gf4p wp = g4(a.W->winx_img) + (size_t)(w * 2 + p) * KXQ * 2 * 64 + lane;
+            const wrsrc_t wrs = wrsrc(a.W->winx_img);
+            const int wsb = (w * 2 + p) * KXQ * 2 * 1024;
 #pragma unroll 2
             for (int q = 0; q < KXQ; ++q) {
                 f4 A[2], Bv[kNT];
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) A[c2] = wp[(q * 2 + c2) * 64];
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = wload4(wrs, lane * 16, wsb + (q * 2 + c2) * 1024);
 #pragma unroll
                 for (int t = 0; t < kNT; ++t)
                     Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 const __bf16* Th = reinterpret_cast<const __bf16*>(U);
                 const __bf16* Tl = Th + NG * kGrpStride;
                 const int slot = ((s16 & 3) << 2) | (s16 >> 2);      // channel i = 4g'+j' of a block lives in slot 4j'+g'
-                gbf8p wwh = (gbf8p)(const bf8*)(a.W->ww_hi_img) + (size_t)l * kNT * KS * 64 + lane;
-                gbf8p wwl = (gbf8p)(const bf8*)(a.W->ww_lo_img) + (size_t)l * kNT * KS * 64 + lane;
+                const wrsrc_t wrh = wrsrc(a.W->ww_hi_img), wrl = wrsrc(a.W->ww_lo_img);
+                const int wsb = l * kNT * KS * 1024;
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
                     const float bt = valid_of(t) ? g1(a.W->btok_rows)[l * 80 + row_of(t)] : 0.f;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         if (tokmix_needed32(S, t, ks)) {
-                            const bf8 Bh = wwh[(t * KS + ks) * 64], Bl = wwl[(t * KS + ks) * 64];
+                            const bf8 Bh = wload8h(wrh, lane * 16, wsb + (t * KS + ks) * 1024), Bl = wload8h(wrl, lane * 16, wsb + (t * KS + ks) * 1024);
                             const int grp = (4 * ks + 3 < NG || 4 * ks + g < NG) ? 4 * ks + g : NG - 1;   // clamp: weights are 0 there
                             const int ao = grp * kGrpStride + (64 * w + slot) * 8;
                             bf8 Ah[kCB], Al[kCB];
@@ -490,14 +491,15 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 }
             }
         } else if (!LS_ABLATED(a, 2)) {
-            gfp wwp = g1(a.W->ww_img) + (size_t)l * kNT * MK * 64 + lane;
+            const wrsrc_t wrs = wrsrc(a.W->ww_img);
+            const int wsb = l * kNT * MK * 256;
             const float* up = U + 64 * w + s16;
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
                 float Bt[MK];
 #pragma unroll
                 for (int m = 0; m < MK; ++m)
-                    if (tokmix_needed(S, t, m)) Bt[m] = wwp[(t * MK + m) * 64];
+                    if (tokmix_needed(S, t, m)) Bt[m] = wload1(wrs, lane * 4, wsb + (t * MK + m) * 256);
                 const float bt = valid_of(t) ? g1(a.W->btok_rows)[l * 80 + row_of(t)] : 0.f;    // Conv1d bias of this row
                 f4 acc[kCB];
 #pragma unroll
@@ -557,9 +559,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                     for (int t = 0; t < kNT; ++t) acc[c2][t] = bc;
                 }
-                const size_t wofs = ((size_t)((l * kWaves + w) * 2 + p) * 16) * 2 * 64 + lane;
-                gbf8p wh = (gbf8p)(const bf8*)(a.W->wch_hi_img) + wofs;
-                gbf8p wl = (gbf8p)(const bf8*)(a.W->wch_lo_img) + wofs;
+                const wrsrc_t wrh = wrsrc(a.W->wch_hi_img), wrl = wrsrc(a.W->wch_lo_img);
+                const int wsb = (((l * kWaves + w) * 2 + p) * 16) * 2 * 1024;
                 const __bf16* Uh = reinterpret_cast<const __bf16*>(U);
                 const __bf16* Ul = Uh + R * kUStride;
                 int rofs[kNT];
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 for (int t = 0; t < kNT; ++t) rofs[t] = rowc_of(t) * kUStride + 8 * g;
                 bf8 Ahn[2], Aln[2];
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) { Ahn[c2] = wh[c2 * 64]; Aln[c2] = wl[c2 * 64]; }
+                for (int c2 = 0; c2 < 2; ++c2) { Ahn[c2] = wload8h(wrh, lane * 16, wsb + c2 * 1024); Aln[c2] = wload8h(wrl, lane * 16, wsb + c2 * 1024); }
                 if (!LS_ABLATED(a, 1))
 #pragma unroll 2
                 for (int q = 0; q < 16; ++q) {
@@ -576,7 +577,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     for (int c2 = 0; c2 < 2; ++c2) { Ah[c2] = Ahn[c2]; Al[c2] = Aln[c2]; }
                     const int qn = (q + 1 < 16) ? q + 1 : 15;
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) { Ahn[c2] = wh[(qn * 2 + c2) * 64]; Aln[c2] = wl[(qn * 2 + c2) * 64]; }
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        Ahn[c2] = wload8h(wrh, lane * 16, wsb + (qn * 2 + c2) * 1024);
+                        Aln[c2] = wload8h(wrl, lane * 16, wsb + (qn * 2 + c2) * 1024);
+                    }
 #pragma unroll
                     for (int t = 0; t < kNT; ++t) {
                         Bh[t] = *reinterpret_cast<const bf8*>(Uh + rofs[t] + 32 * q);
@@ -633,13 +637,16 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                 for (int r = 0; r < NRG; ++r) racc4[c2][r] = (f4){0.f, 0.f, 0.f, 0.f};
             }
-            gf4p wp = g4(a.W->wch_img) + ((size_t)((l * kWaves + w) * 2 + p) * 32) * 2 * 64 + lane;
+            // W fragments through a buffer descriptor (ls_step_common.h: 3.7 instead of 16.8 matrix-pipe cycles per load; same-box A/B
+            // of this loop alone, TED B = 512: 1.4364 -> 1.4182 ms per step)
+            const wrsrc_t wrs = wrsrc(a.W->wch_img);
+            const int wsb = (((l * kWaves + w) * 2 + p) * 32) * 2 * 1024;       // this wave's slice of the image, bytes (wave-uniform)
             const float* ub = U + s16 * kUStride + 4 * g;                 // tile t: + 16*t*kUStride
             // VALU path: remainder row r at + r*kUStride (all lanes the same row); MFMA path: lane's row (lane&3) of group rg at + 4*rg*kUStride
             const float* ur = U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g;
             f4 An[2];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
+            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + c2 * 1024);
             if (!LS_ABLATED(a, 1))
 #pragma unroll 2
             for (int q = 0; q < 32; ++q) {
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 {
                     const int qn = (q + 1 < 32) ? q + 1 : 31;       // branch-free prefetch (last one re-reads q=31)
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[(qn * 2 + c2) * 64];
+                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + (qn * 2 + c2) * 1024);
                 }
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t)
@@ -765,12 +772,13 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int t = 0; t < kNT; ++t) acc[ob][t] = (f4){0.f, 0.f, 0.f, 0.f};
-        gf4p wr = g4(a.W->wout_reg_img) + (size_t)w * NOB * kCB * 64 + lane;
+        const wrsrc_t wrs = wrsrc(a.W->wout_reg_img);
+        const int wsb = w * NOB * kCB * 1024;
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) {
-                const f4 A = wr[(ob * kCB + cb) * 64];
+                const f4 A = wload4(wrs, lane * 16, wsb + (ob * kCB + cb) * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -799,12 +807,13 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             if (u < NU) {
                 const int ob = u / kNT, t = u - ob * kNT;
                 const int rc = (16 * t + s16 < R) ? 16 * t + s16 : R - 1;
-                gf4p wp = g4(a.W->wout_img) + (size_t)ob * 32 * 64 + lane;
+                const wrsrc_t wrs = wrsrc(a.W->wout_img);
+                const int wsb = ob * 32 * 1024;
                 const float* up = &U[rc * kUStride + 4 * g];
                 f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll 4
                 for (int q = 0; q < 32; ++q) {
-                    const f4 A = wp[q * 64];
+                    const f4 A = wload4(wrs, lane * 16, wsb + q * 1024);
                     const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * q);
                     a0 = MFMA(A[0], Bv[0], a0);
                     a1 = MFMA(A[1], Bv[1], a1);

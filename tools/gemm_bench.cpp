@@ -1,0 +1,37 @@
+// Stand-alone timing of launch_gemm_nt (the nn.Linear-shaped fp32 MFMA GEMM) on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -x hip -I livelyspeaker_amd/csrc -I include tools/gemm_bench.cpp livelyspeaker_amd/csrc/ls_gemm.hip -o variants/gemm_bench
+//   variants/gemm_bench M N K [act] [residual]   ->  us per launch and TFLOP/s (HIP events over 50 launches, after 10 warm-ups)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "ls_internal.h"
+#include "ls_train.h"
+
+int main(int argc, char** argv) {
+    if (argc < 4) { std::fprintf(stderr, "usage: gemm_bench M N K [act] [residual]\n"); return 2; }
+    const int M = std::atoi(argv[1]), N = std::atoi(argv[2]), K = std::atoi(argv[3]);
+    const int act = argc > 4 ? std::atoi(argv[4]) : 0, res = argc > 5 ? std::atoi(argv[5]) : 0;
+    float *A, *W, *C, *b, *R;
+    hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&b, N * 4);
+    hipMalloc(&R, (size_t)M * N * 4);
+    std::vector<float> h((size_t)M * K);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.f - 0.5f;
+    hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    h.resize((size_t)N * K);
+    hipMemcpy(W, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(b, 0, N * 4); hipMemset(R, 0, (size_t)M * N * 4);
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 10; ++i) ls::launch_gemm_nt(A, K, W, K, b, res ? R : nullptr, N, C, N, M, N, K, act, st);
+    const int n = 50;
+    hipEventRecord(e0, st);
+    for (int i = 0; i < n; ++i) ls::launch_gemm_nt(A, K, W, K, b, res ? R : nullptr, N, C, N, M, N, K, act, st);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1000.0 / n;
+    std::printf("gemm M=%d N=%d K=%d act=%d res=%d: %.1f us  %.1f TFLOP/s (%.3f of 157.3)\n", M, N, K, act, res, us, 2.0 * M * N * K / us * 1e-6,
+                2.0 * M * N * K / us * 1e-6 / 157.3);
+    return 0;
+}
