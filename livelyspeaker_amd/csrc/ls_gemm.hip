@@ -12,6 +12,14 @@
 // v_mfma_f32_16x16x4_f32, 128x128 tile / 256 threads, K chunk 32, same transposed accumulator form as the step kernel.
 // Split-K (gridDim.z > 1) writes partial tiles to a workspace which k_splitk_reduce sums in a fixed order
 // (deterministic: no float atomics anywhere in the training step).
+//
+// DMA variant (both operands K-contiguous, full tiles -- every nn.Linear of the sampler, the SAG decoder and the long path): the
+// K tiles go global -> LDS with `buffer_load_dwordx4 ... lds` into a double buffer, one barrier per K tile.  Measured on the MI355X
+// (tools/vmem_cost.cpp, issue cost in cycles of a saturated fp32 matrix pipe, 3 waves / SIMD): global_load_dwordx4 16.8 +
+// ds_write_b128 28.0 per 16 B of a lane through registers, 5.7 through the LDS-DMA path -- the register-staged loop spends 13 %
+// of the pipe's time on its 12 staging instructions per 64 MFMAs.  The DMA destination is lane-linear (1 KB per wave instruction =
+// 8 rows x 128 B), so rows sit unpadded at 128 B and the 16-byte chunk c of row r is stored at position c ^ (r & 7): each lane
+// FETCHES the chunk that belongs at its position, and the fragment reads apply the same XOR (conflict-free ds_read_b128).
 #include "ls_internal.h"
 #include "ls_train.h"
 
@@ -24,7 +32,7 @@ constexpr int kTM = 128, kTK = 32, kLdK = kTK + 4, kLdR = kTM + 4;
 
 // epilogue activations: 0 none, 1 SiLU, 2 exp(0.5 y) (std from log-variance), 3 exact GELU (F.gelu default)
 __device__ __forceinline__ float gemm_act(float v, int act) {
-    if (act == 1) return v / (1.0f + expf(-v));
+    if (act == 1) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));   // the step kernel's SiLU (v_exp_f32 + v_rcp_f32)
     if (act == 2) return expf(0.5f * v);
     if (act == 3) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     return v;
@@ -124,12 +132,34 @@ __device__ __forceinline__ f4 frag(const float* s, int row, int kk, int g) {
 // MT: 16-row m tiles per wave -> 128 (MT = 4) or 64 (MT = 2) rows of A per workgroup.  The 64-row tile exists for products whose
 // 128 x 128 tile count fills the chip badly (e.g. 544 tiles on 768 workgroup slots: one CU in eight runs three tiles while the
 // others run two); only the K-contiguous fast path is instantiated with it.
-template <bool AK, bool BK, bool FAST, int MT = 4>
-__global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
+typedef __attribute__((address_space(3))) void* lds_vp;
+
+// descriptor over an operand; the readfirstlane pair keeps it in SGPRs (the compiler does not prove blockIdx arithmetic uniform and
+// would wrap every load in a waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+// one K tile of both operands, global -> LDS: wave wv issues MT + 4 buffer_load_dwordx4 ... lds, each filling 8 rows (1 KB)
+template <int MT>
+__device__ __forceinline__ void gemm_dma_issue(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, float* sA, float* sB, int wv,
+                                               const int (&voA)[MT], const int (&voB)[4], int k0) {
+    const int kb = __builtin_amdgcn_readfirstlane(k0 * 4);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vp)&sA[(wv * MT + i) * 256], 16, voA[i], kb, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vp)&sB[(wv * 4 + i) * 256], 16, voB[i], kb, 0, 0);
+}
+
+template <bool AK, bool BK, bool FAST, int MT = 4, bool DMA = false>
+__global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
     static_assert(MT == 4 || (MT == 2 && AK && FAST), "64-row tiles: K-contiguous A on the fast path only");
+    static_assert(!DMA || (AK && BK && FAST), "LDS-DMA staging: both operands K-contiguous, full tiles");
     constexpr int BM = 32 * MT;
-    constexpr int SA = AK ? BM * kLdK : kTK * kLdR;
-    constexpr int SB = BK ? kTM * kLdK : kTK * kLdR;
+    constexpr int SA = DMA ? 2 * BM * kTK : (AK ? BM * kLdK : kTK * kLdR);
+    constexpr int SB = DMA ? 2 * kTM * kTK : (BK ? kTM * kLdK : kTK * kLdR);
     __shared__ __attribute__((aligned(16))) float sA[SA];
     __shared__ __attribute__((aligned(16))) float sB[SB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -152,6 +182,48 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (DMA) {
+        const auto rsA = uniform_rsrc(a.A.p), rsB = uniform_rsrc(a.B.p);
+        // wave wv stages blocks wv*MT + i of A and wv*4 + i of B (8 rows each); lane = (row in block, position in row)
+        const int rl = lane >> 3, ch = (lane & 7) ^ rl;             // this lane's position holds chunk ch of its row
+        int voA[MT], voB[4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) voA[i] = (int)(((long long)(m0 + (wv * MT + i) * 8 + rl) * a.A.rs + ch * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voB[i] = (int)(((long long)(n0 + (wv * 4 + i) * 8 + rl) * a.B.rs + ch * 4) * 4);
+        // fragment (row, k half kk): chunk 4 kk + g of the row, stored at position (4 kk + g) ^ (row & 7); row & 7 = s16 & 7 for every tile
+        const int o0 = ((g ^ (s16 & 7)) * 4), o1 = o0 ^ 16;
+        const int fa = (wm * 16 * MT + s16) * kTK, fb = (wn * 64 + s16) * kTK;
+        gemm_dma_issue<MT>(rsA, rsB, sA, sB, wv, voA, voB, kbeg);
+        __syncthreads();                                    // carries the vmcnt(0) of the DMA above
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += kTK) {
+            if (k0 + kTK < kend) gemm_dma_issue<MT>(rsA, rsB, sA + (buf ^ 1) * BM * kTK, sB + (buf ^ 1) * kTM * kTK, wv, voA, voB, k0 + kTK);    // lands while this tile is multiplied; its buffer was last read before the previous barrier
+            const float* cA = sA + buf * BM * kTK + fa;
+            const float* cB = sB + buf * kTM * kTK + fb;
+            f4 af[2][MT], bf[2];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) af[0][j] = *reinterpret_cast<const f4*>(cA + 16 * j * kTK + o0);
+            bf[0] = *reinterpret_cast<const f4*>(cB + o0);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int kk = st >> 2, i = st & 3;
+                if (st + 1 < 8) bf[(st + 1) & 1] = *reinterpret_cast<const f4*>(cB + 16 * ((st + 1) & 3) * kTK + (((st + 1) >> 2) ? o1 : o0));
+                if (st == 0) {
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) af[1][j] = *reinterpret_cast<const f4*>(cA + 16 * j * kTK + o1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) acc[i][j] = MFMA(bf[st & 1][e], af[kk][j][e], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
     size_t roffA[4], roffB[4];
     row_offsets<AK>(a.A, roffA, m0, a.M, tid);
     row_offsets<BK>(a.B, roffB, n0, a.N, tid);
@@ -222,6 +294,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
                 }
             }
         }
+    }
     }
     // lane (m = s16 of m tile j, g) holds n = n0 + wn*64 + 16*i + 4*g + {0..3}
     const bool partial = a.splits > 1;
@@ -316,7 +389,17 @@ hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits
     auto balance = [](long long wgs) { const double per = (double)wgs / 256.0; return per / (double)((wgs + 255) / 256); };
     const long long t128 = (long long)grid.x * grid.y * grid.z;
     const bool half = fast && a_kcontig && b_kcontig && balance(2 * t128) > balance(t128) + 0.05;
-    if (half) {
+    // LDS-DMA staging: single-level rows and every byte offset of an operand inside 31 bits (buffer addressing)
+    const bool dma = fast && a_kcontig && b_kcontig && a.A.ri == INT_MAX && a.B.ri == INT_MAX &&
+                     (long long)a.M * a.A.rs < (1ll << 29) && (long long)a.N * a.B.rs < (1ll << 29);
+    if (dma) {
+        if (half) {
+            grid.y *= 2;
+            hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2, true>), grid, dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((k_gemm_tr<true, true, true, 4, true>), grid, dim3(256), 0, st, a);
+        }
+    } else if (half) {
         grid.y *= 2;
         hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2>), grid, dim3(256), 0, st, a);
     } else {

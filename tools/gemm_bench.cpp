@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 #include "ls_internal.h"
 #include "ls_train.h"
@@ -15,11 +16,11 @@ int main(int argc, char** argv) {
     float *A, *W, *C, *b, *R;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&b, N * 4);
     hipMalloc(&R, (size_t)M * N * 4);
-    std::vector<float> h((size_t)M * K);
+    std::vector<float> h((size_t)M * K), hw((size_t)N * K);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.f - 0.5f;
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 40503u + 977u >> 4) & 0xffff) / 65536.f - 0.5f;
     hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    h.resize((size_t)N * K);
-    hipMemcpy(W, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     hipMemset(b, 0, N * 4); hipMemset(R, 0, (size_t)M * N * 4);
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -33,5 +34,18 @@ int main(int argc, char** argv) {
     const double us = ms * 1000.0 / n;
     std::printf("gemm M=%d N=%d K=%d act=%d res=%d: %.1f us  %.1f TFLOP/s (%.3f of 157.3)\n", M, N, K, act, res, us, 2.0 * M * N * K / us * 1e-6,
                 2.0 * M * N * K / us * 1e-6 / 157.3);
+    if (act == 0 && !res) {      // spot check against a host dot product (bias is zero)
+        std::vector<float> c((size_t)M * N);
+        hipMemcpy(c.data(), C, c.size() * 4, hipMemcpyDeviceToHost);
+        double worst = 0;
+        for (int t = 0; t < 4096; ++t) {
+            const int m = (int)((t * 2654435761u) % (unsigned)M), n = (int)((t * 40503u + 17u) % (unsigned)N);
+            double ref = 0;
+            for (int k = 0; k < K; ++k) ref += (double)h[(size_t)m * K + k] * hw[(size_t)n * K + k];
+            const double d = std::fabs(ref - c[(size_t)m * N + n]);
+            if (d > worst) worst = d;
+        }
+        std::printf("    max |C - host dot| over 4096 sampled entries: %.3g %s\n", worst, worst < 1e-3 ? "ok" : "MISMATCH");
+    }
     return 0;
 }
