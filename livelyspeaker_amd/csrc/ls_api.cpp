@@ -62,7 +62,7 @@ struct ls_handle {
     int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
     bool fused = true;
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection, row stride of the output buffer)
-    DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160)
+    DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
     DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_stats;            // long path: workspaces
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -447,9 +447,16 @@ int build_long_weights(ls_handle* h) {
     int rc;
 #define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
     if (S <= 160) {                                                                     // operand image of the fused token-mixing kernel
+        // per-lane fragment order: img[l][q][mt][lane = s16 + 16 g][e] = Wt[l][16 mt + s16][16 q + 4 g + e], zero beyond S
         std::vector<float> wtp((size_t)L * 160 * 160, 0.f);
         for (int l = 0; l < L; ++l)
-            for (int r = 0; r < S; ++r) memcpy(&wtp[((size_t)l * 160 + r) * 160], &wt[((size_t)l * S + r) * S], S * sizeof(float));
+            for (int q = 0; q < 10; ++q)
+                for (int mt = 0; mt < 10; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 16 * mt + (lane & 15), k = 16 * q + 4 * (lane >> 4) + e;
+                            if (r < S && k < S) wtp[(size_t)l * 160 * 160 + (((size_t)q * 10 + mt) * 64 + lane) * 4 + e] = wt[((size_t)l * S + r) * S + k];
+                        }
         UP(lw_wtp, wtp);
     } else {
         h->lw_wtp.release();

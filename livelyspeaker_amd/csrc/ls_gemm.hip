@@ -22,6 +22,7 @@
 // FETCHES the chunk that belongs at its position, and the fragment reads apply the same XOR (conflict-free ds_read_b128).
 #include "ls_internal.h"
 #include "ls_train.h"
+#include "ls_lanes.h"
 
 namespace ls {
 
@@ -133,14 +134,6 @@ __device__ __forceinline__ f4 frag(const float* s, int row, int kk, int g) {
 // 128 x 128 tile count fills the chip badly (e.g. 544 tiles on 768 workgroup slots: one CU in eight runs three tiles while the
 // others run two); only the K-contiguous fast path is instantiated with it.
 typedef __attribute__((address_space(3))) void* lds_vp;
-
-// descriptor over an operand; the readfirstlane pair keeps it in SGPRs (the compiler does not prove blockIdx arithmetic uniform and
-// would wrap every load in a waterfall loop)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* p) {
-    const unsigned long long v = (unsigned long long)(uintptr_t)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
-}
 
 // one K tile of both operands, global -> LDS: wave wv issues MT + 4 buffer_load_dwordx4 ... lds, each filling 8 rows (1 KB)
 template <int MT>
@@ -393,12 +386,10 @@ hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits
     const bool dma = fast && a_kcontig && b_kcontig && a.A.ri == INT_MAX && a.B.ri == INT_MAX &&
                      (long long)a.M * a.A.rs < (1ll << 29) && (long long)a.N * a.B.rs < (1ll << 29);
     if (dma) {
-        if (half) {
-            grid.y *= 2;
-            hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2, true>), grid, dim3(256), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((k_gemm_tr<true, true, true, 4, true>), grid, dim3(256), 0, st, a);
-        }
+        // always 64-row tiles: 48 KB of double buffer lets three workgroups share a CU (the 128-row form: 64 KB, two); measured over the
+        // sampler's shapes (tools/gemm_bench.cpp) the 128-row DMA tile lost to this one and, at some, to the register-staged kernel
+        grid.y *= 2;
+        hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2, true>), grid, dim3(256), 0, st, a);
     } else if (half) {
         grid.y *= 2;
         hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2>), grid, dim3(256), 0, st, a);

@@ -112,7 +112,7 @@ struct LongStepArgs {
     const float* winx;                     // [512][JFP]  x_t columns of input_mapping
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;      // [L][512]
     const float* wt; const float* bt;      // [L][S][S], [L][S]   token-mixing Conv1d(S, S, 1)
-    const float* wtp;                      // [L][160][160] the same, zero-padded (operand image of k_long_tokmix), or null
+    const float* wtp;                      // [L][160 x 160] the same, zero-padded, in k_long_tokmix's per-lane fragment order, or null
     const float* wc; const float* bc;      // [L][512][512], [L][512]
     const float* wout; const float* bout;  // [JF][512], [JF]
     // workspaces

@@ -5,6 +5,19 @@
 
 namespace ls {
 
+// Buffer descriptor over [p, p + 2 GiB) held in SGPRs: loads through it take an SGPR base + one 32-bit VGPR byte offset + an SGPR
+// offset.  Measured on the MI355X (tools/vmem_cost.cpp, 3 waves / SIMD under a saturated fp32 matrix pipe): a global_load_dwordx4 with
+// a per-lane 64-bit address costs 16.8 matrix-pipe cycles of issue, buffer_load_dwordx4 in this form 3.7 (and `... lds`, straight
+// into LDS, 5.7 against 16.8 + 28.0 for load + ds_write_b128), and the per-load 64-bit pointer arithmetic becomes s_add.
+// The readfirstlane pair (through UNSIGNED temporaries: the builtin returns int, and an int OR-ed into the 64-bit address
+// sign-extends) keeps the descriptor in SGPRs where the compiler cannot prove the pointer uniform; without it every load is wrapped
+// in a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((unsigned long long)hi << 32) | (unsigned long long)lo), 0, 0x7fffffff, 0x00020000);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {       // v + v[lane selected by the DPP control]
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));

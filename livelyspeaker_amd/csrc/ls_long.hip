@@ -10,7 +10,7 @@
 // path runs the same arithmetic as separate launches over ALL rows of the batch (row r = (pass, sample, token); pass 0 = cond,
 // 1 = uncond):
 //   k_long_assemble   token sequences: style / emotion tokens + static projection + x_t projection        (RAG.py:110-126)
-//   per layer:  k_long_addemb_stats (x += emb; row statistics) -> k_long_tokmix (LN1 applied while staging, Wt in LDS, MFMA,
+//   per layer:  k_long_addemb_stats (x += emb; row statistics) -> k_long_tokmix (LN1 applied while staging, Wt fragments from L2, MFMA,
 //               x += SiLU(Wt u + bt) in place)  [S > 160: k_long_addemb_ln + a batched, transposed GEMM per sequence]
 //               -> k_layernorm512 (u = LN2(x)) -> channel mixing GEMM (x += SiLU(u Wc^T + bc))
 //   poseFinal GEMM -> k_long_update (CFG lerp + DDPM / DDIM update + noise)                 (cfg_sampler.py:31, gaussian_diffusion.py)
@@ -95,97 +95,88 @@ __global__ __launch_bounds__(256) void k_long_addemb_stats(float* __restrict__ x
 
 // Token mixing of one sequence (Conv1d(S, S, 1) over the token axis, mlp_module.py:51-55, 70-71), fused with LN1 and the SiLU +
 // residual:   x[t][c] += SiLU( sum_k Wt[t][k] * LN1(x)[k][c] + bt[t] )
-// Workgroup = (sequence, 128-channel quarter), 4 waves.  Wt (zero-padded to [KPAD][KPAD] on the host) is staged in LDS ONCE and
-// serves both 64-channel slabs of the quarter; per slab the operand LN1(x)[k][64] is staged (normalised with the row statistics of
-// k_long_addemb_stats and alpha / beta on the way in), then D[token tile][channel tile] runs on v_mfma_f32_16x16x4_f32: wave w owns
-// channel tile w of the slab and all token tiles, A = Wt rows (ds_read_b128 in the k-permuted order, row stride KPAD + 4:
-// conflict-free), B = the operand column (4 ds_read_b32 per 4 k-steps, shared by every token tile).  The result goes back into x in
-// place (a slab's columns are touched by this workgroup only).
+// Workgroup = (sequence, 64-channel slab), 4 waves; wave w owns channel tile w of the slab and every token tile.  The operand
+// LN1(x)[k][64] is staged in LDS (normalised with the row statistics of k_long_addemb_stats and alpha / beta on the way in; rows >= S
+// are zero); the Wt fragments come straight from an L2-resident per-lane image (img[q][mt][lane] = Wt[16 mt + s16][16 q + 4 g ..+3],
+// zero-padded to KPAD x KPAD on the host, 100 KB per layer shared by every workgroup) through a buffer descriptor -- 3.7 matrix-pipe
+// cycles of issue per fragment (tools/vmem_cost.cpp), the next k block's ten fragments in flight while the current one is
+// multiplied.  With Wt in LDS instead (105 KB + the 43 KB operand: one 4-wave workgroup per CU, its 25-deep staging chain, operand
+// staging and in-place epilogue all exposed) the kernel took 42 us at 64 sequences for 10.7 us of MFMA issue; 43 KB lets three
+// workgroups share a CU.  D[token tile][channel tile] on v_mfma_f32_16x16x4_f32, B = the operand column (4 ds_read_b32 per 4
+// k-steps, shared by every token tile); the result goes back into x in place (a slab's columns belong to this workgroup only).
 template <int KPAD>
-__global__ __launch_bounds__(256) void k_long_tokmix(float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wtp,
-                                                     const float* __restrict__ bt, const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                     int S) {
-    constexpr int LW = KPAD + 4, LU = 64 + 4, NMT = KPAD / 16;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sW = lds;                   // [KPAD][LW]
-    float* sU = lds + KPAD * LW;       // [KPAD][LU]  (rows >= S are zero)
-    const int seq = blockIdx.x, quarter = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+__global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wimg,
+                                                        const float* __restrict__ bt, const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                        int S) {
+    constexpr int LU = 64 + 4, NMT = KPAD / 16, NQ = KPAD / 16;
+    __shared__ __attribute__((aligned(16))) float sU[KPAD * LU];       // [KPAD][LU]
+    const int seq = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
     float* xs = x + (size_t)seq * S * kD;
     const float* st = stats + (size_t)seq * S * 2;
-    {   // Wt image -> LDS.  All of a thread's loads are issued before its first LDS write (a load -> write loop runs one L2 round trip
-        // per iteration: 25 of them in a row were 37 of this kernel's 50 us)
-        constexpr int NW = KPAD * (KPAD / 4) / 256;
-        static_assert(KPAD * (KPAD / 4) % 256 == 0, "whole float4 rounds");
-        f4 tw[NW];
+    const auto wrs = uniform_rsrc(wimg);
+    auto wfrag = [&](int q, int mt) {
+        return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (q * NMT + mt) * 1024, 0));
+    };
+    f4 An[NMT];
 #pragma unroll
-        for (int j = 0; j < NW; ++j) tw[j] = *reinterpret_cast<const f4*>(wtp + (size_t)(tid + 256 * j) * 4);     // the image is dense [KPAD][KPAD]
+    for (int mt = 0; mt < NMT; ++mt) An[mt] = wfrag(0, mt);             // in flight during the operand staging
+    {   // operand slab: LN1 applied on the way in; loads first (clamped rows: branch-free), then the LDS writes
+        constexpr int NU = KPAD * 16 / 256;
+        const int c4 = tid & 15;
+        const f4 al = *reinterpret_cast<const f4*>(alpha + c0 + 4 * c4), be = *reinterpret_cast<const f4*>(beta + c0 + 4 * c4);
+        f4 xv[NU];
+        float mu[NU], rs[NU];
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int i = tid + 256 * j, r = i / (KPAD / 4), c4 = i - r * (KPAD / 4);
-            *reinterpret_cast<f4*>(&sW[r * LW + 4 * c4]) = tw[j];
+        for (int j = 0; j < NU; ++j) {
+            const int r = min((tid >> 4) + 16 * j, S - 1);
+            xv[j] = *reinterpret_cast<const f4*>(xs + (size_t)r * kD + c0 + 4 * c4);
+            mu[j] = st[2 * r]; rs[j] = st[2 * r + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int r = (tid >> 4) + 16 * j;
+            const f4 v = (xv[j] - mu[j]) * rs[j] * al + be;
+            *reinterpret_cast<f4*>(&sU[r * LU + 4 * c4]) = r < S ? v : (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    for (int slab = 0; slab < 2; ++slab) {
-        const int c0 = quarter * 128 + slab * 64;
-        if (slab) __syncthreads();                                            // the previous slab's MFMAs are done with sU
-        {   // operand slab: LN1 applied on the way in; loads first (clamped rows: branch-free), then the LDS writes
-            constexpr int NU = KPAD * 16 / 256;
-            const int c4 = tid & 15;
-            const f4 al = *reinterpret_cast<const f4*>(alpha + c0 + 4 * c4), be = *reinterpret_cast<const f4*>(beta + c0 + 4 * c4);
-            f4 xv[NU];
-            float mu[NU], rs[NU];
+    __syncthreads();
+    f4 acc[NMT];
 #pragma unroll
-            for (int j = 0; j < NU; ++j) {
-                const int r = min((tid >> 4) + 16 * j, S - 1);
-                xv[j] = *reinterpret_cast<const f4*>(xs + (size_t)r * kD + c0 + 4 * c4);
-                mu[j] = st[2 * r]; rs[j] = st[2 * r + 1];
-            }
-#pragma unroll
-            for (int j = 0; j < NU; ++j) {
-                const int r = (tid >> 4) + 16 * j;
-                const f4 v = (xv[j] - mu[j]) * rs[j] * al + be;
-                *reinterpret_cast<f4*>(&sU[r * LU + 4 * c4]) = r < S ? v : (f4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        __syncthreads();
-        f4 acc[NMT];
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) acc[mt] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < NMT; ++mt) acc[mt] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-        for (int q = 0; q < KPAD / 16; ++q) {
-            float Bv[4];
+    for (int q = 0; q < NQ; ++q) {
+        float Bv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Bv[e] = sU[(16 * q + 4 * g + e) * LU + 16 * w + s16];
-            f4 A[NMT];
+        for (int e = 0; e < 4; ++e) Bv[e] = sU[(16 * q + 4 * g + e) * LU + 16 * w + s16];
+        f4 A[NMT];
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) A[mt] = *reinterpret_cast<const f4*>(&sW[(16 * mt + s16) * LW + 16 * q + 4 * g]);
+        for (int mt = 0; mt < NMT; ++mt) A[mt] = An[mt];
+        const int qn = q + 1 < NQ ? q + 1 : NQ - 1;                      // branch-free prefetch (the last one re-reads its own block)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)                       // k-step outer: consecutive MFMAs hit different accumulators
+        for (int mt = 0; mt < NMT; ++mt) An[mt] = wfrag(qn, mt);
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][e], Bv[e], acc[mt], 0, 0, 0);
-        }
-        // lane (s16, g) holds D[token = 16 mt + 4 g + r][channel = c0 + 16 w + s16].  All residual loads first, then the stores:
-        // written as `*p = *p + f(acc)` per element the compiler must keep every load behind the previous store (it cannot prove the
-        // addresses distinct), which serialises 40 L2 round trips per lane.
-        float res[NMT][4];
+        for (int e = 0; e < 4; ++e)                       // k-step outer: consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = min(16 * mt + 4 * g + r, S - 1);
-                res[mt][r] = xs[(size_t)t * kD + c0 + 16 * w + s16];
-            }
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = 16 * mt + 4 * g + r;
-                const float v = acc[mt][r] + bt[min(t, S - 1)];
-                if (t < S) xs[(size_t)t * kD + c0 + 16 * w + s16] = res[mt][r] + v / (1.0f + __expf(-v));
-            }
+            for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][e], Bv[e], acc[mt], 0, 0, 0);
     }
+    // lane (s16, g) holds D[token = 16 mt + 4 g + r][channel = c0 + 16 w + s16].  All residual loads first, then the stores: written as
+    // `*p = *p + f(acc)` per element the compiler must keep every load behind the previous store (it cannot prove the addresses
+    // distinct), which serialises 40 L2 round trips per lane.
+    float res[NMT][4];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[mt][r] = xs[(size_t)min(16 * mt + 4 * g + r, S - 1) * kD + c0 + 16 * w + s16];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * mt + 4 * g + r;
+            const float v = acc[mt][r] + bt[min(t, S - 1)];
+            if (t < S) xs[(size_t)t * kD + c0 + 16 * w + s16] = res[mt][r] + v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+        }
 }
 
 // CFG combination + sampler update, element (b, t, c) of the internal [B][T][JF] layout; OUT rows are (pass, b, token) x ldo
@@ -231,21 +222,13 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     // x_t columns of input_mapping: xproj[B*T][512] = x_t[B*T][JF] . Win[:, :JF]^T   (K padded with zero columns of the weight)
     if ((e = launch_gemm_nt(a.x_in, a.JF, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, a.B * a.T, D, a.JF, 0, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a);
-    // fused token mixing needs S <= 160 (its Wt image and operand slab live in LDS); longer sequences take the batched-GEMM form
+    // fused token mixing needs S <= 160 (accumulators for ten token tiles, the operand slab in LDS); longer sequences take the batched-GEMM form
     constexpr int kTokPad = 160;
     const bool fused_tok = a.wtp != nullptr && a.S <= kTokPad;
-    const size_t tok_lds = (size_t)(kTokPad * (kTokPad + 4) + kTokPad * 68) * sizeof(float);
-    if (fused_tok) {
-        static bool attr_set = false;                                          // > 64 KiB of dynamic LDS: opt in once per process
-        if (!attr_set) {
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_long_tokmix<kTokPad>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tok_lds)) != hipSuccess) return e;
-            attr_set = true;
-        }
-    }
     for (int l = 0; l < a.layers; ++l) {
         if (fused_tok) {
             hipLaunchKernelGGL(k_long_addemb_stats, dim3((rows + 3) / 4), dim3(256), 0, st, a.X, a.temb, a.stats, rows);
-            hipLaunchKernelGGL((k_long_tokmix<kTokPad>), dim3(2 * a.B, 4), dim3(256), tok_lds, st, a.X, a.stats, a.wtp + (size_t)l * kTokPad * kTokPad,
+            hipLaunchKernelGGL((k_long_tokmix<kTokPad>), dim3(2 * a.B, 8), dim3(256), 0, st, a.X, a.stats, a.wtp + (size_t)l * kTokPad * kTokPad,
                                a.bt + (size_t)l * a.S, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.S);
         } else {
         hipLaunchKernelGGL(k_long_addemb_ln, dim3((rows + 3) / 4), dim3(256), 0, st, a.X, a.temb, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.U, rows);

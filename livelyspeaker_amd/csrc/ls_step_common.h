@@ -2,6 +2,7 @@
 #pragma once
 #include "ls_internal.h"
 #include "ls_philox.h"
+#include "ls_lanes.h"
 
 namespace ls {
 
@@ -70,18 +71,9 @@ typedef const __attribute__((address_space(1))) float* gfp;
 __device__ __forceinline__ gf4p g4(const float* p) { return (gf4p)(const f4*)p; }
 __device__ __forceinline__ gfp g1(const float* p) { return (gfp)p; }
 
-// Weight images are read through a buffer descriptor: SGPR base + one 32-bit VGPR byte offset (lane * 16) + an SGPR offset that
-// walks the image.  Measured on the MI355X (tools/vmem_cost.cpp, 3 waves / SIMD under a saturated fp32 matrix pipe): a
-// global_load_dwordx4 with a per-lane 64-bit address takes 16.8 matrix-pipe cycles of issue, buffer_load_dwordx4 in this form 3.7,
-// and the per-load v_lshl_add_u64 pointer arithmetic disappears into s_add.
+// Weight images are read through a buffer descriptor (ls_lanes.h: uniform_rsrc): SGPR base + lane * 16 + an SGPR offset that walks the image.
 typedef __amdgpu_buffer_rsrc_t wrsrc_t;
-__device__ __forceinline__ wrsrc_t wrsrc(const void* base) {
-    // the image pointers come out of the DevWeights block through vector loads: without the readfirstlane pair the compiler keeps the
-    // descriptor in VGPRs and wraps every load in a waterfall loop
-    const unsigned long long v = (unsigned long long)(uintptr_t)base;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
-}
+__device__ __forceinline__ wrsrc_t wrsrc(const void* base) { return uniform_rsrc(base); }
 __device__ __forceinline__ f4 wload4(wrsrc_t r, int lane_bytes, int wave_bytes) {
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, wave_bytes, 0));
 }
