@@ -164,9 +164,9 @@ hipError_t launch_randn_fill(float* out_btc, int B, int JF, const CallParams* ca
 hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipStream_t st, int T = kT);
 
 // ---- SAG decoder kernels (ls_sag.hip) ----------------------------------------------------------
-hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bmap, const float* pe, float* q, int B,
+hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bmap, const float* pe, float* q, float* qc, int B,
                               int JF, int n_pre, int D, hipStream_t st);
-hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, int D, hipStream_t st);
+hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, int D, int n_pre_c, hipStream_t st);
 // y = LayerNorm(x (+ bc[row / T], rows of bc bc_stride floats apart))
 hipError_t launch_layernorm512(const float* x, const float* bc, int bc_stride, const float* w, const float* beta, float* y, int rows,
                                hipStream_t st);

@@ -12,8 +12,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 // rows r = b*T + f;  q[r][d] = b_map[d] + [f < n_pre] (W_map[d][:JF] . x[b,:,f] + W_map[d][JF]) + pe[f][d]
 // (motionclip_module.py:155-168: pre_cond is zero beyond the prefix poses, so mapping() leaves just its bias there)
+// qc (optional): the DISTINCT query rows only -- [B * n_pre] prefix rows (b, f < n_pre), then the T - n_pre rows f >= n_pre, which are
+// the same for every sample (b_map + pe[f]): the first layer's packed in_proj runs over these rows instead of all B * T.
 __global__ void k_sag_queries(const float* __restrict__ x, const float* __restrict__ wmap, const float* __restrict__ bmap,
-                              const float* __restrict__ pe, float* __restrict__ q, int JF, int n_pre, int D) {
+                              const float* __restrict__ pe, float* __restrict__ q, float* __restrict__ qc, int JF, int n_pre, int D) {
     extern __shared__ float sx[];
     const int r = blockIdx.x, b = r / kT, f = r % kT;
     if (f < n_pre)
@@ -26,7 +28,12 @@ __global__ void k_sag_queries(const float* __restrict__ x, const float* __restri
             for (int c = 0; c < JF; ++c) v = fmaf(w[c], sx[c], v);
             v += w[JF];
         }
-        q[(size_t)r * D + d] = v + pe[(size_t)f * D + d];
+        v += pe[(size_t)f * D + d];
+        q[(size_t)r * D + d] = v;
+        if (qc) {
+            if (f < n_pre) qc[((size_t)b * n_pre + f) * D + d] = v;
+            else if (b == 0) qc[((size_t)gridDim.x / kT * n_pre + (f - n_pre)) * D + d] = v;
+        }
     }
 }
 
@@ -42,7 +49,9 @@ __global__ void k_sag_queries(const float* __restrict__ x, const float* __restri
 //   softmax        : one wave per query row, lane = key; row max and row sum are wavefront reductions (DPP / readlane)
 //   out = P V      : 3 x (HD/16) tiles, K-dim = 36 keys (P's columns 34, 35 are written as zero)
 template <int HD>
-__global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__ qkv, float* __restrict__ out, int D, int heads) {
+// n_pre_c > 0: qkv holds the distinct rows only (k_sag_queries' qc order): sample b's frame t lives at row b * n_pre_c + t for
+// t < n_pre_c and at the shared row B * n_pre_c + (t - n_pre_c) otherwise.
+__global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__ qkv, float* __restrict__ out, int D, int heads, int n_pre_c) {
     constexpr int LQ = HD + 4, LP = 37, KP = 36;
     __shared__ __attribute__((aligned(16))) float sq[kT * LQ], sk[kT * LQ], sv[kT * LQ];
     __shared__ float sp[kT * LP];
@@ -57,7 +66,8 @@ __global__ __launch_bounds__(256) void k_sag_attention(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int idx = min(tid + 256 * j, kF4 - 1), t = idx / (HD / 4), d4 = idx % (HD / 4);
-            const float* row = qkv + (size_t)(b * kT + t) * 3 * D + h * HD + 4 * d4;
+            const int rr = n_pre_c <= 0 ? b * kT + t : (t < n_pre_c ? b * n_pre_c + t : (int)gridDim.x * n_pre_c + (t - n_pre_c));
+            const float* row = qkv + (size_t)rr * 3 * D + h * HD + 4 * d4;
             vq[j] = *reinterpret_cast<const f4*>(row);
             vk[j] = *reinterpret_cast<const f4*>(row + D);
             vv[j] = *reinterpret_cast<const f4*>(row + 2 * D);
@@ -216,14 +226,14 @@ __global__ __launch_bounds__(256) void k_sag_final(const float* __restrict__ xh,
     }
 }
 
-hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bmap, const float* pe, float* q, int B,
+hipError_t launch_sag_queries(const float* x, const float* wmap, const float* bmap, const float* pe, float* q, float* qc, int B,
                               int JF, int n_pre, int D, hipStream_t st) {
-    hipLaunchKernelGGL(k_sag_queries, dim3(B * kT), dim3(256), JF * sizeof(float), st, x, wmap, bmap, pe, q, JF, n_pre, D);
+    hipLaunchKernelGGL(k_sag_queries, dim3(B * kT), dim3(256), JF * sizeof(float), st, x, wmap, bmap, pe, q, qc, JF, n_pre, D);
     return hipGetLastError();
 }
-hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, int D, hipStream_t st) {
+hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, int D, int n_pre_c, hipStream_t st) {
     if (D / heads != 128) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_sag_attention<128>), dim3(B), dim3(256), 0, st, qkv, out, D, heads);
+    hipLaunchKernelGGL((k_sag_attention<128>), dim3(B), dim3(256), 0, st, qkv, out, D, heads, n_pre_c);
     return hipGetLastError();
 }
 hipError_t launch_layernorm512(const float* x, const float* bc, int bc_stride, const float* w, const float* beta, float* y, int rows,

@@ -38,7 +38,7 @@ struct ls_sag {
     std::map<std::string, std::vector<float>> w;
     std::map<std::string, Buf> dw;      // device copies under the same keys
     bool committed = false;
-    Buf pe, xin, zin, mask, q, qkv, attn, t1, x1, ca, x2, hid, t3, out;
+    Buf pe, xin, zin, mask, q, qc, qkv, attn, t1, x1, ca, x2, hid, t3, out;
     Buf wcross, bcross;      // cross-attention of ALL layers as one [L*D][D] matrix (see ls_sag_commit_weights)
     hipEvent_t ev[2] = {nullptr, nullptr};
     float last_ms = 0.f;
@@ -108,7 +108,7 @@ void ls_sag_destroy(ls_sag* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->dw) kv.second.release();
-    Buf* all[] = {&h->pe, &h->xin, &h->zin, &h->mask, &h->q, &h->qkv, &h->attn, &h->t1, &h->x1, &h->ca, &h->x2, &h->hid, &h->t3, &h->out,
+    Buf* all[] = {&h->pe, &h->xin, &h->zin, &h->mask, &h->q, &h->qc, &h->qkv, &h->attn, &h->t1, &h->x1, &h->ca, &h->x2, &h->hid, &h->t3, &h->out,
                   &h->wcross, &h->bcross};
     for (Buf* b : all) b->release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -213,7 +213,7 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
         dmask = static_cast<const unsigned char*>(h->mask.p);
     }
     const size_t nm = (size_t)M * D * sizeof(float);
-    SCHK(h, h->q.ensure(nm)); SCHK(h, h->qkv.ensure(3 * nm)); SCHK(h, h->attn.ensure(nm)); SCHK(h, h->t1.ensure(nm));
+    SCHK(h, h->q.ensure(nm)); SCHK(h, h->qkv.ensure(3 * (nm + (size_t)128 * D * sizeof(float))));     /* + the compact first layer's tile padding */ SCHK(h, h->attn.ensure(nm)); SCHK(h, h->t1.ensure(nm));
     SCHK(h, h->x1.ensure(nm)); SCHK(h, h->x2.ensure(nm)); SCHK(h, h->t3.ensure(nm));
     SCHK(h, h->hid.ensure((size_t)M * FF * sizeof(float)));
     const int LD = h->cfg.num_layers * D;
@@ -222,15 +222,28 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
     SCHK(h, hipEventRecord(h->ev[0], st));
     // cross-attention terms of all layers: ca[b][l*D + i] = (W_out_l W_v_l) z_b + (W_out_l b_v_l + b_out_l)
     SCHK(h, launch_gemm_nt(h->zin.f(), D, h->wcross.f(), D, h->bcross.f(), nullptr, 0, h->ca.f(), LD, B, LD, D, 0, st));
-    SCHK(h, launch_sag_queries(h->xin.f(), W("mapping.weight"), W("mapping.bias"), h->pe.f(), h->q.f(), B, JF, h->cfg.n_pre_poses, D, st));
+    // First layer: the query rows of frames f >= n_pre are b_map + pe[f] for EVERY sample, so their q / k / v projections are too.  Its
+    // packed in_proj runs over the distinct rows only (B * n_pre + T - n_pre instead of B * T: 12 % of them at T = 34, n_pre = 4),
+    // padded to whole 128-row tiles so that it stays on the GEMM's full-tile path; the attention kernel maps (sample, frame) to them.
+    const int npre = h->cfg.n_pre_poses;
+    const bool compact = npre > 0 && npre < kT;
+    const int Mc = compact ? (B * npre + (kT - npre) + 127) / 128 * 128 : 0;
+    if (compact) {
+        const void* old = h->qc.p;
+        SCHK(h, h->qc.ensure((size_t)Mc * D * sizeof(float)));
+        if (old != h->qc.p) SCHK(h, hipMemsetAsync(h->qc.p, 0, (size_t)Mc * D * sizeof(float), st));       // pad rows: finite inputs
+    }
+    SCHK(h, launch_sag_queries(h->xin.f(), W("mapping.weight"), W("mapping.bias"), h->pe.f(), h->q.f(), compact ? h->qc.f() : nullptr, B, JF, npre, D, st));
     float* xcur = h->q.f();
     char pre[96];
     for (int l = 0; l < h->cfg.num_layers; ++l) {
         snprintf(pre, sizeof pre, "seqTransDecoder.layers.%d.", l);
         const std::string P(pre);
         // self-attention block: x = norm1(x + out_proj(softmax(q k^T / sqrt(128)) v))
-        SCHK(h, launch_gemm_nt(xcur, D, W(P + "self_attn.in_proj_weight"), D, W(P + "self_attn.in_proj_bias"), nullptr, 0, h->qkv.f(), 3 * D, M, 3 * D, D, 0, st));
-        SCHK(h, launch_sag_attention(h->qkv.f(), h->attn.f(), B, H, D, st));
+        const bool lc = compact && l == 0;
+        SCHK(h, launch_gemm_nt(lc ? h->qc.f() : xcur, D, W(P + "self_attn.in_proj_weight"), D, W(P + "self_attn.in_proj_bias"), nullptr, 0, h->qkv.f(), 3 * D,
+                               lc ? Mc : M, 3 * D, D, 0, st));
+        SCHK(h, launch_sag_attention(h->qkv.f(), h->attn.f(), B, H, D, lc ? npre : 0, st));
         SCHK(h, launch_gemm_nt(h->attn.f(), D, W(P + "self_attn.out_proj.weight"), D, W(P + "self_attn.out_proj.bias"), xcur, D, h->t1.f(), D, M, D, D, 0, st));
         SCHK(h, launch_layernorm512(h->t1.f(), nullptr, 0, W(P + "norm1.weight"), W(P + "norm1.bias"), h->x1.f(), M, st));
         // cross-attention block: x = norm2(x + ca_l[b])  (the per-sample vector computed above)

@@ -190,12 +190,13 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < NRG; ++r) racc4[c2][r] = (f4){0.f, 0.f, 0.f, 0.f};
             }
-            gf4p wp = g4(a.wchT_img) + ((size_t)((l * kWaves + w) * 2 + p) * 32) * 2 * 64 + lane;
+            const wrsrc_t wrs = wrsrc(a.wchT_img);                        // buffer-descriptor loads, as in k_step (ls_lanes.h: uniform_rsrc)
+            const int wsb = (((l * kWaves + w) * 2 + p) * 32) * 2 * 1024;
             const float* ub = U + s16 * kUStride + 4 * g;
             const float* ur = U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g;
             f4 An[2];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[c2 * 64];
+            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + c2 * 1024);
 #pragma unroll 2
             for (int q = 0; q < 32; ++q) {
                 f4 A[2], Bv[kFullTiles], Ur[kRemMfma ? NRG : NRV];
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                 {
                     const int qn = (q + 1 < 32) ? q + 1 : 31;
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wp[(qn * 2 + c2) * 64];
+                    for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + (qn * 2 + c2) * 1024);
                 }
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t) Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         const float* X1 = a.x1 + (size_t)l * LR * kD;
         const float* S1 = a.s1 + (size_t)l * LR * 2;
         {
-            gfp wwp = g1(a.wwT_img) + (size_t)l * kNT * MK * 64 + lane;
+            const wrsrc_t wws = wrsrc(a.wwT_img);
+            const int wwb = l * kNT * MK * 256;
             const float* up = U + 64 * w + s16;
             f4 pa[kCB], pb[kCB];
 #pragma unroll
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                 float Bt[MK];
 #pragma unroll
                 for (int m = 0; m < MK; ++m)
-                    if (tokmix_needed(S, t, m)) Bt[m] = wwp[(t * MK + m) * 64];
+                    if (tokmix_needed(S, t, m)) Bt[m] = wload1(wws, lane * 4, wwb + (t * MK + m) * 256);
                 // what the LayerNorm backward of this tile needs: issued before the tile's MFMAs, pinned there
                 const f2 st1 = *reinterpret_cast<const f2*>(S1 + (size_t)growc_of(t) * 2);
                 f4 xs[kCB], al1[kCB];
