@@ -175,23 +175,123 @@ __global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    // lane (m = s16 of m tile j, g) holds n = n0 + wn*64 + 16*i + 4*g + {0..3}
+    const bool partial = a.splits > 1;
+    float* Cz = partial ? a.ws + (size_t)bz * a.M * a.N : nullptr;
+    const bool cvec = a.cns == 1 && (a.crs & 3) == 0 && (a.cri == INT_MAX || (a.cro & 3) == 0) && ((uintptr_t)a.C & 15) == 0 &&
+                      (!a.Cpre || ((uintptr_t)a.Cpre & 15) == 0) && (!a.R || ((uintptr_t)a.R & 15) == 0) &&
+                      (!a.bias || ((uintptr_t)a.bias & 15) == 0);
+    // Full tile with float4-legal output (`fastout`): the bias and every residual / accumulate operand are fetched by fetch_addends()
+    // BEFORE the first store -- interleaved as load -> add -> store per element the compiler must keep each load behind the previous
+    // store, one L2 round trip after the other, 4 * MT in a row at the end of every workgroup.  The DMA loop calls it ahead of its last
+    // K tile, so the operands land under that tile's MFMAs.
+    const bool fastout = FAST && cvec && !partial;
+    f4 biasv[4], rv[4][MT];
+    auto fetch_addends = [&](int m0, int n0) {
+        if (!fastout) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) biasv[i] = a.bias ? *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+        if (a.R || a.accumulate) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const size_t co = lvl(m0 + wm * 16 * MT + 16 * j + s16, a.cri, a.cro, a.crs) + n0 + wn * 64 + 4 * g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rv[i][j] = a.R ? *reinterpret_cast<const f4*>(a.R + co + 16 * i) : (f4){0.f, 0.f, 0.f, 0.f};
+                    if (a.accumulate) rv[i][j] += *reinterpret_cast<const f4*>(a.C + co + 16 * i);
+                }
+            }
+        }
+    };
+    auto epilogue = [&](int m0, int n0) {
+        if (fastout) {
+            size_t co[MT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) co[j] = lvl(m0 + wm * 16 * MT + 16 * j + s16, a.cri, a.cro, a.crs) + n0 + wn * 64 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f4 v = acc[i][j] + biasv[i];
+                    if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co[j] + 16 * i) = v;
+                    if (a.act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gemm_act(v[e], a.act);
+                    }
+                    if (a.R || a.accumulate) v += rv[i][j];
+                    *reinterpret_cast<f4*>(a.C + co[j] + 16 * i) = v;
+                }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m0 + wm * 16 * MT + 16 * j + s16;
+            if (!FAST && m >= a.M) continue;
+            const size_t crow = partial ? (size_t)m * a.N : lvl(m, a.cri, a.cro, a.crs);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + 16 * i + 4 * g;
+                if (!FAST && n >= a.N) continue;
+                f4 v = acc[i][j];
+                if (partial) {
+                    if ((a.N & 3) == 0) *reinterpret_cast<f4*>(&Cz[crow + n]) = v;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (n + e < a.N) Cz[crow + n + e] = v[e];
+                    }
+                    continue;
+                }
+                if (cvec && (FAST || n + 3 < a.N)) {
+                    const size_t co = crow + n;
+                    if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
+                    if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co) = v;
+                    if (a.act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gemm_act(v[e], a.act);
+                    }
+                    if (a.R) v += *reinterpret_cast<const f4*>(a.R + co);
+                    if (a.accumulate) v += *reinterpret_cast<const f4*>(a.C + co);
+                    *reinterpret_cast<f4*>(a.C + co) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= a.N) continue;
+                        float x = v[e];
+                        if (a.bias) x += a.bias[n + e];
+                        const size_t co = crow + (size_t)(n + e) * a.cns;
+                        if (a.Cpre) a.Cpre[co] = x;
+                        x = gemm_act(x, a.act);
+                        if (a.R) x += a.R[co];
+                        if (a.accumulate) x += a.C[co];
+                        a.C[co] = x;
+                    }
+                }
+            }
+        }
+    };
+
     if constexpr (DMA) {
         const auto rsA = uniform_rsrc(a.A.p), rsB = uniform_rsrc(a.B.p);
         // wave wv stages blocks wv*MT + i of A and wv*4 + i of B (8 rows each); lane = (row in block, position in row)
         const int rl = lane >> 3, ch = (lane & 7) ^ rl;             // this lane's position holds chunk ch of its row
+        // fragment (row, k half kk): chunk 4 kk + g of the row, stored at position (4 kk + g) ^ (row & 7); row & 7 = s16 & 7 for every tile
+        const int o0 = ((g ^ (s16 & 7)) * 4), o1 = o0 ^ 16;
+        const int fa = (wm * 16 * MT + s16) * kTK, fb = (wn * 64 + s16) * kTK;
         int voA[MT], voB[4];
 #pragma unroll
         for (int i = 0; i < MT; ++i) voA[i] = (int)(((long long)(m0 + (wv * MT + i) * 8 + rl) * a.A.rs + ch * 4) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) voB[i] = (int)(((long long)(n0 + (wv * 4 + i) * 8 + rl) * a.B.rs + ch * 4) * 4);
-        // fragment (row, k half kk): chunk 4 kk + g of the row, stored at position (4 kk + g) ^ (row & 7); row & 7 = s16 & 7 for every tile
-        const int o0 = ((g ^ (s16 & 7)) * 4), o1 = o0 ^ 16;
-        const int fa = (wm * 16 * MT + s16) * kTK, fb = (wn * 64 + s16) * kTK;
         gemm_dma_issue<MT>(rsA, rsB, sA, sB, wv, voA, voB, kbeg);
         __syncthreads();                                    // carries the vmcnt(0) of the DMA above
         int buf = 0;
+        // (A persistent form -- one workgroup per resident slot walking tiles blockIdx.x, + gridDim.x, ..., the next output tile's first K
+        // tile requested ahead of the current one's last -- measured SLOWER, 229 -> 265 us at 17408 x 1536 x 512: with 4.25 tiles per slot
+        // the static walk ends 5 : 4 unbalanced, which costs more than the hidden first fetch gains.)
         for (int k0 = kbeg; k0 < kend; k0 += kTK) {
-            if (k0 + kTK < kend) gemm_dma_issue<MT>(rsA, rsB, sA + (buf ^ 1) * BM * kTK, sB + (buf ^ 1) * kTM * kTK, wv, voA, voB, k0 + kTK);    // lands while this tile is multiplied; its buffer was last read before the previous barrier
+            // the other buffer was last read before the previous barrier: the next K tile lands in it while this one is multiplied
+            if (k0 + kTK >= kend) fetch_addends(m0, n0);
+            if (k0 + kTK < kend) gemm_dma_issue<MT>(rsA, rsB, sA + (buf ^ 1) * BM * kTK, sB + (buf ^ 1) * kTM * kTK, wv, voA, voB, k0 + kTK);
             const float* cA = sA + buf * BM * kTK + fa;
             const float* cB = sB + buf * kTM * kTK + fb;
             f4 af[2][MT], bf[2];
@@ -289,63 +389,8 @@ __global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
         }
     }
     }
-    // lane (m = s16 of m tile j, g) holds n = n0 + wn*64 + 16*i + 4*g + {0..3}
-    const bool partial = a.splits > 1;
-    float* Cz = partial ? a.ws + (size_t)bz * a.M * a.N : nullptr;
-    const bool cvec = a.cns == 1 && (a.crs & 3) == 0 && (a.cri == INT_MAX || (a.cro & 3) == 0) && ((uintptr_t)a.C & 15) == 0 &&
-                      (!a.Cpre || ((uintptr_t)a.Cpre & 15) == 0) && (!a.R || ((uintptr_t)a.R & 15) == 0) &&
-                      (!a.bias || ((uintptr_t)a.bias & 15) == 0);
-    // FAST tiles are full: no bounds tests (each one is a branch that also serialises the loads behind it), bias fetched once
-    f4 biasv[4];
-    if (FAST && a.bias && !partial) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) biasv[i] = *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g);
-    }
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wm * 16 * MT + 16 * j + s16;
-        if (!FAST && m >= a.M) continue;
-        const size_t crow = partial ? (size_t)m * a.N : lvl(m, a.cri, a.cro, a.crs);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + 16 * i + 4 * g;
-            if (!FAST && n >= a.N) continue;
-            f4 v = acc[i][j];
-            if (partial) {
-                if ((a.N & 3) == 0) *reinterpret_cast<f4*>(&Cz[crow + n]) = v;
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < a.N) Cz[crow + n + e] = v[e];
-                }
-                continue;
-            }
-            if (cvec && (FAST || n + 3 < a.N)) {
-                const size_t co = crow + n;
-                if (a.bias) v += FAST ? biasv[i] : *reinterpret_cast<const f4*>(a.bias + n);
-                if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co) = v;
-                if (a.act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gemm_act(v[e], a.act);
-                }
-                if (a.R) v += *reinterpret_cast<const f4*>(a.R + co);
-                if (a.accumulate) v += *reinterpret_cast<const f4*>(a.C + co);
-                *reinterpret_cast<f4*>(a.C + co) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e >= a.N) continue;
-                    float x = v[e];
-                    if (a.bias) x += a.bias[n + e];
-                    const size_t co = crow + (size_t)(n + e) * a.cns;
-                    if (a.Cpre) a.Cpre[co] = x;
-                    x = gemm_act(x, a.act);
-                    if (a.R) x += a.R[co];
-                    if (a.accumulate) x += a.C[co];
-                    a.C[co] = x;
-                }
-            }
-        }
-    }
+    if (!DMA) fetch_addends(m0, n0);
+    epilogue(m0, n0);
 }
 
 // C[m][n] (+)= sum_z ws[z][m][n] (+ bias); fixed summation order
