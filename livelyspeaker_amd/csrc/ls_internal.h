@@ -170,6 +170,8 @@ hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, 
 // y = LayerNorm(x (+ bc[row / T], rows of bc bc_stride floats apart))
 hipError_t launch_layernorm512(const float* x, const float* bc, int bc_stride, const float* w, const float* beta, float* y, int rows,
                                hipStream_t st);
+hipError_t launch_layernorm512x2(const float* x, const float* w1, const float* b1, const float* bc, int bc_stride, const float* w2,
+                                 const float* b2, float* y, int rows, hipStream_t st);
 hipError_t launch_sag_final(const float* xh, const float* wf, const float* bf, const unsigned char* mask, float* out, int B,
                             int JF, int D, hipStream_t st);
 

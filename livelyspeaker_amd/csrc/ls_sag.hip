@@ -169,6 +169,42 @@ __global__ __launch_bounds__(256) void k_layernorm512(const float* __restrict__ 
     yr[lane + 64] = (v1 - mean) * rstd * wr[lane + 64] + be[lane + 64];
 }
 
+// y = LN2( LN1(x) + bc[b] ): norm1 and norm2 of a decoder layer in one pass over the rows -- between them the layer only adds its
+// cross-attention vector (one memory token: a per-sample constant, ls_sag_api.cpp), so the intermediate never has to leave registers.
+// Same arithmetic, in the same order, as two k_layernorm512 launches.
+__global__ __launch_bounds__(256) void k_layernorm512x2(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ bc, int bc_stride, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float* __restrict__ y, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const f4* xr = reinterpret_cast<const f4*>(x + (size_t)r * kD);
+    const f4* br = reinterpret_cast<const f4*>(bc + (size_t)(r / kT) * bc_stride);
+    f4 v0 = xr[lane], v1 = xr[lane + 64];
+    const f4 c0 = br[lane], c1 = br[lane + 64];
+    const f4 *pw1 = reinterpret_cast<const f4*>(w1), *pb1 = reinterpret_cast<const f4*>(b1), *pw2 = reinterpret_cast<const f4*>(w2), *pb2 = reinterpret_cast<const f4*>(b2);
+    const f4 g10 = pw1[lane], g11 = pw1[lane + 64], e10 = pb1[lane], e11 = pb1[lane + 64];
+    const f4 g20 = pw2[lane], g21 = pw2[lane + 64], e20 = pb2[lane], e21 = pb2[lane + 64];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float s = (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+        const float mean = wave_sum(s) * (1.0f / kD);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = v0[e] - mean, c = v1[e] - mean; q += a * a + c * c; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kD) + 1e-5f);
+        if (pass == 0) {
+            v0 = ((v0 - mean) * rstd * g10 + e10) + c0;
+            v1 = ((v1 - mean) * rstd * g11 + e11) + c1;
+        } else {
+            v0 = (v0 - mean) * rstd * g20 + e20;
+            v1 = (v1 - mean) * rstd * g21 + e21;
+        }
+    }
+    f4* yr = reinterpret_cast<f4*>(y + (size_t)r * kD);
+    yr[lane] = v0;
+    yr[lane + 64] = v1;
+}
+
 // finallayer + "zero for padded area" + permute to [B, J*F, T] (motionclip_module.py:172-176) on v_mfma_f32_16x16x4_f32.
 // Workgroup = one sample: out[c][f] = sum_d W[c][d] x[f][d] as D[feature tile][frame tile] (NCT x 3 tiles of 16), both operands
 // read straight from global memory in the k-permuted float4 order (lane (row, g) holds d = 16q + 4g .. +3: one float4 = 4 MFMA
@@ -239,6 +275,11 @@ hipError_t launch_sag_attention(const float* qkv, float* out, int B, int heads, 
 hipError_t launch_layernorm512(const float* x, const float* bc, int bc_stride, const float* w, const float* beta, float* y, int rows,
                                hipStream_t st) {
     hipLaunchKernelGGL(k_layernorm512, dim3((rows + 3) / 4), dim3(256), 0, st, x, bc, bc_stride, w, beta, y, rows);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm512x2(const float* x, const float* w1, const float* b1, const float* bc, int bc_stride, const float* w2,
+                                 const float* b2, float* y, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_layernorm512x2, dim3((rows + 3) / 4), dim3(256), 0, st, x, w1, b1, bc, bc_stride, w2, b2, y, rows);
     return hipGetLastError();
 }
 hipError_t launch_sag_final(const float* xh, const float* wf, const float* bf, const unsigned char* mask, float* out, int B,

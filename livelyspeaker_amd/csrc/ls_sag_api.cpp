@@ -38,7 +38,7 @@ struct ls_sag {
     std::map<std::string, std::vector<float>> w;
     std::map<std::string, Buf> dw;      // device copies under the same keys
     bool committed = false;
-    Buf pe, xin, zin, mask, q, qc, qkv, attn, t1, x1, ca, x2, hid, t3, out;
+    Buf pe, xin, zin, mask, q, qc, qkv, attn, t1, ca, x2, hid, t3, out;
     Buf wcross, bcross;      // cross-attention of ALL layers as one [L*D][D] matrix (see ls_sag_commit_weights)
     hipEvent_t ev[2] = {nullptr, nullptr};
     float last_ms = 0.f;
@@ -108,7 +108,7 @@ void ls_sag_destroy(ls_sag* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->dw) kv.second.release();
-    Buf* all[] = {&h->pe, &h->xin, &h->zin, &h->mask, &h->q, &h->qc, &h->qkv, &h->attn, &h->t1, &h->x1, &h->ca, &h->x2, &h->hid, &h->t3, &h->out,
+    Buf* all[] = {&h->pe, &h->xin, &h->zin, &h->mask, &h->q, &h->qc, &h->qkv, &h->attn, &h->t1, &h->ca, &h->x2, &h->hid, &h->t3, &h->out,
                   &h->wcross, &h->bcross};
     for (Buf* b : all) b->release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -214,7 +214,7 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
     }
     const size_t nm = (size_t)M * D * sizeof(float);
     SCHK(h, h->q.ensure(nm)); SCHK(h, h->qkv.ensure(3 * (nm + (size_t)128 * D * sizeof(float))));     /* + the compact first layer's tile padding */ SCHK(h, h->attn.ensure(nm)); SCHK(h, h->t1.ensure(nm));
-    SCHK(h, h->x1.ensure(nm)); SCHK(h, h->x2.ensure(nm)); SCHK(h, h->t3.ensure(nm));
+    SCHK(h, h->x2.ensure(nm)); SCHK(h, h->t3.ensure(nm));
     SCHK(h, h->hid.ensure((size_t)M * FF * sizeof(float)));
     const int LD = h->cfg.num_layers * D;
     SCHK(h, h->ca.ensure((size_t)B * LD * sizeof(float)));
@@ -245,9 +245,9 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
                                lc ? Mc : M, 3 * D, D, 0, st));
         SCHK(h, launch_sag_attention(h->qkv.f(), h->attn.f(), B, H, D, lc ? npre : 0, st));
         SCHK(h, launch_gemm_nt(h->attn.f(), D, W(P + "self_attn.out_proj.weight"), D, W(P + "self_attn.out_proj.bias"), xcur, D, h->t1.f(), D, M, D, D, 0, st));
-        SCHK(h, launch_layernorm512(h->t1.f(), nullptr, 0, W(P + "norm1.weight"), W(P + "norm1.bias"), h->x1.f(), M, st));
-        // cross-attention block: x = norm2(x + ca_l[b])  (the per-sample vector computed above)
-        SCHK(h, launch_layernorm512(h->x1.f(), h->ca.f() + (size_t)l * D, LD, W(P + "norm2.weight"), W(P + "norm2.bias"), h->x2.f(), M, st));
+        // ... norm1, then the cross-attention block x = norm2(x + ca_l[b]) (the per-sample vector computed above), in one pass
+        SCHK(h, launch_layernorm512x2(h->t1.f(), W(P + "norm1.weight"), W(P + "norm1.bias"), h->ca.f() + (size_t)l * D, LD, W(P + "norm2.weight"),
+                                      W(P + "norm2.bias"), h->x2.f(), M, st));
         // feed-forward: x = norm3(x + linear2(gelu(linear1(x))))
         SCHK(h, launch_gemm_nt(h->x2.f(), D, W(P + "linear1.weight"), D, W(P + "linear1.bias"), nullptr, 0, h->hid.f(), FF, M, FF, D, 3, st));
         SCHK(h, launch_gemm_nt(h->hid.f(), FF, W(P + "linear2.weight"), FF, W(P + "linear2.bias"), h->x2.f(), D, h->t3.f(), D, M, D, FF, 0, st));
