@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Assemble profiles/<name>.md from what tools/round_measure.sh left under gpurun_out/<dir>/ (bench lines, kernel trace, PMC passes).
+
+    python tools/round_report.py gpurun_out/r02d profiles/r02d_final_measurements.md "Round 2, run D (final build of the round)"
+"""
+import json, os, sys
+
+src, dst, title = sys.argv[1], sys.argv[2], sys.argv[3]
+RUNS = [
+    ("bench_default", "(defaults: TED, B=512, 1000-step DDPM, CFG 1.5)"),
+    ("bench_strong_n1", "`torch.distributed.run --nproc-per-node 1 ... --gpus 1 --global-batch 512` (strong-scaling path, RCCL group of 1)"),
+    ("bench_scale1", "`--scale 1.0` (single pass)"),
+    ("bench_ddim100_full", "`--respacing ddim100` (configs[2] as worded: 100 DDIM steps)"),
+    ("bench_config1_shape", "`--batch 4 --diffusion-steps 50` (configs[0] shape)"),
+    ("bench_beat256", "`--dataset beat --batch 256` (configs[4] at 34 frames, the whole job on one GPU)"),
+    ("bench_beat150_b32", "`--dataset beat150 --batch 32` (configs[4] as worded, per-GPU share of 256/8; synthetic)"),
+    ("bench_beat150_b256", "`--dataset beat150 --batch 256 --diffusion-steps 200` (synthetic)"),
+]
+
+
+def load(name):
+    try:
+        return json.loads(open(os.path.join(src, name + ".json")).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+def cat(path):
+    p = os.path.join(src, path)
+    return open(p).read().rstrip() if os.path.exists(p) else f"(missing: {path})"
+
+
+out = [f"# {title}: bench lines, kernel traces and PMC passes on MI355X", ""]
+tail = cat("pytest_gpu.log").splitlines()[-1] if os.path.exists(os.path.join(src, "pytest_gpu.log")) else "?"
+out += [f"All from ONE `gpurun` call (`tools/round_measure.sh {os.path.basename(src)}`, same box, same build): `pytest -m gpu` ({tail}), the bench lines below, a",
+        "rocprofv3 kernel trace of the headline command, and kernel-trace + PMC passes (one counter per run, `--pmc X --kernel-trace` only) of the",
+        "LivelySpeaker example and the synthetic 150-frame variant.  Assembled by `tools/round_report.py`.", "",
+        "## bench.py lines (value = pose-frames/s; kernel_ms = mean step time from HIP events on the engine's stream)", "",
+        "| run | command (after `python bench.py`) | value | ms per call | kernel_ms | roofline frac | traffic B/launch | parity_in_run max\\|d\\| |", "|---|---|---|---|---|---|---|---|"]
+for name, cmd in RUNS:
+    r = load(name)
+    if not r:
+        out.append(f"| {name} | {cmd} | (missing) | | | | | |")
+        continue
+    rf = r["roofline"]
+    out.append(f"| {name} | {cmd} | {r['value']:.1f} | {r['ms_per_step']:.2f} | {rf.get('kernel_ms')} | {rf.get('frac')} | {rf.get('traffic')} | "
+               f"{(r.get('parity_in_run') or {}).get('max_abs_diff')} |")
+d = load("bench_default")
+if d:
+    out += ["", "Secondary objects of the default line:", ""]
+    for k in ("single_pass", "livelyspeaker", "configs4_beat", "split_precision", "train_step", "cpu_baseline", "shard_check", "parity_in_run"):
+        if k in d:
+            out.append(f"* `{k}`: `{json.dumps(d[k])}`")
+    out += ["", "The default line in full:", "", "```", json.dumps(d), "```"]
+out += ["", "## Kernel trace of the headline command (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 ...`)", "", cat("kt_bench.md"), "",
+        "### per (kernel, grid)", "", cat("kt_dispatch.md"), "",
+        "## LivelySpeaker example (`examples/livelyspeaker_ted.py 512`): per (kernel, grid) dispatch summary", "", cat("lively/kt.md")]
+for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"):
+    out += ["", f"### PMC {c}", "", cat(f"lively/pmc_{c}.md")]
+out += ["", "## Synthetic 150-frame variant, B=32 (`bench.py --dataset beat150 --batch 32 ... --diffusion-steps 20`): dispatch summary", "", cat("long/kt.md"), ""]
+open(dst, "w").write("\n".join(out))
+print("wrote", dst, len(out), "lines")
