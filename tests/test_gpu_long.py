@@ -25,9 +25,9 @@ def long_ctx():
     eng.close()
 
 
-def test_long_prepare_and_forward_vs_oracle(long_ctx):
+@pytest.mark.parametrize("B", [3, 8])      # 8: 2 * 8 * 152 = 2432 rows = whole 128-row tiles -> the GEMM's LDS-DMA path; 3: its general path
+def test_long_prepare_and_forward_vs_oracle(long_ctx, B):
     cfg, eng, orc, oracle = (long_ctx[k] for k in ("cfg", "eng", "orc", "oracle"))
-    B = 3
     y = synth.make_cond(cfg, B)
     eng.prepare(y)
     prep = oracle.prepare(y)
@@ -36,7 +36,7 @@ def test_long_prepare_and_forward_vs_oracle(long_ctx):
     g = np.random.Generator(np.random.PCG64(5))
     x = g.standard_normal((B, cfg.njoints, cfg.nfeats, cfg.nframes)).astype(np.float32)
     eps = g.standard_normal((2, B, 512)).astype(np.float32)
-    for t in (0, 700):
+    for t in ((0, 700) if B == 3 else (300,)):
         oc, ou, og = eng.forward(x, np.full((B,), t), eps[0], eps[1])
         wc = oracle.forward(x, np.full((B,), t), y, False, eps[0])
         wu = oracle.forward(x, np.full((B,), t), y, True, eps[1])
