@@ -434,8 +434,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         f4 alv[kCB], bev[kCB];                      // LN1 affine: in flight during the statistics and their barrier
 #pragma unroll
         for (int cb = 0; cb < kCB; ++cb) {
-            alv[cb] = *g4(a.W->ln1a + l * kD + chw + 16 * cb);
-            bev[cb] = *g4(a.W->ln1b + l * kD + chw + 16 * cb);
+            alv[cb] = wload4(wrsrc(a.W->ln1a), chw * 4, (l * kD + 16 * cb) * 4);
+            bev[cb] = wload4(wrsrc(a.W->ln1b), chw * 4, (l * kD + 16 * cb) * 4);
         }
         ln_stats(TRAIN ? a.tr_s1 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(2 + 8 * l);
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         if constexpr (TRAIN) {   // training keeps LN2's affine explicit (alpha2 / beta2 get their own gradients)
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) {
-                alv2[cb] = *g4(a.W->ln2a + l * kD + chw + 16 * cb);
-                bev2[cb] = *g4(a.W->ln2b + l * kD + chw + 16 * cb);
+                alv2[cb] = wload4(wrsrc(a.W->ln2a), chw * 4, (l * kD + 16 * cb) * 4);
+                bev2[cb] = wload4(wrsrc(a.W->ln2b), chw * 4, (l * kD + 16 * cb) * 4);
             }
         }
         ln_stats(TRAIN ? a.tr_s2 + (size_t)l * a.tr_B * S * 2 : nullptr);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 f4 acc[2][kNT];
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
-                    const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));
+                    const f4 bc = wload4(wrsrc(a.W->bch), chw * 4, (l * kD + 16 * (2 * p + c2)) * 4);
 #pragma unroll
                     for (int t = 0; t < kNT; ++t) acc[c2][t] = bc;
                 }
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             f4 bcv[2];                                    // Linear bias (+ W.beta of LN2); kept for the ragged rows' epilogue
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
-                const f4 bc = *g4(a.W->bch + l * kD + chw + 16 * (2 * p + c2));
+                const f4 bc = wload4(wrsrc(a.W->bch), chw * 4, (l * kD + 16 * (2 * p + c2)) * 4);
                 bcv[c2] = bc;
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t) acc[c2][t] = bc;
