@@ -3,6 +3,7 @@
 //   kinds: 0 global_load_dwordx4 (per-lane 64-bit address)   1 global_load_dword   2 buffer_load_dwordx4 (SGPR resource + VGPR offset)
 //          3 ds_write_b128   4 ds_write_b32   5 global_load_dwordx4 of ONE address for the whole wave (no fan-out in the TA)
 //          9 buffer_load_dwordx4 ... lds (LDS-DMA)  10 global_load_lds_dwordx4  11-13 the 16-byte LDS store as 2 x b64 / write2_b64 / 2 x write2_b32
+//          14 / 15 v_exp_f32 / v_rcp_f32 x 8 (transcendental unit)  16 v_pk_fma_f32 x 4
 //          6 v_fma_f32 x 8 (VALU)  7 global_store_dwordx4  8 v_lshl_add_u64 (the 64-bit pointer bump hipcc emits per load)
 //   hipcc --offload-arch=gfx950 -O3 -x hip tools/vmem_cost.cpp -o variants/vmem_cost
 #include <hip/hip_runtime.h>
@@ -27,6 +28,9 @@ __global__ __launch_bounds__(256, 3) void k_loop(const float* __restrict__ src, 
     const float* gp = src + (size_t)blockIdx.x * 16384 + (KIND == 5 ? wv * 4 : tid * 4);
     float* op = out + 1048576 + (size_t)blockIdx.x * 16384 + tid * 4;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)blockIdx.x * 16384), 0, 0x7fffffff, 0x00020000);
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v pk[NL > 0 ? NL : 1][2], pkc = {1.0001f, 0.5f};
+    for (int i = 0; i < (NL > 0 ? NL : 1); ++i) { pk[i][0] = (f2v){1.f, 2.f}; pk[i][1] = (f2v){3.f, 4.f}; }
     int soff = 0;
     const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sB[wv * 1024]);
     unsigned long long gp64[NL > 0 ? NL : 1], inc64 = 128;
@@ -58,6 +62,18 @@ __global__ __launch_bounds__(256, 3) void k_loop(const float* __restrict__ src, 
             if (KIND == 11) asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" :: "v"(la), "v"(lo2), "v"(hi2));
             if (KIND == 12) asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" :: "v"(la), "v"(lo2), "v"(hi2));
             if (KIND == 13) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3" :: "v"(la), "v"(rg[i][0]), "v"(rg[i][1]), "v"(rg[i][2]), "v"(rg[i][3]));
+            if (KIND == 14) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(rg[i][e & 3]));
+            }
+            if (KIND == 15) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("v_rcp_f32 %0, %0" : "+v"(rg[i][e & 3]));
+            }
+            if (KIND == 16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pk[i][e & 1]) : "v"(pkc));
+            }
             if (KIND == 8) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(gp64[i]) : "v"(inc64));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(256, 3) void k_loop(const float* __restrict__ src, 
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     f4 s = rg[0];
-    for (int i = 0; i < NL; ++i) s[0] += (float)(gp64[i] & 1);
+    for (int i = 0; i < NL; ++i) s[0] += (float)(gp64[i] & 1) + pk[i][0][0] + pk[i][1][1];
     for (int i = 1; i < NL; ++i) s += rg[i];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) s += acc[i][j];
     out[blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3];
@@ -121,6 +137,7 @@ int main() {
     run<9, 6>(src, out, "buffer_load_dwordx4 ... lds"); run<9, 12>(src, out, "buffer_load_dwordx4 ... lds");
     run<10, 6>(src, out, "global_load_lds_dwordx4");
     run<11, 6>(src, out, "2 x ds_write_b64"); run<12, 6>(src, out, "ds_write2_b64"); run<13, 6>(src, out, "2 x ds_write2_b32");
+    run<14, 6>(src, out, "8 x v_exp_f32"); run<15, 6>(src, out, "8 x v_rcp_f32"); run<16, 6>(src, out, "4 x v_pk_fma_f32");
     run<8, 6>(src, out, "v_lshl_add_u64"); run<8, 12>(src, out, "v_lshl_add_u64");
     return 0;
 }
