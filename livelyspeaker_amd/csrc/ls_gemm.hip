@@ -147,7 +147,7 @@ __device__ __forceinline__ void gemm_dma_issue(__amdgpu_buffer_rsrc_t rsA, __amd
 }
 
 template <bool AK, bool BK, bool FAST, int MT = 4, bool DMA = false>
-__global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
+__global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     static_assert(MT == 4 || (MT == 2 && AK && FAST), "64-row tiles: K-contiguous A on the fast path only");
     static_assert(!DMA || (AK && BK && FAST), "LDS-DMA staging: both operands K-contiguous, full tiles");
     constexpr int BM = 32 * MT;
@@ -185,10 +185,12 @@ __global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
     // BEFORE the first store -- interleaved as load -> add -> store per element the compiler must keep each load behind the previous
     // store, one L2 round trip after the other, 4 * MT in a row at the end of every workgroup.  The DMA loop calls it ahead of its last
     // K tile, so the operands land under that tile's MFMAs.
+    // The register-staged variants (128-row tiles: 64 accumulator registers) fetch them one 16-row tile at a time inside the epilogue
+    // instead -- all 4 * MT float4 at once would double their register footprint and cost a wave of occupancy.
     const bool fastout = FAST && cvec && !partial;
-    f4 biasv[4], rv[4][MT];
+    f4 biasv[4], rv[4][DMA ? MT : 1];
     auto fetch_addends = [&](int m0, int n0) {
-        if (!fastout) return;
+        if (!DMA || !fastout) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) biasv[i] = a.bias ? *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
         if (a.R || a.accumulate) {
@@ -208,8 +210,19 @@ __global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
             size_t co[MT];
 #pragma unroll
             for (int j = 0; j < MT; ++j) co[j] = lvl(m0 + wm * 16 * MT + 16 * j + s16, a.cri, a.cro, a.crs) + n0 + wn * 64 + 4 * g;
+            if (!DMA) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
+                for (int i = 0; i < 4; ++i) biasv[i] = a.bias ? *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                if (!DMA && (a.R || a.accumulate)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        rv[i][0] = a.R ? *reinterpret_cast<const f4*>(a.R + co[j] + 16 * i) : (f4){0.f, 0.f, 0.f, 0.f};
+                        if (a.accumulate) rv[i][0] += *reinterpret_cast<const f4*>(a.C + co[j] + 16 * i);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     f4 v = acc[i][j] + biasv[i];
@@ -218,9 +231,10 @@ __global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gemm_act(v[e], a.act);
                     }
-                    if (a.R || a.accumulate) v += rv[i][j];
+                    if (a.R || a.accumulate) v += rv[i][DMA ? j : 0];
                     *reinterpret_cast<f4*>(a.C + co[j] + 16 * i) = v;
                 }
+            }
             return;
         }
 #pragma unroll
@@ -389,7 +403,6 @@ __global__ __launch_bounds__(256, DMA ? 2 : 3) void k_gemm_tr(GemmArgs a) {
         }
     }
     }
-    if (!DMA) fetch_addends(m0, n0);
     epilogue(m0, n0);
 }
 
