@@ -84,7 +84,11 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
     constexpr int kWPre = 3, kWRing = 5;                       // taps in flight; ring size (15 taps per chunk = 3 turns of the ring:
     static_assert(kCvK % kWRing == 0 && kWPre < kWRing, "ring positions must line up across chunks");   // positions repeat per chunk)
     f4 ring[kWRing];
-    const f4* wbase = reinterpret_cast<const f4*>(wimg) + (size_t)(blockIdx.y * 4 + w) * nchunk * kCvK * 64 + lane;
+    // weight image through a buffer descriptor (ls_lanes.h: 3.7 instead of 16.8 matrix-pipe cycles per load): SGPR offset = this wave's
+    // channel tile, + chunk, + tap; VGPR offset = lane * 16
+    const auto wrs = uniform_rsrc(wimg);
+    const int wbase = ((int)blockIdx.y * 4 + w) * nchunk * kCvK * 1024;
+    auto wld = [&](int off) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, off, 0)); };
     __syncthreads();
     int sidx = 0;
     for (int tile = t0; tile < t1; ++tile) {
@@ -96,16 +100,16 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
             const float* sb = sIn[sidx & 1];
             // weight operand: a ring of kWPre taps in flight (one float4 per tap = 16 MFMAs = 512 issue cycles; an L2 round trip under
             // load is longer than that, so a distance of one tap stalled every tap); the ring runs on into the next chunk's image
-            const f4* wp = wbase + (size_t)c * kCvK * 64;
-            const f4* wpn = wbase + (size_t)((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 64;      // next stage's chunk (same tile or the next)
+            const int wp = wbase + c * kCvK * 1024;
+            const int wpn = wbase + ((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 1024;            // next stage's chunk (same tile or the next)
             if (sidx == 0) {
 #pragma unroll
-                for (int k = 0; k < kWPre; ++k) ring[k] = wp[k * 64];
+                for (int k = 0; k < kWPre; ++k) ring[k] = wld(wp + k * 1024);
             }
 #pragma unroll
             for (int k = 0; k < kCvK; ++k) {
                 const f4 A = ring[k % kWRing];
-                ring[(k + kWPre) % kWRing] = (k + kWPre < kCvK) ? wp[(k + kWPre) * 64] : wpn[(k + kWPre - kCvK) * 64];
+                ring[(k + kWPre) % kWRing] = wld((k + kWPre < kCvK) ? wp + (k + kWPre) * 1024 : wpn + (k + kWPre - kCvK) * 1024);
 #pragma unroll
                 for (int cig = 0; cig < 4; ++cig) {
 #pragma unroll
@@ -210,17 +214,19 @@ __global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ 
     __syncthreads();
     constexpr int kWPre = 3, kWRing = 5;                       // weight taps in flight (see k_conv1d_mfma)
     f4 ring[kWRing];
-    const f4* wbase = reinterpret_cast<const f4*>(wimg) + (size_t)(blockIdx.y * 4 + w) * nchunk * kCvK * 64 + lane;
+    const auto wrs = uniform_rsrc(wimg);
+    const int wbase = ((int)blockIdx.y * 4 + w) * nchunk * kCvK * 1024;
+    auto wld = [&](int off) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, off, 0)); };
 #pragma unroll
-    for (int k = 0; k < kWPre; ++k) ring[k] = wbase[k * 64];
+    for (int k = 0; k < kWPre; ++k) ring[k] = wld(wbase + k * 1024);
     for (int c = 0; c < nchunk; ++c) {
         const float* sb = sIn + (c & 1) * bufsz;
-        const f4* wp = wbase + (size_t)c * kCvK * 64;
-        const f4* wpn = wbase + (size_t)((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 64;
+        const int wp = wbase + c * kCvK * 1024;
+        const int wpn = wbase + ((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 1024;
 #pragma unroll
         for (int k = 0; k < kCvK; ++k) {
             const f4 A = ring[k % kWRing];
-            ring[(k + kWPre) % kWRing] = (k + kWPre < kCvK) ? wp[(k + kWPre) * 64] : wpn[(k + kWPre - kCvK) * 64];
+            ring[(k + kWPre) % kWRing] = wld((k + kWPre < kCvK) ? wp + (k + kWPre) * 1024 : wpn + (k + kWPre - kCvK) * 1024);
 #pragma unroll
             for (int cig = 0; cig < 4; ++cig) {
 #pragma unroll
