@@ -565,7 +565,8 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[qt][r] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const f4* wp = reinterpret_cast<const f4*>(wimg) + ((size_t)(blockIdx.y * 2 + cit) * (Cout / 4)) * 4 * 64 + lane;
+    const auto wrs = uniform_rsrc(wimg);                           // weight image through a buffer descriptor (ls_lanes.h)
+    const int wp = (((int)blockIdx.y * 2 + cit) * (Cout / 4)) * 4 * 1024;
     const int bbase = g * kDgDld + 32 * qh + s16 + 2;             // + 4*cogl*Dld*... see below: row = 4*cogl + g
 
     for (int cc = 0; cc < Cout / kDgCo; ++cc) {
@@ -592,10 +593,10 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
         __syncthreads();
 #pragma unroll 2
         for (int cogl = 0; cogl < kDgCo / 4; ++cogl) {
-            const f4* wc = wp + (size_t)(cc * (kDgCo / 4) + cogl) * 4 * 64;
+            const int wc = wp + (cc * (kDgCo / 4) + cogl) * 4 * 1024;
             f4 A[4];
 #pragma unroll
-            for (int pq = 0; pq < 4; ++pq) A[pq] = wc[pq * 64];
+            for (int pq = 0; pq < 4; ++pq) A[pq] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, wc + pq * 1024, 0));
             const float* br = dcs + (4 * cogl) * kDgDld + bbase;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
