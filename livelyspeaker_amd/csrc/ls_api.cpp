@@ -61,9 +61,9 @@ struct ls_handle {
     int JF = 0, S = 0, R = 0, NOB = 0, KXQ = 0, MK = 0, KIN = 0, KF = 0, KFP = 0;      // KFP: KF padded to the GEMM's K tile
     int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
     bool fused = true;
-    int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection, row stride of the output buffer)
+    int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
     DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
-    DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_stats;            // long path: workspaces
+    DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_stats, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -462,7 +462,12 @@ int build_long_weights(ls_handle* h) {
         h->lw_wtp.release();
     }
     UP(lw_wt, wt); UP(lw_bt, bt); UP(lw_wc, wc); UP(lw_bc, bc); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
-    UP(lw_winx, winx); UP(lw_wout, *Wout); UP(bout, *bo);
+    // poseFinal rows padded with zero rows to whole 128-column GEMM tiles: N = 282 would send the product down the general staging
+    // path (41 TFLOP/s at 9728 rows); as 384 columns it is a full-tile LDS-DMA product, the extra columns are never read
+    const int JFN = (JF + 127) / 128 * 128;
+    std::vector<float> woutp((size_t)JFN * D, 0.f);
+    memcpy(woutp.data(), Wout->data(), (size_t)JF * D * sizeof(float));
+    UP(lw_winx, winx); UP(lw_wout, woutp); UP(bout, *bo);
 #undef UP
     return LS_OK;
 }
@@ -504,14 +509,14 @@ hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st)
     if (h->fused) return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
     // long-sequence path: the same step from batch-level kernels (both passes always; exact fp32 only)
     LongStepArgs a{};
-    a.B = B; a.T = h->T; a.S = h->S; a.npre = h->cfg.n_prefix_tokens; a.JF = h->JF; a.JFP = h->JFP; a.ldo = h->JFP; a.layers = h->cfg.layers;
+    a.B = B; a.T = h->T; a.S = h->S; a.npre = h->cfg.n_prefix_tokens; a.JF = h->JF; a.JFP = h->JFP; a.ldo = (h->JF + 127) / 128 * 128; a.layers = h->cfg.layers;
     a.x_in = s.x_in; a.x_out = s.x_out; a.x0_out = s.x0_out; a.fwd_c = s.fwd_c; a.fwd_u = s.fwd_u;
     a.static_c = s.static_c; a.static_u = s.static_u; a.z_mu = s.z_mu; a.z_std = s.z_std; a.emo_tok = s.emo_tok; a.scale = s.scale;
     a.temb = s.temb;
     a.eps_c = s.eps_c; a.eps_u = s.eps_u; a.noise = s.noise; a.const_noise = s.const_noise; a.call = s.call; a.step_id = s.step_id;
     a.winx = h->lw_winx.f(); a.ln1a = h->ln1a.f(); a.ln1b = h->ln1b.f(); a.ln2a = h->ln2a.f(); a.ln2b = h->ln2b.f();
     a.wt = h->lw_wt.f(); a.wtp = h->lw_wtp.f(); a.stats = h->lx_stats.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
-    a.xproj = h->lx_proj.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
+    a.xproj = h->lx_proj.f(); a.xpad = h->lx_xpad.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
     a.sampler = s.sampler; a.t_nonzero = s.t_nonzero; a.clip_denoised = s.clip_denoised;
     a.c0 = s.c0; a.c1 = s.c1; a.c2 = s.c2; a.c3 = s.c3; a.c4 = s.c4;
     return launch_step_long(a, st);
@@ -639,7 +644,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_stats, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -786,14 +791,16 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, h->T));   // y['emo'][:, 0]
     }
     if (!h->fused) {        // workspaces of the long-sequence path: token sequences of both passes, their LayerNorm'd copy, poseFinal output
-        const void* old[4] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p};
+        const void* old[5] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p, h->lx_xpad.p};
         const size_t rows = (size_t)2 * B * h->S;
-        HIPCHK(h, h->lx_proj.ensure((size_t)B * h->T * kD * sizeof(float)));
+        const size_t mpad = ((size_t)B * h->T + 127) / 128 * 128;           // x_t projection on whole 128-row tiles (k_long_padx)
+        HIPCHK(h, h->lx_proj.ensure(mpad * kD * sizeof(float)));
+        HIPCHK(h, h->lx_xpad.ensure(mpad * h->JFP * sizeof(float)));
         HIPCHK(h, h->lx_X.ensure(rows * kD * sizeof(float)));
         HIPCHK(h, h->lx_U.ensure(rows * kD * sizeof(float)));
-        HIPCHK(h, h->lx_OUT.ensure(rows * h->JFP * sizeof(float)));
+        HIPCHK(h, h->lx_OUT.ensure(rows * (size_t)((h->JF + 127) / 128 * 128) * sizeof(float)));
         { const void* os = h->lx_stats.p; HIPCHK(h, h->lx_stats.ensure(rows * 2 * sizeof(float))); if (os != h->lx_stats.p) free_graph(h); }
-        if (old[0] != h->lx_proj.p || old[1] != h->lx_X.p || old[2] != h->lx_U.p || old[3] != h->lx_OUT.p) free_graph(h);
+        if (old[0] != h->lx_proj.p || old[1] != h->lx_X.p || old[2] != h->lx_U.p || old[3] != h->lx_OUT.p || old[4] != h->lx_xpad.p) free_graph(h);
     }
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     HIPCHK(h, hipStreamSynchronize(st));

@@ -24,6 +24,12 @@ namespace ls {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// xpad[r][0..JFP) = x[r][0..JF) | 0 for r < rows, 0 for the pad rows
+__global__ __launch_bounds__(128) void k_long_padx(const float* __restrict__ x, float* __restrict__ xpad, int rows, int JF, int JFP) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < JFP; c += 128) xpad[(size_t)r * JFP + c] = (r < rows && c < JF) ? x[(size_t)r * JF + c] : 0.f;
+}
+
 // X[(p*B + b)*S + s][:] : s = 0 style token (mu + eps * std), s = 1 emotion token (two-prefix variants), else frame t = s - NPRE:
 // xproj[b*T + t] + static_{c|u}[b*T + t].  One 128-thread workgroup per row (one float4 per thread).
 __global__ __launch_bounds__(128) void k_long_assemble(const LongStepArgs a) {
@@ -219,8 +225,12 @@ __global__ __launch_bounds__(256) void k_long_update(const LongStepArgs a) {
 hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     const int rows = 2 * a.B * a.S, D = kD;
     hipError_t e;
-    // x_t columns of input_mapping: xproj[B*T][512] = x_t[B*T][JF] . Win[:, :JF]^T   (K padded with zero columns of the weight)
-    if ((e = launch_gemm_nt(a.x_in, a.JF, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, a.B * a.T, D, a.JF, 0, st)) != hipSuccess) return e;
+    // x_t columns of input_mapping: xproj[B*T][512] = x_t[B*T][JF] . Win[:, :JF]^T.  x_t rows are JF floats (282: not even 16-byte
+    // aligned), which sent this product down the GEMM's general staging path (32 TFLOP/s); k_long_padx copies them into rows of JFP
+    // (zero pad columns, zero pad rows up to a whole 128-row tile) and the product is a full-tile one over K = JFP.
+    const int mpad = (a.B * a.T + 127) / 128 * 128;
+    hipLaunchKernelGGL(k_long_padx, dim3(mpad), dim3(128), 0, st, a.x_in, a.xpad, a.B * a.T, a.JF, a.JFP);
+    if ((e = launch_gemm_nt(a.xpad, a.JFP, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, mpad, D, a.JFP, 0, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a);
     // fused token mixing needs S <= 160 (accumulators for ten token tiles, the operand slab in LDS); longer sequences take the batched-GEMM form
     constexpr int kTokPad = 160;
@@ -247,7 +257,7 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
         if ((e = launch_layernorm512(a.X, nullptr, 0, a.ln2a + (size_t)l * D, a.ln2b + (size_t)l * D, a.U, rows, st)) != hipSuccess) return e;
         if ((e = launch_gemm_nt(a.U, D, a.wc + (size_t)l * D * D, D, a.bc + (size_t)l * D, a.X, D, a.X, D, rows, D, D, 1, st)) != hipSuccess) return e;
     }
-    if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, rows, a.JF, D, 0, st)) != hipSuccess) return e;
+    if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, rows, a.ldo, D, 0, st)) != hipSuccess) return e;      // N = JF padded to 128s (zero weight rows)
     const int TJ = a.T * a.JF;
     hipLaunchKernelGGL(k_long_update, dim3((TJ + 1023) / 1024, a.B), dim3(256), 0, st, a);
     return hipGetLastError();
