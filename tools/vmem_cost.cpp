@@ -31,6 +31,8 @@ __global__ __launch_bounds__(256, 3) void k_loop(const float* __restrict__ src, 
     typedef float f2v __attribute__((ext_vector_type(2)));
     f2v pk[NL > 0 ? NL : 1][2], pkc = {1.0001f, 0.5f};
     for (int i = 0; i < (NL > 0 ? NL : 1); ++i) { pk[i][0] = (f2v){1.f, 2.f}; pk[i][1] = (f2v){3.f, 4.f}; }
+    int iv[NL > 0 ? NL : 1][4];
+    for (int i = 0; i < (NL > 0 ? NL : 1); ++i) for (int e = 0; e < 4; ++e) iv[i][e] = tid + e;
     int soff = 0;
     const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sB[wv * 1024]);
     unsigned long long gp64[NL > 0 ? NL : 1], inc64 = 128;
@@ -74,6 +76,18 @@ __global__ __launch_bounds__(256, 3) void k_loop(const float* __restrict__ src, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pk[i][e & 1]) : "v"(pkc));
             }
+            if (KIND == 17) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("v_add_u32 %0, %0, %1" : "+v"(iv[i][e & 3]) : "v"(3));
+            }
+            if (KIND == 18) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("v_min_u32 %0, %0, %1" : "+v"(iv[i][e & 3]) : "v"(1000000));
+            }
+            if (KIND == 19) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("v_cmp_lt_f32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(rg[i][e & 3]) : "v"(0.25f) : "vcc");
+            }
             if (KIND == 8) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(gp64[i]) : "v"(inc64));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -95,6 +109,7 @@ __global__ __launch_bounds__(256, 3) void k_loop(const float* __restrict__ src, 
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     f4 s = rg[0];
+    for (int i = 0; i < NL; ++i) s[1] += (float)(iv[i][0] + iv[i][3]);
     for (int i = 0; i < NL; ++i) s[0] += (float)(gp64[i] & 1) + pk[i][0][0] + pk[i][1][1];
     for (int i = 1; i < NL; ++i) s += rg[i];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) s += acc[i][j];
@@ -138,6 +153,7 @@ int main() {
     run<10, 6>(src, out, "global_load_lds_dwordx4");
     run<11, 6>(src, out, "2 x ds_write_b64"); run<12, 6>(src, out, "ds_write2_b64"); run<13, 6>(src, out, "2 x ds_write2_b32");
     run<14, 6>(src, out, "8 x v_exp_f32"); run<15, 6>(src, out, "8 x v_rcp_f32"); run<16, 6>(src, out, "4 x v_pk_fma_f32");
+    run<17, 6>(src, out, "8 x v_add_u32"); run<18, 6>(src, out, "8 x v_min_u32"); run<19, 6>(src, out, "8 x (v_cmp_lt_f32 + v_cndmask_b32)");
     run<8, 6>(src, out, "v_lshl_add_u64"); run<8, 12>(src, out, "v_lshl_add_u64");
     return 0;
 }
