@@ -641,9 +641,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             // of this loop alone, TED B = 512: 1.4364 -> 1.4182 ms per step)
             const wrsrc_t wrs = wrsrc(a.W->wch_img);
             const int wsb = (((l * kWaves + w) * 2 + p) * 32) * 2 * 1024;       // this wave's slice of the image, bytes (wave-uniform)
-            const float* ub = U + s16 * kUStride + 4 * g;                 // tile t: + 16*t*kUStride
+            // Operand addresses: three 32-bit LDS bases made opaque to the compiler, everything else in the 16-bit offset field of the
+            // ds_read (tiles 0-1 off `ub0`, tiles 2-3 off `ub2` = + 32 rows, the ragged rows off `ur`; + 64 B per k block).  Left to
+            // itself hipcc keeps ONE base and rebuilds every address beyond 64 KB with a v_add_u32 in front of its read -- 9 per k block,
+            // 576 per layer and wave, 2.5 matrix-pipe cycles each.
+            typedef const __attribute__((address_space(3))) float* ldsp;
+            typedef const __attribute__((address_space(3))) f4* ldsp4;
+            ldsp ub0 = (ldsp)(U + s16 * kUStride + 4 * g);                // tile t: + 16*t*kUStride
+            ldsp ub2 = ub0 + 32 * kUStride;
             // VALU path: remainder row r at + r*kUStride (all lanes the same row); MFMA path: lane's row (lane&3) of group rg at + 4*rg*kUStride
-            const float* ur = U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g;
+            ldsp ur = (ldsp)(U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g);
+            asm volatile("" : "+v"(ub0), "+v"(ub2), "+v"(ur));
             f4 An[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + c2 * 1024);
@@ -660,10 +668,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 }
 #pragma unroll
                 for (int t = 0; t < kFullTiles; ++t)
-                    Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
+                    Bv[t] = *(ldsp4)((t < 2 ? ub0 : ub2) + 16 * (t & 1) * kUStride + 16 * q);
 #pragma unroll
                 for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r)
-                    Ur[r] = *reinterpret_cast<const f4*>(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
+                    Ur[r] = *(ldsp4)(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
                 // Per k: [8 MFMAs][2*NREM scalar FMAs], order pinned.  A/B-tested on MI355X (tools/ab_variants.py, ms/step
                 // at B=512): this 1.513 | [32 MFMA][8*NREM FMA] 1.526 | compiler's own order 1.627 (it hoists the FMAs
                 // next to their ds_reads and stalls) | fine 2:3 interleave 1.646 | 5th MFMA tile instead of FMAs 1.645.
