@@ -493,7 +493,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         } else if (!LS_ABLATED(a, 2)) {
             const wrsrc_t wrs = wrsrc(a.W->ww_img);
             const int wsb = l * kNT * MK * 256;
-            const float* up = U + 64 * w + s16;
+            // source-row addresses off pinned LDS bases (see the channel-mixing loop): row 4 m + g = base[m >> 3] + (m & 7) * 4 rows,
+            // 64 B per channel block in the offset field; the one clamped row group (4 m + g >= R) has its own base
+            typedef const __attribute__((address_space(3))) float* ldsp;
+            constexpr int MB = (MK + 7) / 8;
+            ldsp upb[MB];
+#pragma unroll
+            for (int k = 0; k < MB; ++k) upb[k] = (ldsp)(U + 64 * w + s16 + (32 * k + g) * kUStride);
+            ldsp uplast = (ldsp)(U + 64 * w + s16 + min(4 * (MK - 1) + g, R - 1) * kUStride);
+#pragma unroll
+            for (int k = 0; k < MB; ++k) asm volatile("" : "+v"(upb[k]));
+            asm volatile("" : "+v"(uplast));
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
                 float Bt[MK];
@@ -507,10 +517,10 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
 #pragma unroll
                 for (int m = 0; m < MK; ++m) {
                     if (tokmix_needed(S, t, m)) {
-                        const int srow = (4 * m + 3 < R || 4 * m + g < R) ? 4 * m + g : R - 1;
+                        ldsp src = (4 * m + 3 < R) ? upb[m >> 3] + (4 * (m & 7)) * kUStride : uplast;
 #pragma unroll
                         for (int cb = 0; cb < kCB; ++cb)
-                            acc[cb] = MFMA(up[srow * kUStride + 16 * cb], Bt[m], acc[cb]);
+                            acc[cb] = MFMA(src[16 * cb], Bt[m], acc[cb]);
                     }
                 }
                 if (valid_of(t)) {
