@@ -192,8 +192,13 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
             }
             const wrsrc_t wrs = wrsrc(a.wchT_img);                        // buffer-descriptor loads, as in k_step (ls_lanes.h: uniform_rsrc)
             const int wsb = (((l * kWaves + w) * 2 + p) * 32) * 2 * 1024;
-            const float* ub = U + s16 * kUStride + 4 * g;
-            const float* ur = U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g;
+            // operand addresses off pinned LDS bases + immediate offsets, as in k_step's channel-mixing loop
+            typedef const __attribute__((address_space(3))) float* ldsp;
+            typedef const __attribute__((address_space(3))) f4* ldsp4;
+            ldsp ub0 = (ldsp)(U + s16 * kUStride + 4 * g);
+            ldsp ub2 = ub0 + 32 * kUStride;
+            ldsp ur = (ldsp)(U + (16 * kFullTiles + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g);
+            asm volatile("" : "+v"(ub0), "+v"(ub2), "+v"(ur));
             f4 An[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + c2 * 1024);
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
                     for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + (qn * 2 + c2) * 1024);
                 }
 #pragma unroll
-                for (int t = 0; t < kFullTiles; ++t) Bv[t] = *reinterpret_cast<const f4*>(ub + 16 * t * kUStride + 16 * q);
+                for (int t = 0; t < kFullTiles; ++t) Bv[t] = *(ldsp4)((t < 2 ? ub0 : ub2) + 16 * (t & 1) * kUStride + 16 * q);
 #pragma unroll
                 for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r)
-                    Ur[r] = *reinterpret_cast<const f4*>(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
+                    Ur[r] = *(ldsp4)(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -319,7 +324,15 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
         {
             const wrsrc_t wws = wrsrc(a.wwT_img);
             const int wwb = l * kNT * MK * 256;
-            const float* up = U + 64 * w + s16;
+            typedef const __attribute__((address_space(3))) float* ldsp;
+            constexpr int MB = (MK + 7) / 8;
+            ldsp upb[MB];
+#pragma unroll
+            for (int k = 0; k < MB; ++k) upb[k] = (ldsp)(U + 64 * w + s16 + (32 * k + g) * kUStride);
+            ldsp uplast = (ldsp)(U + 64 * w + s16 + min(4 * (MK - 1) + g, R - 1) * kUStride);
+#pragma unroll
+            for (int k = 0; k < MB; ++k) asm volatile("" : "+v"(upb[k]));
+            asm volatile("" : "+v"(uplast));
             f4 pa[kCB], pb[kCB];
 #pragma unroll
             for (int cb = 0; cb < kCB; ++cb) { pa[cb] = (f4){0.f, 0.f, 0.f, 0.f}; pb[cb] = pa[cb]; }
@@ -344,9 +357,9 @@ __global__ __launch_bounds__(512) void k_mixer_bwd(const MixerBwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MK; ++m) {
                     if (tokmix_needed(S, t, m)) {
-                        const int srow = (4 * m + 3 < R || 4 * m + g < R) ? 4 * m + g : R - 1;
+                        ldsp src = (4 * m + 3 < R) ? upb[m >> 3] + (4 * (m & 7)) * kUStride : uplast;
 #pragma unroll
-                        for (int cb = 0; cb < kCB; ++cb) acc[cb] = MFMA(up[srow * kUStride + 16 * cb], Bt[m], acc[cb]);
+                        for (int cb = 0; cb < kCB; ++cb) acc[cb] = MFMA(src[16 * cb], Bt[m], acc[cb]);
                     }
                 }
 #pragma unroll
