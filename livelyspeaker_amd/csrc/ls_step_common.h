@@ -1,5 +1,6 @@
 // Device-side helpers of the fused step kernel (ls_step.hip) and the training backward (ls_train_bwd.hip).
 #pragma once
+#include <type_traits>
 #include "ls_internal.h"
 #include "ls_philox.h"
 #include "ls_lanes.h"

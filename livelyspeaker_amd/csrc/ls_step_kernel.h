@@ -341,9 +341,13 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     // (2 FMAs per element); LN2's alpha/beta are folded into the channel-mix weights/bias on the host
     // (W' = W.diag(alpha), b' = b + W.beta), so its operand is just (x - mean) * rstd: 1 FMA per element.
     // alv/bev: LN1's alpha/beta of this lane's channels, loaded by the caller BEFORE the statistics (a load per channel block
-    // here cost four serialised L2 round trips per layer); alpha == nullptr: LN2, affine folded into the weights
-    auto ln_store = [&](const float* alpha, const f4 (&alv)[kCB], const f4 (&bev)[kCB], float* gout) {
+    // here cost four serialised L2 round trips per layer); affine = false: LN2 when sampling, affine folded into the weights
+    // `affine` is a compile-time tag (std::true_type: LN1, and LN2 while training): as a run-time `alpha != nullptr` the compiler could
+    // not prove LN1's pointer non-null and computed BOTH forms of every element, selecting with four v_cndmask_b32 per float4
+    // (160 per layer and wave) -- and, in bf16x3 mode, branched on it.
+    auto ln_store = [&](auto affine, const f4 (&alv)[kCB], const f4 (&bev)[kCB], float* gout) {
         (void)gout;
+        constexpr bool alpha = decltype(affine)::value;
         float nmr[kNT];
 #pragma unroll
         for (int t = 0; t < kNT; ++t) nmr[t] = -mean[t] * rstd[t];
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         ln_stats(TRAIN ? a.tr_s1 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(2 + 8 * l);
         fresh();
-        ln_store(a.W->ln1a + l * kD, alv, bev, TRAIN ? a.tr_x1 + (size_t)l * a.tr_B * S * kD : nullptr);
+        ln_store(std::true_type{}, alv, bev, TRAIN ? a.tr_x1 + (size_t)l * a.tr_B * S * kD : nullptr);
         // no workgroup barrier here: token mixing contracts over ROWS, so wave w only reads back the 64 channel columns
         // it has just written itself (LDS operations of one wave execute in order); the LN statistics barrier above
         // already ordered these stores after every wave's reads of the previous operand.
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
         }
         ln_stats(TRAIN ? a.tr_s2 + (size_t)l * a.tr_B * S * 2 : nullptr);
         stamp(5 + 8 * l);      // its two barriers also order every wave's token-mix reads before the stores below
-        ln_store(TRAIN ? a.W->ln2a : nullptr, alv2, bev2, TRAIN ? a.tr_x2 + (size_t)l * a.tr_B * S * kD : nullptr);
+        ln_store(std::integral_constant<bool, TRAIN>{}, alv2, bev2, TRAIN ? a.tr_x2 + (size_t)l * a.tr_B * S * kD : nullptr);
         __syncthreads();
         stamp(6 + 8 * l);
         if constexpr (PREC == 1) {
