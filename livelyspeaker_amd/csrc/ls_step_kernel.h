@@ -224,11 +224,17 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 for (int t = 0; t < kNT; ++t) acc[c2][t] = X[2 * p + c2][t];
             const wrsrc_t wrs = wrsrc(a.W->winx_img);
             const int wsb = (w * 2 + p) * KXQ * 2 * 1024;
+            f4 An[2];                                   // next k block's weight fragments in flight while this one is multiplied
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + c2 * 1024);
 #pragma unroll 2
             for (int q = 0; q < KXQ; ++q) {
                 f4 A[2], Bv[kNT];
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) A[c2] = wload4(wrs, lane * 16, wsb + (q * 2 + c2) * 1024);
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
+                const int qn = q + 1 < KXQ ? q + 1 : KXQ - 1;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + (qn * 2 + c2) * 1024);
 #pragma unroll
                 for (int t = 0; t < kNT; ++t)
                     Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
@@ -833,14 +839,28 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 const int wsb = ob * 32 * 1024;
                 const float* up = &U[rc * kUStride + 4 * g];
                 f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll 4
-                for (int q = 0; q < 32; ++q) {
-                    const f4 A = wload4(wrs, lane * 16, wsb + q * 1024);
-                    const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * q);
-                    a0 = MFMA(A[0], Bv[0], a0);
-                    a1 = MFMA(A[1], Bv[1], a1);
-                    a0 = MFMA(A[2], Bv[2], a0);
-                    a1 = MFMA(A[3], Bv[3], a1);
+                // eight weight fragments in flight ahead of their use (one load per 4 MFMAs: with four in flight, as `unroll 4` left
+                // it, the L2 round trip was exposed -- in-kernel stamps: 154 k cycles for 98 k of MFMA issue at BEAT's 90 units)
+                constexpr int QB = 8;
+                f4 An[QB];
+#pragma unroll
+                for (int k = 0; k < QB; ++k) An[k] = wload4(wrs, lane * 16, wsb + k * 1024);
+#pragma unroll 1
+                for (int q0 = 0; q0 < 32; q0 += QB) {
+                    f4 A[QB];
+#pragma unroll
+                    for (int k = 0; k < QB; ++k) A[k] = An[k];
+                    const int qn = q0 + QB < 32 ? q0 + QB : q0;
+#pragma unroll
+                    for (int k = 0; k < QB; ++k) An[k] = wload4(wrs, lane * 16, wsb + (qn + k) * 1024);
+#pragma unroll
+                    for (int k = 0; k < QB; ++k) {
+                        const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * (q0 + k));
+                        a0 = MFMA(A[k][0], Bv[0], a0);
+                        a1 = MFMA(A[k][1], Bv[1], a1);
+                        a0 = MFMA(A[k][2], Bv[2], a0);
+                        a1 = MFMA(A[k][3], Bv[3], a1);
+                    }
                 }
                 res[i] = a0 + a1;
             }
