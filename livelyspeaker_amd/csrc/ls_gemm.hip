@@ -1,4 +1,4 @@
-// Strided fp32 MFMA GEMM for the training step (forward, data-gradient and weight-gradient products):
+// Strided fp32 MFMA GEMM (the sampler's once-per-call stage, the SAG decoder, the long-sequence path, the FGD evaluator and the training step's forward, data-gradient and weight-gradient products):
 //     C[m][n] (+)= act( sum_k A(m,k) * B(n,k) + bias[n] )
 // A(m,k) and B(n,k) are addressed through two-level strides on both the row and the reduction index
 //     off(m,k) = (m / ri) * ro + (m % ri) * rs  +  (k / ki) * ko + (k % ki) * ks
