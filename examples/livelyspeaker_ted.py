@@ -62,6 +62,8 @@ def infer(model, diffusion, sag_decoder, batch, cond, skip_steps=80, seed=233, n
     draw (slow: ~1.3 s of host RNG at B=512); 'philox' generates the noise inside the step kernel."""
     diffusion.noise_source = noise_source
     B = batch["x"].shape[0]
+    if hasattr(model, "prefetch_condition"):          # optional: the refinement's once-per-call stage overlaps the SAG decode
+        model.prefetch_condition(cond["y"] if "y" in cond else cond)
     decoded_motions = sag_decoder(batch)["output"]
     torch.manual_seed(seed)
     sample = diffusion.ddim_sample_loop(model, (B, 9, 3, 34), clip_denoised=False, model_kwargs=cond, skip_timesteps=skip_steps,

@@ -152,7 +152,7 @@ typedef struct ls_step_args {
 } ls_step_args;
 
 typedef struct ls_timing {
-    float prepare_ms;           /* last ls_prepare, GPU time (HIP events on the handle's stream) */
+    float prepare_ms;           /* last ls_prepare, GPU time (HIP events on the handle's stream); -1 while an ls_prepare_async is in flight */
     float loop_ms;              /* last ls_sample: first step launch .. last step done */
     float total_ms;             /* last ls_sample incl. layout conversion and copies */
     int32_t n_step_launches;
@@ -174,6 +174,10 @@ int ls_commit_weights(ls_handle* h);
 int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; default FP32 */
 int ls_set_schedule(ls_handle* h, const ls_schedule* s);
 int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */
+/* The same, enqueued on the handle's stream WITHOUT waiting: later calls on this handle are ordered behind it, so the caller may
+ * overlap it with work on another stream (LivelySpeaker: the SAG decode, scripts/test_LivelySpeaker_ted.py:88-113, needs none of it).
+ * Device-resident inputs must stay valid until the next synchronising call on this handle; ls_timing.prepare_ms reads -1 until then. */
+int ls_prepare_async(ls_handle* h, const ls_cond* c);
 int ls_sample(ls_handle* h, const ls_sample_args* a);
 int ls_forward(ls_handle* h, const ls_forward_args* a);
 int ls_step(ls_handle* h, const ls_step_args* a);

@@ -98,7 +98,7 @@ class LsEvalConfig(C.Structure):
 
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
-           "ls_set_schedule", "ls_prepare", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
+           "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
            "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
@@ -161,6 +161,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_commit_weights.argtypes = [C.c_void_p]
     lib.ls_set_schedule.argtypes = [C.c_void_p, C.POINTER(LsSchedule)]
     lib.ls_prepare.argtypes = [C.c_void_p, C.POINTER(LsCond)]
+    lib.ls_prepare_async.argtypes = [C.c_void_p, C.POINTER(LsCond)]
     lib.ls_sample.argtypes = [C.c_void_p, C.POINTER(LsSampleArgs)]
     lib.ls_forward.argtypes = [C.c_void_p, C.POINTER(LsForwardArgs)]
     lib.ls_step.argtypes = [C.c_void_p, C.POINTER(LsStepArgs)]
@@ -349,7 +350,10 @@ class Engine:
         self.n_steps = s.n_steps
 
     # ---- per call --------------------------------------------------------------------------------
-    def prepare(self, y: dict):
+    def prepare(self, y: dict, wait: bool = True):
+        """Once-per-call stage.  ``wait=False`` (ls_prepare_async) only enqueues it on the engine's stream: the next sample / forward /
+        step is ordered behind it, and work on other streams (the SAG decode) overlaps it.  The marshalled inputs are kept alive on
+        this object until the next prepare, by which time a synchronising call has long consumed them."""
         emo = y.get("emo") if self.cfg.n_prefix_tokens == 2 else None
         if emo is not None and getattr(emo, "ndim", 2) == 1:   # a bare [B] id vector: broadcast to the callers' [B, T] form
             emo = emo[:, None].repeat(1, self.T) if hasattr(emo, "repeat") and not isinstance(emo, np.ndarray) else np.repeat(np.asarray(emo)[:, None], self.T, 1)
@@ -359,7 +363,12 @@ class Engine:
                    m.f32(y["origin_x"], (B, self.J, self.F, self.T)), m.i64(y["vid_indices"], (B,)),
                    m.i64(emo, (B, self.T)), m.f32(y["scale"], (B,)))
         m.ready()
-        self._check(self.lib.ls_prepare(self.h, C.byref(c)), "ls_prepare")
+        if wait:
+            self._check(self.lib.ls_prepare(self.h, C.byref(c)), "ls_prepare")
+            self._prepare_inputs = None
+        else:
+            self._check(self.lib.ls_prepare_async(self.h, C.byref(c)), "ls_prepare_async")
+            self._prepare_inputs = (m, y)       # device buffers (and any converted copies) stay valid while the copies are in flight
         self.batch = B
 
     def _xshape(self):
@@ -448,6 +457,10 @@ class Engine:
         n = self._check(self.lib.ls_read(self.h, name.encode(), out.ctypes.data_as(c_f32p), out.size), f"ls_read({name})")
         assert n == out.size
         return out
+
+    def synchronize(self):
+        """Wait for everything enqueued on the engine's stream (an asynchronous prepare included)."""
+        self._check(self.lib.ls_synchronize(self.h), "ls_synchronize")
 
     def timing(self) -> dict:
         t = LsTiming()

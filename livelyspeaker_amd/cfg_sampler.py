@@ -18,6 +18,10 @@ class ClassifierFreeSampleModel(nn.Module):
         self.data_rep = self.model.data_rep
         self.cond_mode = self.model.cond_mode
 
+    def prefetch_condition(self, y):
+        """Pass-through of RAG.prefetch_condition (optional hint, no counterpart in the reference)."""
+        self.model.prefetch_condition(y)
+
     def forward(self, x, timesteps, y=None):
         if self.model.cond_mask_prob > 0:
             # draw order of the reference: cond pass eps, then uncond pass eps (RAG.py:120 via cfg_sampler.py:29-30)

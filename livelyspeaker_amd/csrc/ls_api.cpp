@@ -66,7 +66,8 @@ struct ls_handle {
     DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_stats, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [0..3] sample / step timing, [4..5] ls_prepare
+    bool prepare_pending = false;                                                  // ls_prepare_async enqueued, prepare_ms not read back yet
     std::string err;
 
     std::map<std::string, std::vector<float>> w;   // host copies under the reference's state-dict keys
@@ -710,7 +711,14 @@ int ls_set_schedule(ls_handle* h, const ls_schedule* s) {
     return LS_OK;
 }
 
-int ls_prepare(ls_handle* h, const ls_cond* c) {
+// prepare_ms of an ls_prepare_async whose work has finished (called behind every stream synchronisation; `block`: wait for it)
+static void resolve_prepare_timing(ls_handle* h, bool block) {
+    if (!h->prepare_pending) return;
+    if (block ? hipEventSynchronize(h->ev[5]) != hipSuccess : hipEventQuery(h->ev[5]) != hipSuccess) return;
+    if (hipEventElapsedTime(&h->timing.prepare_ms, h->ev[4], h->ev[5]) == hipSuccess) h->prepare_pending = false;
+}
+
+static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
     if (!h || !c) return fail(h, LS_EINVAL, "ls_prepare: null argument");
     if (!h->committed) return fail(h, LS_ESTATE, "ls_prepare before ls_commit_weights");
     if (c->batch < 1) return fail(h, LS_EINVAL, "batch must be >= 1");
@@ -721,7 +729,7 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
     const int od = c->on_device;
     hipStream_t st = h->stream;
     int rc;
-    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    HIPCHK(h, hipEventRecord(h->ev[4], st));
     if ((rc = ingest(h, h->audio, c->audio_input, (size_t)B * AL * sizeof(float), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->origin_x, c->origin_x, (size_t)B * JF * h->T * sizeof(float), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->vid, c->vid_indices, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
@@ -802,14 +810,27 @@ int ls_prepare(ls_handle* h, const ls_cond* c) {
         { const void* os = h->lx_stats.p; HIPCHK(h, h->lx_stats.ensure(rows * 2 * sizeof(float))); if (os != h->lx_stats.p) free_graph(h); }
         if (old[0] != h->lx_proj.p || old[1] != h->lx_X.p || old[2] != h->lx_U.p || old[3] != h->lx_OUT.p || old[4] != h->lx_xpad.p) free_graph(h);
     }
-    HIPCHK(h, hipEventRecord(h->ev[1], st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    HIPCHK(h, hipEventElapsedTime(&h->timing.prepare_ms, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventRecord(h->ev[5], st));
+    if (wait) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipEventElapsedTime(&h->timing.prepare_ms, h->ev[4], h->ev[5]));
+        h->prepare_pending = false;
+    } else {
+        h->timing.prepare_ms = -1.0f;          // until the work is known to be done (next synchronising call / ls_get_timing)
+        h->prepare_pending = true;
+    }
     if (h->B != B) free_graph(h);
     h->B = B;
     h->prepared = true;
     return LS_OK;
 }
+
+int ls_prepare(ls_handle* h, const ls_cond* c) { return prepare_impl(h, c, true); }
+// The same work enqueued on the handle's stream without waiting for it: everything that follows on this handle (ls_sample, ls_forward,
+// ls_step) is stream-ordered behind it, so a caller can overlap the once-per-call stage with work on ANOTHER stream -- LivelySpeaker's
+// SAG decode, which needs none of it (scripts/test_LivelySpeaker_ted.py:88-113 runs the two back to back).  Device-resident inputs
+// must stay valid until the next call on this handle that synchronises; host inputs are staged as in ls_prepare.
+int ls_prepare_async(ls_handle* h, const ls_cond* c) { return prepare_impl(h, c, false); }
 
 int ls_forward(ls_handle* h, const ls_forward_args* a) {
     if (!h || !a) return fail(h, LS_EINVAL, "ls_forward: null argument");
@@ -1034,6 +1055,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     }
     HIPCHK(h, hipEventRecord(h->ev[3], st));
     HIPCHK(h, hipStreamSynchronize(st));
+    resolve_prepare_timing(h, true);
     HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
     HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
     h->timing.n_step_launches = n_exec;
@@ -1107,6 +1129,7 @@ int ls_shard_range(int64_t total, int32_t world, int32_t rank, int64_t* first, i
 
 int ls_get_timing(const ls_handle* h, ls_timing* out) {
     if (!h || !out) return LS_EINVAL;
+    resolve_prepare_timing(const_cast<ls_handle*>(h), false);      // an ls_prepare_async that has finished by now
     *out = h->timing;
     return LS_OK;
 }
@@ -1115,6 +1138,7 @@ int ls_synchronize(ls_handle* h) {
     if (!h) return LS_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    resolve_prepare_timing(h, true);
     return LS_OK;
 }
 

@@ -128,6 +128,7 @@ class RAG(nn.Module):
         self._engine = None
         self._weights_dirty = True
         self._cond_key = None
+        self._prefetched_key = None
         self.n_emotions = n_emotions if n_prefix_tokens == 2 else 0
 
     # ------------------------------------------------------------------ nn.Module plumbing
@@ -173,7 +174,15 @@ class RAG(nn.Module):
             self._engine.set_precision(self.precision)
         return self._engine
 
-    def _engine_prepared(self, y):
+    def prefetch_condition(self, y):
+        """Optional hint (no counterpart in the reference): enqueue the once-per-call stage for ``y`` NOW, without waiting for it.
+        The next forward / sampling call with the same ``y`` finds it resident (stream-ordered behind it), and whatever the caller
+        runs in between on other streams overlaps it -- LivelySpeaker's SAG decode needs none of it
+        (scripts/test_LivelySpeaker_ted.py:88-113 runs the two back to back).  RAG.py:110's in-place ``origin_x[..., 4:] = 0`` happens
+        here instead of at the first forward (the SAG decoder reads the four prefix poses only)."""
+        self._engine_prepared(y, wait=False)
+
+    def _engine_prepared(self, y, wait=True):
         """Run the once-per-call stage (audio encoder, static projection, speaker style) unless ``y`` is the
         conditioning that is already resident.  Reproduces RAG.py:110's in-place ``origin_x[..., 4:] = 0``."""
         eng = self.engine()
@@ -182,7 +191,12 @@ class RAG(nn.Module):
             tail.zero_()                                  # is non-zero keeps origin_x._version (part of the cache key) stable
         names = ('audio_input', 'origin_x', 'vid_indices', 'scale') + (('emo',) if self.n_prefix_tokens == 2 else ())
         key = tuple((n, y[n].data_ptr(), tuple(y[n].shape), y[n]._version) for n in names)
-        if key != self._cond_key or not self.cache_conditioning:
+        if not wait:                                      # prefetch_condition: enqueue only; the next request for this key is served by it
+            eng.prepare({n: y[n] for n in names}, wait=False)
+            self._cond_key = self._prefetched_key = key
+        elif key == getattr(self, "_prefetched_key", None):
+            self._prefetched_key = None                   # one shot, also with cache_conditioning off (the reference re-runs it per call)
+        elif key != self._cond_key or not self.cache_conditioning:
             eng.prepare({n: y[n] for n in names})
             self._cond_key = key
         return eng

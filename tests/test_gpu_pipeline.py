@@ -60,6 +60,44 @@ def test_livelyspeaker_pipeline_matches_chained_oracles():
     assert real.shape == (B, 34, 27)
 
 
+def test_prefetched_condition_equals_the_serial_order():
+    """RAG.prefetch_condition (ls_prepare_async under the SAG decode) must give bit-identical samples to the reference's order
+    (decode, then the once-per-call stage inside the sampling call), with the conditioning cache on or off; prepare_ms reads -1 while
+    the asynchronous stage is in flight and a real time after the call that synchronises."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import livelyspeaker_ted as ex
+    B = 40
+    cfg, model, diffusion, sag_decoder, _ = ex.build()
+    _, batch, cond = ex.make_inputs(cfg, B, guidance_param=2.5)
+    diffusion.noise_source = "philox"
+
+    def run(prefetch):
+        if prefetch:
+            model.prefetch_condition(cond["y"])
+        dec = sag_decoder(batch)["output"]
+        torch.manual_seed(5)
+        out = diffusion.ddim_sample_loop(model, (B, 9, 3, 34), clip_denoised=False, model_kwargs=cond, skip_timesteps=80, init_image=dec,
+                                         progress=False, dump_steps=None, noise=None, const_noise=False)
+        return dec.cpu().numpy(), out.cpu().numpy()
+
+    inner = model.model if hasattr(model, "model") else model
+    for cache in (True, False):
+        inner.cache_conditioning = cache
+        inner._cond_key = None
+        d0, s0 = run(False)
+        inner._cond_key = None
+        d1, s1 = run(True)
+        assert np.array_equal(d0, d1) and np.array_equal(s0, s1), f"cache_conditioning={cache}"
+    eng = inner.engine()
+    inner._cond_key = None
+    model.prefetch_condition(cond["y"])
+    assert eng.timing()["prepare_ms"] == -1.0 or eng.timing()["prepare_ms"] > 0      # in flight, or already done when queried
+    eng.synchronize() if hasattr(eng, "synchronize") else None
+    run(False)
+    assert eng.timing()["prepare_ms"] > 0
+
+
 def test_bench_strong_scaling_path_under_torch_distributed_run(tmp_path):
     """BASELINE configs[3]'s code path end to end on ONE rank: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1
     --global-batch G` (RCCL process group, shard + all_gather inside the timed region, shard cross-check, in-run parity), next to
