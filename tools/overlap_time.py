@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""SAG decode + the refinement's once-per-call stage at B = 512, back to back (the reference's order) vs ls_prepare_async enqueued under
+the decode (RAG.prefetch_condition): wall time of the pair and each stream's own span.  Run on the GPU box."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/examples")
 import livelyspeaker_ted as ex
