@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """SAG decode + the refinement's once-per-call stage at B = 512, back to back (the reference's order) vs ls_prepare_async enqueued under
 the decode (RAG.prefetch_condition): wall time of the pair and each stream's own span.  Run on the GPU box."""
-import sys, time, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/examples")
+import os, sys, time, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
 import livelyspeaker_ted as ex
 B = 512
 cfg, model, diffusion, sag, _ = ex.build()

@@ -2,7 +2,7 @@
 """Shake-out on the GPU box: every sampling path (fused TED / BEAT, long-sequence) and the SAG decoder at odd and tile-aligned batch sizes,
 back to back in one process (allocation sizes, tile paths and buffer re-use all vary); finite outputs only -- parity is tests/."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from livelyspeaker_amd import _lib, synth
 # long path at several batch sizes (different allocation sizes / tile paths), TED + BEAT fused at odd batches, SAG at odd batches
 for ds, Bs in (("beat150", (1, 5, 8, 24, 48, 100)), ("ted", (1, 3, 37, 130, 513)), ("beat", (2, 65, 255))):
