@@ -167,6 +167,7 @@ def test_abi_error_behaviour(ted):
         assert lib.ls_commit_weights(h) == -2 and b"missing weight" in lib.ls_last_error(h)
         cond = L.LsCond(1, 0, None, None, None, None, None)
         assert lib.ls_prepare(h, ctypes.byref(cond)) == -2                 # before weights
+        assert lib.ls_prepare_async(h, ctypes.byref(cond)) == -2           # the asynchronous form validates the same way
         w = np.zeros(7, np.float32)
         assert lib.ls_set_weight(h, b"input_mapping.bias", w.ctypes.data_as(L.c_f32p), w.size) == 0
         assert lib.ls_commit_weights(h) != 0                                # wrong size / still missing keys
