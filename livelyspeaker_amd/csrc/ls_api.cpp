@@ -110,7 +110,7 @@ struct ls_handle {
     CallParams call_host{0, 0};
     int precision = 0;      // 0 exact fp32 MFMA, 1 bf16x3 split-precision channel mixing (ls_set_precision)
 #ifdef LS_DEBUG             // profiling variant of the library only (build_library(defines=['LS_DEBUG'])); never in the shipped .so
-    DevBuf prof;
+    DevBuf prof, wgt;       // wgt: [1024][2] start / end stamps of every workgroup of the last step launch
     bool prof_on = false;   // LS_PROF=<workgroup index>: in-kernel s_memtime phase stamps, read with ls_read("prof")
     int prof_wg = 0;
     int ablate = 0;         // LS_ABLATE (results are wrong when non-zero)
@@ -537,6 +537,7 @@ void fill_common(ls_handle* h, StepArgs& a) {
     a.ablate = h->ablate;
     a.prof = h->prof_on ? static_cast<unsigned long long*>(h->prof.p) : nullptr;
     a.prof_wg = h->prof_wg;
+    a.wgt = h->prof_on ? static_cast<unsigned long long*>(h->wgt.p) : nullptr;
 #endif
 }
 
@@ -624,6 +625,8 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (h->prof_on) {
         std::vector<unsigned long long> z((size_t)kWaves * kProfPoints, 0ull);
         if (upload(h, h->prof, z.data(), z.size() * sizeof(unsigned long long)) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
+        std::vector<unsigned long long> zw(2048, 0ull);
+        if (upload(h, h->wgt, zw.data(), zw.size() * sizeof(unsigned long long)) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
     }
 #endif
     CallParams cp{0, 0};
@@ -649,6 +652,7 @@ void ls_destroy(ls_handle* h) {
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
+    h->wgt.release();
 #endif
     for (int i = 0; i < 4; ++i) { h->conv_w[i].release(); h->conv_b[i].release(); h->conv_img[i].release(); }
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1092,6 +1096,15 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
         cnt = (size_t)kWaves * kProfPoints * 2;     // 64-bit stamps as pairs of 32-bit words
         if (cnt > capacity) return fail(h, LS_EINVAL, "capacity");
         HIPCHK(h, hipMemcpy(host_out, h->prof.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        return (long long)cnt;
+    }
+#endif
+#ifdef LS_DEBUG
+    if (n == "wgt") {
+        if (!h->prof_on) return fail(h, LS_ESTATE, "LS_PROF not set");
+        cnt = 2048 * 2;
+        if (cnt > capacity) return fail(h, LS_EINVAL, "capacity");
+        HIPCHK(h, hipMemcpy(host_out, h->wgt.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
         return (long long)cnt;
     }
 #endif

@@ -93,6 +93,7 @@ struct StepArgs {
     // the shipped library has neither the fields nor the code that reads them, so no environment variable can change its results.
     unsigned long long* prof;  // [8 waves][kProfPoints] s_memtime stamps of workgroup prof_wg (env LS_PROF)
     int prof_wg;
+    unsigned long long* wgt;   // [workgroups][2] s_memtime at the start / end of EVERY workgroup (tools/wg_timeline.py), or null
     int ablate;              // env LS_ABLATE: 1 skip channel-mix MFMAs, 2 skip token-mix, 4 skip LN stats (results are wrong)
 #endif
 };

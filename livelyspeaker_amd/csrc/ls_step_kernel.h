@@ -111,6 +111,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     auto stamp = [&](int idx) {
 #ifdef LS_DEBUG
         if (a.prof && b == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
+        if (a.wgt && tid == 0 && (idx == 0 || idx == 4 + 8 * a.layers)) a.wgt[2 * b + (idx ? 1 : 0)] = __builtin_amdgcn_s_memtime();
 #else
         (void)idx;
 #endif
