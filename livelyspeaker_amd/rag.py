@@ -199,6 +199,7 @@ class RAG(nn.Module):
         elif key != self._cond_key or not self.cache_conditioning:
             eng.prepare({n: y[n] for n in names})
             self._cond_key = key
+            self._prefetched_key = None                   # whatever was prefetched is no longer what the engine holds
         return eng
 
     def _forward_engine(self, x, timesteps, y, want):

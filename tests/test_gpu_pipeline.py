@@ -89,6 +89,20 @@ def test_prefetched_condition_equals_the_serial_order():
         inner._cond_key = None
         d1, s1 = run(True)
         assert np.array_equal(d0, d1) and np.array_equal(s0, s1), f"cache_conditioning={cache}"
+    # a prefetch that is superseded by another conditioning must not be honoured later
+    _, batch2, cond2 = ex.make_inputs(cfg, B, guidance_param=1.5)
+    cond2["y"]["audio_input"] = cond2["y"]["audio_input"] * 0.5
+    inner.cache_conditioning = True
+    inner._cond_key = None
+    _, ref2 = run(False)                                   # cond (resident afterwards)
+    model.prefetch_condition(cond["y"])
+    dec = sag_decoder(batch)["output"]
+    torch.manual_seed(5)
+    other = diffusion.ddim_sample_loop(model, (B, 9, 3, 34), clip_denoised=False, model_kwargs=cond2, skip_timesteps=80, init_image=dec,
+                                       progress=False, dump_steps=None, noise=None, const_noise=False).cpu().numpy()
+    assert not np.array_equal(other, ref2)                 # really the other conditioning
+    _, again = run(False)                                  # back to cond: must re-run the stage, not trust the stale prefetch
+    assert np.array_equal(again, ref2)
     eng = inner.engine()
     inner._cond_key = None
     model.prefetch_condition(cond["y"])
