@@ -169,7 +169,7 @@ class RAG(nn.Module):
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items() if not k.endswith(".pe")}
             self._engine.load_state_dict(sd)
             self._weights_dirty = False
-            self._cond_key = None
+            self._cond_key = self._prefetched_key = None
         if getattr(self._engine, "precision", "fp32") != self.precision:
             self._engine.set_precision(self.precision)
         return self._engine
