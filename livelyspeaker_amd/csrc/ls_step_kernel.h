@@ -175,11 +175,11 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             }
         }
         constexpr int NIT = (R * KXP + 511) / 512;                   // x_t values per thread: 5 (TED) | 41 (BEAT)
-        if constexpr (NIT > 8) {
-            // Wide feature vectors (BEAT, 282): the thread's loads first (clamped address + select: branch-free, in flight together),
-            // then the LDS writes, in blocks of 14 so the registers stay bounded -- as a load -> write loop every iteration paid its own
-            // L2 round trip, 41 in a row.  Same-box A/B (tools/ab_variants.py, 5 rounds): BEAT 0.8508 -> 0.8477 ms/step.  TED (5
-            // iterations) keeps the loop: the same change there measured 1.4334 -> 1.4373.
+        {
+            // The thread's loads first (clamped address + select: branch-free, in flight together), then the LDS writes, in blocks of 14
+            // so the registers stay bounded -- as a load -> write loop every iteration paid its own L2 round trip (41 in a row for
+            // BEAT's 282-wide vectors, 5 for TED).  Same-box A/B (tools/ab_variants.py, 5 rounds): BEAT 0.8508 -> 0.8477 ms/step; TED
+            // 1.3682 -> 1.3653 on the final build (1.4334 -> 1.4373 earlier in the round, under a different register allocation).
             constexpr int CH = 14;
 #pragma unroll
             for (int it0 = 0; it0 < NIT; it0 += CH) {
@@ -205,14 +205,6 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     }
                 }
             }
-        } else
-        for (int idx = tid; idx < R * KXP; idx += 512) {
-            const int r = idx / KXP, k = idx - r * KXP;
-            const int sq = r >= S ? 1 : 0;
-            const int tk = r - sq * S;
-            float v = 0.f;
-            if (tk >= NPRE && k < JF) v = a.x_in[(size_t)sm(sq) * kT * JF + (tk - NPRE) * JF + k];
-            U[r * kUStride + k] = v;
         }
         __syncthreads();
         fresh();
