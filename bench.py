@@ -63,10 +63,17 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of the first timed call")
     ap.add_argument("--parity-samples", type=int, default=2)
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no single-pass / LivelySpeaker / bf16x3 / train legs")
+    ap.add_argument("--legs", default="all", help="secondary legs to run: 'all', 'none' or a comma list of "
+                    "single,split,lively,beat,train,seeds (e.g. --legs lively)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--train-leg", action="store_true", help="also time the training step (default on at 1 GPU; at N>1 it "
                     "adds the RCCL gradient all-reduce, the build's only per-step collective)")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--ranks-share-device", action="store_true",
+                    help="TEST ONLY (1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo on host copies -- RCCL "
+                         "refuses two ranks on one device ('Duplicate GPU detected'), so this exercises the whole N>1 control flow "
+                         "(self-launch, sharding, broadcast, gather, cross-check, max-over-ranks timing) but not RCCL itself")
+    ap.add_argument("--no-traffic-pass", action="store_true", help="do not spawn the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32 = exact (headline); bf16x3 = opt-in split-precision channel mixing")
     return ap.parse_args()
@@ -91,6 +98,51 @@ def pmc_traffic(dataset, B):
         return None, f"{os.path.relpath(PMC_TRAFFIC_FILE, ROOT)} has no entry for this kernel source (re-profile)"
     except Exception as e:
         return None, f"unavailable: {e!r}"[:120]
+
+
+def measure_traffic(a, B):
+    """HBM-side bytes per k_step launch measured IN THIS RUN: two rocprofv3 PMC passes (one counter per run, --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass) of a 40-launch slice of this very workload in
+    a child process; traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the x2 is the guide's gfx950 correction for wide
+    coalesced reads, which is how the weight images and static rows are fetched).  Returns (bytes | None, provenance)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--diffusion-steps", "40", "--no-cpu-baseline",
+             "--no-parity", "--legs", "none", "--no-traffic-pass", "--dataset", a.dataset, "--batch", str(B), "--scale", str(a.scale)]
+    kib, launches = {}, 0
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ls_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--"] + child, capture_output=True, text=True,
+                               timeout=420, env=env, cwd="/tmp")
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-160:]!r}"
+            cur = sqlite3.connect(dbs[0]).cursor()
+            ids = [did for name, did in cur.execute("select name, dispatch_id from kernels") if "k_step" in name]
+            per = {}
+            for did, cname, val in cur.execute("select dispatch_id, counter_name, value from counters_collection"):
+                if cname == counter:
+                    per[did] = per.get(did, 0.0) + val
+            vals = [per[i] for i in ids if i in per]
+            if not vals:
+                return None, f"no {counter} rows for ls::k_step in the PMC pass"
+            kib[counter], launches = sum(vals) / len(vals), len(vals)
+        except Exception as e:
+            return None, f"traffic pass unavailable: {e!r}"[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(round((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)), (
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass, --kernel-trace only) over {launches} "
+        f"k_step launches of a child process running this workload; 2 x FETCH_SIZE ({kib['FETCH_SIZE']:.0f} KiB) + WRITE_SIZE "
+        f"({kib['WRITE_SIZE']:.0f} KiB)")
 
 
 def cpu_baseline(cfg, args):
@@ -215,25 +267,37 @@ def train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence):
     fence()
     el = time.perf_counter() - t0
     if use_dist:
+        from livelyspeaker_amd import shard
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        shard.all_reduce_(tt, torch.distributed.ReduceOp.MAX)
         el = float(tt.item())
     tr.close()
     cpu = None
     if world == 1 and not a.no_cpu_baseline:
         # the torch-CPU oracle (autograd) on this box's host cores, bounded sample: B=32, 2 steps after one warm-up
         from oracle import train_oracle as tro
-        nthr = torch.get_num_threads()
-        orc_t = tro.TrainOracle({k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if not k.endswith(".pe")},
-                                cfg.n_prefix_tokens)
-        xs, yy, nz, dr, ep = synth.make_train_batch(cfg, 32, 0)
-        tt0 = np.random.Generator(np.random.PCG64(0)).integers(0, 1000, size=(32,))
-        orc_t.optimizer_step(orc_t.forward_backward(xs, tt0, nz, yy, dr, ep)[2])
-        c0 = time.perf_counter()
-        for _ in range(2):
-            orc_t.optimizer_step(orc_t.forward_backward(xs, tt0, nz, yy, dr, ep)[2])
-        cpu = {"value": round(2 * 32 / (time.perf_counter() - c0), 2), "unit": "samples/s", "cores": nthr, "kind": "port",
-               "sample": "torch-CPU oracle (oracle/train_oracle.py), B=32, 2 steps after 1 warm-up"}
+        # aten's intra-op pool at the box's full core count (128) is past its sweet spot and very noisy for these shapes (13.9 vs
+        # 32.2 samples/s between two runs of one build in round 2): 16 threads, two warm-up steps, six timed ones, median reported
+        default_threads = torch.get_num_threads()
+        nthr = min(16, default_threads)
+        torch.set_num_threads(nthr)
+        try:
+            orc_t = tro.TrainOracle({k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if not k.endswith(".pe")},
+                                    cfg.n_prefix_tokens)
+            xs, yy, nz, dr, ep = synth.make_train_batch(cfg, 32, 0)
+            tt0 = np.random.Generator(np.random.PCG64(0)).integers(0, 1000, size=(32,))
+            per = []
+            for i in range(8):
+                c0 = time.perf_counter()
+                orc_t.optimizer_step(orc_t.forward_backward(xs, tt0, nz, yy, dr, ep)[2])
+                if i >= 2:
+                    per.append(time.perf_counter() - c0)
+        finally:
+            torch.set_num_threads(default_threads)
+        med = float(np.median(per))
+        cpu = {"value": round(32 / med, 2), "unit": "samples/s", "cores": nthr, "kind": "port",
+               "sample": f"torch-CPU oracle (oracle/train_oracle.py), B=32, {nthr} intra-op threads (torch's default here: {default_threads}), "
+                         f"2 warm-up + 6 timed steps, median step {med * 1e3:.0f} ms (min {min(per) * 1e3:.0f}, max {max(per) * 1e3:.0f})"}
     return {"cpu_baseline": cpu, "what": "forward + Huber/velocity/KLD losses + backward + AdamW (ls_train_*), fp32, inputs resident in HBM",
             "value": round(world * B * n / el, 1), "unit": "samples/s", "ms_per_step": round(el / n * 1e3, 3),
             "fwd_ms": round(fwd / n, 3), "bwd_ms": round(bwd / n, 3), "batch_per_gpu": B,
@@ -248,11 +312,14 @@ def _train_schedule(a):
                                                      lambda_rcxyz=0.0, lambda_fc=0.0), "")
 
 
-def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3):
+def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3, world=1, rank=0, max_over_ranks=lambda v: v):
     """BASELINE configs[2] as the reference runs it (scripts/test_LivelySpeaker_ted.py:85-113): SAG decoder on a synthetic CLIP text
-    feature -> init_image -> CFG RAG refine with ddim100, skip_timesteps=80 (20 steps), guidance 2.5.  Own roofline object."""
+    feature -> init_image -> CFG RAG refine with ddim100, skip_timesteps=80 (20 steps), guidance 2.5.  Own roofline object.
+    On N ranks (weak scaling, B clips per rank): the frozen CLIP text features of the GLOBAL batch exist on rank 0 only (one text
+    encoder) and are broadcast over RCCL inside the timed region -- the north star's "RCCL broadcast of the frozen CLIP text
+    embeddings" -- then every rank decodes + refines its shard and the result is all-gathered."""
     import torch
-    from livelyspeaker_amd import synth
+    from livelyspeaker_amd import shard, synth
     from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
     from livelyspeaker_amd.model_util import create_model_and_diffusion
     from livelyspeaker_amd.motionclip_module import Decoder_TRANSFORMER
@@ -263,26 +330,42 @@ def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3):
     model.cache_conditioning = False
     cfgm = ClassifierFreeSampleModel(model)
     diffusion.noise_source = "philox"
+    diffusion.sample_offset = rank * B
     sag = Decoder_TRANSFORMER(latent_dim=512, n_pre_poses=4, use_style=False)
     sag.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_sag_state_dict(cfg).items()}, strict=False)
     sag.to(dev)
     sag.eval()
-    y_np = synth.make_cond(cfg, B, scale=2.5)
+    total = world * B
+    y_np = synth.make_cond(cfg, B, scale=2.5, seed=synth.SEED_COND + rank)
     y = {k: torch.from_numpy(v).to(dev) for k, v in y_np.items()}
-    batch = {"x": y["origin_x"].clone(), "mask": torch.ones(B, 34, device=dev).bool(),
-             "z": torch.from_numpy(synth.make_text_features(B)).to(dev)}
+    # rank 0 holds the text features of all `total` clips (a device tensor, as a CLIP text encoder would leave them); the other
+    # ranks hold an empty buffer of that shape
+    z_global = (torch.from_numpy(synth.make_text_features(total)) if rank == 0 else torch.zeros(total, 512)).to(dev)
+    batch = {"x": y["origin_x"].clone(), "mask": torch.ones(B, 34, device=dev).bool(), "z": None}
+    bcast = {"ms": 0.0, "n": 0}
 
     def call(overlap=True):
         # the once-per-call stage of the refinement needs nothing from the SAG decode: enqueued first (RAG.prefetch_condition ->
         # ls_prepare_async), it runs on the engine's stream while the decoder runs on its own
         if overlap:
             cfgm.prefetch_condition(y)
+        if world > 1:
+            t0 = time.perf_counter()
+            zg = shard.broadcast_tensor(z_global, dev)              # RCCL broadcast (gloo on host copies in the shared-device test mode)
+            torch.cuda.synchronize()
+            bcast["ms"] += (time.perf_counter() - t0) * 1e3
+            bcast["n"] += 1
+            batch["z"] = zg[rank * B:(rank + 1) * B]
+        else:
+            batch["z"] = z_global
         decoded = sag(batch)["output"]
-        return diffusion.ddim_sample_loop(cfgm, (B, cfg.njoints, cfg.nfeats, cfg.nframes), clip_denoised=False, model_kwargs={"y": y},
-                                          skip_timesteps=80, init_image=decoded, progress=False, dump_steps=None, noise=None,
-                                          const_noise=False)
+        out = diffusion.ddim_sample_loop(cfgm, (B, cfg.njoints, cfg.nfeats, cfg.nframes), clip_denoised=False, model_kwargs={"y": y},
+                                         skip_timesteps=80, init_image=decoded, progress=False, dump_steps=None, noise=None,
+                                         const_noise=False)
+        return shard.gather_samples(out, total) if world > 1 else out
     call()
     eng, seng = model.engine(), sag.engine()
+    bcast["ms"], bcast["n"] = 0.0, 0
     fence()
     t0 = time.perf_counter()
     loop_ms = prep_ms = 0.0
@@ -294,11 +377,14 @@ def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3):
         prep_ms += tm["prepare_ms"]
         launches += tm["n_step_launches"]
     fence()
-    el = (time.perf_counter() - t0) / reps
-    assert bool(torch.isfinite(out).all())
+    el = max_over_ranks((time.perf_counter() - t0) / reps)
+    assert bool(torch.isfinite(out).all()) and out.shape[0] == total
+    if world > 1 and rank == 0:       # the broadcast really delivered rank 0's features: the gathered result of rank r's shard depends on them
+        assert float(out[B:].abs().sum()) > 0
     kernel_ms = loop_ms / max(launches, 1)
     ach = 2 * FLOP_PER_FORWARD["ted"] * B / (kernel_ms * 1e-3) / 1e12
     sag_ms = seng.last_decode_ms()
+    broadcast_ms = bcast["ms"] / max(bcast["n"], 1)
     # the same call in the reference's order (decode, THEN the once-per-call stage inside the sampling call), for the serial split
     call(overlap=False)
     fence()
@@ -306,11 +392,16 @@ def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3):
     for _ in range(reps):
         call(overlap=False)
     fence()
-    el_serial = (time.perf_counter() - t1) / reps
+    el_serial = max_over_ranks((time.perf_counter() - t1) / reps)
     sag_serial, prep_serial = seng.last_decode_ms(), eng.timing()["prepare_ms"]
+    eng.close()
     return {"workload": f"TED LivelySpeaker: SAG decode (synthetic CLIP text feature) + CFG RAG refine, ddim100 with skip_timesteps=80 "
-                        f"(20 DDIM steps, what scripts/test_LivelySpeaker_ted.py runs), batch {B}, guidance 2.5, Philox noise",
-            "value": round(B * cfg.nframes / el, 1), "unit": "pose-frames/s", "ms_per_call": round(el * 1e3, 3),
+                        f"(20 DDIM steps, what scripts/test_LivelySpeaker_ted.py runs), batch {B} per GPU x {world}, guidance 2.5, Philox noise",
+            "value": round(total * cfg.nframes / el, 1), "unit": "pose-frames/s", "ms_per_call": round(el * 1e3, 3), "n_gpus": world,
+            "text_feature_broadcast": (None if world == 1 else
+                                       {"ms": round(broadcast_ms, 3), "bytes": total * 512 * 4, "src": 0,
+                                        "what": "frozen CLIP text features [global batch, 512] fp32 from rank 0 to all ranks, inside the timed call; "
+                                                "followed by an all_gather of the refined clips"}),
             "overlap": "ls_prepare_async on the engine's stream under the SAG decode on its own stream; sag_decode_ms / prepare_ms below are "
                        "each stream's own span while the two share the GPU",
             "sag_decode_ms": None if sag_ms is None else round(sag_ms, 3), "prepare_ms": round(prep_ms / reps, 3),
@@ -364,9 +455,29 @@ def other_config_leg(dataset, B, dev, fence, steps=1000):
                          "flop_per_sample_step": 2 * FLOP_PER_FORWARD[dataset]}}
 
 
+def _self_launch(a):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-exec this script under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 at a free port.  The ranks inherit this process's stdout, so rank 0's ONE JSON line (written to its
+    private duplicate of fd 1, see _reserve_stdout) IS this process's stdout; everything else the ranks print goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts (RCCL P2P setup)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     global _RESULT_OUT
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(_self_launch(a))
     _RESULT_OUT = _reserve_stdout()
     import torch
     import torch.distributed as dist
@@ -378,15 +489,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s): pass --gpus {world} (or run plain "
+                         f"`python bench.py --gpus {a.gpus}`, which launches its own ranks)")
+    if a.ranks_share_device:
+        local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with a single rank)
+    backend = "none"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "gloo" if a.ranks_share_device else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = synth.CONFIGS[a.dataset]
     strong = a.global_batch > 0
@@ -436,6 +556,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        shard.all_reduce_(t, dist.ReduceOp.MAX)
+        return float(t.item())
+
     def timed(n, yy=None):
         """n calls bracketed by barrier + synchronize; max over ranks.  Returns (elapsed, loop_ms, launches, prep_ms, first_out, seed)."""
         loop_ms, launches, prep_ms, first_out, seed, gathered = 0.0, 0, 0.0, None, None, None
@@ -451,10 +578,7 @@ def main():
                 first_out, seed = out, diffusion.last_philox_seed
         fence()
         el = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+        el = max_over_ranks(el)
         return el, loop_ms, launches, prep_ms, first_out, seed, gathered
 
     torch.manual_seed(233)                  # every rank draws the same Philox key per call
@@ -482,14 +606,16 @@ def main():
             shard_check = shard.cross_check(regenerate, first_out, total, equal_shards_of=B)
 
         except Exception as e:          # symmetric on every rank (same code path); never take the headline line down
-            shard_check = {"error": repr(e)[:300], "rccl_ranks": dist.get_world_size() if use_dist else 1}
+            shard_check = {"error": repr(e)[:300], "rccl_ranks": world if backend in ("nccl", "none") else 0, "ranks": world,
+                           "collective_backend": backend}
             diffusion.sample_offset, diffusion.philox_seed = first, None
 
-    extra = not a.no_extra_legs and a.precision == "fp32"
+    extra = not a.no_extra_legs and a.precision == "fp32" and a.legs != "none"
+    legs = set(("single", "split", "lively", "beat", "train", "seeds") if a.legs in ("all", "none") else a.legs.split(","))
 
     # Secondary object: guidance scale 1 (what the reference's callers run): the uncond pass is legitimately skipped
     single = None
-    if extra and a.scale != 1.0:
+    if extra and a.scale != 1.0 and "single" in legs:
         y1 = dict(y, scale=torch.ones(B, device=dev))
         one_call(y1)
         n1 = max(1, min(a.steps, 2))
@@ -507,7 +633,7 @@ def main():
 
     # Secondary leg (never the headline `value`): the opt-in bf16x3 split-precision mode, same workload, same run.
     split = None
-    if extra and not a.no_split_leg:
+    if extra and not a.no_split_leg and "split" in legs:
         model.precision = "bf16x3"
         one_call()
         n2 = max(1, min(a.steps, 2))
@@ -519,17 +645,50 @@ def main():
                  "note": "opt-in (RAG.precision / ls_set_precision); the headline value above is the exact-fp32 path"}
         model.precision = "fp32"
 
-    lively = None
-    if extra and a.dataset == "ted" and world == 1:
+    # Secondary object: the reference's own RNG contract ("identical seeds"): every draw of the loop made from torch's CPU generator
+    # in the reference's order, in K-step segments through two page-locked buffers, uploaded under the previous segment's steps
+    seeds = None
+    if extra and world == 1 and "seeds" in legs and a.dataset != "beat150":
         try:
-            lively = livelyspeaker_leg(cfg, sd, dev, B, fence)
+            diffusion.noise_source = "torch_cpu"
+            torch.manual_seed(233)
+            fence()
+            t0 = time.perf_counter()
+            o_s, _ = one_call()
+            fence()
+            e_s = time.perf_counter() - t0
+            tm = eng.timing()
+            assert bool(torch.isfinite(o_s).all())
+            per_step = (2 * B * 512 + B * cfg.jf * cfg.nframes) * 4
+            n_seg = int(diffusion.last_tape_segments)
+            n_exec_s = diffusion.num_timesteps - a.skip
+            seeds = {"workload": "same as the headline but noise_source='torch_cpu': x_T, two style eps and one randn_like(x) per step drawn from "
+                                 "torch's CPU generator in the reference's order (gaussian_diffusion.py:700-743, RAG.py:120), so "
+                                 "torch.manual_seed(s) reproduces the reference's CPU samples (fixture G7)",
+                     "value": round(total * cfg.nframes / e_s, 2), "unit": "pose-frames/s", "ms_per_call": round(e_s * 1e3, 1),
+                     "host_rng_ms": round(diffusion.last_host_rng_ms, 1), "upload_ms": round(tm["tape_upload_ms"], 2),
+                     "gpu_loop_ms": round(tm["loop_ms"], 1), "segments": n_seg, "steps_per_segment": -(-n_exec_s // max(n_seg, 1)),
+                     "tape_bytes_if_one_piece": per_step * n_exec_s,
+                     "pinned_host_bytes": 2 * (-(-n_exec_s // max(n_seg, 1))) * per_step if n_seg > 1 else per_step * n_exec_s,
+                     "bound": "host RNG (a single-threaded normal generator feeding 2 x B x 512 + B x J x F x T draws per step); the uploads "
+                              "run on the copy stream under the previous segment's steps",
+                     "hipgraph": False if n_seg > 1 else bool(diffusion.use_graph)}
+        except Exception as e:
+            seeds = {"error": repr(e)[:300]}
+        finally:
+            diffusion.noise_source = "philox"
+
+    lively = None
+    if extra and a.dataset == "ted" and not strong and "lively" in legs:
+        try:
+            lively = livelyspeaker_leg(cfg, sd, dev, B, fence, world=world, rank=rank, max_over_ranks=max_over_ranks)
         except Exception as e:                      # never let a secondary leg take the headline line down
             lively = {"error": repr(e)[:300]}
 
     # BASELINE configs[4] in the same run (1 GPU only): BEAT at the reference's 34 frames with the whole 256-clip job on this GPU, and the
     # synthetic 150-frame variant at one GPU's share (256 / 8 = 32 clips)
     others = None
-    if extra and a.dataset == "ted" and world == 1:
+    if extra and a.dataset == "ted" and world == 1 and "beat" in legs:
         others = {}
         for name, ds, bb in (("beat_34_frames_b256", "beat", 256), ("beat150_synthetic_b32", "beat150", 32)):
             try:
@@ -539,7 +698,7 @@ def main():
 
     # Secondary leg: one optimisation step of the denoiser, data-parallel over the ranks.
     train = None
-    if extra and (a.train_leg or world == 1) and not a.no_train_leg and not strong:
+    if extra and (a.train_leg or world == 1) and not a.no_train_leg and not strong and "train" in legs:
         try:
             train = train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence)
         except Exception as e:
@@ -554,7 +713,10 @@ def main():
         achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
         # fp32: FP32-matrix MFMA peak.  bf16x3: three bf16 MFMAs per algorithmic product -> dense bf16 peak / 3.
         peak = MFMA_F32_PEAK_TFLOPS if a.precision == "fp32" else round(2500.0 / 3.0, 1)
-        traffic, traffic_src = pmc_traffic(a.dataset, B)
+        committed, committed_src = pmc_traffic(a.dataset, B)
+        traffic, traffic_src = None, "not measured (--no-traffic-pass)"
+        if world == 1 and not a.no_traffic_pass and a.dataset != "beat150" and a.precision == "fp32":
+            traffic, traffic_src = measure_traffic(a, B)
         rec = {
             "metric": "pose-frames/sec denoised", "value": round(frames / elapsed, 2), "unit": "pose-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
@@ -577,12 +739,17 @@ def main():
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_unit": "B/launch (rocprofv3 PMC)", "traffic_source": traffic_src,
+                         "traffic_from_committed_profile": committed, "traffic_from_committed_profile_source": committed_src,
                          "kernel_ms": round(kernel_ms, 4), "flop_per_launch": flop_launch,
                          "prepare_ms_per_call": round(prep_ms / a.steps, 3)},
         }
         if shard_check is not None:
             rec["shard_check"] = shard_check
             rec["rccl_ranks"] = shard_check["rccl_ranks"]
+            rec["collective_backend"] = backend
+            if a.ranks_share_device:
+                rec["ranks_share_device"] = ("TEST MODE: all ranks on cuda:0, collectives over gloo on host copies (RCCL rejects duplicate "
+                                             "devices); `value` is not a scaling number")
         if not a.no_parity:
             try:
                 rec["parity_in_run"] = parity_in_run(cfg, a, first_out.detach().cpu().numpy(), first_seed, first, y_np, a.parity_samples)
@@ -590,6 +757,8 @@ def main():
                 rec["parity_in_run"] = {"error": repr(e)[:300]}
         if single is not None:
             rec["single_pass"] = single
+        if seeds is not None:
+            rec["identical_seeds_mode"] = seeds
         if lively is not None:
             rec["livelyspeaker"] = lively
         if others is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LS_ABI_VERSION 1
+#define LS_ABI_VERSION 2
 
 enum {
     LS_OK = 0,
@@ -106,7 +106,10 @@ typedef struct ls_sample_args {
     int32_t use_graph;          /* 1: capture the step loop in a hipGraph and replay */
     int32_t clip_denoised;      /* clamp pred_xstart to [-1,1] (callers pass False)  */
     int32_t two_pass_always;    /* 0: when every scale == 1 the uncond pass is skipped (out_u + 1*(out_c - out_u) = out_c,
-                                   cfg_sampler.py:31; the callers run guidance_param = 1); 1: always evaluate both passes */
+                                   cfg_sampler.py:31; the callers run guidance_param = 1); 1: always evaluate both passes.
+                                   NOT bit-identical: in fp32 out_u + 1*(out_c - out_u) differs from out_c by up to one rounding
+                                   of the larger term, so the two settings agree to ~1e-5 on samples (tests: <= 3e-4), not bitwise;
+                                   with 0, ls_step / ls_forward-style raw outputs of the uncond pass are not produced. */
     float eta;                  /* DDIM eta (callers never pass it: 0)              */
     int32_t n_dump;             /* dump_steps (DDPM only, :660-671)                 */
     const int32_t* dump_steps;  /* executed-step counters (0 = first executed step), host memory */
@@ -118,13 +121,24 @@ typedef struct ls_sample_args {
     uint64_t seed;              /* PHILOX key                                       */
     uint64_t sample_offset;     /* PHILOX: global index of sample 0 (shard-invariant streams) */
     float* out;                 /* [B, J, F, T]                                     */
+    /* Segmented TAPE mode (seg_count > 0): this call runs the executed-step counters [seg_begin, seg_begin + seg_count) of the loop
+     * and eps_tape / noise_tape hold THOSE steps only ([seg_count, 2, B, D] / [seg_count, B, J, F, T]) -- the reference's
+     * "identical seeds" mode draws two style eps and one randn_like(x) per step from the host generator
+     * (gaussian_diffusion.py:700-743, RAG.py:120), 4 GB for 512 clips x 1000 steps if drawn in one piece.  seg_begin == 0 starts the
+     * loop (x_init / init_image are read then); x_t stays in the handle between segments; segments must follow each other in
+     * order; `out` (and dump_out) are written by the segment that ends the loop, which is also the only one that waits for the GPU.
+     * Host tapes (on_device == 0) are uploaded on the handle's COPY stream into a two-slot device buffer while the previous
+     * segment's steps run; they should be page-locked, and a segment's host buffers may be reused as soon as the NEXT segment call
+     * has returned.  Plain launches (use_graph is ignored).  seg_count == 0: the whole loop in one call (everything above). */
+    int32_t seg_begin;
+    int32_t seg_count;
 } ls_sample_args;
 
 /* One RAG.forward pair (cond / uncond) and optionally the CFG combination, for model(x,t,y)
  * parity (RAG.py:98-133, cfg_sampler.py:24-31). Any of the three outputs may be NULL. */
 typedef struct ls_forward_args {
     int32_t on_device;
-    int32_t reserved;
+    int32_t no_sync;            /* on_device only: return without waiting for the GPU (order consumers with ls_stream_order) */
     const float* x;             /* [B,J,F,T]                                        */
     const int64_t* timesteps;   /* [B] model-scale t in [0, 5000)                   */
     const float* eps_cond;      /* [B, latent_dim] randn_like of reparameterize (RAG.py:12) */
@@ -135,10 +149,11 @@ typedef struct ls_forward_args {
     float* trace;               /* debug: [B, layers+1, 2*S, latent_dim] residual stream, or NULL */
 } ls_forward_args;
 
-/* One p_sample / ddim_sample step (gaussian_diffusion.py:507-558, 745-798) at schedule index i. */
+/* One p_sample / ddim_sample step (gaussian_diffusion.py:507-558, 745-798) at schedule index i -- or, as the reference's
+ * signature allows (`t` is a [B] tensor), at one schedule index PER SAMPLE (`indices`). */
 typedef struct ls_step_args {
     int32_t sampler;
-    int32_t index;              /* schedule index i (model sees timestep_map[i])    */
+    int32_t index;              /* schedule index i (model sees timestep_map[i]); ignored when indices != NULL */
     int32_t on_device;
     float eta;
     int32_t clip_denoised;
@@ -149,6 +164,14 @@ typedef struct ls_step_args {
     const float* noise;         /* [B,J,F,T]                                        */
     float* sample;              /* [B,J,F,T]                                        */
     float* pred_xstart;         /* [B,J,F,T] or NULL                                */
+    const int64_t* indices;     /* [B] schedule index per sample, or NULL (uniform `index`).  When the entries differ the denoiser runs
+                                   with one timestep-embedding row per sample and the posterior / DDIM update is a separate
+                                   elementwise kernel with per-sample coefficients (same arithmetic as the fused epilogue).  HOST
+                                   indices are validated (a constant vector takes the fused path); DEVICE indices
+                                   (indices_on_device) are never read by the host -- no round trip in a step-by-step caller --
+                                   always take the per-sample path and are clamped into [0, n_steps). */
+    int32_t no_sync;            /* on_device only: return without waiting for the GPU (order consumers with ls_stream_order) */
+    int32_t indices_on_device;
 } ls_step_args;
 
 typedef struct ls_timing {
@@ -158,6 +181,8 @@ typedef struct ls_timing {
     int32_t n_step_launches;
     int32_t graph_replayed;     /* 1 if the loop ran as a hipGraph replay           */
     int32_t single_pass;        /* 1 if the loop ran the single-pass (scale == 1) kernel */
+    float tape_upload_ms;       /* segmented TAPE mode: summed GPU-side duration of the tape uploads of the last loop (copy stream) */
+    int32_t n_segments;         /* segments the last loop ran in (1 = one call)     */
 } ls_timing;
 
 int ls_abi_version(void);
@@ -176,7 +201,9 @@ int ls_set_schedule(ls_handle* h, const ls_schedule* s);
 int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */
 /* The same, enqueued on the handle's stream WITHOUT waiting: later calls on this handle are ordered behind it, so the caller may
  * overlap it with work on another stream (LivelySpeaker: the SAG decode, scripts/test_LivelySpeaker_ted.py:88-113, needs none of it).
- * Device-resident inputs must stay valid until the next synchronising call on this handle; ls_timing.prepare_ms reads -1 until then. */
+ * Device-resident inputs must stay valid until the next synchronising call on this handle; HOST inputs (on_device == 0) have been
+ * copied out of the caller's buffers when the call returns (it waits for those copies, not for the kernels);
+ * ls_timing.prepare_ms reads -1 until the work is known to be done. */
 int ls_prepare_async(ls_handle* h, const ls_cond* c);
 int ls_sample(ls_handle* h, const ls_sample_args* a);
 int ls_forward(ls_handle* h, const ls_forward_args* a);
@@ -204,6 +231,15 @@ int ls_shard_range(int64_t total, int32_t world, int32_t rank, int64_t* first, i
 int ls_get_timing(const ls_handle* h, ls_timing* out);
 int ls_synchronize(ls_handle* h);
 
+/* Stream ordering instead of host synchronisation.  Every handle runs on its own non-blocking HIP stream, which nothing orders
+ * against the caller's streams.  ls_stream_order(device, first, then): work enqueued on `then` AFTER this call waits for the work
+ * enqueued on `first` BEFORE it (an event recorded on `first`, hipStreamWaitEvent on `then`); both are hipStream_t values
+ * (NULL = the device's default stream).  A caller whose inputs were produced on its own stream orders (its stream, handle stream)
+ * before an entry point instead of synchronising the host, and (handle stream, its stream) after a no_sync call before it
+ * consumes device outputs.  The accessors return each handle's stream. */
+int ls_stream_order(int device, void* first, void* then);
+void* ls_stream(const ls_handle* h);
+
 /* ---- SAG decoder ---------------------------------------------------------------
  * Decoder_TRANSFORMER (scripts/model/motionclip_module.py:98-183), called as SAG.decoder(batch) at
  * scripts/test_LivelySpeaker_ted.py:88 to produce init_image for the RAG refine loop.  Separate handle: it is a
@@ -227,6 +263,7 @@ int ls_sag_commit_weights(ls_sag* h);
 int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask,
                   float* out);
 float ls_sag_last_decode_ms(const ls_sag* h);   /* GPU time of the last ls_sag_decode (HIP events on the handle's stream) */
+void* ls_sag_stream(const ls_sag* h);
 
 /* ---- caller-side post-processing of sampled clips ---------------------------------
  * scripts/test_RAG_ted.py:84-111 (layout change, mean add, per-bone normalisation, joint-angle change curve, motion
@@ -310,6 +347,7 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* b, float* gra
 int ls_train_adamw(ls_trainer* h, const float* grad, float lr, float beta1, float beta2, float eps, float weight_decay);
 /* debug / test access to a named internal tensor of the last forward ("out" [B,T,JF], "x_t", "audio_feat" ...) */
 int ls_train_read(ls_trainer* h, const char* what, float* out, size_t n);
+void* ls_train_stream(const ls_trainer* h);
 
 /* ---- FGD feature extractor -------------------------------------------------------
  * EmbeddingNet(...).pose_encoder in eval mode: poses [B, n_frames, pose_dim] -> latent mean [B, base]
@@ -331,6 +369,7 @@ const char* ls_eval_last_error(const ls_eval* h);
 int ls_eval_set_weight(ls_eval* h, const char* key, const float* data, size_t n);
 int ls_eval_commit_weights(ls_eval* h);
 int ls_eval_features(ls_eval* h, int batch, int on_device, const float* poses, float* feat);
+void* ls_eval_stream(const ls_eval* h);
 
 #ifdef __cplusplus
 }

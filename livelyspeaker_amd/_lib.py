@@ -46,11 +46,11 @@ class LsSampleArgs(C.Structure):
                 ("clip_denoised", C.c_int32), ("two_pass_always", C.c_int32), ("eta", C.c_float), ("n_dump", C.c_int32), ("dump_steps", c_i32p), ("dump_out", C.c_void_p),
                 ("x_init", C.c_void_p), ("init_image", C.c_void_p), ("eps_tape", C.c_void_p),
                 ("noise_tape", C.c_void_p), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
-                ("out", C.c_void_p)]
+                ("out", C.c_void_p), ("seg_begin", C.c_int32), ("seg_count", C.c_int32)]
 
 
 class LsForwardArgs(C.Structure):
-    _fields_ = [("on_device", C.c_int32), ("reserved", C.c_int32), ("x", C.c_void_p), ("timesteps", C.c_void_p),
+    _fields_ = [("on_device", C.c_int32), ("no_sync", C.c_int32), ("x", C.c_void_p), ("timesteps", C.c_void_p),
                 ("eps_cond", C.c_void_p), ("eps_uncond", C.c_void_p), ("out_cond", C.c_void_p),
                 ("out_uncond", C.c_void_p), ("out_cfg", C.c_void_p), ("trace", C.c_void_p)]
 
@@ -58,7 +58,8 @@ class LsForwardArgs(C.Structure):
 class LsStepArgs(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("index", C.c_int32), ("on_device", C.c_int32), ("eta", C.c_float),
                 ("clip_denoised", C.c_int32), ("two_pass_always", C.c_int32), ("x", C.c_void_p), ("eps_cond", C.c_void_p), ("eps_uncond", C.c_void_p), ("noise", C.c_void_p),
-                ("sample", C.c_void_p), ("pred_xstart", C.c_void_p)]
+                ("sample", C.c_void_p), ("pred_xstart", C.c_void_p), ("indices", C.c_void_p), ("no_sync", C.c_int32),
+                ("indices_on_device", C.c_int32)]
 
 
 class LsSagConfig(C.Structure):
@@ -75,7 +76,8 @@ class LsPostConfig(C.Structure):
 
 class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32), ("single_pass", C.c_int32)]
+                ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32), ("single_pass", C.c_int32),
+                ("tape_upload_ms", C.c_float), ("n_segments", C.c_int32)]
 
 
 class LsTrainConfig(C.Structure):
@@ -99,7 +101,7 @@ class LsEvalConfig(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
@@ -170,6 +172,10 @@ def load_library(build_if_missing: bool = True):
     lib.ls_read.restype = C.c_longlong
     lib.ls_get_timing.argtypes = [C.c_void_p, C.POINTER(LsTiming)]
     lib.ls_synchronize.argtypes = [C.c_void_p]
+    lib.ls_stream_order.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    for fn in ("ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream"):
+        getattr(lib, fn).argtypes = [C.c_void_p]
+        getattr(lib, fn).restype = C.c_void_p
     lib.ls_philox_x_init.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     lib.ls_set_precision.argtypes = [C.c_void_p, C.c_int]
     lib.ls_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, c_i64p, c_i64p]
@@ -214,7 +220,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_eval_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     lib.ls_eval_commit_weights.argtypes = [C.c_void_p]
     lib.ls_eval_features.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    if lib.ls_abi_version() != 1:
+    if lib.ls_abi_version() != 2:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -229,9 +235,10 @@ class _Marshal:
     If ANY member is a CUDA tensor the whole group is passed as device pointers (on_device=1) and outputs
     are torch CUDA tensors; otherwise everything is host numpy.  Keeps the converted buffers alive."""
 
-    def __init__(self, device_index: int, *members):
+    def __init__(self, device_index: int, *members, stream=None):
         self.on_device = any(_is_cuda(m) for m in members if m is not None)
         self.device_index = device_index
+        self.stream = stream        # the handle's HIP stream (ls_stream & co.): inputs are ordered in front of it, not host-synchronised
         self.keep = []
         if self.on_device:
             import torch
@@ -265,9 +272,20 @@ class _Marshal:
     def ready(self):
         """Call right before the ABI call.  The engine's streams are non-blocking (nothing orders them against torch's), and the
         inputs -- as well as the dtype / contiguity conversions `_conv` may have just enqueued (e.g. the strided `emo[:, 0]` of
-        the BEAT callers) -- were produced on torch's current stream: finish that stream first."""
+        the BEAT callers) and the allocation of the outputs -- belong to torch's current stream: the handle's stream is made to
+        wait for that stream's work so far (an event, ls_stream_order) instead of the host waiting for it."""
         if self.on_device:
-            self.torch.cuda.current_stream(self.dev).synchronize()
+            ts = self.torch.cuda.current_stream(self.dev).cuda_stream
+            if self.stream is None or load_library().ls_stream_order(self.device_index, C.c_void_p(ts), C.c_void_p(self.stream)) != 0:
+                self.torch.cuda.current_stream(self.dev).synchronize()
+
+    def done_async(self):
+        """After a no_sync ABI call: torch's current stream waits for the handle's work (outputs, and inputs it still reads), so
+        consumers on that stream and the allocator's reuse of the marshalled temporaries stay ordered without a host wait."""
+        if self.on_device:
+            ts = self.torch.cuda.current_stream(self.dev).cuda_stream
+            if self.stream is None or load_library().ls_stream_order(self.device_index, C.c_void_p(self.stream), C.c_void_p(ts)) != 0:
+                raise EngineError("ls_stream_order failed")
 
     def out(self, shape):
         """(object, pointer) for an fp32 output of this call."""
@@ -276,6 +294,14 @@ class _Marshal:
             return t, C.c_void_p(t.data_ptr())
         n = np.empty(tuple(shape), np.float32)
         return n, n.ctypes.data_as(C.c_void_p)
+
+
+def _order_after_torch(device_index: int, stream) -> None:
+    """Make a handle's stream wait for the work enqueued so far on torch's current stream of that device."""
+    import torch
+    ts = torch.cuda.current_stream(torch.device("cuda", device_index))
+    if stream is None or load_library().ls_stream_order(device_index, C.c_void_p(ts.cuda_stream), C.c_void_p(stream)) != 0:
+        ts.synchronize()
 
 
 def _np32(a) -> np.ndarray:
@@ -298,6 +324,7 @@ class Engine:
         rc = self.lib.ls_create(C.byref(self.cfg), C.byref(self.h))
         if rc != 0:
             raise EngineError(f"ls_create failed ({rc}): {self.lib.ls_last_error(None).decode()}")
+        self._stream = self.lib.ls_stream(self.h)
         self.J, self.F, self.T, self.D = njoints, nfeats, nframes, latent_dim
         self.S = nframes + n_prefix_tokens
         self.layers = layers
@@ -355,9 +382,17 @@ class Engine:
         step is ordered behind it, and work on other streams (the SAG decode) overlaps it.  The marshalled inputs are kept alive on
         this object until the next prepare, by which time a synchronising call has long consumed them."""
         emo = y.get("emo") if self.cfg.n_prefix_tokens == 2 else None
-        if emo is not None and getattr(emo, "ndim", 2) == 1:   # a bare [B] id vector: broadcast to the callers' [B, T] form
-            emo = emo[:, None].repeat(1, self.T) if hasattr(emo, "repeat") and not isinstance(emo, np.ndarray) else np.repeat(np.asarray(emo)[:, None], self.T, 1)
-        m = _Marshal(self.device, y["audio_input"], y["origin_x"], y["vid_indices"], y["scale"], emo)
+        if emo is not None:
+            # scripts_beat/model/RAG.py:125 reads y['emo'][:, 0] only, whatever the width: a bare [B] vector, [B, 1] or any padded
+            # [B, W] is accepted and presented to the ABI in its [B, T] form (column 0 repeated)
+            if getattr(emo, "ndim", 2) not in (1, 2):
+                raise EngineError(f"y['emo'] must be [B] or [B, W], got shape {tuple(emo.shape)}")
+            col = emo if emo.ndim == 1 else emo[:, 0]
+            if hasattr(col, "expand") and not isinstance(col, np.ndarray):
+                emo = col[:, None].expand(col.shape[0], self.T)
+            else:
+                emo = np.broadcast_to(np.asarray(col)[:, None], (len(col), self.T))
+        m = _Marshal(self.device, y["audio_input"], y["origin_x"], y["vid_indices"], y["scale"], emo, stream=self._stream)
         B = int(y["audio_input"].shape[0])
         c = LsCond(B, int(m.on_device), m.f32(y["audio_input"], (B, self.cfg.audio_len)),
                    m.f32(y["origin_x"], (B, self.J, self.F, self.T)), m.i64(y["vid_indices"], (B,)),
@@ -375,7 +410,7 @@ class Engine:
         return (self.batch, self.J, self.F, self.T)
 
     def forward(self, x, t, eps_c, eps_u, trace=False):
-        m = _Marshal(self.device, x, t, eps_c, eps_u)
+        m = _Marshal(self.device, x, t, eps_c, eps_u, stream=self._stream)
         B, D = self.batch, self.D
         eps_c = eps_c.reshape(B, D)
         eps_u = eps_u.reshape(B, D)
@@ -389,36 +424,65 @@ class Engine:
         self._check(self.lib.ls_forward(self.h, C.byref(a)), "ls_forward")
         return (oc, ou, og, tr) if trace else (oc, ou, og)
 
-    def step(self, sampler, index, x, eps_c, eps_u, noise, eta=0.0, clip_denoised=False, two_pass_always=False):
-        m = _Marshal(self.device, x, eps_c, eps_u, noise)
+    def step(self, sampler, index, x, eps_c, eps_u, noise, eta=0.0, clip_denoised=False, two_pass_always=False, indices=None,
+             no_sync=False):
+        """One p_sample / ddim_sample step.  ``indices``: one schedule index per sample ([B] int64; numpy / CPU tensor = validated
+        on the host, CUDA tensor = never read by the host) instead of the uniform ``index``.  ``no_sync`` (device tensors only):
+        return without waiting for the GPU; the outputs are ordered behind the step on torch's current stream."""
+        m = _Marshal(self.device, x, eps_c, eps_u, noise, stream=self._stream)
         B, D = self.batch, self.D
         out, pout = m.out(self._xshape())
         x0, px0 = m.out(self._xshape())
-        a = LsStepArgs(sampler, index, int(m.on_device), eta, int(clip_denoised), int(two_pass_always), m.f32(x, self._xshape()),
-                       m.f32(eps_c.reshape(B, D)), m.f32(eps_u.reshape(B, D)), m.f32(noise, self._xshape()), pout, px0)
+        pidx, idx_dev = None, 0
+        if indices is not None:
+            if _is_cuda(indices):
+                if not m.on_device:
+                    raise EngineError("device `indices` need device tensors for the other arguments")
+                t = indices.to(dtype=m.torch.int64).contiguous()
+                if tuple(t.shape) != (B,):
+                    raise EngineError(f"indices must be [{B}], got {tuple(t.shape)}")
+                m.keep.append(t)
+                pidx, idx_dev = C.c_void_p(t.data_ptr()), 1
+            else:
+                n = np.ascontiguousarray(indices.detach().cpu().numpy() if hasattr(indices, "detach") else indices, dtype=np.int64)
+                if n.shape != (B,):
+                    raise EngineError(f"indices must be [{B}], got {n.shape}")
+                m.keep.append(n)
+                pidx = n.ctypes.data_as(C.c_void_p)
+        nosync = int(bool(no_sync) and m.on_device)
+        a = LsStepArgs(sampler, int(index), int(m.on_device), eta, int(clip_denoised), int(two_pass_always), m.f32(x, self._xshape()),
+                       m.f32(eps_c.reshape(B, D)), m.f32(eps_u.reshape(B, D)), m.f32(noise, self._xshape()), pout, px0, pidx, nosync, idx_dev)
         m.ready()
         self._check(self.lib.ls_step(self.h, C.byref(a)), "ls_step")
+        if nosync:
+            m.done_async()
+            self._inflight = m          # marshalled copies stay referenced until the next call replaces them
         return out, x0
 
     def sample(self, sampler=LS_SAMPLER_DDPM, x_init=None, eps_tape=None, noise_tape=None, init_image=None,
                skip_timesteps=0, eta=0.0, const_noise=False, dump_steps=None, philox_seed=None, sample_offset=0,
-               use_graph=True, clip_denoised=False, device_out=False, two_pass_always=False):
+               use_graph=True, clip_denoised=False, device_out=False, two_pass_always=False, segment=None):
         """Run the whole loop. TAPE mode when tapes are given, PHILOX mode when ``philox_seed`` is.
         Outputs are torch CUDA tensors if any input is one (or ``device_out``), else numpy."""
         members = [x_init, eps_tape, noise_tape, init_image]
         if device_out:
             import torch
             members.append(torch.empty(1, device=torch.device("cuda", self.device)))
-        m = _Marshal(self.device, *members)
+        m = _Marshal(self.device, *members, stream=self._stream)
         a = LsSampleArgs()
         a.sampler, a.skip_timesteps, a.const_noise, a.on_device = sampler, skip_timesteps, int(const_noise), int(m.on_device)
         a.use_graph, a.eta, a.clip_denoised = int(use_graph), eta, int(clip_denoised)
         a.two_pass_always = int(two_pass_always)
         n_exec = self.n_steps - skip_timesteps
+        if segment is not None:         # (first executed-step counter, count): one piece of a TAPE-mode loop, tapes hold these steps only
+            a.seg_begin, a.seg_count = int(segment[0]), int(segment[1])
+            n_tape, last = a.seg_count, a.seg_begin + a.seg_count == n_exec
+        else:
+            n_tape, last = n_exec, True
         if philox_seed is None:
             a.noise_mode = LS_NOISE_TAPE
-            a.eps_tape = m.f32(eps_tape, (n_exec, 2, self.batch, self.D))
-            a.noise_tape = m.f32(noise_tape, (n_exec,) + self._xshape())
+            a.eps_tape = m.f32(eps_tape, (n_tape, 2, self.batch, self.D))
+            a.noise_tape = m.f32(noise_tape, (n_tape,) + self._xshape())
         else:
             a.noise_mode = LS_NOISE_PHILOX
             a.seed, a.sample_offset = int(philox_seed), int(sample_offset)
@@ -433,10 +497,14 @@ class Engine:
             m.keep.append(ds)
         m.ready()
         self._check(self.lib.ls_sample(self.h, C.byref(a)), "ls_sample")
+        if not last:
+            self._segment_inputs = m     # page-locked host tapes of this segment: referenced until the next segment call has returned
+            return None
+        self._segment_inputs = None
         return (out, dumps) if dump_steps else out
 
     def q_sample(self, index, x_start, noise):
-        m = _Marshal(self.device, x_start, noise)
+        m = _Marshal(self.device, x_start, noise, stream=self._stream)
         out, pout = m.out(tuple(x_start.shape))
         n = int(np.prod(x_start.shape))
         m.ready()
@@ -480,6 +548,7 @@ class SagEngine:
         if rc != 0:
             raise EngineError(f"ls_sag_create failed ({rc}): {self.lib.ls_sag_last_error(None).decode()}")
         self.J, self.F, self.T, self.D, self.device = njoints, nfeats, nframes, latent_dim, device
+        self._stream = self.lib.ls_sag_stream(self.h)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -506,7 +575,7 @@ class SagEngine:
         return float(self.lib.ls_sag_last_decode_ms(self.h))
 
     def decode(self, x, z, mask=None):
-        m = _Marshal(self.device, x, z, mask)
+        m = _Marshal(self.device, x, z, mask, stream=self._stream)
         B = int(x.shape[0])
         out, pout = m.out((B, self.J, self.F, self.T))
         pmask = None
@@ -542,6 +611,7 @@ class Trainer:
         if rc != 0:
             raise EngineError(f"ls_train_create failed ({rc}): {self.lib.ls_train_last_error(None).decode()}")
         self.J, self.F, self.T, self.device, self.n_prefix = njoints, nfeats, nframes, device, n_prefix_tokens
+        self._stream = self.lib.ls_train_stream(self.h)
         self.params = {}
         key = C.create_string_buffer(256)
         off, num = C.c_int64(), C.c_int64()
@@ -594,7 +664,7 @@ class Trainer:
     def forward_backward(self, x_start, t, noise, y: dict, drop, eps) -> dict:
         """One forward + loss + backward; gradients land in ``self.grad`` (flat, device). Returns the loss terms."""
         import torch
-        m = _Marshal(self.device, x_start, noise, drop, eps, y["audio_input"], y["origin_x"], y["vid_indices"], y.get("emo"))
+        m = _Marshal(self.device, x_start, noise, drop, eps, y["audio_input"], y["origin_x"], y["vid_indices"], y.get("emo"), stream=self._stream)
         B = int(x_start.shape[0])
         xs = (B, self.J, self.F, self.T)
         tt = np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.int64)
@@ -605,7 +675,7 @@ class Trainer:
                           m.i64(y["emo"], (B, self.T)) if self.n_prefix == 2 else None)
         terms = LsTrainTerms()
         m.ready()
-        torch.cuda.current_stream(self.grad.device).synchronize()
+        _order_after_torch(self.device, self._stream)     # whatever last touched self.grad on torch's stream (zero_, an all-reduce)
         self._check(self.lib.ls_train_forward_backward(self.h, C.byref(tb), C.c_void_p(self.grad.data_ptr()), C.byref(terms)),
                     "ls_train_forward_backward")
         return {n: float(getattr(terms, n)) for n in ("rot_mse", "vel_mse", "kld", "loss", "total", "fwd_ms", "bwd_ms")}
@@ -615,8 +685,7 @@ class Trainer:
         return {k: g[o:o + n].reshape(self.shapes.get(k, (n,))).copy() for k, (o, n) in self.params.items()}
 
     def adamw(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        import torch
-        torch.cuda.current_stream(self.grad.device).synchronize()     # an all-reduce of self.grad may still be in flight
+        _order_after_torch(self.device, self._stream)     # an all-reduce of self.grad may still be in flight: ordered, not waited for
         self._check(self.lib.ls_train_adamw(self.h, C.c_void_p(self.grad.data_ptr()), lr, betas[0], betas[1], eps, weight_decay),
                     "ls_train_adamw")
 
@@ -654,6 +723,7 @@ class EvalEngine:
         if rc != 0:
             raise EngineError(f"ls_eval_create failed ({rc}): {self.lib.ls_eval_last_error(None).decode()}")
         self.pose_dim, self.T, self.base, self.device = pose_dim, n_frames, base, device
+        self._stream = self.lib.ls_eval_stream(self.h)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -677,7 +747,7 @@ class EvalEngine:
         self._check(self.lib.ls_eval_commit_weights(self.h), "ls_eval_commit_weights")
 
     def features(self, poses):
-        m = _Marshal(self.device, poses)
+        m = _Marshal(self.device, poses, stream=self._stream)
         B = int(poses.shape[0])
         out, pout = m.out((B, self.base))
         m.ready()

@@ -66,7 +66,13 @@ struct ls_handle {
     DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_stats, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [0..3] sample / step timing, [4..5] ls_prepare
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [0..3] sample / step timing, [4..5] ls_prepare, [6] host-input copies of ls_prepare_async
+    // segmented TAPE mode (ls_sample_args.seg_count > 0): tapes arrive in pieces, uploaded on a second stream into two device slots
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_cs[2] = {nullptr, nullptr}, ev_cd[2] = {nullptr, nullptr}, ev_seg[2] = {nullptr, nullptr};   // upload start / done, steps done (per slot)
+    bool slot_used[2] = {false, false}, upload_open[2] = {false, false};
+    int seg_next = -1, seg_index = 0, seg_skip = 0, seg_sampler = 0;
+    float seg_upload_ms = 0.f;
     bool prepare_pending = false;                                                  // ls_prepare_async enqueued, prepare_ms not read back yet
     std::string err;
 
@@ -100,6 +106,8 @@ struct ls_handle {
     DevBuf audio_feat, spart;
     DevBuf xa, xb, xtmp, xio, fwd_c, fwd_u, fwd_cfg, eps, noise, tfwd, tfwd_tmp, tidx, dump, trace, callp;
     DevBuf eps_tape, noise_tape;
+    DevBuf eps_slot[2], noise_slot[2], coef;
+    std::string coef_key;   // (sampler, eta, schedule) the per-index coefficient table `coef` was built for
 
     // cached graph of the step loop
     hipGraph_t graph = nullptr;
@@ -120,6 +128,7 @@ struct ls_handle {
 namespace {
 
 hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st);
+void resolve_prepare_timing(ls_handle* h, bool block);
 
 int fail(ls_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -561,6 +570,139 @@ void fill_sampler(ls_handle* h, StepArgs& a, int sampler, int i, float eta) {
     }
 }
 
+
+// prepare_ms of an ls_prepare_async whose work has finished (called behind every stream synchronisation; `block`: wait for it)
+void resolve_prepare_timing(ls_handle* h, bool block) {
+    if (!h->prepare_pending) return;
+    if (block ? hipEventSynchronize(h->ev[5]) != hipSuccess : hipEventQuery(h->ev[5]) != hipSuccess) return;
+    if (hipEventElapsedTime(&h->timing.prepare_ms, h->ev[4], h->ev[5]) == hipSuccess) h->prepare_pending = false;
+}
+
+// upload timing of a slot whose copy has been enqueued: wait for it (long done in steady state) and add it to the loop's total
+int close_upload(ls_handle* h, int slot) {
+    if (!h->upload_open[slot]) return LS_OK;
+    HIPCHK(h, hipEventSynchronize(h->ev_cd[slot]));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_cs[slot], h->ev_cd[slot]));
+    h->seg_upload_ms += ms;
+    h->upload_open[slot] = false;
+    return LS_OK;
+}
+
+// ls_sample with seg_count > 0: one piece of a TAPE-mode loop (see ls_sample_args in ls_hip.h)
+int sample_segment(ls_handle* h, const ls_sample_args* a) {
+    if (a->noise_mode != LS_NOISE_TAPE) return fail(h, LS_EINVAL, "segmented sampling is for TAPE mode (PHILOX needs no tapes)");
+    if (!a->eps_tape || !a->noise_tape) return fail(h, LS_EINVAL, "segment needs eps_tape and noise_tape");
+    if (a->n_dump > 0 && (a->sampler != LS_SAMPLER_DDPM || !a->dump_steps || !a->dump_out))
+        return fail(h, LS_EINVAL, "dump_steps: DDPM only (ddim_sample_loop raises NotImplementedError, gaussian_diffusion.py:919-920)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, JF = h->JF, od = a->on_device;
+    const int n_exec = h->n_steps - a->skip_timesteps;
+    if (a->seg_begin < 0 || a->seg_begin + a->seg_count > n_exec) return fail(h, LS_EINVAL, "segment [%d, %d) outside the loop's %d steps", a->seg_begin, a->seg_begin + a->seg_count, n_exec);
+    const bool last = a->seg_begin + a->seg_count == n_exec;
+    if (last && !a->out) return fail(h, LS_EINVAL, "ls_sample: null out");
+    const size_t nelem = (size_t)B * JF * h->T;
+    const size_t nx = nelem * sizeof(float);
+    hipStream_t st = h->stream;
+    int rc;
+    if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
+    if (a->seg_begin == 0) {
+        if (!a->x_init) return fail(h, LS_EINVAL, "TAPE mode needs x_init");
+        HIPCHK(h, hipEventRecord(h->ev[0], st));
+        HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->xtmp.ensure(nx)); HIPCHK(h, h->xio.ensure(nx));
+        if ((rc = ingest(h, h->xio, a->x_init, nx, od)) != LS_OK) return rc;
+        HIPCHK(h, launch_to_internal(h->xio.f(), h->xa.f(), B, JF, st, h->T));
+        const int first_index = n_exec - 1;
+        if (a->init_image || a->skip_timesteps > 0) {
+            if (a->init_image) {
+                if ((rc = ingest(h, h->xio, a->init_image, nx, od)) != LS_OK) return rc;
+                HIPCHK(h, launch_to_internal(h->xio.f(), h->xtmp.f(), B, JF, st, h->T));
+            } else {
+                HIPCHK(h, hipMemsetAsync(h->xtmp.p, 0, nx, st));
+            }
+            HIPCHK(h, launch_q_sample(h->xtmp.f(), h->xa.f(), h->xa.f(), nelem, (float)h->t_sac[first_index], (float)h->t_s1mac[first_index], st));
+        }
+        if (a->n_dump > 0) {
+            const void* old = h->dump.p;
+            HIPCHK(h, h->dump.ensure((size_t)a->n_dump * nx));
+            if (old != h->dump.p) free_graph(h);
+        }
+        h->seg_next = 0; h->seg_index = 0; h->seg_skip = a->skip_timesteps; h->seg_sampler = a->sampler; h->seg_upload_ms = 0.f;
+        h->slot_used[0] = h->slot_used[1] = false;
+        HIPCHK(h, hipEventRecord(h->ev[1], st));
+    } else if (a->seg_begin != h->seg_next || a->skip_timesteps != h->seg_skip || a->sampler != h->seg_sampler) {
+        return fail(h, LS_ESTATE, "segment starts at step %d but the loop in progress expects %d (segments run in order, same sampler / skip)",
+                    a->seg_begin, h->seg_next);
+    }
+    const int slot = h->seg_index & 1;
+    const size_t eps_step = (size_t)2 * B * kD, eps_bytes = eps_step * a->seg_count * sizeof(float), nz_bytes = nx * a->seg_count;
+    if (h->slot_used[slot]) {
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_seg[slot], 0));     // the steps that read this slot two segments ago
+        if ((rc = close_upload(h, slot)) != LS_OK) return rc;
+    }
+    if (h->eps_slot[slot].bytes < eps_bytes || h->noise_slot[slot].bytes < nz_bytes) {
+        HIPCHK(h, hipStreamSynchronize(st));                                   // growing a slot frees memory the queued steps may read
+        HIPCHK(h, h->eps_slot[slot].ensure(eps_bytes)); HIPCHK(h, h->noise_slot[slot].ensure(nz_bytes));
+    }
+    if (od) {
+        HIPCHK(h, hipMemcpyAsync(h->eps_slot[slot].p, a->eps_tape, eps_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(h->noise_slot[slot].p, a->noise_tape, nz_bytes, hipMemcpyDeviceToDevice, st));
+    } else {
+        HIPCHK(h, hipEventRecord(h->ev_cs[slot], h->copy_stream));
+        HIPCHK(h, hipMemcpyAsync(h->eps_slot[slot].p, a->eps_tape, eps_bytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(h, hipMemcpyAsync(h->noise_slot[slot].p, a->noise_tape, nz_bytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(h, hipEventRecord(h->ev_cd[slot], h->copy_stream));
+        h->upload_open[slot] = true;
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_cd[slot], 0));
+        if ((rc = close_upload(h, slot ^ 1)) != LS_OK) return rc;              // the PREVIOUS segment's host buffers are free from here on
+    }
+    const bool pair = h->fused && h->all_scale_one && !a->two_pass_always;
+    for (int k = a->seg_begin; k < a->seg_begin + a->seg_count; ++k) {
+        const int i = n_exec - 1 - k, r = k - a->seg_begin;
+        StepArgs s;
+        fill_common(h, s);
+        fill_sampler(h, s, a->sampler, i, a->eta);
+        s.clip_denoised = a->clip_denoised;
+        s.x_in = (k & 1) ? h->xb.f() : h->xa.f();
+        s.x_out = (k & 1) ? h->xa.f() : h->xb.f();
+        s.temb = h->temb.f() + (size_t)i * kD; s.temb_stride = 0;
+        s.step_id = (unsigned)k;
+        s.eps_c = h->eps_slot[slot].f() + ((size_t)r * 2 + 0) * B * kD;
+        s.eps_u = h->eps_slot[slot].f() + ((size_t)r * 2 + 1) * B * kD;
+        s.noise = h->noise_slot[slot].f() + (size_t)r * nelem;
+        s.const_noise = a->const_noise;
+        for (int d = 0; d < a->n_dump; ++d)
+            if (a->dump_steps[d] == k) s.x0_out = h->dump.f() + (size_t)d * nelem;
+        HIPCHK(h, run_step(h, s, B, pair, st));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_seg[slot], st));
+    h->slot_used[slot] = true;
+    h->seg_next = a->seg_begin + a->seg_count;
+    h->seg_index++;
+    if (!last) return LS_OK;
+    HIPCHK(h, hipEventRecord(h->ev[2], st));
+    const float* final_x = (n_exec & 1) ? h->xb.f() : h->xa.f();
+    HIPCHK(h, launch_from_internal(final_x, h->xio.f(), B, JF, st, h->T));
+    if ((rc = egress(h, a->out, h->xio.f(), nx, od)) != LS_OK) return rc;
+    for (int d = 0; d < a->n_dump; ++d) {
+        HIPCHK(h, launch_from_internal(h->dump.f() + (size_t)d * nelem, h->xio.f(), B, JF, st, h->T));
+        if ((rc = egress(h, a->dump_out + (size_t)d * nelem, h->xio.f(), nx, od)) != LS_OK) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[3], st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    resolve_prepare_timing(h, true);
+    if ((rc = close_upload(h, 0)) != LS_OK || (rc = close_upload(h, 1)) != LS_OK) return rc;
+    HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
+    h->timing.n_step_launches = n_exec;
+    h->timing.single_pass = pair ? 1 : 0;
+    h->timing.graph_replayed = 0;
+    h->timing.tape_upload_ms = h->seg_upload_ms;
+    h->timing.n_segments = h->seg_index;
+    h->seg_next = -1;
+    return LS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -615,9 +757,18 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     memcpy(h->convL, convL, sizeof convL);
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     for (auto& ev : h->ev) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    }
+    for (int i = 0; i < 2; ++i) {
+        hipEvent_t* evs[3] = {&h->ev_cs[i], &h->ev_cd[i], &h->ev_seg[i]};
+        for (hipEvent_t* pe : evs) {
+            e = hipEventCreate(pe);
+            if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+        }
     }
     e = init_step_kernels();
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
@@ -656,6 +807,14 @@ void ls_destroy(ls_handle* h) {
 #endif
     for (int i = 0; i < 4; ++i) { h->conv_w[i].release(); h->conv_b[i].release(); h->conv_img[i].release(); }
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 2; ++i) {
+        h->eps_slot[i].release(); h->noise_slot[i].release();
+        if (h->ev_cs[i]) (void)hipEventDestroy(h->ev_cs[i]);
+        if (h->ev_cd[i]) (void)hipEventDestroy(h->ev_cd[i]);
+        if (h->ev_seg[i]) (void)hipEventDestroy(h->ev_seg[i]);
+    }
+    h->coef.release();
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -715,12 +874,6 @@ int ls_set_schedule(ls_handle* h, const ls_schedule* s) {
     return LS_OK;
 }
 
-// prepare_ms of an ls_prepare_async whose work has finished (called behind every stream synchronisation; `block`: wait for it)
-static void resolve_prepare_timing(ls_handle* h, bool block) {
-    if (!h->prepare_pending) return;
-    if (block ? hipEventSynchronize(h->ev[5]) != hipSuccess : hipEventQuery(h->ev[5]) != hipSuccess) return;
-    if (hipEventElapsedTime(&h->timing.prepare_ms, h->ev[4], h->ev[5]) == hipSuccess) h->prepare_pending = false;
-}
 
 static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
     if (!h || !c) return fail(h, LS_EINVAL, "ls_prepare: null argument");
@@ -739,11 +892,20 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
     if ((rc = ingest(h, h->vid, c->vid_indices, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->scale, c->scale, (size_t)B * sizeof(float), od)) != LS_OK) return rc;
     if (c->emo && (rc = ingest(h, h->emo, c->emo, (size_t)B * h->T * sizeof(int64_t), od)) != LS_OK) return rc;
+    if (!wait && !od) {     // ls_prepare_async with HOST inputs: the caller may free / rewrite them as soon as we return
+        HIPCHK(h, hipEventRecord(h->ev[6], st));
+        HIPCHK(h, hipEventSynchronize(h->ev[6]));
+    }
+    h->seg_next = -1;       // a new conditioning ends any segmented loop in progress
     {   // guidance scale 1 for the whole batch (what the reference's callers run: test_RAG_ted.py:183): out_u + 1 * (out_c - out_u)
         // is out_c, so the sampling loop may skip the uncond pass (ls_sample_args.two_pass_always keeps both)
         std::vector<float> sc((size_t)B);
-        if (od) HIPCHK(h, hipMemcpy(sc.data(), c->scale, (size_t)B * sizeof(float), hipMemcpyDeviceToHost));
-        else memcpy(sc.data(), c->scale, (size_t)B * sizeof(float));
+        if (od) {           // read back the ingested copy on the handle's own stream: ordered behind the caller's stream (ls_stream_order)
+            HIPCHK(h, hipMemcpyAsync(sc.data(), h->scale.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+        } else {
+            memcpy(sc.data(), c->scale, (size_t)B * sizeof(float));
+        }
         h->all_scale_one = true;
         for (float v : sc) if (v != 1.0f) { h->all_scale_one = false; break; }
     }
@@ -874,7 +1036,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
         if ((rc = egress(h, outs[i], h->xio.f(), nx, od)) != LS_OK) return rc;
     }
     if (a->trace && (rc = egress(h, a->trace, h->trace.f(), (size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float), od)) != LS_OK) return rc;
-    HIPCHK(h, hipStreamSynchronize(st));
+    if (!(a->no_sync && od)) HIPCHK(h, hipStreamSynchronize(st));
     return LS_OK;
 }
 
@@ -882,7 +1044,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     if (!h || !a) return fail(h, LS_EINVAL, "ls_step: null argument");
     if (!h->prepared) return fail(h, LS_ESTATE, "ls_step before ls_prepare");
     if (!h->have_sched) return fail(h, LS_ESTATE, "ls_step before ls_set_schedule");
-    if (a->index < 0 || a->index >= h->n_steps) return fail(h, LS_EINVAL, "step index %d outside [0,%d)", a->index, h->n_steps);
+    if (!a->indices && (a->index < 0 || a->index >= h->n_steps)) return fail(h, LS_EINVAL, "step index %d outside [0,%d)", a->index, h->n_steps);
     if (!a->x || !a->eps_cond || !a->eps_uncond || !a->noise || !a->sample) return fail(h, LS_EINVAL, "ls_step: null pointer");
     if (a->sampler != LS_SAMPLER_DDPM && a->sampler != LS_SAMPLER_DDIM) return fail(h, LS_EINVAL, "bad sampler");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -890,6 +1052,22 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     const size_t nx = (size_t)B * JF * h->T * sizeof(float);
     hipStream_t st = h->stream;
     int rc;
+    // one schedule index per sample (the reference's `t` is a [B] tensor, gaussian_diffusion.py:507-558 / :745-798).  HOST indices
+    // are validated and a constant vector takes the fused uniform path; DEVICE indices are never read by the host (no round trip
+    // in a step-by-step caller): they always take the per-sample path and are clamped into the table on the device.
+    bool per_sample = false;
+    int index = a->index;
+    if (a->indices && a->indices_on_device) {
+        per_sample = true;
+    } else if (a->indices) {
+        for (int b = 0; b < B; ++b) {
+            if (a->indices[b] < 0 || a->indices[b] >= h->n_steps)
+                return fail(h, LS_EINVAL, "indices[%d] = %lld outside [0,%d)", b, (long long)a->indices[b], h->n_steps);
+            if (a->indices[b] != a->indices[0]) per_sample = true;
+        }
+        index = (int)a->indices[0];
+    }
+    if (per_sample && !h->fused) return fail(h, LS_EUNSUPPORTED, "per-sample timesteps: fused (34-frame) path only");
     if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
     if ((rc = ingest(h, h->xio, a->x, nx, od)) != LS_OK) return rc;
     HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->fwd_cfg.ensure(nx));
@@ -901,20 +1079,48 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     if ((rc = ingest(h, h->noise, a->noise, nx, od)) != LS_OK) return rc;
     StepArgs s;
     fill_common(h, s);
-    fill_sampler(h, s, a->sampler, a->index, a->eta);
     s.clip_denoised = a->clip_denoised;
     s.x_in = h->xa.f(); s.x_out = h->xb.f(); s.x0_out = h->fwd_cfg.f();
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
-    s.noise = h->noise.f();
-    s.temb = h->temb.f() + (size_t)a->index * kD; s.temb_stride = 0;
-    HIPCHK(h, run_step(h, s, B, h->fused && h->all_scale_one && !a->two_pass_always, st));
+    const bool pair = h->fused && h->all_scale_one && !a->two_pass_always;
+    if (!per_sample) {
+        fill_sampler(h, s, a->sampler, index, a->eta);
+        s.noise = h->noise.f();
+        s.temb = h->temb.f() + (size_t)index * kD; s.temb_stride = 0;
+        HIPCHK(h, run_step(h, s, B, pair, st));
+    } else {
+        // denoiser with one timestep-embedding row per sample (what ls_forward does), pred_xstart -> fwd_cfg; then the posterior /
+        // DDIM update with per-sample coefficients as its own elementwise kernel, both driven by the index vector on the device
+        char ck[64];
+        snprintf(ck, sizeof ck, "s%d e%a v%u", a->sampler, (double)a->eta, h->sched_version);
+        if (h->coef_key != ck) {
+            std::vector<float> coef((size_t)h->n_steps * 8, 0.f);
+            for (int i = 0; i < h->n_steps; ++i) {
+                StepArgs t;
+                fill_sampler(h, t, a->sampler, i, a->eta);
+                float* c = &coef[(size_t)i * 8];
+                c[0] = t.t_nonzero ? 1.f : 0.f; c[1] = t.c0; c[2] = t.c1; c[3] = t.c2; c[4] = t.c3; c[5] = t.c4;
+            }
+            if ((rc = upload(h, h->coef, coef.data(), coef.size() * sizeof(float))) != LS_OK) return rc;
+            h->coef_key = ck;
+        }
+        if ((rc = ingest(h, h->tidx, a->indices, (size_t)B * sizeof(int64_t), a->indices_on_device)) != LS_OK) return rc;
+        if (!a->indices_on_device) HIPCHK(h, hipStreamSynchronize(st));        // a host index vector may be a temporary of the caller
+        HIPCHK(h, h->tfwd.ensure((size_t)B * kD * sizeof(float)));
+        HIPCHK(h, launch_gather_rows(h->temb.f(), static_cast<const int64_t*>(h->tidx.p), h->tfwd.f(), B, kD, h->n_steps, st));
+        s.temb = h->tfwd.f(); s.temb_stride = kD;
+        HIPCHK(h, run_step(h, s, B, pair, st));
+        HIPCHK(h, launch_sampler_update(h->xa.f(), h->fwd_cfg.f(), h->noise.f(), h->coef.f(), static_cast<const int64_t*>(h->tidx.p), h->n_steps,
+                                        h->xb.f(), B, JF, h->T, a->sampler == LS_SAMPLER_DDPM ? kDDPM : kDDIM, st));
+    }
     HIPCHK(h, launch_from_internal(h->xb.f(), h->xio.f(), B, JF, st, h->T));
     if ((rc = egress(h, a->sample, h->xio.f(), nx, od)) != LS_OK) return rc;
     if (a->pred_xstart) {
-        HIPCHK(h, launch_from_internal(h->fwd_cfg.f(), h->xio.f(), B, JF, st, h->T));
-        if ((rc = egress(h, a->pred_xstart, h->xio.f(), nx, od)) != LS_OK) return rc;
+        HIPCHK(h, h->xtmp.ensure(nx));
+        HIPCHK(h, launch_from_internal(h->fwd_cfg.f(), h->xtmp.f(), B, JF, st, h->T));
+        if ((rc = egress(h, a->pred_xstart, h->xtmp.f(), nx, od)) != LS_OK) return rc;
     }
-    HIPCHK(h, hipStreamSynchronize(st));
+    if (!(a->no_sync && od)) HIPCHK(h, hipStreamSynchronize(st));
     return LS_OK;
 }
 
@@ -945,6 +1151,8 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     if (a->sampler != LS_SAMPLER_DDPM && a->sampler != LS_SAMPLER_DDIM) return fail(h, LS_EINVAL, "bad sampler");
     if (a->noise_mode != LS_NOISE_TAPE && a->noise_mode != LS_NOISE_PHILOX) return fail(h, LS_EINVAL, "bad noise_mode");
     if (a->skip_timesteps < 0 || a->skip_timesteps >= h->n_steps) return fail(h, LS_EINVAL, "skip_timesteps out of range");
+    if (a->seg_count > 0) return sample_segment(h, a);
+    h->seg_next = -1;
     if (!a->out) return fail(h, LS_EINVAL, "ls_sample: null out");
     const bool tape = a->noise_mode == LS_NOISE_TAPE;
     if (tape && (!a->x_init || !a->eps_tape || !a->noise_tape)) return fail(h, LS_EINVAL, "TAPE mode needs x_init, eps_tape and noise_tape");
@@ -1064,8 +1272,22 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
     h->timing.n_step_launches = n_exec;
     h->timing.single_pass = pair ? 1 : 0;
+    h->timing.tape_upload_ms = 0.f;
+    h->timing.n_segments = 1;
     return LS_OK;
 }
+
+int ls_stream_order(int device, void* first, void* then) {
+    if (hipSetDevice(device) != hipSuccess) return LS_EHIP;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return LS_EHIP;
+    hipError_t e = hipEventRecord(ev, static_cast<hipStream_t>(first));
+    if (e == hipSuccess) e = hipStreamWaitEvent(static_cast<hipStream_t>(then), ev, 0);
+    (void)hipEventDestroy(ev);          // released by the runtime once the recorded work has completed
+    return e == hipSuccess ? LS_OK : LS_EHIP;
+}
+
+void* ls_stream(const ls_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
 
 int ls_philox_x_init(ls_handle* h, int batch, uint64_t seed, uint64_t sample_offset, int on_device, float* out) {
     if (!h || !out || batch < 1) return fail(h, LS_EINVAL, "ls_philox_x_init: bad argument");

@@ -241,4 +241,6 @@ int ls_eval_features(ls_eval* h, int batch, int on_device, const float* poses, f
     return LS_OK;
 }
 
+void* ls_eval_stream(const ls_eval* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
 }  // extern "C"

@@ -161,6 +161,11 @@ hipError_t launch_to_internal(const float* src_bjft, float* dst_btc, int B, int 
 hipError_t launch_from_internal(const float* src_btc, float* dst_bjft, int B, int JF, hipStream_t st, int T = kT);
 hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size_t n, float a, float b,
                            hipStream_t st);
+// posterior / DDIM update with PER-SAMPLE coefficients (ls_step with `indices`): x_t, x0, out in the internal [B][T][JF] layout, noise
+// in the reference layout [B][JF][T]; table [n_steps][8] = {1[t != 0], c0, c1, c2, c3, c4, -, -} with the meanings of StepArgs, one
+// row per schedule index; indices [B] (device) selects each sample's row (clamped into the table)
+hipError_t launch_sampler_update(const float* x_t, const float* x0, const float* noise, const float* table, const int64_t* indices,
+                                 int n_steps, float* out, int B, int JF, int T, int sampler, hipStream_t st);
 hipError_t launch_randn_fill(float* out_btc, int B, int JF, const CallParams* call, unsigned stream_id,
                              hipStream_t st, int T = kT);
 hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipStream_t st, int T = kT);

@@ -116,6 +116,40 @@ hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size
     return hipGetLastError();
 }
 
+// One workgroup per sample: the same arithmetic as the fused step kernel's epilogue (ls_step_kernel.h), coefficients per sample.
+// p_sample / ddim_sample (gaussian_diffusion.py:507-558, 745-798) with a [B] timestep tensor whose entries differ.
+__global__ void k_sampler_update(const float* __restrict__ x_t, const float* __restrict__ x0v, const float* __restrict__ noise,
+                                 const float* __restrict__ table, const int64_t* __restrict__ indices, int n_steps,
+                                 float* __restrict__ out, int JF, int T, int sampler) {
+    const int b = blockIdx.x;
+    long long i = indices[b];
+    i = i < 0 ? 0 : (i >= n_steps ? n_steps - 1 : i);
+    const float* coef = table + (size_t)i * 8;
+    const float nzf = coef[0], c0 = coef[1], c1 = coef[2], c2 = coef[3], c3 = coef[4], c4 = coef[5];
+    const bool t_nonzero = nzf != 0.f;
+    const size_t base = (size_t)b * T * JF;
+    for (int idx = threadIdx.x; idx < T * JF; idx += blockDim.x) {
+        const int f = idx / JF, c = idx - f * JF;
+        const float xt = x_t[base + idx], x0 = x0v[base + idx];
+        const float nz = t_nonzero ? noise[((size_t)b * JF + c) * T + f] : 0.f;
+        float xn;
+        if (sampler == kDDPM) {
+            xn = c0 * x0 + c1 * xt;
+            if (t_nonzero) xn += c2 * nz;
+        } else {
+            const float eps = (c0 * xt - x0) / c1;
+            xn = x0 * c2 + c3 * eps;
+            if (t_nonzero) xn += c4 * nz;
+        }
+        out[base + idx] = xn;
+    }
+}
+hipError_t launch_sampler_update(const float* x_t, const float* x0, const float* noise, const float* table, const int64_t* indices,
+                                 int n_steps, float* out, int B, int JF, int T, int sampler, hipStream_t st) {
+    hipLaunchKernelGGL(k_sampler_update, dim3(B), dim3(256), 0, st, x_t, x0, noise, table, indices, n_steps, out, JF, T, sampler);
+    return hipGetLastError();
+}
+
 // Philox x_T (perf mode): element index follows the reference layout (c*T+f) so it is layout independent.
 __global__ void k_randn_fill(float* __restrict__ out, int JF, const CallParams* __restrict__ call, unsigned stream_id, int T) {
     const int b = blockIdx.x;

@@ -264,4 +264,6 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
 
 float ls_sag_last_decode_ms(const ls_sag* h) { return h ? h->last_ms : -1.f; }
 
+void* ls_sag_stream(const ls_sag* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
 }  // extern "C"

@@ -725,4 +725,6 @@ int ls_train_read(ls_trainer* h, const char* what, float* out, size_t n) {
     return LS_OK;
 }
 
+void* ls_train_stream(const ls_trainer* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
 }  // extern "C"

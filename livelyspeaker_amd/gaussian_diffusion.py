@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import enum
 import math
+import time
 
 import numpy as np
 import torch as th
@@ -72,6 +73,14 @@ def _as_tensor(a, device):
     return (a if isinstance(a, th.Tensor) else th.from_numpy(a)).to(device)
 
 
+def _ref_strides(t):
+    """The reference's model output is `output.reshape(T, B, J, F).permute(1, 2, 3, 0)` (OutputProcess, RAG.py:209-210), so
+    pred_xstart and every sample derived from it are NON-contiguous views whose memory order is [T][B][J][F].  Values aside, that
+    is observable: `randn_like(x)` of the next step consumes the generator in x's memory order.  Same strides here, so a caller
+    that chains p_sample / ddim_sample by hand reproduces the reference's draws exactly as the loops do."""
+    return t.permute(3, 0, 1, 2).contiguous().permute(1, 2, 3, 0)
+
+
 def _extract_into_tensor(arr, timesteps, broadcast_shape):
     res = th.from_numpy(arr).to(device=timesteps.device)[timesteps].float()
     while len(res.shape) < len(broadcast_shape):
@@ -85,6 +94,12 @@ class GaussianDiffusion:
 
     noise_source = "torch_cpu"      # or "philox"
     use_graph = True
+    #: evaluate both CFG passes even when every guidance scale is 1 (ls_sample_args.two_pass_always).  Default False: scale 1
+    #: runs ONE pass (out_u + 1 * (out_c - out_u) = out_c up to one fp32 rounding -- the two settings agree to ~1e-5, not bitwise)
+    two_pass_always = False
+    #: torch_cpu mode: host noise tapes larger than this many bytes are drawn and uploaded in K-step segments (page-locked
+    #: double buffer, upload of segment i+1 under the steps of segment i) instead of one [n_exec, ...] piece
+    tape_segment_bytes = 96 << 20
     philox_seed = None              # philox mode: None = draw the key from torch's generator per call
     last_philox_seed = None
 
@@ -146,6 +161,10 @@ class GaussianDiffusion:
             raise ValueError("ClassifierFreeSampleModel returns None when cond_mask_prob == 0 (cfg_sampler.py:24-31)")
         if not model_kwargs or 'y' not in model_kwargs:
             raise ValueError("model_kwargs={'y': {...}} is required")
+        if 'inpainting_mask' in model_kwargs['y'] and 'inpainted_motion' in model_kwargs['y']:
+            # p_mean_variance's inpainting branch (gaussian_diffusion.py:314-320; BEAT :319) overwrites the model output and, on TED,
+            # draws an extra randn inside q_sample: not built (no reference caller passes the keys) -- refused, never ignored
+            raise NotImplementedError("inpainting (y['inpainting_mask'] + y['inpainted_motion']) is not built on the MI355X path")
         eng = model.model._engine_prepared(model_kwargs['y'])
         key = (id(self), self.num_timesteps)
         if getattr(eng, "_sched_key", None) != key:
@@ -159,26 +178,49 @@ class GaussianDiffusion:
             raise NotImplementedError("denoised_fn / cond_fn / randomize_class / cond_fn_with_grad are not part "
                                       "of the RAG sampling path (no reference caller passes them)")
 
-    def _uniform_index(self, t):
-        t = th.as_tensor(t).detach().cpu()
-        if not bool((t == t[0]).all()):
-            raise NotImplementedError("per-sample timesteps are not supported by the fused step kernel")
-        return int(t[0])
-
     # ------------------------------------------------------------------ single steps
     def _one_step(self, sampler, model, x, t, clip_denoised, model_kwargs, eta, const_noise, denoised_fn, cond_fn):
         self._reject(denoised_fn, cond_fn, False, False)
         eng = self._engine_for(model, model_kwargs, "p_sample/ddim_sample")
-        i = self._uniform_index(t)
         B = x.shape[0]
+        t = th.as_tensor(t)
+        assert t.shape == (B,)                  # gaussian_diffusion.py:311
         eps_c = th.randn(B, 1, eng.D)           # cond pass reparameterize (RAG.py:12), then uncond pass
         eps_u = th.randn(B, 1, eng.D)
         noise = th.randn_like(x, device="cpu", dtype=th.float32)    # follows x's strides like the reference's randn_like(x)
         if const_noise:
             noise = noise[[0]].repeat(B, 1, 1, 1)
-        out, x0 = eng.step(sampler, i, x, eps_c, eps_u, noise, eta=eta, clip_denoised=clip_denoised)
         dev = x.device
-        return {"sample": _as_tensor(out, dev), "pred_xstart": _as_tensor(x0, dev)}
+        if x.is_cuda:
+            eps_c, eps_u, noise = self._stage_step_draws(dev, eps_c, eps_u, noise)
+        # `t` may differ per sample (the reference's signature).  A CUDA `t` is handed to the engine as it is -- never read back, so
+        # a step-by-step caller has no device -> host round trip per step, and with device tensors the call does not wait for the GPU
+        # either (outputs are stream-ordered); a host `t` is validated there and a constant one takes the fused uniform path.
+        out, x0 = eng.step(sampler, 0, x, eps_c, eps_u, noise, eta=eta, clip_denoised=clip_denoised, indices=t.detach(),
+                           two_pass_always=self.two_pass_always, no_sync=x.is_cuda)
+        return {"sample": _ref_strides(_as_tensor(out, dev)), "pred_xstart": _ref_strides(_as_tensor(x0, dev))}
+
+    def _stage_step_draws(self, dev, *draws):
+        """Host draws of one step -> device without a stream synchronisation: a pageable `.to(device)` makes torch wait for its
+        stream (and with it for the previous step); here the draws go through a two-slot ring of page-locked buffers and
+        non-blocking copies, each slot guarded by an event that is waited for only when the slot comes round again."""
+        key = (str(dev),) + tuple(tuple(d.shape) for d in draws)
+        ring = getattr(self, "_step_ring", None)
+        if ring is None or ring["key"] != key:
+            ring = self._step_ring = {"key": key, "turn": 0,
+                                      "slots": [{"bufs": [th.empty(d.shape, dtype=th.float32, pin_memory=True) for d in draws],
+                                                 "event": None} for _ in range(2)]}
+        slot = ring["slots"][ring["turn"] & 1]
+        ring["turn"] += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()         # the copies issued from this slot two steps ago
+        out = []
+        for buf, d in zip(slot["bufs"], draws):
+            buf.copy_(d)
+            out.append(buf.to(dev, non_blocking=True))
+        slot["event"] = th.cuda.Event()
+        slot["event"].record(th.cuda.current_stream(dev))
+        return out
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                  const_noise=False):
@@ -229,24 +271,64 @@ class GaussianDiffusion:
             kw["philox_seed"] = self.last_philox_seed
             kw["sample_offset"] = int(getattr(self, "sample_offset", 0))
         else:
-            eps = th.empty(n_exec, 2, B, eng.D)
-            nz = th.empty((n_exec,) + shape)
             # p_sample/ddim_sample draw `randn_like(x)` (gaussian_diffusion.py:543/787).  x is contiguous at the first
             # executed step, but from then on it is the model-output-shaped view whose memory order is
             # [T][B][J][F] (OutputProcess permutes, RAG.py:209-210), and randn_like preserves strides: the generator
             # stream is consumed in MEMORY order through torch's non-contiguous CPU path.  Reproduce exactly that.
             first_proto = noise.cpu() if (noise is not None and init_image is None and not skip_timesteps) else th.empty(shape)
             later_proto = th.empty(shape[3], shape[0], shape[1], shape[2]).permute(1, 2, 3, 0)
-            for k in range(n_exec):            # the reference's per-step draw order
-                eps[k, 0] = th.randn(B, 1, eng.D)[:, 0]
-                eps[k, 1] = th.randn(B, 1, eng.D)[:, 0]
-                nz[k] = th.randn_like(first_proto if k == 0 else later_proto, dtype=th.float32)
+
+            def draw(k, eps_k, nz_k):          # the reference's per-step draw order
+                eps_k[0] = th.randn(B, 1, eng.D)[:, 0]
+                eps_k[1] = th.randn(B, 1, eng.D)[:, 0]
+                nz_k.copy_(th.randn_like(first_proto if k == 0 else later_proto, dtype=th.float32))
+
+            per_step = (2 * B * eng.D + int(np.prod(shape))) * 4
+            t_rng = 0.0
+            if per_step * n_exec > self.tape_segment_bytes and th.cuda.is_available() and n_exec > 1:
+                # 4 GB at 512 clips x 1000 steps if drawn in one piece: K-step segments through two page-locked buffers instead; the
+                # engine uploads segment i+1 on its copy stream while segment i's steps run (ls_sample_args.seg_begin / seg_count)
+                K = max(1, min(n_exec, self.tape_segment_bytes // (2 * per_step)))
+                ring = self._tape_ring(K, B, eng.D, shape)
+                kw.pop("use_graph")
+                kw["x_init"] = x_init.cpu() if th.is_tensor(x_init) else x_init
+                if th.is_tensor(init_image):
+                    kw["init_image"] = init_image.detach().cpu()
+                kw["two_pass_always"] = self.two_pass_always
+                res = None
+                for si, k0 in enumerate(range(0, n_exec, K)):
+                    n = min(K, n_exec - k0)
+                    eps, nz = ring[si & 1]
+                    t0 = time.perf_counter()
+                    for r in range(n):
+                        draw(k0 + r, eps[r], nz[r])
+                    t_rng += time.perf_counter() - t0
+                    res = eng.sample(eps_tape=eps[:n], noise_tape=nz[:n], segment=(k0, n), **kw)
+                self.last_host_rng_ms, self.last_tape_segments = t_rng * 1e3, -(-n_exec // K)
+                if want_dumps:
+                    return [_as_tensor(d, device).clone() for d in res[1]] if dump_steps else []
+                return _ref_strides(_as_tensor(res, device))
+            eps = th.empty(n_exec, 2, B, eng.D)
+            nz = th.empty((n_exec,) + shape)
+            t0 = time.perf_counter()
+            for k in range(n_exec):
+                draw(k, eps[k], nz[k])
+            self.last_host_rng_ms, self.last_tape_segments = (time.perf_counter() - t0) * 1e3, 1
             kw["eps_tape"], kw["noise_tape"] = eps, nz
+        kw["two_pass_always"] = self.two_pass_always
         kw["device_out"] = th.device(device).type == "cuda"
         res = eng.sample(**kw)
         if want_dumps:
             return [_as_tensor(d, device).clone() for d in res[1]] if dump_steps else []
-        return _as_tensor(res, device)
+        return _ref_strides(_as_tensor(res, device))
+
+    def _tape_ring(self, K, B, D, shape):
+        """Two page-locked (eps [K,2,B,D], noise [K,B,J,F,T]) segments, kept between calls (pinning 100 MB takes tens of ms)."""
+        key = (K, B, D, tuple(shape))
+        if getattr(self, "_tape_ring_key", None) != key:
+            self._tape_ring_bufs = [(th.empty(K, 2, B, D, pin_memory=True), th.empty((K,) + tuple(shape), pin_memory=True)) for _ in range(2)]
+            self._tape_ring_key = key
+        return self._tape_ring_bufs
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,

@@ -186,9 +186,10 @@ class RAG(nn.Module):
         """Run the once-per-call stage (audio encoder, static projection, speaker style) unless ``y`` is the
         conditioning that is already resident.  Reproduces RAG.py:110's in-place ``origin_x[..., 4:] = 0``."""
         eng = self.engine()
-        tail = y['origin_x'][..., self.n_pre_seq:]
-        if tail.numel() and bool(tail.ne(0).any()):       # RAG.py:110 zeroes in place on EVERY forward; writing only when something
-            tail.zero_()                                  # is non-zero keeps origin_x._version (part of the cache key) stable
+        # RAG.py:110 zeroes origin_x[..., 4:] in place on EVERY forward.  Written through `.data` so that origin_x._version (part
+        # of the cache key below) does not move with it -- and unconditionally: testing "is anything non-zero" first was a
+        # device -> host round trip on every forward of a step-by-step caller
+        y['origin_x'].data[..., self.n_pre_seq:].zero_()
         names = ('audio_input', 'origin_x', 'vid_indices', 'scale') + (('emo',) if self.n_prefix_tokens == 2 else ())
         key = tuple((n, y[n].data_ptr(), tuple(y[n].shape), y[n]._version) for n in names)
         if not wait:                                      # prefetch_condition: enqueue only; the next request for this key is served by it

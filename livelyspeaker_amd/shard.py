@@ -16,6 +16,28 @@ import torch
 import torch.distributed as dist
 
 
+def _on() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def _stage(t: torch.Tensor) -> torch.Tensor:
+    """The tensor a collective runs on: device memory under RCCL, a host copy under gloo (whose device-tensor support is partial:
+    used by the CPU tests and by the two-ranks-on-one-GPU bench test, where RCCL refuses the duplicate device)."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
+def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
+    """In-place all_reduce of ``t`` under either backend (no-op without a process group)."""
+    if not _on():
+        return t
+    op = dist.ReduceOp.SUM if op is None else op
+    s = _stage(t)
+    dist.all_reduce(s, op=op)
+    if s is not t:
+        t.copy_(s)
+    return t
+
+
 def shard_range(total: int, world: int, rank: int):
     """Contiguous split of ``total`` samples: rank r owns [first, first+count)."""
     base, extra = divmod(total, world)
@@ -37,7 +59,7 @@ def broadcast_state_dict(sd: dict, device, src: int = 0) -> dict:
     if not (dist.is_available() and dist.is_initialized()):
         return sd
     keys = sorted(sd.keys())
-    flat = torch.cat([sd[k].reshape(-1).to(torch.float32) for k in keys]).to(device)
+    flat = _stage(torch.cat([sd[k].reshape(-1).to(torch.float32) for k in keys]).to(device))
     dist.broadcast(flat, src=src)
     flat = flat.cpu()
     out, off = {}, 0
@@ -53,7 +75,10 @@ def broadcast_tensor(t: torch.Tensor, device, src: int = 0) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()):
         return t
     buf = t.to(device).contiguous()
-    dist.broadcast(buf, src=src)
+    s = _stage(buf)
+    dist.broadcast(s, src=src)
+    if s is not buf:
+        buf.copy_(s)
     return buf
 
 
@@ -72,7 +97,12 @@ def gather_samples(local: torch.Tensor, total: int) -> torch.Tensor:
         buf[: local.shape[0]] = local
         local = buf
     out = local.new_empty((world * pad,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, local)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local)
     if min(counts) == pad:
         return out
     return torch.cat([out[r * pad: r * pad + c] for r, c in enumerate(counts)], dim=0)
@@ -108,19 +138,24 @@ def cross_check(generate, mine: torch.Tensor, total: int, *, equal_shards_of: in
     rank = dist.get_rank() if on else 0
     nb = (rank + 1) % world
     if equal_shards_of is not None:
+        if total != world * equal_shards_of:      # gather_samples lays the shards out by shard_range(total, ...): the two must agree
+            raise ValueError(f"cross_check: total {total} != world {world} x equal_shards_of {equal_shards_of}")
         spans = [(r * equal_shards_of, equal_shards_of) for r in range(world)]
     else:
         spans = [shard_range(total, world, r) for r in range(world)]
     whole = gather_samples(mine, total)
     first, count = spans[nb]
-    redo = generate(first, count, nb)
-    theirs = whole[first:first + count]
-    stats = torch.stack([(redo - theirs).abs().max().double(), redo.double().abs().sum(), theirs.double().abs().sum()])
+    if count > 0:
+        redo = generate(first, count, nb)
+        theirs = whole[first:first + count]
+        stats = torch.stack([(redo - theirs).abs().max().double(), redo.double().abs().sum(), theirs.double().abs().sum()])
+    else:                                         # total < world: the neighbour's shard is empty and contributes nothing
+        stats = torch.zeros(3, dtype=torch.float64, device=mine.device)
     mx, sums = stats[:1].clone(), stats[1:].clone()
-    if on:
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    return {"rccl_ranks": world,
+    all_reduce_(mx, dist.ReduceOp.MAX)
+    all_reduce_(sums, dist.ReduceOp.SUM)
+    backend = dist.get_backend() if on else "none"
+    return {"rccl_ranks": world if backend in ("nccl", "none") else 0, "ranks": world, "collective_backend": backend,
             "what": "every rank re-generated the NEXT rank's shard on its own GPU via sample_offset (same Philox key, that shard's "
                     "conditioning) and compared it with what that rank produced",
             "max_abs_diff": float(mx.item()), "bitwise_equal": bool(mx.item() == 0.0),

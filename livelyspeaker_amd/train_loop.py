@@ -39,7 +39,8 @@ def batch_from_reference_tuple(batch, speaker_model, device):
 def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """Average a flat gradient array over the data-parallel group in place (one bucket; RCCL on GPUs, gloo in CPU tests)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        from .shard import all_reduce_
+        all_reduce_(flat, dist.ReduceOp.SUM)      # device memory under RCCL; a host copy under gloo
         flat.div_(dist.get_world_size())
     return flat
 
@@ -109,12 +110,10 @@ class TrainLoop:
             st, lr = unpack_optimizer_state(self.model, torch.load(path, map_location="cpu"))
             if st["exp_avg"]:
                 self.trainer.load_optimizer_state(st)
-        # opt.load_state_dict restores the annealed lr of the last executed step through param_groups (train_loop.py:96-104);
-        # without an optimizer file, recompute what _anneal_lr left there: step index resume_step - 1
-        if lr is not None:
-            self.cur_lr = lr
-        elif self.lr_anneal_steps:
-            self.cur_lr = self.lr * (1 - (self.resume_step - 1) / self.lr_anneal_steps)
+        # opt.load_state_dict restores the annealed lr of the last executed step through param_groups (train_loop.py:96-104).
+        # Without an optimizer file the reference keeps the AdamW it has just built at args.lr (train_loop.py:60-66): the first
+        # resumed step runs at the un-annealed lr and _anneal_lr takes over after it -- same here.
+        self.cur_lr = lr if lr is not None else self.lr
 
     def sync_model(self):
         """Copy the trained master parameters back into ``self.model`` (so sampling / state_dict() see them)."""

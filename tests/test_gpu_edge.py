@@ -289,6 +289,11 @@ def test_emo_accepts_the_callers_frame_tensor_and_a_bare_id_vector():
         yc["emo"] = wide
         eng.prepare(yc)
         assert np.array_equal(a, eng.sample(**kw))
+        for width in (1, 50):                                                             # [B, 1] and a padded [B, 50]: column 0 is all RAG.py:125 reads
+            eng.prepare(dict(y, emo=np.repeat(y["emo"][:, :1], width, axis=1)))
+            assert np.array_equal(a, eng.sample(**kw)), width
+        with pytest.raises(_lib.EngineError):
+            eng.prepare(dict(y, emo=y["emo"][:, :, None]))
         y2 = dict(y, emo=(y["emo"] + 1) % 8)
         eng.prepare(y2)
         assert not np.array_equal(a, eng.sample(**kw))                                    # the token really depends on it

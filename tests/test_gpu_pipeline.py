@@ -141,3 +141,38 @@ def test_bench_strong_scaling_path_under_torch_distributed_run(tmp_path):
     assert strong["parity_in_run"]["ok"] and weak["parity_in_run"]["ok"]
     assert strong["config"]["global_batch"] == 512 and weak["config"]["global_batch"] == 512
     assert abs(strong["value"] / weak["value"] - 1) < 0.05           # 100-step calls (150 ms): the gather and host jitter are visible
+
+
+def _bench(root, args, timeout=1200):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                   # ONE JSON line on stdout, whatever the ranks print elsewhere
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks_and_runs_the_n_rank_path_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` (no launcher) re-executes itself under torch.distributed.run.  With --ranks-share-device both
+    ranks use cuda:0 -- RCCL refuses that ("Duplicate GPU detected"), so the collectives run over gloo on host copies -- and
+    everything else of the N > 1 path executes for real: rank-0 weight broadcast (rank 1 starts from DIFFERENT weights), Philox
+    streams keyed by the global sample index, shard cross-check of the neighbour's shard, max-over-ranks timing, rank 0's single
+    JSON line; and configs[2]'s leg with the CLIP-feature broadcast + all_gather in its timed region."""
+    root = ROOT
+    common = ["--steps", "1", "--warmup", "1", "--diffusion-steps", "60", "--no-cpu-baseline", "--batch", "128"]
+    two = _bench(root, ["--gpus", "2", "--ranks-share-device", "--legs", "lively"] + common)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["global_batch"] == 256
+    assert two["collective_backend"] == "gloo" and two["rccl_ranks"] == 0 and two["shard_check"]["ranks"] == 2
+    assert two["shard_check"]["bitwise_equal"] and two["shard_check"]["checksum_recomputed"] == two["shard_check"]["checksum_sharded"]
+    assert two["parity_in_run"]["ok"]
+    lv = two["livelyspeaker"]
+    assert "error" not in lv, lv
+    assert lv["n_gpus"] == 2 and lv["text_feature_broadcast"]["bytes"] == 256 * 512 * 4 and lv["text_feature_broadcast"]["ms"] > 0
+    # strong scaling through the same self-launch: 256 clips over the two ranks, gather in the timed region
+    strong = _bench(root, ["--gpus", "2", "--ranks-share-device", "--legs", "none", "--global-batch", "256"] + common)
+    assert strong["scaling"] == "strong" and strong["shard_check"]["bitwise_equal"] and strong["parity_in_run"]["ok"]
+    # one rank, same workload: the leg appears there too, and the values per clip are the same computation
+    one = _bench(root, ["--gpus", "1", "--legs", "lively"] + common)
+    assert one["n_gpus"] == 1 and "error" not in one["livelyspeaker"] and one["livelyspeaker"]["text_feature_broadcast"] is None
+    print("2 ranks on one GPU:", two["value"], lv["value"], lv["text_feature_broadcast"], "| strong:", strong["value"], "| 1 rank:", one["value"])

@@ -235,6 +235,27 @@ def test_trainloop_checkpoint_resume_is_bit_identical(tmp_path, anneal):
         assert np.array_equal(ref[k], got[k]), k
 
 
+def test_trainloop_resume_without_optimizer_file_starts_at_args_lr(tmp_path):
+    """train_loop.py:60-66, 96-104: with no opt%09d.pt beside the checkpoint the reference keeps the AdamW it has just built at
+    args.lr, so the FIRST resumed step runs un-annealed and _anneal_lr takes over after it."""
+    import torch
+    cfg = synth.CONFIGS["ted"]
+    np.random.seed(4); torch.manual_seed(4)
+    _, _, _, first = _loop_fixture(tmp_path / "ck", None, lr_anneal_steps=10)
+    for motion, cond in _batches(cfg, 2):
+        first.run_step(motion, cond)
+        first.step += 1
+    first.save()
+    os.remove(os.path.join(str(tmp_path / "ck"), "opt000000002.pt"))
+    ck = os.path.join(str(tmp_path / "ck"), "model000000002.pt")
+    _, _, _, second = _loop_fixture(tmp_path / "ck", None, resume=ck, lr_anneal_steps=10)
+    assert second.resume_step == 2 and second.cur_lr == 1e-4                      # fresh optimizer: args.lr, not the annealed 0.9e-4
+    assert second.trainer.optimizer_state()["step"] in (0, 1)                      # and fresh moments / step counter
+    motion, cond = _batches(cfg, 1, start=2)[0]
+    second.run_step(motion, cond)
+    assert abs(second.cur_lr - 1e-4 * (1 - 2 / 10)) < 1e-12                        # _anneal_lr after the step: (step 0 + resume 2) / 10
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Full training batch (B=512, the reference's default -b 512): size-independent properties instead of the CPU oracle
 def test_full_batch_gradient_is_deterministic_and_equals_mean_of_half_batches():

@@ -84,7 +84,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ls_abi_version.restype = ctypes.c_int
-    assert lib.ls_abi_version() == 1
+    assert lib.ls_abi_version() == 2
 
 
 def test_shipped_library_has_no_debug_switches():
@@ -119,14 +119,25 @@ def test_abi_shard_range_matches_the_python_shard_layer():
     assert lib.ls_shard_range(8, 2, 2, ctypes.byref(f), ctypes.byref(c)) < 0 and lib.ls_shard_range(8, 0, 0, ctypes.byref(f), ctypes.byref(c)) < 0
 
 
-def test_abi_struct_sizes_match_header_layout():
-    assert ctypes.sizeof(_lib.LsConfig) == 48
-    assert ctypes.sizeof(_lib.LsSchedule) == 8 + 10 * 8
-    assert ctypes.sizeof(_lib.LsCond) == 8 + 5 * 8
-    assert ctypes.sizeof(_lib.LsSampleArgs) == 40 + 2 * 8 + 4 * 8 + 2 * 8 + 8
-    assert ctypes.sizeof(_lib.LsForwardArgs) == 8 + 8 * 8
-    assert ctypes.sizeof(_lib.LsStepArgs) == 24 + 6 * 8
-    assert ctypes.sizeof(_lib.LsTiming) == 24
+def test_abi_struct_sizes_match_header_layout(tmp_path):
+    """The ctypes mirrors against what a C compiler makes of include/ls_hip.h itself: size of every struct and the offset of its
+    last field (gcc is in the image; the header is plain C)."""
+    import subprocess
+    pairs = [("ls_config", _lib.LsConfig), ("ls_schedule", _lib.LsSchedule), ("ls_cond", _lib.LsCond), ("ls_sample_args", _lib.LsSampleArgs),
+             ("ls_forward_args", _lib.LsForwardArgs), ("ls_step_args", _lib.LsStepArgs), ("ls_timing", _lib.LsTiming),
+             ("ls_sag_config", _lib.LsSagConfig), ("ls_post_config", _lib.LsPostConfig), ("ls_train_config", _lib.LsTrainConfig),
+             ("ls_train_batch", _lib.LsTrainBatch), ("ls_train_terms", _lib.LsTrainTerms), ("ls_eval_config", _lib.LsEvalConfig)]
+    src = tmp_path / "sizes.c"
+    body = "".join(f'    printf("{c} %zu %zu\\n", sizeof({c}), offsetof({c}, {py._fields_[-1][0]}));\n' for c, py in pairs)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ls_hip.h"\nint main(void) {\n' + body + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in out.splitlines()}
+    for c, py in pairs:
+        assert got[c] == (ctypes.sizeof(py), getattr(py, py._fields_[-1][0]).offset), (c, got[c])
+    assert ctypes.sizeof(_lib.LsSampleArgs) == 40 + 2 * 8 + 4 * 8 + 2 * 8 + 8 + 8
+    assert ctypes.sizeof(_lib.LsStepArgs) == 24 + 6 * 8 + 8 + 8
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
@@ -346,3 +357,23 @@ def _mk_args_local(cfg):
     return SimpleNamespace(mdm_condm="text", latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1, arch="trans_enc",
                            emb_trans_dec=False, dataset="humanml", lang_model=None, mlpact="silu", diffusion_steps=1000,
                            noise_schedule="cosine", sigma_small=True, lambda_vel=1.0, lambda_rcxyz=0.0, lambda_fc=0.0, njoints=cfg.njoints)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must re-execute itself under torch.distributed.run (one rank per GPU), not exit
+    asking for one.  No GPU here, so each of the two ranks stops at its device check -- which is the evidence that two ranks ran."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""                 # nothing but the JSON line may ever reach stdout
+    assert "must be launched with" not in r.stderr
+    # (the launcher tears the other rank down as soon as one fails, so either rank's message may be the only one)
+    assert "rank 0: local rank 0 but only 0 GPU(s) visible" in r.stderr or "rank 1: local rank 1 but only 0 GPU(s) visible" in r.stderr
+    assert "torch/distributed" in r.stderr                              # the elastic launcher's failure report: it was the launcher that ran them
+    # a launcher / --gpus mismatch is named, not silently accepted
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=600,
+                        cwd=root, env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
+    assert r2.returncode != 0 and "--gpus 1 but the launcher started 2 rank(s)" in r2.stderr

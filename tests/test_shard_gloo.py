@@ -179,7 +179,14 @@ def _xcheck_worker(rank, world, port, q):
         bad_mine = mine + (1e-3 if rank == 1 else 0.0)                  # rank 1 "computes something else"
         bad = shard.cross_check(gen, bad_mine, world * B, equal_shards_of=B)
         ragged = shard.cross_check(lambda f, c, s: gen(f, c, s), gen(*shard.shard_range(5, world, rank), rank), 5)      # 3 + 2 samples
-        q.put((rank, (ok, bad, ragged)))
+        # total < world (shard_range allows it): rank 1 owns nothing; the check must not trip over the empty shard
+        tiny = shard.cross_check(gen, gen(*shard.shard_range(1, world, rank), rank), 1)
+        try:
+            shard.cross_check(gen, mine, world * B + 1, equal_shards_of=B)
+            mismatch = "accepted"
+        except ValueError as e:
+            mismatch = str(e)
+        q.put((rank, (ok, bad, ragged, tiny, mismatch)))
     except Exception as e:
         import traceback
         q.put((rank, RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")))
@@ -202,8 +209,10 @@ def test_world2_shard_cross_check():
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank in (0, 1):
-        ok, bad, ragged = results[rank]
-        assert ok["rccl_ranks"] == 2 and ok["bitwise_equal"] and ok["max_abs_diff"] == 0.0
+        ok, bad, ragged, tiny, mismatch = results[rank]
+        assert ok["ranks"] == 2 and ok["collective_backend"] == "gloo" and ok["rccl_ranks"] == 0     # not RCCL: says so
+        assert ok["bitwise_equal"] and ok["max_abs_diff"] == 0.0
+        assert tiny["bitwise_equal"] and "equal_shards_of" in mismatch
         assert ok["checksum_recomputed"] == ok["checksum_sharded"]
         assert not bad["bitwise_equal"] and abs(bad["max_abs_diff"] - 1e-3) < 1e-6          # seen by EVERY rank (all-reduced)
         assert ragged["bitwise_equal"]
