@@ -652,26 +652,35 @@ def main():
         try:
             diffusion.noise_source = "torch_cpu"
             torch.manual_seed(233)
+            # bounded sample (the host generator makes ~30-70 ms of draws per step at this batch): the LAST n_s steps of the schedule
+            # (skip_timesteps, the reference's own argument); steps are homogeneous, so the full-schedule figure is a linear scaling
+            n_total = diffusion.num_timesteps - a.skip
+            n_s = min(96, n_total)
             fence()
             t0 = time.perf_counter()
-            o_s, _ = one_call()
+            o_s = fn(cfgm, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=diffusion.num_timesteps - n_s, init_image=None,
+                     progress=False, dump_steps=None, noise=None, const_noise=False)
             fence()
             e_s = time.perf_counter() - t0
             tm = eng.timing()
-            assert bool(torch.isfinite(o_s).all())
+            assert bool(torch.isfinite(o_s).all()) and tm["n_step_launches"] == n_s
             per_step = (2 * B * 512 + B * cfg.jf * cfg.nframes) * 4
             n_seg = int(diffusion.last_tape_segments)
-            n_exec_s = diffusion.num_timesteps - a.skip
+            k_seg = -(-n_s // max(n_seg, 1))
+            full_s = e_s * n_total / n_s
             seeds = {"workload": "same as the headline but noise_source='torch_cpu': x_T, two style eps and one randn_like(x) per step drawn from "
                                  "torch's CPU generator in the reference's order (gaussian_diffusion.py:700-743, RAG.py:120), so "
                                  "torch.manual_seed(s) reproduces the reference's CPU samples (fixture G7)",
-                     "value": round(total * cfg.nframes / e_s, 2), "unit": "pose-frames/s", "ms_per_call": round(e_s * 1e3, 1),
-                     "host_rng_ms": round(diffusion.last_host_rng_ms, 1), "upload_ms": round(tm["tape_upload_ms"], 2),
-                     "gpu_loop_ms": round(tm["loop_ms"], 1), "segments": n_seg, "steps_per_segment": -(-n_exec_s // max(n_seg, 1)),
-                     "tape_bytes_if_one_piece": per_step * n_exec_s,
-                     "pinned_host_bytes": 2 * (-(-n_exec_s // max(n_seg, 1))) * per_step if n_seg > 1 else per_step * n_exec_s,
-                     "bound": "host RNG (a single-threaded normal generator feeding 2 x B x 512 + B x J x F x T draws per step); the uploads "
-                              "run on the copy stream under the previous segment's steps",
+                     "sample": f"the last {n_s} of the {n_total} steps (skip_timesteps = {diffusion.num_timesteps - n_s}), scaled linearly to {n_total}",
+                     "value": round(total * cfg.nframes / full_s, 2), "unit": "pose-frames/s", "ms_per_call_scaled": round(full_s * 1e3, 1),
+                     "measured_ms": round(e_s * 1e3, 1), "measured_steps": n_s,
+                     "host_rng_ms_per_step": round(diffusion.last_host_rng_ms / n_s, 2), "upload_ms_per_step": round(tm["tape_upload_ms"] / n_s, 3),
+                     "gpu_kernel_ms_per_step": round(loop_ms / max(launches, 1), 3), "segments": n_seg, "steps_per_segment": k_seg,
+                     "tape_bytes_if_one_piece": per_step * n_total,
+                     "pinned_host_bytes": 2 * k_seg * per_step if n_seg > 1 else per_step * n_s,
+                     "bound": "host RNG: torch's CPU generator is one sequential stream (2 x B x 512 + B x J x F x T normals per step, the "
+                              "randn_like(x) ones through its scalar path because x is a permuted view); the uploads run on the copy stream "
+                              "under the previous segment's steps and the GPU idles between segments",
                      "hipgraph": False if n_seg > 1 else bool(diffusion.use_graph)}
         except Exception as e:
             seeds = {"error": repr(e)[:300]}

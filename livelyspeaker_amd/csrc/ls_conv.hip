@@ -16,6 +16,20 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int kCvK = 15, kCvS = 6, kCvTP = 64, kCvCI = 16, kCvTC = 64;
+
+// Stage stamps for tools/conv_bench.cpp (built with -DLS_CONV_PROF; never in the shipped library): lane 0 of one consumer and one
+// producer wave of ONE workgroup records the cycle counter when it reaches / leaves each per-stage barrier.
+#ifdef LS_CONV_PROF
+__device__ unsigned long long* g_conv_prof = nullptr;      // [2 roles][1024 stages][2]
+__device__ int g_conv_prof_wg = 0;
+#define CV_STAMP(role, sidx, which)                                                                                       \
+    do {                                                                                                                  \
+        if (g_conv_prof && (int)blockIdx.z == g_conv_prof_wg && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (sidx) < 1024) \
+            g_conv_prof[(((role) * 1024) + (sidx)) * 2 + (which)] = __builtin_readcyclecounter();                          \
+    } while (0)
+#else
+#define CV_STAMP(role, sidx, which) do { } while (0)
+#endif
 constexpr int kCvWin = (kCvTP - 1) * kCvS + kCvK;      // 393 input samples per channel per tile
 constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the 4 lane groups (channels) hit different banks
 
@@ -73,7 +87,9 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
         __syncthreads();
         for (int sidx = 0; sidx < nstage; ++sidx) {
             if (sidx + 1 < nstage) stage(sidx + 1, sIn[(sidx + 1) & 1]);
+            if (w == 4) CV_STAMP(1, sidx, 0);
             __syncthreads();
+            if (w == 4) CV_STAMP(1, sidx, 1);
         }
         return;
     }
@@ -119,7 +135,9 @@ __global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ i
                     }
                 }
             }
+            if (w == 0) CV_STAMP(0, sidx, 0);
             __syncthreads();
+            if (w == 0) CV_STAMP(0, sidx, 1);
         }
         // epilogue of this tile (registers -> global only): runs while the producers stage the next tile's second chunk
 #pragma unroll
