@@ -62,8 +62,8 @@ struct ls_handle {
     int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
     bool fused = true;
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
-    DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
-    DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_stats, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
+    DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_wcf, lw_bcf, lw_wsum, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
+    DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_part1, lx_part2, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [0..3] sample / step timing, [4..5] ls_prepare, [6] host-input copies of ls_prepare_async
@@ -472,6 +472,24 @@ int build_long_weights(ls_handle* h) {
         h->lw_wtp.release();
     }
     UP(lw_wt, wt); UP(lw_bt, bt); UP(lw_wc, wc); UP(lw_bc, bc); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
+    if (S <= 160) {     // fused form: LayerNorm 2 folded around the channel-mixing product (ls_long.hip): W' = W diag(alpha2), bias' = b + W beta2,
+                        // wsum[n] = sum_k W'[n][k] (the row's mean enters the epilogue as  - mean * wsum)
+        std::vector<float> wcf((size_t)L * D * D), bcf((size_t)L * D), wsum((size_t)L * D);
+        for (int l = 0; l < L; ++l)
+            for (int n = 0; n < D; ++n) {
+                double sb = bc[(size_t)l * D + n], sw = 0.0;
+                for (int k = 0; k < D; ++k) {
+                    const float wv = wc[((size_t)l * D + n) * D + k];
+                    const float wf = wv * l2a[(size_t)l * D + k];
+                    wcf[((size_t)l * D + n) * D + k] = wf;
+                    sb += (double)wv * (double)l2b[(size_t)l * D + k];
+                    sw += (double)wf;
+                }
+                bcf[(size_t)l * D + n] = (float)sb;
+                wsum[(size_t)l * D + n] = (float)sw;
+            }
+        UP(lw_wcf, wcf); UP(lw_bcf, bcf); UP(lw_wsum, wsum);
+    }
     // poseFinal rows padded with zero rows to whole 128-column GEMM tiles: N = 282 would send the product down the general staging
     // path (41 TFLOP/s at 9728 rows); as 384 columns it is a full-tile LDS-DMA product, the extra columns are never read
     const int JFN = (JF + 127) / 128 * 128;
@@ -525,7 +543,7 @@ hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st)
     a.temb = s.temb;
     a.eps_c = s.eps_c; a.eps_u = s.eps_u; a.noise = s.noise; a.const_noise = s.const_noise; a.call = s.call; a.step_id = s.step_id;
     a.winx = h->lw_winx.f(); a.ln1a = h->ln1a.f(); a.ln1b = h->ln1b.f(); a.ln2a = h->ln2a.f(); a.ln2b = h->ln2b.f();
-    a.wt = h->lw_wt.f(); a.wtp = h->lw_wtp.f(); a.stats = h->lx_stats.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
+    a.wt = h->lw_wt.f(); a.wtp = h->lw_wtp.f(); a.part1 = h->lx_part1.f(); a.part2 = h->lx_part2.f(); a.wcf = h->lw_wcf.f(); a.bcf = h->lw_bcf.f(); a.wsum = h->lw_wsum.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
     a.xproj = h->lx_proj.f(); a.xpad = h->lx_xpad.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
     a.sampler = s.sampler; a.t_nonzero = s.t_nonzero; a.clip_denoised = s.clip_denoised;
     a.c0 = s.c0; a.c1 = s.c1; a.c2 = s.c2; a.c3 = s.c3; a.c4 = s.c4;
@@ -798,7 +816,7 @@ void ls_destroy(ls_handle* h) {
                      &h->st1, &h->st2, &h->st3, &h->feat_c, &h->feat_u, &h->static_c, &h->static_u, &h->z, &h->z_ml, &h->z_mu,
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
-                     &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_stats, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_winx, &h->lw_wout,
+                     &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
                      &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
@@ -966,14 +984,21 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
     }
     if (!h->fused) {        // workspaces of the long-sequence path: token sequences of both passes, their LayerNorm'd copy, poseFinal output
         const void* old[5] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p, h->lx_xpad.p};
-        const size_t rows = (size_t)2 * B * h->S;
+        const size_t rows = ((size_t)2 * B * h->S + 127) / 128 * 128;      // whole 128-row GEMM tiles (the fused channel-mixing product runs over the pad rows too)
         const size_t mpad = ((size_t)B * h->T + 127) / 128 * 128;           // x_t projection on whole 128-row tiles (k_long_padx)
         HIPCHK(h, h->lx_proj.ensure(mpad * kD * sizeof(float)));
         HIPCHK(h, h->lx_xpad.ensure(mpad * h->JFP * sizeof(float)));
-        HIPCHK(h, h->lx_X.ensure(rows * kD * sizeof(float)));
-        HIPCHK(h, h->lx_U.ensure(rows * kD * sizeof(float)));
+        { const size_t before = h->lx_X.bytes + h->lx_U.bytes;
+          HIPCHK(h, h->lx_X.ensure(rows * kD * sizeof(float)));
+          HIPCHK(h, h->lx_U.ensure(rows * kD * sizeof(float)));
+          if (h->lx_X.bytes + h->lx_U.bytes != before) {                    // fresh memory: the pad rows must hold finite values (their products are computed and discarded)
+              HIPCHK(h, hipMemsetAsync(h->lx_X.p, 0, h->lx_X.bytes, st)); HIPCHK(h, hipMemsetAsync(h->lx_U.p, 0, h->lx_U.bytes, st)); } }
         HIPCHK(h, h->lx_OUT.ensure(rows * (size_t)((h->JF + 127) / 128 * 128) * sizeof(float)));
-        { const void* os = h->lx_stats.p; HIPCHK(h, h->lx_stats.ensure(rows * 2 * sizeof(float))); if (os != h->lx_stats.p) free_graph(h); }
+        { const void* o1 = h->lx_part1.p; const void* o2 = h->lx_part2.p;
+          HIPCHK(h, h->lx_part1.ensure(rows * 16 * sizeof(float))); HIPCHK(h, h->lx_part2.ensure(rows * 16 * sizeof(float)));
+          if (o1 != h->lx_part1.p || o2 != h->lx_part2.p) {
+              HIPCHK(h, hipMemsetAsync(h->lx_part1.p, 0, h->lx_part1.bytes, st)); HIPCHK(h, hipMemsetAsync(h->lx_part2.p, 0, h->lx_part2.bytes, st));
+              free_graph(h); } }
         if (old[0] != h->lx_proj.p || old[1] != h->lx_X.p || old[2] != h->lx_U.p || old[3] != h->lx_OUT.p || old[4] != h->lx_xpad.p) free_graph(h);
     }
     HIPCHK(h, hipEventRecord(h->ev[5], st));

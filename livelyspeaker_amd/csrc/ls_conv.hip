@@ -20,7 +20,7 @@ constexpr int kCvK = 15, kCvS = 6, kCvTP = 64, kCvCI = 16, kCvTC = 64;
 // Stage stamps for tools/conv_bench.cpp (built with -DLS_CONV_PROF; never in the shipped library): lane 0 of one consumer and one
 // producer wave of ONE workgroup records the cycle counter when it reaches / leaves each per-stage barrier.
 #ifdef LS_CONV_PROF
-__device__ unsigned long long* g_conv_prof = nullptr;      // [2 roles][1024 stages][2]
+__device__ unsigned long long* g_conv_prof = nullptr;      // [8 waves][1024 stages][2]
 __device__ int g_conv_prof_wg = 0;
 #define CV_STAMP(role, sidx, which)                                                                                       \
     do {                                                                                                                  \
@@ -30,136 +30,212 @@ __device__ int g_conv_prof_wg = 0;
 #else
 #define CV_STAMP(role, sidx, which) do { } while (0)
 #endif
+// timing-only ablations for tools/build_conv_bench.sh (-DLS_CONV_ABL=bits; results are wrong): 1 consumers read no LDS operands,
+// 2 consumers fetch no weight fragments, 4 producers load nothing, 8 no epilogue, 16 producers do nothing at all
+#ifndef LS_CONV_ABL
+#define LS_CONV_ABL 0
+#endif
 constexpr int kCvWin = (kCvTP - 1) * kCvS + kCvK;      // 393 input samples per channel per tile
 constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the 4 lane groups (channels) hit different banks
 
-// wimg: [co tile (Cout/16)][chunk (Cin/16)][step4 (15)][lane 64][4]: element e of step4 q is MFMA step s = 4q+e,
-//       tap k = s / 4 ... see build_conv_image() in ls_api.cpp: step s -> (k = s / 4, cig = s % 4), ci = 4*cig + g
-// Producer / consumer workgroup (512 threads): waves 0-3 only multiply (wave w = channel tile w x the four position tiles:
-// one float4 of weights per tap feeds 16 MFMAs; activations from LDS, weights from L2), waves 4-7 only stage -- they fetch the
-// NEXT chunk's raw input window (25 values per thread, clamped addresses: branch-free and in flight together), apply the
-// previous layer's InstanceNorm + LeakyReLU and write it to the other half of a double-buffered LDS window while the consumers
-// run the current chunk's 240 MFMAs.  One workgroup barrier per chunk.  (As a single-role 256-thread kernel the memory side
-// alone took 276 us and the MFMA side alone 336 us for conv2, and they overlapped poorly: 515 us; this form: 476 us.)
-__global__ __launch_bounds__(512) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
-                                                        const float* __restrict__ wimg, const float* __restrict__ bias,
-                                                        float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout,
-                                                        int ntile, int tpw) {
-    // A workgroup walks `tpw` consecutive 64-position tiles of one (sample, 64-channel group): the (tile, chunk) stages form ONE
-    // pipeline, so the producers' first fetch and the consumers' epilogue of a tile overlap neighbouring stages.
-    // Measured on MI355X at B = 512 (profiles/r02b): conv2 505 -> 499 us, conv3 347 -> 338 us with this and the weight ring below --
-    // and 502 us with the producers additionally software-pipelined two stages deep (raw loads given two stage-times to land; not
-    // kept).  So neither the per-tile prologue, nor the weight fetch, nor the activation fetch latency sets the 12 us stage time
-    // (8 us of it is MFMA issue of the two co-resident workgroups).  Cutting the producers' arithmetic from 10 to 4 VALU operations
-    // per element on interior tiles (no clamp, no tail mask, max() for the LeakyReLU) changed nothing either (496 us): the producer
-    // side is not the limiter in any of its aspects; the consumers' loop -- one LDS operand read per MFMA, 50 % of the LDS pipe
-    // with two workgroups per CU -- sets the pace at 59 % matrix-pipe occupancy.
-    __shared__ float sIn[2][kCvCI * kCvWinP];
+// wimg: [co tile (Cout/16)][chunk (Cin/16)][tap (15)][lane 64][4]: lane (s16, g) of tap k holds W[co = 16 ct + s16][ci = 16 chunk + 4 cig + g][k],
+//       cig = 0..3 (build_shared_weights() in ls_api.cpp): one float4 = the four MFMA steps of one tap.
+//
+// Producer / consumer workgroup (512 threads).  Waves 4-7 only stage: they fetch the NEXT 16-channel window (25 clamped loads per
+// thread, in flight together), apply the previous layer's InstanceNorm + LeakyReLU and write it to the other half of a
+// double-buffered LDS window.  Waves 0-3 only multiply: wave w = channel tile w x the four position tiles, so one float4 of
+// weights per tap feeds 16 MFMAs (15 fragment loads per stage and wave, a ring three taps ahead).  One workgroup barrier per
+// (tile, chunk) stage; a workgroup walks `tpw` consecutive 64-position tiles of one (sample, 64-channel group) as ONE pipeline.
+//
+// Round 3.  In-kernel stamps (tools/conv_bench.cpp -DLS_CONV_PROF, profiles/r03b) of rounds 1-2's form showed the PRODUCERS
+// waiting 14.5 k of every 25.4 k-cycle stage: the consumers set the pace, two of them per SIMD at 7.7 k cycles of MFMA issue per
+// stage each, because (1) every MFMA had its own ds_read_b32 + v_add_u32 with the wait right behind it (20.5 k cycles per stage in
+// the loop) and (2) the per-tile epilogue was 32 dependent DPP reduction chains and 64 separately predicated stores (10 k cycles).
+// Tried first: consumer wave = one position tile x all four channel tiles (one LDS value feeds four MFMAs) -- but then every wave
+// streams the whole 61 KB weight chunk per stage: 480 KB per CU and stage through the 64 B/clk vector-memory path, behind the
+// producers' window loads in the same in-order queues; stages of 26 - 58 k cycles (553 us).  And a one-role form (every wave
+// multiplies and stages a quarter of the next window, three 256-thread workgroups per CU): VMEM loads return in order, so a wave
+// with window loads in flight waits for them at its next weight fragment (553 us too).
+// Kept: the weight reuse of the old mapping (16 MFMAs per fragment) AND one LDS read per four MFMAs, by laying the window out as
+// [row][r][pt]: element x = 96 pt + r of a row (position tile pt, offset r = 6 s16 + tap) sits at slot r, component pt, so the four
+// position tiles' operands of one (lane, tap) are ONE ds_read_b128.  r runs to 104 > 95, so the first 9 elements of tiles 1..3
+// (and the 9 past the last tile) are written twice, also as slots 96..104 of the previous tile.  105 slots = an odd number of
+// 16-byte units per row: conflict-free under gfx950's b128 lane groups for every tap (checked exhaustively).  The epilogue keeps
+// ONE (count, mean, M2) partial per (channel, 64-position tile) instead of four.  The convolution results are bit-identical to the
+// old kernel's (same MFMA order per accumulator); the statistics are merged from coarser partials (double-precision merge, ~1e-8).
+constexpr int kCvSlots = 105, kCvRow = 4 * kCvSlots;       // floats per window row in the [r][pt] layout
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt: every global load in flight --
+// the producers' look-ahead window, the consumers' weight ring -- and every output store would have to land before each stage's barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// this thread's 25 window elements through a buffer descriptor over the whole input tensor: SGPR base + one 32-bit lane offset +
+// immediates (3.7 instead of 13 matrix-pipe cycles of issue per load, and no address arithmetic at all).  No clamping: past the end of
+// a row the loads read the next row (finite values the tail select discards), past the end of the tensor the descriptor returns 0.
+__device__ __forceinline__ void conv_stage_load(float (&vals)[25], __amdgpu_buffer_rsrc_t rs, int off) {
+#pragma unroll
+    for (int q = 0; q < 25; ++q) vals[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 64 * q, 0, 0));
+}
+// element o = c + 16 q of the row: position tile o / 96 = q / 6, offset r = o % 96 = c + 16 (q % 6) (c < 16)
+template <bool TAIL>
+__device__ __forceinline__ void conv_stage_store(const float (&vals)[25], float* __restrict__ dst, int c, int validw, float vm, float vr) {
+    float* d = dst + 4 * c;
+#pragma unroll
+    for (int q = 0; q < 25; ++q) {
+        const int o = c + 16 * q;
+        float v = (vals[q] - vm) * vr;                                  // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
+        v = fmaxf(v, 0.3f * v);
+        if (TAIL) v = o < validw ? v : 0.f;
+        if (q < 24) d[64 * (q % 6) + q / 6] = v;                        // slot r, component pt
+        if (q >= 6 && q % 6 == 0 && c < 9) d[4 * 96 + q / 6 - 1] = v;   // the same element as slot 96 + r of the previous tile
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
+                                                           const float* __restrict__ wimg, const float* __restrict__ bias,
+                                                           float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout,
+                                                           int ntile, int tpw) {
+    __shared__ __attribute__((aligned(16))) float sIn[2][kCvCI * kCvRow];
     const int b = blockIdx.z, co0 = blockIdx.y * kCvTC;
     const int t0 = blockIdx.x * tpw, t1 = min(ntile, t0 + tpw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = Cin / kCvCI;
     const int nstage = (t1 - t0) * nchunk;
-    constexpr int NV = (kCvWin + 15) / 16;
     if (w >= 4) {
-        // ---------------- producers
-        const int pt = tid - 256;
-        auto stage = [&](int sidx, float* dst) {
+        // ---------------- producers: thread (row sr of the 16-channel window, columns sc + 16 q).  (Loads TWO stages ahead -- window s+2
+        // requested before window s+1 is written, straight-line so that the waits really are vmcnt(25) -- measured slower, 496 vs
+        // 482 us: fetch latency is not what the stage waits for.)
+        const int pt = tid - 256, sr = pt >> 4, sc = pt & 15;
+        const auto rsin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)min((long long)gridDim.z * Cin * Lin * 4, 0x7fffffffll), 0x00020000);
+        auto stage = [&](int sidx, float* buf) {
             const int tl = sidx / nchunk, c = sidx - tl * nchunk;
             const int in0 = (t0 + tl) * kCvTP * kCvS;
-            const int validw = Lin - in0;                                   // >= 1 for every tile that has an output position
-            const size_t row = (size_t)b * Cin + c * kCvCI + (pt >> 4);
-            const float vm = stats[row * 2], vr = stats[row * 2 + 1];   // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
-            const float* src = in + row * Lin + in0;
-            float vals[NV];
+            const int validw = min(Lin - in0, kCvWin);                     // >= 1 for every tile that has an output position
+            const int row = (b * Cin + c * kCvCI + sr);
+            const float vm = stats[(size_t)row * 2], vr = stats[(size_t)row * 2 + 1];
+            float vals[25];
+            if (LS_CONV_ABL & 16) return;
+            if (LS_CONV_ABL & 4) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) vals[q] = src[min((pt & 15) + 16 * q, validw - 1)];      // clamped: branch-free, in flight together
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                const int o = (pt & 15) + 16 * q;
-                float v = (vals[q] - vm) * vr;
-                v = v >= 0.f ? v : 0.3f * v;
-                if (o < kCvWin) dst[(pt >> 4) * kCvWinP + o] = o < validw ? v : 0.f;
-            }
+                for (int q = 0; q < 25; ++q) vals[q] = vm + (float)q;
+            } else conv_stage_load(vals, rsin, (row * Lin + in0 + sc) * 4);
+            if (validw >= kCvWin) conv_stage_store<false>(vals, buf + sr * kCvRow, sc, validw, vm, vr);
+            else conv_stage_store<true>(vals, buf + sr * kCvRow, sc, validw, vm, vr);
         };
         stage(0, sIn[0]);
-        __syncthreads();
+        lds_barrier();
         for (int sidx = 0; sidx < nstage; ++sidx) {
             if (sidx + 1 < nstage) stage(sidx + 1, sIn[(sidx + 1) & 1]);
-            if (w == 4) CV_STAMP(1, sidx, 0);
-            __syncthreads();
-            if (w == 4) CV_STAMP(1, sidx, 1);
+            CV_STAMP(w, sidx, 0);
+            lds_barrier();
+            CV_STAMP(w, sidx, 1);
         }
         return;
     }
-    // ---------------- consumers
+    // ---------------- consumers: wave w = channel tile w x position tiles 0..3
     const int s16 = lane & 15, g = lane >> 4;
-    const int lbase = g * kCvWinP + s16 * kCvS;                // + (4*cig)*WinP + 16*pt*S + k per step
-    const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
-    constexpr int kWPre = 3, kWRing = 5;                       // taps in flight; ring size (15 taps per chunk = 3 turns of the ring:
-    static_assert(kCvK % kWRing == 0 && kWPre < kWRing, "ring positions must line up across chunks");   // positions repeat per chunk)
+    const int lbase = g * kCvRow + 4 * (s16 * kCvS);                   // + (4 cig) rows + 4 * tap as immediates
+#ifndef LS_CONV_WPRE
+#define LS_CONV_WPRE 3
+#endif
+    constexpr int kWPre = LS_CONV_WPRE, kWRing = 5;                    // taps of weights in flight; ring size (15 taps per stage = 3 turns)
+    static_assert(kCvK % kWRing == 0 && kWPre < kWRing, "ring positions must line up across stages");
     f4 ring[kWRing];
-    // weight image through a buffer descriptor (ls_lanes.h: 3.7 instead of 16.8 matrix-pipe cycles per load): SGPR offset = this wave's
-    // channel tile, + chunk, + tap; VGPR offset = lane * 16
     const auto wrs = uniform_rsrc(wimg);
     const int wbase = ((int)blockIdx.y * 4 + w) * nchunk * kCvK * 1024;
     auto wld = [&](int off) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, off, 0)); };
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWPre; ++k) ring[k] = wld(wbase + k * 1024);
+    lds_barrier();
+
     int sidx = 0;
     for (int tile = t0; tile < t1; ++tile) {
         const int p0 = tile * kCvTP;
-        f4 acc[4];                                             // [position tile]
+        f4 acc[4];                                                     // [position tile]
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < nchunk; ++c, ++sidx) {
-            const float* sb = sIn[sidx & 1];
-            // weight operand: a ring of kWPre taps in flight (one float4 per tap = 16 MFMAs = 512 issue cycles; an L2 round trip under
-            // load is longer than that, so a distance of one tap stalled every tap); the ring runs on into the next chunk's image
+            const float* sb = sIn[sidx & 1] + lbase;
             const int wp = wbase + c * kCvK * 1024;
             const int wpn = wbase + ((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 1024;            // next stage's chunk (same tile or the next)
-            if (sidx == 0) {
+            f4 Bv[2][4];                                               // [tap parity][cig] = the four position tiles' operands
 #pragma unroll
-                for (int k = 0; k < kWPre; ++k) ring[k] = wld(wp + k * 1024);
-            }
+            for (int cig = 0; cig < 4; ++cig) Bv[0][cig] = *reinterpret_cast<const f4*>(sb + (4 * cig) * kCvRow);
 #pragma unroll
             for (int k = 0; k < kCvK; ++k) {
+                // tap k: [operand reads of tap k+1, weight fragment of tap k+3] pinned in front of [the 16 MFMAs of tap k]: left to itself
+                // the scheduler sinks every load next to its first use and waits for it there
+                if (k + 1 < kCvK && !(LS_CONV_ABL & 1)) {
+#pragma unroll
+                    for (int cig = 0; cig < 4; ++cig) Bv[(k + 1) & 1][cig] = *reinterpret_cast<const f4*>(sb + (4 * cig) * kCvRow + 4 * (k + 1));
+                }
+                const int kn = k + kWPre;
+                if (!(LS_CONV_ABL & 2)) ring[kn % kWRing] = wld(kn < kCvK ? wp + kn * 1024 : wpn + (kn - kCvK) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
                 const f4 A = ring[k % kWRing];
-                ring[(k + kWPre) % kWRing] = wld((k + kWPre < kCvK) ? wp + (k + kWPre) * 1024 : wpn + (k + kWPre - kCvK) * 1024);
 #pragma unroll
-                for (int cig = 0; cig < 4; ++cig) {
+                for (int cig = 0; cig < 4; ++cig)
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) {
-                        const float Bv = sb[lbase + (4 * cig) * kCvWinP + 16 * pt * kCvS + k];
-                        acc[pt] = MFMA(A[cig], Bv, acc[pt]);
-                    }
+                    for (int t = 0; t < 4; ++t) acc[t] = MFMA(A[cig], Bv[k & 1][cig][t], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            CV_STAMP(w, sidx, 0);
+            lds_barrier();
+            CV_STAMP(w, sidx, 1);
+        }
+        // epilogue of this tile: lane (s16, g) holds out[co0 + 16 w + 4 g + j][p0 + 16 t + s16]
+        if ((LS_CONV_ABL & 8) && acc[0][0] != 12345.f) continue;
+        const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
+        float v[4][4];                                                 // [position tile][j]
+        bool valid[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            valid[t] = p0 + 16 * t + s16 < Lout;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[t][j] = acc[t][j] + bv[j];
+        }
+        {
+            float* o = out + ((size_t)b * Cout + co0 + 16 * w + 4 * g) * Lout + p0 + s16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (valid[t]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[(size_t)j * Lout + 16 * t] = v[t][j];
                 }
             }
-            if (w == 0) CV_STAMP(0, sidx, 0);
-            __syncthreads();
-            if (w == 0) CV_STAMP(0, sidx, 1);
         }
-        // epilogue of this tile (registers -> global only): runs while the producers stage the next tile's second chunk
+        if (spart) {
+            // (count, mean, M2) of every (channel, 64-position tile), two-pass inside the tile: a lane first adds up its own four
+            // positions, then ONE 16-lane reduction per channel and pass (8 DPP chains side by side; rounds 1-2 reduced every
+            // 16-position sub-tile separately: 32 chains, ~350 VALU instructions per wave and tile = 0.8 per MFMA of the kernel)
+            const int nv = min(kCvTP, Lout - p0);
+            const float inv_nv = 1.0f / (float)nv;
+            float s1[4], m2[4];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            const int p = p0 + 16 * pt + s16;
-            const bool valid = p < Lout;
-            const int nv = min(16, max(0, Lout - (p0 + 16 * pt)));
-            const float inv_nv = nv > 0 ? 1.0f / (float)nv : 0.f;
+            for (int j = 0; j < 4; ++j)
+                s1[j] = ((valid[0] ? v[0][j] : 0.f) + (valid[1] ? v[1][j] : 0.f)) + ((valid[2] ? v[2][j] : 0.f) + (valid[3] ? v[3][j] : 0.f));
+#define LS_ROW_STEP(arr, CTRL) _Pragma("unroll") for (int j = 0; j < 4; ++j) arr[j] = dpp_add<CTRL>(arr[j]);
+            LS_ROW_STEP(s1, 0xB1) LS_ROW_STEP(s1, 0x4E) LS_ROW_STEP(s1, 0x141) LS_ROW_STEP(s1, 0x140)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + 16 * w + 4 * g + j;
-                const float v = acc[pt][j] + bv[j];
-                if (valid) out[((size_t)b * Cout + co) * Lout + p] = v;
-                if (spart) {
-                    const float s1 = row16_sum(valid ? v : 0.f);
-                    const float mean = s1 * inv_nv;
-                    const float d = valid ? v - mean : 0.f;
-                    const float m2 = row16_sum(d * d);
-                    if (s16 == 0) {
-                        float* sp = spart + (((size_t)b * Cout + co) * (ntile * 4) + tile * 4 + pt) * 3;
-                        sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
-                    }
+                s1[j] *= inv_nv;                                       // mean of the tile
+                float q = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float d = valid[t] ? v[t][j] - s1[j] : 0.f;
+                    q = fmaf(d, d, q);
+                }
+                m2[j] = q;
+            }
+            LS_ROW_STEP(m2, 0xB1) LS_ROW_STEP(m2, 0x4E) LS_ROW_STEP(m2, 0x141) LS_ROW_STEP(m2, 0x140)
+#undef LS_ROW_STEP
+            if (s16 == 0) {
+                float* sp = spart + (((size_t)b * Cout + co0 + 16 * w + 4 * g) * ntile + tile) * 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float* q = sp + (size_t)j * ntile * 3;
+                    q[0] = (float)nv; q[1] = s1[j]; q[2] = m2[j];
                 }
             }
         }
@@ -326,14 +402,23 @@ hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* 
         }
     }
     const int ntile = (Lout + kCvTP - 1) / kCvTP;
-    // tiles per workgroup: the whole row when that still leaves >= 2 workgroups per CU; otherwise split rows until it does
+    // tiles per workgroup: a workgroup walks `tpw` tiles of one (sample, 64-channel group) as one pipeline (one exposed window fill
+    // per workgroup); the chip holds 512 workgroups at a time (2 per CU), so pick the split whose last round is fullest:
+    // cost = rounds x (stages per workgroup + 1)
+    const int nchunk = Cin / kCvCI;
     int tpw = ntile;
-    while (tpw > 1 && (long long)((ntile + tpw - 1) / tpw) * (Cout / kCvTC) * B < 512) tpw = (tpw + 1) / 2;
+    long long best = -1;
+    for (int nx = 1; nx <= ntile; ++nx) {
+        const int t = (ntile + nx - 1) / nx;
+        const long long wgs = (long long)((ntile + t - 1) / t) * (Cout / kCvTC) * B;
+        const long long cost = ((wgs + 511) / 512) * ((long long)t * nchunk + 1);
+        if (best < 0 || cost < best) { best = cost; tpw = t; }
+    }
     dim3 grid((ntile + tpw - 1) / tpw, Cout / kCvTC, B);
     hipLaunchKernelGGL(k_conv1d_mfma, grid, dim3(512), 0, st, in, stats, wimg, bias, out, out_stats ? spart : nullptr, Cin, Cout, Lin, Lout, ntile, tpw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !out_stats) return e;
-    return launch_stats_merge(spart, out_stats, B * Cout, ntile * 4, st);
+    return launch_stats_merge(spart, out_stats, B * Cout, ntile, st);
 }
 
 // conv1 (audio_enc.py:10): Conv1d(1, 32, 15, stride 5, padding 1600) on the raw waveform + the InstanceNorm statistics of

@@ -189,10 +189,37 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     // instead -- all 4 * MT float4 at once would double their register footprint and cost a wave of occupancy.
     const bool fastout = FAST && cvec && !partial;
     f4 biasv[4], rv[4][DMA ? MT : 1];
+    f4 wsv[DMA ? 4 : 1], addv[DMA ? 4 : 1];
+    float lmean[DMA ? MT : 1], lrstd[DMA ? MT : 1];
     auto fetch_addends = [&](int m0, int n0) {
         if (!DMA || !fastout) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) biasv[i] = a.bias ? *reinterpret_cast<const f4*>(a.bias + n0 + wn * 64 + 16 * i + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (DMA) {
+            if (a.ln_part) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wsv[i] = *reinterpret_cast<const f4*>(a.wsum + n0 + wn * 64 + 16 * i + 4 * g);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    // the row's statistics from its eight 64-column partials (equal counts): mean of means; M2 = sum M2_p + 64 sum (mean_p - mean)^2
+                    const f4* pp = reinterpret_cast<const f4*>(a.ln_part + (size_t)(m0 + wm * 16 * MT + 16 * j + s16) * 16);
+                    const f4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+                    const float mean = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) * 0.125f;
+                    float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]));
+                    float dq = 0.f;
+#define LS_DQ(v) { const float d = (v) - mean; dq = fmaf(d, d, dq); }
+                    LS_DQ(p0[0]) LS_DQ(p0[2]) LS_DQ(p1[0]) LS_DQ(p1[2]) LS_DQ(p2[0]) LS_DQ(p2[2]) LS_DQ(p3[0]) LS_DQ(p3[2])
+#undef LS_DQ
+                    m2 = fmaf(64.f, dq, m2);
+                    lmean[j] = mean;
+                    lrstd[j] = 1.0f / sqrtf(m2 * (1.0f / 512.f) + 1e-5f);
+                }
+            }
+            if (a.addn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) addv[i] = *reinterpret_cast<const f4*>(a.addn + n0 + wn * 64 + 16 * i + 4 * g);
+            }
+        }
         if (a.R || a.accumulate) {
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
@@ -223,16 +250,43 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
                         if (a.accumulate) rv[i][0] += *reinterpret_cast<const f4*>(a.C + co[j] + 16 * i);
                     }
                 }
+                f4 outv[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    f4 v = acc[i][j] + biasv[i];
+                    f4 v;
+                    if constexpr (DMA) {
+                        if (a.ln_part) v = (acc[i][j] - lmean[j] * wsv[i]) * lrstd[j] + biasv[i];
+                        else v = acc[i][j] + biasv[i];
+                    } else v = acc[i][j] + biasv[i];
                     if (a.Cpre) *reinterpret_cast<f4*>(a.Cpre + co[j] + 16 * i) = v;
                     if (a.act) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gemm_act(v[e], a.act);
                     }
                     if (a.R || a.accumulate) v += rv[i][DMA ? j : 0];
+                    if constexpr (DMA) { if (a.addn) v += addv[i]; }
                     *reinterpret_cast<f4*>(a.C + co[j] + 16 * i) = v;
+                    outv[i] = v;
+                }
+                if constexpr (DMA) {
+                    if (a.part_out) {
+                        // (mean, M2) of this wave's 64 output columns of row m: 16 values in the lane, the other 48 in the lanes s16 + 16 g'
+                        float sm = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sm += (outv[i][0] + outv[i][1]) + (outv[i][2] + outv[i][3]);
+                        sm = xor32_sum(xor16_sum(sm));
+                        const float mean = sm * (1.0f / 64.f);
+                        float q = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float d = outv[i][e] - mean; q = fmaf(d, d, q); }
+                        q = xor32_sum(xor16_sum(q));
+                        if (g == 0) {
+                            float* po = a.part_out + ((size_t)(m0 + wm * 16 * MT + 16 * j + s16) * (a.N / 64) + (n0 / 64 + wn)) * 2;
+                            po[0] = mean; po[1] = q;
+                        }
+                    }
                 }
             }
             return;

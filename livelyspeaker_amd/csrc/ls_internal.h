@@ -115,13 +115,14 @@ struct LongStepArgs {
     const float* wt; const float* bt;      // [L][S][S], [L][S]   token-mixing Conv1d(S, S, 1)
     const float* wtp;                      // [L][160 x 160] the same, zero-padded, in k_long_tokmix's per-lane fragment order, or null
     const float* wc; const float* bc;      // [L][512][512], [L][512]
+    const float* wcf; const float* bcf; const float* wsum;   // fused form (S <= 160): Wc diag(alpha2), bc + Wc beta2, row sums of the folded weight
+    float* part1; float* part2;            // [rows padded to 128][8][2] (mean, M2) partials of LayerNorm 1 / 2 per 64-channel group
     const float* wout; const float* bout;  // [ldo = JF padded to 128s][512] (zero rows beyond JF), [JF]
     // workspaces
     float* xproj;                          // [B*T rounded up to 128][512]
     float* xpad;                           // [B*T rounded up to 128][JFP]  x_t with zero pad columns / rows (operand of the projection)
     float* X; float* U;                    // [2*B*S][512]
     float* OUT;                            // [2*B*S][ldo]
-    float* stats;                          // [2*B*S][2] (mean, rstd) of LN1
     int sampler, t_nonzero, clip_denoised;
     float c0, c1, c2, c3, c4;
 };

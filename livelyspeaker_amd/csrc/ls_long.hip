@@ -9,12 +9,18 @@
 // The fused kernel (ls_step_kernel.h) keeps a sample's whole [2S][512] operand in one CU's LDS; at S = 152 that is 632 KB, so this
 // path runs the same arithmetic as separate launches over ALL rows of the batch (row r = (pass, sample, token); pass 0 = cond,
 // 1 = uncond):
-//   k_long_assemble   token sequences: style / emotion tokens + static projection + x_t projection        (RAG.py:110-126)
-//   per layer:  k_long_addemb_stats (x += emb; row statistics) -> k_long_tokmix (LN1 applied while staging, Wt fragments from L2, MFMA,
-//               x += SiLU(Wt u + bt) in place)  [S > 160: k_long_addemb_ln + a batched, transposed GEMM per sequence]
-//               -> k_layernorm512 (u = LN2(x)) -> channel mixing GEMM (x += SiLU(u Wc^T + bc))
+//   k_long_assemble   token sequences: style / emotion tokens + static projection + x_t projection        (RAG.py:110-126),
+//                     + the first block's `x += emb`, + LayerNorm-1 partials of the result
+//   per layer (S <= 160), TWO launches (round 3; rounds 1-2: four, with two extra passes over the activations):
+//     k_long_tokmix   LN1 from the row partials while staging, Wt fragments from L2, MFMA, x += SiLU(Wt u + bt) in place,
+//                     + LayerNorm-2 partials of the new rows (one per 64-channel slab)
+//     channel mixing  k_gemm_tr on the RAW rows with LN2 folded around it: W' = Wc diag(alpha2), bias' = bc + Wc beta2 on the host,
+//                     LN2(x) Wc^T + bc = rstd (x W'^T - mean wsum) + bias' in the epilogue (two scalars per row from the partials);
+//                     then SiLU + residual, + the NEXT block's `x += emb`, + that block's LayerNorm-1 partials; the result goes
+//                     to the other activation buffer (the product reads whole rows that other tiles' workgroups would overwrite)
+//   [S > 160: k_long_addemb_ln + a batched, transposed GEMM per sequence -> k_layernorm512 -> channel mixing GEMM, as before]
 //   poseFinal GEMM -> k_long_update (CFG lerp + DDPM / DDIM update + noise)                 (cfg_sampler.py:31, gaussian_diffusion.py)
-// All products run on the fp32 MFMA GEMM k_gemm_tr (ls_gemm.hip).
+// All products run on the fp32 MFMA GEMM k_gemm_tr (ls_gemm.hip).  Row partials: [row][8][2] = (mean, M2) of each 64-channel group.
 #include "ls_internal.h"
 #include "ls_lanes.h"
 #include "ls_philox.h"
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(128) void k_long_padx(const float* __restrict__ x, 
 
 // X[(p*B + b)*S + s][:] : s = 0 style token (mu + eps * std), s = 1 emotion token (two-prefix variants), else frame t = s - NPRE:
 // xproj[b*T + t] + static_{c|u}[b*T + t].  One 128-thread workgroup per row (one float4 per thread).
-__global__ __launch_bounds__(128) void k_long_assemble(const LongStepArgs a) {
+__global__ __launch_bounds__(128) void k_long_assemble(const LongStepArgs a, int fused) {
     const int r = blockIdx.x, s = r % a.S, pb = r / a.S, b = pb % a.B, p = pb / a.B;
     const int ch = 4 * threadIdx.x;
     f4 v;
@@ -52,6 +58,19 @@ __global__ __launch_bounds__(128) void k_long_assemble(const LongStepArgs a) {
         v = mu + e * sd;
     } else {
         v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);
+    }
+    if (fused) {
+        // the first block's `x += emb` (mlp_module.py:68-69) and the (mean, M2) partials of its LayerNorm-1: 16 lanes = one 64-channel group
+        v += *reinterpret_cast<const f4*>(a.temb + ch);
+        const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q = fmaf(d, d, q); }
+        q = row16_sum(q);
+        if ((threadIdx.x & 15) == 0) {
+            float* po = a.part1 + ((size_t)r * 8 + (threadIdx.x >> 4)) * 2;
+            po[0] = mean; po[1] = q;
+        }
     }
     *reinterpret_cast<f4*>(a.X + (size_t)r * kD + ch) = v;
 }
@@ -80,47 +99,28 @@ __global__ __launch_bounds__(256) void k_long_addemb_ln(float* __restrict__ x, c
     ur[lane + 64] = (v1 - mean) * rstd * al[lane + 64] + be[lane + 64];
 }
 
-// x += emb; stats[row] = (mean, rstd) of LN_spatial over the 512 channels -- the normalisation itself is applied by the consumer
-// (k_long_tokmix) while it stages its operand, so no normalised copy of the activations is written.  One wave per row.
-__global__ __launch_bounds__(256) void k_long_addemb_stats(float* __restrict__ x, const float* __restrict__ emb, float* __restrict__ stats, int rows) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= rows) return;
-    f4* xr = reinterpret_cast<f4*>(x + (size_t)r * kD);
-    const f4* er = reinterpret_cast<const f4*>(emb);
-    const f4 v0 = xr[lane] + er[lane], v1 = xr[lane + 64] + er[lane + 64];
-    xr[lane] = v0;
-    xr[lane + 64] = v1;
-    const float s = (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
-    const float mean = wave_sum(s) * (1.0f / kD);
-    float q = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const float c0 = v0[e] - mean, c1 = v1[e] - mean; q += c0 * c0 + c1 * c1; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kD) + 1e-5f);
-    if (lane == 0) { stats[2 * (size_t)r] = mean; stats[2 * (size_t)r + 1] = rstd; }
-}
-
 // Token mixing of one sequence (Conv1d(S, S, 1) over the token axis, mlp_module.py:51-55, 70-71), fused with LN1 and the SiLU +
 // residual:   x[t][c] += SiLU( sum_k Wt[t][k] * LN1(x)[k][c] + bt[t] )
 // Workgroup = (sequence, 64-channel slab), 4 waves; wave w owns channel tile w of the slab and every token tile.  The operand
-// LN1(x)[k][64] is staged in LDS (normalised with the row statistics of k_long_addemb_stats and alpha / beta on the way in; rows >= S
-// are zero); the Wt fragments come straight from an L2-resident per-lane image (img[q][mt][lane] = Wt[16 mt + s16][16 q + 4 g ..+3],
-// zero-padded to KPAD x KPAD on the host, 100 KB per layer shared by every workgroup) through a buffer descriptor -- 3.7 matrix-pipe
-// cycles of issue per fragment (tools/vmem_cost.cpp), the next k block's ten fragments in flight while the current one is
-// multiplied.  With Wt in LDS instead (105 KB + the 43 KB operand: one 4-wave workgroup per CU, its 25-deep staging chain, operand
-// staging and in-place epilogue all exposed) the kernel took 42 us at 64 sequences for 10.7 us of MFMA issue; 43 KB lets three
-// workgroups share a CU.  D[token tile][channel tile] on v_mfma_f32_16x16x4_f32, B = the operand column (4 ds_read_b32 per 4
-// k-steps, shared by every token tile); the result goes back into x in place (a slab's columns belong to this workgroup only).
+// LN1(x)[k][64] is staged in LDS, normalised on the way in with the row's statistics -- merged here from its eight (mean, M2)
+// partials, which the producer of x left behind (k_long_assemble or the previous channel-mixing epilogue): no separate statistics
+// pass over the activations.  The Wt fragments come straight from an L2-resident per-lane image (img[q][mt][lane] =
+// Wt[16 mt + s16][16 q + 4 g ..+3], zero-padded to KPAD x KPAD on the host, 100 KB per layer shared by every workgroup) through a
+// buffer descriptor, the next k block's ten fragments in flight while the current one is multiplied.  D[token tile][channel tile]
+// on v_mfma_f32_16x16x4_f32.  Epilogue through LDS (round 3): SiLU(D + bt) goes back into the operand buffer as [token][channel];
+// then thread (row, 4 channels) adds it to x with float4 loads / stores (rounds 1-2: 40 scalar loads + 40 scalar stores per lane)
+// and reduces the new row's (mean, M2) over the slab -- the LayerNorm-2 partial the channel-mixing epilogue consumes.
 template <int KPAD>
-__global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ wimg,
-                                                        const float* __restrict__ bt, const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                        int S) {
+__global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, const float* __restrict__ part1, float* __restrict__ part2,
+                                                        const float* __restrict__ wimg, const float* __restrict__ bt,
+                                                        const float* __restrict__ alpha, const float* __restrict__ beta, int S) {
     constexpr int LU = 64 + 4, NMT = KPAD / 16, NQ = KPAD / 16;
     __shared__ __attribute__((aligned(16))) float sU[KPAD * LU];       // [KPAD][LU]
     const int seq = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
     float* xs = x + (size_t)seq * S * kD;
-    const float* st = stats + (size_t)seq * S * 2;
+    const float* p1 = part1 + (size_t)seq * S * 16;
     const auto wrs = uniform_rsrc(wimg);
     auto wfrag = [&](int q, int mt) {
         return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (q * NMT + mt) * 1024, 0));
@@ -128,22 +128,29 @@ __global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, c
     f4 An[NMT];
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) An[mt] = wfrag(0, mt);             // in flight during the operand staging
+    constexpr int NU = KPAD * 16 / 256;
+    const int c4 = tid & 15;
     {   // operand slab: LN1 applied on the way in; loads first (clamped rows: branch-free), then the LDS writes
-        constexpr int NU = KPAD * 16 / 256;
-        const int c4 = tid & 15;
         const f4 al = *reinterpret_cast<const f4*>(alpha + c0 + 4 * c4), be = *reinterpret_cast<const f4*>(beta + c0 + 4 * c4);
         f4 xv[NU];
-        float mu[NU], rs[NU];
+        float pm[NU], pq[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             const int r = min((tid >> 4) + 16 * j, S - 1);
             xv[j] = *reinterpret_cast<const f4*>(xs + (size_t)r * kD + c0 + 4 * c4);
-            mu[j] = st[2 * r]; rs[j] = st[2 * r + 1];
+            pm[j] = p1[r * 16 + 2 * (c4 & 7)]; pq[j] = p1[r * 16 + 2 * (c4 & 7) + 1];      // lane c4 holds partial c4 & 7 of its row
         }
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             const int r = (tid >> 4) + 16 * j;
-            const f4 v = (xv[j] - mu[j]) * rs[j] * al + be;
+            // row statistics from the eight equal-count partials: every lane of the 8-lane half row ends with the totals
+            float sm = pm[j];
+            sm = dpp_add<0xB1>(sm); sm = dpp_add<0x4E>(sm); sm = dpp_add<0x141>(sm);
+            const float mu = sm * 0.125f, d = pm[j] - mu;
+            float q = fmaf(64.f * d, d, pq[j]);
+            q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q); q = dpp_add<0x141>(q);
+            const float rs = 1.0f / sqrtf(q * (1.0f / kD) + 1e-5f);
+            const f4 v = (xv[j] - mu) * rs * al + be;
             *reinterpret_cast<f4*>(&sU[r * LU + 4 * c4]) = r < S ? v : (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -167,22 +174,38 @@ __global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, c
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][e], Bv[e], acc[mt], 0, 0, 0);
     }
-    // lane (s16, g) holds D[token = 16 mt + 4 g + r][channel = c0 + 16 w + s16].  All residual loads first, then the stores: written as
-    // `*p = *p + f(acc)` per element the compiler must keep every load behind the previous store (it cannot prove the addresses
-    // distinct), which serialises 40 L2 round trips per lane.
-    float res[NMT][4];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) res[mt][r] = xs[(size_t)min(16 * mt + 4 * g + r, S - 1) * kD + c0 + 16 * w + s16];
+    // lane (s16, g) holds D[token = 16 mt + 4 g + r][channel = c0 + 16 w + s16]: SiLU(D + bt) -> the operand buffer, as [token][channel]
+    __syncthreads();                                                      // every wave has read its last operand column
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = 16 * mt + 4 * g + r;
             const float v = acc[mt][r] + bt[min(t, S - 1)];
-            if (t < S) xs[(size_t)t * kD + c0 + 16 * w + s16] = res[mt][r] + v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+            sU[t * LU + 16 * w + s16] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
         }
+    __syncthreads();
+    // thread (row, channels 4 c4 ..): x += SiLU(.), whole rows as float4; (mean, M2) of the new row over this slab's 64 channels
+    {
+        f4 xv[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) xv[j] = *reinterpret_cast<const f4*>(xs + (size_t)min((tid >> 4) + 16 * j, S - 1) * kD + c0 + 4 * c4);
+        float* p2 = part2 + ((size_t)seq * S * 8 + blockIdx.y) * 2;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int r = (tid >> 4) + 16 * j;
+            const f4 v = xv[j] + *reinterpret_cast<const f4*>(&sU[r * LU + 4 * c4]);
+            const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q = fmaf(d, d, q); }
+            q = row16_sum(q);
+            if (r < S) {
+                *reinterpret_cast<f4*>(xs + (size_t)r * kD + c0 + 4 * c4) = v;
+                if (c4 == 0) { p2[(size_t)r * 16] = mean; p2[(size_t)r * 16 + 1] = q; }
+            }
+        }
+    }
 }
 
 // CFG combination + sampler update, element (b, t, c) of the internal [B][T][JF] layout; OUT rows are (pass, b, token) x ldo
@@ -231,16 +254,30 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     const int mpad = (a.B * a.T + 127) / 128 * 128;
     hipLaunchKernelGGL(k_long_padx, dim3(mpad), dim3(128), 0, st, a.x_in, a.xpad, a.B * a.T, a.JF, a.JFP);
     if ((e = launch_gemm_nt(a.xpad, a.JFP, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, mpad, D, a.JFP, 0, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a);
     // fused token mixing needs S <= 160 (accumulators for ten token tiles, the operand slab in LDS); longer sequences take the batched-GEMM form
     constexpr int kTokPad = 160;
     const bool fused_tok = a.wtp != nullptr && a.S <= kTokPad;
+    hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a, fused_tok ? 1 : 0);
+    float* Xc = a.X;                 // current activations; the fused form ping-pongs between X and U (an even number of layers ends in X)
+    float* Xo = a.U;
+    const int mrows = (rows + 127) / 128 * 128;         // whole GEMM tiles: the pad rows exist in the buffers and are never read back
     for (int l = 0; l < a.layers; ++l) {
         if (fused_tok) {
-            hipLaunchKernelGGL(k_long_addemb_stats, dim3((rows + 3) / 4), dim3(256), 0, st, a.X, a.temb, a.stats, rows);
-            hipLaunchKernelGGL((k_long_tokmix<kTokPad>), dim3(2 * a.B, 8), dim3(256), 0, st, a.X, a.stats, a.wtp + (size_t)l * kTokPad * kTokPad,
+            hipLaunchKernelGGL((k_long_tokmix<kTokPad>), dim3(2 * a.B, 8), dim3(256), 0, st, Xc, a.part1, a.part2, a.wtp + (size_t)l * kTokPad * kTokPad,
                                a.bt + (size_t)l * a.S, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.S);
-        } else {
+            GemmArgs g{};
+            g.A = op_rows(Xc, D, mrows, D);
+            g.B = op_rows(a.wcf + (size_t)l * D * D, D, D, D);
+            g.C = Xo; g.cri = INT_MAX; g.cro = 0; g.crs = D; g.cns = 1;
+            g.bias = a.bcf + (size_t)l * D; g.R = Xc; g.act = 1;
+            g.M = mrows; g.N = D; g.K = D;
+            g.ln_part = a.part2; g.wsum = a.wsum + (size_t)l * D;
+            g.addn = l + 1 < a.layers ? a.temb : nullptr;          // the next block's `x += emb`
+            g.part_out = a.part1;
+            if ((e = launch_gemm_tr(g, true, true, 1, st)) != hipSuccess) return e;
+            float* t = Xc; Xc = Xo; Xo = t;
+            continue;
+        }
         hipLaunchKernelGGL(k_long_addemb_ln, dim3((rows + 3) / 4), dim3(256), 0, st, a.X, a.temb, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.U, rows);
         {   // token mixing, one problem per sequence: C'[channel][token] = sum_k U[k][channel] Wt[token][k] + bt[token], stored at
             // X[token][channel] (crs = 1, cns = 512): the Conv1d bias is per output TOKEN, which is the GEMM's per-column bias in this form
@@ -253,10 +290,10 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
             g.nbatch = 2 * a.B; g.bsA = (long long)a.S * D; g.bsB = 0; g.bsC = (long long)a.S * D;
             if ((e = launch_gemm_tr(g, false, true, 1, st)) != hipSuccess) return e;
         }
-        }
         if ((e = launch_layernorm512(a.X, nullptr, 0, a.ln2a + (size_t)l * D, a.ln2b + (size_t)l * D, a.U, rows, st)) != hipSuccess) return e;
         if ((e = launch_gemm_nt(a.U, D, a.wc + (size_t)l * D * D, D, a.bc + (size_t)l * D, a.X, D, a.X, D, rows, D, D, 1, st)) != hipSuccess) return e;
     }
+    if (fused_tok && Xc != a.X) return hipErrorInvalidValue;              // odd layer counts would end in the other buffer
     if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, rows, a.ldo, D, 0, st)) != hipSuccess) return e;      // N = JF padded to 128s (zero weight rows)
     const int TJ = a.T * a.JF;
     hipLaunchKernelGGL(k_long_update, dim3((TJ + 1023) / 1024, a.B), dim3(256), 0, st, a);

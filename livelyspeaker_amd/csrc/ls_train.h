@@ -32,6 +32,13 @@ struct GemmArgs {
     // (Cpre / R follow C's batch stride; the bias is shared by all problems of the batch)
     int nbatch, splits;
     long long bsA, bsB, bsC;
+    // LayerNorm fused around the product (long-sequence channel mixing, ls_long.hip; LDS-DMA variant only).  With W' = W diag(alpha)
+    // and bias' = bias + W beta folded on the host, LN(x) W^T = rstd (x W'^T - mean * wsum) + bias', wsum[n] = sum_k W'[n][k]: the
+    // product runs on the RAW rows and the normalisation is two per-row scalars in the epilogue.
+    const float* ln_part;    // [M][8][2] (mean, M2) of the eight 64-column groups of every A row, or null
+    const float* wsum;       // [N]
+    const float* addn;       // [N] vector added to every output row after the residual (the next block's `x += emb`), or null
+    float* part_out;         // [M][N / 64][2] (mean, M2) of every 64-column group of the OUTPUT rows (the next LayerNorm's partials), or null
 };
 
 inline GemmOperand gemm_operand(const float* p, int ri, long long ro, long long rs, int ki, long long ko, long long ks, bool kcontig,

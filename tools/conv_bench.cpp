@@ -74,25 +74,35 @@ int main(int argc, char** argv) {
         std::printf("    max |out - host| over 2048 sampled entries: %.3g %s\n", worst, worst < 2e-3 ? "ok" : "MISMATCH");
 #ifdef LS_CONV_PROF
         if (L < 2) {
-            unsigned long long* dprof; hipMalloc(&dprof, 2 * 1024 * 2 * 8); hipMemset(dprof, 0, 2 * 1024 * 2 * 8);
+            unsigned long long* dprof; hipMalloc(&dprof, 8 * 1024 * 2 * 8); hipMemset(dprof, 0, 8 * 1024 * 2 * 8);
             const int wg = B / 2 + 3;
             hipMemcpyToSymbol(HIP_SYMBOL(ls::g_conv_prof), &dprof, sizeof dprof);
             hipMemcpyToSymbol(HIP_SYMBOL(ls::g_conv_prof_wg), &wg, sizeof wg);
             run(); hipStreamSynchronize(st);
-            std::vector<unsigned long long> p(2 * 1024 * 2);
+            std::vector<unsigned long long> p(8 * 1024 * 2);
             hipMemcpy(p.data(), dprof, p.size() * 8, hipMemcpyDeviceToHost);
             unsigned long long* nul = nullptr;
             hipMemcpyToSymbol(HIP_SYMBOL(ls::g_conv_prof), &nul, sizeof nul);
-            const unsigned long long t0 = p[0] < p[2048] ? p[0] : p[2048];
-            std::printf("    stage timeline of workgroup z=%d (cycles since its first stamp): consumer reach/leave | producer reach/leave | who waited\n", wg);
-            double cw = 0, pw = 0; int ns = 0;
+            unsigned long long t0 = ~0ull;
+            for (int wv = 0; wv < 8; ++wv) if (p[wv * 2048] && p[wv * 2048] < t0) t0 = p[wv * 2048];
+            std::printf("    barrier timeline of workgroup z=%d: per stage, when each wave REACHED the barrier (cycles before its release; waves 0-3 multiply, 4-7 stage) | release time\n", wg);
+            double wait[8] = {0}; int ns = 0; unsigned long long last = 0;
             for (int s = 0; s < 1024 && p[2 * s]; ++s) {
-                const long long ca = p[2 * s] - t0, cl = p[2 * s + 1] - t0, pa = p[2048 + 2 * s] - t0, pl = p[2048 + 2 * s + 1] - t0;
-                if (s < 12 || s % 8 == 0) std::printf("      stage %3d: C %8lld %8lld | P %8lld %8lld | %s by %lld\n", s, ca, cl, pa, pl, ca < pa ? "consumer waited" : "producer waited", ca < pa ? pa - ca : ca - pa);
-                cw += cl - ca; pw += pl - pa; ++ns;
+                unsigned long long rel = 0;
+                for (int wv = 0; wv < 8; ++wv) if (p[wv * 2048 + 2 * s] > rel) rel = p[wv * 2048 + 2 * s];   // the last arrival releases it
+                if (s < 16) {
+                    std::printf("      stage %3d:", s);
+                    for (int wv = 0; wv < 8; ++wv) std::printf(" %6lld", (long long)(rel - p[wv * 2048 + 2 * s]));
+                    std::printf(" | %8lld (+%lld)\n", (long long)(rel - t0), (long long)(rel - (last ? last : t0)));
+                }
+                for (int wv = 0; wv < 8; ++wv) wait[wv] += (double)(rel - p[wv * 2048 + 2 * s]);
+                last = rel; ++ns;
             }
-            if (ns) std::printf("    %d stages: mean barrier wait consumer %.0f cycles, producer %.0f cycles; mean stage %.0f cycles\n", ns, cw / ns, pw / ns,
-                                (double)(p[2 * (ns - 1)] - p[0]) / (ns > 1 ? ns - 1 : 1));
+            if (ns) {
+                std::printf("    %d stages, mean stage %.0f cycles; mean wait at the barrier per wave:", ns, (double)(last - t0) / ns);
+                for (int wv = 0; wv < 8; ++wv) std::printf(" %.0f", wait[wv] / ns);
+                std::printf("\n");
+            }
             hipFree(dprof);
         }
 #endif
