@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--parity-samples", type=int, default=2)
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no single-pass / LivelySpeaker / bf16x3 / train legs")
     ap.add_argument("--legs", default="all", help="secondary legs to run: 'all', 'none' or a comma list of "
-                    "single,split,lively,beat,train,seeds (e.g. --legs lively)")
+                    "single,split,lively,beat,train,seeds,small (e.g. --legs lively)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--train-leg", action="store_true", help="also time the training step (default on at 1 GPU; at N>1 it "
                     "adds the RCCL gradient all-reduce, the build's only per-step collective)")
@@ -611,7 +611,7 @@ def main():
             diffusion.sample_offset, diffusion.philox_seed = first, None
 
     extra = not a.no_extra_legs and a.precision == "fp32" and a.legs != "none"
-    legs = set(("single", "split", "lively", "beat", "train", "seeds") if a.legs in ("all", "none") else a.legs.split(","))
+    legs = set(("single", "split", "lively", "beat", "train", "seeds", "small") if a.legs in ("all", "none") else a.legs.split(","))
 
     # Secondary object: guidance scale 1 (what the reference's callers run): the uncond pass is legitimately skipped
     single = None
@@ -686,6 +686,40 @@ def main():
             seeds = {"error": repr(e)[:300]}
         finally:
             diffusion.noise_source = "philox"
+
+    # BASELINE configs[0]'s shape on the GPU (4 clips, 50-step DDPM): a latency case -- the engine runs such batches on its batch-level
+    # kernels (ls_set_path "auto"); the fused one-workgroup-per-sample kernel is timed beside it
+    small = None
+    if extra and world == 1 and "small" in legs and a.dataset == "ted":
+        try:
+            small = {}
+            for path in ("auto", "fused"):
+                m4, d4 = create_model_and_diffusion(mk_args(cfg, 50), "", dataset=a.dataset)
+                m4.load_state_dict(sd, strict=False)
+                m4.to(dev)
+                m4.eval()
+                m4.cache_conditioning = False
+                m4.step_path = path
+                c4 = ClassifierFreeSampleModel(m4)
+                d4.noise_source = "philox"
+                y4 = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_cond(cfg, 4, scale=1.5).items()}
+                call4 = lambda: d4.p_sample_loop(c4, (4, cfg.njoints, cfg.nfeats, cfg.nframes), clip_denoised=False, model_kwargs={"y": y4},
+                                                 skip_timesteps=0, init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
+                call4(); call4()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    o4 = call4()
+                fence()
+                e4 = (time.perf_counter() - t0) / 10
+                tm4 = m4.engine().timing()
+                small[path] = {"ms_per_call": round(e4 * 1e3, 3), "value": round(4 * cfg.nframes / e4, 1), "unit": "pose-frames/s",
+                               "step_ms": round(tm4["loop_ms"] / max(tm4["n_step_launches"], 1), 4), "finite": bool(torch.isfinite(o4).all())}
+                m4.engine().close()
+            small["workload"] = "TED RAG, 4 clips x 34 frames, 50-step DDPM, CFG 1.5 (BASELINE configs[0]'s shape; Philox noise): `auto` = the engine's choice "
+            small["workload"] += "(batch-level kernels below 128 clips), `fused` = one workgroup per clip"
+        except Exception as e:
+            small = {"error": repr(e)[:300]}
 
     lively = None
     if extra and a.dataset == "ted" and not strong and "lively" in legs:
@@ -768,6 +802,8 @@ def main():
             rec["single_pass"] = single
         if seeds is not None:
             rec["identical_seeds_mode"] = seeds
+        if small is not None:
+            rec["config1_shape"] = small
         if lively is not None:
             rec["livelyspeaker"] = lively
         if others is not None:

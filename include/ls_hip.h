@@ -197,6 +197,12 @@ int ls_set_weight(ls_handle* h, const char* key, const float* data, size_t n);
 int ls_commit_weights(ls_handle* h);
 
 int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; default FP32 */
+/* Which kernels a 34-frame model's steps run on.  0 (default): chosen per prepared batch -- the fused kernel gives every sample a
+ * workgroup (= one CU: a step costs one CU's time for eight layers however small the batch), the batch-level kernels of the
+ * long-sequence path spread the same rows over the whole chip and are faster for small batches; 1: always one workgroup per
+ * sample; 2: always batch-level (exact fp32, both CFG passes always evaluated).  Same arithmetic either way, different summation
+ * order: results agree to ~1e-5, not bitwise.  Takes effect at the next ls_prepare. */
+int ls_set_path(ls_handle* h, int mode);
 int ls_set_schedule(ls_handle* h, const ls_schedule* s);
 int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */
 /* The same, enqueued on the handle's stream WITHOUT waiting: later calls on this handle are ordered behind it, so the caller may

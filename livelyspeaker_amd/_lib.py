@@ -101,7 +101,7 @@ class LsEvalConfig(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
@@ -178,6 +178,7 @@ def load_library(build_if_missing: bool = True):
         getattr(lib, fn).restype = C.c_void_p
     lib.ls_philox_x_init.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     lib.ls_set_precision.argtypes = [C.c_void_p, C.c_int]
+    lib.ls_set_path.argtypes = [C.c_void_p, C.c_int]
     lib.ls_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, c_i64p, c_i64p]
     lib.ls_sag_create.argtypes = [C.POINTER(LsSagConfig), C.POINTER(C.c_void_p)]
     lib.ls_sag_destroy.argtypes = [C.c_void_p]
@@ -315,8 +316,12 @@ class Engine:
     """One handle = one GPU. Thin, typed wrapper over the C-ABI; all arrays in/out are host numpy
     (torch CUDA tensors on the same device may be passed to ``sample``/``prepare`` via ``*_device``)."""
 
+    #: which kernels the steps of a 34-frame model run on when the caller does not say: "auto" (batch-level kernels for small batches,
+    #: one workgroup per sample otherwise), "fused", "batch" (ls_set_path)
+    default_path = "auto"
+
     def __init__(self, njoints, nfeats, n_prefix_tokens, audio_len, n_emotions=0, nframes=34, n_pre_seq=4,
-                 latent_dim=512, layers=8, n_speakers=1400, device=0):
+                 latent_dim=512, layers=8, n_speakers=1400, device=0, path=None):
         self.lib = load_library()
         self.cfg = LsConfig(njoints, nfeats, nframes, n_prefix_tokens, n_pre_seq, latent_dim, layers, audio_len,
                             n_speakers, n_emotions, device, 0)
@@ -325,6 +330,9 @@ class Engine:
         if rc != 0:
             raise EngineError(f"ls_create failed ({rc}): {self.lib.ls_last_error(None).decode()}")
         self._stream = self.lib.ls_stream(self.h)
+        self.path = path or Engine.default_path
+        if nframes == 34 and self.path != "auto":
+            self.set_path(self.path)
         self.J, self.F, self.T, self.D = njoints, nfeats, nframes, latent_dim
         self.S = nframes + n_prefix_tokens
         self.layers = layers
@@ -354,6 +362,13 @@ class Engine:
         code = {"fp32": 0, "bf16x3": 1}.get(mode, mode)
         self._check(self.lib.ls_set_precision(self.h, int(code)), "ls_set_precision")
         self.precision = mode
+
+    def set_path(self, mode):
+        """'auto' (default: batch-level kernels for small batches, one workgroup per sample otherwise), 'fused', 'batch'; applies
+        from the next prepare()."""
+        code = {"auto": 0, "fused": 1, "batch": 2}.get(mode, mode)
+        self._check(self.lib.ls_set_path(self.h, int(code)), "ls_set_path")
+        self.path = mode
 
     # ---- weights / schedule --------------------------------------------------------------------
     def load_state_dict(self, sd: dict):

@@ -60,7 +60,10 @@ struct ls_handle {
     Variant var = kTED;
     int JF = 0, S = 0, R = 0, NOB = 0, KXQ = 0, MK = 0, KIN = 0, KF = 0, KFP = 0;      // KFP: KF padded to the GEMM's K tile
     int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
-    bool fused = true;
+    bool fused = true;      // the model HAS the fused kernel (34 frames)
+    bool use_long = false;  // the prepared batch runs the batch-level kernels (always when !fused; small batches of a fused model)
+    int path_mode = 0;      // ls_set_path: 0 auto, 1 one workgroup per sample (fused kernel), 2 batch-level kernels
+    int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
     DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_wcf, lw_bcf, lw_wsum, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
     DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_part1, lx_part2, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
@@ -457,15 +460,18 @@ int build_long_weights(ls_handle* h) {
     int rc;
 #define UP(buf, vec) if ((rc = upload(h, h->buf, (vec).data(), (vec).size() * sizeof(float))) != LS_OK) return rc
     if (S <= 160) {                                                                     // operand image of the fused token-mixing kernel
-        // per-lane fragment order: img[l][q][mt][lane = s16 + 16 g][e] = Wt[l][16 mt + s16][16 q + 4 g + e], zero beyond S
-        std::vector<float> wtp((size_t)L * 160 * 160, 0.f);
+        // per-lane fragment order: img[l][q][mt][lane = s16 + 16 g][e] = Wt[l][16 mt + s16][16 q + 4 g + e], zero beyond S; the token
+        // axis is padded to 48 (three tiles: the reference's 35 / 36 tokens) or to 160
+        const int P = S <= 48 ? 48 : 160, NT = P / 16;
+        h->tokpad = P;
+        std::vector<float> wtp((size_t)L * P * P, 0.f);
         for (int l = 0; l < L; ++l)
-            for (int q = 0; q < 10; ++q)
-                for (int mt = 0; mt < 10; ++mt)
+            for (int q = 0; q < NT; ++q)
+                for (int mt = 0; mt < NT; ++mt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 4; ++e) {
                             const int r = 16 * mt + (lane & 15), k = 16 * q + 4 * (lane >> 4) + e;
-                            if (r < S && k < S) wtp[(size_t)l * 160 * 160 + (((size_t)q * 10 + mt) * 64 + lane) * 4 + e] = wt[((size_t)l * S + r) * S + k];
+                            if (r < S && k < S) wtp[(size_t)l * P * P + (((size_t)q * NT + mt) * 64 + lane) * 4 + e] = wt[((size_t)l * S + r) * S + k];
                         }
         UP(lw_wtp, wtp);
     } else {
@@ -501,8 +507,10 @@ int build_long_weights(ls_handle* h) {
 }
 
 int build_images(ls_handle* h) {
-    int rc = h->fused ? build_fused_images(h) : build_long_weights(h);
+    // a 34-frame model carries both forms: the fused kernel (one workgroup per sample) and the batch-level kernels small batches run on
+    int rc = build_long_weights(h);
     if (rc != LS_OK) return rc;
+    if (h->fused && (rc = build_fused_images(h)) != LS_OK) return rc;
     if ((rc = build_shared_weights(h)) != LS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return LS_OK;
@@ -534,9 +542,12 @@ int ensure_temb_table(ls_handle* h) {
 // pair: the single-pass variant (two samples' cond pass per workgroup), legal when every guidance scale is 1
 hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
     s.batch = B;
-    if (h->fused) return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
-    // long-sequence path: the same step from batch-level kernels (both passes always; exact fp32 only)
+    // one workgroup per sample (fused kernel) unless the prepared batch runs on the batch-level kernels; per-sample timestep rows and
+    // the residual-stream trace exist in the fused kernel only
+    if (h->fused && !(h->use_long && s.temb_stride == 0 && !s.trace)) return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
+    // batch-level path: the same step from separate kernels over all rows (both passes always; exact fp32 only)
     LongStepArgs a{};
+    a.tokpad = h->tokpad;
     a.B = B; a.T = h->T; a.S = h->S; a.npre = h->cfg.n_prefix_tokens; a.JF = h->JF; a.JFP = h->JFP; a.ldo = (h->JF + 127) / 128 * 128; a.layers = h->cfg.layers;
     a.x_in = s.x_in; a.x_out = s.x_out; a.x0_out = s.x0_out; a.fwd_c = s.fwd_c; a.fwd_u = s.fwd_u;
     a.static_c = s.static_c; a.static_u = s.static_u; a.z_mu = s.z_mu; a.z_std = s.z_std; a.emo_tok = s.emo_tok; a.scale = s.scale;
@@ -594,6 +605,21 @@ void resolve_prepare_timing(ls_handle* h, bool block) {
     if (!h->prepare_pending) return;
     if (block ? hipEventSynchronize(h->ev[5]) != hipSuccess : hipEventQuery(h->ev[5]) != hipSuccess) return;
     if (hipEventElapsedTime(&h->timing.prepare_ms, h->ev[4], h->ev[5]) == hipSuccess) h->prepare_pending = false;
+}
+
+// Which kernels the prepared batch runs on.  The fused kernel gives one CU to each sample, so a step costs one CU's time for eight
+// layers (0.68 ms TED) however small the batch; the batch-level kernels spread the same rows over the whole chip (21 launches per
+// step) and win below kLongMaxBatch samples (measured: profiles/r03 small-batch table).  34-frame models only choose; other frame
+// counts have no fused kernel.
+constexpr int kLongMaxBatch = 128;
+void decide_path(ls_handle* h) {
+    const bool before = h->use_long;
+    if (!h->fused) h->use_long = true;
+    else if (h->precision != 0 || h->lw_wtp.p == nullptr) h->use_long = false;
+    else if (h->path_mode == 1) h->use_long = false;
+    else if (h->path_mode == 2) h->use_long = true;
+    else h->use_long = h->B > 0 && h->B <= kLongMaxBatch;
+    if (before != h->use_long) free_graph(h);
 }
 
 // upload timing of a slot whose copy has been enqueued: wait for it (long done in steady state) and add it to the loop's total
@@ -674,7 +700,7 @@ int sample_segment(ls_handle* h, const ls_sample_args* a) {
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_cd[slot], 0));
         if ((rc = close_upload(h, slot ^ 1)) != LS_OK) return rc;              // the PREVIOUS segment's host buffers are free from here on
     }
-    const bool pair = h->fused && h->all_scale_one && !a->two_pass_always;
+    const bool pair = h->fused && !h->use_long && h->all_scale_one && !a->two_pass_always;
     for (int k = a->seg_begin; k < a->seg_begin + a->seg_count; ++k) {
         const int i = n_exec - 1 - k, r = k - a->seg_begin;
         StepArgs s;
@@ -866,6 +892,17 @@ int ls_set_precision(ls_handle* h, int mode) {
     if (!h->fused && mode != LS_PRECISION_FP32) return fail(h, LS_EUNSUPPORTED, "the long-sequence path (nframes != %d) is exact fp32 only", kT);
     if (mode != h->precision) free_graph(h);
     h->precision = mode;
+    if (h->prepared && h->fused && mode != LS_PRECISION_FP32 && h->use_long) decide_path(h);       // bf16x3 exists in the fused kernel only
+    else if (h->prepared) { const bool was = h->use_long; decide_path(h); if (h->use_long && !was) h->prepared = false; }   // its workspaces come from ls_prepare
+    return LS_OK;
+}
+
+int ls_set_path(ls_handle* h, int mode) {
+    if (!h) return LS_EINVAL;
+    if (mode < 0 || mode > 2) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels)", mode);
+    if (mode == 2 && h->fused && h->lw_wtp.p == nullptr && h->committed) return fail(h, LS_EUNSUPPORTED, "batch-level kernels need S <= 160");
+    if (mode == 1 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no fused kernel", kT);
+    if (mode != h->path_mode) { h->path_mode = mode; h->prepared = false; free_graph(h); }      // takes effect at the next ls_prepare (workspaces)
     return LS_OK;
 }
 
@@ -982,7 +1019,8 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         HIPCHK(h, h->emo_tok.ensure((size_t)B * kD * sizeof(float)));
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, h->T));   // y['emo'][:, 0]
     }
-    if (!h->fused) {        // workspaces of the long-sequence path: token sequences of both passes, their LayerNorm'd copy, poseFinal output
+    { const int keepB = h->B; h->B = B; decide_path(h); h->B = keepB; }
+    if (h->use_long) {      // workspaces of the batch-level path: token sequences of both passes (two buffers), row partials, poseFinal output
         const void* old[5] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p, h->lx_xpad.p};
         const size_t rows = ((size_t)2 * B * h->S + 127) / 128 * 128;      // whole 128-row GEMM tiles (the fused channel-mixing product runs over the pad rows too)
         const size_t mpad = ((size_t)B * h->T + 127) / 128 * 128;           // x_t projection on whole 128-row tiles (k_long_padx)
@@ -1107,7 +1145,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     s.clip_denoised = a->clip_denoised;
     s.x_in = h->xa.f(); s.x_out = h->xb.f(); s.x0_out = h->fwd_cfg.f();
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
-    const bool pair = h->fused && h->all_scale_one && !a->two_pass_always;
+    const bool pair = h->fused && !h->use_long && h->all_scale_one && !a->two_pass_always;
     if (!per_sample) {
         fill_sampler(h, s, a->sampler, index, a->eta);
         s.noise = h->noise.f();
@@ -1228,12 +1266,12 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     }
 
     // ---- the loop: for i = T-1-skip ... 0 (gaussian_diffusion.py:724-743 / :994-1014) ----------------
-    const bool pair = h->fused && h->all_scale_one && !a->two_pass_always;
+    const bool pair = h->fused && !h->use_long && h->all_scale_one && !a->two_pass_always;
     std::string key;
     {
         char keybuf[256];
-        snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d", h->precision, B, a->sampler, (double)a->eta,
-                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump);
+        snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d L%d", h->precision, B, a->sampler, (double)a->eta,
+                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, (int)h->use_long);
         key = keybuf;
         for (int d = 0; d < a->n_dump; ++d) key += "," + std::to_string(a->dump_steps[d]);      // the whole list, however long
     }

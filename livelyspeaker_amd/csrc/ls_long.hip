@@ -254,17 +254,22 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     const int mpad = (a.B * a.T + 127) / 128 * 128;
     hipLaunchKernelGGL(k_long_padx, dim3(mpad), dim3(128), 0, st, a.x_in, a.xpad, a.B * a.T, a.JF, a.JFP);
     if ((e = launch_gemm_nt(a.xpad, a.JFP, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, mpad, D, a.JFP, 0, st)) != hipSuccess) return e;
-    // fused token mixing needs S <= 160 (accumulators for ten token tiles, the operand slab in LDS); longer sequences take the batched-GEMM form
-    constexpr int kTokPad = 160;
-    const bool fused_tok = a.wtp != nullptr && a.S <= kTokPad;
+    // fused token mixing needs S <= 160 (accumulators for ten token tiles, the operand slab in LDS); longer sequences take the batched-GEMM form.
+    // Token axis padded to 48 (the reference's 35 / 36 tokens: three tiles) or 160; a.tokpad says which image a.wtp holds.
+    const int kTokPad = a.tokpad;
+    const bool fused_tok = a.wtp != nullptr && a.S <= kTokPad && (kTokPad == 48 || kTokPad == 160);
     hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a, fused_tok ? 1 : 0);
     float* Xc = a.X;                 // current activations; the fused form ping-pongs between X and U (an even number of layers ends in X)
     float* Xo = a.U;
     const int mrows = (rows + 127) / 128 * 128;         // whole GEMM tiles: the pad rows exist in the buffers and are never read back
     for (int l = 0; l < a.layers; ++l) {
         if (fused_tok) {
-            hipLaunchKernelGGL((k_long_tokmix<kTokPad>), dim3(2 * a.B, 8), dim3(256), 0, st, Xc, a.part1, a.part2, a.wtp + (size_t)l * kTokPad * kTokPad,
-                               a.bt + (size_t)l * a.S, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.S);
+            if (kTokPad == 48)
+                hipLaunchKernelGGL((k_long_tokmix<48>), dim3(2 * a.B, 8), dim3(256), 0, st, Xc, a.part1, a.part2, a.wtp + (size_t)l * 48 * 48,
+                                   a.bt + (size_t)l * a.S, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.S);
+            else
+                hipLaunchKernelGGL((k_long_tokmix<160>), dim3(2 * a.B, 8), dim3(256), 0, st, Xc, a.part1, a.part2, a.wtp + (size_t)l * 160 * 160,
+                                   a.bt + (size_t)l * a.S, a.ln1a + (size_t)l * D, a.ln1b + (size_t)l * D, a.S);
             GemmArgs g{};
             g.A = op_rows(Xc, D, mrows, D);
             g.B = op_rows(a.wcf + (size_t)l * D * D, D, D, D);

@@ -125,6 +125,9 @@ class RAG(nn.Module):
         #: 'fp32' = exact fp32 MFMA (default, what parity/bench numbers refer to); 'bf16x3' = opt-in split-precision
         #: channel mixing (3 bf16 MFMAs per fp32 product, ~2^-16 relative; parity-tested against the 1e-3 contract)
         self.precision = "fp32"
+        #: which kernels the diffusion steps run on: None = the engine's default ("auto": batch-level kernels spread over the chip for
+        #: small batches, one workgroup per sample otherwise), "fused", "batch" (ls_set_path; same arithmetic, results agree to ~1e-5)
+        self.step_path = None
         self._engine = None
         self._weights_dirty = True
         self._cond_key = None
@@ -163,7 +166,7 @@ class RAG(nn.Module):
             self._engine = _lib.Engine(self.njoints, self.nfeats, self.n_prefix_tokens,
                                        self.audio_len, n_emotions=self.n_emotions,
                                        nframes=self.nframes, n_pre_seq=self.n_pre_seq, latent_dim=self.latent_dim,
-                                       layers=self.num_layers, n_speakers=1400, device=di)
+                                       layers=self.num_layers, n_speakers=1400, device=di, path=self.step_path)
             self._weights_dirty = True
         if self._weights_dirty:
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items() if not k.endswith(".pe")}
@@ -172,6 +175,9 @@ class RAG(nn.Module):
             self._cond_key = self._prefetched_key = None
         if getattr(self._engine, "precision", "fp32") != self.precision:
             self._engine.set_precision(self.precision)
+        if self.step_path is not None and self._engine.path != self.step_path and self.nframes == 34:
+            self._engine.set_path(self.step_path)
+            self._cond_key = self._prefetched_key = None
         return self._engine
 
     def prefetch_condition(self, y):
