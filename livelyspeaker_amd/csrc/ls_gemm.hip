@@ -146,19 +146,21 @@ __device__ __forceinline__ void gemm_dma_issue(__amdgpu_buffer_rsrc_t rsA, __amd
     for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vp)&sB[(wv * 4 + i) * 256], 16, voB[i], kb, 0, 0);
 }
 
+template <bool AK, bool BK, bool FAST, int MT, bool DMA>
+constexpr int gemm_lds_a() { return DMA ? 2 * 32 * MT * kTK : (AK ? 32 * MT * kLdK : kTK * kLdR); }
+template <bool BK, bool DMA>
+constexpr int gemm_lds_b() { return DMA ? 2 * kTM * kTK : (BK ? kTM * kLdK : kTK * kLdR); }
+
+// one output tile (32 MT rows x 128 columns) of problem bz: tile row `by` (in units of 32 MT rows), tile column `bx`
 template <bool AK, bool BK, bool FAST, int MT = 4, bool DMA = false>
-__global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
-    static_assert(MT == 4 || (MT == 2 && AK && FAST), "64-row tiles: K-contiguous A on the fast path only");
+__device__ __forceinline__ void gemm_tile(GemmArgs a, float* __restrict__ sA, float* __restrict__ sB, int bx, int by, int bz) {
+    static_assert(MT == 4 || ((MT == 2 || MT == 1) && AK && FAST), "64- / 32-row tiles: K-contiguous A on the fast path only");
     static_assert(!DMA || (AK && BK && FAST), "LDS-DMA staging: both operands K-contiguous, full tiles");
+    static_assert(MT != 1 || DMA, "32-row tiles exist in the LDS-DMA kernel only");
     constexpr int BM = 32 * MT;
-    constexpr int SA = DMA ? 2 * BM * kTK : (AK ? BM * kLdK : kTK * kLdR);
-    constexpr int SB = DMA ? 2 * kTM * kTK : (BK ? kTM * kLdK : kTK * kLdR);
-    __shared__ __attribute__((aligned(16))) float sA[SA];
-    __shared__ __attribute__((aligned(16))) float sB[SB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int m0 = by * BM, n0 = bx * kTM;
     const int s16 = lane & 15, g = lane >> 4;
     const int zb = bz / a.splits, z = bz - zb * a.splits;     // (problem of the batch, K split)
@@ -460,6 +462,30 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
     epilogue(m0, n0);
 }
 
+template <bool AK, bool BK, bool FAST, int MT = 4>
+__global__ __launch_bounds__(256, 3) void k_gemm_tr(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[gemm_lds_a<AK, BK, FAST, MT, false>()];
+    __shared__ __attribute__((aligned(16))) float sB[gemm_lds_b<BK, false>()];
+    gemm_tile<AK, BK, FAST, MT, false>(a, sA, sB, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// LDS-DMA kernel: 64 x 128 tiles, and -- for the tiles of a last, badly filled round -- 32 x 128 half tiles.  Workgroups are handed
+// out in blockIdx order as slots free up, so a 1-D grid [nbig whole tiles | 2 (ntiles - nbig) half tiles] is a dynamic schedule for
+// free: 1088 tiles on the chip's 768 slots (17408 x 512, the SAG decoder's out-proj / FFN2) are 768 whole tiles + 640 halves =
+// one round + one short round instead of two rounds of which the second is 42 % full.  Every output element is still produced by one
+// workgroup with the same reduction order, so results do not depend on the split (tests/test_sag.py's batch-composition test).
+__global__ __launch_bounds__(256, 3) void k_gemm_dma(GemmArgs a, int gx, int nbig) {
+    __shared__ __attribute__((aligned(16))) float sA[gemm_lds_a<true, true, true, 2, true>()];
+    __shared__ __attribute__((aligned(16))) float sB[gemm_lds_b<true, true>()];
+    if (gridDim.z > 1 || (int)blockIdx.x < nbig) {            // whole tile (batched / split launches keep the 3-D grid: gx = 0)
+        if (gx == 0) gemm_tile<true, true, true, 2, true>(a, sA, sB, blockIdx.x, blockIdx.y, blockIdx.z);
+        else gemm_tile<true, true, true, 2, true>(a, sA, sB, (int)blockIdx.x % gx, (int)blockIdx.x / gx, 0);
+    } else {
+        const int u = (int)blockIdx.x - nbig, t = nbig + (u >> 1);
+        gemm_tile<true, true, true, 1, true>(a, sA, sB, t % gx, 2 * (t / gx) + (u & 1), 0);
+    }
+}
+
 // C[m][n] (+)= sum_z ws[z][m][n] (+ bias); fixed summation order
 __global__ void k_splitk_reduce(const GemmArgs a, int Z) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,7 +527,15 @@ hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits
         // always 64-row tiles: 48 KB of double buffer lets three workgroups share a CU (the 128-row form: 64 KB, two); measured over the
         // sampler's shapes (tools/gemm_bench.cpp) the 128-row DMA tile lost to this one and, at some, to the register-staged kernel
         grid.y *= 2;
-        hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2, true>), grid, dim3(256), 0, st, a);
+        if (grid.z == 1) {
+            // a last round that fills less than ~60 % of the 768 slots runs as half tiles (a half tile takes ~0.6 of a whole one)
+            const long long tiles = (long long)grid.x * grid.y, slots = 768;
+            const long long rem = tiles % slots;
+            const int nbig = (rem > 0 && rem * 10 < slots * 6 && tiles > slots / 2) ? (int)(tiles - rem) : (int)tiles;
+            hipLaunchKernelGGL(k_gemm_dma, dim3((unsigned)(nbig + 2 * (tiles - nbig))), dim3(256), 0, st, a, (int)grid.x, nbig);
+        } else {
+            hipLaunchKernelGGL(k_gemm_dma, grid, dim3(256), 0, st, a, 0, 0);
+        }
     } else if (half) {
         grid.y *= 2;
         hipLaunchKernelGGL((k_gemm_tr<true, true, true, 2>), grid, dim3(256), 0, st, a);
