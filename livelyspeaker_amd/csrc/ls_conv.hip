@@ -35,6 +35,9 @@ __device__ int g_conv_prof_wg = 0;
 #ifndef LS_CONV_ABL
 #define LS_CONV_ABL 0
 #endif
+#ifndef LS_CONV_WGS
+#define LS_CONV_WGS 2          // workgroups per CU the stride-6 forward kernel is compiled for (register budget)
+#endif
 constexpr int kCvWin = (kCvTP - 1) * kCvS + kCvK;      // 393 input samples per channel per tile
 constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the 4 lane groups (channels) hit different banks
 
@@ -91,7 +94,7 @@ __device__ __forceinline__ void conv_stage_store(const float (&vals)[25], float*
     }
 }
 
-__global__ __launch_bounds__(512, 2) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
+__global__ __launch_bounds__(512, LS_CONV_WGS) void k_conv1d_mfma(const float* __restrict__ in, const float* __restrict__ stats,
                                                            const float* __restrict__ wimg, const float* __restrict__ bias,
                                                            float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout,
                                                            int ntile, int tpw) {
@@ -107,13 +110,15 @@ __global__ __launch_bounds__(512, 2) void k_conv1d_mfma(const float* __restrict_
         // requested before window s+1 is written, straight-line so that the waits really are vmcnt(25) -- measured slower, 496 vs
         // 482 us: fetch latency is not what the stage waits for.)
         const int pt = tid - 256, sr = pt >> 4, sc = pt & 15;
-        const auto rsin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)min((long long)gridDim.z * Cin * Lin * 4, 0x7fffffffll), 0x00020000);
+        // descriptor over THIS sample's rows onwards (32-bit offsets: the whole tensor is 4 GB at 4096 clips); it ends with the tensor
+        const long long left = (long long)(gridDim.z - b) * Cin * Lin * 4;
+        const auto rsin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)b * Cin * Lin, 0, (int)min(left, 0x7fffffffll), 0x00020000);
         auto stage = [&](int sidx, float* buf) {
             const int tl = sidx / nchunk, c = sidx - tl * nchunk;
             const int in0 = (t0 + tl) * kCvTP * kCvS;
             const int validw = min(Lin - in0, kCvWin);                     // >= 1 for every tile that has an output position
-            const int row = (b * Cin + c * kCvCI + sr);
-            const float vm = stats[(size_t)row * 2], vr = stats[(size_t)row * 2 + 1];
+            const int row = c * kCvCI + sr;                                 // row of this sample
+            const float vm = stats[((size_t)b * Cin + row) * 2], vr = stats[((size_t)b * Cin + row) * 2 + 1];
             float vals[25];
             if (LS_CONV_ABL & 16) return;
             if (LS_CONV_ABL & 4) {
