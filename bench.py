@@ -479,6 +479,7 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(_self_launch(a))
     _RESULT_OUT = _reserve_stdout()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on these hosts: RCCL's P2P setup needs it, whoever launched us
     import torch
     import torch.distributed as dist
     from livelyspeaker_amd import shard, synth

@@ -299,7 +299,9 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
         if ((e = launch_gemm_nt(a.U, D, a.wc + (size_t)l * D * D, D, a.bc + (size_t)l * D, a.X, D, a.X, D, rows, D, D, 1, st)) != hipSuccess) return e;
     }
     if (fused_tok && Xc != a.X) return hipErrorInvalidValue;              // odd layer counts would end in the other buffer
-    if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, rows, a.ldo, D, 0, st)) != hipSuccess) return e;      // N = JF padded to 128s (zero weight rows)
+    // poseFinal over whole 128-row tiles as well (N = JF padded to 128s with zero weight rows): 280 rows (4 clips) as they are would
+    // take the GEMM's general staging path, 64 us instead of 8
+    if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, mrows, a.ldo, D, 0, st)) != hipSuccess) return e;
     const int TJ = a.T * a.JF;
     hipLaunchKernelGGL(k_long_update, dim3((TJ + 1023) / 1024, a.B), dim3(256), 0, st, a);
     return hipGetLastError();

@@ -11,12 +11,20 @@ python bench.py --dataset beat150 --batch 32 --no-extra-legs --no-cpu-baseline -
 python bench.py --dataset beat150 --batch 256 --no-extra-legs --no-cpu-baseline --steps 1 --diffusion-steps 200 > "$out/bench_beat150_b256.json" 2> "$out/bench_beat150_b256.err"; echo "beat150/256 rc=$?"
 python bench.py --respacing ddim100 --no-extra-legs --no-cpu-baseline --steps 5 > "$out/bench_ddim100_full.json" 2> "$out/bench_ddim100_full.err"; echo "ddim100 rc=$?"
 python bench.py --batch 4 --diffusion-steps 50 --no-extra-legs --no-cpu-baseline --steps 20 > "$out/bench_config1_shape.json" 2> "$out/bench_config1.err"; echo "config1 rc=$?"
+python bench.py --gpus 2 --ranks-share-device --batch 256 --legs lively --no-cpu-baseline --steps 2 > "$out/bench_two_ranks_one_gpu.json" 2> "$out/bench_two_ranks_one_gpu.err"; echo "2 ranks / 1 GPU rc=$?"
+python tools/smallbatch_time.py ted > "$out/smallbatch_ted.txt" 2>&1; python tools/smallbatch_time.py beat > "$out/smallbatch_beat.txt" 2>&1
+[ -x variants/conv_bench ] && variants/conv_bench 512 > "$out/conv_bench.txt" 2>&1
+[ -x variants/conv_bench_prof ] && variants/conv_bench_prof 512 > "$out/conv_bench_prof.txt" 2>&1
+python tools/sag_time.py > "$out/sag_time.txt" 2>&1
 python bench.py --scale 1.0 --no-extra-legs --no-cpu-baseline > "$out/bench_scale1.json" 2> "$out/bench_scale1.err"; echo "scale1 rc=$?"
 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs > "$out/kt_bench.json" 2> "$out/kt.log"
 python profiles/summarize_rocprof.py "$(ls $out/kt/*.db | head -1)" "kernel trace of bench.py --steps 1 --warmup 1 (headline workload)" "$out/kt_bench.json" > "$out/kt_bench.md"
 python profiles/dispatch_summary.py "$(ls $out/kt/*.db | head -1)" "ls::" > "$out/kt_dispatch.md"
 tools/prof_call.sh "$out/lively" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE" -- python examples/livelyspeaker_ted.py 512
-tools/prof_call.sh "$out/long" "" -- python bench.py --dataset beat150 --batch 32 --no-extra-legs --no-cpu-baseline --no-parity --steps 1 --warmup 1 --diffusion-steps 20
+tools/prof_call.sh "$out/long" "" -- python bench.py --dataset beat150 --batch 32 --no-extra-legs --no-cpu-baseline --no-parity --no-traffic-pass --steps 1 --warmup 1 --diffusion-steps 20
+tools/prof_call.sh "$out/long256" "" -- python bench.py --dataset beat150 --batch 256 --no-extra-legs --no-cpu-baseline --no-parity --no-traffic-pass --steps 1 --warmup 1 --diffusion-steps 20
+tools/prof_call.sh "$out/train" "" -- python tools/train_perf.py ted 512 4
+tools/prof_call.sh "$out/prepare" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" -- python tools/prepare_only.py
 rm -rf "$out"/kt "$out"/*/kt "$out"/*/pmc_*/
 for f in "$out"/bench_*.json; do python - "$f" <<'PY'
 import json, sys
