@@ -13,6 +13,7 @@
 namespace ls {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));       // a float4 at dword alignment (global memory takes it)
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int kCvK = 15, kCvS = 6, kCvTP = 64, kCvCI = 16, kCvTC = 64;
@@ -67,6 +68,7 @@ constexpr int kCvWinP = kCvWin + 4;                    // 397: odd stride -> the
 // ONE (count, mean, M2) partial per (channel, 64-position tile) instead of four.  The convolution results are bit-identical to the
 // old kernel's (same MFMA order per accumulator); the statistics are merged from coarser partials (double-precision merge, ~1e-8).
 constexpr int kCvSlots = 105, kCvRow = 4 * kCvSlots;       // floats per window row in the [r][pt] layout
+constexpr int kCvOutLd = kCvTP + 4;                        // row stride of the accumulator hand-off tile (2-way write conflicts only)
 
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt: every global load in flight --
 // the producers' look-ahead window, the consumers' weight ring -- and every output store would have to land before each stage's barrier.
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(512, LS_CONV_WGS) void k_conv1d_mfma(const float* _
                                                            float* __restrict__ out, float* __restrict__ spart, int Cin, int Cout, int Lin, int Lout,
                                                            int ntile, int tpw) {
     __shared__ __attribute__((aligned(16))) float sIn[2][kCvCI * kCvRow];
+    __shared__ __attribute__((aligned(16))) float sOut[kCvTC * kCvOutLd];     // a finished tile's accumulators, consumers -> producers
     const int b = blockIdx.z, co0 = blockIdx.y * kCvTC;
     const int t0 = blockIdx.x * tpw, t1 = min(ntile, t0 + tpw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -128,14 +131,64 @@ __global__ __launch_bounds__(512, LS_CONV_WGS) void k_conv1d_mfma(const float* _
             if (validw >= kCvWin) conv_stage_store<false>(vals, buf + sr * kCvRow, sc, validw, vm, vr);
             else conv_stage_store<true>(vals, buf + sr * kCvRow, sc, validw, vm, vr);
         };
+        // The tile epilogue belongs to the producers too (round 3): the consumers drop a finished tile's accumulators into sOut and go
+        // straight on multiplying; one stage later the producers -- which wait ~2.5 k cycles per stage anyway -- add the bias, store
+        // whole 256-byte row pieces and reduce the InstanceNorm partials (a 4-lane reduction per channel instead of a 16-lane one).
+        // In the consumers the 20 output stores sat in the same in-order vmcnt queue as the weight fragments: every tile began by
+        // waiting for its predecessor's stores to be acknowledged (timing-only ablation without the epilogue: - 40 us on conv2).
+        const int orow = pt >> 2, oq = pt & 3;                             // drain: thread = (channel row, 16 positions)
+        auto drain = [&](int tile) {
+            if (LS_CONV_ABL & 8) return;
+            const int p0 = tile * kCvTP, pbase = p0 + 16 * oq;
+            const float bvv = bias[co0 + orow];
+            f4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f4*>(&sOut[orow * kCvOutLd + 16 * oq + 4 * i]) + bvv;
+            float* o = out + ((size_t)b * Cout + co0 + orow) * Lout + pbase;
+            const int nvl = min(16, max(0, Lout - pbase));                  // valid positions of this thread
+            if (nvl == 16) {                                                // rows start at any dword: 4-byte-aligned 16-byte stores
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<f4u*>(o + 4 * i) = v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (4 * i + e < nvl) o[4 * i + e] = v[i][e];
+            }
+            if (spart) {
+                // (count, mean, M2) of the (channel, 64-position tile): two-pass inside the tile, the four threads of a row = one DPP quad
+                const int nv = min(kCvTP, Lout - p0);
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s1 += 4 * i + e < nvl ? v[i][e] : 0.f;
+                s1 = dpp_add<0xB1>(s1); s1 = dpp_add<0x4E>(s1);
+                const float mean = s1 / (float)nv;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = 4 * i + e < nvl ? v[i][e] - mean : 0.f; m2 = fmaf(d, d, m2); }
+                m2 = dpp_add<0xB1>(m2); m2 = dpp_add<0x4E>(m2);
+                if (oq == 0) {
+                    float* sp = spart + (((size_t)b * Cout + co0 + orow) * ntile + tile) * 3;
+                    sp[0] = (float)nv; sp[1] = mean; sp[2] = m2;
+                }
+            }
+        };
         stage(0, sIn[0]);
         lds_barrier();
         for (int sidx = 0; sidx < nstage; ++sidx) {
             if (sidx + 1 < nstage) stage(sidx + 1, sIn[(sidx + 1) & 1]);
+            // the tile whose last chunk was stage sidx - 2 sits in sOut since the barrier before this one
+            if (sidx >= 2 && (sidx - 2) % nchunk == nchunk - 1) drain(t0 + (sidx - 2) / nchunk);
             CV_STAMP(w, sidx, 0);
             lds_barrier();
             CV_STAMP(w, sidx, 1);
         }
+        lds_barrier();                                                     // the consumers have dropped the last tile
+        drain(t1 - 1);
         return;
     }
     // ---------------- consumers: wave w = channel tile w x position tiles 0..3
@@ -189,62 +242,14 @@ __global__ __launch_bounds__(512, LS_CONV_WGS) void k_conv1d_mfma(const float* _
             lds_barrier();
             CV_STAMP(w, sidx, 1);
         }
-        // epilogue of this tile: lane (s16, g) holds out[co0 + 16 w + 4 g + j][p0 + 16 t + s16]
-        if ((LS_CONV_ABL & 8) && acc[0][0] != 12345.f) continue;
-        const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
-        float v[4][4];                                                 // [position tile][j]
-        bool valid[4];
+        // hand the tile to the producers: lane (s16, g) holds the accumulators of out[co0 + 16 w + 4 g + j][p0 + 16 t + s16].  sOut was
+        // drained two stages ago at the latest (tiles are nchunk >= 2 stages apart).
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            valid[t] = p0 + 16 * t + s16 < Lout;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[t][j] = acc[t][j] + bv[j];
-        }
-        {
-            float* o = out + ((size_t)b * Cout + co0 + 16 * w + 4 * g) * Lout + p0 + s16;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (valid[t]) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[(size_t)j * Lout + 16 * t] = v[t][j];
-                }
-            }
-        }
-        if (spart) {
-            // (count, mean, M2) of every (channel, 64-position tile), two-pass inside the tile: a lane first adds up its own four
-            // positions, then ONE 16-lane reduction per channel and pass (8 DPP chains side by side; rounds 1-2 reduced every
-            // 16-position sub-tile separately: 32 chains, ~350 VALU instructions per wave and tile = 0.8 per MFMA of the kernel)
-            const int nv = min(kCvTP, Lout - p0);
-            const float inv_nv = 1.0f / (float)nv;
-            float s1[4], m2[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                s1[j] = ((valid[0] ? v[0][j] : 0.f) + (valid[1] ? v[1][j] : 0.f)) + ((valid[2] ? v[2][j] : 0.f) + (valid[3] ? v[3][j] : 0.f));
-#define LS_ROW_STEP(arr, CTRL) _Pragma("unroll") for (int j = 0; j < 4; ++j) arr[j] = dpp_add<CTRL>(arr[j]);
-            LS_ROW_STEP(s1, 0xB1) LS_ROW_STEP(s1, 0x4E) LS_ROW_STEP(s1, 0x141) LS_ROW_STEP(s1, 0x140)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s1[j] *= inv_nv;                                       // mean of the tile
-                float q = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float d = valid[t] ? v[t][j] - s1[j] : 0.f;
-                    q = fmaf(d, d, q);
-                }
-                m2[j] = q;
-            }
-            LS_ROW_STEP(m2, 0xB1) LS_ROW_STEP(m2, 0x4E) LS_ROW_STEP(m2, 0x141) LS_ROW_STEP(m2, 0x140)
-#undef LS_ROW_STEP
-            if (s16 == 0) {
-                float* sp = spart + (((size_t)b * Cout + co0 + 16 * w + 4 * g) * ntile + tile) * 3;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float* q = sp + (size_t)j * ntile * 3;
-                    q[0] = (float)nv; q[1] = s1[j]; q[2] = m2[j];
-                }
-            }
-        }
+            for (int j = 0; j < 4; ++j) sOut[(16 * w + 4 * g + j) * kCvOutLd + 16 * t + s16] = acc[t][j];
     }
+    lds_barrier();                                                         // matches the producers' last barrier: the final tile is in sOut
 }
 
 // The same implicit GEMM for a SHORT output (the last encoder layer: 34 positions from 217 inputs).  With one sample per workgroup
@@ -388,7 +393,7 @@ hipError_t launch_stats_merge(const float* spart, float* stats, int rows, int np
 // workspace of B * Cout * ceil(Lout / 64) * 4 * 3 floats
 hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* wimg, const float* bias, float* out, float* out_stats,
                               float* spart, int B, int Cin, int Cout, int Lin, int Lout, hipStream_t st) {
-    if (Cin % kCvCI || Cout % kCvTC || !stats || (out_stats && !spart)) return hipErrorInvalidValue;
+    if (Cin % kCvCI || Cin < 2 * kCvCI || Cout % kCvTC || !stats || (out_stats && !spart)) return hipErrorInvalidValue;   // >= 2 chunks per tile (hand-off timing)
     if (!out_stats && Lout <= 36 && (Lout - 1) * kCvS + kCvK <= Lin) {
         // short output without statistics (conv4: 34 positions): columns = (sample, position) pairs of 4 samples, 9 tiles
         constexpr int NS = 4, NPT = 9;
