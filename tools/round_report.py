@@ -15,6 +15,8 @@ RUNS = [
     ("bench_beat256", "`--dataset beat --batch 256` (configs[4] at 34 frames, the whole job on one GPU)"),
     ("bench_beat150_b32", "`--dataset beat150 --batch 32` (configs[4] as worded, per-GPU share of 256/8; synthetic)"),
     ("bench_beat150_b256", "`--dataset beat150 --batch 256 --diffusion-steps 200` (synthetic)"),
+    ("bench_two_ranks_one_gpu", "`--gpus 2 --ranks-share-device --batch 256 --legs lively` (self-launched; TWO RANKS ON ONE GPU, collectives over gloo: "
+                                "the N > 1 control flow, not a scaling number)"),
 ]
 
 
@@ -48,7 +50,8 @@ for name, cmd in RUNS:
 d = load("bench_default")
 if d:
     out += ["", "Secondary objects of the default line:", ""]
-    for k in ("single_pass", "livelyspeaker", "configs4_beat", "split_precision", "train_step", "cpu_baseline", "shard_check", "parity_in_run"):
+    for k in ("single_pass", "identical_seeds_mode", "config1_shape", "livelyspeaker", "configs4_beat", "split_precision", "train_step", "cpu_baseline",
+              "shard_check", "parity_in_run"):
         if k in d:
             out.append(f"* `{k}`: `{json.dumps(d[k])}`")
     out += ["", "The default line in full:", "", "```", json.dumps(d), "```"]
@@ -58,5 +61,18 @@ out += ["", "## Kernel trace of the headline command (`rocprofv3 --kernel-trace 
 for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"):
     out += ["", f"### PMC {c}", "", cat(f"lively/pmc_{c}.md")]
 out += ["", "## Synthetic 150-frame variant, B=32 (`bench.py --dataset beat150 --batch 32 ... --diffusion-steps 20`): dispatch summary", "", cat("long/kt.md"), ""]
+two = load("bench_two_ranks_one_gpu")
+if two:
+    out += ["", "## Two ranks on one GPU (`python bench.py --gpus 2 --ranks-share-device ...`, launched by bench.py itself): shard check and the LivelySpeaker leg", "",
+            f"* `shard_check`: `{json.dumps(two.get('shard_check'))}`", f"* `livelyspeaker`: `{json.dumps(two.get('livelyspeaker'))}`"]
+out += ["", "## Synthetic 150-frame variant, B=256: dispatch summary", "", cat("long256/kt.md"),
+        "", "## Training step (`tools/train_perf.py ted 512 4`): dispatch summary", "", cat("train/kt.md"),
+        "", "## Once-per-call stage (`tools/prepare_only.py`, B=512): dispatch summary and PMC passes", "", cat("prepare/kt.md")]
+for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+    out += ["", f"### PMC {c}", "", cat(f"prepare/pmc_{c}.md")]
+out += ["", "## ms per diffusion step over the batch size: fused kernel vs batch-level kernels (`tools/smallbatch_time.py`)", "", "```", cat("smallbatch_ted.txt"), "",
+        cat("smallbatch_beat.txt"), "```",
+        "", "## Stride-6 conv layers stand-alone (`tools/conv_bench.cpp`) and the per-stage barrier timeline of one workgroup (`-DLS_CONV_PROF`)", "", "```",
+        cat("conv_bench.txt"), "", cat("conv_bench_prof.txt"), "```", "", "SAG decode: " + cat("sag_time.txt").splitlines()[-1], ""]
 open(dst, "w").write("\n".join(out))
 print("wrote", dst, len(out), "lines")
