@@ -718,7 +718,7 @@ def main():
                                "step_ms": round(tm4["loop_ms"] / max(tm4["n_step_launches"], 1), 4), "finite": bool(torch.isfinite(o4).all())}
                 m4.engine().close()
             small["workload"] = "TED RAG, 4 clips x 34 frames, 50-step DDPM, CFG 1.5 (BASELINE configs[0]'s shape; Philox noise): `auto` = the engine's choice "
-            small["workload"] += "(batch-level kernels below 128 clips), `fused` = one workgroup per clip"
+            small["workload"] += "(batch-level kernels up to 160 clips), `fused` = one workgroup per clip"
         except Exception as e:
             small = {"error": repr(e)[:300]}
 

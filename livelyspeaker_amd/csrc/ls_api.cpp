@@ -611,7 +611,7 @@ void resolve_prepare_timing(ls_handle* h, bool block) {
 // layers (0.68 ms TED) however small the batch; the batch-level kernels spread the same rows over the whole chip (21 launches per
 // step) and win below kLongMaxBatch samples (measured: profiles/r03 small-batch table).  34-frame models only choose; other frame
 // counts have no fused kernel.
-constexpr int kLongMaxBatch = 128;
+constexpr int kLongMaxBatch = 160;
 void decide_path(ls_handle* h) {
     const bool before = h->use_long;
     if (!h->fused) h->use_long = true;

@@ -30,6 +30,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int kTM = 128, kTK = 32, kLdK = kTK + 4, kLdR = kTM + 4;
+#ifndef LS_GEMM_HALF_MAX
+#define LS_GEMM_HALF_MAX 768      // LDS-DMA grids of at most this many 64-row tiles run as 32-row half tiles (see launch_gemm_tr)
+#endif
 
 // epilogue activations: 0 none, 1 SiLU, 2 exp(0.5 y) (std from log-variance), 3 exact GELU (F.gelu default)
 __device__ __forceinline__ float gemm_act(float v, int act) {
@@ -152,9 +155,8 @@ template <bool BK, bool DMA>
 constexpr int gemm_lds_b() { return DMA ? 2 * kTM * kTK : (BK ? kTM * kLdK : kTK * kLdR); }
 
 // one output tile (32 MT rows x 128 columns) of problem bz: tile row `by` (in units of 32 MT rows), tile column `bx`
-template <bool AK, bool BK, bool FAST, int MT = 4, bool DMA = false, int NB = 2>
+template <bool AK, bool BK, bool FAST, int MT = 4, bool DMA = false>
 __device__ __forceinline__ void gemm_tile(GemmArgs a, float* __restrict__ sA, float* __restrict__ sB, int bx, int by, int bz) {
-    static_assert(NB == 2 || (NB == 3 && DMA), "three LDS buffers: the LDS-DMA kernel's deep-prefetch form");
     static_assert(MT == 4 || ((MT == 2 || MT == 1) && AK && FAST), "64- / 32-row tiles: K-contiguous A on the fast path only");
     static_assert(!DMA || (AK && BK && FAST), "LDS-DMA staging: both operands K-contiguous, full tiles");
     static_assert(MT != 1 || DMA, "32-row tiles exist in the LDS-DMA kernel only");
@@ -354,17 +356,7 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, float* __restrict__ sA, fl
 #pragma unroll
         for (int i = 0; i < 4; ++i) voB[i] = (int)(((long long)(n0 + (wv * 4 + i) * 8 + rl) * a.B.rs + ch * 4) * 4);
         gemm_dma_issue<MT>(rsA, rsB, sA, sB, wv, voA, voB, kbeg);
-        if constexpr (NB == 3) {
-            // deep-prefetch form for grids that do not fill the chip (one or two workgroups per CU: nobody else hides this workgroup's
-            // fetch latency): K tiles k+1 AND k+2 in flight while tile k is multiplied, the barrier waits for tile k+1 only
-            // (vmcnt(MT + 4) = the newest tile's DMA instructions may stay outstanding).  16 K tiles of 1.6 us each (fetch-latency bound,
-            // 26 us for the 384 x 512 x 512 channel-mixing product of a 4-clip batch) become ~1 us each.
-            if (kbeg + kTK < kend) gemm_dma_issue<MT>(rsA, rsB, sA + BM * kTK, sB + kTM * kTK, wv, voA, voB, kbeg + kTK);
-            if (kbeg + kTK < kend) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MT + 4) : "memory");
-            else __syncthreads();
-        } else {
-            __syncthreads();                                // carries the vmcnt(0) of the DMA above
-        }
+        __syncthreads();                                    // carries the vmcnt(0) of the DMA above
         int buf = 0;
         // (A persistent form -- one workgroup per resident slot walking tiles blockIdx.x, + gridDim.x, ..., the next output tile's first K
         // tile requested ahead of the current one's last -- measured SLOWER, 229 -> 265 us at 17408 x 1536 x 512: with 4.25 tiles per slot
@@ -372,38 +364,9 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, float* __restrict__ sA, fl
         for (int k0 = kbeg; k0 < kend; k0 += kTK) {
             // the other buffer was last read before the previous barrier: the next K tile lands in it while this one is multiplied
             if (k0 + kTK >= kend) fetch_addends(m0, n0);
-            if constexpr (NB == 3) {
-                const int nb = buf + 2 >= 3 ? buf - 1 : buf + 2;
-                if (k0 + 2 * kTK < kend) gemm_dma_issue<MT>(rsA, rsB, sA + nb * BM * kTK, sB + nb * kTM * kTK, wv, voA, voB, k0 + 2 * kTK);
-            } else {
-                if (k0 + kTK < kend) gemm_dma_issue<MT>(rsA, rsB, sA + (buf ^ 1) * BM * kTK, sB + (buf ^ 1) * kTM * kTK, wv, voA, voB, k0 + kTK);
-            }
+            if (k0 + kTK < kend) gemm_dma_issue<MT>(rsA, rsB, sA + (buf ^ 1) * BM * kTK, sB + (buf ^ 1) * kTM * kTK, wv, voA, voB, k0 + kTK);
             const float* cA = sA + buf * BM * kTK + fa;
             const float* cB = sB + buf * kTM * kTK + fb;
-            if constexpr (NB == 3) {
-                // one wave per SIMD here: nobody else issues while an accumulator waits for its previous MFMA, so consecutive MFMAs
-                // walk all 4 x MT accumulators (dependency distance 8 instead of 2); all four B fragments of a k half are live
-                f4 afh[2][MT], bfh[2][4];
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                    for (int j = 0; j < MT; ++j) afh[kk][j] = *reinterpret_cast<const f4*>(cA + 16 * j * kTK + (kk ? o1 : o0));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bfh[kk][i] = *reinterpret_cast<const f4*>(cB + 16 * i * kTK + (kk ? o1 : o0));
-                }
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int j = 0; j < MT; ++j) acc[i][j] = MFMA(bfh[kk][i][e], afh[kk][j][e], acc[i][j]);
-                if (k0 + 2 * kTK < kend) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MT + 4) : "memory");
-                else __syncthreads();
-                buf = buf + 1 >= 3 ? 0 : buf + 1;
-                continue;
-            }
             f4 af[2][MT], bf[2];
 #pragma unroll
             for (int j = 0; j < MT; ++j) af[0][j] = *reinterpret_cast<const f4*>(cA + 16 * j * kTK + o0);
@@ -423,16 +386,8 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, float* __restrict__ sA, fl
                     for (int j = 0; j < MT; ++j) acc[i][j] = MFMA(bf[st & 1][e], af[kk][j][e], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (NB == 3) {
-                // tile k+1 must have landed; tile k+2's DMA (issued above, if any) may stay in flight.  The addends of the last iteration
-                // are ordinary loads behind it: the last two iterations wait for everything.
-                if (k0 + 2 * kTK < kend) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MT + 4) : "memory");
-                else __syncthreads();
-                buf = buf + 1 >= 3 ? 0 : buf + 1;
-            } else {
-                __syncthreads();
-                buf ^= 1;
-            }
+            __syncthreads();
+            buf ^= 1;
         }
     } else {
     size_t roffA[4], roffB[4];
@@ -534,15 +489,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm_dma(GemmArgs a, int gx, int nbi
     }
 }
 
-// the same tiles with three LDS buffers (72 KB: two workgroups per CU), for grids of at most two workgroups per CU
-__global__ __launch_bounds__(256, 2) void k_gemm_dma3(GemmArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass has no __amdgpu_buffer_rsrc_t to instantiate this body with)
-    __shared__ __attribute__((aligned(16))) float sA[3 * 64 * kTK];
-    __shared__ __attribute__((aligned(16))) float sB[3 * kTM * kTK];
-    gemm_tile<true, true, true, 2, true, 3>(a, sA, sB, blockIdx.x, blockIdx.y, blockIdx.z);
-#endif
-}
-
 // C[m][n] (+)= sum_z ws[z][m][n] (+ bias); fixed summation order
 __global__ void k_splitk_reduce(const GemmArgs a, int Z) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,8 +530,13 @@ hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits
         // always 64-row tiles: 48 KB of double buffer lets three workgroups share a CU (the 128-row form: 64 KB, two); measured over the
         // sampler's shapes (tools/gemm_bench.cpp) the 128-row DMA tile lost to this one and, at some, to the register-staged kernel
         grid.y *= 2;
-        if ((long long)grid.x * grid.y * grid.z <= 512 && a.K >= 3 * kTK) {
-            hipLaunchKernelGGL(k_gemm_dma3, grid, dim3(256), 0, st, a);
+        if (grid.z == 1 && (long long)grid.x * grid.y <= LS_GEMM_HALF_MAX) {
+            // a grid of at most one 64-row tile per slot: every tile as two 32-row halves -- twice the workgroups, half the MFMAs per wave and
+            // K tile.  A lone workgroup's K tile costs 1.3 us (64 MFMAs per wave + issue + barrier), so what shortens a small product is
+            // fewer MFMAs per wave, not a deeper prefetch (a three-buffer form with tiles k+1 and k+2 in flight measured SLOWER, 29.5 vs
+            // 26.0 us at 384 x 512 x 512; removed).  Measured: 384 x 512 x 512 (a 4-clip batch's channel mixing) 26 -> 13 us, 4608 rows
+            // 43 -> 32 us, 9728 rows 62 -> 55 us; above 768 tiles whole tiles win by 2-3 %.
+            hipLaunchKernelGGL(k_gemm_dma, dim3((unsigned)(2 * grid.x * grid.y)), dim3(256), 0, st, a, (int)grid.x, 0);
         } else if (grid.z == 1) {
             // a last round that fills less than ~60 % of the 768 slots runs as half tiles (a half tile takes ~0.6 of a whole one)
             const long long tiles = (long long)grid.x * grid.y, slots = 768;

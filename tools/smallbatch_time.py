@@ -8,9 +8,11 @@ from livelyspeaker_amd import _lib, synth
 from oracle import rag_oracle as orc          # schedule tables only (tooling)
 
 ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
+if len(sys.argv) > 2:
+    _lib.use_library(sys.argv[2])
 cfg = synth.CONFIGS[ds]
 print(f"{ds}: B | fused ms/step | batch-level ms/step | ratio")
-for B in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256):
+for B in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 144, 160, 176, 192, 256):
     res = {}
     for path in ("fused", "batch"):
         eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=path)
