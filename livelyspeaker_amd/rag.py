@@ -175,6 +175,7 @@ class RAG(nn.Module):
             self._cond_key = self._prefetched_key = None
         if getattr(self._engine, "precision", "fp32") != self.precision:
             self._engine.set_precision(self.precision)
+            self._cond_key = self._prefetched_key = None          # the kernel choice (and with it the workspaces of ls_prepare) may change with it
         if self.step_path is not None and self._engine.path != self.step_path and self.nframes == 34:
             self._engine.set_path(self.step_path)
             self._cond_key = self._prefetched_key = None
