@@ -377,3 +377,58 @@ def test_bench_gpus_n_launches_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=600,
                         cwd=root, env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
     assert r2.returncode != 0 and "--gpus 1 but the launcher started 2 rank(s)" in r2.stderr
+
+
+def test_identical_seeds_tapes_in_segments_are_the_one_piece_tapes(monkeypatch):
+    """The chunked "identical seeds" mode (GaussianDiffusion._loop, noise_source='torch_cpu') must hand the engine exactly the tapes of
+    the one-piece mode, cut into consecutive (first step, count) segments -- same draws from torch's CPU generator in the same order
+    (randn(*shape); per step randn(B,1,512) x 2 and randn_like(x) with x's strides).  The engine is a recording stand-in here."""
+    import torch as th
+    from livelyspeaker_amd import gaussian_diffusion as gd
+    from livelyspeaker_amd.model_util import create_gaussian_diffusion
+    diff = create_gaussian_diffusion(mk_args(steps=23), "")
+
+    class FakeEngine:
+        batch, J, F, T, D = 3, 9, 3, 34, 512
+        def __init__(self):
+            self.calls = []
+        def sample(self, **kw):
+            self.calls.append({k: (v.clone() if th.is_tensor(v) else v) for k, v in kw.items()})
+            last = kw.get("segment") is None or kw["segment"][0] + kw["segment"][1] == 23
+            return th.zeros(3, 9, 3, 34).numpy() if last else None
+
+    def run(segment_bytes):
+        eng = FakeEngine()
+        monkeypatch.setattr(diff, "_engine_for", lambda *a, **k: eng)
+        diff.tape_segment_bytes = segment_bytes
+        th.manual_seed(77)
+        diff.p_sample_loop(object(), (3, 9, 3, 34), clip_denoised=False, model_kwargs={"y": {}}, device="cpu")
+        return eng.calls
+
+    monkeypatch.setattr(th.cuda, "is_available", lambda: True)                       # the chunked path is for the GPU build only
+    monkeypatch.setattr(gd.GaussianDiffusion, "_tape_ring", lambda self, K, B, D, shape:
+                        [(th.empty(K, 2, B, D), th.empty((K,) + tuple(shape))) for _ in range(2)])    # (no page-locked memory here)
+    one = run(1 << 40)
+    assert len(one) == 1 and one[0].get("segment") is None and diff.last_tape_segments == 1
+    per_step = (2 * 3 * 512 + 3 * 9 * 3 * 34) * 4
+    seg = run(2 * 5 * per_step)                                                       # room for two 5-step segments
+    assert [c["segment"] for c in seg] == [(0, 5), (5, 5), (10, 5), (15, 5), (20, 3)] and diff.last_tape_segments == 5
+    assert th.equal(th.cat([c["eps_tape"] for c in seg]), one[0]["eps_tape"])
+    assert th.equal(th.cat([c["noise_tape"] for c in seg]), one[0]["noise_tape"])
+    assert all(th.equal(c["x_init"], one[0]["x_init"]) for c in seg)
+    assert all("use_graph" not in c for c in seg) and "use_graph" in one[0]
+
+
+def test_sampler_outputs_carry_the_reference_strides():
+    """pred_xstart / sample of the reference are permuted views (OutputProcess, RAG.py:209-210): memory order [T][B][J][F].  randn_like
+    of the next step consumes the generator in that order, so the mirror returns the same strides."""
+    import torch as th
+    from livelyspeaker_amd.gaussian_diffusion import _ref_strides
+    x = th.arange(4 * 9 * 3 * 34, dtype=th.float32).reshape(4, 9, 3, 34)
+    r = _ref_strides(x)
+    assert th.equal(r, x) and not r.is_contiguous()
+    want = th.empty(34, 4, 9, 3).permute(1, 2, 3, 0)
+    assert r.stride() == want.stride()
+    th.manual_seed(1); a = th.randn_like(r)
+    th.manual_seed(1); b = th.randn_like(want)
+    assert th.equal(a, b)
