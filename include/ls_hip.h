@@ -132,6 +132,16 @@ typedef struct ls_sample_args {
      * has returned.  Plain launches (use_graph is ignored).  seg_count == 0: the whole loop in one call (everything above). */
     int32_t seg_begin;
     int32_t seg_count;
+    /* p_mean_variance's inpainting branch (gaussian_diffusion.py:314-320; BEAT tree scripts_beat/...:319), off while inpaint_mask is
+     * NULL: every step's (CFG-combined) model output is replaced, where the mask is set, by the given motion -- re-noised with
+     * q_sample(inpainted_motion, t - 1) while t > 0 when inpaint_noised (the TED tree: its randn_like is inpaint_noise[k] in TAPE mode,
+     * the device stream 4 in PHILOX mode), as it is otherwise (the BEAT tree) -- before clip_denoised and the sampler update.  The loop
+     * then runs the denoiser and the update as two launches per step.  Not combined with segments. */
+    const unsigned char* inpaint_mask;   /* [B,J,F,T] bytes (non-zero = take the given motion), or NULL           */
+    const float* inpainted_motion;       /* [B,J,F,T]                                                            */
+    const float* inpaint_noise;          /* TAPE + inpaint_noised: [n_exec,B,J,F,T]; entries of steps with t == 0 unused */
+    int32_t inpaint_noised;
+    int32_t reserved2;
 } ls_sample_args;
 
 /* One RAG.forward pair (cond / uncond) and optionally the CFG combination, for model(x,t,y)
@@ -172,6 +182,9 @@ typedef struct ls_step_args {
                                    always take the per-sample path and are clamped into [0, n_steps). */
     int32_t no_sync;            /* on_device only: return without waiting for the GPU (order consumers with ls_stream_order) */
     int32_t indices_on_device;
+    const unsigned char* inpaint_mask;   /* as in ls_sample_args; uniform `index` only                          */
+    const float* inpainted_motion;
+    const float* inpaint_noise;          /* [B,J,F,T] the randn_like of q_sample(inpainted_motion, t - 1), or NULL = un-noised */
 } ls_step_args;
 
 typedef struct ls_timing {

@@ -46,7 +46,8 @@ class LsSampleArgs(C.Structure):
                 ("clip_denoised", C.c_int32), ("two_pass_always", C.c_int32), ("eta", C.c_float), ("n_dump", C.c_int32), ("dump_steps", c_i32p), ("dump_out", C.c_void_p),
                 ("x_init", C.c_void_p), ("init_image", C.c_void_p), ("eps_tape", C.c_void_p),
                 ("noise_tape", C.c_void_p), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
-                ("out", C.c_void_p), ("seg_begin", C.c_int32), ("seg_count", C.c_int32)]
+                ("out", C.c_void_p), ("seg_begin", C.c_int32), ("seg_count", C.c_int32), ("inpaint_mask", C.c_void_p),
+                ("inpainted_motion", C.c_void_p), ("inpaint_noise", C.c_void_p), ("inpaint_noised", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class LsForwardArgs(C.Structure):
@@ -59,7 +60,7 @@ class LsStepArgs(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("index", C.c_int32), ("on_device", C.c_int32), ("eta", C.c_float),
                 ("clip_denoised", C.c_int32), ("two_pass_always", C.c_int32), ("x", C.c_void_p), ("eps_cond", C.c_void_p), ("eps_uncond", C.c_void_p), ("noise", C.c_void_p),
                 ("sample", C.c_void_p), ("pred_xstart", C.c_void_p), ("indices", C.c_void_p), ("no_sync", C.c_int32),
-                ("indices_on_device", C.c_int32)]
+                ("indices_on_device", C.c_int32), ("inpaint_mask", C.c_void_p), ("inpainted_motion", C.c_void_p), ("inpaint_noise", C.c_void_p)]
 
 
 class LsSagConfig(C.Structure):
@@ -252,6 +253,24 @@ class _Marshal:
     def i64(self, a, shape=None):
         return self._conv(a, np.int64, shape)
 
+    def u8(self, a, shape=None):
+        """bool / byte mask -> bytes"""
+        if a is None:
+            return None
+        if self.on_device:
+            t = self.torch.as_tensor(a).to(device=self.dev, dtype=self.torch.uint8).contiguous()
+            if shape is not None:
+                assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+            self.keep.append(t)
+            return C.c_void_p(t.data_ptr())
+        if hasattr(a, "detach"):
+            a = a.detach().cpu().numpy()
+        n = np.ascontiguousarray(a, dtype=np.uint8)
+        if shape is not None:
+            assert tuple(n.shape) == tuple(shape), (n.shape, tuple(shape))
+        self.keep.append(n)
+        return n.ctypes.data_as(C.c_void_p)
+
     def _conv(self, a, dtype, shape):
         if a is None:
             return None
@@ -440,11 +459,12 @@ class Engine:
         return (oc, ou, og, tr) if trace else (oc, ou, og)
 
     def step(self, sampler, index, x, eps_c, eps_u, noise, eta=0.0, clip_denoised=False, two_pass_always=False, indices=None,
-             no_sync=False):
+             no_sync=False, inpaint=None):
         """One p_sample / ddim_sample step.  ``indices``: one schedule index per sample ([B] int64; numpy / CPU tensor = validated
         on the host, CUDA tensor = never read by the host) instead of the uniform ``index``.  ``no_sync`` (device tensors only):
         return without waiting for the GPU; the outputs are ordered behind the step on torch's current stream."""
-        m = _Marshal(self.device, x, eps_c, eps_u, noise, stream=self._stream)
+        inp = inpaint or (None, None, None)          # (mask, motion, q_sample noise or None): p_mean_variance's inpainting branch
+        m = _Marshal(self.device, x, eps_c, eps_u, noise, inp[1], stream=self._stream)
         B, D = self.batch, self.D
         out, pout = m.out(self._xshape())
         x0, px0 = m.out(self._xshape())
@@ -466,7 +486,8 @@ class Engine:
                 pidx = n.ctypes.data_as(C.c_void_p)
         nosync = int(bool(no_sync) and m.on_device)
         a = LsStepArgs(sampler, int(index), int(m.on_device), eta, int(clip_denoised), int(two_pass_always), m.f32(x, self._xshape()),
-                       m.f32(eps_c.reshape(B, D)), m.f32(eps_u.reshape(B, D)), m.f32(noise, self._xshape()), pout, px0, pidx, nosync, idx_dev)
+                       m.f32(eps_c.reshape(B, D)), m.f32(eps_u.reshape(B, D)), m.f32(noise, self._xshape()), pout, px0, pidx, nosync, idx_dev,
+                       m.u8(inp[0], self._xshape()), m.f32(inp[1], self._xshape()), m.f32(inp[2], self._xshape()))
         m.ready()
         self._check(self.lib.ls_step(self.h, C.byref(a)), "ls_step")
         if nosync:
@@ -476,10 +497,11 @@ class Engine:
 
     def sample(self, sampler=LS_SAMPLER_DDPM, x_init=None, eps_tape=None, noise_tape=None, init_image=None,
                skip_timesteps=0, eta=0.0, const_noise=False, dump_steps=None, philox_seed=None, sample_offset=0,
-               use_graph=True, clip_denoised=False, device_out=False, two_pass_always=False, segment=None):
+               use_graph=True, clip_denoised=False, device_out=False, two_pass_always=False, segment=None, inpaint=None):
         """Run the whole loop. TAPE mode when tapes are given, PHILOX mode when ``philox_seed`` is.
         Outputs are torch CUDA tensors if any input is one (or ``device_out``), else numpy."""
-        members = [x_init, eps_tape, noise_tape, init_image]
+        inp = inpaint or (None, None, None, False)     # (mask, motion, q_sample noise tape or None, re-noise?): the inpainting branch
+        members = [x_init, eps_tape, noise_tape, init_image, inp[1]]
         if device_out:
             import torch
             members.append(torch.empty(1, device=torch.device("cuda", self.device)))
@@ -503,6 +525,12 @@ class Engine:
             a.seed, a.sample_offset = int(philox_seed), int(sample_offset)
         a.x_init = m.f32(x_init, self._xshape())
         a.init_image = m.f32(init_image, self._xshape())
+        if inp[0] is not None:
+            a.inpaint_mask = m.u8(inp[0], self._xshape())
+            a.inpainted_motion = m.f32(inp[1], self._xshape())
+            a.inpaint_noised = int(bool(inp[3]))
+            if inp[2] is not None:
+                a.inpaint_noise = m.f32(inp[2], (n_tape,) + self._xshape())
         out, a.out = m.out(self._xshape())
         dumps = None
         if dump_steps:

@@ -109,6 +109,7 @@ struct ls_handle {
     DevBuf audio_feat, spart;
     DevBuf xa, xb, xtmp, xio, fwd_c, fwd_u, fwd_cfg, eps, noise, tfwd, tfwd_tmp, tidx, dump, trace, callp;
     DevBuf eps_tape, noise_tape;
+    DevBuf inp_m8, inp_maskf, inp_motion, inp_tape;     // inpainting branch: mask bytes / mask as 0-1 floats and motion in the internal layout, q_sample noise tape
     DevBuf eps_slot[2], noise_slot[2], coef;
     std::string coef_key;   // (sampler, eta, schedule) the per-index coefficient table `coef` was built for
 
@@ -607,6 +608,39 @@ void resolve_prepare_timing(ls_handle* h, bool block) {
     if (hipEventElapsedTime(&h->timing.prepare_ms, h->ev[4], h->ev[5]) == hipSuccess) h->prepare_pending = false;
 }
 
+// p_mean_variance's inpainting inputs (gaussian_diffusion.py:314-320) -> device, mask and motion in the internal [B][T][JF] layout
+int stage_inpainting(ls_handle* h, const unsigned char* mask, const float* motion, const float* noise, size_t noise_elems, int on_device) {
+    const int B = h->B, JF = h->JF;
+    const size_t nelem = (size_t)B * JF * h->T, nx = nelem * sizeof(float);
+    hipStream_t st = h->stream;
+    const void* old[4] = {h->inp_m8.p, h->inp_maskf.p, h->inp_motion.p, h->inp_tape.p};
+    int rc;
+    if ((rc = ingest(h, h->inp_m8, mask, nelem, on_device)) != LS_OK) return rc;
+    HIPCHK(h, h->xtmp.ensure(nx)); HIPCHK(h, h->xio.ensure(nx)); HIPCHK(h, h->inp_maskf.ensure(nx)); HIPCHK(h, h->inp_motion.ensure(nx));
+    HIPCHK(h, launch_bytes_to_float(static_cast<const unsigned char*>(h->inp_m8.p), h->xio.f(), nelem, st));
+    HIPCHK(h, launch_to_internal(h->xio.f(), h->inp_maskf.f(), B, JF, st, h->T));
+    if ((rc = ingest(h, h->xio, motion, nx, on_device)) != LS_OK) return rc;
+    HIPCHK(h, launch_to_internal(h->xio.f(), h->inp_motion.f(), B, JF, st, h->T));
+    if (noise && (rc = ingest(h, h->inp_tape, noise, noise_elems * sizeof(float), on_device)) != LS_OK) return rc;
+    if (old[0] != h->inp_m8.p || old[1] != h->inp_maskf.p || old[2] != h->inp_motion.p || old[3] != h->inp_tape.p) free_graph(h);
+    return LS_OK;
+}
+
+// the launch behind a denoiser launch with sampler = kNone: mix, clamp, update (coefficients as fill_sampler left them in `s`)
+hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noised, const float* inoise, const float* noise, int const_noise,
+                              float* x_out, float* dump, unsigned step_id, int clip, int B, hipStream_t st) {
+    InpaintArgs ia{};
+    ia.x_t = s.x_in; ia.x0 = h->fwd_cfg.f(); ia.maskf = h->inp_maskf.f(); ia.motion = h->inp_motion.f();
+    ia.renoise = noised && i > 0;                                      // `if t[0] > 0` (:318)
+    ia.inoise = ia.renoise ? inoise : nullptr;
+    ia.noise = noise; ia.const_noise = const_noise; ia.out = x_out; ia.dump = dump;
+    ia.call = s.call; ia.step_id = step_id;
+    ia.JF = h->JF; ia.T = h->T; ia.sampler = s.sampler; ia.t_nonzero = s.t_nonzero; ia.clip = clip;
+    if (i > 0) { ia.qa = (float)h->t_sac[i - 1]; ia.qb = (float)h->t_s1mac[i - 1]; }       // q_sample(., t - 1), cast like _extract_into_tensor
+    ia.c0 = s.c0; ia.c1 = s.c1; ia.c2 = s.c2; ia.c3 = s.c3; ia.c4 = s.c4;
+    return launch_inpaint_update(ia, B, st);
+}
+
 // Which kernels the prepared batch runs on.  The fused kernel gives one CU to each sample, so a step costs one CU's time for eight
 // layers (0.68 ms TED) however small the batch; the batch-level kernels spread the same rows over the whole chip (21 launches per
 // step) and win below kLongMaxBatch samples (measured: profiles/r03 small-batch table).  34-frame models only choose; other frame
@@ -636,6 +670,7 @@ int close_upload(ls_handle* h, int slot) {
 // ls_sample with seg_count > 0: one piece of a TAPE-mode loop (see ls_sample_args in ls_hip.h)
 int sample_segment(ls_handle* h, const ls_sample_args* a) {
     if (a->noise_mode != LS_NOISE_TAPE) return fail(h, LS_EINVAL, "segmented sampling is for TAPE mode (PHILOX needs no tapes)");
+    if (a->inpaint_mask) return fail(h, LS_EUNSUPPORTED, "the inpainting branch is not combined with segmented tapes");
     if (!a->eps_tape || !a->noise_tape) return fail(h, LS_EINVAL, "segment needs eps_tape and noise_tape");
     if (a->n_dump > 0 && (a->sampler != LS_SAMPLER_DDPM || !a->dump_steps || !a->dump_out))
         return fail(h, LS_EINVAL, "dump_steps: DDPM only (ddim_sample_loop raises NotImplementedError, gaussian_diffusion.py:919-920)");
@@ -858,6 +893,7 @@ void ls_destroy(ls_handle* h) {
         if (h->ev_seg[i]) (void)hipEventDestroy(h->ev_seg[i]);
     }
     h->coef.release();
+    h->inp_m8.release(); h->inp_maskf.release(); h->inp_motion.release(); h->inp_tape.release();
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1131,6 +1167,9 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
         index = (int)a->indices[0];
     }
     if (per_sample && !h->fused) return fail(h, LS_EUNSUPPORTED, "per-sample timesteps: fused (34-frame) path only");
+    const bool inpaint = a->inpaint_mask != nullptr;
+    if (inpaint && per_sample) return fail(h, LS_EUNSUPPORTED, "the inpainting branch takes a uniform step index (the reference tests t[0])");
+    if (inpaint && !a->inpainted_motion) return fail(h, LS_EINVAL, "inpaint_mask without inpainted_motion");
     if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
     if ((rc = ingest(h, h->xio, a->x, nx, od)) != LS_OK) return rc;
     HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->fwd_cfg.ensure(nx));
@@ -1146,7 +1185,17 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     s.x_in = h->xa.f(); s.x_out = h->xb.f(); s.x0_out = h->fwd_cfg.f();
     s.eps_c = h->eps.f(); s.eps_u = h->eps.f() + (size_t)B * kD;
     const bool pair = h->fused && !h->use_long && h->all_scale_one && !a->two_pass_always;
-    if (!per_sample) {
+    if (inpaint) {
+        if ((rc = stage_inpainting(h, a->inpaint_mask, a->inpainted_motion, a->inpaint_noise, (size_t)B * JF * h->T, od)) != LS_OK) return rc;
+        fill_sampler(h, s, a->sampler, index, a->eta);
+        s.noise = h->noise.f();
+        s.temb = h->temb.f() + (size_t)index * kD; s.temb_stride = 0;
+        StepArgs m = s;
+        m.sampler = kNone; m.clip_denoised = 0; m.x_out = nullptr; m.noise = nullptr;
+        HIPCHK(h, run_step(h, m, B, pair, st));
+        HIPCHK(h, run_inpaint_update(h, s, index, a->inpaint_noise != nullptr, h->inp_tape.f(), s.noise, 0, h->xb.f(), nullptr, 0u,
+                                     a->clip_denoised, B, st));
+    } else if (!per_sample) {
         fill_sampler(h, s, a->sampler, index, a->eta);
         s.noise = h->noise.f();
         s.temb = h->temb.f() + (size_t)index * kD; s.temb_stride = 0;
@@ -1264,6 +1313,17 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
         HIPCHK(h, h->dump.ensure((size_t)a->n_dump * nx));
         if (old != h->dump.p) free_graph(h);
     }
+    const bool inpaint = a->inpaint_mask != nullptr;
+    const bool inp_noised = inpaint && a->inpaint_noised;
+    if (inpaint) {
+        if (!a->inpainted_motion) return fail(h, LS_EINVAL, "inpaint_mask without inpainted_motion");
+        if (tape && inp_noised && !a->inpaint_noise) return fail(h, LS_EINVAL, "TAPE mode with inpaint_noised needs inpaint_noise");
+        if ((rc = stage_inpainting(h, a->inpaint_mask, a->inpainted_motion, (tape && inp_noised) ? a->inpaint_noise : nullptr,
+                                   (size_t)n_exec * nelem, od)) != LS_OK) return rc;
+        const void* oldc = h->fwd_cfg.p;
+        HIPCHK(h, h->fwd_cfg.ensure(nx));
+        if (oldc != h->fwd_cfg.p) free_graph(h);
+    }
 
     // ---- the loop: for i = T-1-skip ... 0 (gaussian_diffusion.py:724-743 / :994-1014) ----------------
     const bool pair = h->fused && !h->use_long && h->all_scale_one && !a->two_pass_always;
@@ -1273,6 +1333,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
         snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d L%d", h->precision, B, a->sampler, (double)a->eta,
                  a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, (int)h->use_long);
         key = keybuf;
+        if (inpaint) key += inp_noised ? " I2" : " I1";
         for (int d = 0; d < a->n_dump; ++d) key += "," + std::to_string(a->dump_steps[d]);      // the whole list, however long
     }
     auto enqueue_loop = [&]() -> int {
@@ -1292,8 +1353,19 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
                 s.noise = h->noise_tape.f() + (size_t)k * nelem;
                 s.const_noise = a->const_noise;
             }
+            float* dump_at = nullptr;
             for (int d = 0; d < a->n_dump; ++d)
-                if (a->dump_steps[d] == k) s.x0_out = h->dump.f() + (size_t)d * nelem;
+                if (a->dump_steps[d] == k) dump_at = h->dump.f() + (size_t)d * nelem;
+            if (inpaint) {
+                // two launches: the denoiser alone (CFG-combined model output -> fwd_cfg), then mix + clamp + update
+                StepArgs m = s;
+                m.sampler = kNone; m.clip_denoised = 0; m.x0_out = h->fwd_cfg.f(); m.x_out = nullptr; m.noise = nullptr;
+                HIPCHK(h, run_step(h, m, B, pair, st));
+                HIPCHK(h, run_inpaint_update(h, s, i, inp_noised, tape ? h->inp_tape.f() + (size_t)k * nelem : nullptr, s.noise, s.const_noise,
+                                             s.x_out, dump_at, (unsigned)k, a->clip_denoised, B, st));
+                continue;
+            }
+            if (dump_at) s.x0_out = dump_at;
             HIPCHK(h, run_step(h, s, B, pair, st));
         }
         return LS_OK;

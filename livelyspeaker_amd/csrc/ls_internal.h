@@ -168,6 +168,18 @@ hipError_t launch_q_sample(const float* x0, const float* noise, float* out, size
 // row per schedule index; indices [B] (device) selects each sample's row (clamped into the table)
 hipError_t launch_sampler_update(const float* x_t, const float* x0, const float* noise, const float* table, const int64_t* indices,
                                  int n_steps, float* out, int B, int JF, int T, int sampler, hipStream_t st);
+// p_mean_variance's inpainting branch + process_xstart + the sampler update, after a denoiser launch with sampler = kNone: x0 (internal
+// layout, in: CFG-combined model output, out: pred_xstart) = maskf ? given : x0, given = motion (internal) or qa * motion + qb * n with
+// n = inoise (reference layout) or the Philox stream 4 when `renoise`; then clamp, optional dump copy, DDPM / DDIM update as in k_step
+struct InpaintArgs {
+    const float* x_t; float* x0; const float* maskf; const float* motion; const float* inoise; const float* noise; float* out; float* dump;
+    const CallParams* call; unsigned step_id;
+    int JF, T, renoise, const_noise, sampler, t_nonzero, clip;
+    float qa, qb, c0, c1, c2, c3, c4;
+};
+hipError_t launch_inpaint_update(const InpaintArgs& a, int B, hipStream_t st);
+// bytes [n] -> 0.f / 1.f
+hipError_t launch_bytes_to_float(const unsigned char* src, float* dst, size_t n, hipStream_t st);
 hipError_t launch_randn_fill(float* out_btc, int B, int JF, const CallParams* call, unsigned stream_id,
                              hipStream_t st, int T = kT);
 hipError_t launch_transpose_feat(const float* conv4, float* out_btc, int B, hipStream_t st, int T = kT);

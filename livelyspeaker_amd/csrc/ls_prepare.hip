@@ -150,6 +150,54 @@ hipError_t launch_sampler_update(const float* x_t, const float* x0, const float*
     return hipGetLastError();
 }
 
+// gaussian_diffusion.py:314-320 (mix) + :365-371 (clamp) + :260-282, 507-558, 745-798 (update); one workgroup per sample
+__global__ void k_inpaint_update(const InpaintArgs a) {
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * a.T * a.JF;
+    const unsigned long long gidx = (a.call ? a.call->sample_offset : 0ull) + (unsigned long long)b;
+    for (int idx = threadIdx.x; idx < a.T * a.JF; idx += blockDim.x) {
+        const int f = idx / a.JF, c = idx - f * a.JF;
+        const size_t ri = ((size_t)b * a.JF + c) * a.T + f;                 // the same element in the reference layout
+        float x0 = a.x0[base + idx];
+        if (a.maskf[base + idx] != 0.f) {
+            float given = a.motion[base + idx];
+            if (a.renoise) {
+                const float n = a.inoise ? a.inoise[ri] : philox_normal(a.call, gidx, a.step_id, 4u, (unsigned)(c * a.T + f));
+                given = a.qa * given + a.qb * n;                               // q_sample(inpainted_motion, t - 1)
+            }
+            x0 = given;
+        }
+        if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        a.x0[base + idx] = x0;
+        if (a.dump) a.dump[base + idx] = x0;
+        if (a.sampler == kNone) continue;
+        const float xt = a.x_t[base + idx];
+        float nz = 0.f;
+        if (a.t_nonzero) nz = a.noise ? a.noise[a.const_noise ? ((size_t)c * a.T + f) : ri] : philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(c * a.T + f));
+        float xn;
+        if (a.sampler == kDDPM) {
+            xn = a.c0 * x0 + a.c1 * xt;
+            if (a.t_nonzero) xn += a.c2 * nz;
+        } else {
+            const float eps = (a.c0 * xt - x0) / a.c1;
+            xn = x0 * a.c2 + a.c3 * eps;
+            if (a.t_nonzero) xn += a.c4 * nz;
+        }
+        a.out[base + idx] = xn;
+    }
+}
+hipError_t launch_inpaint_update(const InpaintArgs& a, int B, hipStream_t st) {
+    hipLaunchKernelGGL(k_inpaint_update, dim3(B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+__global__ void k_bytes_to_float(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] ? 1.f : 0.f;
+}
+hipError_t launch_bytes_to_float(const unsigned char* src, float* dst, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_bytes_to_float, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError();
+}
+
 // Philox x_T (perf mode): element index follows the reference layout (c*T+f) so it is layout independent.
 __global__ void k_randn_fill(float* __restrict__ out, int JF, const CallParams* __restrict__ call, unsigned stream_id, int T) {
     const int b = blockIdx.x;

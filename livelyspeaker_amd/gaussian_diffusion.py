@@ -161,16 +161,24 @@ class GaussianDiffusion:
             raise ValueError("ClassifierFreeSampleModel returns None when cond_mask_prob == 0 (cfg_sampler.py:24-31)")
         if not model_kwargs or 'y' not in model_kwargs:
             raise ValueError("model_kwargs={'y': {...}} is required")
-        if 'inpainting_mask' in model_kwargs['y'] and 'inpainted_motion' in model_kwargs['y']:
-            # p_mean_variance's inpainting branch (gaussian_diffusion.py:314-320; BEAT :319) overwrites the model output and, on TED,
-            # draws an extra randn inside q_sample: not built (no reference caller passes the keys) -- refused, never ignored
-            raise NotImplementedError("inpainting (y['inpainting_mask'] + y['inpainted_motion']) is not built on the MI355X path")
         eng = model.model._engine_prepared(model_kwargs['y'])
         key = (id(self), self.num_timesteps)
         if getattr(eng, "_sched_key", None) != key:
             eng.set_schedule(self)
             eng._sched_key = key
         return eng
+
+    @staticmethod
+    def _inpainting(model, model_kwargs, shape):
+        """p_mean_variance's inpainting branch (gaussian_diffusion.py:314-320): active when y carries BOTH keys.  The TED tree re-noises
+        the given motion with q_sample(., t - 1) while t[0] > 0 (one more randn_like per step); the BEAT tree
+        (scripts_beat/diffusion/gaussian_diffusion.py:319) mixes it in as it is.  Returns (mask, motion, re-noise?) or None."""
+        y = model_kwargs['y']
+        if 'inpainting_mask' not in y or 'inpainted_motion' not in y:
+            return None
+        mask, motion = y['inpainting_mask'], y['inpainted_motion']
+        assert tuple(mask.shape) == tuple(motion.shape) == tuple(shape)      # :317
+        return mask, motion, getattr(model.model, "n_prefix_tokens", 1) == 1
 
     @staticmethod
     def _reject(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad):
@@ -187,17 +195,27 @@ class GaussianDiffusion:
         assert t.shape == (B,)                  # gaussian_diffusion.py:311
         eps_c = th.randn(B, 1, eng.D)           # cond pass reparameterize (RAG.py:12), then uncond pass
         eps_u = th.randn(B, 1, eng.D)
+        inp = self._inpainting(model, model_kwargs, tuple(x.shape))
+        inp_arg = None
+        if inp is not None:
+            # q_sample(inpainted_motion, t - 1) draws randn_like(inpainted_motion) between the model call and the step's own noise (:318)
+            t_host = t.detach().cpu()
+            if not bool((t_host == t_host[0]).all()):
+                raise NotImplementedError("the inpainting branch tests t[0] only (gaussian_diffusion.py:318): pass one timestep for the batch")
+            inz = th.randn_like(inp[1], device="cpu", dtype=th.float32) if (inp[2] and int(t_host[0]) > 0) else None
+            inp_arg = (inp[0], inp[1], inz)
+            t = t_host
         noise = th.randn_like(x, device="cpu", dtype=th.float32)    # follows x's strides like the reference's randn_like(x)
         if const_noise:
             noise = noise[[0]].repeat(B, 1, 1, 1)
         dev = x.device
-        if x.is_cuda:
+        if x.is_cuda and inp is None:
             eps_c, eps_u, noise = self._stage_step_draws(dev, eps_c, eps_u, noise)
         # `t` may differ per sample (the reference's signature).  A CUDA `t` is handed to the engine as it is -- never read back, so
         # a step-by-step caller has no device -> host round trip per step, and with device tensors the call does not wait for the GPU
         # either (outputs are stream-ordered); a host `t` is validated there and a constant one takes the fused uniform path.
         out, x0 = eng.step(sampler, 0, x, eps_c, eps_u, noise, eta=eta, clip_denoised=clip_denoised, indices=t.detach(),
-                           two_pass_always=self.two_pass_always, no_sync=x.is_cuda)
+                           two_pass_always=self.two_pass_always, no_sync=x.is_cuda and inp is None, inpaint=inp_arg)
         return {"sample": _ref_strides(_as_tensor(out, dev)), "pred_xstart": _ref_strides(_as_tensor(x0, dev))}
 
     def _stage_step_draws(self, dev, *draws):
@@ -261,6 +279,7 @@ class GaussianDiffusion:
         kw = dict(sampler=sampler, x_init=x_init, init_image=init_image, skip_timesteps=skip_timesteps, eta=eta,
                   const_noise=const_noise, dump_steps=dump_steps or None,
                   use_graph=self.use_graph, clip_denoised=clip_denoised)
+        inp = self._inpainting(model, model_kwargs, shape)
         if philox:
             if const_noise:
                 raise NotImplementedError("const_noise needs noise_source='torch_cpu'")
@@ -270,6 +289,8 @@ class GaussianDiffusion:
             self.last_philox_seed = drawn if self.philox_seed is None else int(self.philox_seed)
             kw["philox_seed"] = self.last_philox_seed
             kw["sample_offset"] = int(getattr(self, "sample_offset", 0))
+            if inp is not None:
+                kw["inpaint"] = (inp[0], inp[1], None, inp[2])           # the re-noising draws come from the device stream too
         else:
             # p_sample/ddim_sample draw `randn_like(x)` (gaussian_diffusion.py:543/787).  x is contiguous at the first
             # executed step, but from then on it is the model-output-shaped view whose memory order is
@@ -278,14 +299,23 @@ class GaussianDiffusion:
             first_proto = noise.cpu() if (noise is not None and init_image is None and not skip_timesteps) else th.empty(shape)
             later_proto = th.empty(shape[3], shape[0], shape[1], shape[2]).permute(1, 2, 3, 0)
 
+            inz = None
+            if inp is not None and inp[2]:
+                inz = th.zeros((n_exec,) + shape)   # q_sample(inpainted_motion, t - 1)'s randn_like, steps with t > 0 (:318)
+                inp_proto = inp[1].detach().cpu() if th.is_tensor(inp[1]) else th.empty(shape)
+
             def draw(k, eps_k, nz_k):          # the reference's per-step draw order
                 eps_k[0] = th.randn(B, 1, eng.D)[:, 0]
                 eps_k[1] = th.randn(B, 1, eng.D)[:, 0]
+                if inz is not None and n_exec - 1 - k > 0:
+                    inz[k] = th.randn_like(inp_proto, dtype=th.float32)
                 nz_k.copy_(th.randn_like(first_proto if k == 0 else later_proto, dtype=th.float32))
 
+            if inp is not None:
+                kw["inpaint"] = (inp[0], inp[1], inz, inp[2])
             per_step = (2 * B * eng.D + int(np.prod(shape))) * 4
             t_rng = 0.0
-            if per_step * n_exec > self.tape_segment_bytes and th.cuda.is_available() and n_exec > 1:
+            if per_step * n_exec > self.tape_segment_bytes and th.cuda.is_available() and n_exec > 1 and inp is None:
                 # 4 GB at 512 clips x 1000 steps if drawn in one piece: K-step segments through two page-locked buffers instead; the
                 # engine uploads segment i+1 on its copy stream while segment i's steps run (ls_sample_args.seg_begin / seg_count)
                 K = max(1, min(n_exec, self.tape_segment_bytes // (2 * per_step)))

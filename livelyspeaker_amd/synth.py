@@ -276,6 +276,20 @@ class NoiseTape:
         return out
 
 
+def make_inpainting(cfg: PathConfig, batch: int, n_steps: int, seed: int = SEED_COND + 3000):
+    """Inputs of p_mean_variance's inpainting branch (gaussian_diffusion.py:314-320): y['inpainting_mask'] (bool: True = take the given
+    motion), y['inpainted_motion'], and the randn_like(inpainted_motion) draws of its q_sample, one per step with t > 0.  The mask
+    keeps the first ten frames of every joint and, beyond them, every third joint."""
+    g = _rng(seed)
+    shp = (batch, cfg.njoints, cfg.nfeats, cfg.nframes)
+    mask = np.zeros(shp, dtype=bool)
+    mask[..., :10] = True
+    mask[:, ::3, :, :] = True
+    motion = _f32(g.standard_normal(shp) * 0.3)
+    noise = _f32(g.standard_normal((n_steps,) + shp))
+    return mask, motion, noise
+
+
 def schedule(diffusion_steps: int, timestep_respacing: str = ""):
     """The product's own schedule object (SpacedDiffusion tables) for tools and examples that drive the engine directly."""
     from types import SimpleNamespace

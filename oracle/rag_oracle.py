@@ -303,10 +303,14 @@ def ddim_update(sch: Schedule, x, x0, i: int, noise, eta: float = 0.0):
 
 def sample_loop(model: RagOracle, sch: Schedule, y: dict, x_init, eps_tape, noise_tape,
                 ddim=False, eta=0.0, skip_timesteps=0, init_image=None, hoisted=True,
-                dump_steps=None, max_steps=None, clip_denoised=False):
+                dump_steps=None, max_steps=None, clip_denoised=False, inpaint=None):
     """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:608-743, 895-1014) with the CFG
     wrapper inlined. eps_tape[k] = (eps_cond, eps_uncond) [2,B,512]; noise_tape[k] [B,J,F,T];
-    k counts executed steps. Returns final sample (and pred_xstart dumps if requested)."""
+    k counts executed steps. Returns final sample (and pred_xstart dumps if requested).
+    inpaint = (mask bool [B,J,F,T], motion [B,J,F,T], noise [n,B,J,F,T] or None): p_mean_variance's inpainting branch
+    (gaussian_diffusion.py:314-320): model_output = model_output * ~mask + q_sample(motion, t - 1) * mask while t > 0 (the TED tree; its
+    q_sample draws noise[k]), + motion * mask at t = 0 -- and always un-noised when noise is None (scripts_beat/diffusion/
+    gaussian_diffusion.py:319)."""
     img = np.asarray(x_init, dtype=F32)
     if skip_timesteps and init_image is None:
         init_image = np.zeros_like(img)
@@ -322,6 +326,11 @@ def sample_loop(model: RagOracle, sch: Schedule, y: dict, x_init, eps_tape, nois
             break
         t_model = np.full((B,), sch.timestep_map[i], dtype=np.int64)     # _WrappedModel, respace.py:125-130
         x0 = model.cfg_forward(img, t_model, y, eps_tape[k][0], eps_tape[k][1], hoisted)
+        if inpaint is not None:
+            mask, motion, inz = inpaint
+            motion = np.asarray(motion, dtype=F32)
+            given = q_sample(sch, motion, i - 1, inz[k]) if (inz is not None and i > 0) else motion
+            x0 = np.where(mask, given, x0).astype(F32)
         if clip_denoised:                                                 # process_xstart, gaussian_diffusion.py:365-371
             x0 = np.clip(x0, -1, 1)
         if dump_steps is not None and k in dump_steps:

@@ -1,6 +1,6 @@
 """Round-3 boundary features, all through the C-ABI on the GPU:
   * per-sample timesteps in p_sample / ddim_sample (gaussian_diffusion.py:507-558, 745-798: `t` is a [B] tensor), host and
-    device index vectors, and the refusal of the inpainting keys (gaussian_diffusion.py:314-320) instead of ignoring them;
+    device index vectors; p_mean_variance's inpainting branch (gaussian_diffusion.py:314-320) against reference fixtures G14;
   * segmented TAPE-mode loops (ls_sample_args.seg_begin / seg_count): bit-identical to the one-piece loop, through the engine
     and through the GaussianDiffusion mirror's chunked "identical seeds" mode;
   * stream ordering instead of host synchronisation (ls_stream_order): inputs produced on a busy side stream, and a
@@ -87,7 +87,7 @@ def test_step_with_one_schedule_index_per_sample(ds, sampler):
         eng.close()
 
 
-def test_p_sample_accepts_a_timestep_tensor_and_refuses_inpainting_keys():
+def test_p_sample_accepts_a_timestep_tensor():
     import torch
     cfg, model, diffusion = _wrapped("ted", "", 50)
     B = 4
@@ -101,12 +101,98 @@ def test_p_sample_accepts_a_timestep_tensor_and_refuses_inpainting_keys():
         uni = diffusion.p_sample(model, x, torch.full((B,), int(t[b])), clip_denoised=False, model_kwargs={"y": y})
         assert max_abs(mixed["sample"][b].cpu(), uni["sample"][b].cpu()) < 2e-6
         assert max_abs(mixed["pred_xstart"][b].cpu(), uni["pred_xstart"][b].cpu()) < 2e-6
-    y_inp = dict(y, inpainting_mask=torch.zeros(B, 9, 3, 34, dtype=torch.bool).cuda(), inpainted_motion=torch.zeros(B, 9, 3, 34).cuda())
+    diffusion.p_sample(model, x, t, clip_denoised=False, model_kwargs={"y": dict(y, inpainting_mask=torch.zeros(B, 9, 3, 34, dtype=torch.bool))})  # one key alone: ignored, as in the reference
+
+
+# ------------------------------------------------------------------------------------------------ inpainting branch
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+@pytest.mark.parametrize("path", ["fused", "batch"])
+def test_inpainting_branch_vs_reference_fixtures(ds, path):
+    """p_mean_variance's inpainting branch (gaussian_diffusion.py:314-320; BEAT tree :319) against fixtures G14 produced by the
+    reference itself: the TED tree re-noises the given motion with q_sample(., t - 1) while t > 0 (its randn_like is one more tape), the
+    BEAT tree mixes it in as it is.  DDPM 30 steps and ddim100 / skip 80 with init_image; both kernel paths; and the size-independent
+    property: at t = 0 the posterior mean IS pred_xstart, so the final sample equals the given motion wherever the mask is set."""
+    import os
+    from conftest import GOLDEN
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    g = np.load(os.path.join(GOLDEN, f"{ds}_golden_r3.npz"))
+    cfg = synth.CONFIGS[ds]
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=path)
+    eng.load_state_dict(synth.make_state_dict(cfg))
+    noised = ds == "ted"
+    try:
+        B = 3
+        eng.prepare(synth.make_cond(cfg, B, scale=1.5))
+        for key, steps, resp, ddim, skip, use_init in (("G14_inpaint_ddpm30_B3_final", 30, "", False, 0, False),
+                                                       ("G14_inpaint_ddim100_skip80_B3_final", 1000, "ddim100", True, 80, True)):
+            sch = orc.Schedule(steps, resp)
+            eng.set_schedule(sch)
+            n = sch.num_timesteps - skip
+            tape = synth.NoiseTape(cfg, B, n)
+            mask, motion, inz = synth.make_inpainting(cfg, B, n)
+            kw = dict(sampler=_lib.LS_SAMPLER_DDIM if ddim else _lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise,
+                      skip_timesteps=skip, init_image=synth.make_init_image(cfg, B) if use_init else None,
+                      inpaint=(mask, motion, inz if noised else None, noised))
+            out = eng.sample(**kw)
+            d = max_abs(out, g[key])
+            print(f"{ds} [{path}] {key}: {d:.3e}")
+            assert d < 3e-4
+            assert np.array_equal(out[mask], motion[mask])                                 # the property
+            assert np.array_equal(out, eng.sample(use_graph=False, **kw))                 # hipGraph replay == plain launches
+            plain = eng.sample(**{k: v for k, v in kw.items() if k != "inpaint"})
+            assert max_abs(plain, g[key]) > 0.5                                            # the branch is what makes the difference
+        # Philox mode: the re-noising draws come from the device stream; the property holds, shards agree
+        eng.set_schedule(orc.Schedule(12, ""))
+        mask, motion, _ = synth.make_inpainting(cfg, B, 12)
+        o1 = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=11, sample_offset=40, inpaint=(mask, motion, None, noised))
+        assert np.isfinite(o1).all() and np.array_equal(o1[mask], motion[mask])
+        # a single step through ls_step: same mix (dump of pred_xstart = the given motion, re-noised or not, under the mask)
+        tape = synth.NoiseTape(cfg, B, 1)
+        inz1 = synth.make_inpainting(cfg, B, 1)[2][0]
+        s, x0 = eng.step(_lib.LS_SAMPLER_DDPM, 5, tape.x_init, tape.eps[0, 0], tape.eps[0, 1], tape.noise[0], inpaint=(mask, motion, inz1 if noised else None))
+        want = orc.q_sample(orc.Schedule(12, ""), motion, 4, inz1) if noised else motion
+        assert max_abs(x0[mask], want[mask]) < 1e-6
+        s0, x00 = eng.step(_lib.LS_SAMPLER_DDPM, 0, tape.x_init, tape.eps[0, 0], tape.eps[0, 1], tape.noise[0], inpaint=(mask, motion, inz1 if noised else None))
+        assert np.array_equal(x00[mask], motion[mask]) and np.array_equal(s0[mask], motion[mask])
+    finally:
+        eng.close()
+
+
+def test_inpainting_keys_through_the_dropin_draw_the_references_stream():
+    """y['inpainting_mask'] + y['inpainted_motion'] through GaussianDiffusion.p_sample_loop: the extra randn_like of q_sample is drawn
+    between the two style eps and the step noise, so replaying torch's stream by hand into the oracle reproduces the sample."""
+    import torch
+    from oracle import rag_oracle as orc
+    cfg, model, diffusion = _wrapped("ted", "", 20)
+    B = 3
+    y_np = synth.make_cond(cfg, B, scale=1.5)
+    mask, motion, _ = synth.make_inpainting(cfg, B, 1)
+    y = {k: torch.from_numpy(v).cuda() for k, v in y_np.items()}
+    y["inpainting_mask"], y["inpainted_motion"] = torch.from_numpy(mask).cuda(), torch.from_numpy(motion).cuda()
+    torch.manual_seed(21)
+    got = diffusion.p_sample_loop(model, (B, 9, 3, 34), clip_denoised=False, model_kwargs={"y": y}, progress=False).cpu().numpy()
+    torch.manual_seed(21)
+    shape = (B, 9, 3, 34)
+    x_init = torch.randn(*shape).numpy()
+    eps, nz, inz = [], [], []
+    for k in range(20):
+        ec, eu = torch.randn(B, 1, 512).numpy().reshape(B, 512), torch.randn(B, 1, 512).numpy().reshape(B, 512)
+        eps.append(np.stack([ec, eu]))
+        inz.append(torch.randn(*shape).numpy() if 19 - k > 0 else np.zeros(shape, np.float32))
+        proto = torch.empty(shape) if k == 0 else torch.empty(34, B, 9, 3).permute(1, 2, 3, 0)
+        nz.append(torch.randn_like(proto).numpy())
+    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    want = orc.sample_loop(oracle, orc.Schedule(20, ""), y_np, x_init, eps, nz, inpaint=(mask, motion, inz))
+    d = max_abs(got, want)
+    print(f"inpainting through the drop-in vs oracle on the replayed stream: {d:.3e}")
+    assert d < 3e-4 and np.array_equal(got[mask], motion[mask])
+    # p_sample with the keys: pred_xstart under the mask is the re-noised motion; a non-uniform t is refused (the reference tests t[0])
+    x = torch.randn(*shape).cuda()
+    r = diffusion.p_sample(model, x, torch.full((B,), 0), clip_denoised=False, model_kwargs={"y": y})
+    assert np.array_equal(r["pred_xstart"].cpu().numpy()[mask], motion[mask])
     with pytest.raises(NotImplementedError):
-        diffusion.p_sample(model, x, t, clip_denoised=False, model_kwargs={"y": y_inp})
-    with pytest.raises(NotImplementedError):
-        diffusion.p_sample_loop(model, (B, 9, 3, 34), clip_denoised=False, model_kwargs={"y": y_inp})
-    diffusion.p_sample(model, x, t, clip_denoised=False, model_kwargs={"y": dict(y, inpainting_mask=y_inp["inpainting_mask"])})  # one key alone: the reference ignores it too
+        diffusion.p_sample(model, x, torch.tensor([0, 1, 2]), clip_denoised=False, model_kwargs={"y": y})
 
 
 # ------------------------------------------------------------------------------------------------ segmented tape loops

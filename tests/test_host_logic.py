@@ -136,8 +136,8 @@ def test_abi_struct_sizes_match_header_layout(tmp_path):
     got = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in out.splitlines()}
     for c, py in pairs:
         assert got[c] == (ctypes.sizeof(py), getattr(py, py._fields_[-1][0]).offset), (c, got[c])
-    assert ctypes.sizeof(_lib.LsSampleArgs) == 40 + 2 * 8 + 4 * 8 + 2 * 8 + 8 + 8
-    assert ctypes.sizeof(_lib.LsStepArgs) == 24 + 6 * 8 + 8 + 8
+    assert ctypes.sizeof(_lib.LsSampleArgs) == 40 + 2 * 8 + 4 * 8 + 2 * 8 + 8 + 8 + 3 * 8 + 8
+    assert ctypes.sizeof(_lib.LsStepArgs) == 24 + 6 * 8 + 8 + 8 + 3 * 8
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

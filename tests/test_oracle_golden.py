@@ -154,3 +154,23 @@ def test_beat_full_ddim100():
     from conftest import GOLDEN
     g = np.load(os.path.join(GOLDEN, "beat_golden_r2.npz"))
     assert max_abs(_loop("beat", 1000, "ddim100", True, 0, False), g["G13_ddim100_full_final"]) < TOL
+
+
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_oracle_inpainting_branch_vs_reference_fixtures(ds):
+    """G14 (tests/golden/make_golden_r3.py): p_mean_variance's inpainting branch as the reference runs it -- TED re-noises the given motion
+    with q_sample(., t - 1) while t > 0, the BEAT tree does not."""
+    import os
+    from conftest import GOLDEN
+    from oracle import rag_oracle as orc
+    g = np.load(os.path.join(GOLDEN, f"{ds}_golden_r3.npz"))
+    cfg = synth.CONFIGS[ds]
+    oracle = orc.RagOracle(synth.make_state_dict(cfg), cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens)
+    B, n = 3, 30
+    sch = orc.Schedule(n, "")
+    tape = synth.NoiseTape(cfg, B, n)
+    mask, motion, inz = synth.make_inpainting(cfg, B, n)
+    out = orc.sample_loop(oracle, sch, synth.make_cond(cfg, B, scale=1.5), tape.x_init, tape.eps, tape.noise,
+                          inpaint=(mask, motion, inz if ds == "ted" else None))
+    assert float(np.abs(out - g["G14_inpaint_ddpm30_B3_final"]).max()) < 1e-4
+    assert np.array_equal(out[mask], motion[mask])
