@@ -508,100 +508,171 @@ hipError_t launch_conv1_fwd(const float* wav, const float* w, const float* bias,
 // Weight gradient of the stride-6 conv layers as an implicit GEMM (training step):
 //     dW[co][ci][k] = sum_{b,p} dC[b][co][p] * act(in[b][ci][6p + k])
 // MFMA M axis = 16 output channels, N axis = 16 weight columns (ci*15 + k), K = 4 positions per MFMA (pos = 4m + g).
-// Workgroup = 64 output channels x 240 columns (16 input channels) x a group of samples; per 64-position tile it stages
-// dC [64][64] and the activation window [16][398] (InstanceNorm + LeakyReLU applied on the way in) in LDS; lane (j, g)
-// reads act_lds[ci_j][k_j + 6g + 24m] = lane base + immediate.  Wave w owns column tiles w, w+4, w+8, w+12 (15 tiles).
-// Partial sums per sample group go to a workspace that k_partial_reduce sums in index order (deterministic).
+// Workgroup = 64 output channels x 240 columns (16 input channels) x a run of 64-position tiles of the flattened
+// (sample, tile) sequence (768 runs = 3 resident workgroups per CU whatever the batch); per tile it stages dC [64][64] and the
+// activation window [16][393] in LDS.  Wave w owns column tiles w, w+4, w+8, w+12 (15 tiles).
+// Round 3 (conv2 / conv3 / conv4 at B = 512: 457 / 339 / 303 us -> 460 / 325 / 236, tools/conv_bwd_bench.cpp):
+//  * conv4 runs here too (rounds 1-2: im2col + GEMM); steps past the valid positions of a tile are skipped (its 34 positions
+//    cost 9 steps, not 16);
+//  * both operands are read as ONE ds_read_b128 per four MFMA steps (before: one ds_read_b32 per operand and step):
+//      dcs  [co][16 chunks of 4]: chunk (4M + g) ^ (co & 15) of row co holds positions 16M + 4e + g, e = 0..3 -- lane (co, g)'s A
+//           values of steps m = 4M .. 4M+3; the XOR makes the four 16-lane groups of a b128 read conflict-free;
+//      acts [ci][33 rows][16]: row r = 6g + k (0..32) holds act[24m + r] for m = 0..15, i.e. lane (ci, k, g)'s B values of all 16
+//           steps in step order (rows 24..32 repeat rows 0..8 one step later); chunk M is stored at M ^ ((r >> 1) & 3);
+//  * the next tile's values stay RAW in registers while the current tile is multiplied and are normalised (InstanceNorm +
+//    LeakyReLU, audio_enc.py:10-11) on their way into LDS (before: at fetch time, an s_waitcnt on every load in front of the MFMAs);
+//    loads go through per-tile buffer descriptors (the window's tail past the sample reads 0; dC past the last position is zeroed,
+//    which makes every mask on the window side unnecessary: a finite value times an exact 0).
+// What bounds it (ablations of tools/build_conv_bench.sh, conv2): MFMAs + operand reads + barriers alone 337 us against a 279 us
+// matrix floor (16 column tiles for 15), + the window / dC write phase 56, + the global loads 35..90.  The fp32 matrix pipe and the
+// fp32 VALU are the same lanes, so the ~1 staging instruction per MFMA is paid in full; a 512-thread form with every LDS image
+// multi-buffered, the dC tile by LDS-DMA and the staging interleaved into the MFMA groups (one barrier per tile) measured SLOWER
+// (491 / 327 / 266): one workgroup per CU leaves nothing to fill its barrier skew and operand-read bursts.
+// Partial sums per workgroup run go to a workspace that k_partial_reduce sums in index order (deterministic).
+#ifndef LS_WG_ABL
+#define LS_WG_ABL 0                      // timing-only ablations for tools/conv_bwd_bench.cpp: 1 no LDS write phase after the first tile,
+#endif                                   // 2 no MFMAs, 8 no global loads after the first tile
 namespace ls {
 
-constexpr int kWgCo = 64, kWgCi = 16, kWgPT = 64, kWgDld = kWgPT + 4;      // 64 output channels x 16 input channels (240 columns)
-constexpr int kWgWin = (kWgPT - 1) * 6 + 15, kWgWinP = kWgWin + 1;      // 393 -> 394
+constexpr int kWgCo = 64, kWgCi = 16, kWgPT = 64;                          // 64 output channels x 16 input channels (240 columns)
+constexpr int kWgWin = (kWgPT - 1) * 6 + 15;                               // 393
+constexpr int kWgRS = 16, kWgCS = 34 * kWgRS;                              // 33 rows of 16 steps per channel (+ one row: bank shift, dummy slot)
+constexpr int kWgNA = 28;                                                  // window values per thread: 4 channels x 7 pieces of 64
 
-__global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ dc, const float* __restrict__ in, const float* __restrict__ stats,
-                                                    float* __restrict__ partial, int Cin, int Cout, int Lin, int Lout, int spw, int B) {
-    __shared__ float dcs[kWgCo * kWgDld];
-    __shared__ float acts[kWgCi * kWgWinP];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 3 workgroups per CU: 50.8 KB of LDS each, <= 168 VGPRs
+void k_conv_wgrad(const float* __restrict__ dc, long long sb, long long sc, const float* __restrict__ in, const float* __restrict__ stats,
+                  float* __restrict__ partial, int Cin, int Cout, int Lin, int Lout, int ntl, int ntot, int tpg) {
+    __shared__ __attribute__((aligned(16))) float dcs[kWgCo * kWgPT];
+    __shared__ __attribute__((aligned(16))) float acts[kWgCi * kWgCS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
     const int ci0 = blockIdx.x * kWgCi, co0 = blockIdx.y * kWgCo;
-    const int b0 = blockIdx.z * spw, b1 = min(B, b0 + spw);
+    const int t0 = blockIdx.z * tpg, t1 = min(ntot, t0 + tpg);
     const int W = Cin * 15;
-    const int ntile = w == 3 ? 3 : 4;               // column tiles of this wave
 
     f4 acc[4][4];                                   // [co tile][column tile]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[i][c] = (f4){0.f, 0.f, 0.f, 0.f};
-    int bbase[4];                                   // lane's activation base per column tile: ci_j * WinP + k_j + 6 g
+    // operand read offsets in bytes; step group M is reached by XOR (the swizzles live in address bits the rest leaves clear)
+    int boff[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int j = 16 * (w + 4 * c) + s16;       // column inside the 240-column chunk (tile 15 of wave 3 is unused)
-        const int cij = j / 15, kj = j - 15 * cij;
-        bbase[c] = (c < ntile ? cij : 0) * kWgWinP + kj + 6 * g;
+        const int j = 16 * (w + 4 * c) + s16;       // column inside the 240-column chunk (tile 15, w = 3 / c = 3, is computed and dropped)
+        const bool real = j < 240;
+        const int cij = real ? j / 15 : 0, kj = real ? j - 15 * (j / 15) : 0;
+        const int r = 6 * g + kj;
+        boff[c] = (cij * kWgCS + r * kWgRS) * 4 + (((r >> 1) & 3) << 4);
     }
-    const int abase = s16 * kWgDld + g;             // + 16 i * Dld + 4 m
+    const int aoff = s16 * kWgPT * 4 + (((s16 & 12) | ((g ^ s16) & 3)) << 4);
+    // window staging: wave w owns channels 4w .. 4w+3, 7 pieces of 64 values each; value x -> row x % 24, step x / 24 (and, for rows
+    // 0..8, a second copy in row 24 + x % 24 one step earlier); values without a slot go to the spare row (no branch).  Both byte
+    // addresses of a piece share one register (16 bits each).
+    unsigned wad[7];
+#pragma unroll
+    for (int pc = 0; pc < 7; ++pc) {
+        const int x = 64 * pc + lane, m = x / 24, r = x - 24 * m;
+        const int base = 4 * w * kWgCS, dummy = base + 33 * kWgRS + (lane & 15);
+        const int wa = (x < kWgWin && m < 16) ? base + r * kWgRS + ((((m >> 2) ^ (r >> 1)) & 3) << 2) + (m & 3) : dummy;
+        const int r2 = r + 24, m2 = m - 1;
+        const int wd = (x < kWgWin && r < 9 && m >= 1) ? base + r2 * kWgRS + ((((m2 >> 2) ^ (r2 >> 1)) & 3) << 2) + (m2 & 3) : dummy;
+        wad[pc] = (unsigned)(wa * 4) | ((unsigned)(wd * 4) << 16);
+    }
+    static_assert(kWgCi * kWgCS * 4 < 65536, "window addresses are packed in 16 bits");
+    // dC staging: thread = (channel w + 4q, position `lane`) of the [64][64] tile
+    const int dwo = (w * kWgPT + (((((lane >> 4) << 2) | (lane & 3)) ^ w) << 2) + ((lane >> 2) & 3)) * 4;   // row w; row w + 4q: ^ ((q & 3) << 6), + q KB
 
-    // Software pipeline over (sample, 64-position tile): the next tile's global loads (16 dC + 25 activation values per
-    // thread, InstanceNorm + LeakyReLU applied in registers) are in flight while the current tile is multiplied.
-    constexpr int ND = kWgCo * kWgPT / 256, NA = (kWgWin + 15) / 16;
-    float rd[ND], ra[NA];
-    const int ntl = (Lout + kWgPT - 1) / kWgPT, ntot = (b1 - b0) * ntl;
+    constexpr int ND = kWgCo * kWgPT / 256;
+    float rd[ND], ra[kWgNA];
+    float fr[4], fn[4];                              // rstd and -mean * rstd of the fetched tile's four channels (wave-uniform)
+    int fp0 = 0;
     auto fetch = [&](int t) {
-        const int b = b0 + t / ntl, p0 = (t % ntl) * kWgPT;
+        const int b = t / ntl, p0 = (t - b * ntl) * kWgPT;
+        const auto rdc = uniform_rsrc(dc + (size_t)b * sb + (size_t)co0 * sc);
+        const int vo = min(p0 + lane, Lout - 1) * 4;                            // clamped position: branch-free load
 #pragma unroll
-        for (int q = 0; q < ND; ++q) {
-            const int idx = tid + 256 * q, co = idx >> 6, p = idx & 63;
-            const float v = dc[((size_t)b * Cout + co0 + co) * Lout + min(p0 + p, Lout - 1)];    // clamped address: branch-free load
-            rd[q] = p0 + p < Lout ? v : 0.f;
-        }
-        const int ci = tid >> 4;
-        const size_t row = (size_t)b * Cin + ci0 + ci;
-        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-        const float* src = in + row * Lin + p0 * 6;
-        const int valid = Lin - p0 * 6;
+        for (int q = 0; q < ND; ++q) rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdc, vo, (w + 4 * q) * (int)sc * 4, 0));
+        fp0 = p0;
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int o = (tid & 15) + 16 * q;
-            float v = (src[min(o, valid - 1)] - mean) * rstd;       // clamped address keeps the 25 loads branch-free and in flight together
-            v = v >= 0.f ? v : 0.3f * v;
-            ra[q] = o < valid ? v : 0.f;
+        for (int cl = 0; cl < 4; ++cl) {
+            const size_t row = (size_t)b * Cin + ci0 + 4 * w + cl;
+            const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+            fr[cl] = rstd; fn[cl] = -mean * rstd;
+            const auto rin = uniform_rsrc(in + row * Lin + p0 * 6, (Lin - p0 * 6) * 4);    // past the sample's end: reads 0
+#pragma unroll
+            for (int pc = 0; pc < 7; ++pc) ra[cl * 7 + pc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, lane * 4 + 256 * pc, 0, 0));
         }
     };
-    if (ntot > 0) fetch(0);
-    for (int t = 0; t < ntot; ++t) {
+    if (t0 < t1) fetch(t0);
+    for (int t = t0; t < t1; ++t) {
         __syncthreads();
+        if (!(LS_WG_ABL & 1) || t == t0) {
+            const bool inside = fp0 + lane < Lout;
 #pragma unroll
-        for (int q = 0; q < ND; ++q) {
-            const int idx = tid + 256 * q;
-            dcs[(idx >> 6) * kWgDld + (idx & 63)] = rd[q];
-        }
+            for (int q = 0; q < ND; ++q)
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(dcs) + ((dwo ^ ((q & 3) << 6)) + q * 4 * kWgPT * 4)) = inside ? rd[q] : 0.f;
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int o = (tid & 15) + 16 * q;
-            if (o < kWgWin) acts[(tid >> 4) * kWgWinP + o] = ra[q];
+            for (int cl = 0; cl < 4; ++cl) {
+                char* ab = reinterpret_cast<char*>(acts) + cl * kWgCS * 4;
+#pragma unroll
+                for (int pc = 0; pc < 7; ++pc) {
+                    float v = fmaf(ra[cl * 7 + pc], fr[cl], fn[cl]);     // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
+                    v = fmaxf(v, 0.3f * v);
+                    *reinterpret_cast<float*>(ab + (wad[pc] & 0xffffu)) = v;
+                    *reinterpret_cast<float*>(ab + (wad[pc] >> 16)) = v;
+                }
+            }
         }
         __syncthreads();
-        if (t + 1 < ntot) fetch(t + 1);
-#pragma unroll 4
-        for (int m = 0; m < kWgPT / 4; ++m) {
-            float A[4], Bv[4];
+        const int mcnt = (min(kWgPT, Lout - (t % ntl) * kWgPT) + 3) >> 2;            // steps that hold data (uniform), >= 1
+        if (t + 1 < t1 && !(LS_WG_ABL & 8)) fetch(t + 1);
+        __builtin_amdgcn_sched_barrier(0);                           // the loads are issued before the first MFMA, not sunk next to their use
+        const char* ab = reinterpret_cast<const char*>(dcs);
+        const char* bb = reinterpret_cast<const char*>(acts);
+        // groups of four steps; not unrolled: with all 16 steps in one block the scheduler hoists every operand read to the top and
+        // spills the staging registers (scratch reloads then queue behind the 44 loads in flight)
+#pragma unroll 1
+        for (int M = 0; M < ((LS_WG_ABL & 2) ? 0 : (mcnt >> 2)); ++M) {
+            f4 A[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) A[i] = dcs[abase + 16 * i * kWgDld + 4 * m];
+            for (int i = 0; i < 4; ++i) A[i] = *reinterpret_cast<const f4*>(ab + ((aoff ^ (M << 6)) + i * 16 * kWgPT * 4));
+            f4 Bv = *reinterpret_cast<const f4*>(bb + (boff[0] ^ (M << 4)));
 #pragma unroll
-            for (int c = 0; c < 4; ++c) Bv[c] = acts[bbase[c] + 24 * m];
+            for (int c = 0; c < 4; ++c) {
+                f4 Bn = Bv;
+                if (c < 3) Bn = *reinterpret_cast<const f4*>(bb + (boff[c + 1] ^ (M << 4)));    // one column tile ahead of the MFMAs that use it
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[i][c] = MFMA(A[i], Bv[c], acc[i][c]);
+                    for (int i = 0; i < 4; ++i) acc[i][c] = MFMA(A[i][e], Bv[e], acc[i][c]);
+                Bv = Bn;
+            }
+        }
+        if ((mcnt & 3) && !(LS_WG_ABL & 2)) {                        // the tile's last, partly filled group (uniform)
+            const int M = mcnt >> 2, ne = mcnt & 3;
+            f4 A[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[i] = *reinterpret_cast<const f4*>(ab + ((aoff ^ (M << 6)) + i * 16 * kWgPT * 4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f4 Bv = *reinterpret_cast<const f4*>(bb + (boff[c] ^ (M << 4)));
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    if (e >= ne) break;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][c] = MFMA(A[i][e], Bv[e], acc[i][c]);
+                }
+            }
         }
     }
     // lane (column s16 of tile, g) holds output channels co0 + 16 i + 4 g + e
     float* pz = partial + (size_t)blockIdx.z * Cout * W;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (c >= ntile) continue;
+        if (16 * (w + 4 * c) >= 240) continue;
         const int J = ci0 * 15 + 16 * (w + 4 * c) + s16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -610,12 +681,21 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ dc
     }
 }
 
-hipError_t launch_conv_wgrad(const float* dc, const float* in, const float* stats, float* partial, int B, int Cin, int Cout, int Lin, int Lout,
-                             int spw, int* ngroups, hipStream_t st) {
-    if (Cin % kWgCi || Cout % kWgCo || !stats || spw < 1) return hipErrorInvalidValue;
-    const int nz = (B + spw - 1) / spw;
+// dC element (b, co, p) at dc[b*sb + co*sc + p]; partial needs *ngroups * Cout * Cin * 15 floats, *ngroups <= conv_wgrad_groups()
+int conv_wgrad_groups(int Cin, int Cout) {                                     // 768 = 3 resident workgroups per CU
+    const int n = 768 / ((Cin / kWgCi) * (Cout / kWgCo));
+    return n < 1 ? 1 : n;
+}
+
+hipError_t launch_conv_wgrad(const float* dc, long long sb, long long sc, const float* in, const float* stats, float* partial, int B, int Cin,
+                             int Cout, int Lin, int Lout, int* ngroups, hipStream_t st) {
+    if (Cin % kWgCi || Cout % kWgCo || !stats || B < 1) return hipErrorInvalidValue;
+    const int ntl = (Lout + kWgPT - 1) / kWgPT, ntot = B * ntl;
+    const int tpg = (ntot + conv_wgrad_groups(Cin, Cout) - 1) / conv_wgrad_groups(Cin, Cout);
+    const int nz = (ntot + tpg - 1) / tpg;
     *ngroups = nz;
-    hipLaunchKernelGGL(k_conv_wgrad, dim3(Cin / kWgCi, Cout / kWgCo, nz), dim3(256), 0, st, dc, in, stats, partial, Cin, Cout, Lin, Lout, spw, B);
+    hipLaunchKernelGGL(k_conv_wgrad, dim3(Cin / kWgCi, Cout / kWgCo, nz), dim3(256), 0, st, dc, sb, sc, in, stats, partial, Cin, Cout, Lin, Lout,
+                       ntl, ntot, tpg);
     return hipGetLastError();
 }
 

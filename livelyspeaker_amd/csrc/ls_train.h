@@ -108,15 +108,17 @@ hipError_t launch_scatter_rows(const float* src, long long src_stride, const int
                                hipStream_t st);
 hipError_t launch_scale_rows(float* x, const float* drop, int B, int per_sample, hipStream_t st);
 // ---- audio encoder backward ----
-hipError_t launch_im2col(const float* in, const float* stats, float* col, int B, int Cin, int Lin, int Lout, int stride, int pad,
-                         hipStream_t st);
+// dst[b][c][r] = src[b][r][c], R <= 64, C % 64 == 0
+hipError_t launch_transpose_rc(const float* src, float* dst, int B, int R, int C, hipStream_t st);
 // conv1 weight gradient with the InstanceNorm backward of its output applied on the fly (dy + row partials from
 // launch_conv_dgrad(..., finalize = false)); partial[(b, chunk)][480]; *nchunk = chunks per sample
 hipError_t launch_conv1_wgrad(const float* dy, const float* craw, const float* stats, const float* rowpart, int nslot, const float* wav,
                               float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk, hipStream_t st);
-// implicit-GEMM weight gradient of a stride-6 conv layer (ls_conv.hip); partial[ngroups][Cout][Cin*15]
-hipError_t launch_conv_wgrad(const float* dc, const float* in, const float* stats, float* partial, int B, int Cin, int Cout, int Lin, int Lout,
-                             int spw, int* ngroups, hipStream_t st);
+// implicit-GEMM weight gradient of a stride-6 conv layer (ls_conv.hip); dC element (b, co, p) at dc[b*sb + co*sc + p];
+// partial[*ngroups][Cout][Cin*15] with *ngroups <= conv_wgrad_groups(Cin, Cout) whatever the batch
+int conv_wgrad_groups(int Cin, int Cout);
+hipError_t launch_conv_wgrad(const float* dc, long long sb, long long sc, const float* in, const float* stats, float* partial, int B,
+                             int Cin, int Cout, int Lin, int Lout, int* ngroups, hipStream_t st);
 // implicit-GEMM data gradient + LeakyReLU' + InstanceNorm backward of a stride-6 conv layer (ls_conv.hip)
 hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
 // finalize = false leaves dy in dc_out and the per-row partial sums in partial[row][*nslot][2] for a fused consumer

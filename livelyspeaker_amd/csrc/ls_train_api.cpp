@@ -71,7 +71,7 @@ struct ls_trainer {
     Buf X1, A1, X2, A2, S1, S2, dA2, dA1, colpart, dembp;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward; X1 / X2 hold x-hat
     Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw, twchT, twwT;    // mixer weight images + the DevWeights block k_step reads
     TrainImgArgs img_args{};
-    Buf out, dout, lossp, kldp, terms, G, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, col, dc[3], ws;
+    Buf out, dout, lossp, kldp, terms, G, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, dAt, col, dc[3], ws;
     size_t ws_floats = 0;
     int B = 0;
     bool have_forward = false;
@@ -192,11 +192,12 @@ int ensure_batch(ls_trainer* h, int B) {
     HIPCHK(h, E(h->lossp, 2 * ((size_t)B * d0.JF / 256 + 2))); HIPCHK(h, E(h->kldp, B)); HIPCHK(h, E(h->terms, 8));
     HIPCHK(h, E(h->part, (size_t)kNW * 2 * kD + (size_t)B * 128 + 4096 * 512 + (size_t)B * 32 * 2 * 2 * ((L[1] + 5) / 6 / 64 + 1)));
     HIPCHK(h, E(h->pw, (size_t)d0.L * B * 4 * d0.S * d0.S)); HIPCHK(h, E(h->pb, (size_t)d0.L * B * 4 * d0.S));
-    HIPCHK(h, E(h->dAf, (size_t)B * d0.T * kAud));
-    // col: conv4's im2col [B*34][1920] and the partial-sum workspace of the implicit-GEMM weight gradients
-    size_t colmax = (size_t)B * L[4] * kCin[3] * 15;
-    for (int i = 1; i < 3; ++i) {
-        const size_t need = (size_t)((B + 1) / 2) * kCout[i] * kCin[i] * 15;
+    HIPCHK(h, E(h->dAf, (size_t)B * d0.T * kAud)); HIPCHK(h, E(h->dAt, (size_t)B * d0.T * kAud));
+    // col: the partial-sum workspace of the implicit-GEMM weight gradients (one [Cout][Cin*15] image per workgroup run; the number of
+    // runs does not grow with the batch) and of conv1's, and the InstanceNorm partials of the forward convs
+    size_t colmax = 0;
+    for (int i = 1; i < 4; ++i) {
+        const size_t need = (size_t)conv_wgrad_groups(kCin[i], kCout[i]) * kCout[i] * kCin[i] * 15;
         if (need > colmax) colmax = need;
     }
     const size_t c1need = (size_t)B * ((L[1] + 255) / 256) * 480;
@@ -403,13 +404,16 @@ static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) 
     // WavEncoder backward, last layer first.  dC4(b, co, p) = dAf[(b*T + p)][co]
     {
         const int W4 = kCin[3] * 15;
-        HIPCHK(h, launch_im2col(h->c[2].f(), h->st[2].f(), h->col.f(), B, kCin[3], L[3], L[4], 6, 0, st));
-        HIPCHK(h, wgrad(h, op_cols(h->dAf.f(), kAud, kAud, BT), op_cols(h->col.f(), W4, W4, BT), false, false, Gr(h, grad, ck(3, "weight")), W4, kAud,
-                        W4, BT));
+        // dC4(b, co, p) = dAf[(b*T + p)][co]: transposed once to [b][co][p] so that both gradients stage position-contiguous rows
+        // (rounds 1-2 read it in place: a 1 KB stride between the lanes of every load)
+        HIPCHK(h, launch_transpose_rc(h->dAf.f(), h->dAt.f(), B, T, kAud, st));
+        int ng = 0;                       // implicit GEMM like conv2 / conv3 (rounds 1-2: im2col + GEMM, 105 + 188 us at B = 512)
+        HIPCHK(h, launch_conv_wgrad(h->dAt.f(), (long long)T * kAud, T, h->c[2].f(), h->st[2].f(), h->col.f(), B, kCin[3], kCout[3], L[3], L[4], &ng, st));
+        HIPCHK(h, launch_partial_reduce(h->col.f(), ng, (long long)kCout[3] * W4, kCout[3] * W4, Gr(h, grad, ck(3, "weight")), 0, st));
         HIPCHK(h, colsum_to(h, h->dAf.f(), INT_MAX, 0, kAud, BT, kAud, Gr(h, grad, ck(3, "bias"))));
-        // data gradient: implicit GEMM + LeakyReLU' + InstanceNorm backward; dC4(b, co, p) = dAf[(b*T + p)][co]
+        // data gradient: implicit GEMM + LeakyReLU' + InstanceNorm backward
         HIPCHK(h, launch_build_dgrad_img(P(h, ck(3, "weight")), h->dimg[3].f(), kCin[3], kCout[3], st));
-        HIPCHK(h, launch_conv_dgrad(h->dAf.f(), (long long)T * kAud, 1, kAud, h->dimg[3].f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), part, B,
+        HIPCHK(h, launch_conv_dgrad(h->dAt.f(), (long long)T * kAud, T, 1, h->dimg[3].f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), part, B,
                                     kCin[3], kCout[3], L[3], L[4], true, nullptr, st));
     }
     int nslot1 = 0;
@@ -417,7 +421,8 @@ static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) 
         const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15;
         {   // weight gradient: implicit GEMM straight from the raw conv output of the layer below (no im2col)
             int ng = 0;
-            HIPCHK(h, launch_conv_wgrad(h->dc[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], C, L[i], Lo, i == 1 ? 2 : 8, &ng, st));   // 512 workgroups = 2 per CU, no tail round
+            HIPCHK(h, launch_conv_wgrad(h->dc[i].f(), (long long)C * Lo, Lo, h->c[i - 1].f(), h->st[i - 1].f(), h->col.f(), B, kCin[i], C, L[i], Lo, &ng,
+                                        st));
             HIPCHK(h, launch_partial_reduce(h->col.f(), ng, (long long)C * W, C * W, Gr(h, grad, ck(i, "weight")), 0, st));
         }
         // (bias gradients of conv1..3 stay exactly 0: a bias that feeds an InstanceNorm cannot change the output; the
@@ -543,7 +548,7 @@ void ls_train_destroy(ls_trainer* h) {
     std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo,
                              &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
                              &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
-                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->col, &h->ws};
+                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->dAt, &h->col, &h->ws};
     for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
     for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->S1, &h->S2, &h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a,

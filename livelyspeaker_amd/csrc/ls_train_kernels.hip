@@ -403,34 +403,21 @@ hipError_t launch_finish_terms(const float* loss_partial, int n_loss, const floa
 
 // ---------------------------------------------------------------------------------------------------------------
 // Audio encoder backward helpers (audio_enc.py:9-20); the stride-6 layers' gradients are implicit GEMMs in ls_conv.hip.
-// im2col (only conv4's weight gradient still uses it: 34 positions): col[(b,p)][ci*15+k] = act(in[b][ci][p*stride + k - pad]),
-// act = LeakyReLU(0.3)(InstanceNorm) of the raw previous conv output when stats != null.
-__global__ void k_im2col(const float* __restrict__ in, const float* __restrict__ stats, float* __restrict__ col, int Cin, int Lin, int Lout,
-                         int stride, int pad, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int W = Cin * 15;
-    const int j = (int)(i % W);
-    const size_t bp = i / W;
-    const int p = (int)(bp % Lout), b = (int)(bp / Lout);
-    const int ci = j / 15, k = j % 15;
-    const int x = p * stride + k - pad;
-    float v = 0.f;
-    if (x >= 0 && x < Lin) {
-        const size_t row = (size_t)b * Cin + ci;
-        v = in[row * Lin + x];
-        if (stats) {
-            v = (v - stats[row * 2]) * stats[row * 2 + 1];
-            v = v >= 0.f ? v : 0.3f * v;
-        }
-    }
-    col[i] = v;
+// dst[b][c][r] = src[b][r][c] for R <= 64 rows: conv4's output gradient arrives as [B][T][256] (rows of the feature GEMM's dA) and
+// the implicit-GEMM gradients stage [channel][position] tiles.  Workgroup = (64 channels, sample); both sides coalesced.
+__global__ __launch_bounds__(256) void k_transpose_rc(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    const float* s = src + (size_t)b * R * C;
+    for (int i = tid; i < R * 64; i += 256) tile[i >> 6][i & 63] = s[(size_t)(i >> 6) * C + c0 + (i & 63)];
+    __syncthreads();
+    float* d = dst + ((size_t)b * C + c0) * R;                    // 64 channel rows of R floats: one contiguous block
+    for (int o = tid; o < R * 64; o += 256) d[o] = tile[o % R][o / R];
 }
 
-hipError_t launch_im2col(const float* in, const float* stats, float* col, int B, int Cin, int Lin, int Lout, int stride, int pad,
-                         hipStream_t st) {
-    const size_t total = (size_t)B * Lout * Cin * 15;
-    hipLaunchKernelGGL(k_im2col, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, stats, col, Cin, Lin, Lout, stride, pad, total);
+hipError_t launch_transpose_rc(const float* src, float* dst, int B, int R, int C, hipStream_t st) {
+    if (R > 64 || C % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_transpose_rc, dim3(C / 64, B), dim3(256), 0, st, src, dst, R, C);
     return hipGetLastError();
 }
 
