@@ -355,11 +355,13 @@ __global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ 
 
 // stats[row] = (mean, 1/sqrt(biased var + 1e-5)) from np partial (count, mean, M2) triples per row, merged in index order
 // with the parallel-variance update (Chan, Golub, LeVeque): exact-arithmetic equivalent of the two-pass statistics.
-__global__ __launch_bounds__(256) void k_stats_merge(const float* __restrict__ spart, float* __restrict__ stats, int rows, int np) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);              // one wave per row
-    if (row >= rows) return;
-    const float* sp = spart + (size_t)row * np * 3;
+// `lpr` lanes per row (a power of two >= 4 covering np where it can): conv3's four partials per row take 4 lanes, not a whole
+// wave (round 3: 11 + 18 + 32 us of pure launch width at B = 512 before).  The merge tree depends on lpr, i.e. on np only.
+__global__ __launch_bounds__(256) void k_stats_merge(const float* __restrict__ spart, float* __restrict__ stats, int rows, int np, int lpr) {
+    const int sub = threadIdx.x & (lpr - 1);
+    const int row = (blockIdx.x * 256 + threadIdx.x) / lpr;
+    const bool live = row < rows;
+    const float* sp = spart + (size_t)(live ? row : 0) * np * 3;
     // merged in double: the mean decides the sign of every normalised activation, i.e. which LeakyReLU slope its gradient
     // gets; keeping it within 1 ulp of the exact mean makes that decision agree with a two-pass fp32 reference
     auto merge = [](double& n, double& mean, double& m2, double nb, double mb, double qb) {
@@ -372,20 +374,22 @@ __global__ __launch_bounds__(256) void k_stats_merge(const float* __restrict__ s
         }
     };
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int i = lane; i < np; i += 64) merge(n, mean, m2, (double)sp[3 * i], (double)sp[3 * i + 1], (double)sp[3 * i + 2]);
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {                                 // butterfly: every lane ends with the full merge
+    for (int i = sub; i < np; i += lpr) merge(n, mean, m2, (double)sp[3 * i], (double)sp[3 * i + 1], (double)sp[3 * i + 2]);
+    for (int o = 1; o < lpr; o <<= 1) {                                // butterfly: every lane of the row ends with the full merge
         const double nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
         merge(n, mean, m2, nb, mb, qb);
     }
-    if (lane == 0) {
+    if (live && sub == 0) {
         stats[(size_t)row * 2] = (float)mean;
         stats[(size_t)row * 2 + 1] = (float)(1.0 / sqrt(m2 / n + 1e-5));
     }
 }
 
 hipError_t launch_stats_merge(const float* spart, float* stats, int rows, int np, hipStream_t st) {
-    hipLaunchKernelGGL(k_stats_merge, dim3((rows + 3) / 4), dim3(256), 0, st, spart, stats, rows, np);
+    int lpr = 4;
+    while (lpr < np && lpr < 64) lpr <<= 1;
+    const long long threads = (long long)rows * lpr;
+    hipLaunchKernelGGL(k_stats_merge, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, spart, stats, rows, np, lpr);
     return hipGetLastError();
 }
 
