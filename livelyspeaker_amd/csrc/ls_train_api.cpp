@@ -200,7 +200,7 @@ int ensure_batch(ls_trainer* h, int B) {
         const size_t need = (size_t)conv_wgrad_groups(kCin[i], kCout[i]) * kCout[i] * kCin[i] * 15;
         if (need > colmax) colmax = need;
     }
-    const size_t c1need = (size_t)B * ((L[1] + 255) / 256) * 480;
+    const size_t c1need = (size_t)B * ((L[1] + 255) / 256) * 480 + (size_t)B * 128;      // conv1's chunk partials + row coefficients
     if (c1need > colmax) colmax = c1need;
     for (int i = 0; i < 3; ++i) {       // InstanceNorm partials of the forward convs
         const size_t need = (size_t)B * kCout[i] * ((L[i + 1] + 63) / 64) * 4 * 3;

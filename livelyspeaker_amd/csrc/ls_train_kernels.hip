@@ -421,67 +421,119 @@ hipError_t launch_transpose_rc(const float* src, float* dst, int B, int R, int C
     return hipGetLastError();
 }
 
-// conv1 (Cin = 1, k 15, stride 5, pad 1600) weight gradient without an im2col: workgroup = (256-position chunk, sample),
-// thread (co, k) accumulates sum_p dC1[b][co][p] * wav[b][5p + k - 1600] from LDS; partial[(b, chunk)][co*15 + k].
-// dC1 is never materialised: k_conv_dgrad left dy = dAct * lrelu'(y) and per-row partial sums of dy and dy*y, and the
-// InstanceNorm backward d c1 = rstd * (dy - mean(dy) - y * mean(dy*y)) is applied here while the tile is staged
-// (saves one read-modify-write pass over the 517 MB tensor).
-constexpr int kC1P = 256, kC1Ld = kC1P + 4;
-__global__ __launch_bounds__(512) void k_conv1_wgrad(const float* __restrict__ dy, const float* __restrict__ craw, const float* __restrict__ stats,
-                                                     const float* __restrict__ rowpart, int nslot, const float* __restrict__ wav,
-                                                     float* __restrict__ partial, int Lin, int Lout, int stride, int pad) {
+// conv1 (Cin = 1, k 15, stride 5, pad 1600) weight gradient: dW1[co][k] = sum_{b,p} dC1[b][co][p] * wav[b][5p + k - 1600].
+// dC1 is never materialised: k_conv_dgrad left dy = dAct * lrelu'(y) and per-row partial sums of dy and dy*y, and the InstanceNorm
+// backward d c1 = rstd * (dy - mean(dy) - y * mean(dy*y)), y = (c_raw - mean) * rstd, is two FMAs per element here:
+// d c1 = a dy + b c_raw + c with per-row a = rstd, b = -rstd^2 mean(dy*y), c = -rstd mean(dy) - b mean (saves a read-modify-write
+// pass over the 517 MB tensor).
+// Round 3: the products run on the matrix pipe (rounds 1-2: 480 threads x 256 FMAs with one ds_read_b32 each behind the staging:
+// 361 us at B = 512 for two 517 MB streams).  Workgroup = (256-position chunk, sample): every wave instruction of the staging reads
+// 256 contiguous bytes of one channel row, the d c1 tile [32][256] and the chunk's waveform window go to LDS; then MFMA M axis = 16
+// channels, N axis = the 15 taps (+ one dead column), K = 4 positions: a lane's A values are one ds_read_b128 per four steps (step e
+// of group M multiplies positions 16M + 4g + e), the B values lane base + immediates in the window.  A workgroup walks four chunks
+// with the next one's 70 loads per thread in flight behind the current one's MFMAs.
+// partial[(b, chunk)][co*15 + k]; a following k_partial_reduce sums them in index order.
+constexpr int kC1P = 256, kC1Ld = kC1P + 4, kC1Win = kC1P * 5 + 16;
+
+// coef[row] = (a, b, c) of d c1 = a dy + b c_raw + c from the row's statistics and its partial sums of dy and dy*y (fixed order)
+__global__ __launch_bounds__(256) void k_in_bwd_coef(const float* __restrict__ stats, const float* __restrict__ rowpart, int nslot, int rows, int L,
+                                                     float* __restrict__ coef) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float sa = 0.f, sc2 = 0.f;
+    for (int i = 0; i < nslot; ++i) {
+        sa += rowpart[((size_t)row * nslot + i) * 2];
+        sc2 += rowpart[((size_t)row * nslot + i) * 2 + 1];
+    }
+    const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
+    const float m1 = sa / (float)L, m2 = sc2 / (float)L;
+    const float bb = -rstd * rstd * m2;
+    coef[(size_t)row * 4] = rstd;
+    coef[(size_t)row * 4 + 1] = bb;
+    coef[(size_t)row * 4 + 2] = -rstd * m1 - bb * mean;
+    coef[(size_t)row * 4 + 3] = 0.f;
+}
+
+constexpr int kC1Run = 4;                               // chunks per workgroup: one accumulator set, one partial, the next chunk's loads in flight
+__global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ dy, const float* __restrict__ craw, const float* __restrict__ coef,
+                                                     const float* __restrict__ wav, float* __restrict__ partial, int Lin, int Lout, int pad) {
     __shared__ __attribute__((aligned(16))) float dcs[32 * kC1Ld];
-    __shared__ float wavs[kC1P * 5 + 16];
-    __shared__ float rowc[32][4];                        // mean, rstd, mean(dy), mean(dy*y) of the 32 (b, co) rows
-    const int b = blockIdx.y, p0 = blockIdx.x * kC1P, tid = threadIdx.x;
-    if (tid < 32) {
-        const size_t row = (size_t)b * 32 + tid;
-        float a = 0.f, c2 = 0.f;
-        for (int i = 0; i < nslot; ++i) {                // fixed order
-            a += rowpart[(row * nslot + i) * 2];
-            c2 += rowpart[(row * nslot + i) * 2 + 1];
+    __shared__ float wavs[kC1Win];
+    __shared__ float rowc[32][4];                        // a, b, c of the 32 (b, co) rows
+    __shared__ float red[4][32][16];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.x * kC1Run, c1 = min(c0 + kC1Run, (Lout + kC1P - 1) / kC1P);
+    // a chunk's values: position p0 + tid of every channel (clamped: branch-free, all in flight together) and 5 window values
+    float vd[32], vc[32], vw[6];
+    const float* wb = wav + (size_t)b * Lin;
+    auto fetch = [&](int c) {
+        const int p0 = c * kC1P;
+        const size_t o = (size_t)b * 32 * Lout + min(p0 + tid, Lout - 1);
+#pragma unroll
+        for (int ch = 0; ch < 32; ++ch) { vd[ch] = dy[o + (size_t)ch * Lout]; vc[ch] = craw[o + (size_t)ch * Lout]; }
+        const int x0 = p0 * 5 - pad;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int x = x0 + tid + 256 * q;
+            const float v = wb[min(max(x, 0), Lin - 1)];
+            vw[q] = (x >= 0 && x < Lin) ? v : 0.f;
         }
-        rowc[tid][0] = stats[row * 2];
-        rowc[tid][1] = stats[row * 2 + 1];
-        rowc[tid][2] = a / (float)Lout;
-        rowc[tid][3] = c2 / (float)Lout;
-    }
-    const int x0 = p0 * stride - pad;
-    for (int i = tid; i < kC1P * 5 + 16; i += 512) {
-        const int x = x0 + i;
-        const float v = wav[(size_t)b * Lin + min(max(x, 0), Lin - 1)];
-        wavs[i] = (x >= 0 && x < Lin) ? v : 0.f;
-    }
-    __syncthreads();
-    for (int i = tid; i < 32 * kC1P; i += 512) {
-        const int co = i / kC1P, p = i % kC1P;
-        const size_t o = ((size_t)b * 32 + co) * Lout + min(p0 + p, Lout - 1);
-        const float y = (craw[o] - rowc[co][0]) * rowc[co][1];
-        const float v = rowc[co][1] * (dy[o] - rowc[co][2] - y * rowc[co][3]);
-        dcs[co * kC1Ld + p] = p0 + p < Lout ? v : 0.f;
-    }
-    __syncthreads();
-    if (tid < 480) {
-        const int co = tid / 15, k = tid % 15;
-        const float* dr = dcs + co * kC1Ld;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int p = 0; p < kC1P; p += 4) {
-            const f4 d = *reinterpret_cast<const f4*>(dr + p);
-            a0 = fmaf(d[0], wavs[5 * p + k], a0);
-            a1 = fmaf(d[1], wavs[5 * p + 5 + k], a1);
-            a2 = fmaf(d[2], wavs[5 * p + 10 + k], a2);
-            a3 = fmaf(d[3], wavs[5 * p + 15 + k], a3);
+    };
+    if (tid < 128) rowc[tid >> 2][tid & 3] = coef[(size_t)b * 128 + tid];
+    fetch(c0);
+    f4 acc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+    const float* bw = wavs + 5 * (64 * w + 4 * g) + s16;  // + 80 M + 5 e
+    const float* aw = dcs + s16 * kC1Ld + 64 * w + 4 * g; // + 16 mt rows, + 16 M
+    for (int c = c0; c < c1; ++c) {
+        __syncthreads();                                 // the previous chunk's MFMAs have read dcs / wavs (first pass: rowc is written)
+        {
+            const bool inside = c * kC1P + tid < Lout;
+#pragma unroll
+            for (int ch = 0; ch < 32; ++ch) {
+                const float v = fmaf(rowc[ch][0], vd[ch], fmaf(rowc[ch][1], vc[ch], rowc[ch][2]));
+                dcs[ch * kC1Ld + tid] = inside ? v : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if (tid + 256 * q < kC1Win) wavs[tid + 256 * q] = vw[q];
         }
-        partial[((size_t)b * gridDim.x + blockIdx.x) * 480 + tid] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (c + 1 < c1) fetch(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int M = 0; M < 4; ++M) {
+            const f4 A0 = *reinterpret_cast<const f4*>(aw + 16 * M), A1 = *reinterpret_cast<const f4*>(aw + 16 * kC1Ld + 16 * M);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float Bv = bw[80 * M + 5 * e];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[e], Bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[e], Bv, acc[1], 0, 0, 0);
+            }
+        }
+    }
+    // lane (k = s16, g) holds channels 16 mt + 4 g + e; the four waves' sums are combined in wave order
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[w][16 * mt + 4 * g + e][s16] = acc[mt][e];
+    __syncthreads();
+    for (int i = tid; i < 480; i += 256) {
+        const int co = i / 15, k = i - 15 * co;
+        partial[((size_t)b * gridDim.x + blockIdx.x) * 480 + i] = ((red[0][co][k] + red[1][co][k]) + red[2][co][k]) + red[3][co][k];
     }
 }
 
 hipError_t launch_conv1_wgrad(const float* dy, const float* craw, const float* stats, const float* rowpart, int nslot, const float* wav,
                               float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk, hipStream_t st) {
     if (stride != 5) return hipErrorInvalidValue;
-    const int nc = (Lout + kC1P - 1) / kC1P;
+    const int nc = ((Lout + kC1P - 1) / kC1P + kC1Run - 1) / kC1Run;      // workgroup runs per sample
     *nchunk = nc;
-    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nc, B), dim3(512), 0, st, dy, craw, stats, rowpart, nslot, wav, partial, Lin, Lout, stride, pad);
+    // the per-row coefficients once (rounds 1-2 and this round's first form: every one of the 31 chunk workgroups of a sample summed
+    // the 42 partials of its 32 rows again, serially, before its first barrier -- 190 of 496 us)
+    float* coef = partial + (size_t)B * nc * 480;
+    hipLaunchKernelGGL(k_in_bwd_coef, dim3((B * 32 + 255) / 256), dim3(256), 0, st, stats, rowpart, nslot, B * 32, Lout, coef);
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nc, B), dim3(256), 0, st, dy, craw, coef, wav, partial, Lin, Lout, pad);
     return hipGetLastError();
 }
 

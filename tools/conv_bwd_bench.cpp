@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
             // conv1's weight gradient consumes conv2's dgrad output (dy + row partials) and the raw conv1 output (here: din)
             const int lw = (li - 1) * 5 + 15 - 3200;
             float *dwav, *dp1, *dg1;
-            hipMalloc(&dwav, (size_t)B * lw * 4); hipMalloc(&dp1, (size_t)B * ((li + 255) / 256) * 480 * 4); hipMalloc(&dg1, 480 * 4);
+            hipMalloc(&dwav, (size_t)B * lw * 4); hipMalloc(&dp1, ((size_t)B * ((li + 255) / 256) * 480 + (size_t)B * 128) * 4); hipMalloc(&dg1, 480 * 4);
             hipMemset(dwav, 0, (size_t)B * lw * 4);
             int nchunk = 0;
             us = time_us(st, [&]() {
