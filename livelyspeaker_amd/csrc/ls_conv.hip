@@ -445,10 +445,19 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ wav
     __shared__ float sw[kC1fWin + 1];
     const int b = blockIdx.y, p0 = blockIdx.x * kC1fP, tid = threadIdx.x;
     const int x0 = p0 * 5 - pad;
-    for (int i = tid; i < kC1fWin; i += 256) {
-        const int x = x0 + i;
-        const float v = wav[(size_t)b * Lin + min(max(x, 0), Lin - 1)];
-        sw[i] = (x >= 0 && x < Lin) ? v : 0.f;
+    {   // all 21 loads of the thread first, then the LDS writes (as a rolled loop every load waited for the one before it: 21 memory
+        // latencies in a row in front of each workgroup's first FMA)
+        constexpr int NW = (kC1fWin + 255) / 256;
+        float wv_[NW];
+        const float* wb = wav + (size_t)b * Lin;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int x = x0 + tid + 256 * q;
+            const float v = wb[min(max(x, 0), Lin - 1)];
+            wv_[q] = (x >= 0 && x < Lin) ? v : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NW; ++q) if (tid + 256 * q < kC1fWin) sw[tid + 256 * q] = wv_[q];
     }
     __syncthreads();
     // thread tid owns positions p0 + tid + 256 q: every store instruction of a wave covers 64 consecutive positions

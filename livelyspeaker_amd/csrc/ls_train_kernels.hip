@@ -383,10 +383,15 @@ hipError_t launch_loss(const float* out, const float* x_start, float* dout, floa
 // terms = {rot_mse, vel_mse, kld, loss = rot + lambda_vel*vel, total = loss + kld_weight*kld}  (train_loop.py:178)
 __global__ void k_finish_terms(const float* __restrict__ lp, int n_loss, const float* __restrict__ kp, int n_kld, float* __restrict__ terms,
                                TrainDims d, float lambda_vel, float kld_weight) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    // one wave: lane l adds entries l, l + 64, ... in index order, then a fixed butterfly (a lone thread walking all 566 entries took
+    // 31 us of dependent loads)
+    const int l = threadIdx.x;
     double r = 0.0, v = 0.0, k = 0.0;
-    for (int i = 0; i < n_loss; ++i) { r += lp[2 * i]; v += lp[2 * i + 1]; }
-    for (int i = 0; i < n_kld; ++i) k += kp[i];
+    for (int i = l; i < n_loss; i += 64) { r += lp[2 * i]; v += lp[2 * i + 1]; }
+    for (int i = l; i < n_kld; i += 64) k += kp[i];
+    for (int o = 32; o >= 1; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); k += __shfl_xor(k, o); }
+    if (l != 0) return;
     const float rot = (float)(r * 0.1 / ((double)d.B * d.JF * d.T));
     const float vel = (float)(v * 0.1 / ((double)d.B * d.JF * (d.T - 1)));
     const float kld = (float)(-0.5 * k / ((double)d.B * kDm));
