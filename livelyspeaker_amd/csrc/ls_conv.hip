@@ -256,28 +256,40 @@ __global__ __launch_bounds__(512, LS_CONV_WGS) void k_conv1d_mfma(const float* _
 // the 34 positions fill 34 of the 64 columns of the tile above (conv4 ran at 0.36 of the MFMA peak, its matrix pipe as busy as
 // conv3's for 63 % of the FLOPs -- profiles/r02a).  Here the N axis enumerates (sample, position) pairs of NS samples: NS = 4 gives
 // 136 columns = 8.5 tiles of 16 -> 9 tiles, 94 % useful.  A lane's activation address is per-lane data anyway (base + compile-time
-// tap / channel offsets), so columns that straddle two samples cost nothing.  Same producer / consumer split, same weight image.
+// tap offsets), so columns that straddle two samples cost nothing.  Same producer / consumer split, same weight image.
+// Round 3: the window is stored channel-minor, [sample][x][slot 4 g + cig <- channel 4 cig + g] with 20 floats per x, so the four
+// MFMA steps of one (tap, column tile) -- channels g, 4 + g, 8 + g, 12 + g at the same x -- are ONE ds_read_b128 (rounds 1-2: one
+// ds_read_b32 per MFMA in a [channel][x] window, 0.56 of the matrix peak); 20 = 5 x 16 bytes per x puts the 16 columns of a tile
+// (x = 6 p + tap) on 16 different bank quads: the four 16-lane groups of the b128 read are conflict-free.  Measured: no faster
+// (185 -> 183 us in the training step; tools/conv_bench.cpp ablations: consumers alone 151 us = 0.72 of the peak, the producers'
+// ~400 instructions per wave and chunk on the same SIMDs cost the other 38) -- kept for the quarter of the LDS traffic.
+#ifndef LS_CS_ABL
+#define LS_CS_ABL 0                      // timing-only: 1 producers stage the first chunk only, 2 no weight loads after the prologue
+#endif
+constexpr int kCsXS = 20;                                      // floats per window position: 16 channels + 4 (bank spread)
 template <int NS, int NPT>
 __global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ in, const float* __restrict__ stats,
                                                          const float* __restrict__ wimg, const float* __restrict__ bias,
-                                                         float* __restrict__ out, int Cin, int Cout, int Lin, int Lout, int B, int winp) {
-    extern __shared__ float sIn[];                             // [2][NS][16][winp]
+                                                         float* __restrict__ out, int Cin, int Cout, int Lin, int Lout, int B, int wn) {
+    extern __shared__ __attribute__((aligned(16))) float sIn[];    // [2][NS][wn][20]
     const int b0 = blockIdx.z * NS, co0 = blockIdx.y * kCvTC;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = Cin / kCvCI;
-    const int wn = (Lout - 1) * kCvS + kCvK;                   // input samples a row of the window holds (<= Lin)
-    const int bufsz = NS * kCvCI * winp;
+    const int bufsz = NS * wn * kCsXS;                         // wn = input samples a row of the window holds (<= Lin)
     if (w >= 4) {
         // ---------------- producers: 16 threads per row, 16 rows per pass, NS passes per chunk
         const int pt = tid - 256;
         constexpr int NQ = 15;                                 // 16-wide groups of a window row: wn <= 35 * 6 + 15 = 225
+        // producer wave v stages channels v, 4 + v, 8 + v, 12 + v: their slots 4 v .. 4 v + 3 are consecutive, so a wave's stores (16 x of
+        // 4 channels) spread over all 32 banks (channels 4 v .. 4 v + 3 would put its 64 lanes on 8)
+        const int ci = 4 * ((pt >> 4) & 3) + (pt >> 6), slot = 4 * (ci & 3) + (ci >> 2);  // channel 4 cig + g -> slot 4 g + cig
         auto stage = [&](int c, float* dst) {
             float vals[NS][NQ], vm[NS], vr[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {                     // every load of the chunk first (clamped addresses: branch-free, in flight together)
                 const int b = min(b0 + s, B - 1);                               // past the batch: staged but never stored
-                const size_t row = (size_t)b * Cin + c * kCvCI + (pt >> 4);
+                const size_t row = (size_t)b * Cin + c * kCvCI + ci;
                 vm[s] = stats[row * 2]; vr[s] = stats[row * 2 + 1];             // InstanceNorm1d + LeakyReLU(0.3), audio_enc.py:10-11
                 const float* src = in + row * Lin;
 #pragma unroll
@@ -285,20 +297,19 @@ __global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ 
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                float* d = dst + (s * kCvCI + (pt >> 4)) * winp;
+                float* d = dst + (s * wn + (pt & 15)) * kCsXS + slot;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int o = (pt & 15) + 16 * q;
                     float v = (vals[s][q] - vm[s]) * vr[s];
-                    v = v >= 0.f ? v : 0.3f * v;
-                    if (o < wn) d[o] = v;
+                    v = fmaxf(v, 0.3f * v);
+                    if ((pt & 15) + 16 * q < wn) d[16 * q * kCsXS] = v;
                 }
             }
         };
         stage(0, sIn);
         __syncthreads();
         for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nchunk) stage(c + 1, sIn + ((c + 1) & 1) * bufsz);
+            if (c + 1 < nchunk && !(LS_CS_ABL & 1)) stage(c + 1, sIn + ((c + 1) & 1) * bufsz);
             __syncthreads();
         }
         return;
@@ -306,13 +317,13 @@ __global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ 
     // ---------------- consumers: wave w = channel tile w x all NPT column tiles
     const int s16 = lane & 15, g = lane >> 4;
     f4 acc[NPT];
-    int lb[NPT];                                               // lane's window base per column tile
+    int lb[NPT];                                               // lane's window base per column tile (floats)
 #pragma unroll
     for (int t = 0; t < NPT; ++t) {
         acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
         const int j = min(16 * t + s16, NS * Lout - 1);
         const int s = j / Lout, p = j - s * Lout;
-        lb[t] = (s * kCvCI + g) * winp + p * kCvS;
+        lb[t] = (s * wn + p * kCvS) * kCsXS + 4 * g;
     }
     const f4 bv = *reinterpret_cast<const f4*>(bias + co0 + 16 * w + 4 * g);
     __syncthreads();
@@ -327,18 +338,23 @@ __global__ __launch_bounds__(512) void k_conv1d_short(const float* __restrict__ 
         const float* sb = sIn + (c & 1) * bufsz;
         const int wp = wbase + c * kCvK * 1024;
         const int wpn = wbase + ((c + 1 < nchunk) ? c + 1 : 0) * kCvK * 1024;
+        f4 Bv[2][NPT];                                         // the operands of tap k + 1 are read before tap k's 36 MFMAs
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) Bv[0][t] = *reinterpret_cast<const f4*>(sb + lb[t]);
 #pragma unroll
         for (int k = 0; k < kCvK; ++k) {
             const f4 A = ring[k % kWRing];
-            ring[(k + kWPre) % kWRing] = wld((k + kWPre < kCvK) ? wp + (k + kWPre) * 1024 : wpn + (k + kWPre - kCvK) * 1024);
+            if (!(LS_CS_ABL & 2)) ring[(k + kWPre) % kWRing] = wld((k + kWPre < kCvK) ? wp + (k + kWPre) * 1024 : wpn + (k + kWPre - kCvK) * 1024);
+            if (k + 1 < kCvK) {
 #pragma unroll
-            for (int cig = 0; cig < 4; ++cig) {
-#pragma unroll
-                for (int t = 0; t < NPT; ++t) {
-                    const float Bv = sb[lb[t] + (4 * cig) * winp + k];
-                    acc[t] = MFMA(A[cig], Bv, acc[t]);
-                }
+                for (int t = 0; t < NPT; ++t) Bv[(k + 1) & 1][t] = *reinterpret_cast<const f4*>(sb + lb[t] + (k + 1) * kCsXS);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cig = 0; cig < 4; ++cig)
+#pragma unroll
+                for (int t = 0; t < NPT; ++t) acc[t] = MFMA(A[cig], Bv[k & 1][t][cig], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -401,8 +417,8 @@ hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* 
     if (!out_stats && Lout <= 36 && (Lout - 1) * kCvS + kCvK <= Lin) {
         // short output without statistics (conv4: 34 positions): columns = (sample, position) pairs of 4 samples, 9 tiles
         constexpr int NS = 4, NPT = 9;
-        const int winp = ((Lout - 1) * kCvS + kCvK) | 1;                  // odd row stride: the 4 lane groups (channels) hit different banks
-        const size_t lds = (size_t)2 * NS * kCvCI * winp * sizeof(float);
+        const int wn = (Lout - 1) * kCvS + kCvK;                          // window positions per sample
+        const size_t lds = (size_t)2 * NS * wn * kCsXS * sizeof(float);
         static bool attr_set = false;                                     // > 64 KiB of dynamic LDS needs the opt-in, once per process
         if (!attr_set) {
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1d_short<NS, NPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -411,7 +427,7 @@ hipError_t launch_conv1d_mfma(const float* in, const float* stats, const float* 
         }
         if (NS * Lout <= 16 * NPT && lds <= 160 * 1024) {
             hipLaunchKernelGGL((k_conv1d_short<NS, NPT>), dim3(1, Cout / kCvTC, (B + NS - 1) / NS), dim3(512), lds, st, in, stats, wimg, bias, out,
-                               Cin, Cout, Lin, Lout, B, winp);
+                               Cin, Cout, Lin, Lout, B, wn);
             return hipGetLastError();
         }
     }
