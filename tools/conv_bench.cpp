@@ -21,6 +21,25 @@ int main(int argc, char** argv) {
     const int Cin[3] = {32, 64, 128}, Cout[3] = {64, 128, 256}, Lin[3] = {7891, 1313, 217}, Lout[3] = {1313, 217, 34};
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    {   // conv1 (1 -> 32 channels, k 15, stride 5, padding 1600) + the InstanceNorm statistics of its output: bound by the 517 MB it writes
+        const int lin = 36267, lout = 7891;
+        float *dw, *dwt, *db, *dout, *dos, *dsp;
+        hipMalloc(&dw, (size_t)B * lin * 4); hipMalloc(&dwt, 480 * 4); hipMalloc(&db, 32 * 4); hipMalloc(&dout, (size_t)B * 32 * lout * 4);
+        hipMalloc(&dos, (size_t)B * 32 * 2 * 4); hipMalloc(&dsp, (size_t)B * 32 * 8 * 4 * 3 * 4);
+        hipMemset(dw, 0, (size_t)B * lin * 4); hipMemset(dwt, 0, 480 * 4); hipMemset(db, 0, 32 * 4);
+        for (int with = 1; with >= 0; --with) {
+            auto run = [&]() { return ls::launch_conv1_fwd(dw, dwt, db, dout, with ? dos : nullptr, dsp, B, lin, lout, 1600, st); };
+            for (int i = 0; i < 600; ++i) run();
+            hipEventRecord(e0, st);
+            for (int i = 0; i < 20; ++i) run();
+            hipEventRecord(e1, st); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double us = ms * 1000.0 / 20;
+            std::printf("conv1 B=%d L %d->%d %s: %.1f us = %.2f TB/s written\n", B, lin, lout, with ? "with its output statistics" : "without statistics", us,
+                        (double)B * 32 * lout * 4 / us * 1e-6);
+        }
+        hipFree(dw); hipFree(dwt); hipFree(db); hipFree(dout); hipFree(dos); hipFree(dsp);
+    }
     for (int L = 0; L < 3; ++L) {
         const int ci = Cin[L], co = Cout[L], li = Lin[L], lo = Lout[L];
         const size_t nin = (size_t)B * ci * li, nout = (size_t)B * co * lo, nw = (size_t)co * ci * 15;
@@ -44,7 +63,9 @@ int main(int argc, char** argv) {
         hipMemcpy(dimg, img.data(), nw * 4, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), co * 4, hipMemcpyHostToDevice);
         const bool stats = L < 2;
         auto run = [&]() { return ls::launch_conv1d_mfma(din, dst, dimg, db, dout, stats ? dos : nullptr, dsp, B, ci, co, li, lo, st); };
-        for (int i = 0; i < 5; ++i) if (run() != hipSuccess) { std::printf("launch failed\n"); return 1; }
+        // (400 untimed launches: the shader clock needs a few hundred ms of load to reach its 2.4 GHz ceiling, and the host check of
+        // the previous layer lets it fall again)
+        for (int i = 0; i < 400; ++i) if (run() != hipSuccess) { std::printf("launch failed\n"); return 1; }
         const int n = 20;
         hipEventRecord(e0, st);
         for (int i = 0; i < n; ++i) run();

@@ -17,7 +17,9 @@ static float frand(size_t i, unsigned m) { return (float)(((i * m + 12345u) >> 7
 template <class F>
 static double time_us(hipStream_t st, F&& run, int n = 10) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) run();
+    // the shader clock needs a few hundred ms of load to reach its ceiling (rocm-smi: 109 MHz idle, 2.4 GHz under bench.py); a timing
+    // that starts cold reads up to 20 % long
+    for (int i = 0; i < 300; ++i) run();              // (every call: the host checks between two timings let the clock fall again)
     hipEventRecord(e0, st);
     for (int i = 0; i < n; ++i) run();
     hipEventRecord(e1, st);
