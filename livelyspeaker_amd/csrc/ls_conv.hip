@@ -741,6 +741,9 @@ hipError_t launch_conv_wgrad(const float* dc, long long sb, long long sc, const 
 // image [ci tile][co group of 4][pair][lane] rebuilt after every optimiser step (k_build_dgrad_img).
 // Epilogue: y = InstanceNorm(c_raw), dy = dAct * lrelu'(y) is written to dc, and per-(sample, channel) partial sums of
 // dy and dy*y go to `partial`; k_in_finalize turns dy into d c_raw = rstd * (dy - mean(dy) - y * mean(dy*y)).
+#ifndef LS_DG_ABL
+#define LS_DG_ABL 0                      // timing-only (tools/conv_bwd_bench.cpp): 16 no waveform gathers, 32 two S1 products instead of 48
+#endif
 namespace ls {
 
 constexpr int kDgQT = 64, kDgDld = kDgQT + 4, kDgCo = 64;
@@ -770,9 +773,18 @@ hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout,
 }
 
 // dC element (b, co, p) at dc_in[b*sb + co*sc + p*sp]
+// FUSE1 (the layer above conv1: Cin == 32, so one workgroup holds all 32 channels of its 384 positions): dy is not written at all.
+// Its only consumer is conv1's weight gradient  dW1[c][k] = sum_{b,x} d c1[b][c][x] wav[b][5x + k - pad],  d c1 = a dy + b' c_raw + c'
+// per (b, c) row (k_in_bwd_coef), i.e.  a S1 + b' S3 + c' S2  with  S1 = sum_x dy wav,  S2 = sum_x wav,  S3 = sum_x c_raw wav -- and
+// S2, S3 do not depend on the backward pass (S3 = bias S2 + w1 . R with R the 15 x 15 autocorrelation of the strided waveform,
+// k_wav_moments).  So the epilogue writes dy back into its LDS tile and multiplies it with the waveform on the matrix pipe
+// (M = 16 channels, N = the 15 taps, K = 4 positions; 48 MFMAs per wave on top of the main loop's 480): s1part[b][tile][x half][32][16].
+// Saves the 517 MB dy write here and conv1's weight-gradient kernel, which read dy and c_raw again (1.03 GB).
+template <bool FUSE1>
 __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc_in, long long sb, long long sc, long long sp,
                                                     const float* __restrict__ wimg, const float* __restrict__ craw, const float* __restrict__ stats,
-                                                    float* __restrict__ dc_out, float* __restrict__ partial, int Cin, int Cout, int Lx, int Lout) {
+                                                    float* __restrict__ dc_out, float* __restrict__ partial, int Cin, int Cout, int Lx, int Lout,
+                                                    const float* __restrict__ wav, int Lw, int wpad, float* __restrict__ s1part) {
     __shared__ __attribute__((aligned(16))) float smem[32 * kDgEpS > kDgCo * kDgDld ? 32 * kDgEpS : kDgCo * kDgDld];
     float* dcs = smem;                 // main loop: dC [64 co][66 q + pad]; epilogue: dAct tile [32 ci][384 x + pad]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -871,10 +883,11 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
             const float av = ep[c * kDgEpS + xl];
             const float dy = y >= 0.f ? av : 0.3f * av;
             if (xl < nx) {
-                dst[xl] = dy;
+                if (!FUSE1) dst[xl] = dy;
                 s1 += dy;
                 s2 += dy * y;
             }
+            if (FUSE1 && !(LS_DG_ABL & 64)) ep[c * kDgEpS + xl] = xl < nx ? dy : 0.f;          // dy replaces dAct in the tile (own element)
         }
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
@@ -883,6 +896,130 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
             pp[0] = s1; pp[1] = s2; pp[2] = 0.f; pp[3] = 0.f;
         }
     }
+    if (FUSE1 && !(LS_DG_ABL & 128)) {
+        // S1[c][k] over this tile: wave = (channel tile w & 1, x half w >> 1); step m multiplies x = 192 (w >> 1) + 4 m + g
+        const int mt = w & 1, kh = w >> 1;
+        float Bw[48];
+        const auto rw = uniform_rsrc(wav + (size_t)b * Lw, Lw * 4);      // past the end: the conv's zero padding (range check)
+        const int xb = x0 + 192 * kh + g;
+        const int i0 = 5 * xb + s16 - wpad;                              // + 20 m
+        if (5 * x0 >= wpad) {                                            // (uniform) no index of this tile is negative
+#pragma unroll
+            for (int m = 0; m < 48; ++m) Bw[m] = (LS_DG_ABL & 16) ? 1.f + m : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, (i0 + 20 * m) * 4, 0, 0));
+        } else {
+            // the left padding.  NOT through the range check: the compiler folds the 80 m into the instruction's immediate offset, and the
+            // hardware does not wrap a negative (= huge unsigned) register offset + immediate back into range -- elements whose own index
+            // was valid came back as 0
+#pragma unroll
+            for (int m = 0; m < 48; ++m) {
+                const int i = i0 + 20 * m;
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, max(i, 0) * 4, 0, 0));
+                Bw[m] = i >= 0 ? v : 0.f;
+            }
+        }
+        __syncthreads();                                                 // every row of the tile holds dy now
+        const float* ar = ep + (16 * mt + s16) * kDgEpS + 192 * kh + g;
+        f4 a1 = (f4){0.f, 0.f, 0.f, 0.f}, a2 = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < ((LS_DG_ABL & 32) ? 2 : 48); m += 2) {
+            a1 = MFMA(ar[4 * m], Bw[m], a1);
+            a2 = MFMA(ar[4 * m + 4], Bw[m + 1], a2);
+        }
+        a1 += a2;
+        // lane (k = s16, g) holds channels 16 mt + 4 g + e
+        float* o = s1part + ((((size_t)b * gridDim.x + blockIdx.x) * 2 + kh) * 32 + 16 * mt + 4 * g) * 16 + s16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[16 * e] = a1[e];
+    }
+}
+
+// S2[k] = sum_p wavpad[5p + k] and R[j][k] = sum_p wavpad[5p + j] wavpad[5p + k] over the Lout positions of conv1 (zero padding `pad`)
+// of every sample: mom[b][part][16][16] with R in [j][k], j, k < 15, and S2[j] in column 15, summed over the kMomParts parts by the
+// consumer.  Workgroup = (part of the positions, sample); the 15 x 16 products are ONE MFMA per four positions (the operand with the
+// ones column is both A and B); the operand comes out of a coalesced LDS copy of the workgroup's stretch of the waveform (one
+// workgroup per sample with a 64-address gather in front of every MFMA took 160 us at B = 512).
+constexpr int kMomParts = 8, kMomWin = 5200;              // window floats per workgroup: 5 * 4 * (steps per workgroup) + 15 <= kMomWin
+__global__ __launch_bounds__(256) void k_wav_moments(const float* __restrict__ wav, float* __restrict__ mom, int Lw, int Lout, int pad) {
+    __shared__ float wv[kMomWin];
+    __shared__ float red[4][16][16];
+    const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
+    const int nstep = (Lout + 3) / 4, per = (nstep + 4 * kMomParts - 1) / (4 * kMomParts);   // steps of 4 positions per wave
+    // the workgroup's stretch of the (zero-padded, Lout-limited) waveform, coalesced: positions [4 * 4 * part * per, + 16 * per)
+    const int pa = 16 * part * per, x0 = 5 * pa - pad, xend = min(5 * (Lout - 1) + 15 - pad, Lw);   // valid wav indices: [max(x0,0), xend)
+    const float* wb = wav + (size_t)b * Lw;
+    {
+        constexpr int NQ = (kMomWin + 255) / 256;                           // all loads first (a rolled loop waits for each in turn)
+        float t[NQ];
+#pragma unroll
+        for (int q = 0; q < ((LS_DG_ABL & 512) ? 1 : NQ); ++q) {
+            const int x = x0 + tid + 256 * q;
+            const float v = wb[min(max(x, 0), Lw - 1)];
+            t[q] = (x >= 0 && x < xend) ? v : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) if (tid + 256 * q < 80 * per + 16) wv[tid + 256 * q] = t[q];
+    }
+    __syncthreads();
+    // (positions >= Lout: their taps beyond the last valid position's window are zeroed above only partly -- mask them out here)
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+    const int ma = (part * 4 + w) * per;
+    const float* lw_ = wv + 20 * (w * per) + 5 * g + s16;                      // + 20 per step
+    for (int q0 = 0; q0 < ((LS_DG_ABL & 256) ? 8 : per); q0 += 8) {                                      // eight operand reads, then eight MFMAs on two accumulators
+        float v[8], one[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u, p = 4 * (ma + q) + g;
+            const bool ok = q < per && ma + q < nstep && p < Lout;
+            v[u] = ok ? lw_[20 * min(q, per - 1)] : 0.f;
+            one[u] = ok ? 1.f : 0.f;                                           // B's column 15 is all ones: R[j][15] = S2[j]
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc = MFMA(s16 == 15 ? 0.f : v[u], s16 == 15 ? one[u] : v[u], acc);
+            acc2 = MFMA(s16 == 15 ? 0.f : v[u + 1], s16 == 15 ? one[u + 1] : v[u + 1], acc2);
+        }
+    }
+    acc += acc2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[w][4 * g + e][s16] = acc[e];
+    __syncthreads();
+    const int j = tid >> 4, k = tid & 15;
+    mom[((size_t)b * kMomParts + part) * 256 + tid] = ((red[0][j][k] + red[1][j][k]) + red[2][j][k]) + red[3][j][k];
+}
+
+// out[b][c*15 + k] = a S1 + b' S3 + c' S2 (see k_conv_dgrad<FUSE1>); a following k_partial_reduce over b gives dW1
+__global__ __launch_bounds__(512) void k_conv1_wgrad_finish(const float* __restrict__ s1part, int nt2, const float* __restrict__ coef,
+                                                            const float* __restrict__ mom, const float* __restrict__ w1, const float* __restrict__ bias1,
+                                                            float* __restrict__ out) {
+    __shared__ float msum[256];
+    const int b = blockIdx.x, c = threadIdx.x >> 4, k = threadIdx.x & 15;
+    if (threadIdx.x < 256) {                                               // the sample's moments: parts summed in index order
+        const float* mb = mom + (size_t)b * kMomParts * 256 + threadIdx.x;
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < kMomParts; ++q) a += mb[q * 256];
+        msum[threadIdx.x] = a;
+    }
+    const float* sp = s1part + (size_t)b * nt2 * 512 + threadIdx.x;
+    float s1 = 0.f;
+#pragma unroll 6
+    for (int i = 0; i < nt2; ++i) s1 += sp[(size_t)i * 512];              // fixed order
+    __syncthreads();
+    if (k == 15) return;
+    const float s2 = msum[k * 16 + 15];
+    float s3 = bias1[c] * s2;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) s3 = fmaf(w1[c * 15 + j], msum[j * 16 + k], s3);
+    const float* cf = coef + ((size_t)b * 32 + c) * 4;
+    out[(size_t)b * 480 + c * 15 + k] = cf[0] * s1 + cf[1] * s3 + cf[2] * s2;
+}
+
+hipError_t launch_wav_moments(const float* wav, float* mom, int B, int Lw, int Lout, int pad, hipStream_t st) {
+    if (80 * (((Lout + 3) / 4 + 4 * kMomParts - 1) / (4 * kMomParts)) + 16 > kMomWin) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_wav_moments, dim3(kMomParts, B), dim3(256), 0, st, wav, mom, Lw, Lout, pad);
+    return hipGetLastError();
 }
 
 // one workgroup per (sample, channel) row: d c_raw = rstd * (dy - mean(dy) - y * mean(dy * y)), in place on dc
@@ -911,10 +1048,34 @@ hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, lon
     const int nq = (Lx + 5) / 6;
     dim3 grid((nq + kDgQT - 1) / kDgQT, Cin / 32, B);
     if (nslot) *nslot = (int)grid.x * 2;
-    hipLaunchKernelGGL(k_conv_dgrad, grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, dc_out, partial, Cin, Cout, Lx, Lout);
+    hipLaunchKernelGGL(k_conv_dgrad<false>, grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, dc_out, partial, Cin, Cout, Lx, Lout,
+                       (const float*)nullptr, 0, 0, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !finalize) return e;
     hipLaunchKernelGGL(k_in_finalize, dim3(B * Cin), dim3(256), 0, st, dc_out, craw, stats, partial, (int)grid.x * 2, Lx);
+    return hipGetLastError();
+}
+
+// The layer above conv1 (Cin == 32) with conv1's weight gradient folded in: no dy tensor.  rowpart [B*32][*nslot][2] as
+// launch_conv_dgrad(finalize = false) leaves it; work needs B * (2 * tiles * 512 + 128 + 480) floats; mom from launch_wav_moments;
+// out_part[B][480] is summed over B by the caller (launch_partial_reduce).
+hipError_t launch_conv_dgrad_conv1(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
+                                   const float* stats, float* rowpart, int B, int Cout, int Lx, int Lout, const float* wav, int Lw, int wpad,
+                                   const float* mom, const float* w1, const float* bias1, float* work, float** out_part, hipStream_t st) {
+    if (Cout % kDgCo) return hipErrorInvalidValue;
+    const int nq = (Lx + 5) / 6;
+    dim3 grid((nq + kDgQT - 1) / kDgQT, 1, B);
+    const int nslot = (int)grid.x * 2, nt2 = (int)grid.x * 2;
+    float* s1part = work;
+    float* coef = s1part + (size_t)B * nt2 * 512;
+    float* outp = coef + (size_t)B * 128;
+    hipLaunchKernelGGL(k_conv_dgrad<true>, grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, (float*)nullptr, rowpart, 32, Cout, Lx, Lout,
+                       wav, Lw, wpad, s1part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if ((e = launch_in_bwd_coef(stats, rowpart, nslot, B * 32, Lx, coef, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3(B), dim3(512), 0, st, s1part, nt2, coef, mom, w1, bias1, outp);
+    *out_part = outp;
     return hipGetLastError();
 }
 

@@ -125,6 +125,12 @@ hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout,
 hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
                              const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, bool finalize,
                              int* nslot, hipStream_t st);
+// conv2's data gradient with conv1's weight gradient folded into its epilogue (ls_conv.hip, k_conv_dgrad<FUSE1>): no dy tensor
+hipError_t launch_wav_moments(const float* wav, float* mom, int B, int Lw, int Lout, int pad, hipStream_t st);      // mom[B][8][16][16]
+hipError_t launch_in_bwd_coef(const float* stats, const float* rowpart, int nslot, int rows, int L, float* coef, hipStream_t st);
+hipError_t launch_conv_dgrad_conv1(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
+                                   const float* stats, float* rowpart, int B, int Cout, int Lx, int Lout, const float* wav, int Lw, int wpad,
+                                   const float* mom, const float* w1, const float* bias1, float* work, float** out_part, hipStream_t st);
 hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
 // ---- optimiser ----
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,

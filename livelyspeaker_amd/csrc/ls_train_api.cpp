@@ -71,7 +71,7 @@ struct ls_trainer {
     Buf X1, A1, X2, A2, S1, S2, dA2, dA1, colpart, dembp;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward; X1 / X2 hold x-hat
     Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw, twchT, twwT;    // mixer weight images + the DevWeights block k_step reads
     TrainImgArgs img_args{};
-    Buf out, dout, lossp, kldp, terms, G, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, dAt, col, dc[3], ws;
+    Buf out, dout, lossp, kldp, terms, G, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, dAt, col, dc[3], wmom, ws;
     size_t ws_floats = 0;
     int B = 0;
     bool have_forward = false;
@@ -180,7 +180,10 @@ int ensure_batch(ls_trainer* h, int B) {
     HIPCHK(h, h->vid.ensure((size_t)B * 8)); HIPCHK(h, h->emo.ensure((size_t)B * d0.T * 8)); HIPCHK(h, h->tidx.ensure((size_t)B * 8));
     HIPCHK(h, E(h->ca, B)); HIPCHK(h, E(h->cb, B));
     for (int i = 0; i < 4; ++i) HIPCHK(h, E(h->c[i], (size_t)B * kCout[i] * L[i + 1]));
-    for (int i = 0; i < 3; ++i) { HIPCHK(h, E(h->st[i], (size_t)B * kCout[i] * 2)); HIPCHK(h, E(h->dc[i], (size_t)B * kCout[i] * L[i + 1])); }
+    // (dc[0], the gradient of conv1's output, is never materialised: its only consumer, conv1's weight gradient, is folded into the
+    //  epilogue of conv2's data gradient -- 517 MB at B = 512)
+    for (int i = 0; i < 3; ++i) { HIPCHK(h, E(h->st[i], (size_t)B * kCout[i] * 2)); if (i) HIPCHK(h, E(h->dc[i], (size_t)B * kCout[i] * L[i + 1])); }
+    HIPCHK(h, E(h->wmom, (size_t)B * 8 * 256));
     HIPCHK(h, E(h->feat, (size_t)B * d0.T * d0.KFP));
     HIPCHK(h, E(h->zc, (size_t)B * kSpk)); HIPCHK(h, E(h->dzc, (size_t)B * kSpk));
     for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));
@@ -200,7 +203,7 @@ int ensure_batch(ls_trainer* h, int B) {
         const size_t need = (size_t)conv_wgrad_groups(kCin[i], kCout[i]) * kCout[i] * kCin[i] * 15;
         if (need > colmax) colmax = need;
     }
-    const size_t c1need = (size_t)B * ((L[1] + 255) / 256) * 480 + (size_t)B * 128;      // conv1's chunk partials + row coefficients
+    const size_t c1need = (size_t)B * (2 * (((L[1] + 5) / 6 + 63) / 64) * 512 + 128 + 480);     // conv1's S1 tile partials + row coefficients + per-sample gradients
     if (c1need > colmax) colmax = c1need;
     for (int i = 0; i < 3; ++i) {       // InstanceNorm partials of the forward convs
         const size_t need = (size_t)B * kCout[i] * ((L[i + 1] + 63) / 64) * 4 * 3;
@@ -416,7 +419,6 @@ static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) 
         HIPCHK(h, launch_conv_dgrad(h->dAt.f(), (long long)T * kAud, T, 1, h->dimg[3].f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), part, B,
                                     kCin[3], kCout[3], L[3], L[4], true, nullptr, st));
     }
-    int nslot1 = 0;
     for (int i = 2; i >= 1; --i) {      // conv3 (i=2), conv2 (i=1): dC_i = dc[i] [B][Cout_i][L_{i+1}]
         const int C = kCout[i], Lo = L[i + 1], W = kCin[i] * 15;
         {   // weight gradient: implicit GEMM straight from the raw conv output of the layer below (no im2col)
@@ -428,17 +430,19 @@ static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) 
         // (bias gradients of conv1..3 stay exactly 0: a bias that feeds an InstanceNorm cannot change the output; the
         //  reference's autograd returns rounding noise of ~1e-7 there)
         HIPCHK(h, launch_build_dgrad_img(P(h, ck(i, "weight")), h->dimg[i].f(), kCin[i], C, st));
-        // the layer-1 output gradient is consumed only by conv1's weight gradient, which applies the InstanceNorm
-        // backward itself: no finalize pass over the 517 MB tensor
-        HIPCHK(h, launch_conv_dgrad(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), part, B,
-                                    kCin[i], C, L[i], Lo, i != 1, i == 1 ? &nslot1 : nullptr, st));
-    }
-    {   // conv1: weight gradient only (its input is data); partials go to the (now free) column buffer
-        const int C = kCout[0], Lo = L[1];
-        int nchunk = 0;
-        HIPCHK(h, launch_conv1_wgrad(h->dc[0].f(), h->c[0].f(), h->st[0].f(), part, nslot1, h->audio.f(), h->col.f(), B, L[0], Lo, kStride[0], kPad[0],
-                                     &nchunk, st));
-        HIPCHK(h, launch_partial_reduce(h->col.f(), B * nchunk, C * 15, C * 15, Gr(h, grad, ck(0, "weight")), 0, st));
+        if (i == 2) {
+            HIPCHK(h, launch_conv_dgrad(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), part, B,
+                                        kCin[i], C, L[i], Lo, true, nullptr, st));
+        } else {
+            // conv2's data gradient is consumed only by conv1's weight gradient (conv1's input is data): folded into its epilogue, the
+            // gradient tensor itself is never written (k_conv_dgrad<FUSE1>); per-sample results are summed over the batch in index order
+            float* outp = nullptr;
+            // (on a side stream under the forward's first convs this latency-bound 50 us kernel cost the forward 200 us: measured, not kept)
+            HIPCHK(h, launch_wav_moments(h->audio.f(), h->wmom.f(), B, L[0], L[1], kPad[0], st));
+            HIPCHK(h, launch_conv_dgrad_conv1(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[0].f(), h->st[0].f(), part, B, C, L[1], Lo,
+                                              h->audio.f(), L[0], kPad[0], h->wmom.f(), P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->col.f(), &outp, st));
+            HIPCHK(h, launch_partial_reduce(outp, B, 480, 480, Gr(h, grad, ck(0, "weight")), 0, st));
+        }
     }
     return LS_OK;
 }
@@ -548,7 +552,7 @@ void ls_train_destroy(ls_trainer* h) {
     std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo,
                              &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
                              &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
-                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->dAt, &h->col, &h->ws};
+                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->dAt, &h->col, &h->wmom, &h->ws};
     for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
     for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->S1, &h->S2, &h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a,

@@ -427,6 +427,8 @@ hipError_t launch_transpose_rc(const float* src, float* dst, int B, int R, int C
 }
 
 // conv1 (Cin = 1, k 15, stride 5, pad 1600) weight gradient: dW1[co][k] = sum_{b,p} dC1[b][co][p] * wav[b][5p + k - 1600].
+// STAND-ALONE form: the training step folds these products into the epilogue of conv2's data gradient (k_conv_dgrad<FUSE1>,
+// ls_conv.hip) and never writes dy; this kernel is what tools/conv_bwd_bench.cpp checks that against and times beside it.
 // dC1 is never materialised: k_conv_dgrad left dy = dAct * lrelu'(y) and per-row partial sums of dy and dy*y, and the InstanceNorm
 // backward d c1 = rstd * (dy - mean(dy) - y * mean(dy*y)), y = (c_raw - mean) * rstd, is two FMAs per element here:
 // d c1 = a dy + b c_raw + c with per-row a = rstd, b = -rstd^2 mean(dy*y), c = -rstd mean(dy) - b mean (saves a read-modify-write
@@ -446,9 +448,11 @@ __global__ __launch_bounds__(256) void k_in_bwd_coef(const float* __restrict__ s
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
     float sa = 0.f, sc2 = 0.f;
-    for (int i = 0; i < nslot; ++i) {
-        sa += rowpart[((size_t)row * nslot + i) * 2];
-        sc2 += rowpart[((size_t)row * nslot + i) * 2 + 1];
+    const float2* rp = reinterpret_cast<const float2*>(rowpart) + (size_t)row * nslot;
+#pragma unroll 8
+    for (int i = 0; i < nslot; ++i) {                                      // fixed order; unrolled so that the loads are in flight together
+        const float2 v = rp[i];
+        sa += v.x; sc2 += v.y;
     }
     const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
     const float m1 = sa / (float)L, m2 = sc2 / (float)L;
@@ -529,6 +533,11 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
     }
 }
 
+hipError_t launch_in_bwd_coef(const float* stats, const float* rowpart, int nslot, int rows, int L, float* coef, hipStream_t st) {
+    hipLaunchKernelGGL(k_in_bwd_coef, dim3((rows + 255) / 256), dim3(256), 0, st, stats, rowpart, nslot, rows, L, coef);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv1_wgrad(const float* dy, const float* craw, const float* stats, const float* rowpart, int nslot, const float* wav,
                               float* partial, int B, int Lin, int Lout, int stride, int pad, int* nchunk, hipStream_t st) {
     if (stride != 5) return hipErrorInvalidValue;
@@ -537,7 +546,7 @@ hipError_t launch_conv1_wgrad(const float* dy, const float* craw, const float* s
     // the per-row coefficients once (rounds 1-2 and this round's first form: every one of the 31 chunk workgroups of a sample summed
     // the 42 partials of its 32 rows again, serially, before its first barrier -- 190 of 496 us)
     float* coef = partial + (size_t)B * nc * 480;
-    hipLaunchKernelGGL(k_in_bwd_coef, dim3((B * 32 + 255) / 256), dim3(256), 0, st, stats, rowpart, nslot, B * 32, Lout, coef);
+    launch_in_bwd_coef(stats, rowpart, nslot, B * 32, Lout, coef, st);
     hipLaunchKernelGGL(k_conv1_wgrad, dim3(nc, B), dim3(256), 0, st, dy, craw, coef, wav, partial, Lin, Lout, pad);
     return hipGetLastError();
 }

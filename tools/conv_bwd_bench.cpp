@@ -126,6 +126,54 @@ int main(int argc, char** argv) {
                 ls::launch_partial_reduce(dp1, B * nchunk, 480, 480, dg1, 0, st);
             });
             std::printf("conv1 wgrad (reads dy + c_raw: %.0f MB): %.1f us = %.2f TB/s\n", 2.0 * nin * 4 / 1e6, us, 2.0 * nin * 4 / us * 1e-6);
+            // the same two results from the fused form (what the training step runs): no dy tensor, conv1's gradient out of the epilogue
+            {
+                std::vector<float> hwav((size_t)B * lw), hw1(480), hb1(32);
+                for (size_t i = 0; i < hwav.size(); ++i) hwav[i] = frand(i, 104729u);
+                for (int i = 0; i < 480; ++i) hw1[i] = frand(i, 1299709u) * 0.3f;
+                for (int i = 0; i < 32; ++i) hb1[i] = frand(i, 15485863u) * 0.1f;
+                hipMemcpy(dwav, hwav.data(), hwav.size() * 4, hipMemcpyHostToDevice);
+                float *dw1, *db1, *dmom, *dwork, *dgf;
+                hipMalloc(&dw1, 480 * 4); hipMalloc(&db1, 32 * 4); hipMalloc(&dmom, (size_t)B * 8 * 256 * 4); hipMalloc(&dgf, 480 * 4);
+                hipMalloc(&dwork, (size_t)B * (2 * (((li + 5) / 6 + 63) / 64) * 512 + 608) * 4);
+                hipMemcpy(dw1, hw1.data(), 480 * 4, hipMemcpyHostToDevice); hipMemcpy(db1, hb1.data(), 32 * 4, hipMemcpyHostToDevice);
+                // c_raw consistent with the waveform (the fused form derives sum c_raw * wav from the weights): overwrite din
+                std::vector<float> hc((size_t)B * 32 * li);
+                for (int b = 0; b < B; ++b)
+                    for (int c = 0; c < 32; ++c)
+                        for (int p = 0; p < li; ++p) {
+                            float v = hb1[c];
+                            for (int k = 0; k < 15; ++k) {
+                                const int x = 5 * p + k - 1600;
+                                if (x >= 0 && x < lw) v = fmaf(hw1[c * 15 + k], hwav[(size_t)b * lw + x], v);
+                            }
+                            hc[((size_t)b * 32 + c) * li + p] = v;
+                        }
+                hipMemcpy(din, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+                // reference: the unfused pair on the same inputs
+                dg(false);
+                ls::launch_conv1_wgrad(dout, din, dst, drow, nslot, dwav, dp1, B, lw, li, 5, 1600, &nchunk, st);
+                ls::launch_partial_reduce(dp1, B * nchunk, 480, 480, dg1, 0, st);
+                float* outp = nullptr;
+                auto fused = [&]() {
+                    ls::launch_wav_moments(dwav, dmom, B, lw, li, 1600, st);
+                    ls::launch_conv_dgrad_conv1(ddc, sb, sc, sp, dimg, din, dst, drow, B, co, li, lo, dwav, lw, 1600, dmom, dw1, db1, dwork, &outp, st);
+                    ls::launch_partial_reduce(outp, B, 480, 480, dgf, 0, st);
+                };
+                const double usf = time_us(st, fused);
+                {
+                    const double usk = time_us(st, [&]() { ls::launch_conv_dgrad_conv1(ddc, sb, sc, sp, dimg, din, dst, drow, B, co, li, lo, dwav, lw, 1600, dmom, dw1, db1, dwork, &outp, st); });
+                    const double usm = time_us(st, [&]() { ls::launch_wav_moments(dwav, dmom, B, lw, li, 1600, st); });
+                    std::printf("    parts: fused dgrad + coefficients + finish %.1f us, waveform moments %.1f us\n", usk, usm);
+                }
+                std::vector<float> g1(480), g2(480);
+                hipMemcpy(g1.data(), dg1, 480 * 4, hipMemcpyDeviceToHost); hipMemcpy(g2.data(), dgf, 480 * 4, hipMemcpyDeviceToHost);
+                double worst = 0, scale = 0;
+                for (int i = 0; i < 480; ++i) { worst = std::fmax(worst, std::fabs((double)g1[i] - g2[i])); scale = std::fmax(scale, std::fabs((double)g1[i])); }
+                std::printf("conv2 dgrad + conv1 wgrad FUSED (waveform moments + epilogue products + finish + batch sum): %.1f us; max |dW1 - unfused| %.3g (largest entry %.3g) %s\n",
+                            usf, worst, scale, worst < 3e-4 * scale ? "ok" : "MISMATCH");
+                hipFree(dw1); hipFree(db1); hipFree(dmom); hipFree(dwork); hipFree(dgf);
+            }
             hipFree(dwav); hipFree(dp1); hipFree(dg1);
         }
         hipFree(din); hipFree(ddc); hipFree(dst); hipFree(dw); hipFree(dpart); hipFree(dgw); hipFree(dimg); hipFree(dout); hipFree(drow);
