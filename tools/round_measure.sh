@@ -15,7 +15,9 @@ python bench.py --gpus 2 --ranks-share-device --batch 256 --legs lively --no-cpu
 python tools/smallbatch_time.py ted > "$out/smallbatch_ted.txt" 2>&1; python tools/smallbatch_time.py beat > "$out/smallbatch_beat.txt" 2>&1
 [ -x variants/conv_bench ] && variants/conv_bench 512 > "$out/conv_bench.txt" 2>&1
 [ -x variants/conv_bench_prof ] && variants/conv_bench_prof 512 > "$out/conv_bench_prof.txt" 2>&1
+[ -x variants/conv_bwd_bench ] && variants/conv_bwd_bench 512 > "$out/conv_bwd_bench.txt" 2>&1
 python tools/sag_time.py > "$out/sag_time.txt" 2>&1
+python tools/train_perf.py ted 512 8 2>&1 | tail -4 > "$out/train_perf.txt"
 python bench.py --scale 1.0 --no-extra-legs --no-cpu-baseline > "$out/bench_scale1.json" 2> "$out/bench_scale1.err"; echo "scale1 rc=$?"
 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs > "$out/kt_bench.json" 2> "$out/kt.log"
 python profiles/summarize_rocprof.py "$(ls $out/kt/*.db | head -1)" "kernel trace of bench.py --steps 1 --warmup 1 (headline workload)" "$out/kt_bench.json" > "$out/kt_bench.md"

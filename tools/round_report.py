@@ -73,6 +73,9 @@ for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
 out += ["", "## ms per diffusion step over the batch size: fused kernel vs batch-level kernels (`tools/smallbatch_time.py`)", "", "```", cat("smallbatch_ted.txt"), "",
         cat("smallbatch_beat.txt"), "```",
         "", "## Stride-6 conv layers stand-alone (`tools/conv_bench.cpp`) and the per-stage barrier timeline of one workgroup (`-DLS_CONV_PROF`)", "", "```",
-        cat("conv_bench.txt"), "", cat("conv_bench_prof.txt"), "```", "", "SAG decode: " + cat("sag_time.txt").splitlines()[-1], ""]
+        cat("conv_bench.txt"), "", cat("conv_bench_prof.txt"), "```",
+        "", "## Backward conv kernels of the training step stand-alone (`tools/conv_bwd_bench.cpp`: timing after a clock warm-up, sampled entries against a host evaluation)",
+        "", "```", cat("conv_bwd_bench.txt"), "```", "", "SAG decode: " + cat("sag_time.txt").splitlines()[-1],
+        "", "Training step (`tools/train_perf.py ted 512 8`, last steps): ", "", "```", cat("train_perf.txt"), "```", ""]
 open(dst, "w").write("\n".join(out))
 print("wrote", dst, len(out), "lines")
