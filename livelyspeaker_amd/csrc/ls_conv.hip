@@ -934,18 +934,25 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
 }
 
 // S2[k] = sum_p wavpad[5p + k] and R[j][k] = sum_p wavpad[5p + j] wavpad[5p + k] over the Lout positions of conv1 (zero padding `pad`)
-// of every sample: mom[b][part][16][16] with R in [j][k], j, k < 15, and S2[j] in column 15, summed over the kMomParts parts by the
+// of every sample: mom[b][part][16][16] with R in [j][k], j, k < 15, and S2[j] in column 15, summed over the gridDim.x parts by the
 // consumer.  Workgroup = (part of the positions, sample); the 15 x 16 products are ONE MFMA per four positions (the operand with the
 // ones column is both A and B); the operand comes out of a coalesced LDS copy of the workgroup's stretch of the waveform (one
 // workgroup per sample with a 64-address gather in front of every MFMA took 160 us at B = 512).
-constexpr int kMomParts = 8, kMomWin = 5200;              // window floats per workgroup: 5 * 4 * (steps per workgroup) + 15 <= kMomWin
+constexpr int kMomWin = 5200;                             // window floats per workgroup: 5 * 4 * (steps per workgroup) + 15 <= kMomWin
+// parts per sample: 8, or as many as it takes for a part's stretch of the waveform to fit the window (longer audio than the reference's)
+int wav_moment_parts(int Lout) {
+    int parts = 8;
+    while (80 * (((Lout + 3) / 4 + 4 * parts - 1) / (4 * parts)) + 16 > kMomWin) ++parts;
+    return parts;
+}
 __global__ __launch_bounds__(256) void k_wav_moments(const float* __restrict__ wav, float* __restrict__ mom, int Lw, int Lout, int pad) {
     __shared__ float wv[kMomWin];
     __shared__ float red[4][16][16];
     const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
-    const int nstep = (Lout + 3) / 4, per = (nstep + 4 * kMomParts - 1) / (4 * kMomParts);   // steps of 4 positions per wave
+    const int nparts = gridDim.x;
+    const int nstep = (Lout + 3) / 4, per = (nstep + 4 * nparts - 1) / (4 * nparts);   // steps of 4 positions per wave
     // the workgroup's stretch of the (zero-padded, Lout-limited) waveform, coalesced: positions [4 * 4 * part * per, + 16 * per)
     const int pa = 16 * part * per, x0 = 5 * pa - pad, xend = min(5 * (Lout - 1) + 15 - pad, Lw);   // valid wav indices: [max(x0,0), xend)
     const float* wb = wav + (size_t)b * Lw;
@@ -986,20 +993,20 @@ __global__ __launch_bounds__(256) void k_wav_moments(const float* __restrict__ w
     for (int e = 0; e < 4; ++e) red[w][4 * g + e][s16] = acc[e];
     __syncthreads();
     const int j = tid >> 4, k = tid & 15;
-    mom[((size_t)b * kMomParts + part) * 256 + tid] = ((red[0][j][k] + red[1][j][k]) + red[2][j][k]) + red[3][j][k];
+    mom[((size_t)b * nparts + part) * 256 + tid] = ((red[0][j][k] + red[1][j][k]) + red[2][j][k]) + red[3][j][k];
 }
 
 // out[b][c*15 + k] = a S1 + b' S3 + c' S2 (see k_conv_dgrad<FUSE1>); a following k_partial_reduce over b gives dW1
 __global__ __launch_bounds__(512) void k_conv1_wgrad_finish(const float* __restrict__ s1part, int nt2, const float* __restrict__ coef,
-                                                            const float* __restrict__ mom, const float* __restrict__ w1, const float* __restrict__ bias1,
-                                                            float* __restrict__ out) {
+                                                            const float* __restrict__ mom, int nparts, const float* __restrict__ w1,
+                                                            const float* __restrict__ bias1, float* __restrict__ out) {
     __shared__ float msum[256];
     const int b = blockIdx.x, c = threadIdx.x >> 4, k = threadIdx.x & 15;
     if (threadIdx.x < 256) {                                               // the sample's moments: parts summed in index order
-        const float* mb = mom + (size_t)b * kMomParts * 256 + threadIdx.x;
+        const float* mb = mom + (size_t)b * nparts * 256 + threadIdx.x;
         float a = 0.f;
-#pragma unroll
-        for (int q = 0; q < kMomParts; ++q) a += mb[q * 256];
+#pragma unroll 8
+        for (int q = 0; q < nparts; ++q) a += mb[q * 256];
         msum[threadIdx.x] = a;
     }
     const float* sp = s1part + (size_t)b * nt2 * 512 + threadIdx.x;
@@ -1017,8 +1024,7 @@ __global__ __launch_bounds__(512) void k_conv1_wgrad_finish(const float* __restr
 }
 
 hipError_t launch_wav_moments(const float* wav, float* mom, int B, int Lw, int Lout, int pad, hipStream_t st) {
-    if (80 * (((Lout + 3) / 4 + 4 * kMomParts - 1) / (4 * kMomParts)) + 16 > kMomWin) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_wav_moments, dim3(kMomParts, B), dim3(256), 0, st, wav, mom, Lw, Lout, pad);
+    hipLaunchKernelGGL(k_wav_moments, dim3(wav_moment_parts(Lout), B), dim3(256), 0, st, wav, mom, Lw, Lout, pad);
     return hipGetLastError();
 }
 
@@ -1074,7 +1080,7 @@ hipError_t launch_conv_dgrad_conv1(const float* dc_in, long long sb, long long s
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if ((e = launch_in_bwd_coef(stats, rowpart, nslot, B * 32, Lx, coef, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3(B), dim3(512), 0, st, s1part, nt2, coef, mom, w1, bias1, outp);
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3(B), dim3(512), 0, st, s1part, nt2, coef, mom, wav_moment_parts(Lx), w1, bias1, outp);
     *out_part = outp;
     return hipGetLastError();
 }

@@ -126,7 +126,8 @@ hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, lon
                              const float* stats, float* dc_out, float* partial, int B, int Cin, int Cout, int Lx, int Lout, bool finalize,
                              int* nslot, hipStream_t st);
 // conv2's data gradient with conv1's weight gradient folded into its epilogue (ls_conv.hip, k_conv_dgrad<FUSE1>): no dy tensor
-hipError_t launch_wav_moments(const float* wav, float* mom, int B, int Lw, int Lout, int pad, hipStream_t st);      // mom[B][8][16][16]
+int wav_moment_parts(int Lout);                                                                                      // parts per sample
+hipError_t launch_wav_moments(const float* wav, float* mom, int B, int Lw, int Lout, int pad, hipStream_t st);      // mom[B][parts][16][16]
 hipError_t launch_in_bwd_coef(const float* stats, const float* rowpart, int nslot, int rows, int L, float* coef, hipStream_t st);
 hipError_t launch_conv_dgrad_conv1(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
                                    const float* stats, float* rowpart, int B, int Cout, int Lx, int Lout, const float* wav, int Lw, int wpad,

@@ -183,7 +183,7 @@ int ensure_batch(ls_trainer* h, int B) {
     // (dc[0], the gradient of conv1's output, is never materialised: its only consumer, conv1's weight gradient, is folded into the
     //  epilogue of conv2's data gradient -- 517 MB at B = 512)
     for (int i = 0; i < 3; ++i) { HIPCHK(h, E(h->st[i], (size_t)B * kCout[i] * 2)); if (i) HIPCHK(h, E(h->dc[i], (size_t)B * kCout[i] * L[i + 1])); }
-    HIPCHK(h, E(h->wmom, (size_t)B * 8 * 256));
+    HIPCHK(h, E(h->wmom, (size_t)B * wav_moment_parts(L[1]) * 256));
     HIPCHK(h, E(h->feat, (size_t)B * d0.T * d0.KFP));
     HIPCHK(h, E(h->zc, (size_t)B * kSpk)); HIPCHK(h, E(h->dzc, (size_t)B * kSpk));
     for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));

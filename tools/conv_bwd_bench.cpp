@@ -134,7 +134,7 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < 32; ++i) hb1[i] = frand(i, 15485863u) * 0.1f;
                 hipMemcpy(dwav, hwav.data(), hwav.size() * 4, hipMemcpyHostToDevice);
                 float *dw1, *db1, *dmom, *dwork, *dgf;
-                hipMalloc(&dw1, 480 * 4); hipMalloc(&db1, 32 * 4); hipMalloc(&dmom, (size_t)B * 8 * 256 * 4); hipMalloc(&dgf, 480 * 4);
+                hipMalloc(&dw1, 480 * 4); hipMalloc(&db1, 32 * 4); hipMalloc(&dmom, (size_t)B * ls::wav_moment_parts(li) * 256 * 4); hipMalloc(&dgf, 480 * 4);
                 hipMalloc(&dwork, (size_t)B * (2 * (((li + 5) / 6 + 63) / 64) * 512 + 608) * 4);
                 hipMemcpy(dw1, hw1.data(), 480 * 4, hipMemcpyHostToDevice); hipMemcpy(db1, hb1.data(), 32 * 4, hipMemcpyHostToDevice);
                 // c_raw consistent with the waveform (the fused form derives sum c_raw * wav from the weights): overwrite din
