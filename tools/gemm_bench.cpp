@@ -1,6 +1,6 @@
 // Stand-alone timing of launch_gemm_nt (the nn.Linear-shaped fp32 MFMA GEMM) on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -x hip -I livelyspeaker_amd/csrc -I include tools/gemm_bench.cpp livelyspeaker_amd/csrc/ls_gemm.hip -o variants/gemm_bench
-//   variants/gemm_bench M N K [act] [residual]   ->  us per launch and TFLOP/s (HIP events over 50 launches, after 10 warm-ups)
+//   variants/gemm_bench M N K [act] [residual]   ->  us per launch and TFLOP/s (HIP events over 50 launches, after 1500 untimed ones: the shader clock needs a few hundred ms of load to reach its ceiling)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     hipMemcpy(R, hr.data(), hr.size() * 4, hipMemcpyHostToDevice);
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 10; ++i) ls::launch_gemm_nt(A, K, W, K, b, res ? R : nullptr, N, C, N, M, N, K, act, st);
+    for (int i = 0; i < 1500; ++i) ls::launch_gemm_nt(A, K, W, K, b, res ? R : nullptr, N, C, N, M, N, K, act, st);
     const int n = 50;
     hipEventRecord(e0, st);
     for (int i = 0; i < n; ++i) ls::launch_gemm_nt(A, K, W, K, b, res ? R : nullptr, N, C, N, M, N, K, act, st);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the HIP training step (GPU box): python tools/train_perf.py [dataset] [B] [steps]"""
+"""Time the HIP training step (GPU box): python tools/train_perf.py [dataset] [B] [steps] [library.so]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,8 @@ from livelyspeaker_amd import _lib, synth
 ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+if len(sys.argv) > 4:
+    _lib.use_library(sys.argv[4])            # an A/B variant of the library (livelyspeaker_amd.build.build_library(defines=..., out=...))
 cfg = synth.CONFIGS[ds]
 tr = _lib.Trainer(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
 tr.load_state_dict(synth.make_state_dict(cfg))
