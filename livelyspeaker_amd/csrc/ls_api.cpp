@@ -978,7 +978,9 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
     hipStream_t st = h->stream;
     int rc;
     HIPCHK(h, hipEventRecord(h->ev[4], st));
-    if ((rc = ingest(h, h->audio, c->audio_input, (size_t)B * AL * sizeof(float), od)) != LS_OK) return rc;
+    // a device-resident waveform is read in place by conv1, its only consumer (74 MB at B = 512: the copy was 28 us of the stage):
+    // ls_prepare synchronises before it returns, and ls_prepare_async's contract keeps device inputs valid until the next synchronising call
+    if (!od && (rc = ingest(h, h->audio, c->audio_input, (size_t)B * AL * sizeof(float), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->origin_x, c->origin_x, (size_t)B * JF * h->T * sizeof(float), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->vid, c->vid_indices, (size_t)B * sizeof(int64_t), od)) != LS_OK) return rc;
     if ((rc = ingest(h, h->scale, c->scale, (size_t)B * sizeof(float), od)) != LS_OK) return rc;
@@ -1005,7 +1007,7 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
     const int* Lc = h->convL;
     DevBuf* outs[4] = {&h->c1, &h->c2, &h->c3, &h->c4};
     DevBuf* stats[3] = {&h->st1, &h->st2, &h->st3};
-    const float* in = h->audio.f();
+    const float* in = od ? static_cast<const float*>(c->audio_input) : h->audio.f();
     const float* in_stats = nullptr;
     // every conv kernel also produces the InstanceNorm statistics of its own output (partials -> k_stats_merge), so the
     // activations are written once and read once
