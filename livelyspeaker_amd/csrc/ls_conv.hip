@@ -780,46 +780,51 @@ hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout,
 // k_wav_moments).  So the epilogue writes dy back into its LDS tile and multiplies it with the waveform on the matrix pipe
 // (M = 16 channels, N = the 15 taps, K = 4 positions; 48 MFMAs per wave on top of the main loop's 480): s1part[b][tile][x half][32][16].
 // Saves the 517 MB dy write here and conv1's weight-gradient kernel, which read dy and c_raw again (1.03 GB).
-template <bool FUSE1>
+// WIDE: the tile shape for SHORT layers (round 3): 64 input channels x 48 q per workgroup, wave = one channel tile x three q tiles (45 MFMAs
+// per weight fragment instead of 30, every wave its own fragments).  conv4's 37 q fill 37 of 48 tile positions instead of 37 of 64, conv3's
+// 219 fill 219 of 240 instead of 219 of 256.  The epilogue handles the 64 channels as two halves of 32 through the same LDS tile.
+template <bool FUSE1, bool WIDE>
 __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc_in, long long sb, long long sc, long long sp,
                                                     const float* __restrict__ wimg, const float* __restrict__ craw, const float* __restrict__ stats,
                                                     float* __restrict__ dc_out, float* __restrict__ partial, int Cin, int Cout, int Lx, int Lout,
                                                     const float* __restrict__ wav, int Lw, int wpad, float* __restrict__ s1part) {
-    __shared__ __attribute__((aligned(16))) float smem[32 * kDgEpS > kDgCo * kDgDld ? 32 * kDgEpS : kDgCo * kDgDld];
-    float* dcs = smem;                 // main loop: dC [64 co][66 q + pad]; epilogue: dAct tile [32 ci][384 x + pad]
+    static_assert(!(FUSE1 && WIDE), "the fused form is conv2's: 32 input channels");
+    constexpr int NCT = WIDE ? 4 : 2, NQW = WIDE ? 3 : 2, QT = WIDE ? 48 : kDgQT, EPS = 6 * QT + 4;   // channel tiles, q tiles per wave, q per workgroup
+    __shared__ __attribute__((aligned(16))) float smem[32 * EPS > kDgCo * kDgDld ? 32 * EPS : kDgCo * kDgDld];
+    float* dcs = smem;                 // main loop: dC [64 co][QT + 2 q + pad]; epilogue: dAct tile [32 ci][6 QT x + pad]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, ci0 = blockIdx.y * 32, q0 = blockIdx.x * kDgQT;
-    const int cit = w & 1, qh = w >> 1;
+    const int b = blockIdx.z, ci0 = blockIdx.y * 16 * NCT, q0 = blockIdx.x * QT;
+    const int cit = WIDE ? w : (w & 1), qh = WIDE ? 0 : (w >> 1);
 
-    f4 acc[2][6];
+    f4 acc[NQW][6];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < NQW; ++qt)
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[qt][r] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const auto wrs = uniform_rsrc(wimg);                           // weight image through a buffer descriptor (ls_lanes.h)
-    const int wp = (((int)blockIdx.y * 2 + cit) * (Cout / 4)) * 4 * 1024;
+    const int wp = (((int)blockIdx.y * NCT + cit) * (Cout / 4)) * 4 * 1024;
     const int bbase = g * kDgDld + 32 * qh + s16 + 2;             // + 4*cogl*Dld*... see below: row = 4*cogl + g
 
     for (int cc = 0; cc < Cout / kDgCo; ++cc) {
         __syncthreads();
         {
             // all of this thread's loads first (clamped addresses: branch-free, in flight together), then the LDS writes
-            constexpr int kN = kDgCo * (kDgQT + 2), kPer = (kN + 255) / 256;
+            constexpr int kN = kDgCo * (QT + 2), kPer = (kN + 255) / 256;
             float v[kPer];
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
                 const int idx = min(tid + 256 * i, kN - 1);
-                const int co = idx / (kDgQT + 2), jj = idx - co * (kDgQT + 2);
+                const int co = idx / (QT + 2), jj = idx - co * (QT + 2);
                 const int pc = min(max(q0 - 2 + jj, 0), Lout - 1);
                 v[i] = dc_in[(size_t)b * sb + (size_t)(cc * kDgCo + co) * sc + (size_t)pc * sp];
             }
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
                 const int idx = tid + 256 * i;
-                const int co = idx / (kDgQT + 2), jj = idx - co * (kDgQT + 2);
+                const int co = idx / (QT + 2), jj = idx - co * (QT + 2);
                 const int p = q0 - 2 + jj;
                 if (idx < kN) dcs[co * kDgDld + jj] = (p >= 0 && p < Lout) ? v[i] : 0.f;
             }
@@ -834,12 +839,14 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
             const float* br = dcs + (4 * cogl) * kDgDld + bbase;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const float B0 = br[-t], B1 = br[16 - t];
+                float Bq[NQW];
+#pragma unroll
+                for (int qt = 0; qt < NQW; ++qt) Bq[qt] = br[16 * qt - t];
 #pragma unroll
                 for (int r = 0; r < (t < 2 ? 6 : 3); ++r) {
                     const int pair = t < 2 ? t * 6 + r : 12 + r;
-                    acc[0][r] = MFMA(A[pair >> 2][pair & 3], B0, acc[0][r]);
-                    acc[1][r] = MFMA(A[pair >> 2][pair & 3], B1, acc[1][r]);
+#pragma unroll
+                    for (int qt = 0; qt < NQW; ++qt) acc[qt][r] = MFMA(A[pair >> 2][pair & 3], Bq[qt], acc[qt][r]);
                 }
             }
         }
@@ -849,51 +856,58 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
     // busy, 62 % of wave time in s_waitcnt).  The tile goes through LDS instead ([32 channels][384 x], reusing the operand
     // buffer) and every wave then streams whole channel rows: coalesced c_raw loads and dy stores, one (sum dy, sum dy*y) pair
     // per row and workgroup.
-    __syncthreads();
     float* ep = smem;
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float* dst = ep + (16 * cit + 4 * g + e) * kDgEpS + 6 * (32 * qh + 16 * qt + s16);
-#pragma unroll
-            for (int r2 = 0; r2 < 3; ++r2) *reinterpret_cast<float2*>(dst + 2 * r2) = make_float2(acc[qt][2 * r2][e], acc[qt][2 * r2 + 1][e]);
-        }
-    __syncthreads();
-    const int x0 = 6 * q0, nx = min(6 * kDgQT, Lx - x0);                  // valid x of this tile (>= 1)
+    const int x0 = 6 * q0, nx = min(6 * QT, Lx - x0);                      // valid x of this tile (>= 1)
     const int nslot = gridDim.x * 2;
-    float cv[8][6];                                                      // the accumulators are dead: their registers hold the c_raw tile
+    constexpr int NK = (6 * QT + 63) / 64;                                 // 64-wide pieces of a tile row
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float* cr = craw + ((size_t)b * Cin + ci0 + w + 4 * i) * Lx + x0;
+    for (int half = 0; half < (WIDE ? 2 : 1); ++half) {
+        __syncthreads();                                                   // the operand buffer / the previous half's tile is free
+        if (!WIDE || (cit >> 1) == half) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cv[i][k] = cr[min(lane + 64 * k, nx - 1)];   // clamped: 48 branch-free loads in flight together
-    }
+            for (int qt = 0; qt < NQW; ++qt)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = w + 4 * i;
-        const size_t row = (size_t)b * Cin + ci0 + c;
-        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-        float* dst = dc_out + row * Lx + x0;
-        float s1 = 0.f, s2 = 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    float* dst = ep + (16 * (WIDE ? (cit & 1) : cit) + 4 * g + e) * EPS + 6 * (32 * qh + 16 * qt + s16);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int xl = lane + 64 * k;
-            const float y = (cv[i][k] - mean) * rstd;
-            const float av = ep[c * kDgEpS + xl];
-            const float dy = y >= 0.f ? av : 0.3f * av;
-            if (xl < nx) {
-                if (!FUSE1) dst[xl] = dy;
-                s1 += dy;
-                s2 += dy * y;
-            }
-            if (FUSE1 && !(LS_DG_ABL & 64)) ep[c * kDgEpS + xl] = xl < nx ? dy : 0.f;          // dy replaces dAct in the tile (own element)
+                    for (int r2 = 0; r2 < 3; ++r2) *reinterpret_cast<float2*>(dst + 2 * r2) = make_float2(acc[qt][2 * r2][e], acc[qt][2 * r2 + 1][e]);
+                }
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0) {                                                 // slot layout kept for the consumers: 2 per position tile
-            float* pp = partial + (row * nslot + blockIdx.x * 2) * 2;
-            pp[0] = s1; pp[1] = s2; pp[2] = 0.f; pp[3] = 0.f;
+        __syncthreads();
+        float cv[8][NK];                                                   // the accumulators are dead: their registers hold the c_raw tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* cr = craw + ((size_t)b * Cin + ci0 + 32 * half + w + 4 * i) * Lx + x0;
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) cv[i][kq] = cr[min(lane + 64 * kq, nx - 1)];   // clamped: branch-free loads in flight together
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = w + 4 * i;
+            const size_t row = (size_t)b * Cin + ci0 + 32 * half + c;
+            const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+            float* dst = dc_out + row * Lx + x0;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const int xl = lane + 64 * kq;
+                const bool in_tile = (6 * QT) % 64 == 0 || xl < 6 * QT;    // the last piece of a 288-wide row is partial
+                const float y = (cv[i][kq] - mean) * rstd;
+                const float av = in_tile ? ep[c * EPS + min(xl, 6 * QT - 1)] : 0.f;
+                const float dy = y >= 0.f ? av : 0.3f * av;
+                if (xl < nx) {
+                    if (!FUSE1) dst[xl] = dy;
+                    s1 += dy;
+                    s2 += dy * y;
+                }
+                if (FUSE1 && !(LS_DG_ABL & 64)) ep[c * EPS + xl] = xl < nx ? dy : 0.f;          // dy replaces dAct in the tile (own element)
+            }
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) {                                                 // slot layout kept for the consumers: 2 per position tile
+                float* pp = partial + (row * nslot + blockIdx.x * 2) * 2;
+                pp[0] = s1; pp[1] = s2; pp[2] = 0.f; pp[3] = 0.f;
+            }
         }
     }
     if (FUSE1 && !(LS_DG_ABL & 128)) {
@@ -918,7 +932,7 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(const float* __restrict__ dc
             }
         }
         __syncthreads();                                                 // every row of the tile holds dy now
-        const float* ar = ep + (16 * mt + s16) * kDgEpS + 192 * kh + g;
+        const float* ar = ep + (16 * mt + s16) * EPS + 192 * kh + g;
         f4 a1 = (f4){0.f, 0.f, 0.f, 0.f}, a2 = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < ((LS_DG_ABL & 32) ? 2 : 48); m += 2) {
@@ -1052,10 +1066,17 @@ hipError_t launch_conv_dgrad(const float* dc_in, long long sb, long long sc, lon
                              int* nslot, hipStream_t st) {
     if (Cin % 32 || Cout % kDgCo) return hipErrorInvalidValue;
     const int nq = (Lx + 5) / 6;
-    dim3 grid((nq + kDgQT - 1) / kDgQT, Cin / 32, B);
+    // tile shape: 64 channels x 48 q where that wastes fewer tile positions than 32 x 64 (short layers: conv4's 37 q, conv3's 219)
+    const int t64 = (nq + 63) / 64 * 64, t48 = (nq + 47) / 48 * 48;
+    const bool wide = Cin % 64 == 0 && t48 < t64;
+    dim3 grid(wide ? t48 / 48 : t64 / 64, wide ? Cin / 64 : Cin / 32, B);
     if (nslot) *nslot = (int)grid.x * 2;
-    hipLaunchKernelGGL(k_conv_dgrad<false>, grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, dc_out, partial, Cin, Cout, Lx, Lout,
-                       (const float*)nullptr, 0, 0, (float*)nullptr);
+    if (wide)
+        hipLaunchKernelGGL((k_conv_dgrad<false, true>), grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, dc_out, partial, Cin, Cout, Lx, Lout,
+                           (const float*)nullptr, 0, 0, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((k_conv_dgrad<false, false>), grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, dc_out, partial, Cin, Cout, Lx, Lout,
+                           (const float*)nullptr, 0, 0, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !finalize) return e;
     hipLaunchKernelGGL(k_in_finalize, dim3(B * Cin), dim3(256), 0, st, dc_out, craw, stats, partial, (int)grid.x * 2, Lx);
@@ -1075,7 +1096,7 @@ hipError_t launch_conv_dgrad_conv1(const float* dc_in, long long sb, long long s
     float* s1part = work;
     float* coef = s1part + (size_t)B * nt2 * 512;
     float* outp = coef + (size_t)B * 128;
-    hipLaunchKernelGGL(k_conv_dgrad<true>, grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, (float*)nullptr, rowpart, 32, Cout, Lx, Lout,
+    hipLaunchKernelGGL((k_conv_dgrad<true, false>), grid, dim3(256), 0, st, dc_in, sb, sc, sp, wimg, craw, stats, (float*)nullptr, rowpart, 32, Cout, Lx, Lout,
                        wav, Lw, wpad, s1part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
