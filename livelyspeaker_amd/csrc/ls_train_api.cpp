@@ -54,6 +54,7 @@ struct ls_trainer {
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    const float* audio_in = nullptr;                           // this step's waveform: the caller's device tensor in place, or h->audio (host input)
     std::string err;
     std::vector<Param> table;
     std::map<std::string, int> index;
@@ -243,7 +244,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
     TRAIN_LOCALS(h, d);
     // WavEncoder (audio_enc.py:9-25): raw conv outputs + InstanceNorm statistics are kept for the backward
     // (the column buffer is free during the forward: it serves as the statistics-partials workspace)
-    HIPCHK(h, launch_conv1_fwd(h->audio.f(), P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), h->st[0].f(), h->col.f(), B, L[0], L[1],
+    HIPCHK(h, launch_conv1_fwd(h->audio_in, P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), h->st[0].f(), h->col.f(), B, L[0], L[1],
                                kPad[0], st));
     for (int i = 1; i < 4; ++i) {
         HIPCHK(h, launch_build_conv_img(P(h, ck(i, "weight")), h->img[i].f(), kCin[i], kCout[i], st));
@@ -438,9 +439,9 @@ static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) 
             // gradient tensor itself is never written (k_conv_dgrad<FUSE1>); per-sample results are summed over the batch in index order
             float* outp = nullptr;
             // (on a side stream under the forward's first convs this latency-bound 50 us kernel cost the forward 200 us: measured, not kept)
-            HIPCHK(h, launch_wav_moments(h->audio.f(), h->wmom.f(), B, L[0], L[1], kPad[0], st));
+            HIPCHK(h, launch_wav_moments(h->audio_in, h->wmom.f(), B, L[0], L[1], kPad[0], st));
             HIPCHK(h, launch_conv_dgrad_conv1(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[0].f(), h->st[0].f(), part, B, C, L[1], Lo,
-                                              h->audio.f(), L[0], kPad[0], h->wmom.f(), P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->col.f(), &outp, st));
+                                              h->audio_in, L[0], kPad[0], h->wmom.f(), P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->col.f(), &outp, st));
             HIPCHK(h, launch_partial_reduce(outp, B, 480, 480, Gr(h, grad, ck(0, "weight")), 0, st));
         }
     }
@@ -667,8 +668,10 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
         (rc = ingest(h, h->tidx, tm.data(), B * 8, false)) || (rc = ingest(h, h->x_start, tb->x_start, nx, od)) ||
         (rc = ingest(h, h->noise, tb->noise, nx, od)) || (rc = ingest(h, h->origin_x, tb->origin_x, nx, od)) ||
         (rc = ingest(h, h->drop, tb->drop, B * 4, od)) || (rc = ingest(h, h->eps, tb->eps, (size_t)B * kD * 4, od)) ||
-        (rc = ingest(h, h->audio, tb->audio_input, (size_t)B * L[0] * 4, od)) || (rc = ingest(h, h->vid, tb->vid_indices, B * 8, od)))
+        (!od && (rc = ingest(h, h->audio, tb->audio_input, (size_t)B * L[0] * 4, od))) || (rc = ingest(h, h->vid, tb->vid_indices, B * 8, od)))
         return rc;
+    // a device-resident waveform (74 MB at B = 512) is read in place: this call synchronises before it returns
+    h->audio_in = od ? static_cast<const float*>(tb->audio_input) : h->audio.f();
     if (d.NPRE == 2 && (rc = ingest(h, h->emo, tb->emo, (size_t)B * T * 8, od))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));      // host staging vectors go out of scope below
     HIPCHK(h, hipEventRecord(h->ev[0], st));
