@@ -54,7 +54,11 @@ struct ls_trainer {
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    const float* audio_in = nullptr;                           // this step's waveform: the caller's device tensor in place, or h->audio (host input)
+    // this step's batch: the caller's device tensors in place, or the handle's copies of host inputs (ls_train_forward_backward
+    // synchronises before it returns, so nothing is read after the call)
+    const float *audio_in = nullptr, *in_x = nullptr, *in_noise = nullptr, *in_origin = nullptr, *in_drop = nullptr, *in_eps = nullptr;
+    const int64_t *in_vid = nullptr, *in_emo = nullptr;
+    Buf hostpack;                                              // q_sample coefficients + timestep rows of the batch: [ca | cb | tidx], one upload
     std::string err;
     std::vector<Param> table;
     std::map<std::string, int> index;
@@ -251,7 +255,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         HIPCHK(h, launch_conv1d_mfma(h->c[i - 1].f(), h->st[i - 1].f(), h->img[i].f(), P(h, ck(i, "bias")), h->c[i].f(), i < 3 ? h->st[i].f() : nullptr,
                                      h->col.f(), B, kCin[i], kCout[i], L[i], L[i + 1], st));
     }
-    HIPCHK(h, launch_build_feat_train(h->x_start.f(), h->noise.f(), h->origin_x.f(), h->c[3].f(), h->drop.f(), h->ca.f(), h->cb.f(), h->feat.f(),
+    HIPCHK(h, launch_build_feat_train(h->in_x, h->in_noise, h->in_origin, h->c[3].f(), h->in_drop, h->hostpack.f(), h->hostpack.f() + B, h->feat.f(),
                                       h->x_t.f(), d, h->cfg.model.n_pre_seq, st));
     {   // input_mapping (RAG.py:114) -> frame rows of the token sequence
         GemmArgs a = gemm(op_rows(h->feat.f(), d.KFP, BT, d.KF), op_rows(P(h, "input_mapping.weight"), d.KF, kD, d.KF),
@@ -260,7 +264,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         a.bias = P(h, "input_mapping.bias");
         HIPCHK(h, gemm_run(h, a, true, true));
     }
-    HIPCHK(h, launch_gather_rows(P(h, "speaker_embedding.weight"), reinterpret_cast<const int64_t*>(h->vid.p), h->zc.f(), B, kSpk,
+    HIPCHK(h, launch_gather_rows(P(h, "speaker_embedding.weight"), h->in_vid, h->zc.f(), B, kSpk,
                                  h->cfg.model.n_speakers, st));
     for (int k = 0; k < 2; ++k) {
         GemmArgs a = gemm(op_rows(h->zc.f(), kSpk, B, kSpk), op_rows(P(h, k ? "speaker_logvar.weight" : "speaker_mu.weight"), kSpk, kD, kSpk),
@@ -268,10 +272,10 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         a.bias = P(h, k ? "speaker_logvar.bias" : "speaker_mu.bias");
         HIPCHK(h, gemm_run(h, a, true, true));
     }
-    HIPCHK(h, launch_style_fwd(h->mu.f(), h->lv.f(), h->eps.f(), d.NPRE == 2 ? P(h, "emotion_embedding.weight") : nullptr,
-                               reinterpret_cast<const int64_t*>(h->emo.p), T, h->xcur.f(), h->kldp.f(), B, S, d.NPRE, st));
+    HIPCHK(h, launch_style_fwd(h->mu.f(), h->lv.f(), h->in_eps, d.NPRE == 2 ? P(h, "emotion_embedding.weight") : nullptr,
+                               h->in_emo, T, h->xcur.f(), h->kldp.f(), B, S, d.NPRE, st));
     // TimestepEmbedder (mlp_module.py:123-136)
-    HIPCHK(h, launch_gather_rows(h->pe.f(), reinterpret_cast<const int64_t*>(h->tidx.p), h->pe_rows.f(), B, kD, kPeRows, st));
+    HIPCHK(h, launch_gather_rows(h->pe.f(), reinterpret_cast<const int64_t*>(h->hostpack.f() + 2 * B), h->pe_rows.f(), B, kD, kPeRows, st));
     {
         GemmArgs a = gemm(op_rows(h->pe_rows.f(), kD, B, kD), op_rows(P(h, "backbone.embed_timestep.time_embed.0.weight"), kD, kD, kD), h->hid.f(),
                           kD, B, kD, kD);
@@ -304,7 +308,7 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
         HIPCHK(h, gemm_run(h, a, true, true));
     }
     const int nlb = (B * JF + 255) / 256;
-    HIPCHK(h, launch_loss(h->out.f(), h->x_start.f(), h->dout.f(), h->lossp.f(), d, h->cfg.lambda_vel, st));
+    HIPCHK(h, launch_loss(h->out.f(), h->in_x, h->dout.f(), h->lossp.f(), d, h->cfg.lambda_vel, st));
     HIPCHK(h, launch_finish_terms(h->lossp.f(), nlb, h->kldp.f(), B, h->terms.f(), d, h->cfg.lambda_vel, h->cfg.kld_weight, st));
     return LS_OK;
 }
@@ -361,7 +365,7 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
 static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad) {
     TRAIN_LOCALS(h, d);
     // G = d loss / d [style | (emotion) | input_mapping rows]
-    HIPCHK(h, launch_style_bwd(h->G.f(), h->mu.f(), h->lv.f(), h->eps.f(), h->dmu.f(), h->dlv.f(), B, S, h->cfg.kld_weight, st));
+    HIPCHK(h, launch_style_bwd(h->G.f(), h->mu.f(), h->lv.f(), h->in_eps, h->dmu.f(), h->dlv.f(), B, S, h->cfg.kld_weight, st));
     for (int k = 0; k < 2; ++k) {
         const float* dz = k ? h->dlv.f() : h->dmu.f();
         const char* wk = k ? "speaker_logvar.weight" : "speaker_mu.weight";
@@ -371,9 +375,9 @@ static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad)
         a.accumulate = k;
         HIPCHK(h, gemm_run(h, a, true, false));
     }
-    HIPCHK(h, launch_scatter_rows(h->dzc.f(), kSpk, reinterpret_cast<const int64_t*>(h->vid.p), 1, B, kSpk, Gr(h, grad, "speaker_embedding.weight"), st));
+    HIPCHK(h, launch_scatter_rows(h->dzc.f(), kSpk, h->in_vid, 1, B, kSpk, Gr(h, grad, "speaker_embedding.weight"), st));
     if (d.NPRE == 2)
-        HIPCHK(h, launch_scatter_rows(h->G.f() + kD, (long long)S * kD, reinterpret_cast<const int64_t*>(h->emo.p), T, B, kD,
+        HIPCHK(h, launch_scatter_rows(h->G.f() + kD, (long long)S * kD, h->in_emo, T, B, kD,
                                       Gr(h, grad, "emotion_embedding.weight"), st));
     // input_mapping
     const float* dH = h->G.f() + (size_t)d.NPRE * kD;
@@ -385,7 +389,7 @@ static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad)
                           gemm_operand(P(h, "input_mapping.weight") + 2 * JF + 1, INT_MAX, 0, 1, INT_MAX, 0, d.KF, false, kAud, kD), h->dAf.f(), kAud,
                           BT, kAud, kD);
         HIPCHK(h, gemm_run(h, a, true, false));
-        HIPCHK(h, launch_scale_rows(h->dAf.f(), h->drop.f(), B, T * kAud, st));
+        HIPCHK(h, launch_scale_rows(h->dAf.f(), h->in_drop, B, T * kAud, st));
     }
     // TimestepEmbedder
     {
@@ -550,7 +554,7 @@ void ls_train_destroy(ls_trainer* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.model.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo,
+    std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->hostpack,
                              &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
                              &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
                              &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->dAt, &h->col, &h->wmom, &h->ws};
@@ -657,22 +661,30 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
     const int T = d.T;
 
     // ---- host side of q_sample / timestep lookup ----
-    std::vector<float> ca(B), cb(B);
-    std::vector<int64_t> tm(B);
+    // [ca (B floats) | cb (B floats) | timestep-table rows (B int64)] in one staging vector and one upload
+    std::vector<float> pack((size_t)4 * B);
+    int64_t* tm = reinterpret_cast<int64_t*>(pack.data() + 2 * B);
     for (int b = 0; b < B; ++b) {
         const int64_t t = tb->t[b];
         if (t < 0 || t >= h->cfg.diffusion_steps) return fail(h, LS_EINVAL, "ls_train_forward_backward: t[%d] = %lld out of range", b, (long long)t);
-        ca[b] = (float)h->sac[t]; cb[b] = (float)h->s1mac[t]; tm[b] = h->tmap[t];
+        pack[b] = (float)h->sac[t]; pack[B + b] = (float)h->s1mac[t]; tm[b] = h->tmap[t];
     }
-    if ((rc = ingest(h, h->ca, ca.data(), B * 4, false)) || (rc = ingest(h, h->cb, cb.data(), B * 4, false)) ||
-        (rc = ingest(h, h->tidx, tm.data(), B * 8, false)) || (rc = ingest(h, h->x_start, tb->x_start, nx, od)) ||
-        (rc = ingest(h, h->noise, tb->noise, nx, od)) || (rc = ingest(h, h->origin_x, tb->origin_x, nx, od)) ||
-        (rc = ingest(h, h->drop, tb->drop, B * 4, od)) || (rc = ingest(h, h->eps, tb->eps, (size_t)B * kD * 4, od)) ||
-        (!od && (rc = ingest(h, h->audio, tb->audio_input, (size_t)B * L[0] * 4, od))) || (rc = ingest(h, h->vid, tb->vid_indices, B * 8, od)))
+    if ((rc = ingest(h, h->hostpack, pack.data(), (size_t)16 * B, false))) return rc;
+    // device-resident batch tensors are read in place (rounds 1-2 copied each into the handle: nine 4 us copies in front of every step)
+    auto in_place = [&](Buf& own, const void* src, size_t bytes, const void** out) -> int {
+        if (od) { *out = src; return LS_OK; }
+        int r = ingest(h, own, src, bytes, false);
+        *out = own.p;
+        return r;
+    };
+    if ((rc = in_place(h->x_start, tb->x_start, nx, (const void**)&h->in_x)) || (rc = in_place(h->noise, tb->noise, nx, (const void**)&h->in_noise)) ||
+        (rc = in_place(h->origin_x, tb->origin_x, nx, (const void**)&h->in_origin)) || (rc = in_place(h->drop, tb->drop, B * 4, (const void**)&h->in_drop)) ||
+        (rc = in_place(h->eps, tb->eps, (size_t)B * kD * 4, (const void**)&h->in_eps)) ||
+        (rc = in_place(h->audio, tb->audio_input, (size_t)B * L[0] * 4, (const void**)&h->audio_in)) ||
+        (rc = in_place(h->vid, tb->vid_indices, B * 8, (const void**)&h->in_vid)))
         return rc;
-    // a device-resident waveform (74 MB at B = 512) is read in place: this call synchronises before it returns
-    h->audio_in = od ? static_cast<const float*>(tb->audio_input) : h->audio.f();
-    if (d.NPRE == 2 && (rc = ingest(h, h->emo, tb->emo, (size_t)B * T * 8, od))) return rc;
+    h->in_emo = nullptr;
+    if (d.NPRE == 2 && (rc = in_place(h->emo, tb->emo, (size_t)B * T * 8, (const void**)&h->in_emo))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));      // host staging vectors go out of scope below
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     HIPCHK(h, hipMemsetAsync(grad, 0, (size_t)h->flat * 4, st));
