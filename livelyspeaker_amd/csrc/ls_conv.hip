@@ -766,6 +766,52 @@ __global__ void k_build_dgrad_img(const float* __restrict__ w, float* __restrict
     img[i] = v;
 }
 
+// Both operand images (forward / weight-gradient layout of ls_api.cpp, data-gradient layout above) of the three stride-6 layers in ONE
+// launch (the training step rebuilt them in six: 30 us of launch latency per step)
+struct ConvImgJobs { const float* w[3]; float* img[3]; float* dimg[3]; int Cin[3], Cout[3]; int first[7]; };   // first[j]: first block of job j
+__global__ __launch_bounds__(256) void k_build_conv_imgs(const ConvImgJobs a) {
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 6; ++q) j += (int)blockIdx.x >= a.first[q];
+    const int L = j >> 1, Cin = a.Cin[L], Cout = a.Cout[L];
+    const size_t i = (size_t)((int)blockIdx.x - a.first[j]) * 256 + threadIdx.x;
+    const float* w = a.w[L];
+    if (!(j & 1)) {                                                 // forward image: [co tile][chunk][k][lane][cig]
+        if (i >= (size_t)Cout * Cin * 15) return;
+        const int cig = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        size_t r = i >> 8;
+        const int k = (int)(r % 15); r /= 15;
+        const int nchunk = Cin / 16;
+        const int ch = (int)(r % nchunk), ct = (int)(r / nchunk);
+        a.img[L][i] = w[((size_t)(16 * ct + (lane & 15)) * Cin + 16 * ch + 4 * cig + (lane >> 4)) * 15 + k];
+    } else {                                                        // data-gradient image (k_build_dgrad_img)
+        if (i >= (size_t)(Cin / 16) * (Cout / 4) * 16 * 64) return;
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), pq = (int)((i >> 8) & 3);
+        size_t rr = i >> 10;
+        const int cog = (int)(rr % (Cout / 4)), cit = (int)(rr / (Cout / 4));
+        const int pair = 4 * pq + e;
+        float v = 0.f;
+        if (pair < 15) {
+            const int t = pair < 12 ? pair / 6 : 2, r = pair < 12 ? pair % 6 : pair - 12;
+            v = w[((size_t)(4 * cog + (lane >> 4)) * Cin + 16 * cit + (lane & 15)) * 15 + r + 6 * t];
+        }
+        a.dimg[L][i] = v;
+    }
+}
+
+hipError_t launch_build_conv_imgs(const float* const w[3], float* const img[3], float* const dimg[3], const int Cin[3], const int Cout[3], hipStream_t st) {
+    ConvImgJobs a;
+    int nb = 0;
+    for (int L = 0; L < 3; ++L) {
+        a.w[L] = w[L]; a.img[L] = img[L]; a.dimg[L] = dimg[L]; a.Cin[L] = Cin[L]; a.Cout[L] = Cout[L];
+        a.first[2 * L] = nb;     nb += (int)(((size_t)Cout[L] * Cin[L] * 15 + 255) / 256);
+        a.first[2 * L + 1] = nb; nb += (int)(((size_t)(Cin[L] / 16) * (Cout[L] / 4) * 16 * 64 + 255) / 256);
+    }
+    a.first[6] = nb;
+    hipLaunchKernelGGL(k_build_conv_imgs, dim3(nb), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_dgrad_img(const float* w, float* img, int Cin, int Cout, hipStream_t st) {
     const size_t total = (size_t)(Cin / 16) * (Cout / 4) * 16 * 64;
     hipLaunchKernelGGL(k_build_dgrad_img, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, img, Cin, Cout);

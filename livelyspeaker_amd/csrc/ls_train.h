@@ -132,6 +132,8 @@ hipError_t launch_in_bwd_coef(const float* stats, const float* rowpart, int nslo
 hipError_t launch_conv_dgrad_conv1(const float* dc_in, long long sb, long long sc, long long sp, const float* wimg, const float* craw,
                                    const float* stats, float* rowpart, int B, int Cout, int Lx, int Lout, const float* wav, int Lw, int wpad,
                                    const float* mom, const float* w1, const float* bias1, float* work, float** out_part, hipStream_t st);
+// forward + data-gradient operand images of conv2..conv4 in one launch
+hipError_t launch_build_conv_imgs(const float* const w[3], float* const img[3], float* const dimg[3], const int Cin[3], const int Cout[3], hipStream_t st);
 hipError_t launch_build_conv_img(const float* w, float* img, int Cin, int Cout, hipStream_t st);
 // ---- optimiser ----
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,

@@ -250,8 +250,13 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
     // (the column buffer is free during the forward: it serves as the statistics-partials workspace)
     HIPCHK(h, launch_conv1_fwd(h->audio_in, P(h, ck(0, "weight")), P(h, ck(0, "bias")), h->c[0].f(), h->st[0].f(), h->col.f(), B, L[0], L[1],
                                kPad[0], st));
+    {   // the stride-6 layers' operand images (forward / weight gradient and data gradient), rebuilt from the master weights: one launch
+        const float* w3[3] = {P(h, ck(1, "weight")), P(h, ck(2, "weight")), P(h, ck(3, "weight"))};
+        float* im[3] = {h->img[1].f(), h->img[2].f(), h->img[3].f()};
+        float* dm[3] = {h->dimg[1].f(), h->dimg[2].f(), h->dimg[3].f()};
+        HIPCHK(h, launch_build_conv_imgs(w3, im, dm, kCin + 1, kCout + 1, st));
+    }
     for (int i = 1; i < 4; ++i) {
-        HIPCHK(h, launch_build_conv_img(P(h, ck(i, "weight")), h->img[i].f(), kCin[i], kCout[i], st));
         HIPCHK(h, launch_conv1d_mfma(h->c[i - 1].f(), h->st[i - 1].f(), h->img[i].f(), P(h, ck(i, "bias")), h->c[i].f(), i < 3 ? h->st[i].f() : nullptr,
                                      h->col.f(), B, kCin[i], kCout[i], L[i], L[i + 1], st));
     }
@@ -420,7 +425,6 @@ static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) 
         HIPCHK(h, launch_partial_reduce(h->col.f(), ng, (long long)kCout[3] * W4, kCout[3] * W4, Gr(h, grad, ck(3, "weight")), 0, st));
         HIPCHK(h, colsum_to(h, h->dAf.f(), INT_MAX, 0, kAud, BT, kAud, Gr(h, grad, ck(3, "bias"))));
         // data gradient: implicit GEMM + LeakyReLU' + InstanceNorm backward
-        HIPCHK(h, launch_build_dgrad_img(P(h, ck(3, "weight")), h->dimg[3].f(), kCin[3], kCout[3], st));
         HIPCHK(h, launch_conv_dgrad(h->dAt.f(), (long long)T * kAud, T, 1, h->dimg[3].f(), h->c[2].f(), h->st[2].f(), h->dc[2].f(), part, B,
                                     kCin[3], kCout[3], L[3], L[4], true, nullptr, st));
     }
@@ -434,7 +438,6 @@ static int train_backward_audio(ls_trainer* h, const TrainDims& d, float* grad) 
         }
         // (bias gradients of conv1..3 stay exactly 0: a bias that feeds an InstanceNorm cannot change the output; the
         //  reference's autograd returns rounding noise of ~1e-7 there)
-        HIPCHK(h, launch_build_dgrad_img(P(h, ck(i, "weight")), h->dimg[i].f(), kCin[i], C, st));
         if (i == 2) {
             HIPCHK(h, launch_conv_dgrad(h->dc[i].f(), (long long)C * Lo, Lo, 1, h->dimg[i].f(), h->c[i - 1].f(), h->st[i - 1].f(), h->dc[i - 1].f(), part, B,
                                         kCin[i], C, L[i], Lo, true, nullptr, st));
