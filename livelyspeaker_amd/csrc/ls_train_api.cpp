@@ -124,7 +124,7 @@ int ingest(ls_trainer* h, Buf& dst, const void* src, size_t bytes, bool on_devic
 int splits_for(int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int s = (768 + tiles - 1) / tiles;
-    const int smax = K / 256 > 0 ? K / 256 : 1;
+    const int smax = K / 64 > 0 ? K / 64 : 1;        // at least two 32-deep K tiles per split (K / 256 left a 512 x 512 x 512 weight gradient on 32 workgroups: 25 us)
     if (s > smax) s = smax;
     return s < 1 ? 1 : s;
 }
@@ -142,7 +142,7 @@ GemmArgs gemm(GemmOperand A, GemmOperand B, float* C, long long ldc, int M, int 
 hipError_t gemm_run(ls_trainer* h, GemmArgs a, bool a_k, bool b_k) {
     int s = 1;
     const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (!a.act && !a.Cpre && !a.R && tiles < 128 && h->ws.p) {
+    if (!a.act && !a.Cpre && !a.R && tiles < 256 && h->ws.p) {
         a.ws = h->ws.f(); a.ws_floats = h->ws_floats;
         s = splits_for(a.M, a.N, a.K);
         while (s > 1 && (size_t)s * a.M * a.N > h->ws_floats) --s;
@@ -168,7 +168,7 @@ hipError_t wgrad_batched(ls_trainer* h, GemmOperand dy_cols, GemmOperand x_cols,
     a.nbatch = nbatch; a.bsA = bs_dy; a.bsB = bs_x; a.bsC = bs_c;
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128) * nbatch;
     int s = (768 + tiles - 1) / tiles;
-    const int smax = K / 256 > 0 ? K / 256 : 1;
+    const int smax = K / 64 > 0 ? K / 64 : 1;        // at least two 32-deep K tiles per split (K / 256 left a 512 x 512 x 512 weight gradient on 32 workgroups: 25 us)
     if (s > smax) s = smax;
     while (s > 1 && (size_t)nbatch * s * M * N > h->ws_floats) --s;
     return launch_gemm_tr(a, false, false, s < 1 ? 1 : s, h->stream);
