@@ -57,7 +57,7 @@ inline GemmOperand op_cols(const float* p, long long ld, int rows, int K) { retu
 
 hipError_t launch_gemm_tr(GemmArgs a, bool a_kcontig, bool b_kcontig, int splits, hipStream_t st);
 
-struct TrainDims { int B, S, T, NPRE, JF, KF, KFP, D, L; };   // KF = 2*JF+1+256 input_mapping fan-in, KFP = padded to 4
+struct TrainDims { int B, S, T, NPRE, JF, KF, KFP, D, L; };   // KF = 2*JF+1+256 input_mapping fan-in, KFP = padded to 32
 
 // ---- forward ----
 hipError_t launch_build_feat_train(const float* x_start, const float* noise, const float* origin_x, const float* c4, const float* drop,
@@ -107,6 +107,7 @@ hipError_t launch_style_bwd(const float* g0, const float* mu, const float* lv, c
 hipError_t launch_scatter_rows(const float* src, long long src_stride, const int64_t* idx, int idx_stride, int n, int cols, float* table,
                                hipStream_t st);
 hipError_t launch_scale_rows(float* x, const float* drop, int B, int per_sample, hipStream_t st);
+hipError_t launch_build_inmap_images(const float* w, float* wpad, float* waT, int KF, int KFP, int a0, hipStream_t st);
 // ---- audio encoder backward ----
 // dst[b][c][r] = src[b][r][c], R <= 64, C % 64 == 0
 hipError_t launch_transpose_rc(const float* src, float* dst, int B, int R, int C, hipStream_t st);

@@ -58,6 +58,7 @@ struct ls_trainer {
     // synchronises before it returns, so nothing is read after the call)
     const float *audio_in = nullptr, *in_x = nullptr, *in_noise = nullptr, *in_origin = nullptr, *in_drop = nullptr, *in_eps = nullptr;
     const int64_t *in_vid = nullptr, *in_emo = nullptr;
+    Buf wpad, waT;                                             // input_mapping.weight zero-padded to [512][KFP]; its audio columns transposed [256][512]
     Buf hostpack;                                              // q_sample coefficients + timestep rows of the batch: [ca | cb | tidx], one upload
     std::string err;
     std::vector<Param> table;
@@ -189,7 +190,7 @@ int ensure_batch(ls_trainer* h, int B) {
     //  epilogue of conv2's data gradient -- 517 MB at B = 512)
     for (int i = 0; i < 3; ++i) { HIPCHK(h, E(h->st[i], (size_t)B * kCout[i] * 2)); if (i) HIPCHK(h, E(h->dc[i], (size_t)B * kCout[i] * L[i + 1])); }
     HIPCHK(h, E(h->wmom, (size_t)B * wav_moment_parts(L[1]) * 256));
-    HIPCHK(h, E(h->feat, (size_t)B * d0.T * d0.KFP));
+    HIPCHK(h, E(h->feat, (size_t)B * d0.T * d0.KFP)); HIPCHK(h, E(h->wpad, (size_t)kD * d0.KFP)); HIPCHK(h, E(h->waT, (size_t)kAud * kD));
     HIPCHK(h, E(h->zc, (size_t)B * kSpk)); HIPCHK(h, E(h->dzc, (size_t)B * kSpk));
     for (Buf* b : {&h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->demb, &h->dmu, &h->dlv, &h->dhid}) HIPCHK(h, E(*b, (size_t)B * kD));
     for (Buf* b : {&h->xcur, &h->G}) HIPCHK(h, E(*b, R * kD));
@@ -263,8 +264,11 @@ static int train_forward(ls_trainer* h, const TrainDims& d) {
     HIPCHK(h, launch_build_feat_train(h->in_x, h->in_noise, h->in_origin, h->c[3].f(), h->in_drop, h->hostpack.f(), h->hostpack.f() + B, h->feat.f(),
                                       h->x_t.f(), d, h->cfg.model.n_pre_seq, st));
     {   // input_mapping (RAG.py:114) -> frame rows of the token sequence
-        GemmArgs a = gemm(op_rows(h->feat.f(), d.KFP, BT, d.KF), op_rows(P(h, "input_mapping.weight"), d.KF, kD, d.KF),
-                          h->xcur.f() + (size_t)d.NPRE * kD, kD, BT, kD, d.KF);
+        // operands with 16-byte-aligned rows and a reduction length of whole K tiles (the master weight's rows are 311 floats: that product
+        // ran the GEMM's generic path at 34 % matrix-pipe occupancy, 101 us; the audio-gradient product below likewise, 27 %)
+        HIPCHK(h, launch_build_inmap_images(P(h, "input_mapping.weight"), h->wpad.f(), h->waT.f(), d.KF, d.KFP, 2 * d.JF + 1, st));
+        GemmArgs a = gemm(op_rows(h->feat.f(), d.KFP, BT, d.KFP), op_rows(h->wpad.f(), d.KFP, kD, d.KFP),
+                          h->xcur.f() + (size_t)d.NPRE * kD, kD, BT, kD, d.KFP);
         a.cri = T; a.cro = (long long)S * kD; a.crs = kD;
         a.bias = P(h, "input_mapping.bias");
         HIPCHK(h, gemm_run(h, a, true, true));
@@ -391,9 +395,8 @@ static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad)
     HIPCHK(h, colsum_to(h, dH, T, (long long)S * kD, kD, BT, kD, Gr(h, grad, "input_mapping.bias")));
     {   // d audio features = dH . Win[:, 2JF+1:], then the mask_cond scale
         GemmArgs a = gemm(gemm_operand(dH, T, (long long)S * kD, kD, INT_MAX, 0, 1, true, BT, kD),
-                          gemm_operand(P(h, "input_mapping.weight") + 2 * JF + 1, INT_MAX, 0, 1, INT_MAX, 0, d.KF, false, kAud, kD), h->dAf.f(), kAud,
-                          BT, kAud, kD);
-        HIPCHK(h, gemm_run(h, a, true, false));
+                          op_rows(h->waT.f(), kD, kAud, kD), h->dAf.f(), kAud, BT, kAud, kD);
+        HIPCHK(h, gemm_run(h, a, true, true));
         HIPCHK(h, launch_scale_rows(h->dAf.f(), h->in_drop, B, T * kAud, st));
     }
     // TimestepEmbedder
@@ -473,7 +476,7 @@ int ls_train_create(const ls_train_config* cfg, ls_trainer** out) {
     h->cfg = *cfg;
     TrainDims& d = h->d;
     d.B = 0; d.T = m.nframes; d.NPRE = m.n_prefix_tokens; d.S = d.T + d.NPRE; d.JF = m.njoints * m.nfeats;
-    d.KF = 2 * d.JF + 1 + kAud; d.KFP = (d.KF + 3) / 4 * 4; d.D = kD; d.L = m.layers;
+    d.KF = 2 * d.JF + 1 + kAud; d.KFP = (d.KF + 31) / 32 * 32; d.D = kD; d.L = m.layers;      // KFP: whole 32-deep K tiles (the input_mapping product takes the GEMM's LDS-DMA path)
     h->convL[0] = m.audio_len;
     for (int i = 0; i < 4; ++i) h->convL[i + 1] = (h->convL[i] + 2 * kPad[i] - 15) / kStride[i] + 1;
     if (h->convL[4] != d.T) { delete h; return fail(nullptr, LS_EINVAL, "ls_train_create: audio_len %d gives %d audio frames, need %d", m.audio_len, h->convL[4], d.T); }
@@ -557,7 +560,7 @@ void ls_train_destroy(ls_trainer* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.model.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->hostpack,
+    std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->hostpack, &h->wpad, &h->waT,
                              &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
                              &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
                              &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->dAt, &h->col, &h->wmom, &h->ws};

@@ -52,6 +52,27 @@ hipError_t launch_build_feat_train(const float* x_start, const float* noise, con
     return hipGetLastError();
 }
 
+// Two GEMM-friendly copies of input_mapping.weight [512][KF], rebuilt from the master parameters every step:
+//   wpad[n][k] = W[n][k] (k < KF), 0 up to KFP (whole 32-deep K tiles, 16-byte-aligned rows);  waT[j][n] = W[n][a0 + j] (the 256 audio columns,
+//   reduction index contiguous: the operand of d audio features = dH . W[:, a0:])
+__global__ void k_build_inmap_images(const float* __restrict__ w, float* __restrict__ wpad, float* __restrict__ waT, int KF, int KFP, int a0) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < kDm * KFP) {
+        const int n = i / KFP, k = i - n * KFP;
+        wpad[i] = k < KF ? w[(size_t)n * KF + k] : 0.f;
+    }
+    if (i < 256 * kDm) {
+        const int j = i / kDm, n = i - j * kDm;
+        waT[i] = w[(size_t)n * KF + a0 + j];
+    }
+}
+
+hipError_t launch_build_inmap_images(const float* w, float* wpad, float* waT, int KF, int KFP, int a0, hipStream_t st) {
+    const int total = kDm * KFP > 256 * kDm ? kDm * KFP : 256 * kDm;
+    hipLaunchKernelGGL(k_build_inmap_images, dim3((total + 255) / 256), dim3(256), 0, st, w, wpad, waT, KF, KFP, a0);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // da = g * silu'(apre); per-wave partial column sums of da in partial[wave][512] (-> bias gradient)
 __global__ __launch_bounds__(256) void k_silu_bwd_colsum(const float* __restrict__ g, const float* __restrict__ apre,
