@@ -33,22 +33,37 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out
 //   feat_a[(b,f)] = audio feature conv4[b,:,f]                                          (256 columns: the cond pass only)
 // so that static_u = feat_p . Wpre^T + b  and  static_c = static_u + feat_a . Waud^T  (mask_cond zeroes the audio term of the uncond
 // pass, RAG.py:82-83): K = KPP + 256 in total instead of 2 x (KPP + 256).
-__global__ void k_build_feats(const float* __restrict__ origin_x, const float* __restrict__ conv4,
-                              float* __restrict__ feat_p, float* __restrict__ feat_a, int JF, int KPP, int n_pre_seq, int T) {
-    const int b = blockIdx.x / T, f = blockIdx.x % T;
-    float* fp = feat_p + (size_t)blockIdx.x * KPP;
-    float* fa = feat_a + (size_t)blockIdx.x * kAudioFeat;
-    for (int c = threadIdx.x; c < KPP; c += blockDim.x) {
+// One workgroup per (sample, run of <= 48 frames): conv4's [256][frames] block is staged through LDS so that both its reads (whole row pieces)
+// and the [frame][256] writes are coalesced (round 3; one workgroup per (sample, frame) read it with a stride of T floats between lanes: 25 us
+// at B = 512).
+constexpr int kBfTC = 48;
+__global__ __launch_bounds__(256) void k_build_feats(const float* __restrict__ origin_x, const float* __restrict__ conv4,
+                                                     float* __restrict__ feat_p, float* __restrict__ feat_a, int JF, int KPP, int n_pre_seq, int T) {
+    __shared__ float tile[kAudioFeat * (kBfTC + 1)];
+    const int b = blockIdx.x, f0 = blockIdx.y * kBfTC, nf = min(kBfTC, T - f0), tid = threadIdx.x;
+    const float* src = conv4 + (size_t)b * kAudioFeat * T + f0;
+    {   // thread = channel `tid`: its row piece, all loads first (a rolled load -> LDS loop waits for each load in turn)
+        float v[kBfTC];
+#pragma unroll
+        for (int f = 0; f < kBfTC; ++f) v[f] = src[(size_t)tid * T + min(f, nf - 1)];
+#pragma unroll
+        for (int f = 0; f < kBfTC; ++f) tile[tid * (kBfTC + 1) + f] = v[f];
+    }
+    float* fp = feat_p + ((size_t)b * T + f0) * KPP;
+    for (int i = tid; i < nf * KPP; i += 256) {
+        const int f = f0 + i / KPP, c = i % KPP;
         float v = 0.f;
         if (f < n_pre_seq) v = c < JF ? origin_x[((size_t)b * JF + c) * T + f] : (c == JF ? 1.f : 0.f);
-        fp[c] = v;
+        fp[i] = v;
     }
-    for (int c = threadIdx.x; c < kAudioFeat; c += blockDim.x) fa[c] = conv4[((size_t)b * kAudioFeat + c) * T + f];
+    __syncthreads();
+    float* fa = feat_a + ((size_t)b * T + f0) * kAudioFeat;
+    for (int i = tid; i < nf * kAudioFeat; i += 256) fa[i] = tile[(i & (kAudioFeat - 1)) * (kBfTC + 1) + i / kAudioFeat];
 }
 
 hipError_t launch_build_feats(const float* origin_x, const float* conv4, float* feat_p, float* feat_a,
                               int B, int JF, int KPP, int n_pre_seq, hipStream_t st, int T) {
-    hipLaunchKernelGGL(k_build_feats, dim3(B * T), dim3(256), 0, st, origin_x, conv4, feat_p, feat_a, JF, KPP, n_pre_seq, T);
+    hipLaunchKernelGGL(k_build_feats, dim3(B, (T + kBfTC - 1) / kBfTC), dim3(256), 0, st, origin_x, conv4, feat_p, feat_a, JF, KPP, n_pre_seq, T);
     return hipGetLastError();
 }
 
