@@ -21,34 +21,50 @@ __device__ __forceinline__ float silu_grad(float a) {
 // ---------------------------------------------------------------------------------------------------------------
 // q_sample (gaussian_diffusion.py:240-258) fused into the InputProcess / input_mapping operand (RAG.py:106-114, 184-192):
 // feat[(b,t)][:] = [x_t[b,:,t] | origin_x[b,:,t] (t < n_pre_seq) | bit | conv4[b,:,t] * (1 - drop[b])], zero padded to KFP
-__global__ void k_build_feat_train(const float* __restrict__ x_start, const float* __restrict__ noise,
+// One workgroup per sample (round 3): conv4's [256][T] block goes through an LDS transpose, so its reads are row pieces and the [T][256] writes
+// whole rows (one workgroup per (sample, frame) read it with a stride of T floats between lanes: 38 us at B = 512).
+constexpr int kBftT = 34;                                                  // frames of the trained models (ls_train_create checks)
+__global__ __launch_bounds__(256) void k_build_feat_train(const float* __restrict__ x_start, const float* __restrict__ noise,
                                    const float* __restrict__ origin_x, const float* __restrict__ c4, const float* __restrict__ drop,
                                    const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ feat,
                                    float* __restrict__ x_t, TrainDims d, int n_pre_seq) {
-    const int b = blockIdx.x / d.T, t = blockIdx.x % d.T;
-    float* fr = feat + (size_t)blockIdx.x * d.KFP;
-    const float keep = 1.0f - drop[b];
-    for (int j = threadIdx.x; j < d.KFP; j += blockDim.x) {
-        float v = 0.f;
-        if (j < d.JF) {
-            const size_t i = ((size_t)b * d.JF + j) * d.T + t;
-            v = ca[b] * x_start[i] + cb[b] * noise[i];
-            x_t[i] = v;
-        } else if (j < 2 * d.JF) {
-            v = t < n_pre_seq ? origin_x[((size_t)b * d.JF + (j - d.JF)) * d.T + t] : 0.f;
-        } else if (j == 2 * d.JF) {
-            v = t < n_pre_seq ? 1.f : 0.f;
-        } else if (j < d.KF) {
-            v = c4[((size_t)b * 256 + (j - 2 * d.JF - 1)) * d.T + t] * keep;
-        }
-        fr[j] = v;
+    __shared__ float tile[256 * (kBftT + 1)];
+    const int b = blockIdx.x, tid = threadIdx.x, T = d.T;
+    {   // thread = audio channel `tid`: its T values, all loads first
+        float v[kBftT];
+        const float* src = c4 + ((size_t)b * 256 + tid) * T;
+#pragma unroll
+        for (int t = 0; t < kBftT; ++t) v[t] = src[t];
+#pragma unroll
+        for (int t = 0; t < kBftT; ++t) tile[tid * (kBftT + 1) + t] = v[t];
+    }
+    float* fb = feat + (size_t)b * T * d.KFP;
+    const float a0 = ca[b], b0 = cb[b], keep = 1.0f - drop[b];
+    for (int i = tid; i < d.JF * T; i += 256) {                            // x_t = q_sample(x_start, t, noise) and the prefix poses: [JF][T] in, [T][KFP] out
+        const int j = i / T, t = i - j * T;
+        const size_t g = (size_t)b * d.JF * T + i;
+        const float v = a0 * x_start[g] + b0 * noise[g];
+        x_t[g] = v;
+        fb[(size_t)t * d.KFP + j] = v;
+        fb[(size_t)t * d.KFP + d.JF + j] = t < n_pre_seq ? origin_x[g] : 0.f;
+    }
+    const int npad = d.KFP - d.KF + 1;                                     // the bit column and the zero padding
+    for (int i = tid; i < T * npad; i += 256) {
+        const int t = i / npad, c = i - t * npad;
+        if (c == 0) fb[(size_t)t * d.KFP + 2 * d.JF] = t < n_pre_seq ? 1.f : 0.f;
+        else fb[(size_t)t * d.KFP + d.KF + c - 1] = 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < T * 256; i += 256) {
+        const int t = i >> 8, c = i & 255;
+        fb[(size_t)t * d.KFP + 2 * d.JF + 1 + c] = tile[c * (kBftT + 1) + t] * keep;
     }
 }
 
 hipError_t launch_build_feat_train(const float* x_start, const float* noise, const float* origin_x, const float* c4, const float* drop,
                                    const float* ca, const float* cb, float* feat, float* x_t, TrainDims d, int n_pre_seq, hipStream_t st) {
-    hipLaunchKernelGGL(k_build_feat_train, dim3(d.B * d.T), dim3(256), 0, st, x_start, noise, origin_x, c4, drop, ca, cb, feat, x_t, d,
-                       n_pre_seq);
+    if (d.T != kBftT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_build_feat_train, dim3(d.B), dim3(256), 0, st, x_start, noise, origin_x, c4, drop, ca, cb, feat, x_t, d, n_pre_seq);
     return hipGetLastError();
 }
 
