@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LS_ABI_VERSION 2
+#define LS_ABI_VERSION 3
 
 enum {
     LS_OK = 0,
@@ -196,6 +196,7 @@ typedef struct ls_timing {
     int32_t single_pass;        /* 1 if the loop ran the single-pass (scale == 1) kernel */
     float tape_upload_ms;       /* segmented TAPE mode: summed GPU-side duration of the tape uploads of the last loop (copy stream) */
     int32_t n_segments;         /* segments the last loop ran in (1 = one call)     */
+    int32_t step_path;          /* kernels the last loop's steps ran on: 0 one workgroup per sample (fused), 1 batch-level, 2 sample-split */
 } ls_timing;
 
 int ls_abi_version(void);
@@ -211,10 +212,12 @@ int ls_commit_weights(ls_handle* h);
 
 int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; default FP32 */
 /* Which kernels a 34-frame model's steps run on.  0 (default): chosen per prepared batch -- the fused kernel gives every sample a
- * workgroup (= one CU: a step costs one CU's time for eight layers however small the batch), the batch-level kernels of the
- * long-sequence path spread the same rows over the whole chip and are faster for small batches; 1: always one workgroup per
- * sample; 2: always batch-level (exact fp32, both CFG passes always evaluated).  Same arithmetic either way, different summation
- * order: results agree to ~1e-5, not bitwise.  Takes effect at the next ls_prepare. */
+ * workgroup (= one CU: a step costs one CU's time for eight layers however small the batch); the sample-split kernel spreads a
+ * sample over 16 workgroups (2 CFG passes x 8 channel slices) that exchange LayerNorm partials and rows through L2 inside ONE launch
+ * per step, and takes the small batches; 1: always one workgroup per sample; 2: the batch-level kernels of the long-sequence path
+ * (21 launches per step; exact fp32, both CFG passes always evaluated); 3: always the sample-split kernel (exact fp32).  Same
+ * arithmetic every way, different summation order: results agree to ~1e-5, not bitwise.  Takes effect at the next ls_prepare;
+ * ls_timing.step_path reports what ran. */
 int ls_set_path(ls_handle* h, int mode);
 int ls_set_schedule(ls_handle* h, const ls_schedule* s);
 int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */

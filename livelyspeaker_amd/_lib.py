@@ -78,7 +78,7 @@ class LsPostConfig(C.Structure):
 class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32), ("single_pass", C.c_int32),
-                ("tape_upload_ms", C.c_float), ("n_segments", C.c_int32)]
+                ("tape_upload_ms", C.c_float), ("n_segments", C.c_int32), ("step_path", C.c_int32)]
 
 
 class LsTrainConfig(C.Structure):
@@ -222,7 +222,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_eval_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     lib.ls_eval_commit_weights.argtypes = [C.c_void_p]
     lib.ls_eval_features.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    if lib.ls_abi_version() != 2:
+    if lib.ls_abi_version() != 3:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -335,8 +335,8 @@ class Engine:
     """One handle = one GPU. Thin, typed wrapper over the C-ABI; all arrays in/out are host numpy
     (torch CUDA tensors on the same device may be passed to ``sample``/``prepare`` via ``*_device``)."""
 
-    #: which kernels the steps of a 34-frame model run on when the caller does not say: "auto" (batch-level kernels for small batches,
-    #: one workgroup per sample otherwise), "fused", "batch" (ls_set_path)
+    #: which kernels the steps of a 34-frame model run on when the caller does not say: "auto" (the sample-split kernel for small
+    #: batches, one workgroup per sample otherwise), "fused", "batch", "coop" (ls_set_path)
     default_path = "auto"
 
     def __init__(self, njoints, nfeats, n_prefix_tokens, audio_len, n_emotions=0, nframes=34, n_pre_seq=4,
@@ -383,9 +383,10 @@ class Engine:
         self.precision = mode
 
     def set_path(self, mode):
-        """'auto' (default: batch-level kernels for small batches, one workgroup per sample otherwise), 'fused', 'batch'; applies
-        from the next prepare()."""
-        code = {"auto": 0, "fused": 1, "batch": 2}.get(mode, mode)
+        """'auto' (default: the sample-split kernel for small batches, one workgroup per sample otherwise), 'fused', 'batch'
+        (batch-level kernels, 21 launches per step), 'coop' (sample-split kernel); applies from the next prepare().  None = 'auto'."""
+        mode = "auto" if mode is None else mode
+        code = {"auto": 0, "fused": 1, "batch": 2, "coop": 3}.get(mode, mode)
         self._check(self.lib.ls_set_path(self.h, int(code)), "ls_set_path")
         self.path = mode
 

@@ -62,7 +62,12 @@ struct ls_handle {
     int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
     bool fused = true;      // the model HAS the fused kernel (34 frames)
     bool use_long = false;  // the prepared batch runs the batch-level kernels (always when !fused; small batches of a fused model)
-    int path_mode = 0;      // ls_set_path: 0 auto, 1 one workgroup per sample (fused kernel), 2 batch-level kernels
+    int path_mode = 0;      // ls_set_path: 0 auto, 1 one workgroup per sample (fused kernel), 2 batch-level kernels, 3 sample-split kernel
+    bool use_coop = false;  // the prepared batch runs the sample-split kernel (ls_coop_kernel.h: 16 workgroups per sample)
+    DevBuf wtok1_img;       // token-mix operand of one pass (sample-split kernel)
+    DevBuf co_x, co_x2, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
+    unsigned coop_launches = 0;                        // launches since the granule words were zeroed: epoch = 64 * ordinal
+    unsigned coop_err_host = 0;
     int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
     DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_wcf, lw_bcf, lw_wsum, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
@@ -197,6 +202,8 @@ int build_fused_images(ls_handle* h) {
         l2a((size_t)L * D), l2b((size_t)L * D), ww((size_t)L * kNT * MK * 64), bt((size_t)L * 80, 0.f);
     std::vector<unsigned short> wch_hi((size_t)L * D * D), wch_lo((size_t)L * D * D);
     const int KS = (R + 31) / 32;
+    const int MK1 = (S + 3) / 4;
+    std::vector<float> wt1((size_t)L * 3 * MK1 * 64);
     std::vector<unsigned short> wwh((size_t)L * kNT * KS * 64 * 8), wwl((size_t)L * kNT * KS * 64 * 8);
     char key[160];
     for (int l = 0; l < L; ++l) {
@@ -271,6 +278,13 @@ int build_fused_images(ls_handle* h) {
                         wwl[o] = f32_to_bf16(v - bf16_to_f32(wwh[o]));
                     }
         for (int r = 0; r < R; ++r) bt[(size_t)l * 80 + r] = (*b1)[r % S];
+        // wtok1_img[l][t][m][lane] = Wt[r = 16t + (lane&15)][r' = 4m + (lane>>4)] of ONE pass, zero outside S x S (ls_coop_kernel.h)
+        for (int t = 0; t < 3; ++t)
+            for (int m = 0; m < MK1; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = 16 * t + (lane & 15), rp = 4 * m + (lane >> 4);
+                    wt1[(((size_t)l * 3 + t) * MK1 + m) * 64 + lane] = (r < S && rp < S) ? (*Wt)[(size_t)r * S + rp] : 0.f;
+                }
     }
     const auto* Win = find_w(h, "input_mapping.weight", (size_t)D * KIN);        // RAG.py:62
     const auto* bin = find_w(h, "input_mapping.bias", D);
@@ -323,7 +337,7 @@ int build_fused_images(ls_handle* h) {
     if ((rc = upload(h, h->ww_hi_img, wwh.data(), wwh.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->ww_lo_img, wwl.data(), wwl.size() * sizeof(unsigned short))) != LS_OK) return rc;
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
-    UP(ww_img, ww); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
+    UP(ww_img, ww); UP(wtok1_img, wt1); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
 #undef UP
     DevWeights dw{};
     dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
@@ -332,7 +346,7 @@ int build_fused_images(ls_handle* h) {
     dw.ww_hi_img = static_cast<const unsigned short*>(h->ww_hi_img.p);
     dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
-    dw.ww_img = h->ww_img.f(); dw.btok_rows = h->btok_rows.f();
+    dw.ww_img = h->ww_img.f(); dw.wtok1_img = h->wtok1_img.f(); dw.btok_rows = h->btok_rows.f();
     dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
     if ((rc = upload(h, h->devw, &dw, sizeof dw)) != LS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -543,6 +557,21 @@ int ensure_temb_table(ls_handle* h) {
 // pair: the single-pass variant (two samples' cond pass per workgroup), legal when every guidance scale is 1
 hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
     s.batch = B;
+    if (h->use_coop && !s.trace) {
+        // sample-split kernel: 16 (CFG) or 8 (single pass) workgroups per sample, as many samples per launch as are resident at once
+        const int np = pair ? 1 : 2, per = kCoopMaxGroups / np;
+        for (int b0 = 0; b0 < B; b0 += per) {
+            StepArgs c = s;
+            c.cx = h->co_x.f(); c.cx2 = h->co_x2.f();
+            c.cgran = static_cast<unsigned long long*>(h->co_gran.p); c.cflag = static_cast<unsigned long long*>(h->co_flag.p);
+            c.cerr = static_cast<unsigned*>(h->co_err.p);
+            c.epoch = (++h->coop_launches) * 64u;
+            c.b0 = b0; c.npass = np;
+            hipError_t e = launch_step_coop(h->var, c, B - b0 < per ? B - b0 : per, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     // one workgroup per sample (fused kernel) unless the prepared batch runs on the batch-level kernels; per-sample timestep rows and
     // the residual-stream trace exist in the fused kernel only
     if (h->fused && !(h->use_long && s.temb_stride == 0 && !s.trace)) return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
@@ -646,15 +675,44 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 // step) and win below kLongMaxBatch samples (measured: profiles/r03 small-batch table).  34-frame models only choose; other frame
 // counts have no fused kernel.
 constexpr int kLongMaxBatch = 160;
+// The sample-split kernel (ls_coop_kernel.h) spreads a sample over 16 workgroups inside ONE launch per step; it takes the small
+// batches (measured crossovers: profiles/r04 throughput-vs-batch table).  Exact fp32 only.
+constexpr int kCoopMaxBatch = 128;
 void decide_path(ls_handle* h) {
-    const bool before = h->use_long;
+    const bool before = h->use_long, before_c = h->use_coop;
+    h->use_coop = false;
     if (!h->fused) h->use_long = true;
-    else if (h->precision != 0 || h->lw_wtp.p == nullptr) h->use_long = false;
+    else if (h->precision != 0) h->use_long = false;
     else if (h->path_mode == 1) h->use_long = false;
-    else if (h->path_mode == 2) h->use_long = true;
-    else h->use_long = h->B > 0 && h->B <= kLongMaxBatch;
-    if (before != h->use_long) free_graph(h);
+    else if (h->path_mode == 2) h->use_long = h->lw_wtp.p != nullptr;
+    else if (h->path_mode == 3) { h->use_long = false; h->use_coop = true; }
+    else {
+        h->use_coop = h->B > 0 && h->B <= kCoopMaxBatch;
+        h->use_long = !h->use_coop && h->lw_wtp.p != nullptr && h->B > 0 && h->B <= kLongMaxBatch;
+    }
+    if (before != h->use_long || before_c != h->use_coop) free_graph(h);
 }
+
+// zero the granule / flag words of the sample-split kernel (stream-ordered: a memset node when captured) and restart the epochs
+hipError_t coop_reset(ls_handle* h, hipStream_t st) {
+    if (!h->use_coop) return hipSuccess;
+    hipError_t e = hipMemsetAsync(h->co_gran.p, 0, h->co_gran.bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(h->co_flag.p, 0, h->co_flag.bytes, st);
+    h->coop_launches = 0;
+    return e;
+}
+
+// after a stream synchronisation: did a hand-off spin of the sample-split kernel run out?  (Never observed; a result computed past a
+// timeout is garbage, so the call fails loudly.)
+int coop_check(ls_handle* h) {
+    if (!h->use_coop) return LS_OK;
+    unsigned v = 0;
+    HIPCHK(h, hipMemcpy(&v, h->co_err.p, sizeof v, hipMemcpyDeviceToHost));
+    if (!v) return LS_OK;
+    HIPCHK(h, hipMemset(h->co_err.p, 0, sizeof v));
+    return fail(h, LS_EHIP, "sample-split step kernel: an inter-workgroup hand-off timed out; the results of this call are invalid");
+}
+int step_path_code(const ls_handle* h) { return h->use_coop ? 2 : (h->use_long ? 1 : 0); }
 
 // upload timing of a slot whose copy has been enqueued: wait for it (long done in steady state) and add it to the loop's total
 int close_upload(ls_handle* h, int slot) {
@@ -706,6 +764,7 @@ int sample_segment(ls_handle* h, const ls_sample_args* a) {
             HIPCHK(h, h->dump.ensure((size_t)a->n_dump * nx));
             if (old != h->dump.p) free_graph(h);
         }
+        HIPCHK(h, coop_reset(h, st));
         h->seg_next = 0; h->seg_index = 0; h->seg_skip = a->skip_timesteps; h->seg_sampler = a->sampler; h->seg_upload_ms = 0.f;
         h->slot_used[0] = h->slot_used[1] = false;
         HIPCHK(h, hipEventRecord(h->ev[1], st));
@@ -771,6 +830,8 @@ int sample_segment(ls_handle* h, const ls_sample_args* a) {
     HIPCHK(h, hipStreamSynchronize(st));
     resolve_prepare_timing(h, true);
     if ((rc = close_upload(h, 0)) != LS_OK || (rc = close_upload(h, 1)) != LS_OK) return rc;
+    if ((rc = coop_check(h)) != LS_OK) return rc;
+    h->timing.step_path = step_path_code(h);
     HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
     HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
     h->timing.n_step_launches = n_exec;
@@ -851,6 +912,16 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     }
     e = init_step_kernels();
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
+    if (h->fused) {         // sample-split kernel: LDS opt-in and one launch's worth of exchange workspaces (independent of the batch)
+        e = init_coop_kernels();
+        if (e == hipSuccess) e = h->co_x.ensure((size_t)kCoopMaxGroups * 36 * kD * sizeof(float));
+        if (e == hipSuccess) e = h->co_x2.ensure((size_t)kCoopMaxGroups * 36 * kD * sizeof(float));
+        if (e == hipSuccess) e = h->co_gran.ensure((size_t)kCoopMaxGroups * 2 * 36 * 8 * 2 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = h->co_flag.ensure((size_t)kCoopMaxGroups * 16 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = h->co_err.ensure(sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemsetAsync(h->co_err.p, 0, sizeof(unsigned), h->stream);
+        if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "sample-split kernel setup: %s", hipGetErrorString(e)); }
+    }
 #ifdef LS_DEBUG
     if (h->prof_on) {
         std::vector<unsigned long long> z((size_t)kWaves * kProfPoints, 0ull);
@@ -878,7 +949,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_x2, &h->co_gran, &h->co_flag, &h->co_err};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -935,7 +1006,9 @@ int ls_set_precision(ls_handle* h, int mode) {
 
 int ls_set_path(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
-    if (mode < 0 || mode > 2) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels)", mode);
+    if (mode < 0 || mode > 3) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel)", mode);
+    if (mode == 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no sample-split kernel", kT);
+    if (mode == 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split kernel is exact fp32 only");
     if (mode == 2 && h->fused && h->lw_wtp.p == nullptr && h->committed) return fail(h, LS_EUNSUPPORTED, "batch-level kernels need S <= 160");
     if (mode == 1 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no fused kernel", kT);
     if (mode != h->path_mode) { h->path_mode = mode; h->prepared = false; free_graph(h); }      // takes effect at the next ls_prepare (workspaces)
@@ -1128,6 +1201,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
         HIPCHK(h, h->trace.ensure((size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float)));
         s.trace = h->trace.f();
     }
+    HIPCHK(h, coop_reset(h, st));
     HIPCHK(h, run_step(h, s, B, false, st));      // model(x, t, y) parity entry: both passes always
     float* outs[3] = {a->out_cond, a->out_uncond, a->out_cfg};
     const float* srcs[3] = {h->fwd_c.f(), h->fwd_u.f(), h->fwd_cfg.f()};
@@ -1137,7 +1211,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
         if ((rc = egress(h, outs[i], h->xio.f(), nx, od)) != LS_OK) return rc;
     }
     if (a->trace && (rc = egress(h, a->trace, h->trace.f(), (size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float), od)) != LS_OK) return rc;
-    if (!(a->no_sync && od)) HIPCHK(h, hipStreamSynchronize(st));
+    if (!(a->no_sync && od)) { HIPCHK(h, hipStreamSynchronize(st)); if ((rc = coop_check(h)) != LS_OK) return rc; }
     return LS_OK;
 }
 
@@ -1181,6 +1255,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     HIPCHK(h, hipMemcpyAsync(h->eps.f(), a->eps_cond, (size_t)B * kD * sizeof(float), kind, st));
     HIPCHK(h, hipMemcpyAsync(h->eps.f() + (size_t)B * kD, a->eps_uncond, (size_t)B * kD * sizeof(float), kind, st));
     if ((rc = ingest(h, h->noise, a->noise, nx, od)) != LS_OK) return rc;
+    HIPCHK(h, coop_reset(h, st));
     StepArgs s;
     fill_common(h, s);
     s.clip_denoised = a->clip_denoised;
@@ -1234,7 +1309,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
         HIPCHK(h, launch_from_internal(h->fwd_cfg.f(), h->xtmp.f(), B, JF, st, h->T));
         if ((rc = egress(h, a->pred_xstart, h->xtmp.f(), nx, od)) != LS_OK) return rc;
     }
-    if (!(a->no_sync && od)) HIPCHK(h, hipStreamSynchronize(st));
+    if (!(a->no_sync && od)) { HIPCHK(h, hipStreamSynchronize(st)); if ((rc = coop_check(h)) != LS_OK) return rc; }
     return LS_OK;
 }
 
@@ -1333,12 +1408,13 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     {
         char keybuf[256];
         snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d L%d", h->precision, B, a->sampler, (double)a->eta,
-                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, (int)h->use_long);
+                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, step_path_code(h));
         key = keybuf;
         if (inpaint) key += inp_noised ? " I2" : " I1";
         for (int d = 0; d < a->n_dump; ++d) key += "," + std::to_string(a->dump_steps[d]);      // the whole list, however long
     }
     auto enqueue_loop = [&]() -> int {
+        HIPCHK(h, coop_reset(h, st));              // a memset node at the head of the captured loop: replays start from zeroed granules
         for (int k = 0; k < n_exec; ++k) {
             const int i = n_exec - 1 - k;
             StepArgs s;
@@ -1405,6 +1481,8 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     HIPCHK(h, hipEventRecord(h->ev[3], st));
     HIPCHK(h, hipStreamSynchronize(st));
     resolve_prepare_timing(h, true);
+    if ((rc = coop_check(h)) != LS_OK) return rc;
+    h->timing.step_path = step_path_code(h);
     HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
     HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
     h->timing.n_step_launches = n_exec;

@@ -36,6 +36,7 @@ struct DevWeights {
     const unsigned short* ww_lo_img;
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
+    const float* wtok1_img;  // [L][3][ceil(S/4)][64]   token-mix operand of ONE pass (sample-split kernel, ls_coop_kernel.h)
     const float* btok_rows;  // [L][80]
     const float* winx_img;   // [8][2 passes][KXQ][2 cb][64][4]   x_t columns of input_mapping
     const float* wout_img;   // [NOB][32][64][4]   poseFinal, k in natural order (operand staged in LDS)
@@ -88,6 +89,15 @@ struct StepArgs {
     float* tr_xout;          // [tr_B*S][512] output of the last layer
     int tr_B;
     float* trace;            // [B][L+1][2S][512] or null
+    // ---- sample-split kernel (k_coop, ls_coop_kernel.h): exchange workspaces of ONE launch (kCoopMaxGroups (sample, pass) groups)
+    float* cx;               // [groups][36][512] raw rows entering channel mixing (the LayerNorm-2 hand-off)
+    float* cx2;              // [groups][36][512] final rows (the poseFinal hand-off)
+    unsigned long long* cgran;   // [groups][2 areas][36 rows][8 slices][2] {tag, value} granules: (mean, M2) partials of the two LayerNorms
+    unsigned long long* cflag;   // [samples][16] {tag, -} ready flags of the final rows
+    unsigned* cerr;          // set non-zero by a workgroup whose bounded spin ran out
+    unsigned epoch;          // tag base of this launch: unique among the launches since the granule words were last zeroed
+    int b0;                  // first sample of this launch
+    int npass;               // 2: cond + uncond (CFG); 1: cond only (every guidance scale is 1)
 #ifdef LS_DEBUG
     // Profiling builds only (tools/phase_profile.py, tools/ab_variants.py compile their own -DLS_DEBUG variant of the library):
     // the shipped library has neither the fields nor the code that reads them, so no environment variable can change its results.
@@ -128,6 +138,11 @@ struct LongStepArgs {
     float c0, c1, c2, c3, c4;
 };
 hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st);
+
+// sample-split step kernel for small batches (ls_coop.hip): 16 workgroups per sample (2 passes x 8 channel slices of 4 waves)
+constexpr int kCoopMaxGroups = 64;     // (sample, pass) groups of one launch: 512 workgroups = two per CU, all resident at once
+hipError_t init_coop_kernels();
+hipError_t launch_step_coop(Variant v, const StepArgs& a, int nsamples, hipStream_t st);
 
 // prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
 // pair: 0 = CFG (cond + uncond pass of one sample per workgroup), 1 = single pass (guidance scale 1: two samples per workgroup)
