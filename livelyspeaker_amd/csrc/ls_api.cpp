@@ -65,9 +65,11 @@ struct ls_handle {
     int path_mode = 0;      // ls_set_path: 0 auto, 1 one workgroup per sample (fused kernel), 2 batch-level kernels, 3 sample-split kernel
     bool use_coop = false;  // the prepared batch runs the sample-split kernel (ls_coop_kernel.h: 16 workgroups per sample)
     DevBuf wtok1_img;       // token-mix operand of one pass (sample-split kernel)
-    DevBuf co_x, co_x2, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
+    DevBuf co_x, co_part, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
     unsigned coop_launches = 0;                        // launches since the granule words were zeroed: epoch = 64 * ordinal
     unsigned coop_err_host = 0;
+    int coop_groups_max = kCoopMaxGroups, coop_groups = 0;   // (sample, pass) groups per launch: cap, and what the workspaces hold
+    int coop_xmap = 0;      // blockIdx -> (group, slice) mapping of the sample-split kernel (speed only; LS_COOP_XMAP in -DLS_DEBUG builds)
     int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
     DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_wcf, lw_bcf, lw_wsum, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
@@ -340,7 +342,7 @@ int build_fused_images(ls_handle* h) {
     UP(ww_img, ww); UP(wtok1_img, wt1); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
 #undef UP
     DevWeights dw{};
-    dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f();
+    dw.wch_img = h->wch_img.f(); dw.bch = h->bch.f(); dw.wsum = h->lw_wsum.f();
     dw.wch_hi_img = static_cast<const unsigned short*>(h->wch_hi_img.p);
     dw.wch_lo_img = static_cast<const unsigned short*>(h->wch_lo_img.p);
     dw.ww_hi_img = static_cast<const unsigned short*>(h->ww_hi_img.p);
@@ -559,14 +561,14 @@ hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st)
     s.batch = B;
     if (h->use_coop && !s.trace) {
         // sample-split kernel: 16 (CFG) or 8 (single pass) workgroups per sample, as many samples per launch as are resident at once
-        const int np = pair ? 1 : 2, per = kCoopMaxGroups / np;
+        const int np = pair ? 1 : 2, per = h->coop_groups / np;
         for (int b0 = 0; b0 < B; b0 += per) {
             StepArgs c = s;
-            c.cx = h->co_x.f(); c.cx2 = h->co_x2.f();
+            c.cx = h->co_x.f(); c.cpart = h->co_part.f();
             c.cgran = static_cast<unsigned long long*>(h->co_gran.p); c.cflag = static_cast<unsigned long long*>(h->co_flag.p);
             c.cerr = static_cast<unsigned*>(h->co_err.p);
             c.epoch = (++h->coop_launches) * 64u;
-            c.b0 = b0; c.npass = np;
+            c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap;
             hipError_t e = launch_step_coop(h->var, c, B - b0 < per ? B - b0 : per, st);
             if (e != hipSuccess) return e;
         }
@@ -879,6 +881,8 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
 #ifdef LS_DEBUG
     if (const char* ab = getenv("LS_ABLATE")) h->ablate = atoi(ab);
     if (const char* pr = getenv("LS_PROF")) { h->prof_on = true; h->prof_wg = atoi(pr); }
+    if (const char* xm = getenv("LS_COOP_XMAP")) h->coop_xmap = atoi(xm);
+    if (const char* gm = getenv("LS_COOP_GROUPS")) h->coop_groups_max = atoi(gm);
 #endif
     h->var = var;
     h->JF = JF;
@@ -914,10 +918,6 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
     if (h->fused) {         // sample-split kernel: LDS opt-in and one launch's worth of exchange workspaces (independent of the batch)
         e = init_coop_kernels();
-        if (e == hipSuccess) e = h->co_x.ensure((size_t)kCoopMaxGroups * 36 * kD * sizeof(float));
-        if (e == hipSuccess) e = h->co_x2.ensure((size_t)kCoopMaxGroups * 36 * kD * sizeof(float));
-        if (e == hipSuccess) e = h->co_gran.ensure((size_t)kCoopMaxGroups * 2 * 36 * 8 * 2 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = h->co_flag.ensure((size_t)kCoopMaxGroups * 16 * sizeof(unsigned long long));
         if (e == hipSuccess) e = h->co_err.ensure(sizeof(unsigned));
         if (e == hipSuccess) e = hipMemsetAsync(h->co_err.p, 0, sizeof(unsigned), h->stream);
         if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "sample-split kernel setup: %s", hipGetErrorString(e)); }
@@ -949,7 +949,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_x2, &h->co_gran, &h->co_flag, &h->co_err};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -1131,6 +1131,18 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, h->T));   // y['emo'][:, 0]
     }
     { const int keepB = h->B; h->B = B; decide_path(h); h->B = keepB; }
+    if (h->use_coop) {      // exchange workspaces of the sample-split kernel: one launch's worth of (sample, pass) groups
+        const int groups = 2 * B < h->coop_groups_max ? 2 * B : h->coop_groups_max;
+        const void* old[4] = {h->co_x.p, h->co_part.p, h->co_gran.p, h->co_flag.p};
+        const size_t before = h->co_x.bytes;
+        HIPCHK(h, h->co_x.ensure((size_t)groups * 36 * kD * sizeof(float)));
+        if (h->co_x.bytes != before) HIPCHK(h, hipMemsetAsync(h->co_x.p, 0, h->co_x.bytes, st));     // rows a 35-row pass never writes are pulled into LDS (never read)
+        HIPCHK(h, h->co_part.ensure((size_t)groups * 8 * 36 * (size_t)h->NOB * 16 * sizeof(float)));
+        HIPCHK(h, h->co_gran.ensure((size_t)groups * 2 * 36 * 8 * 2 * sizeof(unsigned long long)));
+        HIPCHK(h, h->co_flag.ensure((size_t)groups * 16 * sizeof(unsigned long long)));
+        if (old[0] != h->co_x.p || old[1] != h->co_part.p || old[2] != h->co_gran.p || old[3] != h->co_flag.p) free_graph(h);
+        h->coop_groups = groups;
+    }
     if (h->use_long) {      // workspaces of the batch-level path: token sequences of both passes (two buffers), row partials, poseFinal output
         const void* old[5] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p, h->lx_xpad.p};
         const size_t rows = ((size_t)2 * B * h->S + 127) / 128 * 128;      // whole 128-row GEMM tiles (the fused channel-mixing product runs over the pad rows too)

@@ -18,10 +18,12 @@ hipError_t init_coop_kernels() {
 // One launch = `nsamples` samples starting at a.b0, a.npass passes each, 8 slice workgroups per (sample, pass).  The caller keeps the
 // grid within what is resident at once (kCoopMaxGroups groups = 512 workgroups, two per CU): the slices of a group wait for each other.
 hipError_t launch_step_coop(Variant v, const StepArgs& a, int nsamples, hipStream_t st) {
-    if (nsamples < 1 || nsamples * a.npass > kCoopMaxGroups || (a.npass != 1 && a.npass != 2)) return hipErrorInvalidValue;
-    const dim3 grid(nsamples * a.npass * kCoopSlices);
-    if (v == kTED) hipLaunchKernelGGL((k_coop<35, 1, 27>), grid, dim3(kCoopThreads), coop_lds_bytes(), st, a);
-    else hipLaunchKernelGGL((k_coop<36, 2, 282>), grid, dim3(kCoopThreads), coop_lds_bytes(), st, a);
+    if (nsamples < 1 || (a.npass != 1 && a.npass != 2)) return hipErrorInvalidValue;
+    StepArgs c = a;
+    c.ngroups = nsamples * a.npass;
+    const dim3 grid((a.xmap ? (c.ngroups + 7) / 8 * 8 : c.ngroups) * kCoopSlices);
+    if (v == kTED) hipLaunchKernelGGL((k_coop<35, 1, 27>), grid, dim3(kCoopThreads), coop_lds_bytes(), st, c);
+    else hipLaunchKernelGGL((k_coop<36, 2, 282>), grid, dim3(kCoopThreads), coop_lds_bytes(), st, c);
     return hipGetLastError();
 }
 

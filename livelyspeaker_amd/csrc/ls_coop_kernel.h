@@ -14,9 +14,16 @@
 //     holds one eighth of the weights (1 MB).  Placement is a speed matter only -- every hand-off below is placement-independent.
 //   * what crosses workgroups (the 8 slices of one (sample, pass)), per layer:
 //       SYNC1  LayerNorm-1: (mean, M2) of each row over the slice's 64 channels                      288 B per workgroup
-//       SYNC2  LayerNorm-2: the same, plus the slice of the raw rows x[S][64] (channel mixing contracts over all 512)  9 KB
-//     and once per step the final rows (poseFinal contracts over all 512 channels; the CFG combination needs both passes).
+//       SYNC2  LayerNorm-2: the same, plus the slice's rows x[S][64] (channel mixing contracts over all 512 channels)  9 KB
+//     and once per step partial poseFinal outputs (poseFinal contracts over all 512 channels; the CFG combination needs both passes).
 //     Token mixing contracts over ROWS and stays inside the workgroup.
+//   * SYNC2 never blocks: LayerNorm 2 is folded AROUND the channel-mixing product (as ls_long.hip does),
+//         LN2(x) W'^T + b' = rstd2 * ((x - mu1) W'^T - (mu2 - mu1) wsum) + b',      wsum[n] = sum_k W'[n][k],
+//     with the rows centred on the LayerNorm-1 mean every slice already holds (no cancellation: mu2 - mu1 is small), so the MFMAs
+//     need no statistic: a workgroup starts on its OWN 64 channels of k straight from registers, pulls the other slices' rows
+//     global -> LDS by LDS-DMA (no VGPR round trip) one slice ahead of the MFMAs as their ready flags come up, and applies
+//     (mu2, rstd2) -- long arrived by then -- in the epilogue.  The rows travel and sit in LDS as [slice][k block of 16][row][16]:
+//     every MFMA B-operand read and every DMA chunk is one contiguous, conflict-free 1 KiB.
 //   * hand-off protocol (cdna_hip_programming.md section 6, Guideline 16, forms R1 / R2): payload = 16-byte write-through (sc1)
 //     stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, then the row statistics are published as 8-byte
 //     {tag, value} granules with relaxed agent-scope atomic stores -- the granules ARE the flags.  Consumers poll the granules with
@@ -25,6 +32,9 @@
 //     timeout the workgroup records it in StepArgs::cerr and carries on (the host then fails the call).
 //   * single-buffered payload is safe: a slice rewrites its rows of layer l+1 only after SYNC1(l+1), which every consumer reaches
 //     after its reads of layer l; the statistics alternate between two granule areas for the same reason.
+//   * poseFinal: every slice contracts its own 64 channels for all outputs (operand = its rows, staged in LDS), publishes the
+//     partial [S][J*F]; the (frame, 4 outputs) quads of the sample are then dealt out to its 16 workgroups, which sum the 8 partials
+//     of each pass in a fixed order, combine the passes (CFG) and apply the sampler update.
 #pragma once
 #include "ls_step_common.h"
 #include "ls_lanes.h"
@@ -37,8 +47,9 @@ constexpr int kCoopSlices = 8;             // channel slices of 64
 constexpr int kCoopRows = 36;              // rows of one pass in the exchange buffers (S <= 36)
 constexpr int kCoopU1Stride = 80;          // LDS row stride of the token-mix operand [S][64]: = 16 mod 32, conflict-free column reads
 constexpr unsigned kCoopSpinLimit = 1u << 18;       // polls (~1-2 us each) before a hand-off wait gives up: waits are < 1 ms when the slices are resident
-// LDS: psum [4][48] f2 | stat [48] f2 | REM [4][4][16] | U [36][520]
-constexpr int kCoopLdsFloats = 2 * kCoopWaves * 48 + 2 * 48 + kCoopWaves * 4 * 16 + kCoopRows * kUStride;
+constexpr int kCoopSliceFloats = 4 * kCoopRows * 16;   // one slice's rows in exchange order [4 k blocks][36 rows][16]: 9216 B
+// LDS: psum [4][48] f2 | stat [48] f2 | REM [4][4][16] | U [8 slices][4][36][16]
+constexpr int kCoopLdsFloats = 2 * kCoopWaves * 48 + 2 * 48 + kCoopWaves * 4 * 16 + kCoopSlices * kCoopSliceFloats;
 
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long* gu64p;
@@ -52,6 +63,11 @@ __device__ __forceinline__ void st_sc1(f4 v, wrsrc_t r, int voff) {
 __device__ __forceinline__ unsigned long long gran_load(const unsigned long long* p) {
     return __hip_atomic_load((gu64p)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+typedef __attribute__((address_space(3))) void* coop_lds_vp;
+// 1 KiB global -> LDS, lane i's 16 bytes to lds + 16 i (LDS-DMA, no VGPR round trip); sc1: never served from this CU's L1
+__device__ __forceinline__ void dma_sc1(wrsrc_t r, float* lds, int lane_bytes, int wave_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (coop_lds_vp)lds, 16, lane_bytes, wave_bytes, 0, 16);
+}
 __device__ __forceinline__ void gran_store(unsigned long long* p, unsigned tag, float v) {
     __hip_atomic_store((gu64p)p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -60,29 +76,37 @@ template <int S, int NPRE, int JF>
 __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
     constexpr int KXQ = (JF + 15) / 16;
     constexpr int KXP = KXQ * 16;
+    constexpr int XSTR = KXP + 4;               // LDS row stride of the x_t staging
     constexpr int NOB = (JF + 15) / 16;
+    constexpr int NOBP = NOB * 16;              // padded output columns
     constexpr int NT1 = 3;                      // 16-row tiles of one pass
     constexpr int NREM = S - 32;                // rows of the ragged third tile: 3 (TED) | 4 (BEAT)
     constexpr bool kRemMfma = (NREM % 4 == 0);  // BEAT: one v_mfma_f32_4x4x1 row group; TED: scalar FMAs (see k_step)
     constexpr int NRV = kRemMfma ? 1 : NREM;
     constexpr int MK1 = (S + 3) / 4;            // k steps of the token-mix GEMM of one pass
-    constexpr int NU = NOB * NT1;               // output-projection work units (out block, row tile)
+    constexpr int NQUAD = kT * (NOBP / 4);      // (frame, 4 output columns) quads of one sample
     static_assert(S > 32 && S <= kCoopRows, "one pass = two full row tiles + a ragged one");
     static_assert(NREM >= 1 && NREM <= 4, "ragged tile");
+    static_assert(S * XSTR <= kCoopSlices * kCoopSliceFloats, "x_t staging fits the operand buffer");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f2* pst = reinterpret_cast<f2*>(smem);                         // [4 waves][48 rows] (mean, M2) over 16 channels
     f2* stat = pst + kCoopWaves * 48;                              // [48 rows] (mean, rstd) over all 512 channels
     float* REM = smem + 2 * kCoopWaves * 48 + 2 * 48;              // [4 waves][4][16] ragged-row patch
-    float* U = REM + kCoopWaves * 4 * 16;                          // [36][520] channel-mix operand; overlays: x_t staging, token-mix operand
+    float* U = REM + kCoopWaves * 4 * 16;                          // [8 slices][4 k blocks][36 rows][16]; overlays: x_t staging, token-mix operand
 
     const int tid = threadIdx.x;
     int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
-    const int c = bid & 7;                                          // channel slice
     const int np = a.npass;
-    const int pg = bid >> 3;                                        // launch-local (sample, pass) group
+    // blockIdx -> (group, slice).  xmap 0: slice = bid % 8, i.e. slice c of every group on XCD c (each XCD's L2 holds one eighth of the
+    // weights; every row hand-off crosses XCDs).  xmap 1: group = 8 (bid / 64) + bid % 8, slice = (bid / 8) % 8, i.e. the 8 slices of a
+    // group on ONE XCD (a published slice is fetched from the memory side once per XCD, its other six readers hit L2; each XCD streams
+    // all the weights).  Observed round-robin placement; a different placement changes only speed.
+    const int c = a.xmap ? ((bid >> 3) & 7) : (bid & 7);            // channel slice
+    const int pg = a.xmap ? ((bid >> 6) * 8 + (bid & 7)) : (bid >> 3);      // launch-local (sample, pass) group
+    if (pg >= a.ngroups) return;                                    // xmap 1 rounds the grid up to whole sets of 8 groups
     const int p = np == 2 ? (pg & 1) : 0;
     const int bl = np == 2 ? (pg >> 1) : pg;                        // launch-local sample
     const int b = a.b0 + bl;                                        // sample of the prepared batch
@@ -99,10 +123,18 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
     auto valid_of = [&](int t) { return 16 * t + 15 < S ? true : 16 * t + s16 < S; };
     auto rowc_of = [&](int t) { const int r = 16 * t + s16; return (16 * t + 15 < S || r < S) ? r : S - 1; };
 
-    float* xg = a.cx + (size_t)pg * kCoopRows * kD;                 // raw rows of this (sample, pass): [36][512]
+    float* xg = a.cx + (size_t)pg * kCoopSlices * kCoopSliceFloats;     // centred rows of this (sample, pass), exchange order
     unsigned long long* gran = a.cgran + (size_t)pg * 2 * kCoopRows * kCoopSlices * 2;   // [2 areas][36 rows][8 slices][2] granules
     unsigned spin_bad = 0;
-
+    // phase stamps, -DLS_DEBUG builds only (tools/coop_profile.py): lane 0 of every wave of one workgroup records s_memtime
+    auto stamp = [&](int idx) {
+#ifdef LS_DEBUG
+        if (a.prof && bid == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
+#else
+        (void)idx;
+#endif
+    };
+    stamp(0);
     f4 X[NT1];
 
     // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
@@ -155,7 +187,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
                 const int idx = tid + kCoopThreads * (it0 + itl);
                 if (idx < S * KXP) {
                     const int r = idx / KXP;
-                    U[r * kUStride + (idx - r * KXP)] = xv[itl];
+                    U[r * XSTR + (idx - r * KXP)] = xv[itl];
                 }
             }
         }
@@ -167,15 +199,19 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
         // winx_img[8][2][KXQ][2][64][4] (ls_api.cpp build_fused_images): 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1)
         const wrsrc_t wrs = wrsrc(a.W->winx_img);
         const int wsb = ((c * 2 + (w >> 1)) * KXQ * 2 + (w & 1)) * 1024;
-        f4 An = wload4(wrs, lane * 16, wsb);
-#pragma unroll 2
+        constexpr int EPF = KXQ < 4 ? KXQ : 4;                       // weight fragments in flight
+        f4 An[EPF];
+#pragma unroll
+        for (int k = 0; k < EPF; ++k) An[k] = wload4(wrs, lane * 16, wsb + k * 2048);
+#pragma unroll EPF
         for (int q = 0; q < KXQ; ++q) {
-            const f4 A = An;
-            const int qn = q + 1 < KXQ ? q + 1 : KXQ - 1;
-            An = wload4(wrs, lane * 16, wsb + qn * 2048);
+            const f4 A = An[0];
+#pragma unroll
+            for (int k = 0; k + 1 < EPF; ++k) An[k] = An[k + 1];
+            An[EPF - 1] = wload4(wrs, lane * 16, wsb + min(q + EPF, KXQ - 1) * 2048);
             f4 Bv[NT1];
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
+            for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * XSTR + 16 * q + 4 * g]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -187,10 +223,10 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
 
     // LN_spatial statistics (mlp_module.py:29-33) of every row over all 512 channels, across the 8 slice workgroups:
     // lane: two passes over its 4 channels; Chan's parallel-variance merge over the 4 lane groups (VALU swaps), the 4 waves (LDS) and
-    // the 8 slices (granules through L2 / memory).  `payload`: the caller has issued this workgroup's sc1 payload stores; they are
-    // drained before the granules -- which double as the payload's ready flags -- are published.
-    float mean[NT1], rstd[NT1];
-    auto ln_sync = [&](int area, unsigned tag, bool payload) {
+    // the 8 slices (granules through L2 / memory).
+    // ln_publish: this slice's (mean, M2) of every row -> granule area `area`.  `payload`: the caller has issued this workgroup's
+    // write-through payload stores; they are drained before the granules -- which double as the payload's ready flags -- go out.
+    auto ln_publish = [&](int area, unsigned tag, bool payload) {
 #pragma unroll
         for (int t = 0; t < NT1; ++t) {
             const f4 v = X[t];
@@ -217,7 +253,6 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
         }
         if (payload) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores
         __syncthreads();
-        unsigned long long* ga = gran + (size_t)area * kCoopRows * kCoopSlices * 2;
         if (tid < S) {                                                          // row tid: merge the 4 waves, publish the slice's partial
             f2 pw[kCoopWaves];
             float ms = 0.f, qs = 0.f;
@@ -227,16 +262,22 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
             float dd = 0.f;
 #pragma unroll
             for (int ww = 0; ww < kCoopWaves; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
-            unsigned long long* gp = ga + ((size_t)tid * kCoopSlices + c) * 2;
+            unsigned long long* gp = gran + (size_t)area * kCoopRows * kCoopSlices * 2 + ((size_t)tid * kCoopSlices + c) * 2;
             gran_store(gp, tag, mt);
             gran_store(gp + 1, tag, qs + 16.0f * dd);
         }
-        // gather: thread (row = tid >> 3, slice = tid & 7) + a second row 32 + (tid >> 3) for the first 8 * NREM threads
+    };
+    // ln_gather: wait for all 8 slices' partials of every row, merge -> stat[row] = (mean, rstd) and this lane's rows' values
+    float mean[NT1], rstd[NT1];
+    auto ln_gather = [&](int area, unsigned tag, int stamp_at) {
+        const unsigned long long* ga = gran + (size_t)area * kCoopRows * kCoopSlices * 2;
+        // thread (row = tid >> 3, slice = tid & 7) + a second row 32 + (tid >> 3) for the first 8 * NREM threads
         const int sl = tid & 7, r0 = tid >> 3, r1 = 32 + (tid >> 3);
         const bool has1 = tid < 8 * NREM;
         const unsigned long long* g0 = ga + ((size_t)r0 * kCoopSlices + sl) * 2;
         const unsigned long long* g1p = ga + ((size_t)(has1 ? r1 : r0) * kCoopSlices + sl) * 2;
         unsigned long long v0, v1, v2, v3;
+        stamp(stamp_at);
         for (unsigned spins = 0;; ++spins) {
             v0 = gran_load(g0); v1 = gran_load(g0 + 1);
             v2 = gran_load(g1p); v3 = gran_load(g1p + 1);
@@ -266,126 +307,175 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
     };
 
     const wrsrc_t xrs = uniform_rsrc(xg);
+    const f4 temb4 = *reinterpret_cast<const f4*>(a.temb + (size_t)b * a.temb_stride + chw);     // the same row at every block
+    stamp(1);
 
     // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
     for (int l = 0; l < a.layers; ++l) {
         fresh();
         {   // x = x + emb  (re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
-            const f4 e = *reinterpret_cast<const f4*>(a.temb + (size_t)b * a.temb_stride + chw);
 #pragma unroll
             for (int t = 0; t < NT1; ++t)
-                if (valid_of(t)) X[t] += e;
+                if (valid_of(t)) X[t] += temb4;
         }
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
         const f4 al1 = wload4(wrsrc(a.W->ln1a), chw * 4, l * kD * 4), be1 = wload4(wrsrc(a.W->ln1b), chw * 4, l * kD * 4);
-        ln_sync(0, a.epoch + 2 * l + 1, false);
-        fresh();
+        // token-mix weights and biases of this layer: in flight during the LayerNorm-1 exchange (they depend on no activation)
+        float Bt[NT1][MK1], btb[NT1];
+        {
+            const wrsrc_t wrs = wrsrc(a.W->wtok1_img);
+            const int wsb = l * NT1 * MK1 * 256;
 #pragma unroll
-        for (int t = 0; t < NT1; ++t)
+            for (int t = 0; t < NT1; ++t) {
+#pragma unroll
+                for (int m = 0; m < MK1; ++m) Bt[t][m] = wload1(wrs, lane * 4, wsb + (t * MK1 + m) * 256);
+                btb[t] = g1(a.W->btok_rows)[l * 80 + min(16 * t + s16, S - 1)];
+            }
+        }
+        ln_publish(0, a.epoch + 2 * l + 1, false);
+        ln_gather(0, a.epoch + 2 * l + 1, 2 + 8 * l + 5);
+        stamp(2 + 8 * l);
+        fresh();
+        float mu1[NT1];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            mu1[t] = mean[t];
             if (valid_of(t)) {
                 const float nm = -mean[t] * rstd[t];
                 f4 u = __builtin_elementwise_fma(X[t], (f4){rstd[t], rstd[t], rstd[t], rstd[t]}, (f4){nm, nm, nm, nm});
                 u = __builtin_elementwise_fma(u, al1, be1);
                 *reinterpret_cast<f4*>(&U[(16 * t + s16) * kCoopU1Stride + 16 * w + 4 * g]) = u;
             }
+        }
         // token mixing contracts over ROWS: wave w reads back only the 16 channel columns it has just written (LDS operations of one
-        // wave execute in order); the barriers of ln_sync ordered these stores after every wave's reads of the previous operand
+        // wave execute in order); the barriers of the LayerNorm exchange ordered these stores after every wave's reads of the previous operand
         __builtin_amdgcn_wave_barrier();
         fresh();
         {
             // out[ch][r] = sum_r' u[r'][ch] * Wt[r][r'] + bt[r] as D[channel][row]: A = u^T from LDS, B = the Conv1d weights in per-lane
             // fragment order: wtok1_img[l][t][m][lane] = Wt[16 t + (lane & 15)][4 m + (lane >> 4)] (zero outside S x S)
-            const wrsrc_t wrs = wrsrc(a.W->wtok1_img);
-            const int wsb = l * NT1 * MK1 * 256;
 #pragma unroll
             for (int t = 0; t < NT1; ++t) {
-                float Bt[MK1];
-#pragma unroll
-                for (int m = 0; m < MK1; ++m) Bt[m] = wload1(wrs, lane * 4, wsb + (t * MK1 + m) * 256);
-                const float bt = valid_of(t) ? g1(a.W->btok_rows)[l * 80 + 16 * t + s16] : 0.f;
+                const float bt = btb[t];
                 f4 acc = (f4){bt, bt, bt, bt};
 #pragma unroll
                 for (int m = 0; m < MK1; ++m) {
                     const int sr = (4 * m + 3 < S) ? 4 * m + g : min(4 * m + g, S - 1);   // clamped rows meet zero weights
-                    acc = MFMA(U[sr * kCoopU1Stride + 16 * w + s16], Bt[m], acc);
+                    acc = MFMA(U[sr * kCoopU1Stride + 16 * w + s16], Bt[t][m], acc);
                 }
                 if (valid_of(t)) X[t] = silu_acc4(acc, X[t]);
             }
         }
+        stamp(3 + 8 * l);
         fresh();
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
-        // publish this slice's raw rows (write-through), then the LayerNorm-2 partials as their ready flags
+        // This slice's rows, centred on the LayerNorm-1 mean: into its own region of the operand buffer and (write-through) to the
+        // other slices; wave w holds k block w of the slice.  Every wave is past its token-mix reads of the overlay when it gets here,
+        // but the OTHER waves may not be: the own-slice store waits for the barrier inside ln_publish ... so it goes to global first.
+        {
+            float* own = U + c * kCoopSliceFloats + w * (kCoopRows * 16);
 #pragma unroll
-        for (int t = 0; t < NT1; ++t)
-            if (valid_of(t)) st_sc1(X[t], xrs, ((16 * t + s16) * kD + chw) * 4);
-        ln_sync(1, a.epoch + 2 * l + 2, true);
-        fresh();
-        {   // all 512 channels of the S rows -> LDS, normalised on the way (LN2's alpha / beta are folded into the channel-mix weights)
-            constexpr int NLD = kCoopRows / 2;                       // 18 x (2 rows x 512 floats) per pass of the 256 threads
-            f4 xv[NLD];
-            const int col = (tid & 127) * 4, rh = tid >> 7;
+            for (int t = 0; t < NT1; ++t)
+                if (valid_of(t)) st_sc1(X[t] - (f4){mu1[t], mu1[t], mu1[t], mu1[t]}, xrs, ((c * 4 + w) * kCoopRows * 16 + (16 * t + s16) * 16 + 4 * g) * 4);
+            ln_publish(1, a.epoch + 2 * l + 2, true);                // LayerNorm-2 partials of the RAW rows; its barrier: token mixing is over
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) xv[i] = ld_sc1(xrs, (min(2 * i + rh, S - 1) * kD + col) * 4);
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int r = 2 * i + rh;
-                if (r < S) {
-                    const f2 st = stat[r];
-                    const float nm = -st.x * st.y;
-                    *reinterpret_cast<f4*>(&U[r * kUStride + col]) = __builtin_elementwise_fma(xv[i], (f4){st.y, st.y, st.y, st.y}, (f4){nm, nm, nm, nm});
-                }
-            }
+            for (int t = 0; t < NT1; ++t)
+                if (valid_of(t)) *reinterpret_cast<f4*>(&own[(16 * t + s16) * 16 + 4 * g]) = X[t] - (f4){mu1[t], mu1[t], mu1[t], mu1[t]};
         }
-        __syncthreads();
+        stamp(4 + 8 * l);
         fresh();
         {
-            const f4 bc = wload4(wrsrc(a.W->bch), chw * 4, l * kD * 4);
+            const f4 bc = wload4(wrsrc(a.W->bch), chw * 4, l * kD * 4), ws4 = wload4(wrsrc(a.W->wsum), chw * 4, l * kD * 4);
             f4 acc[2];
-            acc[0] = bc; acc[1] = bc;
+            acc[0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
             float racc[NRV];
             f4 racc4 = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < NRV; ++r) racc[r] = 0.f;
-            // wch_img[L][8][2][32 q][2][64][4]: 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1)
+            // wch_img[L][8][2][32 q][2][64][4]: 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1); k block q = 4 s + q' of slice s
             const wrsrc_t wrs = wrsrc(a.W->wch_img);
             const int wsb = (((l * 8 + c) * 2 + (w >> 1)) * 32 * 2 + (w & 1)) * 1024;
-            typedef const __attribute__((address_space(3))) float* ldsp;
-            typedef const __attribute__((address_space(3))) f4* ldsp4;
-            ldsp ub0 = (ldsp)(U + s16 * kUStride + 4 * g);
-            ldsp ur = (ldsp)(U + (32 + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g);
-            asm volatile("" : "+v"(ub0), "+v"(ur));
+            auto qof = [&](int n) { return ((c + (n >> 2)) & 7) * 4 + (n & 3); };      // the n-th k block in this workgroup's slice order
             constexpr int PF = 4;                                    // weight fragments in flight ahead of their use
             f4 An[PF];
 #pragma unroll
-            for (int k = 0; k < PF; ++k) An[k] = wload4(wrs, lane * 16, wsb + k * 2048);
-#pragma unroll 4
-            for (int q = 0; q < 32; ++q) {
-                const f4 A = An[0];
+            for (int k = 0; k < PF; ++k) An[k] = wload4(wrs, lane * 16, wsb + qof(k) * 2048);
+            const unsigned long long* ga = gran + (size_t)kCoopRows * kCoopSlices * 2;         // area 1: row 0's mean granule = slice ready
+            const unsigned tag2 = a.epoch + 2 * l + 2;
+            // Pull the 7 other slices (9 chunks of 1 KiB each, dealt over the waves) into their LDS regions as soon as their rows are
+            // published: lane s polls slice s.  The pulls fly while this slice's own k blocks are multiplied from LDS.
+            {
+                for (unsigned spins = 0;; ++spins) {
+                    const bool ok = (unsigned)(gran_load(ga + (size_t)(lane & 7) * 2) >> 32) == tag2;
+                    if (__all(ok)) break;
+                    if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                stamp(70 + 2 * l);
+#pragma unroll 1
+                for (int i = 1; i < kCoopSlices; ++i) {
+                    const int s = (c + i) & 7;
 #pragma unroll
-                for (int k = 0; k + 1 < PF; ++k) An[k] = An[k + 1];
-                An[PF - 1] = wload4(wrs, lane * 16, wsb + min(q + PF, 31) * 2048);
-                f4 Bv[2], Ur[kRemMfma ? 1 : NRV];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) Bv[t] = *(ldsp4)(ub0 + 16 * t * kUStride + 16 * q);
-#pragma unroll
-                for (int r = 0; r < (kRemMfma ? 1 : NRV); ++r) Ur[r] = *(ldsp4)(ur + r * kUStride + 16 * q);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = MFMA(A[j], Bv[t][j], acc[t]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (kRemMfma) {
-                        racc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(A[j], Ur[0][j], racc4, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < NRV; ++r) racc[r] = fmaf(A[j], Ur[r][j], racc[r]);
+                    for (int j = 0; j < 3; ++j) {
+                        const int ch = w + 4 * j;                    // wave-uniform
+                        if (ch < 9) dma_sc1(xrs, U + s * kCoopSliceFloats + ch * 256, lane * 16, (s * kCoopSliceFloats + ch * 256) * 4);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            typedef const __attribute__((address_space(3))) f4* ldsp4;
+            __syncthreads();                                         // own slice visible to every wave
+#pragma unroll 1
+            for (int i = 0; i < kCoopSlices; ++i) {
+                const int s = (c + i) & 7;
+                if (i == 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's chunks have landed in LDS ...
+                    __syncthreads();                                  // ... and so have the other waves'
+                    stamp(71 + 2 * l);
+                }
+                const float* ub = U + s * kCoopSliceFloats + s16 * 16 + 4 * g;
+                const float* ubr = U + s * kCoopSliceFloats + (32 + (kRemMfma ? (lane & 3) : 0)) * 16 + 4 * g;
+                // operands of a k block are read while the previous block is multiplied (one wave per SIMD at small batches: nothing
+                // else hides the LDS latency)
+                f4 Bn[2], Un[kRemMfma ? 1 : NRV];
+                auto ldb = [&](int qq) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) Bn[t] = *(ldsp4)(ub + (qq * kCoopRows + 16 * t) * 16);
+#pragma unroll
+                    for (int r = 0; r < (kRemMfma ? 1 : NRV); ++r) Un[r] = *(ldsp4)(ubr + (qq * kCoopRows + r) * 16);
+                };
+                ldb(0);
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int n = 4 * i + qq;
+                    const f4 A = An[0];
+#pragma unroll
+                    for (int k = 0; k + 1 < PF; ++k) An[k] = An[k + 1];
+                    An[PF - 1] = wload4(wrs, lane * 16, wsb + qof(min(n + PF, 31)) * 2048);
+                    f4 Bv[2], Ur[kRemMfma ? 1 : NRV];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) Bv[t] = Bn[t];
+#pragma unroll
+                    for (int r = 0; r < (kRemMfma ? 1 : NRV); ++r) Ur[r] = Un[r];
+                    if (qq + 1 < 4) ldb(qq + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) acc[t] = MFMA(A[j], Bv[t][j], acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (kRemMfma) {
+                            racc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(A[j], Ur[0][j], racc4, 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NRV; ++r) racc[r] = fmaf(A[j], Ur[r][j], racc[r]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            stamp(5 + 8 * l);
             fresh();
             // ragged rows: sum the 4 k subsets, then [channel-lane][row] -> [row-lane][channel-reg] through a per-wave LDS patch
             float* rem = REM + w * (4 * 16);
@@ -401,39 +491,79 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
                     if (g == 0) rem[r * 16 + s16] = v;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            // LayerNorm 2 around the product: v = rstd2 * (acc - (mu2 - mu1) wsum) + b'
+            ln_gather(1, tag2, 2 + 8 * l + 6);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) X[t] = silu_acc4(acc[t], X[t]);
+            for (int t = 0; t < 2; ++t) {
+                const float dm = mean[t] - mu1[t];
+                const f4 v = (acc[t] - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd[t], rstd[t], rstd[t], rstd[t]} + bc;
+                X[t] = silu_acc4(v, X[t]);
+            }
             if (s16 < NREM) {
                 const f4 rv = *reinterpret_cast<const f4*>(&rem[s16 * 16 + 4 * g]);
-                X[2] = silu_acc4(rv + bc, X[2]);
+                const float dm = mean[2] - mu1[2];
+                const f4 v = (rv - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd[2], rstd[2], rstd[2], rstd[2]} + bc;
+                X[2] = silu_acc4(v, X[2]);
             }
-            __builtin_amdgcn_wave_barrier();
         }
+        stamp(6 + 8 * l);
     }
 
     // ================= OutputProcess.poseFinal (RAG.py:205-211) + CFG + sampler update =============
-    // Every slice publishes its final rows into the second exchange buffer (the first may still be read by a slower slice's
-    // layer-(L-1) gather) and raises a flag; the (out block, row tile) units of the sample are then spread over its workgroups and
-    // waves, unit 4 j + w to wave w of workgroup j = p * 8 + c, and each unit owner computes BOTH passes of its unit.
     fresh();
     const int j16 = p * kCoopSlices + c;
+    const int n16 = np * kCoopSlices;                                // workgroups of this sample
     const unsigned tagF = a.epoch + 2 * a.layers + 1;
     {
-        const wrsrc_t ors = uniform_rsrc(a.cx2 + (size_t)pg * kCoopRows * kD);
+        // this slice's final rows -> LDS [S][64] (token-mix operand layout); the last ln_gather's barrier ordered every wave's
+        // channel-mix reads before these stores
 #pragma unroll
         for (int t = 0; t < NT1; ++t)
-            if (valid_of(t)) st_sc1(X[t], ors, ((16 * t + s16) * kD + chw) * 4);
+            if (valid_of(t)) *reinterpret_cast<f4*>(&U[(16 * t + s16) * kCoopU1Stride + 16 * w + 4 * g]) = X[t];
+        __syncthreads();
+        // partial poseFinal over this slice's 64 channels: unit (out block ob, row tile t) = 16 MFMAs; wout_reg_img[8][NOB][4][64][4]
+        // holds Wout[16 ob + (lane & 15)][64 c + 16 q' + 4 (lane >> 4) + j] (ls_api.cpp build_fused_images)
+        float* part = a.cpart + ((size_t)pg * kCoopSlices + c) * kCoopRows * NOBP;
+        const wrsrc_t prs = uniform_rsrc(part);
+        const wrsrc_t wrs = wrsrc(a.W->wout_reg_img);
+        constexpr int MAXOB = (NOB + kCoopWaves - 1) / kCoopWaves;   // out blocks per wave: block ob = w + 4 i
+        f4 An[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + min(w, NOB - 1)) * 4 + qq) * 1024);
+#pragma unroll 1
+        for (int i = 0; i < MAXOB; ++i) {
+            const int ob = w + kCoopWaves * i;                       // wave-uniform
+            if (ob >= NOB) break;
+            f4 A[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) A[qq] = An[qq];
+            const int obn = min(ob + kCoopWaves, NOB - 1);           // the next block's fragments fly under this block's MFMAs
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + obn) * 4 + qq) * 1024);
+            f4 o[NT1];
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) o[t] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                f4 Bv[NT1];
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kCoopU1Stride + 16 * qq + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) o[t] = MFMA(A[qq][j], Bv[t][j], o[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+                if (valid_of(t)) st_sc1(o[t], prs, ((16 * t + s16) * NOBP + 16 * ob + 4 * g) * 4);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                             // also: every wave is done with the last channel-mix operand
+        __syncthreads();
         unsigned long long* fl = a.cflag + (size_t)bl * 16;
         if (tid == 0) gran_store(fl + j16, tagF, 0.f);
-        if (4 * j16 >= NU) {                                         // no unit for this workgroup
-            if (spin_bad && lane == 0) atomicOr(a.cerr, 1u);
-            return;
-        }
+        stamp(2 + 8 * a.layers);
         if (tid < 64) {
-            const int k = min(tid, np * kCoopSlices - 1);
+            const int k = min(tid, n16 - 1);
             for (unsigned spins = 0;; ++spins) {
                 const bool ok = (unsigned)(gran_load(fl + k) >> 32) == tagF;
                 if (__all(ok)) break;
@@ -443,119 +573,81 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
         }
         __syncthreads();
     }
-    const int nwv = kCoopWaves * np * kCoopSlices;                   // waves of this sample
-    constexpr int MAXR = (NU + 4 * kCoopSlices - 1) / (4 * kCoopSlices);      // unit rounds when a single pass runs (np = 1)
-    f4 oacc[2][MAXR];
-#pragma unroll
-    for (int rd = 0; rd < MAXR; ++rd) { oacc[0][rd] = (f4){0.f, 0.f, 0.f, 0.f}; oacc[1][rd] = oacc[0][rd]; }
-    for (int pp = 0; pp < np; ++pp) {
-        const wrsrc_t ors = uniform_rsrc(a.cx2 + (size_t)(bl * np + pp) * kCoopRows * kD);
-        {
-            constexpr int NLD = kCoopRows / 2;
-            f4 xv[NLD];
-            const int col = (tid & 127) * 4, rh = tid >> 7;
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) xv[i] = ld_sc1(ors, (min(2 * i + rh, S - 1) * kD + col) * 4);
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int r = 2 * i + rh;
-                if (r < S) *reinterpret_cast<f4*>(&U[r * kUStride + col]) = xv[i];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rd = 0; rd < MAXR; ++rd) {
-            const int u = 4 * j16 + w + rd * nwv;                    // wave-uniform
-            if (u < NU) {
-                const int ob = u / NT1, tt = u - ob * NT1;
-                const int rc = min(16 * tt + s16, S - 1);
-                const wrsrc_t wrs = wrsrc(a.W->wout_img);            // [NOB][32 q][64][4], k in natural order
-                const int wsb = ob * 32 * 1024;
-                const float* up = &U[rc * kUStride + 4 * g];
-                f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-                constexpr int QB = 8;
-                f4 An[QB];
-#pragma unroll
-                for (int k = 0; k < QB; ++k) An[k] = wload4(wrs, lane * 16, wsb + k * 1024);
-#pragma unroll 1
-                for (int q0 = 0; q0 < 32; q0 += QB) {
-                    f4 A[QB];
-#pragma unroll
-                    for (int k = 0; k < QB; ++k) A[k] = An[k];
-                    const int qn = q0 + QB < 32 ? q0 + QB : q0;
-#pragma unroll
-                    for (int k = 0; k < QB; ++k) An[k] = wload4(wrs, lane * 16, wsb + (qn + k) * 1024);
-#pragma unroll
-                    for (int k = 0; k < QB; ++k) {
-                        const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * (q0 + k));
-                        a0 = MFMA(A[k][0], Bv[0], a0);
-                        a1 = MFMA(A[k][1], Bv[1], a1);
-                        a0 = MFMA(A[k][2], Bv[2], a0);
-                        a1 = MFMA(A[k][3], Bv[3], a1);
-                    }
-                }
-                if (pp == 0) oacc[0][rd] = a0 + a1; else oacc[1][rd] = a0 + a1;
-            }
-        }
-        __syncthreads();                                             // the operand buffer is restaged for the other pass
-    }
+    stamp(3 + 8 * a.layers);
     if (spin_bad && lane == 0) atomicOr(a.cerr, 1u);
 
-    // ====== CFG lerp (cfg_sampler.py:31) + posterior / DDIM update (gaussian_diffusion.py:260-282, 507-558, 745-798): lane (s16, g)
-    //        holds out columns 16 ob + 4 g .. + 3 of row 16 tt + s16, both passes ======================
-#pragma unroll
-    for (int rd = 0; rd < MAXR; ++rd) {
-        const int u = 4 * j16 + w + rd * nwv;
-        if (u >= NU) break;
-        const int ob = u / NT1, tt = u - ob * NT1;
-        const int r = 16 * tt + s16;
-        const int f = r - NPRE;
-        if (r >= S || f < 0) continue;
+    // ====== sum of the 8 partials of each pass, CFG lerp (cfg_sampler.py:31), posterior / DDIM update (gaussian_diffusion.py:260-282,
+    //        507-558, 745-798): quad (frame f, columns 4 cq .. + 3), dealt over the sample's workgroups ======================
+    {
+        const int per = (NQUAD + n16 - 1) / n16;
         const float sc = (np == 2 && a.scale) ? a.scale[b] : 1.0f;
         const unsigned long long gidx = (a.call ? a.call->sample_offset : 0ull) + (unsigned long long)b;
         const size_t base = (size_t)b * kT * JF;
+        const wrsrc_t p0 = uniform_rsrc(a.cpart + (size_t)(bl * np) * kCoopSlices * kCoopRows * NOBP);
+        for (int i = tid; i < per; i += kCoopThreads) {
+            const int quad = j16 * per + i;
+            if (quad >= NQUAD) break;
+            const int f = quad / (NOBP / 4), cq = quad - f * (NOBP / 4);
+            const int off = ((NPRE + f) * NOBP + 4 * cq) * 4;
+            f4 pc[kCoopSlices], pu[kCoopSlices];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int cc = 16 * ob + 4 * g + jj;
-            if (cc >= JF) continue;
-            const int idx = f * JF + cc;
-            const float bo = g1(a.W->bout)[cc];
-            const float oc = oacc[0][rd][jj] + bo;
-            float x0;
+            for (int s = 0; s < kCoopSlices; ++s) pc[s] = ld_sc1(p0, off + s * kCoopRows * NOBP * 4);
             if (np == 2) {
-                const float ou = oacc[1][rd][jj] + bo;
-                if (a.fwd_c) a.fwd_c[base + idx] = oc;
-                if (a.fwd_u) a.fwd_u[base + idx] = ou;
-                x0 = ou + sc * (oc - ou);
-            } else {
-                x0 = oc;                                             // scale == 1: the CFG combination is the cond output
+#pragma unroll
+                for (int s = 0; s < kCoopSlices; ++s) pu[s] = ld_sc1(p0, off + (kCoopSlices + s) * kCoopRows * NOBP * 4);
             }
-            if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-            if (a.x0_out) a.x0_out[base + idx] = x0;
-            if (a.sampler != kNone) {
-                const float xt = a.x_in[base + idx];
-                float nz = 0.f;
-                if (a.t_nonzero) {
-                    if (a.noise) {
-                        const size_t bn = a.const_noise ? 0 : (size_t)b;
-                        nz = a.noise[(bn * JF + cc) * kT + f];
-                    } else {
-                        nz = philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(cc * kT + f));
-                    }
-                }
-                float xn;
-                if (a.sampler == kDDPM) {
-                    xn = a.c0 * x0 + a.c1 * xt;
-                    if (a.t_nonzero) xn += a.c2 * nz;
+            f4 oc4 = pc[0], ou4 = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 1; s < kCoopSlices; ++s) oc4 += pc[s];
+            if (np == 2) {
+                ou4 = pu[0];
+#pragma unroll
+                for (int s = 1; s < kCoopSlices; ++s) ou4 += pu[s];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int cc = 4 * cq + jj;
+                if (cc >= JF) continue;
+                const int idx = f * JF + cc;
+                const float bo = g1(a.W->bout)[cc];
+                const float oc = oc4[jj] + bo;
+                float x0;
+                if (np == 2) {
+                    const float ou = ou4[jj] + bo;
+                    if (a.fwd_c) a.fwd_c[base + idx] = oc;
+                    if (a.fwd_u) a.fwd_u[base + idx] = ou;
+                    x0 = ou + sc * (oc - ou);
                 } else {
-                    const float eps = (a.c0 * xt - x0) / a.c1;
-                    xn = x0 * a.c2 + a.c3 * eps;
-                    if (a.t_nonzero) xn += a.c4 * nz;
+                    x0 = oc;                                         // scale == 1: the CFG combination is the cond output
                 }
-                a.x_out[base + idx] = xn;
+                if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                if (a.x0_out) a.x0_out[base + idx] = x0;
+                if (a.sampler != kNone) {
+                    const float xt = a.x_in[base + idx];
+                    float nz = 0.f;
+                    if (a.t_nonzero) {
+                        if (a.noise) {
+                            const size_t bn = a.const_noise ? 0 : (size_t)b;
+                            nz = a.noise[(bn * JF + cc) * kT + f];
+                        } else {
+                            nz = philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(cc * kT + f));
+                        }
+                    }
+                    float xn;
+                    if (a.sampler == kDDPM) {
+                        xn = a.c0 * x0 + a.c1 * xt;
+                        if (a.t_nonzero) xn += a.c2 * nz;
+                    } else {
+                        const float eps = (a.c0 * xt - x0) / a.c1;
+                        xn = x0 * a.c2 + a.c3 * eps;
+                        if (a.t_nonzero) xn += a.c4 * nz;
+                    }
+                    a.x_out[base + idx] = xn;
+                }
             }
         }
     }
+    stamp(5 + 8 * a.layers);
 }
 
 }  // namespace ls

@@ -28,6 +28,7 @@ struct CallParams {
 struct DevWeights {
     const float* wch_img;    // [L][8][2 passes][32 q][2 cb][64 lanes][4]   channel-mix Linear(512,512)
     const float* bch;        // [L][512]
+    const float* wsum;       // [L][512] row sums of the LN2-folded channel-mix weights (sample-split kernel: LayerNorm 2 around the product)
     // bf16x3 split-precision mode: W' = hi + lo with hi = bf16(W'), lo = bf16(W' - hi); operand order of
     // v_mfma_f32_16x16x32_bf16 (lane (n, g) holds k = 32q + 8g .. +7): [L][8][2 passes][16 q][2 cb][64 lanes][8]
     const unsigned short* wch_hi_img;
@@ -90,14 +91,16 @@ struct StepArgs {
     int tr_B;
     float* trace;            // [B][L+1][2S][512] or null
     // ---- sample-split kernel (k_coop, ls_coop_kernel.h): exchange workspaces of ONE launch (kCoopMaxGroups (sample, pass) groups)
-    float* cx;               // [groups][36][512] raw rows entering channel mixing (the LayerNorm-2 hand-off)
-    float* cx2;              // [groups][36][512] final rows (the poseFinal hand-off)
+    float* cx;               // [groups][8 slices][4 k blocks][36 rows][16] rows entering channel mixing, centred on the LayerNorm-1 mean
+    float* cpart;            // [groups][8 slices][36][J*F padded to 16s] partial poseFinal outputs of each slice
     unsigned long long* cgran;   // [groups][2 areas][36 rows][8 slices][2] {tag, value} granules: (mean, M2) partials of the two LayerNorms
     unsigned long long* cflag;   // [samples][16] {tag, -} ready flags of the final rows
     unsigned* cerr;          // set non-zero by a workgroup whose bounded spin ran out
     unsigned epoch;          // tag base of this launch: unique among the launches since the granule words were last zeroed
     int b0;                  // first sample of this launch
     int npass;               // 2: cond + uncond (CFG); 1: cond only (every guidance scale is 1)
+    int ngroups;             // (sample, pass) groups of this launch
+    int xmap;                // blockIdx -> (group, slice) mapping, see k_coop
 #ifdef LS_DEBUG
     // Profiling builds only (tools/phase_profile.py, tools/ab_variants.py compile their own -DLS_DEBUG variant of the library):
     // the shipped library has neither the fields nor the code that reads them, so no environment variable can change its results.

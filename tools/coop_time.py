@@ -1,13 +1,16 @@
 """Step time of the sampling loop by kernel path and batch: python tools/coop_time.py [ted|beat] [steps]
 Prints ms/step (hipGraph replay, Philox noise) for each (path, B) -- the throughput-vs-batch table of profiles/."""
+import os
 import sys
-import time
 
 import numpy as np
 
 sys.path.insert(0, ".")
 from livelyspeaker_amd import _lib, synth  # noqa: E402
 from oracle import rag_oracle as orc  # noqa: E402
+
+if os.environ.get("LS_LIB"):
+    _lib.use_library(os.environ["LS_LIB"])
 
 
 def main():
