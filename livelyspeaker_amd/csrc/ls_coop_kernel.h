@@ -8,8 +8,11 @@
 //   p_mean_variance / p_sample / ddim_sample   scripts/diffusion/gaussian_diffusion.py:284-399, 507-558, 745-798
 //
 // Mapping:
-//   * workgroup = (sample b, CFG pass p, channel slice c): 4 waves, the S = 35 | 36 rows of ONE pass x 64 of the 512 channels.
-//     Wave w owns channels [64c + 16w, +16) of every row = 12 VGPRs of residual stream, in the MFMA C/D layout exactly as in k_step.
+//   * workgroup = (sample b, CFG pass p, channel slice c): 8 waves, the S = 35 | 36 rows of ONE pass x 64 of the 512 channels.
+//     Wave (w, h), w = 0..3, h = 0..1: channels [64c + 16w, +16), in the MFMA C/D layout exactly as in k_step; for the residual
+//     stream, LayerNorm, token mixing and the epilogues it owns the rows of half h (h = 0: rows 0..15, h = 1: rows 16..S-1 = one
+//     full tile + the ragged 3 | 4 rows); for the channel-mixing MFMAs it takes k blocks 2h, 2h+1 of every slice for ALL rows (each
+//     weight fragment is loaded by one wave and meets two row tiles), and the two halves swap partial sums through LDS.
 //     blockIdx = (b * npass + p) * 8 + c, so slice c of every sample runs on XCD c (observed round-robin placement): each XCD's L2
 //     holds one eighth of the weights (1 MB).  Placement is a speed matter only -- every hand-off below is placement-independent.
 //   * what crosses workgroups (the 8 slices of one (sample, pass)), per layer:
@@ -41,15 +44,15 @@
 
 namespace ls {
 
-constexpr int kCoopThreads = 256;
-constexpr int kCoopWaves = 4;
+constexpr int kCoopThreads = 512;
+constexpr int kCoopWaves = 8;
 constexpr int kCoopSlices = 8;             // channel slices of 64
 constexpr int kCoopRows = 36;              // rows of one pass in the exchange buffers (S <= 36)
 constexpr int kCoopU1Stride = 80;          // LDS row stride of the token-mix operand [S][64]: = 16 mod 32, conflict-free column reads
 constexpr unsigned kCoopSpinLimit = 1u << 18;       // polls (~1-2 us each) before a hand-off wait gives up: waits are < 1 ms when the slices are resident
 constexpr int kCoopSliceFloats = 4 * kCoopRows * 16;   // one slice's rows in exchange order [4 k blocks][36 rows][16]: 9216 B
-// LDS: psum [4][48] f2 | stat [48] f2 | REM [4][4][16] | U [8 slices][4][36][16]
-constexpr int kCoopLdsFloats = 2 * kCoopWaves * 48 + 2 * 48 + kCoopWaves * 4 * 16 + kCoopSlices * kCoopSliceFloats;
+// LDS: psum [4][48] f2 | stat [48] f2 | U [8 slices][4][36][16]
+constexpr int kCoopLdsFloats = 2 * 4 * 48 + 2 * 48 + kCoopSlices * kCoopSliceFloats;
 
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long* gu64p;
@@ -68,12 +71,15 @@ typedef __attribute__((address_space(3))) void* coop_lds_vp;
 __device__ __forceinline__ void dma_sc1(wrsrc_t r, float* lds, int lane_bytes, int wave_bytes) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (coop_lds_vp)lds, 16, lane_bytes, wave_bytes, 0, 16);
 }
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every LDS-DMA pull and
+// weight prefetch in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void gran_store(unsigned long long* p, unsigned tag, float v) {
     __hip_atomic_store((gu64p)p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int S, int NPRE, int JF>
-__global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
+__global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     constexpr int KXQ = (JF + 15) / 16;
     constexpr int KXP = KXQ * 16;
     constexpr int XSTR = KXP + 4;               // LDS row stride of the x_t staging
@@ -84,26 +90,27 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
     constexpr bool kRemMfma = (NREM % 4 == 0);  // BEAT: one v_mfma_f32_4x4x1 row group; TED: scalar FMAs (see k_step)
     constexpr int NRV = kRemMfma ? 1 : NREM;
     constexpr int MK1 = (S + 3) / 4;            // k steps of the token-mix GEMM of one pass
+    constexpr int NU = NOB * NT1;               // output-projection work units (out block, row tile)
+    constexpr int MAXU = (NU + kCoopWaves - 1) / kCoopWaves;
     constexpr int NQUAD = kT * (NOBP / 4);      // (frame, 4 output columns) quads of one sample
     static_assert(S > 32 && S <= kCoopRows, "one pass = two full row tiles + a ragged one");
     static_assert(NREM >= 1 && NREM <= 4, "ragged tile");
     static_assert(S * XSTR <= kCoopSlices * kCoopSliceFloats, "x_t staging fits the operand buffer");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f2* pst = reinterpret_cast<f2*>(smem);                         // [4 waves][48 rows] (mean, M2) over 16 channels
-    f2* stat = pst + kCoopWaves * 48;                              // [48 rows] (mean, rstd) over all 512 channels
-    float* REM = smem + 2 * kCoopWaves * 48 + 2 * 48;              // [4 waves][4][16] ragged-row patch
-    float* U = REM + kCoopWaves * 4 * 16;                          // [8 slices][4 k blocks][36 rows][16]; overlays: x_t staging, token-mix operand
+    f2* pst = reinterpret_cast<f2*>(smem);                         // [4 channel blocks][48 rows] (mean, M2) over 16 channels
+    f2* stat = pst + 4 * 48;                                       // [48 rows] (mean, rstd) over all 512 channels
+    float* U = smem + 2 * 4 * 48 + 2 * 48;                         // [8 slices][4 k blocks][36 rows][16]; overlays: x_t staging, token-mix operand, partial sums
 
     const int tid = threadIdx.x;
     int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 3, h = wv >> 2;                              // 16-channel block, row half
     const int bid = blockIdx.x;
     const int np = a.npass;
     // blockIdx -> (group, slice).  xmap 0: slice = bid % 8, i.e. slice c of every group on XCD c (each XCD's L2 holds one eighth of the
-    // weights; every row hand-off crosses XCDs).  xmap 1: group = 8 (bid / 64) + bid % 8, slice = (bid / 8) % 8, i.e. the 8 slices of a
-    // group on ONE XCD (a published slice is fetched from the memory side once per XCD, its other six readers hit L2; each XCD streams
-    // all the weights).  Observed round-robin placement; a different placement changes only speed.
+    // weights; every row hand-off crosses XCDs).  xmap 1: the 8 slices of a group on ONE XCD (measured 35 % slower: the granule polls of
+    // a group then queue on one L2).  Observed round-robin placement; a different placement changes only speed.
     const int c = a.xmap ? ((bid >> 3) & 7) : (bid & 7);            // channel slice
     const int pg = a.xmap ? ((bid >> 6) * 8 + (bid & 7)) : (bid >> 3);      // launch-local (sample, pass) group
     if (pg >= a.ngroups) return;                                    // xmap 1 rounds the grid up to whole sets of 8 groups
@@ -120,8 +127,10 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
         g = lane >> 4;
         chw = 64 * c + 16 * w + 4 * g;
     };
-    auto valid_of = [&](int t) { return 16 * t + 15 < S ? true : 16 * t + s16 < S; };
-    auto rowc_of = [&](int t) { const int r = 16 * t + s16; return (16 * t + 15 < S || r < S) ? r : S - 1; };
+    // this lane's rows: r0 = 16 h + s16 (always a real row), r1 = 32 + s16 (half 1 only, the ragged rows)
+    auto row0 = [&]() { return 16 * h + s16; };
+    auto live1 = [&]() { return h == 1 && s16 < NREM; };
+    auto row1c = [&]() { return min(32 + s16, S - 1); };
 
     float* xg = a.cx + (size_t)pg * kCoopSlices * kCoopSliceFloats;     // centred rows of this (sample, pass), exchange order
     unsigned long long* gran = a.cgran + (size_t)pg * 2 * kCoopRows * kCoopSlices * 2;   // [2 areas][36 rows][8 slices][2] granules
@@ -129,46 +138,41 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
     // phase stamps, -DLS_DEBUG builds only (tools/coop_profile.py): lane 0 of every wave of one workgroup records s_memtime
     auto stamp = [&](int idx) {
 #ifdef LS_DEBUG
-        if (a.prof && bid == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
+        if (a.prof && bid == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[wv * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
 #else
         (void)idx;
 #endif
     };
     stamp(0);
-    f4 X[NT1];
+
+    f4 X0, X1;                                                      // residual stream: rows r0 / r1 of this lane's 4 channels
 
     // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
     {
         const unsigned long long goff = a.call ? a.call->sample_offset : 0ull;
-#pragma unroll
-        for (int t = 0; t < NT1; ++t) {
-            const int tk = rowc_of(t);
-            f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-            if (valid_of(t)) {
-                if (tk >= NPRE) {
-                    v = *reinterpret_cast<const f4*>((unc ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + chw);
-                } else if (tk == 0) {                               // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
-                    const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + chw);
-                    const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + chw);
-                    f4 e;
-                    const float* ep = unc ? a.eps_u : a.eps_c;
-                    if (ep) {
-                        e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + chw);
-                    } else {
-                        float z[4];
-                        philox_normal4(a.call, goff + (unsigned long long)b, a.step_id, unc ? 2u : 1u, (unsigned)(chw >> 2), z);
-                        e = (f4){z[0], z[1], z[2], z[3]};
-                    }
-                    v = mu + e * sd;
-                } else {                                            // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
-                    v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + chw);
+        auto base_row = [&](int tk) -> f4 {
+            if (tk >= NPRE) return *reinterpret_cast<const f4*>((unc ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + chw);
+            if (tk == 0) {                                          // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
+                const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + chw);
+                const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + chw);
+                f4 e;
+                const float* ep = unc ? a.eps_u : a.eps_c;
+                if (ep) {
+                    e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + chw);
+                } else {
+                    float z[4];
+                    philox_normal4(a.call, goff + (unsigned long long)b, a.step_id, unc ? 2u : 1u, (unsigned)(chw >> 2), z);
+                    e = (f4){z[0], z[1], z[2], z[3]};
                 }
+                return mu + e * sd;
             }
-            X[t] = v;
-        }
+            return *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + chw);       // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
+        };
+        X0 = base_row(row0());
+        X1 = live1() ? base_row(row1c()) : (f4){0.f, 0.f, 0.f, 0.f};
         // x_t of this sample -> LDS [S][KXP] (zero for prefix tokens and pad columns); loads first, then the writes, in blocks
         constexpr int NIT = (S * KXP + kCoopThreads - 1) / kCoopThreads;
-        constexpr int CH = 14;
+        constexpr int CH = 11;
 #pragma unroll
         for (int it0 = 0; it0 < NIT; it0 += CH) {
             float xv[CH];
@@ -193,9 +197,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
         }
         __syncthreads();
         fresh();
-        f4 acc[NT1];
-#pragma unroll
-        for (int t = 0; t < NT1; ++t) acc[t] = X[t];
+        f4 acc0 = X0, acc1 = X1;
         // winx_img[8][2][KXQ][2][64][4] (ls_api.cpp build_fused_images): 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1)
         const wrsrc_t wrs = wrsrc(a.W->winx_img);
         const int wsb = ((c * 2 + (w >> 1)) * KXQ * 2 + (w & 1)) * 1024;
@@ -203,107 +205,106 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
         f4 An[EPF];
 #pragma unroll
         for (int k = 0; k < EPF; ++k) An[k] = wload4(wrs, lane * 16, wsb + k * 2048);
+        const float* u0 = &U[row0() * XSTR + 4 * g];
+        const float* u1 = &U[row1c() * XSTR + 4 * g];
 #pragma unroll EPF
         for (int q = 0; q < KXQ; ++q) {
             const f4 A = An[0];
 #pragma unroll
             for (int k = 0; k + 1 < EPF; ++k) An[k] = An[k + 1];
             An[EPF - 1] = wload4(wrs, lane * 16, wsb + min(q + EPF, KXQ - 1) * 2048);
-            f4 Bv[NT1];
+            const f4 B0 = *reinterpret_cast<const f4*>(u0 + 16 * q);
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * XSTR + 16 * q + 4 * g]);
+            for (int j = 0; j < 4; ++j) acc0 = MFMA(A[j], B0[j], acc0);
+            if (h) {
+                const f4 B1 = *reinterpret_cast<const f4*>(u1 + 16 * q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < NT1; ++t) acc[t] = MFMA(A[j], Bv[t][j], acc[t]);
+                for (int j = 0; j < 4; ++j) acc1 = MFMA(A[j], B1[j], acc1);
+            }
         }
-#pragma unroll
-        for (int t = 0; t < NT1; ++t) X[t] = valid_of(t) ? acc[t] : (f4){0.f, 0.f, 0.f, 0.f};   // pad rows stay zero
+        X0 = acc0;
+        X1 = live1() ? acc1 : (f4){0.f, 0.f, 0.f, 0.f};             // pad rows stay zero
     }
 
     // LN_spatial statistics (mlp_module.py:29-33) of every row over all 512 channels, across the 8 slice workgroups:
-    // lane: two passes over its 4 channels; Chan's parallel-variance merge over the 4 lane groups (VALU swaps), the 4 waves (LDS) and
-    // the 8 slices (granules through L2 / memory).
+    // lane: two passes over its 4 channels; Chan's parallel-variance merge over the 4 lane groups (VALU swaps), the 4 channel blocks
+    // (LDS) and the 8 slices (granules through L2 / memory).
     // ln_publish: this slice's (mean, M2) of every row -> granule area `area`.  `payload`: the caller has issued this workgroup's
     // write-through payload stores; they are drained before the granules -- which double as the payload's ready flags -- go out.
+    auto lane_part = [&](f4 v, float& m, float& m2) {
+        m = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
+        const f4 d4 = v - (f4){m, m, m, m};
+        m2 = (d4[0] * d4[0] + d4[1] * d4[1]) + (d4[2] * d4[2] + d4[3] * d4[3]);
+        {
+            float ma, mb, qa, qb;
+            xor16_pair(m, ma, mb);
+            xor16_pair(m2, qa, qb);
+            const float d = mb - ma;
+            m2 = (qa + qb) + d * d * 2.0f;
+            m = 0.5f * (ma + mb);
+        }
+        {
+            float ma, mb, qa, qb;
+            xor32_pair(m, ma, mb);
+            xor32_pair(m2, qa, qb);
+            const float d = mb - ma;
+            m2 = (qa + qb) + d * d * 4.0f;
+            m = 0.5f * (ma + mb);
+        }
+    };
     auto ln_publish = [&](int area, unsigned tag, bool payload) {
-#pragma unroll
-        for (int t = 0; t < NT1; ++t) {
-            const f4 v = X[t];
-            float m = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
-            const f4 d4 = v - (f4){m, m, m, m};
-            float m2 = (d4[0] * d4[0] + d4[1] * d4[1]) + (d4[2] * d4[2] + d4[3] * d4[3]);
-            {
-                float ma, mb, qa, qb;
-                xor16_pair(m, ma, mb);
-                xor16_pair(m2, qa, qb);
-                const float d = mb - ma;
-                m2 = (qa + qb) + d * d * 2.0f;
-                m = 0.5f * (ma + mb);
-            }
-            {
-                float ma, mb, qa, qb;
-                xor32_pair(m, ma, mb);
-                xor32_pair(m2, qa, qb);
-                const float d = mb - ma;
-                m2 = (qa + qb) + d * d * 4.0f;
-                m = 0.5f * (ma + mb);
-            }
-            if (g == 0) pst[w * 48 + 16 * t + s16] = (f2){m, m2};
+        float m, m2;
+        lane_part(X0, m, m2);
+        if (g == 0) pst[w * 48 + row0()] = (f2){m, m2};
+        if (h) {                                                     // wave-uniform
+            lane_part(X1, m, m2);
+            if (g == 0) pst[w * 48 + 32 + s16] = (f2){m, m2};
         }
         if (payload) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores
         __syncthreads();
-        if (tid < S) {                                                          // row tid: merge the 4 waves, publish the slice's partial
-            f2 pw[kCoopWaves];
+        if (tid < S) {                                                          // row tid: merge the 4 channel blocks, publish the slice's partial
+            f2 pw[4];
             float ms = 0.f, qs = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < kCoopWaves; ++ww) { pw[ww] = pst[ww * 48 + tid]; ms += pw[ww].x; qs += pw[ww].y; }
+            for (int ww = 0; ww < 4; ++ww) { pw[ww] = pst[ww * 48 + tid]; ms += pw[ww].x; qs += pw[ww].y; }
             const float mt = ms * 0.25f;
             float dd = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < kCoopWaves; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
+            for (int ww = 0; ww < 4; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
             unsigned long long* gp = gran + (size_t)area * kCoopRows * kCoopSlices * 2 + ((size_t)tid * kCoopSlices + c) * 2;
             gran_store(gp, tag, mt);
             gran_store(gp + 1, tag, qs + 16.0f * dd);
         }
     };
     // ln_gather: wait for all 8 slices' partials of every row, merge -> stat[row] = (mean, rstd) and this lane's rows' values
-    float mean[NT1], rstd[NT1];
+    float mean0, rstd0, mean1, rstd1;
     auto ln_gather = [&](int area, unsigned tag, int stamp_at) {
         const unsigned long long* ga = gran + (size_t)area * kCoopRows * kCoopSlices * 2;
-        // thread (row = tid >> 3, slice = tid & 7) + a second row 32 + (tid >> 3) for the first 8 * NREM threads
-        const int sl = tid & 7, r0 = tid >> 3, r1 = 32 + (tid >> 3);
-        const bool has1 = tid < 8 * NREM;
-        const unsigned long long* g0 = ga + ((size_t)r0 * kCoopSlices + sl) * 2;
-        const unsigned long long* g1p = ga + ((size_t)(has1 ? r1 : r0) * kCoopSlices + sl) * 2;
-        unsigned long long v0, v1, v2, v3;
+        // thread (row = tid >> 3, slice = tid & 7); threads beyond the S rows re-read the last row
+        const int sl = tid & 7, r = min(tid >> 3, S - 1);
+        const bool live = (tid >> 3) < S;
+        const unsigned long long* g0 = ga + ((size_t)r * kCoopSlices + sl) * 2;
+        unsigned long long v0, v1;
         stamp(stamp_at);
-        for (unsigned spins = 0;; ++spins) {
-            v0 = gran_load(g0); v1 = gran_load(g0 + 1);
-            v2 = gran_load(g1p); v3 = gran_load(g1p + 1);
-            const bool ok = (unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag && (unsigned)(v2 >> 32) == tag && (unsigned)(v3 >> 32) == tag;
-            if (__all(ok)) break;
-            if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }     // after one timeout the launch only drains
-            __builtin_amdgcn_s_sleep(1);
-        }
-        auto merge8 = [&](unsigned long long vm, unsigned long long vq, int row, bool live) {
-            const float pm = __uint_as_float((unsigned)vm), pq = __uint_as_float((unsigned)vq);
+        if (wv * 8 < S) {                                            // waves whose rows exist poll (wave-uniform)
+            for (unsigned spins = 0;; ++spins) {
+                v0 = gran_load(g0); v1 = gran_load(g0 + 1);
+                const bool ok = (unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag;
+                if (__all(ok)) break;
+                if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }     // after one timeout the launch only drains
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const float pm = __uint_as_float((unsigned)v0), pq = __uint_as_float((unsigned)v1);
             float sm = pm;
             sm = dpp_add<0xB1>(sm); sm = dpp_add<0x4E>(sm); sm = dpp_add<0x141>(sm);     // the 8 lanes of one row
             const float mu = sm * 0.125f, d = pm - mu;
             float q = fmaf(64.f * d, d, pq);
             q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q); q = dpp_add<0x141>(q);
-            if (live && sl == 0) stat[row] = (f2){mu, rsqrtf(q * (1.0f / kD) + 1e-5f)};
-        };
-        merge8(v0, v1, r0, true);
-        merge8(v2, v3, r1, has1);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < NT1; ++t) {
-            const f2 st = stat[rowc_of(t)];
-            mean[t] = st.x;
-            rstd[t] = st.y;
+            if (live && sl == 0) stat[r] = (f2){mu, rsqrtf(q * (1.0f / kD) + 1e-5f)};
         }
+        __syncthreads();
+        const f2 s0 = stat[row0()], s1 = stat[row1c()];
+        mean0 = s0.x; rstd0 = s0.y; mean1 = s1.x; rstd1 = s1.y;
     };
 
     const wrsrc_t xrs = uniform_rsrc(xg);
@@ -313,74 +314,70 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
     // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
     for (int l = 0; l < a.layers; ++l) {
         fresh();
-        {   // x = x + emb  (re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
-#pragma unroll
-            for (int t = 0; t < NT1; ++t)
-                if (valid_of(t)) X[t] += temb4;
-        }
+        // x = x + emb  (re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
+        X0 += temb4;
+        if (live1()) X1 += temb4;
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
         const f4 al1 = wload4(wrsrc(a.W->ln1a), chw * 4, l * kD * 4), be1 = wload4(wrsrc(a.W->ln1b), chw * 4, l * kD * 4);
-        // token-mix weights and biases of this layer: in flight during the LayerNorm-1 exchange (they depend on no activation)
-        float Bt[NT1][MK1], btb[NT1];
+        // token-mix weights and biases of this wave's row tiles (tile h, and the ragged tile 2 for half 1): in flight during the
+        // LayerNorm-1 exchange (they depend on no activation).  wtok1_img[l][t][m][lane] = Wt[16 t + (lane & 15)][4 m + (lane >> 4)]
+        float Bt0[MK1], Bt1[MK1], btb0, btb1;
         {
             const wrsrc_t wrs = wrsrc(a.W->wtok1_img);
             const int wsb = l * NT1 * MK1 * 256;
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) {
-#pragma unroll
-                for (int m = 0; m < MK1; ++m) Bt[t][m] = wload1(wrs, lane * 4, wsb + (t * MK1 + m) * 256);
-                btb[t] = g1(a.W->btok_rows)[l * 80 + min(16 * t + s16, S - 1)];
+            for (int m = 0; m < MK1; ++m) {
+                Bt0[m] = wload1(wrs, lane * 4, wsb + (h * MK1 + m) * 256);
+                Bt1[m] = wload1(wrs, lane * 4, wsb + (2 * MK1 + m) * 256);
             }
+            btb0 = g1(a.W->btok_rows)[l * 80 + row0()];
+            btb1 = g1(a.W->btok_rows)[l * 80 + row1c()];
         }
         ln_publish(0, a.epoch + 2 * l + 1, false);
         ln_gather(0, a.epoch + 2 * l + 1, 2 + 8 * l + 5);
         stamp(2 + 8 * l);
         fresh();
-        float mu1[NT1];
-#pragma unroll
-        for (int t = 0; t < NT1; ++t) {
-            mu1[t] = mean[t];
-            if (valid_of(t)) {
-                const float nm = -mean[t] * rstd[t];
-                f4 u = __builtin_elementwise_fma(X[t], (f4){rstd[t], rstd[t], rstd[t], rstd[t]}, (f4){nm, nm, nm, nm});
-                u = __builtin_elementwise_fma(u, al1, be1);
-                *reinterpret_cast<f4*>(&U[(16 * t + s16) * kCoopU1Stride + 16 * w + 4 * g]) = u;
-            }
+        const float mu1_0 = mean0, mu1_1 = mean1;
+        {
+            const float nm = -mean0 * rstd0;
+            f4 u = __builtin_elementwise_fma(X0, (f4){rstd0, rstd0, rstd0, rstd0}, (f4){nm, nm, nm, nm});
+            u = __builtin_elementwise_fma(u, al1, be1);
+            *reinterpret_cast<f4*>(&U[row0() * kCoopU1Stride + 16 * w + 4 * g]) = u;
         }
-        // token mixing contracts over ROWS: wave w reads back only the 16 channel columns it has just written (LDS operations of one
-        // wave execute in order); the barriers of the LayerNorm exchange ordered these stores after every wave's reads of the previous operand
-        __builtin_amdgcn_wave_barrier();
+        if (live1()) {
+            const float nm = -mean1 * rstd1;
+            f4 u = __builtin_elementwise_fma(X1, (f4){rstd1, rstd1, rstd1, rstd1}, (f4){nm, nm, nm, nm});
+            u = __builtin_elementwise_fma(u, al1, be1);
+            *reinterpret_cast<f4*>(&U[(32 + s16) * kCoopU1Stride + 16 * w + 4 * g]) = u;
+        }
+        __syncthreads();                                             // token mixing contracts over ROWS: both halves' rows of these channels
         fresh();
         {
-            // out[ch][r] = sum_r' u[r'][ch] * Wt[r][r'] + bt[r] as D[channel][row]: A = u^T from LDS, B = the Conv1d weights in per-lane
-            // fragment order: wtok1_img[l][t][m][lane] = Wt[16 t + (lane & 15)][4 m + (lane >> 4)] (zero outside S x S)
+            // out[ch][r] = sum_r' u[r'][ch] * Wt[r][r'] + bt[r] as D[channel][row]: A = u^T from LDS, B = the Conv1d weights
+            f4 acc0 = (f4){btb0, btb0, btb0, btb0}, acc1 = (f4){btb1, btb1, btb1, btb1};
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) {
-                const float bt = btb[t];
-                f4 acc = (f4){bt, bt, bt, bt};
-#pragma unroll
-                for (int m = 0; m < MK1; ++m) {
-                    const int sr = (4 * m + 3 < S) ? 4 * m + g : min(4 * m + g, S - 1);   // clamped rows meet zero weights
-                    acc = MFMA(U[sr * kCoopU1Stride + 16 * w + s16], Bt[t][m], acc);
-                }
-                if (valid_of(t)) X[t] = silu_acc4(acc, X[t]);
+            for (int m = 0; m < MK1; ++m) {
+                const int sr = (4 * m + 3 < S) ? 4 * m + g : min(4 * m + g, S - 1);   // clamped rows meet zero weights
+                const float av = U[sr * kCoopU1Stride + 16 * w + s16];
+                acc0 = MFMA(av, Bt0[m], acc0);
+                if (h) acc1 = MFMA(av, Bt1[m], acc1);
             }
+            X0 = silu_acc4(acc0, X0);
+            if (live1()) X1 = silu_acc4(acc1, X1);
         }
         stamp(3 + 8 * l);
         fresh();
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
-        // This slice's rows, centred on the LayerNorm-1 mean: into its own region of the operand buffer and (write-through) to the
-        // other slices; wave w holds k block w of the slice.  Every wave is past its token-mix reads of the overlay when it gets here,
-        // but the OTHER waves may not be: the own-slice store waits for the barrier inside ln_publish ... so it goes to global first.
+        // This slice's rows, centred on the LayerNorm-1 mean: (write-through) to the other slices, and into its own region of the operand
+        // buffer once every wave is past its token-mix reads of the overlay (the barrier inside ln_publish); k block w of the slice.
         {
+            const f4 c0 = X0 - (f4){mu1_0, mu1_0, mu1_0, mu1_0}, c1 = X1 - (f4){mu1_1, mu1_1, mu1_1, mu1_1};
+            st_sc1(c0, xrs, ((c * 4 + w) * kCoopRows * 16 + row0() * 16 + 4 * g) * 4);
+            if (live1()) st_sc1(c1, xrs, ((c * 4 + w) * kCoopRows * 16 + (32 + s16) * 16 + 4 * g) * 4);
+            ln_publish(1, a.epoch + 2 * l + 2, true);                // LayerNorm-2 partials of the RAW rows
             float* own = U + c * kCoopSliceFloats + w * (kCoopRows * 16);
-#pragma unroll
-            for (int t = 0; t < NT1; ++t)
-                if (valid_of(t)) st_sc1(X[t] - (f4){mu1[t], mu1[t], mu1[t], mu1[t]}, xrs, ((c * 4 + w) * kCoopRows * 16 + (16 * t + s16) * 16 + 4 * g) * 4);
-            ln_publish(1, a.epoch + 2 * l + 2, true);                // LayerNorm-2 partials of the RAW rows; its barrier: token mixing is over
-#pragma unroll
-            for (int t = 0; t < NT1; ++t)
-                if (valid_of(t)) *reinterpret_cast<f4*>(&own[(16 * t + s16) * 16 + 4 * g]) = X[t] - (f4){mu1[t], mu1[t], mu1[t], mu1[t]};
+            *reinterpret_cast<f4*>(&own[row0() * 16 + 4 * g]) = c0;
+            if (live1()) *reinterpret_cast<f4*>(&own[(32 + s16) * 16 + 4 * g]) = c1;
         }
         stamp(4 + 8 * l);
         fresh();
@@ -392,16 +389,18 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
             f4 racc4 = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < NRV; ++r) racc[r] = 0.f;
-            // wch_img[L][8][2][32 q][2][64][4]: 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1); k block q = 4 s + q' of slice s
+            // wch_img[L][8][2][32 q][2][64][4]: 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1); k block q = 4 s + q' of slice s.
+            // Half h multiplies k blocks q' = 2h, 2h + 1 of every slice, slices in ring order from its own.
             const wrsrc_t wrs = wrsrc(a.W->wch_img);
             const int wsb = (((l * 8 + c) * 2 + (w >> 1)) * 32 * 2 + (w & 1)) * 1024;
-            auto qof = [&](int n) { return ((c + (n >> 2)) & 7) * 4 + (n & 3); };      // the n-th k block in this workgroup's slice order
+            auto qof = [&](int n) { return ((c + (n >> 1)) & 7) * 4 + 2 * h + (n & 1); };     // the n-th of this wave's 16 k blocks
             constexpr int PF = 4;                                    // weight fragments in flight ahead of their use
             f4 An[PF];
 #pragma unroll
             for (int k = 0; k < PF; ++k) An[k] = wload4(wrs, lane * 16, wsb + qof(k) * 2048);
             const unsigned long long* ga = gran + (size_t)kCoopRows * kCoopSlices * 2;         // area 1: row 0's mean granule = slice ready
             const unsigned tag2 = a.epoch + 2 * l + 2;
+            lds_barrier();                                           // own slice visible to every wave
             // Pull the 7 other slices (9 chunks of 1 KiB each, dealt over the waves) into their LDS regions as soon as their rows are
             // published: lane s polls slice s.  The pulls fly while this slice's own k blocks are multiplied from LDS.
             {
@@ -415,27 +414,21 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
 #pragma unroll 1
                 for (int i = 1; i < kCoopSlices; ++i) {
                     const int s = (c + i) & 7;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int ch = w + 4 * j;                    // wave-uniform
-                        if (ch < 9) dma_sc1(xrs, U + s * kCoopSliceFloats + ch * 256, lane * 16, (s * kCoopSliceFloats + ch * 256) * 4);
-                    }
+                    dma_sc1(xrs, U + s * kCoopSliceFloats + wv * 256, lane * 16, (s * kCoopSliceFloats + wv * 256) * 4);
+                    if (wv == 0) dma_sc1(xrs, U + s * kCoopSliceFloats + 8 * 256, lane * 16, (s * kCoopSliceFloats + 8 * 256) * 4);
                 }
             }
             typedef const __attribute__((address_space(3))) f4* ldsp4;
-            __syncthreads();                                         // own slice visible to every wave
 #pragma unroll 1
             for (int i = 0; i < kCoopSlices; ++i) {
                 const int s = (c + i) & 7;
                 if (i == 1) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's chunks have landed in LDS ...
-                    __syncthreads();                                  // ... and so have the other waves'
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // this wave's chunks have landed in LDS, and so have the other waves'
                     stamp(71 + 2 * l);
                 }
-                const float* ub = U + s * kCoopSliceFloats + s16 * 16 + 4 * g;
-                const float* ubr = U + s * kCoopSliceFloats + (32 + (kRemMfma ? (lane & 3) : 0)) * 16 + 4 * g;
-                // operands of a k block are read while the previous block is multiplied (one wave per SIMD at small batches: nothing
-                // else hides the LDS latency)
+                const float* ub = U + s * kCoopSliceFloats + (2 * h * kCoopRows + s16) * 16 + 4 * g;
+                const float* ubr = U + s * kCoopSliceFloats + (2 * h * kCoopRows + 32 + (kRemMfma ? (lane & 3) : 0)) * 16 + 4 * g;
+                // operands of a k block are read while the previous block is multiplied
                 f4 Bn[2], Un[kRemMfma ? 1 : NRV];
                 auto ldb = [&](int qq) {
 #pragma unroll
@@ -445,18 +438,18 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
                 };
                 ldb(0);
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int n = 4 * i + qq;
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int n = 2 * i + qq;
                     const f4 A = An[0];
 #pragma unroll
                     for (int k = 0; k + 1 < PF; ++k) An[k] = An[k + 1];
-                    An[PF - 1] = wload4(wrs, lane * 16, wsb + qof(min(n + PF, 31)) * 2048);
+                    An[PF - 1] = wload4(wrs, lane * 16, wsb + qof(min(n + PF, 15)) * 2048);
                     f4 Bv[2], Ur[kRemMfma ? 1 : NRV];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) Bv[t] = Bn[t];
 #pragma unroll
                     for (int r = 0; r < (kRemMfma ? 1 : NRV); ++r) Ur[r] = Un[r];
-                    if (qq + 1 < 4) ldb(qq + 1);
+                    if (qq + 1 < 2) ldb(qq + 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -477,33 +470,40 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
             }
             stamp(5 + 8 * l);
             fresh();
-            // ragged rows: sum the 4 k subsets, then [channel-lane][row] -> [row-lane][channel-reg] through a per-wave LDS patch
-            float* rem = REM + w * (4 * 16);
+            // The two halves swap partial sums through LDS (overlaid on the operand buffer, which every wave has finished reading
+            // after the barrier): wave (w, h) keeps row tile h and hands tile 1 - h to wave (w, 1 - h); the ragged rows' partials --
+            // summed over the 4 k subsets of the lanes first, [channel-lane][row] -> [row-lane][channel-reg] -- all go to half 1.
+            __syncthreads();
+            float* xch = U + wv * 256;                               // [8 waves][64 lanes][4]
+            float* rag = U + 8 * 256 + wv * 64;                      // [8 waves][4 rows][16 channels]
+            *reinterpret_cast<f4*>(&xch[lane * 4]) = h ? acc[0] : acc[1];
             if constexpr (kRemMfma) {
                 f4 v = racc4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = xor32_sum(xor16_sum(v[i]));
-                if (g == 0) *reinterpret_cast<f4*>(&rem[(lane & 3) * 16 + 4 * (s16 >> 2)]) = v;
+                if (g == 0) *reinterpret_cast<f4*>(&rag[(lane & 3) * 16 + 4 * (s16 >> 2)]) = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < NRV; ++r) {
                     const float v = xor32_sum(xor16_sum(racc[r]));
-                    if (g == 0) rem[r * 16 + s16] = v;
+                    if (g == 0) rag[r * 16 + s16] = v;
                 }
             }
             // LayerNorm 2 around the product: v = rstd2 * (acc - (mu2 - mu1) wsum) + b'
-            ln_gather(1, tag2, 2 + 8 * l + 6);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float dm = mean[t] - mu1[t];
-                const f4 v = (acc[t] - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd[t], rstd[t], rstd[t], rstd[t]} + bc;
-                X[t] = silu_acc4(v, X[t]);
+            ln_gather(1, tag2, 2 + 8 * l + 6);                       // its barrier: the partner's partials are in LDS
+            {
+                const f4 mine = h ? acc[1] : acc[0];
+                const f4 sum = mine + *reinterpret_cast<const f4*>(&U[(wv ^ 4) * 256 + lane * 4]);
+                const float dm = mean0 - mu1_0;
+                const f4 v = (sum - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd0, rstd0, rstd0, rstd0} + bc;
+                X0 = silu_acc4(v, X0);
             }
-            if (s16 < NREM) {
-                const f4 rv = *reinterpret_cast<const f4*>(&rem[s16 * 16 + 4 * g]);
-                const float dm = mean[2] - mu1[2];
-                const f4 v = (rv - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd[2], rstd[2], rstd[2], rstd[2]} + bc;
-                X[2] = silu_acc4(v, X[2]);
+            if (live1()) {
+                const f4 rv = *reinterpret_cast<const f4*>(&rag[s16 * 16 + 4 * g]) +
+                              *reinterpret_cast<const f4*>(&U[8 * 256 + (wv ^ 4) * 64 + s16 * 16 + 4 * g]);
+                const float dm = mean1 - mu1_1;
+                const f4 v = (rv - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd1, rstd1, rstd1, rstd1} + bc;
+                X1 = silu_acc4(v, X1);
             }
         }
         stamp(6 + 8 * l);
@@ -515,47 +515,41 @@ __global__ __launch_bounds__(kCoopThreads, 2) void k_coop(const StepArgs a) {
     const int n16 = np * kCoopSlices;                                // workgroups of this sample
     const unsigned tagF = a.epoch + 2 * a.layers + 1;
     {
-        // this slice's final rows -> LDS [S][64] (token-mix operand layout); the last ln_gather's barrier ordered every wave's
-        // channel-mix reads before these stores
-#pragma unroll
-        for (int t = 0; t < NT1; ++t)
-            if (valid_of(t)) *reinterpret_cast<f4*>(&U[(16 * t + s16) * kCoopU1Stride + 16 * w + 4 * g]) = X[t];
+        // this slice's final rows -> LDS [S][64] (token-mix operand layout): every wave has to be past its reads of the partial sums
+        __syncthreads();
+        *reinterpret_cast<f4*>(&U[row0() * kCoopU1Stride + 16 * w + 4 * g]) = X0;
+        if (live1()) *reinterpret_cast<f4*>(&U[(32 + s16) * kCoopU1Stride + 16 * w + 4 * g]) = X1;
         __syncthreads();
         // partial poseFinal over this slice's 64 channels: unit (out block ob, row tile t) = 16 MFMAs; wout_reg_img[8][NOB][4][64][4]
         // holds Wout[16 ob + (lane & 15)][64 c + 16 q' + 4 (lane >> 4) + j] (ls_api.cpp build_fused_images)
         float* part = a.cpart + ((size_t)pg * kCoopSlices + c) * kCoopRows * NOBP;
         const wrsrc_t prs = uniform_rsrc(part);
         const wrsrc_t wrs = wrsrc(a.W->wout_reg_img);
-        constexpr int MAXOB = (NOB + kCoopWaves - 1) / kCoopWaves;   // out blocks per wave: block ob = w + 4 i
         f4 An[4];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + min(w, NOB - 1)) * 4 + qq) * 1024);
+        for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + min(wv, NU - 1) / NT1) * 4 + qq) * 1024);
 #pragma unroll 1
-        for (int i = 0; i < MAXOB; ++i) {
-            const int ob = w + kCoopWaves * i;                       // wave-uniform
-            if (ob >= NOB) break;
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = wv + kCoopWaves * i;                       // wave-uniform
+            if (u >= NU) break;
+            const int ob = u / NT1, t = u - ob * NT1;
             f4 A[4];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) A[qq] = An[qq];
-            const int obn = min(ob + kCoopWaves, NOB - 1);           // the next block's fragments fly under this block's MFMAs
+            const int obn = min(u + kCoopWaves, NU - 1) / NT1;       // the next unit's fragments fly under this unit's MFMAs
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + obn) * 4 + qq) * 1024);
-            f4 o[NT1];
-#pragma unroll
-            for (int t = 0; t < NT1; ++t) o[t] = (f4){0.f, 0.f, 0.f, 0.f};
+            const int rc = min(16 * t + s16, S - 1);
+            f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                f4 Bv[NT1];
-#pragma unroll
-                for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kCoopU1Stride + 16 * qq + 4 * g]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < NT1; ++t) o[t] = MFMA(A[qq][j], Bv[t][j], o[t]);
+                const f4 Bv = *reinterpret_cast<const f4*>(&U[rc * kCoopU1Stride + 16 * qq + 4 * g]);
+                a0 = MFMA(A[qq][0], Bv[0], a0);
+                a1 = MFMA(A[qq][1], Bv[1], a1);
+                a0 = MFMA(A[qq][2], Bv[2], a0);
+                a1 = MFMA(A[qq][3], Bv[3], a1);
             }
-#pragma unroll
-            for (int t = 0; t < NT1; ++t)
-                if (valid_of(t)) st_sc1(o[t], prs, ((16 * t + s16) * NOBP + 16 * ob + 4 * g) * 4);
+            if (16 * t + s16 < S) st_sc1(a0 + a1, prs, ((16 * t + s16) * NOBP + 16 * ob + 4 * g) * 4);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
