@@ -197,6 +197,8 @@ typedef struct ls_timing {
     float tape_upload_ms;       /* segmented TAPE mode: summed GPU-side duration of the tape uploads of the last loop (copy stream) */
     int32_t n_segments;         /* segments the last loop ran in (1 = one call)     */
     int32_t step_path;          /* kernels the last loop's steps ran on: 0 one workgroup per sample (fused), 1 batch-level, 2 sample-split */
+    int32_t tail_samples;       /* fused path with a partial last round: samples of that round, run on ...        */
+    int32_t tail_path;          /* ... 1 the batch-level, 2 the sample-split kernels (0: none)                     */
 } ls_timing;
 
 int ls_abi_version(void);

@@ -64,6 +64,9 @@ struct ls_handle {
     bool use_long = false;  // the prepared batch runs the batch-level kernels (always when !fused; small batches of a fused model)
     int path_mode = 0;      // ls_set_path: 0 auto, 1 one workgroup per sample (fused kernel), 2 batch-level kernels, 3 sample-split kernel
     bool use_coop = false;  // the prepared batch runs the sample-split kernel (ls_coop_kernel.h: 16 workgroups per sample)
+    // fused main path with a partial last round: the last tail_n samples run on the sample-split (tail_path 2) or batch-level (1) kernels
+    int tail_n = 0, tail_path = 0;
+    bool plan_pair = false; // the plan assumed the single-pass form (every guidance scale 1)
     DevBuf wtok1_img;       // token-mix operand of one pass (sample-split kernel)
     DevBuf co_x, co_part, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
     unsigned coop_launches = 0;                        // launches since the granule words were zeroed: epoch = 64 * ordinal
@@ -555,42 +558,57 @@ int ensure_temb_table(ls_handle* h) {
     return LS_OK;
 }
 
-// precision 0: exact fp32 (k_step<..,0>); 1: bf16x3 inside the same one-workgroup-per-sample kernel (k_step<..,1>)
-// pair: the single-pass variant (two samples' cond pass per workgroup), legal when every guidance scale is 1
-hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
-    s.batch = B;
-    if (h->use_coop && !s.trace) {
-        // sample-split kernel: 16 (CFG) or 8 (single pass) workgroups per sample, as many samples per launch as are resident at once
-        const int np = pair ? 1 : 2, per = h->coop_groups / np;
-        for (int b0 = 0; b0 < B; b0 += per) {
-            StepArgs c = s;
-            c.cx = h->co_x.f(); c.cpart = h->co_part.f();
-            c.cgran = static_cast<unsigned long long*>(h->co_gran.p); c.cflag = static_cast<unsigned long long*>(h->co_flag.p);
-            c.cerr = static_cast<unsigned*>(h->co_err.p);
-            c.epoch = (++h->coop_launches) * 64u;
-            c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap;
-            hipError_t e = launch_step_coop(h->var, c, B - b0 < per ? B - b0 : per, st);
-            if (e != hipSuccess) return e;
-        }
-        return hipSuccess;
+// the sample-split kernel over samples [first, first + n): 16 (CFG) or 8 (single pass) workgroups per sample, as many samples per
+// launch as are resident at once
+hipError_t run_coop(ls_handle* h, const StepArgs& s, int first, int n, bool pair, hipStream_t st) {
+    const int np = pair ? 1 : 2, per = h->coop_groups / np;
+    for (int b0 = first; b0 < first + n; b0 += per) {
+        StepArgs c = s;
+        c.cx = h->co_x.f(); c.cpart = h->co_part.f();
+        c.cgran = static_cast<unsigned long long*>(h->co_gran.p); c.cflag = static_cast<unsigned long long*>(h->co_flag.p);
+        c.cerr = static_cast<unsigned*>(h->co_err.p);
+        c.epoch = (++h->coop_launches) * 64u;
+        c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap;
+        hipError_t e = launch_step_coop(h->var, c, first + n - b0 < per ? first + n - b0 : per, st);
+        if (e != hipSuccess) return e;
     }
-    // one workgroup per sample (fused kernel) unless the prepared batch runs on the batch-level kernels; per-sample timestep rows and
-    // the residual-stream trace exist in the fused kernel only
-    if (h->fused && !(h->use_long && s.temb_stride == 0 && !s.trace)) return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
-    // batch-level path: the same step from separate kernels over all rows (both passes always; exact fp32 only)
+    return hipSuccess;
+}
+
+// the batch-level kernels over samples [first, first + n): the same step from separate kernels over all rows (both passes always; exact fp32 only)
+hipError_t run_long(ls_handle* h, const StepArgs& s, int first, int n, hipStream_t st) {
     LongStepArgs a{};
+    const size_t ox = (size_t)first * h->T * h->JF, od = (size_t)first * kD, os = (size_t)first * h->T * kD;
+    auto sh = [](auto* p, size_t o) { return p ? p + o : p; };
     a.tokpad = h->tokpad;
-    a.B = B; a.T = h->T; a.S = h->S; a.npre = h->cfg.n_prefix_tokens; a.JF = h->JF; a.JFP = h->JFP; a.ldo = (h->JF + 127) / 128 * 128; a.layers = h->cfg.layers;
-    a.x_in = s.x_in; a.x_out = s.x_out; a.x0_out = s.x0_out; a.fwd_c = s.fwd_c; a.fwd_u = s.fwd_u;
-    a.static_c = s.static_c; a.static_u = s.static_u; a.z_mu = s.z_mu; a.z_std = s.z_std; a.emo_tok = s.emo_tok; a.scale = s.scale;
+    a.B = n; a.b0 = first; a.T = h->T; a.S = h->S; a.npre = h->cfg.n_prefix_tokens; a.JF = h->JF; a.JFP = h->JFP; a.ldo = (h->JF + 127) / 128 * 128; a.layers = h->cfg.layers;
+    a.x_in = s.x_in + ox; a.x_out = sh(s.x_out, ox); a.x0_out = sh(s.x0_out, ox); a.fwd_c = sh(s.fwd_c, ox); a.fwd_u = sh(s.fwd_u, ox);
+    a.static_c = s.static_c + os; a.static_u = s.static_u + os; a.z_mu = s.z_mu + od; a.z_std = s.z_std + od; a.emo_tok = sh(s.emo_tok, od); a.scale = sh(s.scale, (size_t)first);
     a.temb = s.temb;
-    a.eps_c = s.eps_c; a.eps_u = s.eps_u; a.noise = s.noise; a.const_noise = s.const_noise; a.call = s.call; a.step_id = s.step_id;
+    a.eps_c = sh(s.eps_c, od); a.eps_u = sh(s.eps_u, od); a.noise = sh(s.noise, s.const_noise ? (size_t)0 : ox); a.const_noise = s.const_noise; a.call = s.call; a.step_id = s.step_id;
     a.winx = h->lw_winx.f(); a.ln1a = h->ln1a.f(); a.ln1b = h->ln1b.f(); a.ln2a = h->ln2a.f(); a.ln2b = h->ln2b.f();
     a.wt = h->lw_wt.f(); a.wtp = h->lw_wtp.f(); a.part1 = h->lx_part1.f(); a.part2 = h->lx_part2.f(); a.wcf = h->lw_wcf.f(); a.bcf = h->lw_bcf.f(); a.wsum = h->lw_wsum.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
     a.xproj = h->lx_proj.f(); a.xpad = h->lx_xpad.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
     a.sampler = s.sampler; a.t_nonzero = s.t_nonzero; a.clip_denoised = s.clip_denoised;
     a.c0 = s.c0; a.c1 = s.c1; a.c2 = s.c2; a.c3 = s.c3; a.c4 = s.c4;
     return launch_step_long(a, st);
+}
+
+// One diffusion step of the prepared batch on the kernels decide_path chose.
+// precision 0: exact fp32 (k_step<..,0>); 1: bf16x3 inside the same one-workgroup-per-sample kernel (k_step<..,1>)
+// pair: the single-pass variant (two samples' cond pass per workgroup), legal when every guidance scale is 1
+hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
+    s.batch = B;
+    if (h->use_coop && !s.trace) return run_coop(h, s, 0, B, pair, st);
+    // per-sample timestep rows exist in the fused and the sample-split kernel, the residual-stream trace in the fused kernel only
+    if (!h->fused || (h->use_long && s.temb_stride == 0 && !s.trace)) return run_long(h, s, 0, B, st);
+    // one workgroup per sample; a partial last round goes to the kernels that fill the chip with few samples
+    int nf = B;
+    if (h->tail_n > 0 && h->tail_n < B && !s.trace && pair == h->plan_pair && (h->tail_path == 2 || s.temb_stride == 0)) nf = B - h->tail_n;
+    s.batch = nf;
+    hipError_t e = launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, nf, st);
+    if (e != hipSuccess || nf == B) return e;
+    return h->tail_path == 2 ? run_coop(h, s, nf, B - nf, pair, st) : run_long(h, s, nf, B - nf, st);
 }
 
 void fill_common(ls_handle* h, StepArgs& a) {
@@ -672,32 +690,51 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
     return launch_inpaint_update(ia, B, st);
 }
 
-// Which kernels the prepared batch runs on.  The fused kernel gives one CU to each sample, so a step costs one CU's time for eight
-// layers (0.68 ms TED) however small the batch; the batch-level kernels spread the same rows over the whole chip (21 launches per
-// step) and win below kLongMaxBatch samples (measured: profiles/r03 small-batch table).  34-frame models only choose; other frame
-// counts have no fused kernel.
-constexpr int kLongMaxBatch = 160;
-// The sample-split kernel (ls_coop_kernel.h) spreads a sample over 16 workgroups inside ONE launch per step; it takes the small
-// batches (measured crossovers: profiles/r04 throughput-vs-batch table).  Exact fp32 only.
-constexpr int kCoopMaxBatch = 128;
+// Which kernels the prepared batch runs on (34-frame models; other frame counts have only the batch-level kernels).
+//   fused         one workgroup = one CU per sample: a step costs one CU's time for eight layers however small the batch, and a batch
+//                 of 256 k + r samples pays k + 1 full rounds;
+//   sample-split  16 workgroups per sample inside one launch (ls_coop_kernel.h), 32 samples per launch;
+//   batch-level   every row of the batch through 21 launches per step that fill the chip (ls_long.hip).
+// Step-time models in ms, measured on MI355X (profiles/r04_throughput_vs_batch.md): the plan is the cheapest of
+//   all sample-split | all batch-level | all fused | full fused rounds + the remainder on sample-split or batch-level.
+struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round; };
+constexpr PathCost kCostTed{0.100f, 0.00105f, 0.175f, 0.0030f, 0.68f}, kCostBeat{0.114f, 0.0011f, 0.166f, 0.0034f, 0.79f};
+float coop_ms(const PathCost& c, int n, int np) {
+    float ms = 0.f;
+    for (int g = n * np; g > 0; g -= kCoopMaxGroups) ms += c.coop_base + c.coop_per_group * (g < kCoopMaxGroups ? g : kCoopMaxGroups);
+    return ms;
+}
 void decide_path(ls_handle* h) {
     const bool before = h->use_long, before_c = h->use_coop;
-    h->use_coop = false;
+    const int before_t = h->tail_n * 4 + h->tail_path;
+    h->use_coop = false; h->use_long = false; h->tail_n = 0; h->tail_path = 0;
+    const bool have_long = h->lw_wtp.p != nullptr;
+    h->plan_pair = h->all_scale_one;
     if (!h->fused) h->use_long = true;
-    else if (h->precision != 0) h->use_long = false;
-    else if (h->path_mode == 1) h->use_long = false;
-    else if (h->path_mode == 2) h->use_long = h->lw_wtp.p != nullptr;
-    else if (h->path_mode == 3) { h->use_long = false; h->use_coop = true; }
-    else {
-        h->use_coop = h->B > 0 && h->B <= kCoopMaxBatch;
-        h->use_long = !h->use_coop && h->lw_wtp.p != nullptr && h->B > 0 && h->B <= kLongMaxBatch;
+    else if (h->precision != 0 || h->path_mode == 1) {}
+    else if (h->path_mode == 2) h->use_long = have_long;
+    else if (h->path_mode == 3) h->use_coop = true;
+    else if (h->B > 0) {
+        const PathCost& c = h->var == kTED ? kCostTed : kCostBeat;
+        const int B = h->B, np = h->plan_pair ? 1 : 2, round = h->plan_pair ? 512 : 256;
+        auto long_ms = [&](int n) { return have_long ? c.long_base + c.long_per_sample * n : 1e30f; };
+        const float all_coop = coop_ms(c, B, np), all_long = long_ms(B), all_fused = c.fused_round * ((B + round - 1) / round);
+        float best = all_fused;
+        int r = B % round;
+        if (B > round && r > 0) {       // full rounds + remainder
+            const float head = c.fused_round * (B / round), tc = head + coop_ms(c, r, np), tl = head + long_ms(r);
+            if (tc < best && tc <= tl) { best = tc; h->tail_n = r; h->tail_path = 2; }
+            else if (tl < best) { best = tl; h->tail_n = r; h->tail_path = 1; }
+        }
+        if (all_coop < best && all_coop <= all_long) { h->use_coop = true; h->tail_n = 0; h->tail_path = 0; }
+        else if (all_long < best) { h->use_long = true; h->tail_n = 0; h->tail_path = 0; }
     }
-    if (before != h->use_long || before_c != h->use_coop) free_graph(h);
+    if (before != h->use_long || before_c != h->use_coop || before_t != h->tail_n * 4 + h->tail_path) free_graph(h);
 }
 
 // zero the granule / flag words of the sample-split kernel (stream-ordered: a memset node when captured) and restart the epochs
 hipError_t coop_reset(ls_handle* h, hipStream_t st) {
-    if (!h->use_coop) return hipSuccess;
+    if (!h->use_coop && h->tail_path != 2) return hipSuccess;
     hipError_t e = hipMemsetAsync(h->co_gran.p, 0, h->co_gran.bytes, st);
     if (e == hipSuccess) e = hipMemsetAsync(h->co_flag.p, 0, h->co_flag.bytes, st);
     h->coop_launches = 0;
@@ -707,7 +744,7 @@ hipError_t coop_reset(ls_handle* h, hipStream_t st) {
 // after a stream synchronisation: did a hand-off spin of the sample-split kernel run out?  (Never observed; a result computed past a
 // timeout is garbage, so the call fails loudly.)
 int coop_check(ls_handle* h) {
-    if (!h->use_coop) return LS_OK;
+    if (!h->use_coop && h->tail_path != 2) return LS_OK;
     unsigned v = 0;
     HIPCHK(h, hipMemcpy(&v, h->co_err.p, sizeof v, hipMemcpyDeviceToHost));
     if (!v) return LS_OK;
@@ -715,6 +752,12 @@ int coop_check(ls_handle* h) {
     return fail(h, LS_EHIP, "sample-split step kernel: an inter-workgroup hand-off timed out; the results of this call are invalid");
 }
 int step_path_code(const ls_handle* h) { return h->use_coop ? 2 : (h->use_long ? 1 : 0); }
+void report_path(ls_handle* h, bool pair) {
+    h->timing.step_path = step_path_code(h);
+    const bool tail = h->tail_n > 0 && pair == h->plan_pair && !h->use_coop && !h->use_long;
+    h->timing.tail_samples = tail ? h->tail_n : 0;
+    h->timing.tail_path = tail ? h->tail_path : 0;
+}
 
 // upload timing of a slot whose copy has been enqueued: wait for it (long done in steady state) and add it to the loop's total
 int close_upload(ls_handle* h, int slot) {
@@ -833,7 +876,7 @@ int sample_segment(ls_handle* h, const ls_sample_args* a) {
     resolve_prepare_timing(h, true);
     if ((rc = close_upload(h, 0)) != LS_OK || (rc = close_upload(h, 1)) != LS_OK) return rc;
     if ((rc = coop_check(h)) != LS_OK) return rc;
-    h->timing.step_path = step_path_code(h);
+    report_path(h, pair);
     HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
     HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
     h->timing.n_step_launches = n_exec;
@@ -999,8 +1042,12 @@ int ls_set_precision(ls_handle* h, int mode) {
     if (!h->fused && mode != LS_PRECISION_FP32) return fail(h, LS_EUNSUPPORTED, "the long-sequence path (nframes != %d) is exact fp32 only", kT);
     if (mode != h->precision) free_graph(h);
     h->precision = mode;
-    if (h->prepared && h->fused && mode != LS_PRECISION_FP32 && h->use_long) decide_path(h);       // bf16x3 exists in the fused kernel only
-    else if (h->prepared) { const bool was = h->use_long; decide_path(h); if (h->use_long && !was) h->prepared = false; }   // its workspaces come from ls_prepare
+    if (h->prepared) {      // the plan may move to kernels whose workspaces the last ls_prepare did not allocate: prepare again then
+        const bool wl = h->use_long, wc = h->use_coop;
+        const int wt = h->tail_n * 4 + h->tail_path;
+        decide_path(h);
+        if ((h->use_long && !wl) || (h->use_coop && !wc) || (h->tail_n && wt != h->tail_n * 4 + h->tail_path)) h->prepared = false;
+    }
     return LS_OK;
 }
 
@@ -1131,8 +1178,9 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, h->T));   // y['emo'][:, 0]
     }
     { const int keepB = h->B; h->B = B; decide_path(h); h->B = keepB; }
-    if (h->use_coop) {      // exchange workspaces of the sample-split kernel: one launch's worth of (sample, pass) groups
-        const int groups = 2 * B < h->coop_groups_max ? 2 * B : h->coop_groups_max;
+    if (h->use_coop || h->tail_path == 2) {      // exchange workspaces of the sample-split kernel: one launch's worth of (sample, pass) groups
+        const int nco = h->use_coop ? B : h->tail_n;
+        const int groups = 2 * nco < h->coop_groups_max ? 2 * nco : h->coop_groups_max;
         const void* old[4] = {h->co_x.p, h->co_part.p, h->co_gran.p, h->co_flag.p};
         const size_t before = h->co_x.bytes;
         HIPCHK(h, h->co_x.ensure((size_t)groups * 36 * kD * sizeof(float)));
@@ -1143,10 +1191,11 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         if (old[0] != h->co_x.p || old[1] != h->co_part.p || old[2] != h->co_gran.p || old[3] != h->co_flag.p) free_graph(h);
         h->coop_groups = groups;
     }
-    if (h->use_long) {      // workspaces of the batch-level path: token sequences of both passes (two buffers), row partials, poseFinal output
+    if (h->use_long || h->tail_path == 1) {      // workspaces of the batch-level path: token sequences of both passes (two buffers), row partials, poseFinal output
+        const size_t nlo = h->use_long ? B : h->tail_n;
         const void* old[5] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p, h->lx_xpad.p};
-        const size_t rows = ((size_t)2 * B * h->S + 127) / 128 * 128;      // whole 128-row GEMM tiles (the fused channel-mixing product runs over the pad rows too)
-        const size_t mpad = ((size_t)B * h->T + 127) / 128 * 128;           // x_t projection on whole 128-row tiles (k_long_padx)
+        const size_t rows = ((size_t)2 * nlo * h->S + 127) / 128 * 128;      // whole 128-row GEMM tiles (the fused channel-mixing product runs over the pad rows too)
+        const size_t mpad = ((size_t)nlo * h->T + 127) / 128 * 128;           // x_t projection on whole 128-row tiles (k_long_padx)
         HIPCHK(h, h->lx_proj.ensure(mpad * kD * sizeof(float)));
         HIPCHK(h, h->lx_xpad.ensure(mpad * h->JFP * sizeof(float)));
         { const size_t before = h->lx_X.bytes + h->lx_U.bytes;
@@ -1420,7 +1469,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     {
         char keybuf[256];
         snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d L%d", h->precision, B, a->sampler, (double)a->eta,
-                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, step_path_code(h));
+                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, step_path_code(h) + 4 * h->tail_path + 16 * h->tail_n);
         key = keybuf;
         if (inpaint) key += inp_noised ? " I2" : " I1";
         for (int d = 0; d < a->n_dump; ++d) key += "," + std::to_string(a->dump_steps[d]);      // the whole list, however long
@@ -1494,7 +1543,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     HIPCHK(h, hipStreamSynchronize(st));
     resolve_prepare_timing(h, true);
     if ((rc = coop_check(h)) != LS_OK) return rc;
-    h->timing.step_path = step_path_code(h);
+    report_path(h, pair);
     HIPCHK(h, hipEventElapsedTime(&h->timing.loop_ms, h->ev[1], h->ev[2]));
     HIPCHK(h, hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[3]));
     h->timing.n_step_launches = n_exec;

@@ -117,6 +117,7 @@ enum Variant { kTED = 0, kBEAT = 1 };
 // Arguments of one diffusion step of the long-sequence path (ls_long.hip): same roles as StepArgs, plus the batch-level workspaces.
 struct LongStepArgs {
     int B, T, S, npre, JF, JFP, ldo, layers;
+    int b0;                                // index of this launch's first sample in the prepared batch (its Philox streams); pointers are already shifted
     int tokpad;                            // token axis of the wtp image: 48 (S <= 48) or 160
     const float* x_in; float* x_out; float* x0_out; float* fwd_c; float* fwd_u;      // internal layout [B][T][JF]
     const float* static_c; const float* static_u; const float* z_mu; const float* z_std; const float* emo_tok; const float* scale;

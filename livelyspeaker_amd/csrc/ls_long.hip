@@ -52,7 +52,7 @@ __global__ __launch_bounds__(128) void k_long_assemble(const LongStepArgs a, int
         if (ep) e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + ch);
         else {
             float z[4];
-            philox_normal4(a.call, a.call->sample_offset + (unsigned long long)b, a.step_id, 1u + p, (unsigned)(ch >> 2), z);
+            philox_normal4(a.call, a.call->sample_offset + (unsigned long long)(a.b0 + b), a.step_id, 1u + p, (unsigned)(ch >> 2), z);
             e = (f4){z[0], z[1], z[2], z[3]};
         }
         v = mu + e * sd;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_long_update(const LongStepArgs a) {
     const int b = blockIdx.y;
     const int TJ = a.T * a.JF;
     const float sc = a.scale ? a.scale[b] : 1.0f;
-    const unsigned long long gidx = a.call->sample_offset + (unsigned long long)b;
+    const unsigned long long gidx = a.call->sample_offset + (unsigned long long)(a.b0 + b);
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < TJ; idx += gridDim.x * 256) {
         const int f = idx / a.JF, c = idx - f * a.JF;
         const float bo = a.bout[c];

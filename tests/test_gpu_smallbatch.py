@@ -119,14 +119,16 @@ def test_the_two_paths_agree_and_auto_switches_with_the_batch():
     d = max_abs(outs["fused"], outs["batch"])
     print(f"fused vs batch-level kernels, 30 steps, B = 9: {d:.3e}")
     assert 0 < d < 5e-5                                              # same arithmetic, different summation order: close, not bitwise
-    # auto: a small batch takes the batch-level kernels (both passes even at scale 1), a large one the fused kernel (single pass at scale 1)
+    # auto: a small batch takes the sample-split kernel, a medium one the batch-level kernels (both passes even at scale 1), a large one
+    # the fused kernel; scale 1 runs single-pass wherever the kernels have that form
     _, eng = _engine("ted", "auto")
     try:
         eng.set_schedule(orc.Schedule(4, ""))
-        for B, want_single in ((6, 0), (300, 1)):
-            eng.prepare(synth.make_cond(cfg, B, scale=1.0))
+        for B, scale, want_path, want_single in ((6, 1.0, 2, 1), (6, 1.5, 2, 0), (120, 1.5, 1, 0), (300, 1.0, 0, 1), (256, 1.5, 0, 0)):
+            eng.prepare(synth.make_cond(cfg, B, scale=scale))
             out = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=5)
-            assert np.isfinite(out).all() and eng.timing()["single_pass"] == want_single, B
+            t = eng.timing()
+            assert np.isfinite(out).all() and (t["step_path"], t["single_pass"]) == (want_path, want_single), (B, scale, t)
         # the opt-in split-precision mode exists in the fused kernel only: a small batch stays there
         eng.set_precision("bf16x3")
         eng.prepare(synth.make_cond(cfg, 6, scale=1.0))
