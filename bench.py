@@ -73,6 +73,11 @@ def parse():
                     help="TEST ONLY (1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo on host copies -- RCCL "
                          "refuses two ranks on one device ('Duplicate GPU detected'), so this exercises the whole N>1 control flow "
                          "(self-launch, sharding, broadcast, gather, cross-check, max-over-ranks timing) but not RCCL itself")
+    ap.add_argument("--launcher", default="torchrun", choices=["torchrun", "threads"],
+                    help="N > 1: 'torchrun' = one process per GPU with torch.distributed (RCCL, gloo fallback); 'threads' = ONE process, "
+                         "N engine handles on N devices driven by N Python threads, no collective at all (an independent N-GPU number)")
+    ap.add_argument("--no-rccl", action="store_true", help="do not try RCCL: collectives over gloo on host copies")
+    ap.add_argument("--rccl-probe-timeout", type=float, default=120.0, help="seconds the RCCL bring-up + first collectives may take")
     ap.add_argument("--no-traffic-pass", action="store_true", help="do not spawn the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32 = exact (headline); bf16x3 = opt-in split-precision channel mixing")
@@ -478,9 +483,116 @@ def _self_launch(a):
     return subprocess.run(cmd, env=env).returncode
 
 
+def threads_main(a):
+    """`--launcher threads`: the N-device run without any process group.  One process, N engine handles (one per device; all on
+    cuda:0 with --ranks-share-device), N Python threads -- ctypes releases the GIL inside ls_sample, so the devices run concurrently.
+    The global batch is split with ls_shard_range exactly like the torchrun path (shard r = rank r's batch, Philox streams keyed by
+    the global sample index through sample_offset), the results are concatenated on the host, and shard 1 is re-generated on device
+    0 as the cross-check.  Same barrier -> K calls -> barrier timing, max over threads = the wall time of the slowest device."""
+    global _RESULT_OUT
+    _RESULT_OUT = _reserve_stdout()
+    import ctypes
+    import threading
+    import torch
+    from livelyspeaker_amd import _lib, synth
+    world = a.gpus
+    ndev = torch.cuda.device_count()
+    if not a.ranks_share_device and world > ndev:
+        raise SystemExit(f"--launcher threads --gpus {world}: only {ndev} GPU(s) visible (add --ranks-share-device to test on one)")
+    cfg = synth.CONFIGS[a.dataset]
+    strong = a.global_batch > 0
+    total = a.global_batch if strong else world * a.batch
+    lib = _lib.load_library()
+    spans = []
+    for r in range(world):
+        f, c = ctypes.c_int64(), ctypes.c_int64()
+        assert lib.ls_shard_range(total, world, r, ctypes.byref(f), ctypes.byref(c)) == 0
+        spans.append((f.value, c.value))
+    sd = synth.make_state_dict(cfg, seed=synth.SEED_WEIGHTS)
+    sch = synth.schedule(a.diffusion_steps, a.respacing)
+    ddim = a.respacing.startswith("ddim")
+    sampler = _lib.LS_SAMPLER_DDIM if ddim else _lib.LS_SAMPLER_DDPM
+    engines = []
+    for r in range(world):
+        e = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions,
+                        device=0 if a.ranks_share_device else r, path="auto")
+        e.load_state_dict(sd)
+        e.set_schedule(sch)
+        if a.precision != "fp32":
+            e.set_precision(a.precision)
+        engines.append(e)
+    conds = [synth.make_cond(cfg, spans[r][1], scale=a.scale, seed=synth.SEED_COND + r) for r in range(world)]
+    seed = 20260929
+    outs, times, errs = [None] * world, [0.0] * world, []
+    bar = threading.Barrier(world)
+
+    def worker(r, n, keep):
+        try:
+            e = engines[r]
+            bar.wait()
+            t0 = time.perf_counter()
+            for i in range(n):
+                e.prepare(conds[r])
+                o = e.sample(sampler=sampler, philox_seed=seed, sample_offset=spans[r][0], skip_timesteps=a.skip, use_graph=not a.no_graph)
+                if keep and i == 0:
+                    outs[r] = o
+            bar.wait()
+            times[r] = time.perf_counter() - t0
+        except Exception as ex:         # noqa: BLE001
+            errs.append(repr(ex)[:300])
+            bar.abort()
+
+    def run(n, keep):
+        ths = [threading.Thread(target=worker, args=(r, n, keep)) for r in range(world)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise SystemExit(f"threads launcher: {errs}")
+        return max(times)
+
+    if a.warmup:
+        run(a.warmup, False)
+    elapsed = run(a.steps, True)
+    whole = np.concatenate(outs, axis=0)
+    assert whole.shape[0] == total and np.isfinite(whole).all()
+    # cross-check: device 0 re-generates the NEXT shard by itself (same Philox key, that shard's conditioning, sample_offset)
+    nb = 1 % world
+    engines[0].prepare(conds[nb])
+    redo = engines[0].sample(sampler=sampler, philox_seed=seed, sample_offset=spans[nb][0], skip_timesteps=a.skip, use_graph=not a.no_graph)
+    diff = float(np.abs(redo - outs[nb]).max())
+    tm = engines[0].timing()
+    n_exec = sch.num_timesteps - a.skip
+    rec = {"metric": "pose-frames/sec denoised", "value": round(total * cfg.nframes * a.steps / elapsed, 2), "unit": "pose-frames/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "strong" if strong else "weak", "vs_baseline": None,
+           "dtype": "f32" if a.precision == "fp32" else "bf16x3 split (fp32 accumulate) for channel mixing, f32 elsewhere", "data": "synthetic",
+           "launcher": "threads: one process, one engine handle per device, one Python thread per handle (ctypes releases the GIL); no process "
+                       "group, no collective -- shards by ls_shard_range + sample_offset, results concatenated on the host",
+           "config": {"workload": f"{a.dataset.upper()} RAG, batch {spans[0][1]} x {cfg.nframes} frames per GPU, {n_exec}-step {'DDIM' if ddim else 'DDPM'}, "
+                                  f"CFG scale {a.scale}, random-init weights + synthetic conditioning, Philox noise on device",
+                      "global_batch": total, "frames": cfg.nframes, "denoise_steps": n_exec, "guidance_scale": a.scale,
+                      "parallelism": f"batch-sharded x{world}, no collective", "hipgraph": not a.no_graph},
+           "collective_backend": "none", "rccl_ranks": 0,
+           "shard_check": {"what": "device 0 re-generated the next shard via sample_offset and compared it with that handle's result",
+                           "max_abs_diff": diff, "bitwise_equal": diff == 0.0, "ranks": world},
+           "roofline": {"bound": "mfma", "kernel_ms_device0": round(tm["loop_ms"] / max(tm["n_step_launches"], 1), 4), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "note": "per-device kernel time of the last call on device 0; the headline roofline object is the torchrun launcher's"}}
+    if a.ranks_share_device:
+        rec["ranks_share_device"] = "TEST MODE: every handle on cuda:0 (the handles time-share one GPU); `value` is not a scaling number"
+    for e in engines:
+        e.close()
+    _RESULT_OUT.write(json.dumps(rec) + "\n")
+    _RESULT_OUT.flush()
+    return 0
+
+
 def main():
     global _RESULT_OUT
     a = parse()
+    if a.launcher == "threads":
+        return threads_main(a)
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(_self_launch(a))
     _RESULT_OUT = _reserve_stdout()
@@ -504,17 +616,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with a single rank)
-    backend = "none"
+    backend, groups = "none", None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = "gloo" if a.ranks_share_device else "nccl"
-        from datetime import timedelta
-        tmo = timedelta(minutes=15)              # a rank that never arrives ends the run with an error instead of holding the node
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+        # gloo default group (control plane; a rank that never arrives ends the run with an error after 15 minutes instead of holding
+        # the node) + an RCCL group for the data collectives that is PROBED first: if RCCL does not come up, or its first collectives
+        # fail or hang, every rank stays on gloo with its own GPU and the line says so (collective_backend, rccl_ranks: 0, rccl_error)
+        groups = shard.init_groups(dev, rank, world, want_rccl=not a.no_rccl, probe_timeout_s=a.rccl_probe_timeout)
+        backend = groups["collective_backend"]
 
     cfg = synth.CONFIGS[a.dataset]
     strong = a.global_batch > 0
@@ -800,9 +910,11 @@ def main():
             rec["shard_check"] = shard_check
             rec["rccl_ranks"] = shard_check["rccl_ranks"]
             rec["collective_backend"] = backend
+            if groups is not None and groups.get("rccl_error"):
+                rec["rccl_error"] = groups["rccl_error"]
             if a.ranks_share_device:
-                rec["ranks_share_device"] = ("TEST MODE: all ranks on cuda:0, collectives over gloo on host copies (RCCL rejects duplicate "
-                                             "devices); `value` is not a scaling number")
+                rec["ranks_share_device"] = ("TEST MODE: all ranks on cuda:0 (RCCL rejects duplicate devices, so its probe fails and the "
+                                             "collectives fall back to gloo on host copies -- the fallback path itself); `value` is not a scaling number")
         if not a.no_parity:
             try:
                 rec["parity_in_run"] = parity_in_run(cfg, a, first_out.detach().cpu().numpy(), first_seed, first, y_np, a.parity_samples)

@@ -351,7 +351,9 @@ class Engine:
             raise EngineError(f"ls_create failed ({rc}): {self.lib.ls_last_error(None).decode()}")
         self._stream = self.lib.ls_stream(self.h)
         self.path = path or Engine.default_path
-        if nframes == 34 and self.path != "auto":
+        if nframes != 34:
+            self.path = "batch"                       # other frame counts have only the batch-level kernels (ls_set_path refuses the rest)
+        elif self.path != "auto":
             self.set_path(self.path)
         self.J, self.F, self.T, self.D = njoints, nfeats, nframes, latent_dim
         self.S = nframes + n_prefix_tokens

@@ -17,7 +17,7 @@ using namespace ls;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;     // message of this thread's last failed ls_create (handles may be created from several threads)
 
 struct DevBuf {
     void* p = nullptr;

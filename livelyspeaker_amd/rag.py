@@ -125,8 +125,9 @@ class RAG(nn.Module):
         #: 'fp32' = exact fp32 MFMA (default, what parity/bench numbers refer to); 'bf16x3' = opt-in split-precision
         #: channel mixing (3 bf16 MFMAs per fp32 product, ~2^-16 relative; parity-tested against the 1e-3 contract)
         self.precision = "fp32"
-        #: which kernels the diffusion steps run on: None = the engine's default ("auto": batch-level kernels spread over the chip for
-        #: small batches, one workgroup per sample otherwise), "fused", "batch" (ls_set_path; same arithmetic, results agree to ~1e-5)
+        #: which kernels the diffusion steps run on: None = the engine's default ("auto": chosen per batch from a step-time model --
+        #: the sample-split kernel for small batches, batch-level kernels in the middle, one workgroup per sample from ~176 clips),
+        #: "fused", "batch", "coop" (ls_set_path; same arithmetic, results agree to ~1e-5)
         self.step_path = None
         self._engine = None
         self._weights_dirty = True
@@ -176,8 +177,9 @@ class RAG(nn.Module):
         if getattr(self._engine, "precision", "fp32") != self.precision:
             self._engine.set_precision(self.precision)
             self._cond_key = self._prefetched_key = None          # the kernel choice (and with it the workspaces of ls_prepare) may change with it
-        if self.step_path is not None and self._engine.path != self.step_path and self.nframes == 34:
-            self._engine.set_path(self.step_path)
+        want_path = self.step_path if self.step_path is not None else _lib.Engine.default_path      # None = the engine's default, both ways
+        if self._engine.path != want_path and self.nframes == 34:
+            self._engine.set_path(want_path)
             self._cond_key = self._prefetched_key = None
         return self._engine
 

@@ -16,14 +16,81 @@ import torch
 import torch.distributed as dist
 
 
+#: process group the data collectives run on: None = the default group.  ``init_groups`` sets it to an RCCL group when one comes up
+#: healthy and leaves the gloo default group (host copies) otherwise.
+_GROUP = None
+
+
 def _on() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def backend() -> str:
+    """Backend of the group the data collectives use ("nccl" = RCCL, "gloo", or "none" without a process group)."""
+    return dist.get_backend(_GROUP) if _on() else "none"
+
+
+def use_group(group) -> None:
+    global _GROUP
+    _GROUP = group
+
+
+def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_timeout_s: float = 120.0, timeout_min: float = 15.0) -> dict:
+    """Bring up the process groups so that a broken RCCL cannot take the job down (the reference's ``dist_util.setup_dist`` is a
+    stub, scripts/mdm_utils/dist_util.py:18-41, so there is nothing to mirror).  The DEFAULT group is gloo over TCP on the
+    rendezvous the launcher gave us: it carries the control plane (barriers, agreement) and, if need be, the data on host copies.
+    An RCCL group over the same ranks is then created and PROBED (one all_reduce + one all_gather on ``device``, waited for with a
+    timeout in a helper thread); only if every rank's probe succeeded do the data collectives move onto it.  Returns a record for
+    the bench line: {collective_backend, rccl_ranks, rccl_error}."""
+    import threading
+    from datetime import timedelta
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(minutes=timeout_min))
+    use_group(None)
+    info = {"collective_backend": "gloo", "rccl_ranks": 0, "rccl_error": None}
+    if not want_rccl:
+        info["rccl_error"] = "not requested"
+        return info
+    ok, err, grp = 1, None, None
+    box = {}
+
+    def probe():
+        try:
+            g = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=timedelta(seconds=max(30.0, probe_timeout_s)))
+            box["group"] = g
+            t = torch.full((1024,), float(rank + 1), device=device)
+            dist.all_reduce(t, group=g)
+            out = torch.empty(world * 8, device=device)
+            dist.all_gather_into_tensor(out, torch.full((8,), float(rank), device=device), group=g)
+            torch.cuda.synchronize(device)
+            want = world * (world + 1) / 2
+            if float(t[0].item()) != want or [float(v) for v in out[::8].tolist()] != [float(r) for r in range(world)]:
+                raise RuntimeError(f"RCCL probe returned wrong values ({float(t[0].item())} != {want})")
+            box["ok"] = True
+        except Exception as e:              # noqa: BLE001  (any failure means: stay on gloo)
+            box["err"] = repr(e)[:300]
+
+    th = threading.Thread(target=probe, daemon=True)
+    th.start()
+    th.join(probe_timeout_s)
+    if th.is_alive():
+        ok, err = 0, f"RCCL probe did not finish within {probe_timeout_s:.0f} s"
+    elif not box.get("ok"):
+        ok, err = 0, box.get("err", "RCCL probe failed")
+    agree = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)            # over gloo: every rank takes the same decision
+    if int(agree.item()) == 1:
+        use_group(box["group"])
+        info.update(collective_backend="nccl", rccl_ranks=world)
+    else:
+        info["rccl_error"] = err or "RCCL probe failed on another rank"
+    return info
+
+
 def _stage(t: torch.Tensor) -> torch.Tensor:
     """The tensor a collective runs on: device memory under RCCL, a host copy under gloo (whose device-tensor support is partial:
-    used by the CPU tests and by the two-ranks-on-one-GPU bench test, where RCCL refuses the duplicate device)."""
-    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+    used by the CPU tests, by the two-ranks-on-one-GPU bench test, where RCCL refuses the duplicate device, and whenever the RCCL
+    probe of ``init_groups`` failed)."""
+    return t.cpu() if (t.is_cuda and backend() == "gloo") else t
 
 
 def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
@@ -32,7 +99,7 @@ def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
         return t
     op = dist.ReduceOp.SUM if op is None else op
     s = _stage(t)
-    dist.all_reduce(s, op=op)
+    dist.all_reduce(s, op=op, group=_GROUP)
     if s is not t:
         t.copy_(s)
     return t
@@ -60,7 +127,7 @@ def broadcast_state_dict(sd: dict, device, src: int = 0) -> dict:
         return sd
     keys = sorted(sd.keys())
     flat = _stage(torch.cat([sd[k].reshape(-1).to(torch.float32) for k in keys]).to(device))
-    dist.broadcast(flat, src=src)
+    dist.broadcast(flat, src=src, group=_GROUP)
     flat = flat.cpu()
     out, off = {}, 0
     for k in keys:
@@ -76,7 +143,7 @@ def broadcast_tensor(t: torch.Tensor, device, src: int = 0) -> torch.Tensor:
         return t
     buf = t.to(device).contiguous()
     s = _stage(buf)
-    dist.broadcast(s, src=src)
+    dist.broadcast(s, src=src, group=_GROUP)
     if s is not buf:
         buf.copy_(s)
     return buf
@@ -97,12 +164,12 @@ def gather_samples(local: torch.Tensor, total: int) -> torch.Tensor:
         buf[: local.shape[0]] = local
         local = buf
     out = local.new_empty((world * pad,) + tuple(local.shape[1:]))
-    if local.is_cuda and dist.get_backend() == "gloo":
+    if local.is_cuda and backend() == "gloo":
         host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(host, local.cpu())
+        dist.all_gather_into_tensor(host, local.cpu(), group=_GROUP)
         out.copy_(host)
     else:
-        dist.all_gather_into_tensor(out, local)
+        dist.all_gather_into_tensor(out, local, group=_GROUP)
     if min(counts) == pad:
         return out
     return torch.cat([out[r * pad: r * pad + c] for r, c in enumerate(counts)], dim=0)
@@ -154,8 +221,8 @@ def cross_check(generate, mine: torch.Tensor, total: int, *, equal_shards_of: in
     mx, sums = stats[:1].clone(), stats[1:].clone()
     all_reduce_(mx, dist.ReduceOp.MAX)
     all_reduce_(sums, dist.ReduceOp.SUM)
-    backend = dist.get_backend() if on else "none"
-    return {"rccl_ranks": world if backend in ("nccl", "none") else 0, "ranks": world, "collective_backend": backend,
+    be = backend()
+    return {"rccl_ranks": world if be in ("nccl", "none") else 0, "ranks": world, "collective_backend": be,
             "what": "every rank re-generated the NEXT rank's shard on its own GPU via sample_offset (same Philox key, that shard's "
                     "conditioning) and compared it with what that rank produced",
             "max_abs_diff": float(mx.item()), "bitwise_equal": bool(mx.item() == 0.0),

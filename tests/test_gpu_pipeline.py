@@ -164,6 +164,7 @@ def test_bench_launches_its_own_ranks_and_runs_the_n_rank_path_with_two_ranks_on
     two = _bench(root, ["--gpus", "2", "--ranks-share-device", "--legs", "lively"] + common)
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["global_batch"] == 256
     assert two["collective_backend"] == "gloo" and two["rccl_ranks"] == 0 and two["shard_check"]["ranks"] == 2
+    assert two["rccl_error"]            # RCCL was TRIED (shard.init_groups), failed its probe, and the run carried on over gloo and said so
     assert two["shard_check"]["bitwise_equal"] and two["shard_check"]["checksum_recomputed"] == two["shard_check"]["checksum_sharded"]
     assert two["parity_in_run"]["ok"]
     lv = two["livelyspeaker"]
@@ -176,3 +177,59 @@ def test_bench_launches_its_own_ranks_and_runs_the_n_rank_path_with_two_ranks_on
     one = _bench(root, ["--gpus", "1", "--legs", "lively"] + common)
     assert one["n_gpus"] == 1 and "error" not in one["livelyspeaker"] and one["livelyspeaker"]["text_feature_broadcast"] is None
     print("2 ranks on one GPU:", two["value"], lv["value"], lv["text_feature_broadcast"], "| strong:", strong["value"], "| 1 rank:", one["value"])
+
+
+def test_bench_threads_launcher_two_handles_on_one_gpu():
+    """`--launcher threads`: one process, one engine handle per device driven by one Python thread each, no process group and no
+    collective -- the independent N-device number / cross-check of the torchrun path.  On this one-GPU box both handles sit on
+    cuda:0 (--ranks-share-device): same shards, same Philox streams as two torchrun ranks would produce."""
+    common = ["--steps", "1", "--warmup", "1", "--diffusion-steps", "60", "--batch", "128"]
+    thr = _bench(ROOT, ["--gpus", "2", "--launcher", "threads", "--ranks-share-device"] + common)
+    assert thr["n_gpus"] == 2 and thr["config"]["global_batch"] == 256 and thr["collective_backend"] == "none" and thr["rccl_ranks"] == 0
+    assert thr["shard_check"]["bitwise_equal"] and thr["launcher"].startswith("threads")
+    strong = _bench(ROOT, ["--gpus", "2", "--launcher", "threads", "--ranks-share-device", "--global-batch", "300"] + common)
+    assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 300 and strong["shard_check"]["bitwise_equal"]
+    print("threads launcher, 2 handles on one GPU:", thr["value"], "| strong 300:", strong["value"])
+
+
+def test_two_handles_driven_from_two_threads_equal_the_sequential_results():
+    """include/ls_hip.h: "a handle is not thread-safe, distinct handles are independent".  Two handles on cuda:0 (different batches,
+    different kernels: the fused one and the sample-split one), each driven by its own thread at the same time, give bitwise the
+    results they give one after the other; a failing ls_create on one thread does not disturb the other thread's error text."""
+    import threading
+    import numpy as np
+    from livelyspeaker_amd import _lib, synth
+    from oracle import rag_oracle as orc
+    cfg = synth.TED
+    sd = synth.make_state_dict(cfg)
+    engs = []
+    for path, B in (("fused", 130), ("coop", 24)):
+        e = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, path=path)
+        e.load_state_dict(sd)
+        e.set_schedule(orc.Schedule(40, ""))
+        e.prepare(synth.make_cond(cfg, B, seed=B))
+        engs.append(e)
+    try:
+        seq = [e.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=7 + i) for i, e in enumerate(engs)]
+        for rnd in range(3):
+            got, errs = [None, None], []
+            bar = threading.Barrier(2)
+
+            def work(i):
+                try:
+                    bar.wait()
+                    for _ in range(3):
+                        got[i] = engs[i].sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=7 + i)
+                    if i == 1:          # a failing create on this thread: its message must not leak into the other thread's state
+                        with pytest.raises(_lib.EngineError, match="unsupported shape"):
+                            _lib.Engine(5, 5, 1, cfg.audio_len)
+                except Exception as ex:     # noqa: BLE001
+                    errs.append(ex)
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            assert not errs, errs
+            assert np.array_equal(got[0], seq[0]) and np.array_equal(got[1], seq[1]), rnd
+    finally:
+        for e in engs:
+            e.close()

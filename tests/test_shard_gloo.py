@@ -217,3 +217,42 @@ def test_world2_shard_cross_check():
         assert not bad["bitwise_equal"] and abs(bad["max_abs_diff"] - 1e-3) < 1e-6          # seen by EVERY rank (all-reduced)
         assert ragged["bitwise_equal"]
     assert results[0][0] == results[1][0]
+
+
+# ---- shard.init_groups: RCCL is tried, probed, and abandoned for gloo when it does not come up (here: no GPU at all) ---------------
+def _groups_worker(rank, world, port, want_rccl, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        from livelyspeaker_amd import shard
+        info = shard.init_groups(torch.device("cpu"), rank, world, want_rccl=want_rccl, probe_timeout_s=60.0, timeout_min=2.0)
+        t = torch.full((4,), float(rank + 1))
+        shard.all_reduce_(t)                                             # the data collectives work on whatever group was chosen
+        whole = shard.gather_samples(torch.full((2, 1, 1, 1), float(rank)), 2 * world)
+        q.put((rank, (info, t.tolist(), whole.flatten().tolist(), shard.backend())))
+    except Exception as e:
+        import traceback
+        q.put((rank, RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("want_rccl", [False, True])
+def test_world2_process_groups_fall_back_to_gloo_when_rccl_does_not_come_up(want_rccl):
+    """bench.py's bring-up on a box without GPUs: the RCCL group cannot be created (or its probe collectives fail), every rank agrees
+    on that over the gloo default group, and the run carries on over gloo, reporting collective_backend / rccl_ranks / rccl_error."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_groups_worker, args=(r, 2, port, want_rccl, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in ps)
+    for p in ps:
+        p.join(60)
+    for r in range(2):
+        assert not isinstance(res[r], Exception), res[r]
+        info, red, whole, be = res[r]
+        assert info["collective_backend"] == "gloo" and info["rccl_ranks"] == 0 and info["rccl_error"] and be == "gloo", info
+        assert red == [3.0] * 4 and whole == [0.0, 0.0, 1.0, 1.0]
