@@ -3,8 +3,9 @@
 Mirrors (names, argument meaning, error behaviour) of
 ``scripts/diffusion/gaussian_diffusion.py``: ``get_named_beta_schedule`` (:26-49),
 ``betas_for_alpha_bar`` (:52-70), ``GaussianDiffusion`` tables (:168-204), ``q_sample`` (:240-258),
-``p_sample`` (:507-558), ``p_sample_loop`` (:608-671), ``ddim_sample`` (:745-798),
-``ddim_sample_loop`` (:895-943) and ``_extract_into_tensor`` (:1651-1664).
+``q_posterior_mean_variance`` (:260-282), ``p_mean_variance`` (:284-399), ``p_sample`` (:507-558), ``p_sample_loop`` (:608-671),
+``p_sample_loop_progressive`` (:673-743), ``ddim_sample`` (:745-798), ``ddim_sample_loop`` (:895-943),
+``ddim_sample_loop_progressive`` (:945-1014) and ``_extract_into_tensor`` (:1651-1664).
 
 Only the schedule tables live here (fp64 numpy, as in the reference).  All per-step arithmetic
 (CFG'd model evaluation + posterior / DDIM update) runs in the fused gfx950 step kernel behind the
@@ -144,6 +145,16 @@ class GaussianDiffusion:
         return (_extract_into_tensor(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
                 + _extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
 
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """Mean and variance of q(x_{t-1} | x_t, x_0) (gaussian_diffusion.py:260-282): elementwise on the caller's tensors."""
+        assert x_start.shape == x_t.shape
+        posterior_mean = (_extract_into_tensor(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                          + _extract_into_tensor(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        posterior_variance = _extract_into_tensor(self.posterior_variance, t, x_t.shape)
+        posterior_log_variance_clipped = _extract_into_tensor(self.posterior_log_variance_clipped, t, x_t.shape)
+        assert posterior_mean.shape[0] == posterior_variance.shape[0] == posterior_log_variance_clipped.shape[0] == x_start.shape[0]
+        return posterior_mean, posterior_variance, posterior_log_variance_clipped
+
     def _scale_timesteps(self, t):
         return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
 
@@ -187,12 +198,23 @@ class GaussianDiffusion:
                                       "of the RAG sampling path (no reference caller passes them)")
 
     # ------------------------------------------------------------------ single steps
-    def _one_step(self, sampler, model, x, t, clip_denoised, model_kwargs, eta, const_noise, denoised_fn, cond_fn):
+    def _one_step(self, sampler, model, x, t, clip_denoised, model_kwargs, eta, const_noise, denoised_fn, cond_fn, *, index=None,
+                  mean_only=False):
+        """One p_sample / ddim_sample.  index: the caller (a progressive loop) knows the batch's one schedule index on the host, so the
+        step runs exactly the launches the whole-loop entry points run.  mean_only: p_mean_variance -- the step's own noise is neither
+        drawn nor added, so 'sample' is the posterior mean."""
         self._reject(denoised_fn, cond_fn, False, False)
         eng = self._engine_for(model, model_kwargs, "p_sample/ddim_sample")
         B = x.shape[0]
         t = th.as_tensor(t)
         assert t.shape == (B,)                  # gaussian_diffusion.py:311
+        if index is None and eng.T != 34:
+            # only the fused and sample-split kernels (34 frames) take one timestep per sample; the batch-level kernels of the other
+            # frame counts take the batch's one timestep, read here on the host
+            t_host = t.detach().cpu()
+            if not bool((t_host == t_host[0]).all()):
+                raise NotImplementedError("nframes != 34 runs on the batch-level kernels, which take ONE timestep for the batch")
+            index = int(t_host[0])
         eps_c = th.randn(B, 1, eng.D)           # cond pass reparameterize (RAG.py:12), then uncond pass
         eps_u = th.randn(B, 1, eng.D)
         inp = self._inpainting(model, model_kwargs, tuple(x.shape))
@@ -205,16 +227,20 @@ class GaussianDiffusion:
             inz = th.randn_like(inp[1], device="cpu", dtype=th.float32) if (inp[2] and int(t_host[0]) > 0) else None
             inp_arg = (inp[0], inp[1], inz)
             t = t_host
-        noise = th.randn_like(x, device="cpu", dtype=th.float32)    # follows x's strides like the reference's randn_like(x)
-        if const_noise:
-            noise = noise[[0]].repeat(B, 1, 1, 1)
+        if mean_only:
+            noise = th.zeros(tuple(x.shape), dtype=th.float32)
+        else:
+            noise = th.randn_like(x, device="cpu", dtype=th.float32)    # follows x's strides like the reference's randn_like(x)
+            if const_noise:
+                noise = noise[[0]].repeat(B, 1, 1, 1)
         dev = x.device
         if x.is_cuda and inp is None:
             eps_c, eps_u, noise = self._stage_step_draws(dev, eps_c, eps_u, noise)
         # `t` may differ per sample (the reference's signature).  A CUDA `t` is handed to the engine as it is -- never read back, so
         # a step-by-step caller has no device -> host round trip per step, and with device tensors the call does not wait for the GPU
         # either (outputs are stream-ordered); a host `t` is validated there and a constant one takes the fused uniform path.
-        out, x0 = eng.step(sampler, 0, x, eps_c, eps_u, noise, eta=eta, clip_denoised=clip_denoised, indices=t.detach(),
+        out, x0 = eng.step(sampler, 0 if index is None else int(index), x, eps_c, eps_u, noise, eta=eta, clip_denoised=clip_denoised,
+                           indices=t.detach() if index is None else None,
                            two_pass_always=self.two_pass_always, no_sync=x.is_cuda and inp is None, inpaint=inp_arg)
         return {"sample": _ref_strides(_as_tensor(out, dev)), "pred_xstart": _ref_strides(_as_tensor(x0, dev))}
 
@@ -239,6 +265,20 @@ class GaussianDiffusion:
         slot["event"] = th.cuda.Event()
         slot["event"].record(th.cuda.current_stream(dev))
         return out
+
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """p(x_{t-1} | x_t) and the prediction of x_0 (gaussian_diffusion.py:284-399) under START_X + FIXED_SMALL: the CFG-wrapped model
+        call (its two style draws, and the inpainting branch's q_sample draw), process_xstart, the posterior mean -- one launch of the
+        step kernel with the noise term off -- and the table variances broadcast like _extract_into_tensor does."""
+        if model_kwargs is None:
+            model_kwargs = {}
+        r = self._one_step(_lib.LS_SAMPLER_DDPM, model, x, t, clip_denoised, model_kwargs, 0.0, False, denoised_fn, None, mean_only=True)
+        t = th.as_tensor(t).to(r["sample"].device)
+        model_mean, pred_xstart = r["sample"], r["pred_xstart"]
+        model_variance = _extract_into_tensor(self.posterior_variance, t, x.shape)
+        model_log_variance = _extract_into_tensor(self.posterior_log_variance_clipped, t, x.shape)
+        assert model_mean.shape == model_log_variance.shape == pred_xstart.shape == x.shape
+        return {"mean": model_mean, "variance": model_variance, "log_variance": model_log_variance, "pred_xstart": pred_xstart}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                  const_noise=False):
@@ -366,6 +406,48 @@ class GaussianDiffusion:
         self._reject(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
         return self._loop(_lib.LS_SAMPLER_DDPM, model, shape, noise, clip_denoised, model_kwargs, device,
                           skip_timesteps, init_image, dump_steps, const_noise, 0.0)
+
+    def _progressive(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, skip_timesteps,
+                     init_image, randomize_class, cond_fn_with_grad, const_noise, eta):
+        """p_sample_loop_progressive / ddim_sample_loop_progressive (gaussian_diffusion.py:673-743, 945-1014): the same draws in the same
+        order as the reference's generator -- x_T, then per step what p_sample / ddim_sample draws -- one step-kernel launch per yield,
+        tensors device-resident when the model is (no host synchronisation between yields)."""
+        self._reject(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        if device is None:
+            device = next(model.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        if noise is not None:
+            img = noise
+        else:
+            img = th.randn(*shape)                  # torch's CPU generator, like every draw of this module ("identical seeds")
+            if const_noise:
+                img = img[[0]].repeat(img.shape[0], 1, 1, 1)
+        img = img.to(device)
+        if skip_timesteps and init_image is None:
+            init_image = th.zeros_like(img)
+        indices = list(range(self.num_timesteps - skip_timesteps))[::-1]
+        if init_image is not None:
+            # q_sample(init_image, indices[0], img) on the engine's elementwise kernel -- the one the whole-loop entry points use, so a
+            # generator's yields are bitwise theirs
+            eng = self._engine_for(model, model_kwargs, "sample loop")
+            img = _as_tensor(eng.q_sample(indices[0], _as_tensor(init_image, img.device).float().contiguous(), img.float().contiguous()), img.device)
+        for i in indices:
+            t = th.full((shape[0],), i, dtype=th.long)
+            out = self._one_step(sampler, model, img, t, clip_denoised, model_kwargs, eta, const_noise, None, None, index=i)
+            yield out
+            img = out["sample"]
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                                  randomize_class=False, cond_fn_with_grad=False, const_noise=False):
+        return self._progressive(_lib.LS_SAMPLER_DDPM, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                                 skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, 0.0)
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
+                                     randomize_class=False, cond_fn_with_grad=False, const_noise=False):
+        return self._progressive(_lib.LS_SAMPLER_DDIM, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                                 skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, eta)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
