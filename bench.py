@@ -796,9 +796,12 @@ def main():
                      "gpu_kernel_ms_per_step": round(loop_ms / max(launches, 1), 3), "segments": n_seg, "steps_per_segment": k_seg,
                      "tape_bytes_if_one_piece": per_step * n_total,
                      "pinned_host_bytes": 2 * k_seg * per_step if n_seg > 1 else per_step * n_s,
-                     "bound": "host RNG: torch's CPU generator is one sequential stream (2 x B x 512 + B x J x F x T normals per step, the "
-                              "randn_like(x) ones through its scalar path because x is a permuted view); the uploads run on the copy stream "
-                              "under the previous segment's steps and the GPU idles between segments",
+                     "host_rng": ("native restatement of torch's CPU normal stream (csrc/ls_torch_rng.cpp: mt19937 words sequentially, the float and "
+                                  "double Box-Muller transforms on worker threads), continued from and handed back to torch's generator state; checked "
+                                  "bitwise against torch once per process" if getattr(diffusion, "last_host_rng_native", False) else
+                                  "torch's own generator (the native restatement does not reproduce this torch build)"),
+                     "bound": "host RNG: one sequential mt19937 stream (2 x B x 512 + B x J x F x T normals per step); the uploads run on the copy "
+                              "stream under the previous segment's steps and the GPU idles while a segment is drawn",
                      "hipgraph": False if n_seg > 1 else bool(diffusion.use_graph)}
         except Exception as e:
             seeds = {"error": repr(e)[:300]}

@@ -264,6 +264,22 @@ int ls_synchronize(ls_handle* h);
 int ls_stream_order(int device, void* first, void* then);
 void* ls_stream(const ls_handle* h);
 
+/* ---- torch's CPU normal stream, natively ("identical seeds" mode off the Python critical path) ----------------------------------
+ * The reference draws every normal of a sampling loop from torch's global CPU generator (gaussian_diffusion.py:700-743; RAG.py:10-13,
+ * 120), so torch.manual_seed(s) fixes the sample.  These two entry points make the same draws from the same state: `state` is the
+ * 5056-byte blob of torch.get_rng_state() (mt19937 words + the cached Box-Muller sample), updated in place -- hand it back with
+ * torch.set_rng_state().  Host memory only; no GPU involved.  n_threads workers share the transcendental part.
+ * ls_trng_randn: torch.randn(n), float32 contiguous (n >= 16: the 16-block float Box-Muller; n < 16: the per-element double path).
+ * ls_trng_fill_steps: the per-step draws of n_steps sampling steps in the reference's order -- randn(B,1,D) of the cond pass, of the
+ * uncond pass, then randn_like(x) -- into eps [n_steps][2][B][D] and noise [n_steps][B][J][F][T]; x is the model-output-shaped view
+ * (memory order [T][B][J][F], consumed in that order by torch's per-element path) except at the first step when first_contiguous.
+ * variant: the float transform of the contiguous draws -- 0 = libm (torch's DEFAULT-capability kernel), 1..4 = the Cephes polynomials
+ * of torch's AVX2 / AVX512 kernels under the four ways their multiply-adds can have been contracted to FMAs; livelyspeaker_amd finds
+ * the variant that reproduces torch bit for bit once per process and keeps torch's generator if none does. */
+int ls_trng_randn(uint8_t* state, size_t state_bytes, float* out, size_t n, int variant, int n_threads);
+int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, int F, int T, int n_steps, int first_contiguous,
+                       float* eps, float* noise, int variant, int n_threads);
+
 /* ---- SAG decoder ---------------------------------------------------------------
  * Decoder_TRANSFORMER (scripts/model/motionclip_module.py:98-183), called as SAG.decoder(batch) at
  * scripts/test_LivelySpeaker_ted.py:88 to produce init_image for the RAG refine loop.  Separate handle: it is a

@@ -101,6 +101,10 @@ class GaussianDiffusion:
     #: torch_cpu mode: host noise tapes larger than this many bytes are drawn and uploaded in K-step segments (page-locked
     #: double buffer, upload of segment i+1 under the steps of segment i) instead of one [n_exec, ...] piece
     tape_segment_bytes = 96 << 20
+    #: torch_cpu mode: make the per-step draws natively from torch's generator state (same values, same final generator state) when the
+    #: native restatement reproduces this torch build; False = always call torch's generator
+    native_host_rng = True
+    last_host_rng_native = False
     philox_seed = None              # philox mode: None = draw the key from torch's generator per call
     last_philox_seed = None
 
@@ -351,6 +355,20 @@ class GaussianDiffusion:
                     inz[k] = th.randn_like(inp_proto, dtype=th.float32)
                 nz_k.copy_(th.randn_like(first_proto if k == 0 else later_proto, dtype=th.float32))
 
+            # The same draws made natively from torch's generator state (torch_rng.py: mt19937 + torch's two normal transforms restated
+            # in C++, the transcendental part on worker threads) when the restatement reproduces this torch build bit for bit -- checked
+            # once per process -- and the loop draws nothing else in between (no inpainting draws, contiguous first x).
+            from . import torch_rng
+            native = torch_rng.variant() if (self.native_host_rng and inz is None and first_proto.is_contiguous()) else -1
+            self.last_host_rng_native = native >= 0
+
+            def draw_steps(k0, eps_seg, nz_seg):            # steps k0 .. k0 + len(eps_seg) into (eps [n,2,B,D], noise [n,B,J,F,T])
+                if native >= 0:
+                    torch_rng.fill_steps(eps_seg, nz_seg, k0 == 0, native)
+                else:
+                    for r in range(eps_seg.shape[0]):
+                        draw(k0 + r, eps_seg[r], nz_seg[r])
+
             if inp is not None:
                 kw["inpaint"] = (inp[0], inp[1], inz, inp[2])
             per_step = (2 * B * eng.D + int(np.prod(shape))) * 4
@@ -370,8 +388,7 @@ class GaussianDiffusion:
                     n = min(K, n_exec - k0)
                     eps, nz = ring[si & 1]
                     t0 = time.perf_counter()
-                    for r in range(n):
-                        draw(k0 + r, eps[r], nz[r])
+                    draw_steps(k0, eps[:n], nz[:n])
                     t_rng += time.perf_counter() - t0
                     res = eng.sample(eps_tape=eps[:n], noise_tape=nz[:n], segment=(k0, n), **kw)
                 self.last_host_rng_ms, self.last_tape_segments = t_rng * 1e3, -(-n_exec // K)
@@ -381,8 +398,7 @@ class GaussianDiffusion:
             eps = th.empty(n_exec, 2, B, eng.D)
             nz = th.empty((n_exec,) + shape)
             t0 = time.perf_counter()
-            for k in range(n_exec):
-                draw(k, eps[k], nz[k])
+            draw_steps(0, eps, nz)
             self.last_host_rng_ms, self.last_tape_segments = (time.perf_counter() - t0) * 1e3, 1
             kw["eps_tape"], kw["noise_tape"] = eps, nz
         kw["two_pass_always"] = self.two_pass_always

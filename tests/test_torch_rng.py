@@ -1,0 +1,80 @@
+"""CPU: torch's CPU normal stream restated natively (csrc/ls_torch_rng.cpp, livelyspeaker_amd/torch_rng.py) -- the "identical seeds"
+contract (torch.manual_seed fixes every draw of the reference's loop: gaussian_diffusion.py:700-743, RAG.py:10-13, 120) without
+torch's generator on the critical path.  Bitwise against torch itself: values, draw order, and the generator state left behind."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from livelyspeaker_amd import _lib, torch_rng
+
+
+def _native_randn(n, variant):
+    lib = _lib.load_library()
+    st = torch.get_rng_state()
+    out = torch.empty(n)
+    assert lib.ls_trng_randn(st.data_ptr(), st.numel(), out.data_ptr(), n, variant, 2) == 0
+    torch.set_rng_state(st)
+    return out
+
+
+def test_state_blob_layout_is_the_one_the_native_code_assumes():
+    torch.manual_seed(233)
+    s = torch.get_rng_state().numpy()
+    assert s.size == 5056
+    u32 = s.view(np.uint32)
+    assert (u32[0], u32[2], u32[3], u32[4]) == (233, 1, 1, 0)                  # seed | left = 1 | seeded | next = 0
+    torch.randn(3, dtype=torch.float64)                                         # two pairs: one sample stays cached
+    s = torch.get_rng_state().numpy()
+    assert s.view(np.uint32)[2] == 624 - 7 and s[5024:5032].view(np.float64)[0] != 0.0 and s[5040:5044].view(np.int32)[0] == 1
+
+
+def test_a_variant_reproduces_this_torch_build():
+    v = torch_rng.variant()
+    print("torch CPU capability:", torch.backends.cpu.get_cpu_capability(), "-> native float transform variant", v)
+    assert v >= 0, "no restated variant reproduces torch's contiguous float normals on this machine (callers fall back to torch)"
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 31, 32, 33, 100, 2048, 4099, 1 << 17])
+def test_randn_equals_torch_for_every_size_class(n):
+    v = torch_rng.variant()
+    assert v >= 0
+    torch.manual_seed(7 + n)
+    want, want_after = torch.randn(n), torch.randn(5, dtype=torch.float64)
+    torch.manual_seed(7 + n)
+    got = _native_randn(n, v)
+    assert torch.equal(got, want) and torch.equal(torch.randn(5, dtype=torch.float64), want_after)      # same generator state afterwards
+
+
+@pytest.mark.parametrize("B,first", [(1, True), (3, True), (3, False), (4, False), (6, True)])
+def test_step_draws_equal_torchs_in_order_value_and_final_state(B, first):
+    v = torch_rng.variant()
+    assert v >= 0
+    shape = dict(n=5, B=B, D=512, J=9, F=3, T=34)
+    torch.manual_seed(99)
+    torch.randn(3)                                          # a cached double sample waiting in the generator
+    s0 = torch.get_rng_state()
+    want_e, want_n = torch_rng._torch_steps(first_contiguous=first, **shape)
+    want_after = torch.randn(4, dtype=torch.float64)
+    torch.set_rng_state(s0)
+    eps, nz = torch.empty_like(want_e), torch.empty_like(want_n)
+    torch_rng.fill_steps(eps, nz, first, v)
+    assert torch.equal(eps, want_e) and torch.equal(nz, want_n)
+    assert torch.equal(torch.randn(4, dtype=torch.float64), want_after)
+    # and in two pieces: the second piece starts where the first one left the generator (segmented tapes)
+    torch.set_rng_state(s0)
+    torch_rng.fill_steps(eps[:2], nz[:2], first, v)
+    torch_rng.fill_steps(eps[2:], nz[2:], False, v)
+    assert torch.equal(eps, want_e) and torch.equal(nz, want_n)
+
+
+def test_bad_arguments_are_rejected():
+    lib = _lib.load_library()
+    st = torch.get_rng_state()
+    out = torch.empty(32)
+    assert lib.ls_trng_randn(st.data_ptr(), 100, out.data_ptr(), 32, 0, 1) < 0             # not a torch state blob
+    assert lib.ls_trng_randn(st.data_ptr(), st.numel(), out.data_ptr(), 32, 9, 1) < 0      # unknown variant
+    bad = st.clone()
+    bad[12] = 0                                                                            # "not seeded"
+    assert lib.ls_trng_randn(bad.data_ptr(), bad.numel(), out.data_ptr(), 32, 0, 1) < 0
