@@ -453,13 +453,15 @@ def other_config_leg(dataset, B, dev, fence, steps=1000):
     tm = model.engine().timing()
     km = tm["loop_ms"] / max(tm["n_step_launches"], 1)
     ach = 2 * FLOP_PER_FORWARD[dataset] * B / (km * 1e-3) / 1e12
-    path = getattr(model.engine(), "path", "auto")
+    names = {0: "fused step kernel (one workgroup per clip)", 1: "batch-level kernels (ls_long.hip, 21 launches per step)",
+             2: "sample-split step kernel (ls_coop_kernel.h: 16 workgroups per clip, one launch per step)"}
+    kernels = names[tm["step_path"]] + (f" + the last {tm['tail_samples']} clips on the {names[tm['tail_path']].split(' (')[0]}" if tm["tail_samples"] else "")
     model.engine().close()
     return {"workload": f"{dataset.upper()} RAG, batch {B} x {cfg.nframes} frames, {steps}-step DDPM, CFG 1.5, Philox noise"
                         + (" -- SYNTHETIC shape (150 frames: the reference cannot run it), perf-only, no parity claim vs the reference"
                            if dataset == "beat150" else ""),
             "value": round(B * cfg.nframes / el, 1), "unit": "pose-frames/s", "ms_per_call": round(el * 1e3, 2),
-            "kernels": ("batch-level (ls_long.hip)" if (cfg.nframes != 34 or (path == "auto" and B <= 160)) else "fused step kernel (one workgroup per clip)"),
+            "kernels": kernels + (" -- self-pinned: checked against this repository's oracle only" if dataset == "beat150" else ""),
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "step_ms": round(km, 4),
                          "flop_per_sample_step": 2 * FLOP_PER_FORWARD[dataset]}}
@@ -834,11 +836,11 @@ def main():
                 fence()
                 e4 = (time.perf_counter() - t0) / 10
                 tm4 = m4.engine().timing()
-                small[path] = {"ms_per_call": round(e4 * 1e3, 3), "value": round(4 * cfg.nframes / e4, 1), "unit": "pose-frames/s",
+                small[path] = {"step_path": tm4["step_path"], "ms_per_call": round(e4 * 1e3, 3), "value": round(4 * cfg.nframes / e4, 1), "unit": "pose-frames/s",
                                "step_ms": round(tm4["loop_ms"] / max(tm4["n_step_launches"], 1), 4), "finite": bool(torch.isfinite(o4).all())}
                 m4.engine().close()
             small["workload"] = "TED RAG, 4 clips x 34 frames, 50-step DDPM, CFG 1.5 (BASELINE configs[0]'s shape; Philox noise): `auto` = the engine's choice "
-            small["workload"] += "(batch-level kernels up to 160 clips), `fused` = one workgroup per clip"
+            small["workload"] += "(the sample-split kernel: 16 workgroups per clip, one launch per step), `fused` = one workgroup per clip"
         except Exception as e:
             small = {"error": repr(e)[:300]}
 
