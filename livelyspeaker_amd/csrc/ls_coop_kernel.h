@@ -90,8 +90,6 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     constexpr bool kRemMfma = (NREM % 4 == 0);  // BEAT: one v_mfma_f32_4x4x1 row group; TED: scalar FMAs (see k_step)
     constexpr int NRV = kRemMfma ? 1 : NREM;
     constexpr int MK1 = (S + 3) / 4;            // k steps of the token-mix GEMM of one pass
-    constexpr int NU = NOB * NT1;               // output-projection work units (out block, row tile)
-    constexpr int MAXU = (NU + kCoopWaves - 1) / kCoopWaves;
     constexpr int NQUAD = kT * (NOBP / 4);      // (frame, 4 output columns) quads of one sample
     static_assert(S > 32 && S <= kCoopRows, "one pass = two full row tiles + a ragged one");
     static_assert(NREM >= 1 && NREM <= 4, "ragged tile");
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         fresh();
         f4 acc0 = X0, acc1 = X1;
         // winx_img[8][2][KXQ][2][64][4] (ls_api.cpp build_fused_images): 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1)
@@ -261,7 +259,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             if (g == 0) pst[w * 48 + 32 + s16] = (f2){m, m2};
         }
         if (payload) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores
-        __syncthreads();
+        lds_barrier();
         if (tid < S) {                                                          // row tid: merge the 4 channel blocks, publish the slice's partial
             f2 pw[4];
             float ms = 0.f, qs = 0.f;
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     };
     // ln_gather: wait for all 8 slices' partials of every row, merge -> stat[row] = (mean, rstd) and this lane's rows' values
     float mean0, rstd0, mean1, rstd1;
-    auto ln_gather = [&](int area, unsigned tag, int stamp_at) {
+    auto ln_gather = [&](int area, unsigned tag, int stamp_at, bool drain = false) {
         const unsigned long long* ga = gran + (size_t)area * kCoopRows * kCoopSlices * 2;
         // thread (row = tid >> 3, slice = tid & 7); threads beyond the S rows re-read the last row
         const int sl = tid & 7, r = min(tid >> 3, S - 1);
@@ -302,7 +300,8 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q); q = dpp_add<0x141>(q);
             if (live && sl == 0) stat[r] = (f2){mu, rsqrtf(q * (1.0f / kD) + 1e-5f)};
         }
-        __syncthreads();
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the caller's LDS-DMA pulls have landed before anyone passes the barrier
+        lds_barrier();
         const f2 s0 = stat[row0()], s1 = stat[row1c()];
         mean0 = s0.x; rstd0 = s0.y; mean1 = s1.x; rstd1 = s1.y;
     };
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             u = __builtin_elementwise_fma(u, al1, be1);
             *reinterpret_cast<f4*>(&U[(32 + s16) * kCoopU1Stride + 16 * w + 4 * g]) = u;
         }
-        __syncthreads();                                             // token mixing contracts over ROWS: both halves' rows of these channels
+        lds_barrier();                                             // token mixing contracts over ROWS: both halves' rows of these channels
         fresh();
         {
             // out[ch][r] = sum_r' u[r'][ch] * Wt[r][r'] + bt[r] as D[channel][row]: A = u^T from LDS, B = the Conv1d weights
@@ -423,7 +422,9 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             for (int i = 0; i < kCoopSlices; ++i) {
                 const int s = (c + i) & 7;
                 if (i == 1) {
-                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // this wave's chunks have landed in LDS, and so have the other waves'
+                    // LayerNorm-2 statistics while the pulls land (their granules came up with the ready flags); its barrier waits for
+                    // vmcnt(0) first: this wave's chunks have landed in LDS, and so have the other waves'
+                    ln_gather(1, tag2, 2 + 8 * l + 6, true);
                     stamp(71 + 2 * l);
                 }
                 const float* ub = U + s * kCoopSliceFloats + (2 * h * kCoopRows + s16) * 16 + 4 * g;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             // The two halves swap partial sums through LDS (overlaid on the operand buffer, which every wave has finished reading
             // after the barrier): wave (w, h) keeps row tile h and hands tile 1 - h to wave (w, 1 - h); the ragged rows' partials --
             // summed over the 4 k subsets of the lanes first, [channel-lane][row] -> [row-lane][channel-reg] -- all go to half 1.
-            __syncthreads();
+            lds_barrier();
             float* xch = U + wv * 256;                               // [8 waves][64 lanes][4]
             float* rag = U + 8 * 256 + wv * 64;                      // [8 waves][4 rows][16 channels]
             *reinterpret_cast<f4*>(&xch[lane * 4]) = h ? acc[0] : acc[1];
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
                 }
             }
             // LayerNorm 2 around the product: v = rstd2 * (acc - (mu2 - mu1) wsum) + b'
-            ln_gather(1, tag2, 2 + 8 * l + 6);                       // its barrier: the partner's partials are in LDS
+            lds_barrier();                                         // the partner's partials are in LDS
             {
                 const f4 mine = h ? acc[1] : acc[0];
                 const f4 sum = mine + *reinterpret_cast<const f4*>(&U[(wv ^ 4) * 256 + lane * 4]);
@@ -516,43 +517,49 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     const unsigned tagF = a.epoch + 2 * a.layers + 1;
     {
         // this slice's final rows -> LDS [S][64] (token-mix operand layout): every wave has to be past its reads of the partial sums
-        __syncthreads();
+        lds_barrier();
         *reinterpret_cast<f4*>(&U[row0() * kCoopU1Stride + 16 * w + 4 * g]) = X0;
         if (live1()) *reinterpret_cast<f4*>(&U[(32 + s16) * kCoopU1Stride + 16 * w + 4 * g]) = X1;
-        __syncthreads();
+        lds_barrier();
         // partial poseFinal over this slice's 64 channels: unit (out block ob, row tile t) = 16 MFMAs; wout_reg_img[8][NOB][4][64][4]
         // holds Wout[16 ob + (lane & 15)][64 c + 16 q' + 4 (lane >> 4) + j] (ls_api.cpp build_fused_images)
         float* part = a.cpart + ((size_t)pg * kCoopSlices + c) * kCoopRows * NOBP;
         const wrsrc_t prs = uniform_rsrc(part);
         const wrsrc_t wrs = wrsrc(a.W->wout_reg_img);
+        // out block ob = wv + 8 i: its four weight fragments once for the three row tiles, the next block's in flight meanwhile
+        constexpr int MAXOB = (NOB + kCoopWaves - 1) / kCoopWaves;
         f4 An[4];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + min(wv, NU - 1) / NT1) * 4 + qq) * 1024);
+        for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + min(wv, NOB - 1)) * 4 + qq) * 1024);
 #pragma unroll 1
-        for (int i = 0; i < MAXU; ++i) {
-            const int u = wv + kCoopWaves * i;                       // wave-uniform
-            if (u >= NU) break;
-            const int ob = u / NT1, t = u - ob * NT1;
+        for (int i = 0; i < MAXOB; ++i) {
+            const int ob = wv + kCoopWaves * i;                      // wave-uniform
+            if (ob >= NOB) break;
             f4 A[4];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) A[qq] = An[qq];
-            const int obn = min(u + kCoopWaves, NU - 1) / NT1;       // the next unit's fragments fly under this unit's MFMAs
+            const int obn = min(ob + kCoopWaves, NOB - 1);
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + obn) * 4 + qq) * 1024);
-            const int rc = min(16 * t + s16, S - 1);
-            f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            f4 o[NT1];
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) o[t] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const f4 Bv = *reinterpret_cast<const f4*>(&U[rc * kCoopU1Stride + 16 * qq + 4 * g]);
-                a0 = MFMA(A[qq][0], Bv[0], a0);
-                a1 = MFMA(A[qq][1], Bv[1], a1);
-                a0 = MFMA(A[qq][2], Bv[2], a0);
-                a1 = MFMA(A[qq][3], Bv[3], a1);
+                f4 Bv[NT1];
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[min(16 * t + s16, S - 1) * kCoopU1Stride + 16 * qq + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) o[t] = MFMA(A[qq][j], Bv[t][j], o[t]);
             }
-            if (16 * t + s16 < S) st_sc1(a0 + a1, prs, ((16 * t + s16) * NOBP + 16 * ob + 4 * g) * 4);
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+                if (16 * t + s16 < S) st_sc1(o[t], prs, ((16 * t + s16) * NOBP + 16 * ob + 4 * g) * 4);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        lds_barrier();
         unsigned long long* fl = a.cflag + (size_t)bl * 16;
         if (tid == 0) gran_store(fl + j16, tagF, 0.f);
         stamp(2 + 8 * a.layers);
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     stamp(3 + 8 * a.layers);
     if (spin_bad && lane == 0) atomicOr(a.cerr, 1u);

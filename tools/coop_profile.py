@@ -29,23 +29,19 @@ L = 8
 E = 2 + 8 * L
 print(f"{ds} B={B} workgroup {os.environ['LS_PROF']}: total (wave mean) = {np.mean(st[:, E + 3] - st[:, 0]):.0f}  [s_memtime ticks]")
 print(f"  embed                      : {np.mean(st[:, 1] - st[:, 0]):9.0f}")
-names = ["temb + LN1 partials/publish", "SYNC1 wait + merge", "LN1 store + token mixing", "rows publish + LN2 partials", "channel mixing (MFMA + pulls)",
-         "ragged-row patch", "LN2 gather + epilogue"]
-acc = np.zeros(7)
+names = ["temb + LN1 partials/publish", "SYNC1 wait + merge", "LN1 store + token mixing", "rows publish + LN2 partials", "ready-flag wait + pulls issued",
+         "own k blocks", "LN2 gather + pulls landed", "remaining k blocks", "partial-sum swap + epilogue"]
+acc = np.zeros(len(names))
 prev = st[:, 1].copy()
 for l in range(L):
     b = 2 + 8 * l
-    seq = [b + 5, b + 0, b + 1, b + 2, b + 3, b + 6, b + 4]
+    seq = [b + 5, b + 0, b + 1, b + 2, 70 + 2 * l, b + 6, 71 + 2 * l, b + 3, b + 4]
     for i, pnt in enumerate(seq):
         acc[i] += np.mean(st[:, pnt] - prev)
         prev = st[:, pnt].copy()
-for i in range(7):
-    print(f"  {names[i]:29s}: {acc[i] / L:9.0f} /layer")
+for i in range(len(names)):
+    print(f"  {names[i]:31s}: {acc[i] / L:9.0f} /layer")
 print(f"  partial poseFinal + publish  : {np.mean(st[:, E] - prev):9.0f}")
 print(f"  flags wait                   : {np.mean(st[:, E + 1] - st[:, E]):9.0f}")
 print(f"  reduce + CFG + sampler update: {np.mean(st[:, E + 3] - st[:, E + 1]):9.0f}")
-pd = np.mean([np.mean(st[:, 70 + 2 * l] - st[:, 2 + 8 * l + 2]) for l in range(L)])
-la = np.mean([np.mean(st[:, 71 + 2 * l] - st[:, 70 + 2 * l]) for l in range(L)])
-rest = np.mean([np.mean(st[:, 2 + 8 * l + 3] - st[:, 71 + 2 * l]) for l in range(L)])
-print(f"  channel mixing split: ready-flag wait {pd:.0f} | pulls issued .. landed (own k blocks multiplied meanwhile) {la:.0f} | 28 k blocks {rest:.0f}")
 print("  per-layer totals (wave 0):", [int(st[0, 2 + 8 * l + 4] - (st[0, 2 + 8 * (l - 1) + 4] if l else st[0, 1])) for l in range(L)])
