@@ -432,3 +432,15 @@ def test_sampler_outputs_carry_the_reference_strides():
     th.manual_seed(1); a = th.randn_like(r)
     th.manual_seed(1); b = th.randn_like(want)
     assert th.equal(a, b)
+
+
+def test_committed_traffic_profile_was_taken_on_the_shipped_step_kernel():
+    """profiles/k_step_traffic.json (rocprofv3 PMC passes, the figure bench.py quotes as roofline.traffic_from_committed_profile) is
+    keyed to the SHA-256 of ls_step_kernel.h it was measured on: a kernel edit without re-profiling (tools/traffic_measure.sh) fails here
+    instead of silently leaving a stale profile behind the bench line."""
+    import hashlib
+    import json
+    doc = json.load(open(os.path.join(ROOT, "profiles", "k_step_traffic.json")))
+    now = hashlib.sha256(open(os.path.join(ROOT, "livelyspeaker_amd", "csrc", "ls_step_kernel.h"), "rb").read()).hexdigest()
+    stale = [k for k, e in doc["entries"].items() if e["kernel_source_sha256"] != now]
+    assert not stale, f"re-take profiles/k_step_traffic.json (tools/traffic_measure.sh on the GPU box): stale entries {stale}"
