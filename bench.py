@@ -257,7 +257,7 @@ def train_leg(a, cfg, model, diffusion, dev, world, rank, use_dist, fence):
     y = {k: tod(v) for k, v in y.items()}
     t = np.random.Generator(np.random.PCG64(rank)).integers(0, 1000, size=(B,))
     # a training run is thousands of steps: the steady state is what is timed.  8 untimed steps first -- the shader clock needs a few
-    # hundred ms of load to reach its ceiling; 1 warm-up + 4 steps read 7.07 ms where the steady state is 6.85
+    # hundred ms of load to reach its ceiling (docs/DESIGN_NOTES_r1-r3.md §3.2 (a)); 1 warm-up + 4 steps read 7.07 ms where the steady state is 6.85
     n, nwarm = 12, 8
     fwd = bwd = 0.0
     terms = None

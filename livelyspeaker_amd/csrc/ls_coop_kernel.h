@@ -7,7 +7,7 @@
 //   OutputProcess                       scripts/model/RAG.py:205-211
 //   p_mean_variance / p_sample / ddim_sample   scripts/diffusion/gaussian_diffusion.py:284-399, 507-558, 745-798
 //
-// Mapping (DESIGN.md section 3.9):
+// Mapping (DESIGN.md section 3.2):
 //   * workgroup = (sample b, CFG pass p, channel slice c): 8 waves, the S = 35 | 36 rows of ONE pass x 64 of the 512 channels.
 //     Wave (w, h), w = 0..3, h = 0..1: channels [64c + 16w, +16), in the MFMA C/D layout exactly as in k_step; for the residual
 //     stream, LayerNorm, token mixing and the epilogues it owns the rows of half h (h = 0: rows 0..15, h = 1: rows 16..S-1 = one
