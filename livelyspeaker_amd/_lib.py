@@ -444,6 +444,10 @@ class Engine:
         else:
             self._check(self.lib.ls_prepare_async(self.h, C.byref(c)), "ls_prepare_async")
             self._prepare_inputs = (m, y)       # device buffers (and any converted copies) stay valid while the copies are in flight
+            if m.on_device:
+                # conv1 reads a device-resident waveform IN PLACE (no ingest copy): whatever the caller enqueues next on torch's stream --
+                # e.g. refilling the same batch buffer -- has to wait for the engine's stream, exactly like the outputs of a no_sync call
+                m.done_async()
         self.batch = B
 
     def _xshape(self):
