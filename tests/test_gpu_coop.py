@@ -174,6 +174,41 @@ def test_determinism_under_load_and_next_to_another_handle():
         other.close()
 
 
+def test_two_sample_split_handles_at_once_do_not_starve_each_other():
+    """Two handles whose step kernels BOTH wait on their own workgroups (512 + 512 workgroups competing for the chip's 512 slots): the
+    slices of a group have consecutive block ids and are dispatched together, so neither kernel can hold slots while waiting for
+    blocks that cannot start.  Results bitwise the sequential ones; a starved hand-off would end in the bounded spin's error."""
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg = synth.TED
+    engs = []
+    for B in (32, 30):
+        _, e = _engine("ted")
+        e.set_schedule(orc.Schedule(30, ""))
+        e.prepare(synth.make_cond(cfg, B, seed=B))
+        engs.append(e)
+    try:
+        seq = [e.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=21 + i) for i, e in enumerate(engs)]
+        got, errs = [None, None], []
+        bar = threading.Barrier(2)
+
+        def work(i):
+            try:
+                bar.wait()
+                for _ in range(6):
+                    got[i] = engs[i].sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=21 + i)
+            except Exception as ex:     # noqa: BLE001
+                errs.append(ex)
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errs, errs
+        assert np.array_equal(got[0], seq[0]) and np.array_equal(got[1], seq[1])
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_auto_takes_the_sample_split_kernel_for_small_batches_only():
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
