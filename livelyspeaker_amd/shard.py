@@ -50,11 +50,13 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
     if not want_rccl:
         info["rccl_error"] = "not requested"
         return info
-    ok, err, grp = 1, None, None
+    ok, err = 1, None
     box = {}
 
     def probe():
         try:
+            if getattr(device, "type", "cpu") == "cuda":
+                torch.cuda.set_device(device)       # the current device is per host thread: this helper thread starts on device 0
             g = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=timedelta(seconds=max(30.0, probe_timeout_s)))
             box["group"] = g
             t = torch.full((1024,), float(rank + 1), device=device)

@@ -12,7 +12,10 @@ python bench.py --dataset beat150 --batch 256 --no-extra-legs --no-cpu-baseline 
 python bench.py --respacing ddim100 --no-extra-legs --no-cpu-baseline --steps 5 > "$out/bench_ddim100_full.json" 2> "$out/bench_ddim100_full.err"; echo "ddim100 rc=$?"
 python bench.py --batch 4 --diffusion-steps 50 --no-extra-legs --no-cpu-baseline --steps 20 > "$out/bench_config1_shape.json" 2> "$out/bench_config1.err"; echo "config1 rc=$?"
 python bench.py --gpus 2 --ranks-share-device --batch 256 --legs lively --no-cpu-baseline --steps 2 > "$out/bench_two_ranks_one_gpu.json" 2> "$out/bench_two_ranks_one_gpu.err"; echo "2 ranks / 1 GPU rc=$?"
-python tools/smallbatch_time.py ted > "$out/smallbatch_ted.txt" 2>&1; python tools/smallbatch_time.py beat > "$out/smallbatch_beat.txt" 2>&1
+python tools/coop_time.py ted 30 4,16,32,64,96,128,160,192,224,256,288,320,384,448,512 coop,batch,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_ted.txt"
+python tools/coop_time.py beat 30 4,32,64,128,192,256 coop,batch,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_beat.txt"
+python bench.py --gpus 2 --launcher threads --ranks-share-device --batch 256 --steps 2 > "$out/bench_threads_two_handles.json" 2> "$out/bench_threads.err"; echo "threads launcher rc=$?"
+tools/prof_call.sh "$out/coop" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU FETCH_SIZE WRITE_SIZE" -- python tools/coop_time.py beat 20 32 coop
 [ -x variants/conv_bench ] && variants/conv_bench 512 > "$out/conv_bench.txt" 2>&1
 [ -x variants/conv_bench_prof ] && variants/conv_bench_prof 512 > "$out/conv_bench_prof.txt" 2>&1
 [ -x variants/conv_bwd_bench ] && variants/conv_bwd_bench 512 > "$out/conv_bwd_bench.txt" 2>&1

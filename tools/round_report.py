@@ -15,6 +15,8 @@ RUNS = [
     ("bench_beat256", "`--dataset beat --batch 256` (configs[4] at 34 frames, the whole job on one GPU)"),
     ("bench_beat150_b32", "`--dataset beat150 --batch 32` (configs[4] as worded, per-GPU share of 256/8; synthetic)"),
     ("bench_beat150_b256", "`--dataset beat150 --batch 256 --diffusion-steps 200` (synthetic)"),
+    ("bench_threads_two_handles", "`--gpus 2 --launcher threads --ranks-share-device --batch 256` (ONE process, two engine handles on one GPU driven by two "
+                                  "threads, no process group: the collective-free launcher, not a scaling number)"),
     ("bench_two_ranks_one_gpu", "`--gpus 2 --ranks-share-device --batch 256 --legs lively` (self-launched; TWO RANKS ON ONE GPU, collectives over gloo: "
                                 "the N > 1 control flow, not a scaling number)"),
 ]
@@ -45,7 +47,7 @@ for name, cmd in RUNS:
         out.append(f"| {name} | {cmd} | (missing) | | | | | |")
         continue
     rf = r["roofline"]
-    out.append(f"| {name} | {cmd} | {r['value']:.1f} | {r['ms_per_step']:.2f} | {rf.get('kernel_ms')} | {rf.get('frac')} | {rf.get('traffic')} | "
+    out.append(f"| {name} | {cmd} | {r['value']:.1f} | {r['ms_per_step']:.2f} | {rf.get('kernel_ms', rf.get('kernel_ms_device0'))} | {rf.get('frac')} | {rf.get('traffic')} | "
                f"{(r.get('parity_in_run') or {}).get('max_abs_diff')} |")
 d = load("bench_default")
 if d:
@@ -70,8 +72,12 @@ out += ["", "## Synthetic 150-frame variant, B=256: dispatch summary", "", cat("
         "", "## Once-per-call stage (`tools/prepare_only.py`, B=512): dispatch summary and PMC passes", "", cat("prepare/kt.md")]
 for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
     out += ["", f"### PMC {c}", "", cat(f"prepare/pmc_{c}.md")]
-out += ["", "## ms per diffusion step over the batch size: fused kernel vs batch-level kernels (`tools/smallbatch_time.py`)", "", "```", cat("smallbatch_ted.txt"), "",
-        cat("smallbatch_beat.txt"), "```",
+out += ["", "## ms per diffusion step over the batch size, by kernel family and for `auto` (`tools/coop_time.py`)", "", "```", cat("tvb_ted.txt"), "",
+        cat("tvb_beat.txt"), "```",
+        "", "## Sample-split step kernel, BEAT B = 32 (`tools/coop_time.py beat 20 32 coop`): dispatch summary and PMC passes", "", cat("coop/kt.md")]
+for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+    out += ["", f"### PMC {c}", "", "\n".join(l for l in cat(f"coop/pmc_{c}.md").splitlines() if "k_coop" in l or l.startswith("| kernel") or l.startswith("|---"))]
+out += [
         "", "## Stride-6 conv layers stand-alone (`tools/conv_bench.cpp`) and the per-stage barrier timeline of one workgroup (`-DLS_CONV_PROF`)", "", "```",
         cat("conv_bench.txt"), "", cat("conv_bench_prof.txt"), "```",
         "", "## Backward conv kernels of the training step stand-alone (`tools/conv_bwd_bench.cpp`: timing after a clock warm-up, sampled entries against a host evaluation)",
