@@ -30,6 +30,8 @@ import torch as th
 
 from . import _lib
 
+_TH_RANDN, _TH_RANDN_LIKE = th.randn, th.randn_like      # as imported: a caller (or test) that replaces them wants to see every draw
+
 
 def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=1.0):
     if schedule_name == "linear":
@@ -359,7 +361,8 @@ class GaussianDiffusion:
             # in C++, the transcendental part on worker threads) when the restatement reproduces this torch build bit for bit -- checked
             # once per process -- and the loop draws nothing else in between (no inpainting draws, contiguous first x).
             from . import torch_rng
-            native = torch_rng.variant() if (self.native_host_rng and inz is None and first_proto.is_contiguous()) else -1
+            intercepted = th.randn is not _TH_RANDN or th.randn_like is not _TH_RANDN_LIKE      # someone patched torch's draw functions
+            native = torch_rng.variant() if (self.native_host_rng and inz is None and first_proto.is_contiguous() and not intercepted) else -1
             self.last_host_rng_native = native >= 0
 
             def draw_steps(k0, eps_seg, nz_seg):            # steps k0 .. k0 + len(eps_seg) into (eps [n,2,B,D], noise [n,B,J,F,T])

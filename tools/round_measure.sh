@@ -35,7 +35,7 @@ for f in "$out"/bench_*.json; do python - "$f" <<'PY'
 import json, sys
 try:
     r = json.load(open(sys.argv[1]))
-    print(sys.argv[1].split("/")[-1], r["value"], r["ms_per_step"], r["roofline"]["kernel_ms"], r["roofline"]["frac"], (r.get("parity_in_run") or {}).get("max_abs_diff"), (r.get("shard_check") or {}).get("bitwise_equal"))
+    print(sys.argv[1].split("/")[-1], r["value"], r["ms_per_step"], r["roofline"].get("kernel_ms", r["roofline"].get("kernel_ms_device0")), r["roofline"]["frac"], (r.get("parity_in_run") or {}).get("max_abs_diff"), (r.get("shard_check") or {}).get("bitwise_equal"))
 except Exception as e:
     print(sys.argv[1], "ERR", e)
 PY
