@@ -208,7 +208,8 @@ int build_fused_images(ls_handle* h) {
     std::vector<unsigned short> wch_hi((size_t)L * D * D), wch_lo((size_t)L * D * D);
     const int KS = (R + 31) / 32;
     const int MK1 = (S + 3) / 4;
-    std::vector<float> wt1((size_t)L * 3 * MK1 * 64);
+    const int MQ1 = (MK1 + 3) / 4;
+    std::vector<float> wt1((size_t)L * 3 * MQ1 * 256);
     std::vector<unsigned short> wwh((size_t)L * kNT * KS * 64 * 8), wwl((size_t)L * kNT * KS * 64 * 8);
     char key[160];
     for (int l = 0; l < L; ++l) {
@@ -283,12 +284,12 @@ int build_fused_images(ls_handle* h) {
                         wwl[o] = f32_to_bf16(v - bf16_to_f32(wwh[o]));
                     }
         for (int r = 0; r < R; ++r) bt[(size_t)l * 80 + r] = (*b1)[r % S];
-        // wtok1_img[l][t][m][lane] = Wt[r = 16t + (lane&15)][r' = 4m + (lane>>4)] of ONE pass, zero outside S x S (ls_coop_kernel.h)
+        // wtok1_img[l][t][mq][lane][j] = Wt[r = 16t + (lane&15)][r' = 4(4mq + j) + (lane>>4)] of ONE pass, zero outside S x S (ls_coop_kernel.h)
         for (int t = 0; t < 3; ++t)
-            for (int m = 0; m < MK1; ++m)
+            for (int m = 0; m < 4 * MQ1; ++m)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = 16 * t + (lane & 15), rp = 4 * m + (lane >> 4);
-                    wt1[(((size_t)l * 3 + t) * MK1 + m) * 64 + lane] = (r < S && rp < S) ? (*Wt)[(size_t)r * S + rp] : 0.f;
+                    wt1[((((size_t)l * 3 + t) * MQ1 + (m >> 2)) * 64 + lane) * 4 + (m & 3)] = (r < S && rp < S) ? (*Wt)[(size_t)r * S + rp] : 0.f;
                 }
     }
     const auto* Win = find_w(h, "input_mapping.weight", (size_t)D * KIN);        // RAG.py:62

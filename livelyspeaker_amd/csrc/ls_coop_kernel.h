@@ -90,6 +90,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     constexpr bool kRemMfma = (NREM % 4 == 0);  // BEAT: one v_mfma_f32_4x4x1 row group; TED: scalar FMAs (see k_step)
     constexpr int NRV = kRemMfma ? 1 : NREM;
     constexpr int MK1 = (S + 3) / 4;            // k steps of the token-mix GEMM of one pass
+    constexpr int MQ1 = (MK1 + 3) / 4;          // ... in groups of four (one 16-byte weight fragment per lane)
     constexpr int NQUAD = kT * (NOBP / 4);      // (frame, 4 output columns) quads of one sample
     static_assert(S > 32 && S <= kCoopRows, "one pass = two full row tiles + a ragged one");
     static_assert(NREM >= 1 && NREM <= 4, "ragged tile");
@@ -255,11 +256,17 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     };
     auto ln_publish = [&](int area, unsigned tag, bool payload) {
         float m, m2;
-        lane_part(X0, m, m2);
-        if (g == 0) pst[w * 48 + row0()] = (f2){m, m2};
-        if (h) {                                                     // wave-uniform
-            lane_part(X1, m, m2);
-            if (g == 0) pst[w * 48 + 32 + s16] = (f2){m, m2};
+        if (h) {                                                     // wave-uniform; the two rows' chains in one block, so that they interleave
+            float n, n2;
+            lane_part(X0, m, m2);
+            lane_part(X1, n, n2);
+            if (g == 0) {
+                pst[w * 48 + row0()] = (f2){m, m2};
+                pst[w * 48 + 32 + s16] = (f2){n, n2};
+            }
+        } else {
+            lane_part(X0, m, m2);
+            if (g == 0) pst[w * 48 + row0()] = (f2){m, m2};
         }
         if (payload) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores
         lds_barrier();
@@ -325,22 +332,23 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
         X0 += temb4;
         if (live1()) X1 += temb4;
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
+        ln_publish(0, a.epoch + 2 * l + 1, false);
+        // LayerNorm affine, token-mix weights and biases of this wave's row tiles (tile h, and the ragged tile 2 for half 1): requested
+        // AFTER the partials are out (22 dword loads per wave ahead of them cost the chain ~1 k clocks of issue), in flight during the
+        // exchange -- they depend on no activation.  wtok1_img[l][t][mq][lane][j] = Wt[16 t + (lane & 15)][4 (4 mq + j) + (lane >> 4)]
         const f4 al1 = wload4(rs_ln1a, chw * 4, l * kD * 4), be1 = wload4(rs_ln1b, chw * 4, l * kD * 4);
-        // token-mix weights and biases of this wave's row tiles (tile h, and the ragged tile 2 for half 1): in flight during the
-        // LayerNorm-1 exchange (they depend on no activation).  wtok1_img[l][t][m][lane] = Wt[16 t + (lane & 15)][4 m + (lane >> 4)]
-        float Bt0[MK1], Bt1[MK1], btb0, btb1;
+        f4 Bt0[MQ1], Bt1[MQ1];
+        float btb0, btb1;
         {
-            const wrsrc_t wrs = rs_wtok1;
-            const int wsb = l * NT1 * MK1 * 256;
+            const int wsb = l * NT1 * MQ1 * 1024;
 #pragma unroll
-            for (int m = 0; m < MK1; ++m) {
-                Bt0[m] = wload1(wrs, lane * 4, wsb + (h * MK1 + m) * 256);
-                Bt1[m] = wload1(wrs, lane * 4, wsb + (2 * MK1 + m) * 256);
+            for (int m = 0; m < MQ1; ++m) {
+                Bt0[m] = wload4(rs_wtok1, lane * 16, wsb + (h * MQ1 + m) * 1024);
+                Bt1[m] = h ? wload4(rs_wtok1, lane * 16, wsb + (2 * MQ1 + m) * 1024) : (f4){0.f, 0.f, 0.f, 0.f};
             }
             btb0 = p_btok[l * 80 + row0()];
             btb1 = p_btok[l * 80 + row1c()];
         }
-        ln_publish(0, a.epoch + 2 * l + 1, false);
         ln_gather(0, a.epoch + 2 * l + 1, 2 + 8 * l + 5);
         stamp(2 + 8 * l);
         fresh();
@@ -366,8 +374,8 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             for (int m = 0; m < MK1; ++m) {
                 const int sr = (4 * m + 3 < S) ? 4 * m + g : min(4 * m + g, S - 1);   // clamped rows meet zero weights
                 const float av = U[sr * kCoopU1Stride + 16 * w + s16];
-                acc0 = MFMA(av, Bt0[m], acc0);
-                if (h) acc1 = MFMA(av, Bt1[m], acc1);
+                acc0 = MFMA(av, Bt0[m >> 2][m & 3], acc0);
+                if (h) acc1 = MFMA(av, Bt1[m >> 2][m & 3], acc1);
             }
             X0 = silu_acc4(acc0, X0);
             if (live1()) X1 = silu_acc4(acc1, X1);

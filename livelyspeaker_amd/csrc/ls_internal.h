@@ -37,7 +37,7 @@ struct DevWeights {
     const unsigned short* ww_lo_img;
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
-    const float* wtok1_img;  // [L][3][ceil(S/4)][64]   token-mix operand of ONE pass (sample-split kernel, ls_coop_kernel.h)
+    const float* wtok1_img;  // [L][3][ceil(S/16)][64][4]   token-mix operand of ONE pass (sample-split kernel, ls_coop_kernel.h)
     const float* btok_rows;  // [L][80]
     const float* winx_img;   // [8][2 passes][KXQ][2 cb][64][4]   x_t columns of input_mapping
     const float* wout_img;   // [NOB][32][64][4]   poseFinal, k in natural order (operand staged in LDS)
