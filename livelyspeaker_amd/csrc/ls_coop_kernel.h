@@ -434,8 +434,15 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
                 }
             }
             typedef const __attribute__((address_space(3))) f4* ldsp4;
+            // Two slices (= PF k blocks) per trip, so that fragment k of the trip lives in An[k] and is re-requested in place: a rolled
+            // one-slice loop rotates An[] through register moves, and a move of the newest fragment waits for it -- vmcnt(0) at the end of
+            // every iteration, i.e. no prefetch across iterations at all.
+            static_assert(PF == 4 && kCoopSlices % 2 == 0, "the slice loop is unrolled by PF k blocks");
 #pragma unroll 1
-            for (int i = 0; i < kCoopSlices; ++i) {
+            for (int ip = 0; ip < kCoopSlices / 2; ++ip)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int i = 2 * ip + hf;
                 const int s = (c + i) & 7;
                 if (i == 0) __builtin_amdgcn_s_setprio(0);
                 if (i == 1) {
@@ -460,10 +467,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int n = 2 * i + qq;
-                    const f4 A = An[0];
-#pragma unroll
-                    for (int k = 0; k + 1 < PF; ++k) An[k] = An[k + 1];
-                    An[PF - 1] = wload4(wrs, lane * 16, wsb + qof(min(n + PF, 15)) * 2048);
+                    const f4 A = An[2 * hf + qq];
                     f4 Bv[2], Ur[kRemMfma ? 1 : NRV];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) Bv[t] = Bn[t];
@@ -486,6 +490,9 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    // re-requested in place AFTER its last use (requested before, the old and the new fragment are both live and the new one
+                    // is copied into place at the back edge -- behind a wait for it)
+                    An[2 * hf + qq] = wload4(wrs, lane * 16, wsb + qof(min(n + PF, 15)) * 2048);
                 }
             }
             stamp(5 + 8 * l);
