@@ -699,7 +699,7 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 // Step-time models in ms, measured on MI355X (profiles/r04_throughput_vs_batch.md): the plan is the cheapest of
 //   all sample-split | all batch-level | all fused | full fused rounds + the remainder on sample-split or batch-level.
 struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round; };
-constexpr PathCost kCostTed{0.100f, 0.00105f, 0.175f, 0.0030f, 0.68f}, kCostBeat{0.114f, 0.0011f, 0.166f, 0.0034f, 0.79f};
+constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f};
 float coop_ms(const PathCost& c, int n, int np) {
     float ms = 0.f;
     for (int g = n * np; g > 0; g -= kCoopMaxGroups) ms += c.coop_base + c.coop_per_group * (g < kCoopMaxGroups ? g : kCoopMaxGroups);
