@@ -15,6 +15,7 @@ python bench.py --gpus 2 --ranks-share-device --batch 256 --legs lively --no-cpu
 python tools/coop_time.py ted 30 4,16,32,64,96,128,160,192,224,256,288,320,384,448,512 coop,batch,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_ted.txt"
 python tools/coop_time.py beat 30 4,32,64,128,192,256 coop,batch,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_beat.txt"
 python bench.py --gpus 2 --launcher threads --ranks-share-device --batch 256 --steps 2 > "$out/bench_threads_two_handles.json" 2> "$out/bench_threads.err"; echo "threads launcher rc=$?"
+tools/prof_call.sh "$out/kstep" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" -- python tools/coop_time.py ted 20 512 fused
 tools/prof_call.sh "$out/coop" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU FETCH_SIZE WRITE_SIZE" -- python tools/coop_time.py beat 20 32 coop
 [ -x variants/conv_bench ] && variants/conv_bench 512 > "$out/conv_bench.txt" 2>&1
 [ -x variants/conv_bench_prof ] && variants/conv_bench_prof 512 > "$out/conv_bench_prof.txt" 2>&1
