@@ -60,6 +60,9 @@ typedef __attribute__((address_space(1))) unsigned long long* gu64p;
 __device__ __forceinline__ f4 ld_sc1(wrsrc_t r, int voff) {
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 16));     // aux 16 = sc1: served from L2 / memory, never this CU's L1
 }
+__device__ __forceinline__ float ld_sc1_1(wrsrc_t r, int voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 16));
+}
 __device__ __forceinline__ void st_sc1(f4 v, wrsrc_t r, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, voff, 0, 16);       // write-through
 }
@@ -612,6 +615,71 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
         const unsigned long long gidx = (a.call ? a.call->sample_offset : 0ull) + (unsigned long long)b;
         const size_t base = (size_t)b * kT * JF;
         const wrsrc_t p0 = uniform_rsrc(a.cpart + (size_t)(bl * np) * kCoopSlices * kCoopRows * NOBP);
+        // Few quads per workgroup (TED: 17): one thread per output ELEMENT (a quad's four columns on four lanes: 4x the threads for the
+        // Philox draws and the update; the same sums in the same order).  Many (BEAT: 77): one thread per quad -- measured 1 % faster
+        // there at 32 clips, 2 % slower for TED.
+        constexpr bool kByElement = 4 * ((NQUAD + 15) / 16) <= 128;
+        if constexpr (kByElement) {
+        for (int e = tid; e < 4 * per; e += kCoopThreads) {
+            const int quad = j16 * per + (e >> 2), jj = e & 3;
+            if (quad >= NQUAD) break;
+            const int f = quad / (NOBP / 4), cq = quad - f * (NOBP / 4);
+            const int cc = 4 * cq + jj;
+            if (cc >= JF) continue;
+            const int off = ((NPRE + f) * NOBP + cc) * 4;
+            float pc[kCoopSlices], pu[kCoopSlices];
+#pragma unroll
+            for (int s = 0; s < kCoopSlices; ++s) pc[s] = ld_sc1_1(p0, off + s * kCoopRows * NOBP * 4);
+            if (np == 2) {
+#pragma unroll
+                for (int s = 0; s < kCoopSlices; ++s) pu[s] = ld_sc1_1(p0, off + (kCoopSlices + s) * kCoopRows * NOBP * 4);
+            }
+            const int idx = f * JF + cc;
+            const float xt = a.sampler != kNone ? a.x_in[base + idx] : 0.f;
+            float oc = pc[0], ou = 0.f;
+#pragma unroll
+            for (int s = 1; s < kCoopSlices; ++s) oc += pc[s];
+            if (np == 2) {
+                ou = pu[0];
+#pragma unroll
+                for (int s = 1; s < kCoopSlices; ++s) ou += pu[s];
+            }
+            const float bo = p_bout[cc];
+            oc += bo;
+            float x0;
+            if (np == 2) {
+                ou += bo;
+                if (a.fwd_c) a.fwd_c[base + idx] = oc;
+                if (a.fwd_u) a.fwd_u[base + idx] = ou;
+                x0 = ou + sc * (oc - ou);
+            } else {
+                x0 = oc;                                             // scale == 1: the CFG combination is the cond output
+            }
+            if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (a.x0_out) a.x0_out[base + idx] = x0;
+            if (a.sampler != kNone) {
+                float nz = 0.f;
+                if (a.t_nonzero) {
+                    if (a.noise) {
+                        const size_t bn = a.const_noise ? 0 : (size_t)b;
+                        nz = a.noise[(bn * JF + cc) * kT + f];
+                    } else {
+                        nz = philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(cc * kT + f));
+                    }
+                }
+                float xn;
+                if (a.sampler == kDDPM) {
+                    xn = a.c0 * x0 + a.c1 * xt;
+                    if (a.t_nonzero) xn += a.c2 * nz;
+                } else {
+                    const float eps = (a.c0 * xt - x0) / a.c1;
+                    xn = x0 * a.c2 + a.c3 * eps;
+                    if (a.t_nonzero) xn += a.c4 * nz;
+                }
+                a.x_out[base + idx] = xn;
+            }
+        }
+        } else {
         for (int i = tid; i < per; i += kCoopThreads) {
             const int quad = j16 * per + i;
             if (quad >= NQUAD) break;
@@ -673,6 +741,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
                     a.x_out[base + idx] = xn;
                 }
             }
+        }
         }
     }
     stamp(5 + 8 * a.layers);
