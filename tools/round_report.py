@@ -77,6 +77,20 @@ out += ["", "## ms per diffusion step over the batch size, by kernel family and 
         "", "## Sample-split step kernel, BEAT B = 32 (`tools/coop_time.py beat 20 32 coop`): dispatch summary and PMC passes", "", cat("coop/kt.md")]
 for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
     out += ["", f"### PMC {c}", "", "\n".join(l for l in cat(f"coop/pmc_{c}.md").splitlines() if "k_coop" in l or l.startswith("| kernel") or l.startswith("|---"))]
+KSTEP = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+         "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")
+rows = []
+for c in KSTEP:
+    for l in cat(f"kstep/pmc_{c}.md").splitlines():
+        if "k_step" in l:
+            rows.append(l)
+            break
+if rows:
+    out += ["", "## Fused step kernel, TED B = 512 (`tools/coop_time.py ted 20 512 fused`): one PMC pass per counter, mean per launch summed over the chip",
+            "", "| kernel | workgroups (x,y,z) x threads | launches | avg us | min us | vgpr | lds B | counters (mean per launch) |", "|---|---|---|---|---|---|---|---|"] + rows + [
+            "", "Reading (1024 SIMDs, 8 XCDs): GRBM_GUI_ACTIVE / 8 = cycles of the launch; SQ_VALU_MFMA_BUSY_CYCLES / 1024 = matrix-pipe cycles per SIMD",
+            "(= SQ_INSTS_MFMA / 1024 x 32: every `v_mfma_f32_16x16x4_f32` holds the pipe 32 cycles); (SQ_INSTS_VALU - SQ_INSTS_MFMA) / 1024 x 4 = issue",
+            "cycles of the other vector instructions per SIMD; SQ_VALU_MFMA_COEXEC_CYCLES = 0: the two never overlap on this kernel."]
 out += [
         "", "## Stride-6 conv layers stand-alone (`tools/conv_bench.cpp`) and the per-stage barrier timeline of one workgroup (`-DLS_CONV_PROF`)", "", "```",
         cat("conv_bench.txt"), "", cat("conv_bench_prof.txt"), "```",
