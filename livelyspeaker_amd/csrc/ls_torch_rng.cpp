@@ -17,7 +17,9 @@
 // The generator state travels as torch.get_rng_state()'s 5056-byte blob (layout probed in tests/test_torch_rng.py), updated in place,
 // so torch.set_rng_state() leaves torch's generator exactly where the reference's draws would have left it.
 //
-// Speed: the mt19937 words are produced sequentially (they must be), the transcendental part is spread over worker threads.
+// Speed: the mt19937 words are produced sequentially (they must be) but in bulk -- the state update and the tempering are plain array
+// loops the compiler vectorises (an AVX2 clone is picked at run time) -- by the calling thread, which hands every job's transcendental
+// part to a pool of worker threads and goes on generating the next job's words meanwhile.
 #include "ls_hip.h"
 
 // every product and sum below rounds where it is written: no contraction by THIS compiler (the FMAs of the restated kernels are explicit)
@@ -26,6 +28,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -85,12 +92,58 @@ struct Mt {
         y ^= (y >> 18);
         return y;
     }
+    // n words of the same stream in bulk.  `left - 1` words of the current block are still unread, at st[next ...]
+    void fill_words(uint32_t* out, size_t n);
     float uf() { return (float)(word() & ((1u << 24) - 1)) * (1.0f / (float)(1u << 24)); }                 // uniform_real<float>
     double ud() {                                                                                           // uniform_real<double>: random64
         const uint64_t hi = word(), lo = word();
         return (double)(((hi << 32) | lo) & ((1ull << 53) - 1)) * (1.0 / (double)(1ull << 53));
     }
 };
+
+// The block update and the tempering as array loops (same recurrence as next_state / word): in the first loop every read is ahead of
+// the write, in the second the value read was written 227 iterations earlier, so both vectorise.
+#define LS_MT_BLOCK_BODY                                                                                                    \
+    for (int i = 0; i < kN - kM; ++i) {                                                                                     \
+        const uint32_t y = (st[i] & 0x80000000u) | (st[i + 1] & 0x7fffffffu);                                               \
+        st[i] = st[i + kM] ^ (y >> 1) ^ ((0u - (st[i + 1] & 1u)) & 0x9908b0dfu);                                            \
+    }                                                                                                                       \
+    for (int i = kN - kM; i < kN - 1; ++i) {                                                                                \
+        const uint32_t y = (st[i] & 0x80000000u) | (st[i + 1] & 0x7fffffffu);                                               \
+        st[i] = st[i + kM - kN] ^ (y >> 1) ^ ((0u - (st[i + 1] & 1u)) & 0x9908b0dfu);                                       \
+    }                                                                                                                       \
+    {                                                                                                                       \
+        const uint32_t y = (st[kN - 1] & 0x80000000u) | (st[0] & 0x7fffffffu);                                              \
+        st[kN - 1] = st[kM - 1] ^ (y >> 1) ^ ((0u - (st[0] & 1u)) & 0x9908b0dfu);                                           \
+    }
+#define LS_MT_TEMPER_BODY                                                                                                   \
+    for (size_t i = 0; i < m; ++i) {                                                                                        \
+        uint32_t y = src[i];                                                                                                \
+        y ^= (y >> 11);                                                                                                     \
+        y ^= (y << 7) & 0x9d2c5680u;                                                                                        \
+        y ^= (y << 15) & 0xefc60000u;                                                                                       \
+        y ^= (y >> 18);                                                                                                     \
+        out[i] = y;                                                                                                         \
+    }
+void mt_block_base(uint32_t* __restrict__ st) { LS_MT_BLOCK_BODY }
+void mt_temper_base(const uint32_t* __restrict__ src, uint32_t* __restrict__ out, size_t m) { LS_MT_TEMPER_BODY }
+__attribute__((target("avx2"))) void mt_block_avx2(uint32_t* __restrict__ st) { LS_MT_BLOCK_BODY }
+__attribute__((target("avx2"))) void mt_temper_avx2(const uint32_t* __restrict__ src, uint32_t* __restrict__ out, size_t m) { LS_MT_TEMPER_BODY }
+__attribute__((target("avx512f,prefer-vector-width=512"))) void mt_block_avx512(uint32_t* __restrict__ st) { LS_MT_BLOCK_BODY }
+__attribute__((target("avx512f,prefer-vector-width=512"))) void mt_temper_avx512(const uint32_t* __restrict__ src, uint32_t* __restrict__ out, size_t m) { LS_MT_TEMPER_BODY }
+
+void Mt::fill_words(uint32_t* out, size_t n) {
+    static const int isa = __builtin_cpu_supports("avx512f") ? 2 : __builtin_cpu_supports("avx2") ? 1 : 0;
+    while (n > 0) {
+        if (left - 1 == 0) {                 // word(): --left == 0 -> next_state(), and the word it then reads leaves left at kN
+            if (isa == 2) mt_block_avx512(st); else if (isa == 1) mt_block_avx2(st); else mt_block_base(st);
+            left = kN + 1; next = 0;
+        }
+        const size_t m = n < (size_t)(left - 1) ? n : (size_t)(left - 1);
+        if (isa == 2) mt_temper_avx512(st + next, out, m); else if (isa == 1) mt_temper_avx2(st + next, out, m); else mt_temper_base(st + next, out, m);
+        next += (uint32_t)m; left -= (int)m; out += m; n -= m;
+    }
+}
 
 // ---- the float transform of the contiguous path -------------------------------------------------------------------------------
 // variant 0: normal_fill_16<float> as written (std::log / std::cos / std::sin of float): torch's DEFAULT-capability kernel.
@@ -194,85 +247,165 @@ void fill16(float* d, int variant) {
     fill16_cephes(d, variant);
 }
 
-void parallel_for(size_t n, int threads, const std::function<void(size_t, size_t)>& fn);
-
-}  // namespace
-
-#include <functional>
-
-namespace {
-
-void parallel_for(size_t n, int threads, const std::function<void(size_t, size_t)>& fn) {
-    if (threads <= 1 || n < 4096) { fn(0, n); return; }
-    std::vector<std::thread> th;
-    const size_t per = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
-        const size_t a = (size_t)t * per, b = a + per < n ? a + per : n;
-        if (a >= b) break;
-        th.emplace_back(fn, a, b);
+// ---- worker pool: the calling thread produces jobs (their words), the workers run the transcendental part ----------------------------
+class Pool {
+public:
+    explicit Pool(int threads) {
+        for (int t = 0; t < threads; ++t) th_.emplace_back([this] { work(); });
     }
-    for (auto& x : th) x.join();
-}
-
-// one deferred piece of transcendental work: a contiguous float draw (uniforms already in place) or a serial double draw
-struct ContigJob { float* out; size_t n; std::vector<float> tail; bool has_tail; int variant; };
-struct SerialJob {
-    float* out;                      // contiguous [B][J][F][T]
-    int B, J, F, T;
-    bool permuted;                   // true: element e in MEMORY order [T][B][J][F]; false: e in [B][J][F][T] order (fewer than 16 elements)
-    size_t n;
-    bool lead_cached; double lead;   // element 0 comes from the generator's cached sample
-    std::vector<double> u;           // (u1, u2) per pair for elements lead_cached .. n
+    ~Pool() {
+        wait();
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // fn(a, b) over [0, n) in chunks; runs inline without workers or for small jobs
+    void run(size_t n, size_t chunk, std::function<void(size_t, size_t)> fn) {
+        if (th_.empty() || n <= chunk) { if (n) fn(0, n); return; }
+        auto f = std::make_shared<std::function<void(size_t, size_t)>>(std::move(fn));
+        {
+            std::lock_guard<std::mutex> l(m_);
+            for (size_t a = 0; a < n; a += chunk) { q_.push_back([f, a, n, chunk] { (*f)(a, a + chunk < n ? a + chunk : n); }); ++pending_; }
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+    }
+private:
+    void work() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job();
+            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    size_t pending_ = 0;
+    bool stop_ = false;
 };
 
-size_t dst_index(const SerialJob& j, size_t e) {
+inline float word_to_uf(uint32_t w) { return (float)(w & ((1u << 24) - 1)) * (1.0f / (float)(1u << 24)); }                 // uniform_real<float>
+inline double words_to_ud(uint32_t hi, uint32_t lo) {                                                                        // uniform_real<double>: random64
+    return (double)((((uint64_t)hi << 32) | lo) & ((1ull << 53) - 1)) * (1.0 / (double)(1ull << 53));
+}
+// one pair of normal_distribution<double>: the cos branch is the sample, the sin branch the cached one
+inline void normal_pair(const uint32_t* w, double& zc, double& zs) {
+    const double u1 = words_to_ud(w[0], w[1]), u2 = words_to_ud(w[2], w[3]);
+    const double r = ::sqrt(-2.0 * ::log1p(-u2));
+    const double theta = 2.0 * 3.14159265358979323846 * u1;
+    zs = r * ::sin(theta);
+    zc = r * ::cos(theta);
+}
+
+// A contiguous float draw of n >= 16 elements: the words land in `out` itself (one per element) and are turned into uniforms and then
+// normals in place, 16 at a time.  A length that is not a multiple of 16 re-draws the LAST 16 elements ("recompute the last 16 values").
+void draw_contig(Mt& g, Pool& pool, float* out, size_t n, int variant) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(out);
+    g.fill_words(w, n);
+    const size_t blocks = n / 16;
+    auto block = [variant](float* d) {
+        uint32_t* u = reinterpret_cast<uint32_t*>(d);
+        float f[16];
+        for (int i = 0; i < 16; ++i) f[i] = word_to_uf(u[i]);
+        fill16(f, variant);
+        memcpy(d, f, sizeof f);
+    };
+    if (n % 16) {                        // rare: finish this job before the tail overwrites the end of its last full block
+        pool.wait();
+        for (size_t i = 0; i < blocks; ++i) block(out + 16 * i);
+        uint32_t tw[16];
+        g.fill_words(tw, 16);
+        float f[16];
+        for (int i = 0; i < 16; ++i) f[i] = word_to_uf(tw[i]);
+        fill16(f, variant);
+        memcpy(out + n - 16, f, sizeof f);
+        return;
+    }
+    pool.run(blocks, 2048, [out, block](size_t a, size_t b) { for (size_t i = a; i < b; ++i) block(out + 16 * i); });
+}
+
+// An element-at-a-time double draw of n elements, element e stored at dst(e).  The generator's cached sample is consumed first and the
+// one left over by an odd count is computed HERE (the next draw needs it before the workers have run).
+struct SerialShape { int B, J, F, T; bool permuted; };    // permuted: element e is in MEMORY order [T][B][J][F] of a [B][J][F][T] tensor
+inline size_t dst_index(const SerialShape& j, size_t e) {
     if (!j.permuted) return e;
     const size_t bjf = (size_t)j.B * j.J * j.F, t = e / bjf, r = e - t * bjf;       // r = (b * J + j) * F + f
     return r * j.T + t;
 }
-
-void gen_contig(Mt& g, float* out, size_t n, ContigJob& job, int variant) {
-    job.variant = variant;
-    for (size_t i = 0; i < n; ++i) out[i] = g.uf();
-    job.out = out; job.n = n; job.has_tail = (n % 16) != 0;
-    if (job.has_tail) { job.tail.resize(16); for (int i = 0; i < 16; ++i) job.tail[i] = g.uf(); }
-}
-void run_contig(ContigJob& job, int threads) {
-    const size_t blocks = job.n / 16;
-    parallel_for(blocks, threads, [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) fill16(job.out + 16 * i, job.variant); });
-    if (job.has_tail) {              // "recompute the last 16 values": they overlap the last full block
-        fill16(job.tail.data(), job.variant);
-        memcpy(job.out + job.n - 16, job.tail.data(), 16 * sizeof(float));
+// Word buffers of the serial draws in flight: a ring of uninitialised arrays kept by the calling thread between calls (fresh 4 MB
+// vectors per step cost a zero-fill and page faults on the producer's critical path); wrapping around waits for the workers.
+struct WordRing {
+    static constexpr int kSlots = 8;
+    std::unique_ptr<uint32_t[]> buf[kSlots];
+    size_t cap = 0;
+    int used = 0;
+    uint32_t* get(Pool& pool, size_t n) {
+        if (n > cap || used == kSlots) {
+            pool.wait();
+            used = 0;
+            if (n > cap) { for (auto& b : buf) b.reset(new uint32_t[n]); cap = n; }
+        }
+        return buf[used++].get();
     }
-}
-
-void gen_serial(Mt& g, SerialJob& j) {
-    j.lead_cached = false;
-    size_t e = 0;
-    if (g.cached_valid && j.n > 0) { j.lead_cached = true; j.lead = g.cached; g.cached_valid = 0; e = 1; }
-    const size_t pairs = (j.n - e + 1) / 2;
-    j.u.resize(2 * pairs);
-    for (size_t p = 0; p < pairs; ++p) { j.u[2 * p] = g.ud(); j.u[2 * p + 1] = g.ud(); }
-}
-// returns the sample left over for the generator's cache when the element count is odd
-void run_serial(SerialJob& j, int threads, Mt& g) {
-    const size_t e0 = j.lead_cached ? 1 : 0, pairs = j.u.size() / 2;
-    if (j.lead_cached) j.out[dst_index(j, 0)] = (float)(j.lead * 1.0 + 0.0);
-    double leftover = 0.0;
-    bool has_left = false;
-    parallel_for(pairs, threads, [&](size_t a, size_t b) {
-        for (size_t p = a; p < b; ++p) {
-            const double u1 = j.u[2 * p], u2 = j.u[2 * p + 1];
-            const double r = ::sqrt(-2.0 * ::log1p(-u2));
-            const double theta = 2.0 * 3.14159265358979323846 * u1;
-            const double zs = r * ::sin(theta), zc = r * ::cos(theta);
-            const size_t e = e0 + 2 * p;
-            j.out[dst_index(j, e)] = (float)(zc * 1.0 + 0.0);
-            if (e + 1 < j.n) j.out[dst_index(j, e + 1)] = (float)(zs * 1.0 + 0.0);
-            else { leftover = zs; has_left = true; }             // only the last pair of the job can get here
+};
+void draw_serial(Mt& g, Pool& pool, WordRing& ring, float* out, size_t n, SerialShape sh) {
+    size_t e0 = 0;
+    if (g.cached_valid && n > 0) { out[dst_index(sh, 0)] = (float)(g.cached * 1.0 + 0.0); g.cached_valid = 0; e0 = 1; }
+    const size_t pairs = (n - e0 + 1) / 2;
+    if (!pairs) return;
+    uint32_t* w = ring.get(pool, 4 * pairs);
+    g.fill_words(w, 4 * pairs);
+    if ((n - e0) & 1) {                  // the last pair's sin branch stays in the generator
+        double zc, zs;
+        normal_pair(w + 4 * (pairs - 1), zc, zs);
+        g.cached = zs; g.cached_valid = 1;
+    }
+    if (!sh.permuted) {
+        pool.run(pairs, 8192, [w, out, e0, n](size_t a, size_t b) {
+            for (size_t p = a; p < b; ++p) {
+                double zc, zs;
+                normal_pair(w + 4 * p, zc, zs);
+                const size_t e = e0 + 2 * p;
+                out[e] = (float)(zc * 1.0 + 0.0);
+                if (e + 1 < n) out[e + 1] = (float)(zs * 1.0 + 0.0);
+            }
+        });
+        return;
+    }
+    // Memory-order draw of a [B][J][F][T] tensor: element e = t * BJF + r lands at r * T + t.  The work is dealt by DESTINATION (a range
+    // of r for every t), so that a worker owns whole cache lines of `out`; dealt by e, neighbouring t planes -- interleaved in memory --
+    // would be written by different threads at the same time.  A pair that straddles two ranges is evaluated by both.
+    const size_t bjf = (size_t)sh.B * sh.J * sh.F, T = (size_t)sh.T;
+    pool.run(bjf, 256, [w, out, e0, n, bjf, T](size_t ra, size_t rb) {
+        for (size_t t = 0; t < T; ++t) {
+            size_t e = t * bjf + ra;
+            const size_t e_end = t * bjf + rb;          // <= n
+            if (e < e0) ++e;                             // element 0 came from the generator's cached sample
+            double zc, zs;
+            if (e < e_end && ((e - e0) & 1)) {           // second member of a pair that starts in the previous range
+                normal_pair(w + 4 * ((e - e0) >> 1), zc, zs);
+                out[(e - t * bjf) * T + t] = (float)(zs * 1.0 + 0.0);
+                ++e;
+            }
+            for (; e < e_end; e += 2) {
+                normal_pair(w + 4 * ((e - e0) >> 1), zc, zs);
+                out[(e - t * bjf) * T + t] = (float)(zc * 1.0 + 0.0);
+                if (e + 1 < e_end) out[(e + 1 - t * bjf) * T + t] = (float)(zs * 1.0 + 0.0);
+            }
         }
     });
-    if (has_left) { g.cached = leftover; g.cached_valid = 1; }
 }
 
 }  // namespace
@@ -285,14 +418,13 @@ int ls_trng_randn(uint8_t* state, size_t state_bytes, float* out, size_t n, int 
     if (variant > 0 && !__builtin_cpu_supports("fma")) return LS_EUNSUPPORTED;
     Mt g;
     if (!g.load(state)) return LS_EINVAL;
-    if (n >= 16) {
-        ContigJob job;
-        gen_contig(g, out, n, job, variant);
-        run_contig(job, n_threads);
-    } else {
-        SerialJob j{out, 1, 1, 1, (int)n, false, n, false, 0.0, {}};
-        gen_serial(g, j);
-        run_serial(j, 1, g);
+    {
+        Pool pool(n >= 65536 && n_threads > 1 ? n_threads : 0);
+        static thread_local WordRing ring;
+        ring.used = 0;
+        if (n >= 16) draw_contig(g, pool, out, n, variant);
+        else draw_serial(g, pool, ring, out, n, SerialShape{1, 1, 1, (int)n, false});
+        pool.wait();
     }
     g.store(state);
     return LS_OK;
@@ -306,27 +438,23 @@ int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, 
     Mt g;
     if (!g.load(state)) return LS_EINVAL;
     const size_t ne = (size_t)B * D, nx = (size_t)B * J * F * T;
-    // One step at a time: the mt19937 words sequentially, then that step's transcendental work on the worker threads.  (Generating a
-    // whole segment's words first would need the cached-sample hand-over between steps before the transforms have run.)
-    for (int k = 0; k < n_steps; ++k) {
-        float* ec = eps + (size_t)(2 * k) * ne;
-        float* eu = ec + ne;
-        float* nz = noise + (size_t)k * nx;
-        ContigJob c0, c1, c2;
-        SerialJob s{nz, B, J, F, T, true, nx, false, 0.0, {}};
-        const bool contig_noise = (k == 0 && first_contiguous) && nx >= 16;
-        if (ne >= 16) { gen_contig(g, ec, ne, c0, variant); gen_contig(g, eu, ne, c1, variant); }
-        else {          // never the case for D = 512; kept exact anyway
-            for (float* p : {ec, eu}) { SerialJob t{p, 1, 1, 1, (int)ne, false, ne, false, 0.0, {}}; gen_serial(g, t); run_serial(t, 1, g); }
+    {
+        // The calling thread walks the steps in the reference's draw order producing words; the workers transform behind it.
+        Pool pool(n_threads > 1 ? n_threads : 0);
+        static thread_local WordRing ring;
+        ring.used = 0;
+        for (int k = 0; k < n_steps; ++k) {
+            float* ec = eps + (size_t)(2 * k) * ne;
+            float* nz = noise + (size_t)k * nx;
+            for (float* p : {ec, ec + ne}) {
+                if (ne >= 16) draw_contig(g, pool, p, ne, variant);
+                else draw_serial(g, pool, ring, p, ne, SerialShape{1, 1, 1, (int)ne, false});      // never the case for D = 512; kept exact anyway
+            }
+            const bool first_c = k == 0 && first_contiguous;
+            if (first_c && nx >= 16) draw_contig(g, pool, nz, nx, variant);
+            else draw_serial(g, pool, ring, nz, nx, SerialShape{B, J, F, T, !first_c});             // a contiguous x of < 16 elements: serial, in order
         }
-        if (contig_noise) gen_contig(g, nz, nx, c2, variant);
-        else {
-            if (k == 0 && first_contiguous) s.permuted = false;          // fewer than 16 elements: serial, in [B][J][F][T] order
-            gen_serial(g, s);
-        }
-        if (ne >= 16) { run_contig(c0, n_threads); run_contig(c1, n_threads); }
-        if (contig_noise) run_contig(c2, n_threads);
-        else run_serial(s, n_threads, g);
+        pool.wait();
     }
     g.store(state);
     return LS_OK;
