@@ -798,12 +798,14 @@ def main():
                      "gpu_kernel_ms_per_step": round(loop_ms / max(launches, 1), 3), "segments": n_seg, "steps_per_segment": k_seg,
                      "tape_bytes_if_one_piece": per_step * n_total,
                      "pinned_host_bytes": 2 * k_seg * per_step if n_seg > 1 else per_step * n_s,
-                     "host_rng": ("native restatement of torch's CPU normal stream (csrc/ls_torch_rng.cpp: mt19937 words sequentially, the float and "
-                                  "double Box-Muller transforms on worker threads), continued from and handed back to torch's generator state; checked "
+                     "host_rng": ("native restatement of torch's CPU normal stream (csrc/ls_torch_rng.cpp: mt19937 words in bulk by one producer thread -- "
+                                  "vectorised block update and tempering -- the float and double Box-Muller transforms on a worker pool behind "
+                                  "it), continued from and handed back to torch's generator state; checked "
                                   "bitwise against torch once per process" if getattr(diffusion, "last_host_rng_native", False) else
                                   "torch's own generator (the native restatement does not reproduce this torch build)"),
-                     "bound": "host RNG: one sequential mt19937 stream (2 x B x 512 + B x J x F x T normals per step); the uploads run on the copy "
-                              "stream under the previous segment's steps and the GPU idles while a segment is drawn",
+                     "bound": ("the slower of host RNG (one sequential mt19937 stream: 2 x B x 512 + B x J x F x T normals = 1.46 M words per step at "
+                               "512 clips) and the step kernel: a segment is drawn while the previous segment's steps run, its upload rides the copy "
+                               "stream; `value` scales a 96-step sample linearly, so per-call fixed costs are counted ten times over"),
                      "hipgraph": False if n_seg > 1 else bool(diffusion.use_graph)}
         except Exception as e:
             seeds = {"error": repr(e)[:300]}
