@@ -69,6 +69,26 @@ def test_step_draws_equal_torchs_in_order_value_and_final_state(B, first):
     assert torch.equal(eps, want_e) and torch.equal(nz, want_n)
 
 
+@pytest.mark.parametrize("threads", [1, 5])
+def test_step_draws_at_a_size_that_is_dealt_to_the_worker_pool(threads, monkeypatch):
+    """B = 201: every draw is split into several pool tasks (contiguous draws by 16-blocks, the memory-order draw by destination range,
+    pairs straddling the ranges), with and without worker threads; odd element counts hand the cached sample from step to step."""
+    v = torch_rng.variant()
+    assert v >= 0
+    monkeypatch.setattr(torch_rng, "n_threads", lambda: threads)
+    shape = dict(n=3, B=201, D=512, J=9, F=3, T=33)        # B*J*F*T odd per step
+    torch.manual_seed(1234)
+    torch.randn(1)
+    s0 = torch.get_rng_state()
+    want_e, want_n = torch_rng._torch_steps(first_contiguous=False, **shape)
+    want_after = torch.randn(4, dtype=torch.float64)
+    torch.set_rng_state(s0)
+    eps, nz = torch.empty_like(want_e), torch.empty_like(want_n)
+    torch_rng.fill_steps(eps, nz, False, v)
+    assert torch.equal(eps, want_e) and torch.equal(nz, want_n)
+    assert torch.equal(torch.randn(4, dtype=torch.float64), want_after)
+
+
 def test_bad_arguments_are_rejected():
     lib = _lib.load_library()
     st = torch.get_rng_state()
