@@ -7,7 +7,6 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from livelyspeaker_amd import _lib, synth  # noqa: E402
-from oracle import rag_oracle as orc  # noqa: E402
 
 if os.environ.get("LS_LIB"):
     _lib.use_library(os.environ["LS_LIB"])
@@ -24,7 +23,7 @@ def main():
     for path in paths:
         eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=path)
         eng.load_state_dict(sd)
-        eng.set_schedule(orc.Schedule(steps, ""))
+        eng.set_schedule(synth.schedule(steps))
         for B in batches:
             eng.prepare(synth.make_cond(cfg, B))
             eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=1)          # capture

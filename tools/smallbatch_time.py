@@ -5,7 +5,6 @@ fused = one workgroup per sample (ls_step_kernel.h), batch = batch-level kernels
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from livelyspeaker_amd import _lib, synth
-from oracle import rag_oracle as orc          # schedule tables only (tooling)
 
 ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
 if len(sys.argv) > 2:
@@ -17,7 +16,7 @@ for B in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 144, 160, 176, 192, 256):
     for path in ("fused", "batch"):
         eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=path)
         eng.load_state_dict(synth.make_state_dict(cfg))
-        eng.set_schedule(orc.Schedule(60, ""))
+        eng.set_schedule(synth.schedule(60))
         eng.prepare(synth.make_cond(cfg, B, scale=1.5))
         for _ in range(3):
             eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=3)
