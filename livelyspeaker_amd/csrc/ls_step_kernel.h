@@ -55,6 +55,14 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
     constexpr int NRV = kRemMfma ? 1 : NREM;       // rows (VALU path)
     constexpr int NG = (R + 7) / 8;            // 8-row groups of the transposed bf16 operand of token mixing
     constexpr int KS = (R + 31) / 32;          // k steps (32 source rows) of the bf16 token-mix MFMA
+    // bf16x3 token mixing: the operand stays ROW-major (the two [R][520] bf16 planes the channel mixing uses, 8-byte stores) and the MFMA
+    // A fragment -- 8 consecutive source rows of one channel per lane -- is gathered by gfx950's transposing LDS read
+    // (ds_read_b64_tr_b16: lane i of a 16-lane group supplies row k0 + i / 4, columns 4 (i % 4) .. + 3, and receives column i of rows
+    // k0 .. k0 + 3); 0: the operand is written transposed with 160 ds_write_b16 per wave and layer (rounds 1-3).
+#ifndef LS_TOK_TR
+#define LS_TOK_TR 1
+#endif
+    constexpr bool kTokTr = LS_TOK_TR != 0;
     constexpr int kGrpStride = kD * 8 + 16;    // bf16 per 8-row group (+32 B so the two row halves of a tile miss each other's banks)
     static_assert(2 * NG * kGrpStride * 2 <= (R * kUStride + kWaves * 2 * NREM * 16) * 4, "bf16 token-mix planes must fit U + REM");
     static_assert(NREM > 0 && NREM <= 16, "ragged tile");
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
             }
 #pragma unroll
             for (int t = 0; t < kNT; ++t)
-                if (PREC == 1 && alpha && !valid_of(t) && row_of(t) < 8 * NG) {
+                if (PREC == 1 && alpha && !kTokTr && !valid_of(t) && row_of(t) < 8 * NG) {
                     __bf16* Th = reinterpret_cast<__bf16*>(U);
                     __bf16* Tl = Th + NG * kGrpStride;
                     const int r = row_of(t);
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         if (gr >= 0 && !LS_TRAIN_ABL) *reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb) = u;
                     }
                     if (alpha) u = __builtin_elementwise_fma(u, al, be);
-                    if (PREC == 1 && alpha) {
+                    if (PREC == 1 && alpha && !kTokTr) {
                         // token-mix operand, bf16x3: the contraction runs over ROWS, so the MFMA A operand needs 8
                         // consecutive source rows of one channel in 16 contiguous bytes: UT[row/8][channel][row%8]
                         // slot of channel (g, j) inside its 16-channel block is 4*j + g (bit-fields swapped), so the four lane
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                             Th[o + 32 * j] = hi;
                             Tl[o + 32 * j] = (__bf16)(u[j] - (float)hi);
                         }
-                    } else if (PREC == 1 && !alpha) {
+                    } else if (PREC == 1 && (!alpha || kTokTr)) {
                         // bf16x3 operand: u = hi + lo (+ O(2^-17 |u|)), hi = bf16_rne(u), lo = bf16_rne(u - hi);
                         // two bf16 planes [R][520] in the space of the fp32 buffer
                         __bf16* Uh = reinterpret_cast<__bf16*>(U);
@@ -473,13 +481,34 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     for (int ks = 0; ks < KS; ++ks) {
                         if (tokmix_needed32(S, t, ks)) {
                             const bf8 Bh = wload8h(wrh, lane * 16, wsb + (t * KS + ks) * 1024), Bl = wload8h(wrl, lane * 16, wsb + (t * KS + ks) * 1024);
-                            const int grp = (4 * ks + 3 < NG || 4 * ks + g < NG) ? 4 * ks + g : NG - 1;   // clamp: weights are 0 there
-                            const int ao = grp * kGrpStride + (64 * w + slot) * 8;
                             bf8 Ah[kCB], Al[kCB];
+                            if constexpr (kTokTr) {
+                                typedef short s4v __attribute__((ext_vector_type(4)));
+                                typedef __attribute__((address_space(3))) s4v* lds4;
+                                const __bf16* Ph = reinterpret_cast<const __bf16*>(U);
+                                const __bf16* Pl = Ph + R * kUStride;
+                                // rows past the last one are clamped: their weights are 0 and the clamped row is finite
+                                const int r0 = min(32 * ks + 8 * g + (s16 >> 2), R - 1), r1 = min(32 * ks + 8 * g + 4 + (s16 >> 2), R - 1);
+                                const int c0 = 64 * w + 4 * (s16 & 3);
 #pragma unroll
-                            for (int cb = 0; cb < kCB; ++cb) {
-                                Ah[cb] = *reinterpret_cast<const bf8*>(Th + ao + 16 * cb * 8);
-                                Al[cb] = *reinterpret_cast<const bf8*>(Tl + ao + 16 * cb * 8);
+                                for (int cb = 0; cb < kCB; ++cb) {
+                                    const s4v h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Ph + r0 * kUStride + c0 + 16 * cb));
+                                    const s4v h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Ph + r1 * kUStride + c0 + 16 * cb));
+                                    const s4v l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Pl + r0 * kUStride + c0 + 16 * cb));
+                                    const s4v l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Pl + r1 * kUStride + c0 + 16 * cb));
+                                    typedef short s8v __attribute__((ext_vector_type(8)));
+                                    Ah[cb] = __builtin_bit_cast(bf8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                                    Al[cb] = __builtin_bit_cast(bf8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                                    (void)sizeof(s8v);
+                                }
+                            } else {
+                                const int grp = (4 * ks + 3 < NG || 4 * ks + g < NG) ? 4 * ks + g : NG - 1;   // clamp: weights are 0 there
+                                const int ao = grp * kGrpStride + (64 * w + slot) * 8;
+#pragma unroll
+                                for (int cb = 0; cb < kCB; ++cb) {
+                                    Ah[cb] = *reinterpret_cast<const bf8*>(Th + ao + 16 * cb * 8);
+                                    Al[cb] = *reinterpret_cast<const bf8*>(Tl + ao + 16 * cb * 8);
+                                }
                             }
 #pragma unroll
                             for (int cb = 0; cb < kCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[cb], Bh, acc[cb], 0, 0, 0);
