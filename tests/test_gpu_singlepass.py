@@ -56,6 +56,33 @@ def test_scale1_loops_vs_reference_fixture(ds, golden_r2):
         eng.close()
 
 
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_scale1_split_precision_vs_reference_fixture(ds, golden_r2):
+    """The opt-in bf16x3 arithmetic on the two-samples-per-workgroup (single-pass) form of the fused kernel: its token-mix operand is
+    gathered by the transposing LDS read; contract 1e-3 against the reference's fixture."""
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg, eng = _engine(ds)
+    g = golden_r2[ds]
+    try:
+        eng.set_precision("bf16x3")
+        B = 5
+        eng.prepare(synth.make_cond(cfg, B, scale=1.0))
+        for key, steps, resp, ddim, skip, use_init in (("G11_scale1_ddpm50_B5_final", 50, "", False, 0, False),
+                                                       ("G11_scale1_ddim100_skip80_B5_final", 1000, "ddim100", True, 80, True)):
+            sch = orc.Schedule(steps, resp)
+            eng.set_schedule(sch)
+            tape = synth.NoiseTape(cfg, B, sch.num_timesteps - skip)
+            out = eng.sample(sampler=_lib.LS_SAMPLER_DDIM if ddim else _lib.LS_SAMPLER_DDPM, x_init=tape.x_init, eps_tape=tape.eps,
+                             noise_tape=tape.noise, skip_timesteps=skip, init_image=synth.make_init_image(cfg, B) if use_init else None)
+            t = eng.timing()
+            d = max_abs(out, g[key])
+            print(f"{ds} bf16x3 {key}: {d:.3e} (single_pass {t['single_pass']}, path {t['step_path']})")
+            assert t["single_pass"] == 1 and t["step_path"] == 0 and d < 1e-3
+    finally:
+        eng.close()
+
+
 def test_single_pass_is_selected_only_when_every_scale_is_one():
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
