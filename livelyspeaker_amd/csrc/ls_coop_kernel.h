@@ -23,9 +23,9 @@
 //   * SYNC2 never blocks: LayerNorm 2 is folded AROUND the channel-mixing product (as ls_long.hip does),
 //         LN2(x) W'^T + b' = rstd2 * ((x - mu1) W'^T - (mu2 - mu1) wsum) + b',      wsum[n] = sum_k W'[n][k],
 //     with the rows centred on the LayerNorm-1 mean every slice already holds (no cancellation: mu2 - mu1 is small), so the MFMAs
-//     need no statistic: a workgroup starts on its OWN 64 channels of k straight from registers, pulls the other slices' rows
-//     global -> LDS by LDS-DMA (no VGPR round trip) one slice ahead of the MFMAs as their ready flags come up, and applies
-//     (mu2, rstd2) -- long arrived by then -- in the epilogue.  The rows travel and sit in LDS as [slice][k block of 16][row][16]:
+//     need no statistic: a workgroup multiplies its OWN 64 channels of k while the other seven slices' rows -- requested all at once
+//     when their ready flags are up -- are pulled global -> LDS by LDS-DMA (no VGPR round trip), and applies (mu2, rstd2), merged
+//     while the pulls land, in the epilogue.  The rows travel and sit in LDS as [slice][k block of 16][row][16]:
 //     every MFMA B-operand read and every DMA chunk is one contiguous, conflict-free 1 KiB.
 //   * hand-off protocol (cdna_hip_programming.md section 6, Guideline 16, forms R1 / R2): payload = 16-byte write-through (sc1)
 //     stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, then the row statistics are published as 8-byte
