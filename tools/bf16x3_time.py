@@ -1,3 +1,4 @@
+"""Step time of the fused kernel in the opt-in bf16x3 mode (TED B = 512, BEAT B = 256; hipGraph replay); LS_LIB=<library.so> for an A/B."""
 import sys, os
 sys.path.insert(0, ".")
 from livelyspeaker_amd import _lib, synth

@@ -1,3 +1,4 @@
+"""ms per step of ls_trng_fill_steps (the native torch-RNG stream) at B = 512 by worker-thread count: python tools/rng_bench.py [library.so]"""
 import sys, time, ctypes, numpy as np, torch
 sys.path.insert(0, ".")
 from livelyspeaker_amd import _lib
