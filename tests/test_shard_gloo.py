@@ -256,3 +256,23 @@ def test_world2_process_groups_fall_back_to_gloo_when_rccl_does_not_come_up(want
         info, red, whole, be = res[r]
         assert info["collective_backend"] == "gloo" and info["rccl_ranks"] == 0 and info["rccl_error"] and be == "gloo", info
         assert red == [3.0] * 4 and whole == [0.0, 0.0, 1.0, 1.0]
+
+
+def test_world4_bring_up_and_gather_order():
+    """The same bring-up with four ranks (the driver's N = 4 / 8 runs are the first with more than two): every rank reaches the same
+    verdict, the reduction and the rank-ordered gather see all of them."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_groups_worker, args=(r, world, port, True, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+    for r in range(world):
+        assert not isinstance(res[r], Exception), res[r]
+        info, red, whole, be = res[r]
+        assert info["collective_backend"] == "gloo" and info["rccl_ranks"] == 0 and be == "gloo", info
+        assert red == [10.0] * 4 and whole == [float(k) for k in range(world) for _ in range(2)]
