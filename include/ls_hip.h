@@ -196,9 +196,9 @@ typedef struct ls_timing {
     int32_t single_pass;        /* 1 if the loop ran the single-pass (scale == 1) kernel */
     float tape_upload_ms;       /* segmented TAPE mode: summed GPU-side duration of the tape uploads of the last loop (copy stream) */
     int32_t n_segments;         /* segments the last loop ran in (1 = one call)     */
-    int32_t step_path;          /* kernels the last loop's steps ran on: 0 one workgroup per sample (fused), 1 batch-level, 2 sample-split */
+    int32_t step_path;          /* kernels the last loop's steps ran on: 0 one workgroup per sample (fused), 1 batch-level, 2 sample-split, 3 one workgroup per (sample, pass) */
     int32_t tail_samples;       /* fused path with a partial last round: samples of that round, run on ...        */
-    int32_t tail_path;          /* ... 1 the batch-level, 2 the sample-split kernels (0: none)                     */
+    int32_t tail_path;          /* ... 1 the batch-level, 2 the sample-split, 3 the one-pass-per-workgroup kernels (0: none) */
 } ls_timing;
 
 int ls_abi_version(void);
@@ -217,7 +217,9 @@ int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; def
  * workgroup (= one CU: a step costs one CU's time for eight layers however small the batch); the sample-split kernel spreads a
  * sample over 16 workgroups (2 CFG passes x 8 channel slices) that exchange LayerNorm partials and rows through L2 inside ONE launch
  * per step, and takes the small batches; 1: always one workgroup per sample; 2: the batch-level kernels of the long-sequence path
- * (21 launches per step; exact fp32, both CFG passes always evaluated); 3: always the sample-split kernel (exact fp32).  Same
+ * (21 launches per step; exact fp32, both CFG passes always evaluated); 3: always the sample-split kernel (exact fp32); 4: always the
+ * one-pass-per-workgroup kernel (a workgroup of 4 waves per (sample, CFG pass), two independent workgroups per CU, the passes combined by
+ * the later of the two: half-CU granularity, exact fp32).  Same
  * arithmetic every way, different summation order: results agree to ~1e-5, not bitwise.  Takes effect at the next ls_prepare;
  * ls_timing.step_path reports what ran. */
 int ls_set_path(ls_handle* h, int mode);

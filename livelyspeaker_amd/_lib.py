@@ -339,7 +339,7 @@ class Engine:
     (torch CUDA tensors on the same device may be passed to ``sample``/``prepare`` via ``*_device``)."""
 
     #: which kernels the steps of a 34-frame model run on when the caller does not say: "auto" (the sample-split kernel for small
-    #: batches, one workgroup per sample otherwise), "fused", "batch", "coop" (ls_set_path)
+    #: batches, one workgroup per sample or per (sample, pass) otherwise), "fused", "batch", "coop", "pass" (ls_set_path)
     default_path = "auto"
 
     def __init__(self, njoints, nfeats, n_prefix_tokens, audio_len, n_emotions=0, nframes=34, n_pre_seq=4,
@@ -389,9 +389,10 @@ class Engine:
 
     def set_path(self, mode):
         """'auto' (default: the sample-split kernel for small batches, one workgroup per sample otherwise), 'fused', 'batch'
-        (batch-level kernels, 21 launches per step), 'coop' (sample-split kernel); applies from the next prepare().  None = 'auto'."""
+        (batch-level kernels, 21 launches per step), 'coop' (sample-split kernel), 'pass' (one workgroup per (sample, CFG pass), two per
+        CU); applies from the next prepare().  None = 'auto'."""
         mode = "auto" if mode is None else mode
-        code = {"auto": 0, "fused": 1, "batch": 2, "coop": 3}.get(mode, mode)
+        code = {"auto": 0, "fused": 1, "batch": 2, "coop": 3, "pass": 4}.get(mode, mode)
         self._check(self.lib.ls_set_path(self.h, int(code)), "ls_set_path")
         self.path = mode
 

@@ -62,9 +62,13 @@ struct ls_handle {
     int T = kT;             // frames; 34 = the reference's (fused step kernel), anything else = the long-sequence path (ls_long.hip)
     bool fused = true;      // the model HAS the fused kernel (34 frames)
     bool use_long = false;  // the prepared batch runs the batch-level kernels (always when !fused; small batches of a fused model)
-    int path_mode = 0;      // ls_set_path: 0 auto, 1 one workgroup per sample (fused kernel), 2 batch-level kernels, 3 sample-split kernel
+    int path_mode = 0;      // ls_set_path: 0 auto, 1 one workgroup per sample (fused kernel), 2 batch-level kernels, 3 sample-split kernel, 4 one workgroup per (sample, pass)
+    bool use_pass = false;  // the prepared batch runs the one-pass-per-workgroup kernel (ls_pass_kernel.h: two independent workgroups per CU)
+    DevBuf pa_out, pa_cnt;  // its CFG hand-off: pass outputs [n][2][T][J*F], arrival tickets [n]
+    int pass_n = 0;         // samples the hand-off buffers hold
     bool use_coop = false;  // the prepared batch runs the sample-split kernel (ls_coop_kernel.h: 16 workgroups per sample)
-    // fused main path with a partial last round: the last tail_n samples run on the sample-split (tail_path 2) or batch-level (1) kernels
+    // fused main path with a partial last round: the last tail_n samples run on the sample-split (tail_path 2), batch-level (1) or
+    // one-pass-per-workgroup (3) kernels
     int tail_n = 0, tail_path = 0;
     bool plan_pair = false; // the plan assumed the single-pass form (every guidance scale 1)
     DevBuf wtok1_img;       // token-mix operand of one pass (sample-split kernel)
@@ -576,6 +580,14 @@ hipError_t run_coop(ls_handle* h, const StepArgs& s, int first, int n, bool pair
     return hipSuccess;
 }
 
+// the one-pass-per-workgroup kernel over samples [first, first + n): 2 (CFG) or 1 (single pass) workgroups per sample, one launch
+hipError_t run_pass(ls_handle* h, const StepArgs& s, int first, int n, bool pair, hipStream_t st) {
+    StepArgs c = s;
+    c.pf = h->pa_out.f(); c.pcnt = static_cast<unsigned*>(h->pa_cnt.p);
+    c.b0 = first; c.npass = pair ? 1 : 2;
+    return launch_step_pass(h->var, c, n, st);
+}
+
 // the batch-level kernels over samples [first, first + n): the same step from separate kernels over all rows (both passes always; exact fp32 only)
 hipError_t run_long(ls_handle* h, const StepArgs& s, int first, int n, hipStream_t st) {
     LongStepArgs a{};
@@ -601,14 +613,16 @@ hipError_t run_long(ls_handle* h, const StepArgs& s, int first, int n, hipStream
 hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
     s.batch = B;
     if (h->use_coop && !s.trace) return run_coop(h, s, 0, B, pair, st);
+    if (h->use_pass && !s.trace) return run_pass(h, s, 0, B, pair, st);
     // per-sample timestep rows exist in the fused and the sample-split kernel, the residual-stream trace in the fused kernel only
     if (!h->fused || (h->use_long && s.temb_stride == 0 && !s.trace)) return run_long(h, s, 0, B, st);
     // one workgroup per sample; a partial last round goes to the kernels that fill the chip with few samples
     int nf = B;
-    if (h->tail_n > 0 && h->tail_n < B && !s.trace && pair == h->plan_pair && (h->tail_path == 2 || s.temb_stride == 0)) nf = B - h->tail_n;
+    if (h->tail_n > 0 && h->tail_n < B && !s.trace && pair == h->plan_pair && (h->tail_path >= 2 || s.temb_stride == 0)) nf = B - h->tail_n;
     s.batch = nf;
     hipError_t e = launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, nf, st);
     if (e != hipSuccess || nf == B) return e;
+    if (h->tail_path == 3) return run_pass(h, s, nf, B - nf, pair, st);
     return h->tail_path == 2 ? run_coop(h, s, nf, B - nf, pair, st) : run_long(h, s, nf, B - nf, st);
 }
 
@@ -694,47 +708,60 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 // Which kernels the prepared batch runs on (34-frame models; other frame counts have only the batch-level kernels).
 //   fused         one workgroup = one CU per sample: a step costs one CU's time for eight layers however small the batch, and a batch
 //                 of 256 k + r samples pays k + 1 full rounds;
+//   pass          one workgroup per (sample, CFG pass), two per CU (ls_pass_kernel.h): half-CU units, 128 samples fill the chip;
 //   sample-split  16 workgroups per sample inside one launch (ls_coop_kernel.h), 32 samples per launch;
 //   batch-level   every row of the batch through 21 launches per step that fill the chip (ls_long.hip).
-// Step-time models in ms, measured on MI355X (profiles/r04_throughput_vs_batch.md): the plan is the cheapest of
-//   all sample-split | all batch-level | all fused | full fused rounds + the remainder on sample-split or batch-level.
-struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round; };
-constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f};
+// Step-time models in ms, measured on MI355X (profiles/r05_throughput_vs_batch.md): the plan is the cheapest of
+//   all sample-split | all batch-level | all fused | all pass | full fused rounds + the remainder on sample-split, batch-level or pass.
+struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single; };
+constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.70f, 0.40f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.81f, 0.46f};
 float coop_ms(const PathCost& c, int n, int np) {
     float ms = 0.f;
     for (int g = n * np; g > 0; g -= kCoopMaxGroups) ms += c.coop_base + c.coop_per_group * (g < kCoopMaxGroups ? g : kCoopMaxGroups);
     return ms;
 }
+// one-pass-per-workgroup kernel: 512 workgroups are resident (two per CU, pass_round each); up to 256 left over run one per CU
+float pass_ms(const PathCost& c, int n, int np) {
+    const int wgs = n * np, full = wgs / 512, rem = wgs % 512;
+    return c.pass_round * full + (rem == 0 ? 0.f : rem <= 256 ? c.pass_single : c.pass_round);
+}
 void decide_path(ls_handle* h) {
-    const bool before = h->use_long, before_c = h->use_coop;
+    const int before = (h->use_long ? 1 : 0) + (h->use_coop ? 2 : 0) + (h->use_pass ? 4 : 0);
     const int before_t = h->tail_n * 4 + h->tail_path;
-    h->use_coop = false; h->use_long = false; h->tail_n = 0; h->tail_path = 0;
+    h->use_coop = false; h->use_long = false; h->use_pass = false; h->tail_n = 0; h->tail_path = 0;
     const bool have_long = h->lw_wtp.p != nullptr;
     h->plan_pair = h->all_scale_one;
     if (!h->fused) h->use_long = true;
     else if (h->precision != 0 || h->path_mode == 1) {}
     else if (h->path_mode == 2) h->use_long = have_long;
     else if (h->path_mode == 3) h->use_coop = true;
+    else if (h->path_mode == 4) h->use_pass = true;
     else if (h->B > 0) {
         const PathCost& c = h->var == kTED ? kCostTed : kCostBeat;
         const int B = h->B, np = h->plan_pair ? 1 : 2, round = h->plan_pair ? 512 : 256;
         auto long_ms = [&](int n) { return have_long ? c.long_base + c.long_per_sample * n : 1e30f; };
-        const float all_coop = coop_ms(c, B, np), all_long = long_ms(B), all_fused = c.fused_round * ((B + round - 1) / round);
-        float best = all_fused;
-        int r = B % round;
-        if (B > round && r > 0) {       // full rounds + remainder
-            const float head = c.fused_round * (B / round), tc = head + coop_ms(c, r, np), tl = head + long_ms(r);
-            if (tc < best && tc <= tl) { best = tc; h->tail_n = r; h->tail_path = 2; }
-            else if (tl < best) { best = tl; h->tail_n = r; h->tail_path = 1; }
+        // whole batch on one kernel family: 0 fused, 1 batch-level, 2 sample-split, 3 pass (ties go to the earlier entry)
+        const float whole[4] = {c.fused_round * ((B + round - 1) / round), long_ms(B), coop_ms(c, B, np), pass_ms(c, B, np)};
+        int best_w = 0;
+        for (int k = 1; k < 4; ++k) if (whole[k] < whole[best_w]) best_w = k;
+        float best = whole[best_w];
+        const int r = B % round;
+        if (B > round && r > 0) {       // full fused rounds + remainder
+            const float head = c.fused_round * (B / round);
+            const float tail[4] = {1e30f, head + long_ms(r), head + coop_ms(c, r, np), head + pass_ms(c, r, np)};
+            int bt = 1;
+            for (int k = 2; k < 4; ++k) if (tail[k] < tail[bt]) bt = k;
+            if (tail[bt] < best) { best = tail[bt]; best_w = 0; h->tail_n = r; h->tail_path = bt; }
         }
-        if (all_coop < best && all_coop <= all_long) { h->use_coop = true; h->tail_n = 0; h->tail_path = 0; }
-        else if (all_long < best) { h->use_long = true; h->tail_n = 0; h->tail_path = 0; }
+        h->use_long = best_w == 1; h->use_coop = best_w == 2; h->use_pass = best_w == 3;
     }
-    if (before != h->use_long || before_c != h->use_coop || before_t != h->tail_n * 4 + h->tail_path) free_graph(h);
+    if (before != (h->use_long ? 1 : 0) + (h->use_coop ? 2 : 0) + (h->use_pass ? 4 : 0) || before_t != h->tail_n * 4 + h->tail_path) free_graph(h);
 }
 
 // zero the granule / flag words of the sample-split kernel (stream-ordered: a memset node when captured) and restart the epochs
 hipError_t coop_reset(ls_handle* h, hipStream_t st) {
+    if (h->use_pass || h->tail_path == 3)          // arrival tickets of the one-pass-per-workgroup kernel: two per step, counted within the call
+        if (hipError_t e = hipMemsetAsync(h->pa_cnt.p, 0, h->pa_cnt.bytes, st); e != hipSuccess) return e;
     if (!h->use_coop && h->tail_path != 2) return hipSuccess;
     hipError_t e = hipMemsetAsync(h->co_gran.p, 0, h->co_gran.bytes, st);
     if (e == hipSuccess) e = hipMemsetAsync(h->co_flag.p, 0, h->co_flag.bytes, st);
@@ -752,10 +779,10 @@ int coop_check(ls_handle* h) {
     HIPCHK(h, hipMemset(h->co_err.p, 0, sizeof v));
     return fail(h, LS_EHIP, "sample-split step kernel: an inter-workgroup hand-off timed out; the results of this call are invalid");
 }
-int step_path_code(const ls_handle* h) { return h->use_coop ? 2 : (h->use_long ? 1 : 0); }
+int step_path_code(const ls_handle* h) { return h->use_pass ? 3 : h->use_coop ? 2 : (h->use_long ? 1 : 0); }
 void report_path(ls_handle* h, bool pair) {
     h->timing.step_path = step_path_code(h);
-    const bool tail = h->tail_n > 0 && pair == h->plan_pair && !h->use_coop && !h->use_long;
+    const bool tail = h->tail_n > 0 && pair == h->plan_pair && !h->use_coop && !h->use_long && !h->use_pass;
     h->timing.tail_samples = tail ? h->tail_n : 0;
     h->timing.tail_path = tail ? h->tail_path : 0;
 }
@@ -962,6 +989,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
     if (h->fused) {         // sample-split kernel: LDS opt-in and one launch's worth of exchange workspaces (independent of the batch)
         e = init_coop_kernels();
+        if (e == hipSuccess) e = init_pass_kernels();
         if (e == hipSuccess) e = h->co_err.ensure(sizeof(unsigned));
         if (e == hipSuccess) e = hipMemsetAsync(h->co_err.p, 0, sizeof(unsigned), h->stream);
         if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "sample-split kernel setup: %s", hipGetErrorString(e)); }
@@ -993,7 +1021,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -1044,19 +1072,19 @@ int ls_set_precision(ls_handle* h, int mode) {
     if (mode != h->precision) free_graph(h);
     h->precision = mode;
     if (h->prepared) {      // the plan may move to kernels whose workspaces the last ls_prepare did not allocate: prepare again then
-        const bool wl = h->use_long, wc = h->use_coop;
+        const bool wl = h->use_long, wc = h->use_coop, wp = h->use_pass;
         const int wt = h->tail_n * 4 + h->tail_path;
         decide_path(h);
-        if ((h->use_long && !wl) || (h->use_coop && !wc) || (h->tail_n && wt != h->tail_n * 4 + h->tail_path)) h->prepared = false;
+        if ((h->use_long && !wl) || (h->use_coop && !wc) || (h->use_pass && !wp) || (h->tail_n && wt != h->tail_n * 4 + h->tail_path)) h->prepared = false;
     }
     return LS_OK;
 }
 
 int ls_set_path(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
-    if (mode < 0 || mode > 3) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel)", mode);
-    if (mode == 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no sample-split kernel", kT);
-    if (mode == 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split kernel is exact fp32 only");
+    if (mode < 0 || mode > 4) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel, 4 one workgroup per (sample, pass))", mode);
+    if (mode >= 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has neither the sample-split nor the one-pass-per-workgroup kernel", kT);
+    if (mode >= 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split and one-pass-per-workgroup kernels are exact fp32 only");
     if (mode == 2 && h->fused && h->lw_wtp.p == nullptr && h->committed) return fail(h, LS_EUNSUPPORTED, "batch-level kernels need S <= 160");
     if (mode == 1 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no fused kernel", kT);
     if (mode != h->path_mode) { h->path_mode = mode; h->prepared = false; free_graph(h); }      // takes effect at the next ls_prepare (workspaces)
@@ -1191,6 +1219,15 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         HIPCHK(h, h->co_flag.ensure((size_t)groups * 16 * sizeof(unsigned long long)));
         if (old[0] != h->co_x.p || old[1] != h->co_part.p || old[2] != h->co_gran.p || old[3] != h->co_flag.p) free_graph(h);
         h->coop_groups = groups;
+    }
+    if (h->use_pass || h->tail_path == 3) {      // CFG hand-off of the one-pass-per-workgroup kernel: each pass's output, one ticket word per sample
+        const int npa = h->use_pass ? B : h->tail_n;
+        const void* old[2] = {h->pa_out.p, h->pa_cnt.p};
+        HIPCHK(h, h->pa_out.ensure((size_t)npa * 2 * h->T * h->JF * sizeof(float)));
+        HIPCHK(h, h->pa_cnt.ensure((size_t)npa * sizeof(unsigned)));
+        HIPCHK(h, hipMemsetAsync(h->pa_cnt.p, 0, h->pa_cnt.bytes, st));
+        if (old[0] != h->pa_out.p || old[1] != h->pa_cnt.p) free_graph(h);
+        h->pass_n = npa;
     }
     if (h->use_long || h->tail_path == 1) {      // workspaces of the batch-level path: token sequences of both passes (two buffers), row partials, poseFinal output
         const size_t nlo = h->use_long ? B : h->tail_n;

@@ -101,6 +101,9 @@ struct StepArgs {
     int npass;               // 2: cond + uncond (CFG); 1: cond only (every guidance scale is 1)
     int ngroups;             // (sample, pass) groups of this launch
     int xmap;                // blockIdx -> (group, slice) mapping, see k_coop
+    // ---- one-pass-per-workgroup kernel (k_pass, ls_pass_kernel.h): b0 / npass as above, plus the CFG hand-off of ONE launch
+    float* pf;               // [samples][2 passes][T][J*F] poseFinal output of each pass (write-through)
+    unsigned* pcnt;          // [samples] arrival tickets: two per step, zeroed ahead of every call
 #ifdef LS_DEBUG
     // Profiling builds only (tools/phase_profile.py, tools/ab_variants.py compile their own -DLS_DEBUG variant of the library):
     // the shipped library has neither the fields nor the code that reads them, so no environment variable can change its results.
@@ -147,6 +150,10 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st);
 constexpr int kCoopMaxGroups = 64;     // (sample, pass) groups of one launch: 512 workgroups = two per CU, all resident at once
 hipError_t init_coop_kernels();
 hipError_t launch_step_coop(Variant v, const StepArgs& a, int nsamples, hipStream_t st);
+
+// one-pass-per-workgroup step kernel (ls_pass.hip): npass workgroups of 4 waves per sample, two workgroups per CU
+hipError_t init_pass_kernels();
+hipError_t launch_step_pass(Variant v, const StepArgs& a, int nsamples, hipStream_t st);
 
 // prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
 // pair: 0 = CFG (cond + uncond pass of one sample per workgroup), 1 = single pass (guidance scale 1: two samples per workgroup)

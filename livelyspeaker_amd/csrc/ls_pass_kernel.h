@@ -1,0 +1,639 @@
+// One-pass-per-workgroup diffusion step for gfx950 (MI355X): one launch = one p_sample / ddim_sample step, like k_step
+// (ls_step_kernel.h), but a workgroup holds ONE CFG pass of one sample -- S = 35 | 36 rows, 4 waves, ~78 KB of LDS -- so that two
+// INDEPENDENT workgroups share a CU.  What that buys over k_step's one-sample-per-CU mapping:
+//   * granularity: 128 clips fill the chip (k_step: 256), and a batch of 256 k + r clips pays for r in half-CU units;
+//   * the two workgroups of a CU are not phase-locked by a common barrier: one's LayerNorm / SiLU phases run beside the other's MFMAs.
+// Same reference arithmetic as k_step:
+//   ClassifierFreeSampleModel.forward   scripts/model/cfg_sampler.py:24-31   (two INDEPENDENT forwards: what makes the split legal)
+//   RAG.forward                         scripts/model/RAG.py:98-133
+//   TransMLP / MLPblock / LN_spatial    scripts/model/mlp_module.py:21-91
+//   OutputProcess                       scripts/model/RAG.py:205-211
+//   p_mean_variance / p_sample / ddim_sample   scripts/diffusion/gaussian_diffusion.py:284-399, 507-558, 745-798
+//
+// Mapping:
+//   * workgroup = (sample b, pass p), blockIdx = b * npass + p; 256 threads.  Wave w owns channels [128 w, 128 w + 128) of all rows in the
+//     MFMA C/D layout (lane & 15 = row of the tile, 4 (lane >> 4) + reg = channel of the 16-channel block): 8 blocks x 3 row tiles
+//     = 96 VGPRs of residual stream, resident for the whole forward.  Rows 32 .. S-1 (3 | 4 of the third tile's 16) are multiplied on the
+//     VALU (TED) or by v_mfma_f32_4x4x1 (BEAT) in channel mixing, exactly as k_step treats its ragged tile.
+//   * the weight images are k_step's (ls_api.cpp build_fused_images): this wave's 128 channels are the 64-channel slices 2 w and 2 w + 1 of
+//     the 8-wave kernel, so no second copy of the weights exists.
+//   * CFG combination: each pass writes its poseFinal output [T][J*F] write-through (sc1), every wave drains, barrier, one lane takes a
+//     ticket (relaxed agent-scope fetch_add on the sample's counter; zeroed by a memset node ahead of every call, two tickets per step).
+//     The workgroup that draws the odd ticket is the LAST of its sample: it reads the other pass's output with sc1 loads, combines the
+//     two in pass order (result independent of which one arrived last), and applies the sampler update.  Nobody waits for anybody:
+//     correct for any dispatch order, placement or residency (cdna_hip_programming.md section 6, Guideline 16, counter form).
+//     npass = 1 (every guidance scale is 1): no hand-off at all, the grid is one workgroup per sample.
+#pragma once
+#include "ls_step_common.h"
+#include "ls_lanes.h"
+
+namespace ls {
+
+constexpr int kPassThreads = 256;
+constexpr int kPassWaves = 4;
+constexpr int kPassCB = 8;                 // 16-channel blocks owned by one wave (4 waves * 8 * 16 = 512)
+constexpr int kPassNT = 3;                 // 16-row tiles of one pass (S = 35 | 36 -> 48)
+
+__host__ __device__ constexpr int pass_lds_floats(int S) {
+    // psum [4 waves][48 rows] (mean, M2) | U [S][520] | REM [4 waves][4 blocks][S - 32 rows][16]
+    return 2 * kPassWaves * 16 * kPassNT + S * kUStride + kPassWaves * 4 * (S - 32) * 16;
+}
+
+typedef unsigned pass_u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned* pass_gu32p;
+
+#ifndef LS_PASS_BPREF
+#define LS_PASS_BPREF 0                     // channel mixing: the LDS operands of k block q + 1 are requested while block q is multiplied
+#endif
+
+template <int S, int NPRE, int JF>
+__global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
+    constexpr int KXQ = (JF + 15) / 16;      // 16-wide k groups of the x_t part of input_mapping
+    constexpr int KXP = KXQ * 16;
+    constexpr int NOB = (JF + 15) / 16;      // 16-wide output blocks of poseFinal
+    constexpr int OSTR = NOB * 16 + 4;
+    constexpr int NT = kPassNT, CB = kPassCB, NW = kPassWaves;
+    constexpr int NREM = S - 32;             // rows of the ragged third tile: 3 (TED) | 4 (BEAT)
+    constexpr bool kRemMfma = (NREM % 4 == 0);
+    constexpr int NRG = kRemMfma ? NREM / 4 : 1;
+    constexpr int NRV = kRemMfma ? 1 : NREM;
+    constexpr int MK = (S + 3) / 4;          // k steps of the token-mix GEMM
+    constexpr int MQ = (MK + 3) / 4;         // ... in groups of four (one 16-byte weight fragment per lane)
+    constexpr int NU = NOB * NT;             // output-projection work units (wide outputs)
+    constexpr int MAXU = (NU + NW - 1) / NW;
+    static_assert(S > 32 && S <= 36, "one pass = two full row tiles + a ragged one of at most 4 rows");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* psum = smem;                          // [4][48] (mean, M2) pairs of the LayerNorm merge
+    float* U = smem + 2 * NW * 16 * NT;          // [S][520] fp32 operand
+    float* REM = U + S * kUStride;               // [4 waves][4][NREM][16] ragged-row patch
+
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = a.npass;
+    const int bid = blockIdx.x;
+    const int p = np == 2 ? (bid & 1) : 0;
+    const int bl = np == 2 ? (bid >> 1) : bid;      // launch-local sample
+    const int b = a.b0 + bl;                        // sample of the prepared batch
+    const bool unc = p == 1;
+    int s16 = lane & 15;
+    int g = lane >> 4;
+    int chw = 128 * w + 4 * g;                      // + 16 cb + j = this lane's channels
+    // see k_step: laundering the lane id at phase boundaries keeps per-lane addresses phase-local, so the residual stream stays in registers
+    auto fresh = [&]() {
+        asm volatile("" : "+v"(lane));
+        s16 = lane & 15;
+        g = lane >> 4;
+        chw = 128 * w + 4 * g;
+    };
+    auto row_of = [&](int t) { return 16 * t + s16; };
+    auto valid_of = [&](int t) { return t < 2 ? true : (s16 < NREM); };
+    auto rowc_of = [&](int t) { return t < 2 ? 16 * t + s16 : min(32 + s16, S - 1); };
+
+    f4 X[CB][NT];
+
+    auto stamp = [&](int idx) {
+#ifdef LS_DEBUG
+        if (a.prof && bid == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
+        if (a.wgt && tid == 0 && (idx == 0 || idx == 4 + 8 * a.layers)) a.wgt[2 * bid + (idx ? 1 : 0)] = __builtin_amdgcn_s_memtime();
+#else
+        (void)idx;
+#endif
+    };
+    stamp(0);
+
+    // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
+    {
+        const unsigned long long goff = a.call ? a.call->sample_offset : 0ull;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tk = rowc_of(t);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int ch = chw + 16 * cb;
+                f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+                if (valid_of(t)) {
+                    if (tk >= NPRE) {
+                        v = *reinterpret_cast<const f4*>((unc ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + ch);
+                    } else if (tk == 0) {
+                        // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
+                        const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + ch);
+                        const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + ch);
+                        f4 e;
+                        const float* ep = unc ? a.eps_u : a.eps_c;
+                        if (ep) {
+                            e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + ch);
+                        } else {
+                            float z[4];            // this lane's 4 consecutive channels = one Philox block
+                            philox_normal4(a.call, goff + (unsigned long long)b, a.step_id, unc ? 2u : 1u, (unsigned)(ch >> 2), z);
+                            e = (f4){z[0], z[1], z[2], z[3]};
+                        }
+                        v = mu + e * sd;
+                    } else {
+                        v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);      // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
+                    }
+                }
+                X[cb][t] = v;
+            }
+        }
+        // x_t of this sample -> LDS [S][KXP] (zero for prefix tokens and pad columns): loads first, then the writes, in blocks
+        constexpr int NIT = (S * KXP + kPassThreads - 1) / kPassThreads;
+        constexpr int CH = 14;
+#pragma unroll
+        for (int it0 = 0; it0 < NIT; it0 += CH) {
+            float xv[CH];
+#pragma unroll
+            for (int itl = 0; itl < CH; ++itl) {
+                if (it0 + itl >= NIT) break;
+                const int idx = min(tid + kPassThreads * (it0 + itl), S * KXP - 1);
+                const int r = idx / KXP, k = idx - r * KXP;
+                const bool live = r >= NPRE && k < JF;
+                xv[itl] = a.x_in[(size_t)b * kT * JF + (live ? (r - NPRE) * JF + k : 0)];
+                if (!live) xv[itl] = 0.f;
+            }
+#pragma unroll
+            for (int itl = 0; itl < CH; ++itl) {
+                if (it0 + itl >= NIT) break;
+                const int idx = tid + kPassThreads * (it0 + itl);
+                if (idx < S * KXP) {
+                    const int r = idx / KXP;
+                    U[r * kUStride + (idx - r * KXP)] = xv[itl];
+                }
+            }
+        }
+        __syncthreads();
+        fresh();
+        // winx_img[8][2][KXQ][2][64][4]: 16-channel block 8 w + cb = (8-wave slice 2 w + (cb >> 2), pass (cb >> 1) & 1, c2 = cb & 1)
+        const wrsrc_t wrs = wrsrc(a.W->winx_img);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {                // two channel blocks at a time: 6 accumulators
+            f4 acc[2][NT];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[c2][t] = X[2 * pp + c2][t];
+            const int wsb = ((2 * w + (pp >> 1)) * 2 + (pp & 1)) * KXQ * 2 * 1024;
+            f4 An[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + c2 * 1024);
+#pragma unroll 2
+            for (int q = 0; q < KXQ; ++q) {
+                f4 A[2], Bv[NT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[c2] = An[c2];
+                const int qn = q + 1 < KXQ ? q + 1 : KXQ - 1;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + (qn * 2 + c2) * 1024);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[rowc_of(t) * kUStride + 16 * q + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[c2][t] = MFMA(A[c2][j], Bv[t][j], acc[c2][t]);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) X[2 * pp + c2][t] = valid_of(t) ? acc[c2][t] : (f4){0.f, 0.f, 0.f, 0.f};   // pad rows stay zero
+        }
+    }
+    stamp(1);
+
+    // LN_spatial statistics over the 512 channels of each row (mlp_module.py:29-33): two passes over the lane's 32 channels, then Chan's
+    // parallel-variance merge over the 4 lane groups (two cross-lane exchanges) and the 4 waves (LDS) -- one workgroup barrier per LayerNorm.
+    float mean[NT], rstd[NT];
+    auto ln_stats = [&]() {
+        f2* pst = reinterpret_cast<f2*>(psum);            // [4 waves][48 rows] (mean, M2) of 128 channels
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f4 sv = X[0][t];
+#pragma unroll
+            for (int cb = 1; cb < CB; ++cb) sv += X[cb][t];
+            const float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+            float m = s * (1.0f / 32.0f);
+            const f4 mv = (f4){m, m, m, m};
+            f4 qv = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const f4 d = X[cb][t] - mv;
+                qv = __builtin_elementwise_fma(d, d, qv);
+            }
+            float m2 = (qv[0] + qv[1]) + (qv[2] + qv[3]);
+            {   // the lane group 16 lanes away (32 + 32 values), then 32 lanes away (64 + 64)
+                float ma, mb, qa, qb;
+                xor16_pair(m, ma, mb);
+                xor16_pair(m2, qa, qb);
+                const float d = mb - ma;
+                m2 = (qa + qb) + d * d * 16.0f;
+                m = 0.5f * (ma + mb);
+            }
+            {
+                float ma, mb, qa, qb;
+                xor32_pair(m, ma, mb);
+                xor32_pair(m2, qa, qb);
+                const float d = mb - ma;
+                m2 = (qa + qb) + d * d * 32.0f;
+                m = 0.5f * (ma + mb);
+            }
+            if (g == 0) pst[w * 48 + 16 * t + s16] = (f2){m, m2};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f2 pw[NW];
+            f2 acc2 = (f2){0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                pw[ww] = pst[ww * 48 + 16 * t + s16];
+                acc2 += pw[ww];
+            }
+            const float mt = acc2.x * (1.0f / NW);
+            float dd = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
+            mean[t] = mt;
+            rstd[t] = rsqrtf((acc2.y + 128.0f * dd) * (1.0f / kD) + 1e-5f);
+        }
+    };
+    // the normalised operand of this lane's channels -> LDS [row][520]; LN1 applies alpha / beta here, LN2's are folded into the
+    // channel-mix weights on the host (W' = W diag(alpha), b' = b + W beta)
+    auto ln_store = [&](auto affine, const f4 (&alv)[CB], const f4 (&bev)[CB]) {
+        constexpr bool alpha = decltype(affine)::value;
+        float nmr[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) nmr[t] = -mean[t] * rstd[t];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (valid_of(t)) {
+                    const f4 rs = (f4){rstd[t], rstd[t], rstd[t], rstd[t]}, nm = (f4){nmr[t], nmr[t], nmr[t], nmr[t]};
+                    f4 u = __builtin_elementwise_fma(X[cb][t], rs, nm);
+                    if (alpha) u = __builtin_elementwise_fma(u, alv[cb], bev[cb]);
+                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                }
+    };
+
+    // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
+    for (int l = 0; l < a.layers; ++l) {
+        fresh();
+        {   // x = x + emb  (re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
+            const float* te = a.temb + (size_t)b * a.temb_stride + chw;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const f4 e = *reinterpret_cast<const f4*>(te + 16 * cb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (valid_of(t)) X[cb][t] += e;
+            }
+        }
+        // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
+        f4 alv[CB], bev[CB];                        // LN1 affine: in flight during the statistics and their barrier
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            alv[cb] = wload4(wrsrc(a.W->ln1a), chw * 4, (l * kD + 16 * cb) * 4);
+            bev[cb] = wload4(wrsrc(a.W->ln1b), chw * 4, (l * kD + 16 * cb) * 4);
+        }
+        ln_stats();
+        stamp(2 + 8 * l);
+        fresh();
+        ln_store(std::true_type{}, alv, bev);
+        // no workgroup barrier: token mixing contracts over ROWS, wave w reads back only the 128 channel columns it has just written
+        __builtin_amdgcn_wave_barrier();
+        stamp(3 + 8 * l);
+        fresh();
+        {
+            // out[ch][r] = sum_r' u[r'][ch] * Wt[r][r'] + bt[r] as D[channel][row]: A = u^T from LDS, B = the Conv1d weights (one pass:
+            // wtok1_img[l][t][mq][lane][j] = Wt[16 t + (lane & 15)][4 (4 mq + j) + (lane >> 4)]).  Channel block by channel block: the
+            // block's MK source values are read once and meet the three row tiles (three independent accumulators).
+            const wrsrc_t wrs = wrsrc(a.W->wtok1_img);
+            const int wsb = l * NT * MQ * 1024;
+            f4 Bt[NT][MQ];
+            float bt[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int m = 0; m < MQ; ++m) Bt[t][m] = wload4(wrs, lane * 16, wsb + (t * MQ + m) * 1024);
+                bt[t] = g1(a.W->btok_rows)[l * 80 + rowc_of(t)];
+            }
+            typedef const __attribute__((address_space(3))) float* ldsp;
+            ldsp up[MK];
+#pragma unroll
+            for (int m = 0; m < MK; ++m) up[m] = (ldsp)(U + min(4 * m + g, S - 1) * kUStride + 128 * w + s16);   // clamped rows meet zero weights
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                float av[MK];
+#pragma unroll
+                for (int m = 0; m < MK; ++m) av[m] = up[m][16 * cb];
+                f4 acc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = (f4){bt[t], bt[t], bt[t], bt[t]};
+#pragma unroll
+                for (int m = 0; m < MK; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = MFMA(av[m], Bt[t][m >> 2][m & 3], acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (valid_of(t)) X[cb][t] = silu_acc4(acc[t], X[cb][t]);
+            }
+        }
+        stamp(4 + 8 * l);
+        fresh();
+        // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
+        ln_stats();            // its barrier also orders every wave's token-mix reads before the stores below
+        stamp(5 + 8 * l);
+        ln_store(std::false_type{}, alv, bev);
+        __syncthreads();
+        stamp(6 + 8 * l);
+        // Rows 32 .. S-1 on the VALU (TED) / v_mfma_f32_4x4x1 (BEAT) from the same A-operand registers, as in k_step.
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                 // 4 channel blocks x 2 full tiles = 8 accumulators per half
+            fresh();
+            f4 acc[4][2];
+            float racc[4][NRV];
+            f4 racc4[4][NRG];
+            f4 bcv[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f4 bc = wload4(wrsrc(a.W->bch), chw * 4, (l * kD + 16 * (4 * pp + c4)) * 4);
+                bcv[c4] = bc;
+                acc[c4][0] = bc; acc[c4][1] = bc;
+#pragma unroll
+                for (int r = 0; r < NRV; ++r) racc[c4][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < NRG; ++r) racc4[c4][r] = (f4){0.f, 0.f, 0.f, 0.f};
+            }
+            // wch_img[L][8][2][32 q][2][64][4]: block 8 w + 4 pp + c4 = (8-wave slice 2 w + pp, pass c4 >> 1, c2 = c4 & 1)
+            const wrsrc_t wrs = wrsrc(a.W->wch_img);
+            const int wsb = ((l * 8 + 2 * w + pp) * 2 * 32) * 2 * 1024;
+            auto woff = [&](int q, int c4) { return wsb + ((((c4 >> 1) * 32 + q) * 2) + (c4 & 1)) * 1024; };
+            typedef const __attribute__((address_space(3))) float* ldsp;
+            typedef const __attribute__((address_space(3))) f4* ldsp4;
+            ldsp ub0 = (ldsp)(U + s16 * kUStride + 4 * g);                 // tile t: + 16 t rows
+            ldsp ur = (ldsp)(U + (32 + (kRemMfma ? (lane & 3) : 0)) * kUStride + 4 * g);
+            asm volatile("" : "+v"(ub0), "+v"(ur));
+            f4 An[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) An[c4] = wload4(wrs, lane * 16, woff(0, c4));
+            f4 Bn[2], Un[kRemMfma ? NRG : NRV];
+            auto ldb = [&](int q) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) Bn[t] = *(ldsp4)(ub0 + 16 * t * kUStride + 16 * q);
+#pragma unroll
+                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r) Un[r] = *(ldsp4)(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
+            };
+            if (LS_PASS_BPREF) ldb(0);
+#pragma unroll 2
+            for (int q = 0; q < 32; ++q) {
+                f4 A[4], Bv[2], Ur[kRemMfma ? NRG : NRV];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) A[c4] = An[c4];
+                {
+                    const int qn = (q + 1 < 32) ? q + 1 : 31;       // branch-free prefetch (the last one re-reads q = 31)
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) An[c4] = wload4(wrs, lane * 16, woff(qn, c4));
+                }
+                if (!LS_PASS_BPREF) ldb(q);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) Bv[t] = Bn[t];
+#pragma unroll
+                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r) Ur[r] = Un[r];
+                // per k: [8 MFMAs][4 * NREM scalar FMAs], order pinned (k_step: the compiler's own order stalls on the FMAs' ds_reads)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) acc[c4][t] = MFMA(A[c4][j], Bv[t][j], acc[c4][t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (LS_PASS_BPREF && j == 0) ldb((q + 1 < 32) ? q + 1 : 31);
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        if constexpr (kRemMfma) {
+#pragma unroll
+                            for (int r = 0; r < NRG; ++r)
+                                racc4[c4][r] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[c4][j], Ur[r][j], racc4[c4][r], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NRV; ++r) racc[c4][r] = fmaf(A[c4][j], Ur[r][j], racc[c4][r]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fresh();
+            // ragged rows: sum the 4 k subsets of the lane groups, then [channel-lane][row] -> [row-lane][channel-reg] through a per-wave patch
+            float* rem = REM + w * (4 * NREM * 16);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                if constexpr (kRemMfma) {
+#pragma unroll
+                    for (int r = 0; r < NRG; ++r) {
+                        f4 v = racc4[c4][r];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = xor32_sum(xor16_sum(v[i]));
+                        // lane (block = lane >> 2, row = lane & 3) holds channels 4 (s16 >> 2) .. + 3 of row 4 r + (lane & 3)
+                        if (g == 0) *reinterpret_cast<f4*>(&rem[(c4 * NREM + 4 * r + (lane & 3)) * 16 + 4 * (s16 >> 2)]) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NRV; ++r) {
+                        const float v = xor32_sum(xor16_sum(racc[c4][r]));
+                        if (g == 0) rem[(c4 * NREM + r) * 16 + s16] = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int cb = 4 * pp + c4;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) X[cb][t] = silu_acc4(acc[c4][t], X[cb][t]);
+                if (s16 < NREM) {
+                    const f4 rv = *reinterpret_cast<const f4*>(&rem[(c4 * NREM + s16) * 16 + 4 * g]);
+                    X[cb][2] = silu_acc4(rv + bcv[c4], X[cb][2]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (pp == 0) stamp(7 + 8 * l);
+        }
+        stamp(9 + 8 * l);
+    }
+
+    // ================= OutputProcess.poseFinal (RAG.py:205-211) ====================================
+    stamp(2 + 8 * a.layers);
+    fresh();
+    __syncthreads();                       // every wave is done reading the last LN2 operand: U is free
+    constexpr bool kOutFromRegs = (NOB <= 2);
+    constexpr int OROWS = kOutFromRegs ? NW * S : S;
+    static_assert(OROWS * OSTR <= S * kUStride, "OUT overlay must fit the operand buffer");
+    float* OUT = U;
+    if constexpr (kOutFromRegs) {
+        // Narrow output (TED): every wave contracts over ITS OWN 128 channels straight from the residual registers (a valid MFMA B
+        // operand; wout_reg_img carries the matching k permutation), writes a [S][32] partial; the 4 partials are summed below.
+        f4 acc[NOB][NT];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[ob][t] = (f4){0.f, 0.f, 0.f, 0.f};
+        const wrsrc_t wrs = wrsrc(a.W->wout_reg_img);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                // wout_reg_img[8][NOB][4][64][4]: 8-wave slice 2 w + (cb >> 2), block cb & 3
+                const f4 A = wload4(wrs, lane * 16, (((2 * w + (cb >> 2)) * NOB + ob) * 4 + (cb & 3)) * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[ob][t] = MFMA(A[j], X[cb][t][j], acc[ob][t]);
+            }
+        stamp(3 + 8 * a.layers);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (valid_of(t)) *reinterpret_cast<f4*>(&OUT[(w * S + row_of(t)) * OSTR + 16 * ob + 4 * g]) = acc[ob][t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (valid_of(t))
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = X[cb][t];
+        __syncthreads();
+        f4 res[MAXU];
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = w + NW * i;          // wave-uniform
+            res[i] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (u < NU) {
+                const int ob = u / NT, t = u - ob * NT;
+                const int rc = min(16 * t + s16, S - 1);
+                const wrsrc_t wrs = wrsrc(a.W->wout_img);
+                const int wsb = ob * 32 * 1024;
+                const float* up = &U[rc * kUStride + 4 * g];
+                f4 a0 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                constexpr int QB = 8;              // weight fragments in flight ahead of their use
+                f4 An[QB];
+#pragma unroll
+                for (int k = 0; k < QB; ++k) An[k] = wload4(wrs, lane * 16, wsb + k * 1024);
+#pragma unroll 1
+                for (int q0 = 0; q0 < 32; q0 += QB) {
+                    f4 A[QB];
+#pragma unroll
+                    for (int k = 0; k < QB; ++k) A[k] = An[k];
+                    const int qn = q0 + QB < 32 ? q0 + QB : q0;
+#pragma unroll
+                    for (int k = 0; k < QB; ++k) An[k] = wload4(wrs, lane * 16, wsb + (qn + k) * 1024);
+#pragma unroll
+                    for (int k = 0; k < QB; ++k) {
+                        const f4 Bv = *reinterpret_cast<const f4*>(up + 16 * (q0 + k));
+                        a0 = MFMA(A[k][0], Bv[0], a0);
+                        a1 = MFMA(A[k][1], Bv[1], a1);
+                        a0 = MFMA(A[k][2], Bv[2], a0);
+                        a1 = MFMA(A[k][3], Bv[3], a1);
+                    }
+                }
+                res[i] = a0 + a1;
+            }
+        }
+        stamp(3 + 8 * a.layers);
+        fresh();
+        __syncthreads();                       // operand buffer is free: overlay OUT[row][c]
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = w + NW * i;
+            if (u < NU) {
+                const int ob = u / NT, t = u - ob * NT;
+                const int r = 16 * t + s16;
+                if (r < S) *reinterpret_cast<f4*>(&OUT[r * OSTR + 16 * ob + 4 * g]) = res[i];
+            }
+        }
+    }
+    __syncthreads();
+    auto out_at = [&](int r, int c) {
+        if constexpr (kOutFromRegs) {
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) v += OUT[(ww * S + r) * OSTR + c];
+            return v;
+        } else {
+            return OUT[r * OSTR + c];
+        }
+    };
+
+    // ====== hand-off of the pass output, CFG lerp (cfg_sampler.py:31), posterior / DDIM update (gaussian_diffusion.py:260-282,
+    //        507-558, 745-798), written back in the internal [B][T][JF] layout ======================
+    const float* other = nullptr;
+    if (np == 2) {
+        float* mine = a.pf + ((size_t)bl * 2 + p) * (kT * JF);
+        const wrsrc_t prs = uniform_rsrc(mine);
+        for (int idx = tid; idx < kT * JF; idx += kPassThreads) {
+            const int f = idx / JF, c = idx - f * JF;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out_at(NPRE + f, c)), prs, idx * 4, 0, 16);     // sc1: write-through
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains
+        __syncthreads();
+        unsigned* flagw = reinterpret_cast<unsigned*>(psum);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add((pass_gu32p)(a.pcnt + bl), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flagw[0] = old & 1u;                              // odd ticket: the other pass of this step is already out
+        }
+        __syncthreads();
+        if (!flagw[0]) return;                                // first of the sample: done
+        other = a.pf + ((size_t)bl * 2 + (1 - p)) * (kT * JF);
+    }
+    stamp(3 + 8 * a.layers + 1);
+    {
+        const float sc = (np == 2 && a.scale) ? a.scale[b] : 1.0f;
+        const unsigned long long gidx = (a.call ? a.call->sample_offset : 0ull) + (unsigned long long)b;
+        const size_t base = (size_t)b * kT * JF;
+        const wrsrc_t ors = uniform_rsrc(np == 2 ? other : a.x_in);
+        for (int idx = tid; idx < kT * JF; idx += kPassThreads) {
+            const int f = idx / JF, c = idx - f * JF;
+            const float bo = g1(a.W->bout)[c];
+            const float own = out_at(NPRE + f, c);
+            float x0;
+            if (np == 2) {
+                const float oth = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ors, idx * 4, 0, 16));   // sc1: never this CU's L1
+                const float oc = (unc ? oth : own) + bo, ou = (unc ? own : oth) + bo;
+                if (a.fwd_c) a.fwd_c[base + idx] = oc;
+                if (a.fwd_u) a.fwd_u[base + idx] = ou;
+                x0 = ou + sc * (oc - ou);
+            } else {
+                x0 = own + bo;                                // scale == 1: the CFG combination is the cond output
+            }
+            if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (a.x0_out) a.x0_out[base + idx] = x0;
+            if (a.sampler != kNone) {
+                const float xt = a.x_in[base + idx];
+                float nz = 0.f;
+                if (a.t_nonzero) {
+                    if (a.noise) {
+                        const size_t bn = a.const_noise ? 0 : (size_t)b;
+                        nz = a.noise[(bn * JF + c) * kT + f];
+                    } else {
+                        nz = philox_normal(a.call, gidx, a.step_id, 3u, (unsigned)(c * kT + f));
+                    }
+                }
+                float xn;
+                if (a.sampler == kDDPM) {
+                    xn = a.c0 * x0 + a.c1 * xt;
+                    if (a.t_nonzero) xn += a.c2 * nz;
+                } else {
+                    const float eps = (a.c0 * xt - x0) / a.c1;
+                    xn = x0 * a.c2 + a.c3 * eps;
+                    if (a.t_nonzero) xn += a.c4 * nz;
+                }
+                a.x_out[base + idx] = xn;
+            }
+        }
+    }
+    stamp(4 + 8 * a.layers);
+}
+
+}  // namespace ls
