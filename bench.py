@@ -456,7 +456,8 @@ def other_config_leg(dataset, B, dev, fence, steps=1000):
     names = {0: "fused step kernel (one workgroup per clip)", 1: "batch-level kernels (ls_long.hip, 21 launches per step)",
              2: "sample-split step kernel (ls_coop_kernel.h: 16 workgroups per clip, one launch per step)",
              3: "one-pass-per-workgroup step kernel (ls_pass_kernel.h: a workgroup per (clip, CFG pass), two per CU)"}
-    kernels = names[tm["step_path"]] + (f" + the last {tm['tail_samples']} clips on the {names[tm['tail_path']].split(' (')[0]}" if tm["tail_samples"] else "")
+    kernels = names[tm["step_path"]] + (f" + {tm['tail_samples']} clips on the {names[tm['tail_path']].split(' (')[0]}" if tm["tail_samples"] else "") \
+        + (f" + {tm['tail2_samples']} clips on the {names[tm['tail2_path']].split(' (')[0]}" if tm["tail2_samples"] else "")
     model.engine().close()
     return {"workload": f"{dataset.upper()} RAG, batch {B} x {cfg.nframes} frames, {steps}-step DDPM, CFG 1.5, Philox noise"
                         + (" -- SYNTHETIC shape (150 frames: the reference cannot run it), perf-only, no parity claim vs the reference"

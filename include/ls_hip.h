@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LS_ABI_VERSION 3
+#define LS_ABI_VERSION 4
 
 enum {
     LS_OK = 0,
@@ -197,8 +197,10 @@ typedef struct ls_timing {
     float tape_upload_ms;       /* segmented TAPE mode: summed GPU-side duration of the tape uploads of the last loop (copy stream) */
     int32_t n_segments;         /* segments the last loop ran in (1 = one call)     */
     int32_t step_path;          /* kernels the last loop's steps ran on: 0 one workgroup per sample (fused), 1 batch-level, 2 sample-split, 3 one workgroup per (sample, pass) */
-    int32_t tail_samples;       /* fused path with a partial last round: samples of that round, run on ...        */
+    int32_t tail_samples;       /* a batch the plan splits (e.g. full fused rounds + a partial one): samples of the second piece, run on ... */
     int32_t tail_path;          /* ... 1 the batch-level, 2 the sample-split, 3 the one-pass-per-workgroup kernels (0: none) */
+    int32_t tail2_samples;      /* third piece of the plan (e.g. 416 clips = 256 fused + 128 one-pass-per-workgroup + 32 sample-split) */
+    int32_t tail2_path;
 } ls_timing;
 
 int ls_abi_version(void);

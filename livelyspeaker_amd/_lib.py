@@ -79,7 +79,7 @@ class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32), ("single_pass", C.c_int32),
                 ("tape_upload_ms", C.c_float), ("n_segments", C.c_int32), ("step_path", C.c_int32),
-                ("tail_samples", C.c_int32), ("tail_path", C.c_int32)]
+                ("tail_samples", C.c_int32), ("tail_path", C.c_int32), ("tail2_samples", C.c_int32), ("tail2_path", C.c_int32)]
 
 
 class LsTrainConfig(C.Structure):
@@ -225,7 +225,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_eval_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     lib.ls_eval_commit_weights.argtypes = [C.c_void_p]
     lib.ls_eval_features.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    if lib.ls_abi_version() != 3:
+    if lib.ls_abi_version() != 4:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -55,6 +55,10 @@ float bf16_to_f32(unsigned short h) {
 
 }  // namespace
 
+// one piece of a step plan: samples [first, first + n) of the prepared batch on one kernel family
+// (0 fused: one workgroup per sample, 1 batch-level kernels, 2 sample-split kernel, 3 one workgroup per (sample, pass))
+struct Seg { int path, first, n; };
+
 struct ls_handle {
     ls_config cfg{};
     Variant var = kTED;
@@ -67,9 +71,11 @@ struct ls_handle {
     DevBuf pa_out, pa_cnt;  // its CFG hand-off: pass outputs [n][2][T][J*F], arrival tickets [n]
     int pass_n = 0;         // samples the hand-off buffers hold
     bool use_coop = false;  // the prepared batch runs the sample-split kernel (ls_coop_kernel.h: 16 workgroups per sample)
-    // fused main path with a partial last round: the last tail_n samples run on the sample-split (tail_path 2), batch-level (1) or
-    // one-pass-per-workgroup (3) kernels
-    int tail_n = 0, tail_path = 0;
+    // the step plan of the prepared batch (decide_path): up to three pieces, e.g. 416 clips = 256 on the fused kernel + 128 on the
+    // one-pass-per-workgroup kernel (one workgroup per CU) + 32 on the sample-split kernel.  use_long / use_coop / use_pass: the whole batch
+    // is on that family (one piece).
+    int nseg = 1;
+    Seg seg[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     bool plan_pair = false; // the plan assumed the single-pass form (every guidance scale 1)
     DevBuf wtok1_img;       // token-mix operand of one pass (sample-split kernel)
     DevBuf co_x, co_part, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
@@ -607,23 +613,46 @@ hipError_t run_long(ls_handle* h, const StepArgs& s, int first, int n, hipStream
     return launch_step_long(a, st);
 }
 
+// samples of the plan's piece on kernel family `path` (0 if the plan has none)
+int seg_n(const ls_handle* h, int path) {
+    for (int i = 0; i < h->nseg; ++i) if (h->seg[i].path == path) return h->seg[i].n;
+    return 0;
+}
+// everything that identifies the plan (graph key, "did the plan change")
+long long plan_code(const ls_handle* h) {
+    long long c = h->nseg;
+    for (int i = 0; i < h->nseg; ++i) c = c * 8209 + h->seg[i].path + 4 * (long long)h->seg[i].n;
+    return c;
+}
+
 // One diffusion step of the prepared batch on the kernels decide_path chose.
 // precision 0: exact fp32 (k_step<..,0>); 1: bf16x3 inside the same one-workgroup-per-sample kernel (k_step<..,1>)
 // pair: the single-pass variant (two samples' cond pass per workgroup), legal when every guidance scale is 1
+bool plan_applies(const ls_handle* h, const StepArgs& s, bool pair) {
+    if (!h->fused) return true;                                        // batch-level kernels only
+    if (s.trace) return false;                                         // the residual-stream trace exists in the fused kernel only
+    if (h->nseg > 1 && pair != h->plan_pair) return false;             // a split plan was costed for the other form
+    for (int i = 0; i < h->nseg; ++i)
+        if (h->seg[i].path == 1 && s.temb_stride != 0) return false;   // per-sample timestep rows: every kernel but the batch-level ones
+    return true;
+}
 hipError_t run_step(ls_handle* h, StepArgs& s, int B, bool pair, hipStream_t st) {
     s.batch = B;
-    if (h->use_coop && !s.trace) return run_coop(h, s, 0, B, pair, st);
-    if (h->use_pass && !s.trace) return run_pass(h, s, 0, B, pair, st);
-    // per-sample timestep rows exist in the fused and the sample-split kernel, the residual-stream trace in the fused kernel only
-    if (!h->fused || (h->use_long && s.temb_stride == 0 && !s.trace)) return run_long(h, s, 0, B, st);
-    // one workgroup per sample; a partial last round goes to the kernels that fill the chip with few samples
-    int nf = B;
-    if (h->tail_n > 0 && h->tail_n < B && !s.trace && pair == h->plan_pair && (h->tail_path >= 2 || s.temb_stride == 0)) nf = B - h->tail_n;
-    s.batch = nf;
-    hipError_t e = launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, nf, st);
-    if (e != hipSuccess || nf == B) return e;
-    if (h->tail_path == 3) return run_pass(h, s, nf, B - nf, pair, st);
-    return h->tail_path == 2 ? run_coop(h, s, nf, B - nf, pair, st) : run_long(h, s, nf, B - nf, st);
+    if (!h->fused) return run_long(h, s, 0, B, st);
+    if (!plan_applies(h, s, pair)) return launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, B, st);
+    for (int i = 0; i < h->nseg; ++i) {
+        const Seg& g = h->seg[i];
+        const int n = h->nseg == 1 ? B : g.n;
+        hipError_t e;
+        switch (g.path) {
+        case 0: s.batch = n; e = g.first == 0 ? launch_step(h->var, h->precision == 1 ? 1 : 0, pair ? 1 : 0, s, n, st) : hipErrorInvalidValue; s.batch = B; break;
+        case 1: e = run_long(h, s, g.first, n, st); break;
+        case 2: e = run_coop(h, s, g.first, n, pair, st); break;
+        default: e = run_pass(h, s, g.first, n, pair, st); break;
+        }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 void fill_common(ls_handle* h, StepArgs& a) {
@@ -714,7 +743,7 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 // Step-time models in ms, measured on MI355X (profiles/r05_throughput_vs_batch.md): the plan is the cheapest of
 //   all sample-split | all batch-level | all fused | all pass | full fused rounds + the remainder on sample-split, batch-level or pass.
 struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single; };
-constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.70f, 0.40f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.81f, 0.46f};
+constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.70f, 0.423f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.842f, 0.503f};
 float coop_ms(const PathCost& c, int n, int np) {
     float ms = 0.f;
     for (int g = n * np; g > 0; g -= kCoopMaxGroups) ms += c.coop_base + c.coop_per_group * (g < kCoopMaxGroups ? g : kCoopMaxGroups);
@@ -726,43 +755,60 @@ float pass_ms(const PathCost& c, int n, int np) {
     return c.pass_round * full + (rem == 0 ? 0.f : rem <= 256 ? c.pass_single : c.pass_round);
 }
 void decide_path(ls_handle* h) {
-    const int before = (h->use_long ? 1 : 0) + (h->use_coop ? 2 : 0) + (h->use_pass ? 4 : 0);
-    const int before_t = h->tail_n * 4 + h->tail_path;
-    h->use_coop = false; h->use_long = false; h->use_pass = false; h->tail_n = 0; h->tail_path = 0;
+    const long long before = plan_code(h);
+    h->use_coop = false; h->use_long = false; h->use_pass = false;
+    h->nseg = 1; h->seg[0] = {0, 0, h->B};
     const bool have_long = h->lw_wtp.p != nullptr;
     h->plan_pair = h->all_scale_one;
-    if (!h->fused) h->use_long = true;
+    if (!h->fused) h->seg[0].path = 1;
     else if (h->precision != 0 || h->path_mode == 1) {}
-    else if (h->path_mode == 2) h->use_long = have_long;
-    else if (h->path_mode == 3) h->use_coop = true;
-    else if (h->path_mode == 4) h->use_pass = true;
+    else if (h->path_mode == 2) h->seg[0].path = have_long ? 1 : 0;
+    else if (h->path_mode == 3) h->seg[0].path = 2;
+    else if (h->path_mode == 4) h->seg[0].path = 3;
     else if (h->B > 0) {
         const PathCost& c = h->var == kTED ? kCostTed : kCostBeat;
-        const int B = h->B, np = h->plan_pair ? 1 : 2, round = h->plan_pair ? 512 : 256;
-        auto long_ms = [&](int n) { return have_long ? c.long_base + c.long_per_sample * n : 1e30f; };
-        // whole batch on one kernel family: 0 fused, 1 batch-level, 2 sample-split, 3 pass (ties go to the earlier entry)
-        const float whole[4] = {c.fused_round * ((B + round - 1) / round), long_ms(B), coop_ms(c, B, np), pass_ms(c, B, np)};
-        int best_w = 0;
-        for (int k = 1; k < 4; ++k) if (whole[k] < whole[best_w]) best_w = k;
-        float best = whole[best_w];
-        const int r = B % round;
-        if (B > round && r > 0) {       // full fused rounds + remainder
-            const float head = c.fused_round * (B / round);
-            const float tail[4] = {1e30f, head + long_ms(r), head + coop_ms(c, r, np), head + pass_ms(c, r, np)};
-            int bt = 1;
-            for (int k = 2; k < 4; ++k) if (tail[k] < tail[bt]) bt = k;
-            if (tail[bt] < best) { best = tail[bt]; best_w = 0; h->tail_n = r; h->tail_path = bt; }
+        const int B = h->B, np = h->plan_pair ? 1 : 2, round = 512 / np, unit = 256 / np;     // unit: samples that put ONE pass workgroup on every CU
+        auto cost = [&](int path, int n) -> float {
+            switch (path) {
+            case 0: return c.fused_round * ((n + round - 1) / round);
+            case 1: return have_long ? c.long_base + c.long_per_sample * n : 1e30f;
+            case 2: return coop_ms(c, n, np);
+            default: return pass_ms(c, n, np);
+            }
+        };
+        // head: the full fused rounds; the remainder r on one family, or -- beyond one pass workgroup per CU -- `unit` samples on the
+        // one-pass-per-workgroup kernel and the rest on the sample-split / batch-level kernels (ties go to the earlier candidate)
+        const int head = B >= round ? B / round * round : 0, r = B - head;
+        float best = 1e30f;
+        Seg tail[2] = {{0, 0, 0}, {0, 0, 0}};
+        int ntail = 0;
+        if (r > 0) {
+            for (int path = 0; path < 4; ++path) {
+                const float t = cost(path, r);
+                if (t < best) { best = t; ntail = 1; tail[0] = {path, head, r}; }
+            }
+            if (r > unit)
+                for (int path = 1; path < 3; ++path) {
+                    const float t = cost(3, unit) + cost(path, r - unit);
+                    if (t < best) { best = t; ntail = 2; tail[0] = {3, head, unit}; tail[1] = {path, head + unit, r - unit}; }
+                }
         }
-        h->use_long = best_w == 1; h->use_coop = best_w == 2; h->use_pass = best_w == 3;
+        h->nseg = 0;
+        if (head > 0) h->seg[h->nseg++] = {0, 0, head};
+        for (int i = 0; i < ntail; ++i) {
+            if (h->nseg > 0 && tail[i].path == 0 && h->seg[h->nseg - 1].path == 0) h->seg[h->nseg - 1].n += tail[i].n;      // one more fused round
+            else h->seg[h->nseg++] = tail[i];
+        }
     }
-    if (before != (h->use_long ? 1 : 0) + (h->use_coop ? 2 : 0) + (h->use_pass ? 4 : 0) || before_t != h->tail_n * 4 + h->tail_path) free_graph(h);
+    h->use_long = h->nseg == 1 && h->seg[0].path == 1;
+    h->use_coop = h->nseg == 1 && h->seg[0].path == 2;
+    h->use_pass = h->nseg == 1 && h->seg[0].path == 3;
+    if (before != plan_code(h)) free_graph(h);
 }
 
 // zero the granule / flag words of the sample-split kernel (stream-ordered: a memset node when captured) and restart the epochs
 hipError_t coop_reset(ls_handle* h, hipStream_t st) {
-    if (h->use_pass || h->tail_path == 3)          // arrival tickets of the one-pass-per-workgroup kernel: two per step, counted within the call
-        if (hipError_t e = hipMemsetAsync(h->pa_cnt.p, 0, h->pa_cnt.bytes, st); e != hipSuccess) return e;
-    if (!h->use_coop && h->tail_path != 2) return hipSuccess;
+    if (seg_n(h, 2) == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(h->co_gran.p, 0, h->co_gran.bytes, st);
     if (e == hipSuccess) e = hipMemsetAsync(h->co_flag.p, 0, h->co_flag.bytes, st);
     h->coop_launches = 0;
@@ -772,19 +818,20 @@ hipError_t coop_reset(ls_handle* h, hipStream_t st) {
 // after a stream synchronisation: did a hand-off spin of the sample-split kernel run out?  (Never observed; a result computed past a
 // timeout is garbage, so the call fails loudly.)
 int coop_check(ls_handle* h) {
-    if (!h->use_coop && h->tail_path != 2) return LS_OK;
+    if (seg_n(h, 2) == 0) return LS_OK;
     unsigned v = 0;
     HIPCHK(h, hipMemcpy(&v, h->co_err.p, sizeof v, hipMemcpyDeviceToHost));
     if (!v) return LS_OK;
     HIPCHK(h, hipMemset(h->co_err.p, 0, sizeof v));
     return fail(h, LS_EHIP, "sample-split step kernel: an inter-workgroup hand-off timed out; the results of this call are invalid");
 }
-int step_path_code(const ls_handle* h) { return h->use_pass ? 3 : h->use_coop ? 2 : (h->use_long ? 1 : 0); }
 void report_path(ls_handle* h, bool pair) {
-    h->timing.step_path = step_path_code(h);
-    const bool tail = h->tail_n > 0 && pair == h->plan_pair && !h->use_coop && !h->use_long && !h->use_pass;
-    h->timing.tail_samples = tail ? h->tail_n : 0;
-    h->timing.tail_path = tail ? h->tail_path : 0;
+    const bool split = h->nseg > 1 && pair == h->plan_pair;
+    h->timing.step_path = (h->nseg == 1 || split) ? h->seg[0].path : 0;
+    h->timing.tail_samples = split ? h->seg[1].n : 0;
+    h->timing.tail_path = split ? h->seg[1].path : 0;
+    h->timing.tail2_samples = split && h->nseg > 2 ? h->seg[2].n : 0;
+    h->timing.tail2_path = split && h->nseg > 2 ? h->seg[2].path : 0;
 }
 
 // upload timing of a slot whose copy has been enqueued: wait for it (long done in steady state) and add it to the loop's total
@@ -1072,10 +1119,9 @@ int ls_set_precision(ls_handle* h, int mode) {
     if (mode != h->precision) free_graph(h);
     h->precision = mode;
     if (h->prepared) {      // the plan may move to kernels whose workspaces the last ls_prepare did not allocate: prepare again then
-        const bool wl = h->use_long, wc = h->use_coop, wp = h->use_pass;
-        const int wt = h->tail_n * 4 + h->tail_path;
+        const long long was = plan_code(h);
         decide_path(h);
-        if ((h->use_long && !wl) || (h->use_coop && !wc) || (h->use_pass && !wp) || (h->tail_n && wt != h->tail_n * 4 + h->tail_path)) h->prepared = false;
+        if (was != plan_code(h)) h->prepared = false;
     }
     return LS_OK;
 }
@@ -1207,8 +1253,8 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         HIPCHK(h, launch_gather_rows(h->emo_emb.f(), static_cast<const int64_t*>(h->emo.p), h->emo_tok.f(), B, kD, h->cfg.n_emotions, st, h->T));   // y['emo'][:, 0]
     }
     { const int keepB = h->B; h->B = B; decide_path(h); h->B = keepB; }
-    if (h->use_coop || h->tail_path == 2) {      // exchange workspaces of the sample-split kernel: one launch's worth of (sample, pass) groups
-        const int nco = h->use_coop ? B : h->tail_n;
+    if (seg_n(h, 2) > 0) {      // exchange workspaces of the sample-split kernel: one launch's worth of (sample, pass) groups
+        const int nco = seg_n(h, 2);
         const int groups = 2 * nco < h->coop_groups_max ? 2 * nco : h->coop_groups_max;
         const void* old[4] = {h->co_x.p, h->co_part.p, h->co_gran.p, h->co_flag.p};
         const size_t before = h->co_x.bytes;
@@ -1220,8 +1266,8 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         if (old[0] != h->co_x.p || old[1] != h->co_part.p || old[2] != h->co_gran.p || old[3] != h->co_flag.p) free_graph(h);
         h->coop_groups = groups;
     }
-    if (h->use_pass || h->tail_path == 3) {      // CFG hand-off of the one-pass-per-workgroup kernel: each pass's output, one ticket word per sample
-        const int npa = h->use_pass ? B : h->tail_n;
+    if (seg_n(h, 3) > 0) {      // CFG hand-off of the one-pass-per-workgroup kernel: each pass's output, one ticket word per sample
+        const int npa = seg_n(h, 3);
         const void* old[2] = {h->pa_out.p, h->pa_cnt.p};
         HIPCHK(h, h->pa_out.ensure((size_t)npa * 2 * h->T * h->JF * sizeof(float)));
         HIPCHK(h, h->pa_cnt.ensure((size_t)npa * sizeof(unsigned)));
@@ -1229,8 +1275,8 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         if (old[0] != h->pa_out.p || old[1] != h->pa_cnt.p) free_graph(h);
         h->pass_n = npa;
     }
-    if (h->use_long || h->tail_path == 1) {      // workspaces of the batch-level path: token sequences of both passes (two buffers), row partials, poseFinal output
-        const size_t nlo = h->use_long ? B : h->tail_n;
+    if (seg_n(h, 1) > 0) {      // workspaces of the batch-level path: token sequences of both passes (two buffers), row partials, poseFinal output
+        const size_t nlo = seg_n(h, 1);
         const void* old[5] = {h->lx_proj.p, h->lx_X.p, h->lx_U.p, h->lx_OUT.p, h->lx_xpad.p};
         const size_t rows = ((size_t)2 * nlo * h->S + 127) / 128 * 128;      // whole 128-row GEMM tiles (the fused channel-mixing product runs over the pad rows too)
         const size_t mpad = ((size_t)nlo * h->T + 127) / 128 * 128;           // x_t projection on whole 128-row tiles (k_long_padx)
@@ -1506,8 +1552,8 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     std::string key;
     {
         char keybuf[256];
-        snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d L%d", h->precision, B, a->sampler, (double)a->eta,
-                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, step_path_code(h) + 4 * h->tail_path + 16 * h->tail_n);
+        snprintf(keybuf, sizeof keybuf, "P%d B%d s%d e%a k%d n%d c%d cl%d w%u v%u p%d d%d L%lld", h->precision, B, a->sampler, (double)a->eta,
+                 a->skip_timesteps, a->noise_mode, a->const_noise, a->clip_denoised, h->weights_version, h->sched_version, (int)pair, a->n_dump, plan_code(h));
         key = keybuf;
         if (inpaint) key += inp_noised ? " I2" : " I1";
         for (int d = 0; d < a->n_dump; ++d) key += "," + std::to_string(a->dump_steps[d]);      // the whole list, however long
@@ -1660,6 +1706,7 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
         else if (n == "z_mu") { src = h->z_mu.f(); cnt = B * kD; }
         else if (n == "z_logvar") { src = h->z_logvar.f(); cnt = B * kD; }
         else if (n == "z_std") { src = h->z_std.f(); cnt = B * kD; }
+        else if (n == "pass_tickets" && h->pa_cnt.p) { src = h->pa_cnt.f(); cnt = (size_t)h->pass_n; }      // raw words (diagnostics)
         else return fail(h, LS_EINVAL, "ls_read: unknown buffer '%s'", name);
     }
     if (cnt > capacity) return fail(h, LS_EINVAL, "ls_read('%s'): need %zu floats, capacity %zu", name, cnt, capacity);

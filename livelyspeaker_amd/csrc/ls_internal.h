@@ -103,7 +103,7 @@ struct StepArgs {
     int xmap;                // blockIdx -> (group, slice) mapping, see k_coop
     // ---- one-pass-per-workgroup kernel (k_pass, ls_pass_kernel.h): b0 / npass as above, plus the CFG hand-off of ONE launch
     float* pf;               // [samples][2 passes][T][J*F] poseFinal output of each pass (write-through)
-    unsigned* pcnt;          // [samples] arrival tickets: two per step, zeroed ahead of every call
+    unsigned* pcnt;          // [samples] arrival tickets: zeroed by ls_prepare, back at zero after every step
 #ifdef LS_DEBUG
     // Profiling builds only (tools/phase_profile.py, tools/ab_variants.py compile their own -DLS_DEBUG variant of the library):
     // the shipped library has neither the fields nor the code that reads them, so no environment variable can change its results.

@@ -18,7 +18,7 @@
 //   * the weight images are k_step's (ls_api.cpp build_fused_images): this wave's 128 channels are the 64-channel slices 2 w and 2 w + 1 of
 //     the 8-wave kernel, so no second copy of the weights exists.
 //   * CFG combination: each pass writes its poseFinal output [T][J*F] write-through (sc1), every wave drains, barrier, one lane takes a
-//     ticket (relaxed agent-scope fetch_add on the sample's counter; zeroed by a memset node ahead of every call, two tickets per step).
+//     ticket (relaxed agent-scope fetch_add on the sample's counter: zeroed by ls_prepare, and set back to zero by the second taker).
 //     The workgroup that draws the odd ticket is the LAST of its sample: it reads the other pass's output with sc1 loads, combines the
 //     two in pass order (result independent of which one arrived last), and applies the sampler update.  Nobody waits for anybody:
 //     correct for any dispatch order, placement or residency (cdna_hip_programming.md section 6, Guideline 16, counter form).
@@ -42,6 +42,12 @@ __host__ __device__ constexpr int pass_lds_floats(int S) {
 typedef unsigned pass_u4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned* pass_gu32p;
 
+// Wave priority (the CU's two workgroups are independent and compete for the SIMDs): 0 none; 1 falls with the layer index (the workgroup
+// that is ahead yields, so the two stay level and neither is left to finish alone); 2 the same for the long products only, the
+// LayerNorm / token-mixing / epilogue phases always at the top level
+#ifndef LS_PASS_PRIO
+#define LS_PASS_PRIO 2
+#endif
 #ifndef LS_PASS_BPREF
 #define LS_PASS_BPREF 0                     // channel mixing: the LDS operands of k block q + 1 are requested while block q is multiplied
 #endif
@@ -280,6 +286,11 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
     for (int l = 0; l < a.layers; ++l) {
         fresh();
+        if (LS_PASS_PRIO == 1) {
+            if (l < 2) __builtin_amdgcn_s_setprio(3); else if (l < 4) __builtin_amdgcn_s_setprio(2); else if (l < 6) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        } else if (LS_PASS_PRIO == 2) {
+            __builtin_amdgcn_s_setprio(3);
+        }
         {   // x = x + emb  (re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
             const float* te = a.temb + (size_t)b * a.temb_stride + chw;
 #pragma unroll
@@ -348,6 +359,9 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         ln_store(std::false_type{}, alv, bev);
         __syncthreads();
         stamp(6 + 8 * l);
+        if (LS_PASS_PRIO == 2) {
+            if (l < 3) __builtin_amdgcn_s_setprio(2); else if (l < 6) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         // Rows 32 .. S-1 on the VALU (TED) / v_mfma_f32_4x4x1 (BEAT) from the same A-operand registers, as in k_step.
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {                 // 4 channel blocks x 2 full tiles = 8 accumulators per half
@@ -467,6 +481,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     // ================= OutputProcess.poseFinal (RAG.py:205-211) ====================================
     stamp(2 + 8 * a.layers);
     fresh();
+    if (LS_PASS_PRIO) __builtin_amdgcn_s_setprio(0);
     __syncthreads();                       // every wave is done reading the last LN2 operand: U is free
     constexpr bool kOutFromRegs = (NOB <= 2);
     constexpr int OROWS = kOutFromRegs ? NW * S : S;
@@ -582,9 +597,12 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add((pass_gu32p)(a.pcnt + bl), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flagw[0] = old & 1u;                              // odd ticket: the other pass of this step is already out
+            // the later one hands the word back as it found it at the start of the step (0): the next step -- a later launch -- needs no
+            // reset between launches (a memset node replayed ahead of the loop was observed to write a garbage pattern instead of zeros)
+            if (old & 1u) __hip_atomic_store((pass_gu32p)(a.pcnt + bl), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (!flagw[0]) return;                                // first of the sample: done
+        if (!flagw[0]) { stamp(4 + 8 * a.layers); return; }   // first of the sample: done
         other = a.pf + ((size_t)bl * 2 + (1 - p)) * (kT * JF);
     }
     stamp(3 + 8 * a.layers + 1);

@@ -228,11 +228,12 @@ def test_auto_takes_the_sample_split_kernel_for_small_batches_only():
         eng.close()
 
 
-@pytest.mark.parametrize("ds,B,want_tail", [("ted", 300, (44, 2)), ("ted", 400, (144, 1)), ("beat", 288, (32, 2))])
+@pytest.mark.parametrize("ds,B,want_tail", [("ted", 300, (44, 2, 0, 0)), ("ted", 400, (128, 3, 16, 2)), ("beat", 288, (32, 2, 0, 0))])
 def test_partial_last_round_goes_to_the_small_batch_kernels(ds, B, want_tail):
     """256 k + r samples on the fused kernel pay k + 1 full rounds.  `auto` runs the k full rounds on it and the r samples on the
-    sample-split or the batch-level kernels (whichever the step-time model says is cheaper): every sample as the fused kernel alone
-    computes it (to summation order), in TAPE and in PHILOX mode (the tail's Philox streams are keyed by its global sample index)."""
+    sample-split, the one-pass-per-workgroup or the batch-level kernels, or on two of them (whatever the step-time model says is
+    cheapest): every sample as the fused kernel alone computes it (to summation order), in TAPE and in PHILOX mode (the tail's Philox
+    streams are keyed by its global sample index)."""
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
     cfg = synth.CONFIGS[ds]
@@ -242,12 +243,12 @@ def test_partial_last_round_goes_to_the_small_batch_kernels(ds, B, want_tail):
         try:
             outs[path] = _loop(eng, cfg, 6, "", False, 0, False, B=B)
             t = eng.timing()
-            assert t["step_path"] == 0 and (t["tail_samples"], t["tail_path"]) == (want_tail if path == "auto" else (0, 0)), t
+            assert t["step_path"] == 0 and (t["tail_samples"], t["tail_path"], t["tail2_samples"], t["tail2_path"]) == (want_tail if path == "auto" else (0, 0, 0, 0)), t
             outs[path + "_philox"] = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=17, sample_offset=1000)
         finally:
             eng.close()
     d, dp = max_abs(outs["fused"], outs["auto"]), max_abs(outs["fused_philox"], outs["auto_philox"])
-    nf = B - want_tail[0]
+    nf = B - want_tail[0] - want_tail[2]
     print(f"{ds} B = {B}: fused vs fused + tail {want_tail}: tape {d:.3e}, philox {dp:.3e}")
     assert np.array_equal(outs["fused"][:nf], outs["auto"][:nf]) and np.array_equal(outs["fused_philox"][:nf], outs["auto_philox"][:nf])
     assert 0 < d < 5e-5 and 0 < dp < 5e-5

@@ -84,7 +84,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ls_abi_version.restype = ctypes.c_int
-    assert lib.ls_abi_version() == 3
+    assert lib.ls_abi_version() == 4
 
 
 def test_shipped_library_has_no_debug_switches():

@@ -25,7 +25,7 @@ from livelyspeaker_amd import _lib, synth
 ds, B, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 _lib.use_library(sys.argv[4])
 cfg = synth.CONFIGS[ds]
-eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, nframes=cfg.nframes)
+eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, nframes=cfg.nframes, path=os.environ.get('LS_AB_PATH') or None)
 eng.load_state_dict(synth.make_state_dict(cfg))
 if os.environ.get("LS_PRECISION"): eng.set_precision(os.environ["LS_PRECISION"])
 eng.set_schedule(synth.schedule(steps))

@@ -32,7 +32,8 @@ def main():
                 eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=1)
                 best = min(best, eng.timing()["loop_ms"] / steps)
             t = eng.timing()
-            print(f"{path:6s} B={B:4d}  {best:8.4f} ms/step  {B * 34 / best:10.0f} frames/s  path={t['step_path']}", flush=True)
+            print(f"{path:6s} B={B:4d}  {best:8.4f} ms/step  {B * 34 / best:10.0f} frames/s  path={t['step_path']}" + (f" +{t['tail_samples']}@{t['tail_path']}" if t['tail_samples'] else "")
+                  + (f" +{t['tail2_samples']}@{t['tail2_path']}" if t['tail2_samples'] else ""), flush=True)
         eng.close()
 
 

@@ -23,7 +23,9 @@ _lib.use_library(DEBUG_LIB)
 ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 cfg = synth.CONFIGS[ds]
-eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
+PATH = os.environ.get("LS_PROF_PATH", "fused")          # "fused" (k_step, 8 waves) or "pass" (k_pass, 4 waves)
+NWV = 4 if PATH == "pass" else 8
+eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=PATH)
 eng.load_state_dict(synth.make_state_dict(cfg))
 if os.environ.get("LS_PROF_PRECISION"):
     eng.set_precision(os.environ["LS_PROF_PRECISION"])
@@ -33,10 +35,10 @@ for _ in range(2):
     eng.sample(sampler=0, philox_seed=1)
 raw = np.empty(8 * 96 * 2, np.float32)
 n = eng.lib.ls_read(eng.h, b"prof", raw.ctypes.data_as(_lib.c_f32p), raw.size)
-st = raw.view(np.uint64).reshape(8, 96).astype(np.float64)
+st = raw.view(np.uint64).reshape(8, 96).astype(np.float64)[:NWV]
 L = 8
 names = ["LN1 stats(+temb)", "LN1 store+bar", "token-mix", "LN2 stats", "LN2 store+bar", "GEMM pass0+epi", "GEMM pass1+epi", "(trace)"]
-print(f"{ds} B={B}: total cycles (wave mean) = {np.mean(st[:, 4 + 8 * L] - st[:, 0]):.0f}")
+print(f"{ds} B={B} path={PATH}: total cycles (wave mean) = {np.mean(st[:, 4 + 8 * L] - st[:, 0]):.0f}")
 print(f"  embed                : {np.mean(st[:, 1] - st[:, 0]):9.0f}")
 prev = st[:, 1].copy()
 acc = np.zeros(7)
@@ -56,5 +58,5 @@ if os.environ.get("LS_PROF_RAW"):
     l = 3
     base = st[:, 1 + 8 * l].min()
     print("per-wave stamps of layer 3 (cycles since earliest previous-layer end):")
-    for wv in range(8):
+    for wv in range(NWV):
         print(f"  wave {wv}:", [int(st[wv, p + 8 * l] - base) for p in (1, 2, 3, 4, 5, 6, 7, 9)])
