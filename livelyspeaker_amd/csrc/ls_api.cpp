@@ -78,6 +78,7 @@ struct ls_handle {
     Seg seg[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     bool plan_pair = false; // the plan assumed the single-pass form (every guidance scale 1)
     DevBuf wtok1_img;       // token-mix operand of one pass (sample-split kernel)
+    DevBuf wtok1_hi_img, wtok1_lo_img;   // the same as bf16 hi / lo planes (one-pass-per-workgroup kernel, bf16x3)
     DevBuf co_x, co_part, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
     unsigned coop_launches = 0;                        // launches since the granule words were zeroed: epoch = 64 * ordinal
     unsigned coop_err_host = 0;
@@ -221,6 +222,8 @@ int build_fused_images(ls_handle* h) {
     const int MQ1 = (MK1 + 3) / 4;
     std::vector<float> wt1((size_t)L * 3 * MQ1 * 256);
     std::vector<unsigned short> wwh((size_t)L * kNT * KS * 64 * 8), wwl((size_t)L * kNT * KS * 64 * 8);
+    const int KS1 = (S + 31) / 32;
+    std::vector<unsigned short> wt1h((size_t)L * 3 * KS1 * 64 * 8), wt1l((size_t)L * 3 * KS1 * 64 * 8);
     char key[160];
     for (int l = 0; l < L; ++l) {
         auto K = [&](const char* suffix) { snprintf(key, sizeof key, "backbone.mlps.%d.%s", l, suffix); return std::string(key); };
@@ -294,6 +297,17 @@ int build_fused_images(ls_handle* h) {
                         wwl[o] = f32_to_bf16(v - bf16_to_f32(wwh[o]));
                     }
         for (int r = 0; r < R; ++r) bt[(size_t)l * 80 + r] = (*b1)[r % S];
+        // wtok1_hi / lo [l][t][ks][lane][e] = Wt[r = 16t + (lane&15)][r' = 32ks + 8(lane>>4) + e] of ONE pass as bf16 hi / lo planes (ls_pass_kernel.h)
+        for (int t = 0; t < 3; ++t)
+            for (int ks = 0; ks < KS1; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 16 * t + (lane & 15), rp = 32 * ks + 8 * (lane >> 4) + e;
+                        const float v = (r < S && rp < S) ? (*Wt)[(size_t)r * S + rp] : 0.f;
+                        const size_t o = ((((size_t)l * 3 + t) * KS1 + ks) * 64 + lane) * 8 + e;
+                        wt1h[o] = f32_to_bf16(v);
+                        wt1l[o] = f32_to_bf16(v - bf16_to_f32(wt1h[o]));
+                    }
         // wtok1_img[l][t][mq][lane][j] = Wt[r = 16t + (lane&15)][r' = 4(4mq + j) + (lane>>4)] of ONE pass, zero outside S x S (ls_coop_kernel.h)
         for (int t = 0; t < 3; ++t)
             for (int m = 0; m < 4 * MQ1; ++m)
@@ -352,6 +366,8 @@ int build_fused_images(ls_handle* h) {
     if ((rc = upload(h, h->wch_lo_img, wch_lo.data(), wch_lo.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->ww_hi_img, wwh.data(), wwh.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->ww_lo_img, wwl.data(), wwl.size() * sizeof(unsigned short))) != LS_OK) return rc;
+    if ((rc = upload(h, h->wtok1_hi_img, wt1h.data(), wt1h.size() * sizeof(unsigned short))) != LS_OK) return rc;
+    if ((rc = upload(h, h->wtok1_lo_img, wt1l.data(), wt1l.size() * sizeof(unsigned short))) != LS_OK) return rc;
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
     UP(ww_img, ww); UP(wtok1_img, wt1); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
 #undef UP
@@ -363,6 +379,7 @@ int build_fused_images(ls_handle* h) {
     dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
     dw.ww_img = h->ww_img.f(); dw.wtok1_img = h->wtok1_img.f(); dw.btok_rows = h->btok_rows.f();
+    dw.wtok1_hi_img = static_cast<const unsigned short*>(h->wtok1_hi_img.p); dw.wtok1_lo_img = static_cast<const unsigned short*>(h->wtok1_lo_img.p);
     dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
     if ((rc = upload(h, h->devw, &dw, sizeof dw)) != LS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -591,7 +608,7 @@ hipError_t run_pass(ls_handle* h, const StepArgs& s, int first, int n, bool pair
     StepArgs c = s;
     c.pf = h->pa_out.f(); c.pcnt = static_cast<unsigned*>(h->pa_cnt.p);
     c.b0 = first; c.npass = pair ? 1 : 2;
-    return launch_step_pass(h->var, c, n, st);
+    return launch_step_pass(h->var, h->precision == 1 ? 1 : 0, c, n, st);
 }
 
 // the batch-level kernels over samples [first, first + n): the same step from separate kernels over all rows (both passes always; exact fp32 only)
@@ -744,6 +761,8 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 //   all sample-split | all batch-level | all fused | all pass | full fused rounds + the remainder on sample-split, batch-level or pass.
 struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single; };
 constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.70f, 0.423f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.842f, 0.503f};
+// bf16x3 (opt-in precision) exists in the fused and the one-pass-per-workgroup kernels only; measured on MI355X (tools/bf16x3_time.py)
+constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.302f};
 float coop_ms(const PathCost& c, int n, int np) {
     float ms = 0.f;
     for (int g = n * np; g > 0; g -= kCoopMaxGroups) ms += c.coop_base + c.coop_per_group * (g < kCoopMaxGroups ? g : kCoopMaxGroups);
@@ -761,18 +780,20 @@ void decide_path(ls_handle* h) {
     const bool have_long = h->lw_wtp.p != nullptr;
     h->plan_pair = h->all_scale_one;
     if (!h->fused) h->seg[0].path = 1;
-    else if (h->precision != 0 || h->path_mode == 1) {}
+    else if (h->path_mode == 1) {}
+    else if (h->path_mode == 4) h->seg[0].path = 3;
+    else if (h->precision != 0 && h->path_mode != 0) {}
     else if (h->path_mode == 2) h->seg[0].path = have_long ? 1 : 0;
     else if (h->path_mode == 3) h->seg[0].path = 2;
-    else if (h->path_mode == 4) h->seg[0].path = 3;
     else if (h->B > 0) {
-        const PathCost& c = h->var == kTED ? kCostTed : kCostBeat;
+        const bool bf = h->precision != 0;
+        const PathCost& c = bf ? (h->var == kTED ? kCostTedBf : kCostBeatBf) : (h->var == kTED ? kCostTed : kCostBeat);
         const int B = h->B, np = h->plan_pair ? 1 : 2, round = 512 / np, unit = 256 / np;     // unit: samples that put ONE pass workgroup on every CU
         auto cost = [&](int path, int n) -> float {
             switch (path) {
             case 0: return c.fused_round * ((n + round - 1) / round);
-            case 1: return have_long ? c.long_base + c.long_per_sample * n : 1e30f;
-            case 2: return coop_ms(c, n, np);
+            case 1: return have_long && !bf ? c.long_base + c.long_per_sample * n : 1e30f;
+            case 2: return bf ? 1e30f : coop_ms(c, n, np);
             default: return pass_ms(c, n, np);
             }
         };
@@ -787,7 +808,7 @@ void decide_path(ls_handle* h) {
                 const float t = cost(path, r);
                 if (t < best) { best = t; ntail = 1; tail[0] = {path, head, r}; }
             }
-            if (r > unit)
+            if (r > unit && !bf)
                 for (int path = 1; path < 3; ++path) {
                     const float t = cost(3, unit) + cost(path, r - unit);
                     if (t < best) { best = t; ntail = 2; tail[0] = {3, head, unit}; tail[1] = {path, head + unit, r - unit}; }
@@ -1045,7 +1066,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (h->prof_on) {
         std::vector<unsigned long long> z((size_t)kWaves * kProfPoints, 0ull);
         if (upload(h, h->prof, z.data(), z.size() * sizeof(unsigned long long)) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
-        std::vector<unsigned long long> zw(2048, 0ull);
+        std::vector<unsigned long long> zw(4096, 0ull);      // [1024][2] stamps | [2048] hardware ids (k_pass)
         if (upload(h, h->wgt, zw.data(), zw.size() * sizeof(unsigned long long)) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
     }
 #endif
@@ -1068,7 +1089,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt, &h->wtok1_hi_img, &h->wtok1_lo_img};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -1130,7 +1151,7 @@ int ls_set_path(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
     if (mode < 0 || mode > 4) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel, 4 one workgroup per (sample, pass))", mode);
     if (mode >= 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has neither the sample-split nor the one-pass-per-workgroup kernel", kT);
-    if (mode >= 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split and one-pass-per-workgroup kernels are exact fp32 only");
+    if (mode == 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split kernel is exact fp32 only");
     if (mode == 2 && h->fused && h->lw_wtp.p == nullptr && h->committed) return fail(h, LS_EUNSUPPORTED, "batch-level kernels need S <= 160");
     if (mode == 1 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no fused kernel", kT);
     if (mode != h->path_mode) { h->path_mode = mode; h->prepared = false; free_graph(h); }      // takes effect at the next ls_prepare (workspaces)
@@ -1687,6 +1708,13 @@ long long ls_read(ls_handle* h, const char* name, float* host_out, size_t capaci
         cnt = 2048 * 2;
         if (cnt > capacity) return fail(h, LS_EINVAL, "capacity");
         HIPCHK(h, hipMemcpy(host_out, h->wgt.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        return (long long)cnt;
+    }
+    if (n == "wgt_hw") {       // k_pass: HW_ID | XCC_ID << 32 of every workgroup's wave 0
+        if (!h->prof_on) return fail(h, LS_ESTATE, "LS_PROF not set");
+        cnt = 2048 * 2;
+        if (cnt > capacity) return fail(h, LS_EINVAL, "capacity");
+        HIPCHK(h, hipMemcpy(host_out, static_cast<unsigned long long*>(h->wgt.p) + 2048, cnt * sizeof(float), hipMemcpyDeviceToHost));
         return (long long)cnt;
     }
 #endif

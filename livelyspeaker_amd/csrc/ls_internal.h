@@ -38,6 +38,8 @@ struct DevWeights {
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
     const float* wtok1_img;  // [L][3][ceil(S/16)][64][4]   token-mix operand of ONE pass (sample-split kernel, ls_coop_kernel.h)
+    const unsigned short* wtok1_hi_img;   // [L][3][ceil(S/32)][64][8]  the same as bf16 hi / lo planes (one-pass-per-workgroup kernel, bf16x3)
+    const unsigned short* wtok1_lo_img;
     const float* btok_rows;  // [L][80]
     const float* winx_img;   // [8][2 passes][KXQ][2 cb][64][4]   x_t columns of input_mapping
     const float* wout_img;   // [NOB][32][64][4]   poseFinal, k in natural order (operand staged in LDS)
@@ -153,7 +155,7 @@ hipError_t launch_step_coop(Variant v, const StepArgs& a, int nsamples, hipStrea
 
 // one-pass-per-workgroup step kernel (ls_pass.hip): npass workgroups of 4 waves per sample, two workgroups per CU
 hipError_t init_pass_kernels();
-hipError_t launch_step_pass(Variant v, const StepArgs& a, int nsamples, hipStream_t st);
+hipError_t launch_step_pass(Variant v, int prec, const StepArgs& a, int nsamples, hipStream_t st);
 
 // prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
 // pair: 0 = CFG (cond + uncond pass of one sample per workgroup), 1 = single pass (guidance scale 1: two samples per workgroup)

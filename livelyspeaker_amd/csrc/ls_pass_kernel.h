@@ -48,11 +48,17 @@ typedef __attribute__((address_space(1))) unsigned* pass_gu32p;
 #ifndef LS_PASS_PRIO
 #define LS_PASS_PRIO 2
 #endif
+#ifndef LS_PASS_PFD
+#define LS_PASS_PFD 2                       // bf16x3 channel mixing: weight fragments requested this many k blocks ahead
+#endif
 #ifndef LS_PASS_BPREF
 #define LS_PASS_BPREF 0                     // channel mixing: the LDS operands of k block q + 1 are requested while block q is multiplied
 #endif
 
-template <int S, int NPRE, int JF>
+// PREC = 1: bf16x3 split precision (opt-in, as in k_step): operands u = hi + lo as two bf16 planes, W.u ~= hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  bf16 MFMAs and the fp32 VALU do not share lanes, and the CU's two workgroups are
+// independent, so one's LayerNorm / SiLU phases run beside the other's products.
+template <int S, int NPRE, int JF, int PREC = 0>
 __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     constexpr int KXQ = (JF + 15) / 16;      // 16-wide k groups of the x_t part of input_mapping
     constexpr int KXP = KXQ * 16;
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     constexpr int MQ = (MK + 3) / 4;         // ... in groups of four (one 16-byte weight fragment per lane)
     constexpr int NU = NOB * NT;             // output-projection work units (wide outputs)
     constexpr int MAXU = (NU + NW - 1) / NW;
+    constexpr int KS = (S + 31) / 32;        // k steps (32 source rows) of the bf16 token-mix MFMA
     static_assert(S > 32 && S <= 36, "one pass = two full row tiles + a ragged one of at most 4 rows");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -103,6 +110,8 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #ifdef LS_DEBUG
         if (a.prof && bid == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[w * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
         if (a.wgt && tid == 0 && (idx == 0 || idx == 4 + 8 * a.layers)) a.wgt[2 * bid + (idx ? 1 : 0)] = __builtin_amdgcn_s_memtime();
+        if (a.wgt && tid == 0 && idx == 0 && bid < 2048)
+            a.wgt[2048 + bid] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
 #else
         (void)idx;
 #endif
@@ -279,7 +288,21 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                     const f4 rs = (f4){rstd[t], rstd[t], rstd[t], rstd[t]}, nm = (f4){nmr[t], nmr[t], nmr[t], nmr[t]};
                     f4 u = __builtin_elementwise_fma(X[cb][t], rs, nm);
                     if (alpha) u = __builtin_elementwise_fma(u, alv[cb], bev[cb]);
-                    *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                    if constexpr (PREC == 1) {
+                        // u = hi + lo (+ O(2^-17 |u|)), hi = bf16_rne(u), lo = bf16_rne(u - hi): two bf16 planes [S][520] in the fp32 buffer's space
+                        __bf16* Uh = reinterpret_cast<__bf16*>(U);
+                        __bf16* Ul = Uh + S * kUStride;
+                        bf4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            hi[j] = (__bf16)u[j];
+                            lo[j] = (__bf16)(u[j] - (float)hi[j]);
+                        }
+                        *reinterpret_cast<bf4*>(&Uh[row_of(t) * kUStride + chw + 16 * cb]) = hi;
+                        *reinterpret_cast<bf4*>(&Ul[row_of(t) * kUStride + chw + 16 * cb]) = lo;
+                    } else {
+                        *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = u;
+                    }
                 }
     };
 
@@ -316,7 +339,62 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         __builtin_amdgcn_wave_barrier();
         stamp(3 + 8 * l);
         fresh();
-        {
+        if constexpr (PREC == 1) {
+            // bf16x3 token mixing: the operand stays row-major (the two bf16 planes) and the MFMA A fragment -- 8 consecutive source rows
+            // of one channel per lane -- is gathered by ds_read_b64_tr_b16 (see k_step).  wtok1_hi / lo [l][t][ks][lane][8] =
+            // Wt[16 t + (lane & 15)][32 ks + 8 (lane >> 4) + e], zero outside S x S.
+            typedef short s4v __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s4v* lds4;
+            const wrsrc_t wrh = wrsrc(a.W->wtok1_hi_img), wrl = wrsrc(a.W->wtok1_lo_img);
+            const int wsb = l * NT * KS * 1024;
+            bf8 Bh[NT][KS], Bl[NT][KS];
+            float bt[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    Bh[t][ks] = wload8h(wrh, lane * 16, wsb + (t * KS + ks) * 1024);
+                    Bl[t][ks] = wload8h(wrl, lane * 16, wsb + (t * KS + ks) * 1024);
+                }
+                bt[t] = g1(a.W->btok_rows)[l * 80 + rowc_of(t)];
+            }
+            const __bf16* Ph = reinterpret_cast<const __bf16*>(U);
+            const __bf16* Pl = Ph + S * kUStride;
+            int ro[KS][2];                                  // rows past the last one are clamped: their weights are 0 and the clamped row is finite
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                ro[ks][0] = min(32 * ks + 8 * g + (s16 >> 2), S - 1) * kUStride + 128 * w + 4 * (s16 & 3);
+                ro[ks][1] = min(32 * ks + 8 * g + 4 + (s16 >> 2), S - 1) * kUStride + 128 * w + 4 * (s16 & 3);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                bf8 Ah[KS], Al[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const s4v h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Ph + ro[ks][0] + 16 * cb));
+                    const s4v h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Ph + ro[ks][1] + 16 * cb));
+                    const s4v l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Pl + ro[ks][0] + 16 * cb));
+                    const s4v l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Pl + ro[ks][1] + 16 * cb));
+                    Ah[ks] = __builtin_bit_cast(bf8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    Al[ks] = __builtin_bit_cast(bf8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                f4 acc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = (f4){bt[t], bt[t], bt[t], bt[t]};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[ks], Bh[t][ks], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[ks], Bl[t][ks], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[ks], Bh[t][ks], acc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (valid_of(t)) X[cb][t] = silu_acc4(acc[t], X[cb][t]);
+            }
+        } else {
             // out[ch][r] = sum_r' u[r'][ch] * Wt[r][r'] + bt[r] as D[channel][row]: A = u^T from LDS, B = the Conv1d weights (one pass:
             // wtok1_img[l][t][mq][lane][j] = Wt[16 t + (lane & 15)][4 (4 mq + j) + (lane >> 4)]).  Channel block by channel block: the
             // block's MK source values are read once and meet the three row tiles (three independent accumulators).
@@ -362,6 +440,97 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         if (LS_PASS_PRIO == 2) {
             if (l < 3) __builtin_amdgcn_s_setprio(2); else if (l < 6) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
+        if constexpr (PREC == 1) {
+            // ---- bf16x3: W'.u ~= hi_w.hi_u + hi_w.lo_u + lo_w.hi_u (bf16 x bf16 products are exact in fp32; the dropped lo.lo term and the
+            // split residuals are O(2^-16) relative); all three row tiles padded (bf16 MFMAs are cheap), two channel blocks at a time.
+            // wch_hi / lo [L][8][2][16 q][2][64][8]: block 8 w + 2 pp + c2 = (8-wave slice 2 w + (pp >> 1), pass pp & 1, c2)
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                fresh();
+                f4 acc[2][NT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const f4 bc = wload4(wrsrc(a.W->bch), chw * 4, (l * kD + 16 * (2 * pp + c2)) * 4);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[c2][t] = bc;
+                }
+                const wrsrc_t wrh = wrsrc(a.W->wch_hi_img), wrl = wrsrc(a.W->wch_lo_img);
+                const int wsb = ((((l * 8 + 2 * w + (pp >> 1)) * 2 + (pp & 1)) * 16) * 2) * 1024;
+                const __bf16* Uh = reinterpret_cast<const __bf16*>(U);
+                const __bf16* Ul = Uh + S * kUStride;
+                int rofs[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rofs[t] = rowc_of(t) * kUStride + 8 * g;
+                // One wave per SIMD and workgroup: nothing but this wave's own prefetch hides the L2 round trip of the weight fragments, and a
+                // k block is only 18 bf16 MFMAs (~290 clocks) long -- fragments are requested PFD blocks ahead (fully unrolled: the stages
+                // are renamed, not moved)
+                constexpr int PFD = LS_PASS_PFD;
+                bf8 Ahq[PFD][2], Alq[PFD][2];
+#pragma unroll
+                for (int k = 0; k < PFD; ++k)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        Ahq[k][c2] = wload8h(wrh, lane * 16, wsb + (k * 2 + c2) * 1024);
+                        Alq[k][c2] = wload8h(wrl, lane * 16, wsb + (k * 2 + c2) * 1024);
+                    }
+                // the LDS operands are software-pipelined too: the hi plane of block q + 1 is requested at the top of block q, its lo plane
+                // once the hi plane of block q has met its last MFMA (36 live operand registers instead of 48 for a full double buffer)
+                bf8 Bhn[NT], Bln[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    Bhn[t] = *reinterpret_cast<const bf8*>(Uh + rofs[t]);
+                    Bln[t] = *reinterpret_cast<const bf8*>(Ul + rofs[t]);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    bf8 Ah[2], Al[2], Bh[NT], Bl[NT];
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) { Ah[c2] = Ahq[q % PFD][c2]; Al[c2] = Alq[q % PFD][c2]; }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { Bh[t] = Bhn[t]; Bl[t] = Bln[t]; }
+                    // pinned: left to itself the scheduler sinks each request to just ahead of its use (one L2 round trip per fragment)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + PFD < 16) {
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            Ahq[q % PFD][c2] = wload8h(wrh, lane * 16, wsb + ((q + PFD) * 2 + c2) * 1024);
+                            Alq[q % PFD][c2] = wload8h(wrl, lane * 16, wsb + ((q + PFD) * 2 + c2) * 1024);
+                        }
+                    }
+                    if (q + 1 < 16) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) Bhn[t] = *reinterpret_cast<const bf8*>(Uh + rofs[t] + 32 * (q + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // term-major order: 6 independent accumulators between two MFMAs on the same one
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[t], acc[c2][t], 0, 0, 0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[t], acc[c2][t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + 1 < 16) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) Bln[t] = *reinterpret_cast<const bf8*>(Ul + rofs[t] + 32 * (q + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[c2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[t], acc[c2][t], 0, 0, 0);
+                }
+                fresh();
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (valid_of(t)) X[2 * pp + c2][t] = silu_acc4(acc[c2][t], X[2 * pp + c2][t]);
+                if (pp == 1) stamp(7 + 8 * l);
+            }
+        } else {
         // Rows 32 .. S-1 on the VALU (TED) / v_mfma_f32_4x4x1 (BEAT) from the same A-operand registers, as in k_step.
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {                 // 4 channel blocks x 2 full tiles = 8 accumulators per half
@@ -474,6 +643,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             if (pp == 0) stamp(7 + 8 * l);
+        }
         }
         stamp(9 + 8 * l);
     }

@@ -219,11 +219,12 @@ def test_auto_takes_the_sample_split_kernel_for_small_batches_only():
             eng.prepare(synth.make_cond(cfg, B))
             out = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=5)
             assert np.isfinite(out).all() and eng.timing()["step_path"] == want, B
-        # the split-precision mode exists in the fused kernel only
+        # the split-precision mode exists in the fused and the one-pass-per-workgroup kernels only: never the sample-split kernel
         eng.set_precision("bf16x3")
-        eng.prepare(synth.make_cond(cfg, 6))
-        eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=5)
-        assert eng.timing()["step_path"] == 0
+        for B, want in ((6, 3), (512, 0)):
+            eng.prepare(synth.make_cond(cfg, B))
+            eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=5)
+            assert eng.timing()["step_path"] == want, B
     finally:
         eng.close()
 

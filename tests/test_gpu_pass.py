@@ -137,3 +137,35 @@ def test_pass_kernel_determinism_under_load_and_next_to_another_handle():
     finally:
         eng.close()
         other.close()
+
+
+@pytest.mark.parametrize("ds", ["ted", "beat"])
+def test_bf16x3_on_the_pass_kernel_meets_the_parity_contract(ds, golden):
+    """The opt-in split-precision arithmetic (three bf16 MFMAs per product) inside the one-pass-per-workgroup kernel, both forms:
+    contract 1e-3 against the reference's fixtures (G1 forwards, G3 / G4 / G5 loops, G11 scale 1 single-pass)."""
+    from livelyspeaker_amd import _lib
+    from oracle import rag_oracle as orc
+    cfg, eng = _engine(ds)
+    g = golden[ds]
+    g2 = np.load(os.path.join(GOLDEN, f"{ds}_golden_r2.npz"))
+    try:
+        eng.set_precision("bf16x3")
+        x, eps, noise = _g1_inputs(cfg)
+        eng.prepare(synth.make_cond(cfg, 4))
+        worst = 0.0
+        for t in (0, 500, 999):
+            oc, ou, _ = eng.forward(x, np.full(4, t, np.int64), eps[0], eps[1])
+            worst = max(worst, max_abs(oc, g[f"G1_t{t}_c"]), max_abs(ou, g[f"G1_t{t}_u"]))
+        d3 = max_abs(_loop(eng, cfg, 50, "", False, 0, False), g["G3_ddpm50_final"])
+        assert eng.timing()["step_path"] == 3
+        d4 = max_abs(_loop(eng, cfg, 1000, "ddim100", True, 80, True), g["G4_ddim100_skip80_final"])
+        d11 = max_abs(_loop(eng, cfg, 50, "", False, 0, False, B=5, scale=1.0), g2["G11_scale1_ddpm50_B5_final"])
+        assert eng.timing()["single_pass"] == 1 and eng.timing()["step_path"] == 3
+        print(f"{ds} bf16x3 [pass]: forward {worst:.3e}  G3 {d3:.3e}  G4 skip80 {d4:.3e}  G11 {d11:.3e}")
+        assert max(worst, d3, d4, d11) < 1e-3
+        if ds == "ted":
+            d5 = max_abs(_loop(eng, cfg, 1000, "", False, 0, False), g["G5_ddpm1000_final"])
+            print(f"      G5 1000 steps {d5:.3e}")
+            assert d5 < 1e-3
+    finally:
+        eng.close()

@@ -20,10 +20,10 @@ def golden_r2():
     return {ds: np.load(os.path.join(GOLDEN, f"{ds}_golden_r2.npz")) for ds in ("ted", "beat")}
 
 
-def _engine(ds):
+def _engine(ds, path=None):
     from livelyspeaker_amd import _lib
     cfg = synth.CONFIGS[ds]
-    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions)
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=path)
     eng.load_state_dict(synth.make_state_dict(cfg))
     return cfg, eng
 
@@ -62,7 +62,7 @@ def test_scale1_split_precision_vs_reference_fixture(ds, golden_r2):
     gathered by the transposing LDS read; contract 1e-3 against the reference's fixture."""
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
-    cfg, eng = _engine(ds)
+    cfg, eng = _engine(ds, "fused")
     g = golden_r2[ds]
     try:
         eng.set_precision("bf16x3")

@@ -19,6 +19,8 @@ cfg = synth.CONFIGS[ds]
 PATH = os.environ.get("LS_PROF_PATH", "fused")          # "fused" (k_step: B workgroups) or "pass" (k_pass: 2 B workgroups)
 eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=PATH)
 eng.load_state_dict(synth.make_state_dict(cfg))
+if os.environ.get("LS_PROF_PRECISION"):
+    eng.set_precision(os.environ["LS_PROF_PRECISION"])
 eng.set_schedule(synth.schedule(8))
 eng.prepare(synth.make_cond(cfg, B))
 for _ in range(2):
