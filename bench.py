@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--launcher", default="torchrun", choices=["torchrun", "threads"],
                     help="N > 1: 'torchrun' = one process per GPU with torch.distributed (RCCL, gloo fallback); 'threads' = ONE process, "
                          "N engine handles on N devices driven by N Python threads, no collective at all (an independent N-GPU number)")
+    ap.add_argument("--path", default="auto", choices=["auto", "fused", "batch", "coop", "pass"],
+                    help="kernel family of the step loop (ls_set_path); default: the engine's plan for the batch")
     ap.add_argument("--no-rccl", action="store_true", help="do not try RCCL: collectives over gloo on host copies")
     ap.add_argument("--rccl-probe-timeout", type=float, default=120.0, help="seconds the RCCL bring-up + first collectives may take")
     ap.add_argument("--no-traffic-pass", action="store_true", help="do not spawn the two rocprofv3 PMC passes that measure roofline.traffic")
@@ -519,7 +521,7 @@ def threads_main(a):
     engines = []
     for r in range(world):
         e = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions,
-                        device=0 if a.ranks_share_device else r, path="auto")
+                        device=0 if a.ranks_share_device else r, path=a.path)
         e.load_state_dict(sd)
         e.set_schedule(sch)
         if a.precision != "fp32":
@@ -649,6 +651,8 @@ def main():
     model.to(dev)
     model.eval()
     model.precision = a.precision
+    if a.path != "auto":
+        model.step_path = a.path
     model.cache_conditioning = False        # every timed call re-runs the once-per-call stage (a new batch)
     cfgm = ClassifierFreeSampleModel(model)
     diffusion.noise_source = "philox"
@@ -954,7 +958,7 @@ def main():
         _RESULT_OUT.flush()
     if use_dist:
         dist.barrier()
-        dist.destroy_process_group()
+        shard.finish(0)        # destroy_process_group -- or os._exit when an RCCL probe thread had to be abandoned (said on stderr)
 
 
 def _reserve_stdout():

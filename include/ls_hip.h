@@ -201,6 +201,8 @@ typedef struct ls_timing {
     int32_t tail_path;          /* ... 1 the batch-level, 2 the sample-split, 3 the one-pass-per-workgroup kernels (0: none) */
     int32_t tail2_samples;      /* third piece of the plan (e.g. 416 clips = 256 fused + 128 one-pass-per-workgroup + 32 sample-split) */
     int32_t tail2_path;
+    int32_t n_cus;              /* compute units of the handle's device (hipDeviceProp.multiProcessorCount): what the plans and the
+                                   sample-split kernel's residency are derived from */
 } ls_timing;
 
 int ls_abi_version(void);

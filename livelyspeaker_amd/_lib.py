@@ -79,7 +79,7 @@ class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32), ("single_pass", C.c_int32),
                 ("tape_upload_ms", C.c_float), ("n_segments", C.c_int32), ("step_path", C.c_int32),
-                ("tail_samples", C.c_int32), ("tail_path", C.c_int32), ("tail2_samples", C.c_int32), ("tail2_path", C.c_int32)]
+                ("tail_samples", C.c_int32), ("tail_path", C.c_int32), ("tail2_samples", C.c_int32), ("tail2_path", C.c_int32), ("n_cus", C.c_int32)]
 
 
 class LsTrainConfig(C.Structure):

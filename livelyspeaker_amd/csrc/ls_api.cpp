@@ -82,7 +82,8 @@ struct ls_handle {
     DevBuf co_x, co_part, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
     unsigned coop_launches = 0;                        // launches since the granule words were zeroed: epoch = 64 * ordinal
     unsigned coop_err_host = 0;
-    int coop_groups_max = kCoopMaxGroups, coop_groups = 0;   // (sample, pass) groups per launch: cap, and what the workspaces hold
+    int n_cu = 256;         // compute units of the device (hipDeviceProp.multiProcessorCount): residency of the sample-split kernel, round sizes of the plans
+    int coop_groups_max = kCoopMaxGroups, coop_groups = 0;   // (sample, pass) groups per launch: cap (two workgroups per CU, eight per group), and what the workspaces hold
     int coop_xmap = 0;      // blockIdx -> (group, slice) mapping of the sample-split kernel (speed only; LS_COOP_XMAP in -DLS_DEBUG builds)
     int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
@@ -763,15 +764,15 @@ struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, f
 constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.70f, 0.423f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.842f, 0.503f};
 // bf16x3 (opt-in precision) exists in the fused and the one-pass-per-workgroup kernels only; measured on MI355X (tools/bf16x3_time.py)
 constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.302f};
-float coop_ms(const PathCost& c, int n, int np) {
+float coop_ms(const PathCost& c, int n, int np, int gmax) {
     float ms = 0.f;
-    for (int g = n * np; g > 0; g -= kCoopMaxGroups) ms += c.coop_base + c.coop_per_group * (g < kCoopMaxGroups ? g : kCoopMaxGroups);
+    for (int g = n * np; g > 0; g -= gmax) ms += c.coop_base + c.coop_per_group * (g < gmax ? g : gmax);
     return ms;
 }
-// one-pass-per-workgroup kernel: 512 workgroups are resident (two per CU, pass_round each); up to 256 left over run one per CU
-float pass_ms(const PathCost& c, int n, int np) {
-    const int wgs = n * np, full = wgs / 512, rem = wgs % 512;
-    return c.pass_round * full + (rem == 0 ? 0.f : rem <= 256 ? c.pass_single : c.pass_round);
+// one-pass-per-workgroup kernel: two workgroups per CU are resident (pass_round each); up to one per CU left over run alone on their CU
+float pass_ms(const PathCost& c, int n, int np, int n_cu) {
+    const int wgs = n * np, full = wgs / (2 * n_cu), rem = wgs % (2 * n_cu);
+    return c.pass_round * full + (rem == 0 ? 0.f : rem <= n_cu ? c.pass_single : c.pass_round);
 }
 void decide_path(ls_handle* h) {
     const long long before = plan_code(h);
@@ -788,13 +789,15 @@ void decide_path(ls_handle* h) {
     else if (h->B > 0) {
         const bool bf = h->precision != 0;
         const PathCost& c = bf ? (h->var == kTED ? kCostTedBf : kCostBeatBf) : (h->var == kTED ? kCostTed : kCostBeat);
-        const int B = h->B, np = h->plan_pair ? 1 : 2, round = 512 / np, unit = 256 / np;     // unit: samples that put ONE pass workgroup on every CU
+        const int B = h->B, np = h->plan_pair ? 1 : 2, round = 2 * h->n_cu / np, unit = h->n_cu / np;     // round: samples of one fused round; unit: samples that put ONE pass workgroup on every CU
+        const float thr = 256.0f / (float)h->n_cu;          // throughput-bound terms (measured on 256 CUs) on a smaller / larger device
+        const int gmax = h->coop_groups_max > 0 ? h->coop_groups_max : 1;
         auto cost = [&](int path, int n) -> float {
             switch (path) {
             case 0: return c.fused_round * ((n + round - 1) / round);
-            case 1: return have_long && !bf ? c.long_base + c.long_per_sample * n : 1e30f;
-            case 2: return bf ? 1e30f : coop_ms(c, n, np);
-            default: return pass_ms(c, n, np);
+            case 1: return have_long && !bf ? c.long_base + c.long_per_sample * thr * n : 1e30f;
+            case 2: return bf || h->coop_groups_max < np ? 1e30f : coop_ms(c, n, np, gmax);
+            default: return pass_ms(c, n, np, h->n_cu);
             }
         };
         // head: the full fused rounds; the remainder r on one family, or -- beyond one pass workgroup per CU -- `unit` samples on the
@@ -1017,6 +1020,14 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (e != hipSuccess) return fail(nullptr, LS_EHIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
     ls_handle* h = new ls_handle();
     h->cfg = *cfg;
+    {   // chip geometry: the step-time models were measured on 256 CUs; rounds, residency and the throughput-bound terms follow the device
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, cfg->device);
+        if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipGetDeviceProperties(%d): %s", cfg->device, hipGetErrorString(e)); }
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        h->coop_groups_max = 2 * h->n_cu / 8 < kCoopMaxGroups ? 2 * h->n_cu / 8 : kCoopMaxGroups;       // every slice of a launch must be resident: they wait for each other
+        h->timing.n_cus = h->n_cu;
+    }
 #ifdef LS_DEBUG
     if (const char* ab = getenv("LS_ABLATE")) h->ablate = atoi(ab);
     if (const char* pr = getenv("LS_PROF")) { h->prof_on = true; h->prof_wg = atoi(pr); }
@@ -1152,6 +1163,8 @@ int ls_set_path(ls_handle* h, int mode) {
     if (mode < 0 || mode > 4) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel, 4 one workgroup per (sample, pass))", mode);
     if (mode >= 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has neither the sample-split nor the one-pass-per-workgroup kernel", kT);
     if (mode == 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split kernel is exact fp32 only");
+    if (mode == 3 && h->coop_groups_max < 2)
+        return fail(h, LS_EUNSUPPORTED, "the sample-split kernel needs the 16 workgroups of a sample resident at once (two per CU): %d CUs are too few", h->n_cu);
     if (mode == 2 && h->fused && h->lw_wtp.p == nullptr && h->committed) return fail(h, LS_EUNSUPPORTED, "batch-level kernels need S <= 160");
     if (mode == 1 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no fused kernel", kT);
     if (mode != h->path_mode) { h->path_mode = mode; h->prepared = false; free_graph(h); }      // takes effect at the next ls_prepare (workspaces)

@@ -12,6 +12,8 @@ on how many GPUs the batch is split over.  Works with backend "nccl" (= RCCL) on
 """
 from __future__ import annotations
 
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -19,6 +21,11 @@ import torch.distributed as dist
 #: process group the data collectives run on: None = the default group.  ``init_groups`` sets it to an RCCL group when one comes up
 #: healthy and leaves the gloo default group (host copies) otherwise.
 _GROUP = None
+
+
+#: True once an RCCL probe thread has been abandoned (it may sit in a hung collective for good): ``finish`` then ends the process with
+#: ``os._exit`` instead of waiting for interpreter shutdown to get past that thread and RCCL's own teardown.
+_ABANDONED_PROBE = False
 
 
 def _on() -> bool:
@@ -42,8 +49,16 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
     An RCCL group over the same ranks is then created and PROBED (one all_reduce + one all_gather on ``device``, waited for with a
     timeout in a helper thread); only if every rank's probe succeeded do the data collectives move onto it.  Returns a record for
     the bench line: {collective_backend, rccl_ranks, rccl_error}."""
+    import os
     import threading
     from datetime import timedelta
+    global _ABANDONED_PROBE
+    # A collective of the probe that hangs stays registered with ProcessGroupNCCL's watchdog; with torch's default error handling the
+    # watchdog aborts the WHOLE process when it times out -- minutes after the run has moved on over gloo.  The probe's verdict is
+    # taken here, by the join below, so the watchdog must not be able to end the process: no async error handling, and a group timeout
+    # far beyond the join's (the abandoned thread is dealt with by `finish`).
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(minutes=timeout_min))
     use_group(None)
     info = {"collective_backend": "gloo", "rccl_ranks": 0, "rccl_error": None}
@@ -57,7 +72,7 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
         try:
             if getattr(device, "type", "cpu") == "cuda":
                 torch.cuda.set_device(device)       # the current device is per host thread: this helper thread starts on device 0
-            g = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=timedelta(seconds=max(30.0, probe_timeout_s)))
+            g = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=timedelta(seconds=max(3600.0, 20.0 * probe_timeout_s)))
             box["group"] = g
             t = torch.full((1024,), float(rank + 1), device=device)
             dist.all_reduce(t, group=g)
@@ -75,7 +90,9 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
     th.start()
     th.join(probe_timeout_s)
     if th.is_alive():
-        ok, err = 0, f"RCCL probe did not finish within {probe_timeout_s:.0f} s"
+        ok, err = 0, f"RCCL probe did not finish within {probe_timeout_s:.0f} s (probe thread abandoned; the process will leave through os._exit)"
+        _ABANDONED_PROBE = True
+        print(f"[shard] rank {rank}: {err}", file=sys.stderr, flush=True)
     elif not box.get("ok"):
         ok, err = 0, box.get("err", "RCCL probe failed")
     agree = torch.tensor([ok], dtype=torch.int32)
@@ -85,7 +102,26 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
         info.update(collective_backend="nccl", rccl_ranks=world)
     else:
         info["rccl_error"] = err or "RCCL probe failed on another rank"
+        if box.get("ok") and not th.is_alive():          # this rank's RCCL came up but another rank's did not: give the communicator back
+            try:
+                dist.destroy_process_group(box["group"])
+            except Exception as e:                      # noqa: BLE001  (teardown of a half-working RCCL must not take the run down either)
+                info["rccl_error"] += f"; destroy_process_group: {e!r}"[:120]
+    info["rccl_probe_abandoned"] = _ABANDONED_PROBE
     return info
+
+
+def finish(code: int = 0) -> None:
+    """Last call of a multi-rank program.  If an RCCL probe thread was abandoned, interpreter shutdown would wait on RCCL's teardown
+    of a communicator that never finished coming up: flush what was printed and leave through ``os._exit`` -- deterministically, and
+    said so on stderr.  Otherwise: the ordinary ``destroy_process_group``."""
+    import os
+    if _ABANDONED_PROBE:
+        print(f"[shard] leaving through os._exit({code}): an RCCL probe thread is still inside a collective", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(code)
+    if _on():
+        dist.destroy_process_group()
 
 
 def _stage(t: torch.Tensor) -> torch.Tensor:

@@ -192,6 +192,24 @@ def test_bench_threads_launcher_two_handles_on_one_gpu():
     print("threads launcher, 2 handles on one GPU:", thr["value"], "| strong 300:", strong["value"])
 
 
+def test_eight_launchers_on_one_gpu_both_ways():
+    """What one GPU allows of the driver's N = 8 run: eight torchrun ranks on cuda:0 (gloo control plane, RCCL probed and refused,
+    every rank re-generating its neighbour's shard bitwise, ONE JSON line), and eight engine handles driven by eight threads of one
+    process.  Throughput here is eight step loops time-sharing one GPU (eight streams over the runtime's hardware queues), not a
+    scaling number; what is checked is that nothing deadlocks or serialises completely: the eight handles together reach at least
+    half of what one handle does with the same 512 clips."""
+    common = ["--steps", "1", "--warmup", "1", "--diffusion-steps", "40", "--no-cpu-baseline", "--legs", "none"]
+    eight = _bench(ROOT, ["--gpus", "8", "--ranks-share-device", "--batch", "16"] + common, timeout=1800)
+    assert eight["n_gpus"] == 8 and eight["config"]["global_batch"] == 128 and eight["collective_backend"] == "gloo" and eight["rccl_error"]
+    assert eight["shard_check"]["ranks"] == 8 and eight["shard_check"]["bitwise_equal"] and eight["parity_in_run"]["ok"]
+    thr_common = ["--steps", "2", "--warmup", "1", "--diffusion-steps", "100"]
+    thr = _bench(ROOT, ["--gpus", "8", "--launcher", "threads", "--ranks-share-device", "--batch", "64", "--path", "pass"] + thr_common)
+    one = _bench(ROOT, ["--gpus", "1", "--launcher", "threads", "--batch", "512"] + thr_common)
+    assert thr["n_gpus"] == 8 and thr["config"]["global_batch"] == 512 and thr["shard_check"]["bitwise_equal"] and thr["shard_check"]["ranks"] == 8
+    print("8 ranks on one GPU:", eight["value"], "| 8 handles / 8 threads:", thr["value"], "| 1 handle, 512 clips:", one["value"])
+    assert thr["value"] > 0.5 * one["value"]
+
+
 def test_two_handles_driven_from_two_threads_equal_the_sequential_results():
     """include/ls_hip.h: "a handle is not thread-safe, distinct handles are independent".  Two handles on cuda:0 (different batches,
     different kernels: the fused one and the sample-split one), each driven by its own thread at the same time, give bitwise the

@@ -276,3 +276,104 @@ def test_world4_bring_up_and_gather_order():
         info, red, whole, be = res[r]
         assert info["collective_backend"] == "gloo" and info["rccl_ranks"] == 0 and be == "gloo", info
         assert red == [10.0] * 4 and whole == [float(k) for k in range(world) for _ in range(2)]
+
+
+# ---- eight ranks (the driver's N = 8 run is the first time eight launchers meet): bring-up verdict, reduction, rank-ordered gather
+# with a RAGGED total, and the shard cross-check, all over gloo ---------------------------------------------------------------------
+def _world8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        from livelyspeaker_amd import shard
+        info = shard.init_groups(torch.device("cpu"), rank, world, want_rccl=True, probe_timeout_s=60.0, timeout_min=3.0)
+        t = torch.full((4,), float(rank + 1))
+        shard.all_reduce_(t)
+        total = 3 * world + 5                                             # ragged: the first five ranks own one sample more
+        first, count = shard.shard_range(total, world, rank)
+
+        def gen(f, c, shard_index):
+            idx = torch.arange(f, f + c, dtype=torch.float32)
+            return (torch.cos(idx * 78.233)[:, None, None, None] * torch.ones(c, 2, 1, 3)).contiguous()
+
+        mine = gen(first, count, rank)
+        whole = shard.gather_samples(mine, total)
+        chk = shard.cross_check(gen, mine, total)
+        q.put((rank, (info, t.tolist(), whole[:, 0, 0, 0].tolist(), (first, count), chk)))
+        shard.finish(0)
+    except Exception as e:
+        import traceback
+        q.put((rank, RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")))
+
+
+def test_world8_bring_up_ragged_gather_and_cross_check():
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=400) for _ in ps)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    total = 3 * world + 5
+    want = torch.cos(torch.arange(total, dtype=torch.float32) * 78.233).tolist()
+    covered = []
+    for r in range(world):
+        assert not isinstance(res[r], Exception), res[r]
+        info, red, whole, (first, count), chk = res[r]
+        assert info["collective_backend"] == "gloo" and info["rccl_ranks"] == 0 and not info["rccl_probe_abandoned"], info
+        assert red == [36.0] * 4 and whole == want                         # every rank holds the whole batch in global order
+        assert chk["ranks"] == 8 and chk["bitwise_equal"] and chk["checksum_recomputed"] == chk["checksum_sharded"], chk
+        covered += list(range(first, first + count))
+    assert covered == list(range(total))
+
+
+# ---- an RCCL probe that HANGS: the run goes on over gloo, says so, and the process leaves through os._exit (exit code kept) --------
+def _hung_probe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+    real_new_group = dist.new_group
+
+    def hanging_new_group(*a, **k):
+        if k.get("backend") == "nccl":
+            time.sleep(3600)                                               # a communicator that never comes up
+        return real_new_group(*a, **k)
+
+    dist.new_group = hanging_new_group
+    try:
+        from livelyspeaker_amd import shard
+        info = shard.init_groups(torch.device("cpu"), rank, world, want_rccl=True, probe_timeout_s=3.0, timeout_min=2.0)
+        t = torch.full((2,), float(rank + 1))
+        shard.all_reduce_(t)
+        q.put((rank, (info, t.tolist(), os.environ.get("TORCH_NCCL_ASYNC_ERROR_HANDLING"))))
+        dist.barrier()
+        shard.finish(7)                                                    # must not wait for the sleeping probe thread
+        q.put((rank, "finish returned"))
+    except Exception as e:
+        import traceback
+        q.put((rank, RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")))
+
+
+def test_a_hung_rccl_probe_is_abandoned_and_the_process_exits_deterministically():
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_hung_probe_worker, args=(r, 2, port, q)) for r in range(2)]
+    t0 = time.time()
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in ps)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 7                                             # os._exit(7): not killed by a watchdog, not stuck in teardown
+    assert time.time() - t0 < 200
+    for r in range(2):
+        assert not isinstance(res[r], Exception), res[r]
+        info, red, env = res[r]
+        assert info["collective_backend"] == "gloo" and info["rccl_probe_abandoned"] and "abandoned" in info["rccl_error"], info
+        assert red == [3.0, 3.0] and env == "0"
+    assert q.empty()                                                       # nobody got past finish()
