@@ -596,7 +596,7 @@ hipError_t run_coop(ls_handle* h, const StepArgs& s, int first, int n, bool pair
         c.cx = h->co_x.f(); c.cpart = h->co_part.f();
         c.cgran = static_cast<unsigned long long*>(h->co_gran.p); c.cflag = static_cast<unsigned long long*>(h->co_flag.p);
         c.cerr = static_cast<unsigned*>(h->co_err.p);
-        c.epoch = (++h->coop_launches) * 64u;
+        c.epoch = (++h->coop_launches) * kCoopEpochStride;      // tags of one launch: epoch + 1 .. epoch + 2 * layers + 1 < the stride (checked in decide_path / ls_set_path)
         c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap;
         hipError_t e = launch_step_coop(h->var, c, first + n - b0 < per ? first + n - b0 : per, st);
         if (e != hipSuccess) return e;
@@ -796,7 +796,7 @@ void decide_path(ls_handle* h) {
             switch (path) {
             case 0: return c.fused_round * ((n + round - 1) / round);
             case 1: return have_long && !bf ? c.long_base + c.long_per_sample * thr * n : 1e30f;
-            case 2: return bf || h->coop_groups_max < np ? 1e30f : coop_ms(c, n, np, gmax);
+            case 2: return bf || h->coop_groups_max < np || 2 * h->cfg.layers + 2 > (int)kCoopEpochStride ? 1e30f : coop_ms(c, n, np, gmax);
             default: return pass_ms(c, n, np, h->n_cu);
             }
         };
@@ -1163,6 +1163,8 @@ int ls_set_path(ls_handle* h, int mode) {
     if (mode < 0 || mode > 4) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel, 4 one workgroup per (sample, pass))", mode);
     if (mode >= 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has neither the sample-split nor the one-pass-per-workgroup kernel", kT);
     if (mode == 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split kernel is exact fp32 only");
+    if (mode == 3 && 2 * h->cfg.layers + 2 > (int)kCoopEpochStride)
+        return fail(h, LS_EUNSUPPORTED, "the sample-split kernel tags its hand-offs with %u values per launch: %d layers need %d", kCoopEpochStride, h->cfg.layers, 2 * h->cfg.layers + 2);
     if (mode == 3 && h->coop_groups_max < 2)
         return fail(h, LS_EUNSUPPORTED, "the sample-split kernel needs the 16 workgroups of a sample resident at once (two per CU): %d CUs are too few", h->n_cu);
     if (mode == 2 && h->fused && h->lw_wtp.p == nullptr && h->committed) return fail(h, LS_EUNSUPPORTED, "batch-level kernels need S <= 160");

@@ -150,6 +150,7 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st);
 
 // sample-split step kernel for small batches (ls_coop.hip): 16 workgroups per sample (2 passes x 8 channel slices of 4 waves)
 constexpr int kCoopMaxGroups = 64;     // (sample, pass) groups of one launch: 512 workgroups = two per CU, all resident at once
+constexpr unsigned kCoopEpochStride = 64;   // hand-off tags per launch: 2 * layers + 1 of them are used, so layers <= 31 (the reference: 8)
 hipError_t init_coop_kernels();
 hipError_t launch_step_coop(Variant v, const StepArgs& a, int nsamples, hipStream_t st);
 

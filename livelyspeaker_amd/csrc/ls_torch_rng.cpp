@@ -127,13 +127,28 @@ struct Mt {
     }
 void mt_block_base(uint32_t* __restrict__ st) { LS_MT_BLOCK_BODY }
 void mt_temper_base(const uint32_t* __restrict__ src, uint32_t* __restrict__ out, size_t m) { LS_MT_TEMPER_BODY }
+// ISA clones and run-time dispatch are x86 features: elsewhere the engine library still builds, the word loops run in their base form
+// and the FMA-contracted float transforms (variants 1..4) report LS_EUNSUPPORTED (the Python side then keeps torch's own draws)
+#if defined(__x86_64__)
+#define LS_TRNG_X86 1
 __attribute__((target("avx2"))) void mt_block_avx2(uint32_t* __restrict__ st) { LS_MT_BLOCK_BODY }
 __attribute__((target("avx2"))) void mt_temper_avx2(const uint32_t* __restrict__ src, uint32_t* __restrict__ out, size_t m) { LS_MT_TEMPER_BODY }
 __attribute__((target("avx512f,prefer-vector-width=512"))) void mt_block_avx512(uint32_t* __restrict__ st) { LS_MT_BLOCK_BODY }
 __attribute__((target("avx512f,prefer-vector-width=512"))) void mt_temper_avx512(const uint32_t* __restrict__ src, uint32_t* __restrict__ out, size_t m) { LS_MT_TEMPER_BODY }
+inline int mt_isa() { static const int isa = __builtin_cpu_supports("avx512f") ? 2 : __builtin_cpu_supports("avx2") ? 1 : 0; return isa; }
+inline bool have_fma() { return __builtin_cpu_supports("fma"); }
+#else
+#define LS_TRNG_X86 0
+inline void mt_block_avx2(uint32_t* st) { mt_block_base(st); }
+inline void mt_temper_avx2(const uint32_t* src, uint32_t* out, size_t m) { mt_temper_base(src, out, m); }
+inline void mt_block_avx512(uint32_t* st) { mt_block_base(st); }
+inline void mt_temper_avx512(const uint32_t* src, uint32_t* out, size_t m) { mt_temper_base(src, out, m); }
+inline int mt_isa() { return 0; }
+inline bool have_fma() { return false; }
+#endif
 
 void Mt::fill_words(uint32_t* out, size_t n) {
-    static const int isa = __builtin_cpu_supports("avx512f") ? 2 : __builtin_cpu_supports("avx2") ? 1 : 0;
+    const int isa = mt_isa();
     while (n > 0) {
         if (left - 1 == 0) {                 // word(): --left == 0 -> next_state(), and the word it then reads leaves left at kN
             if (isa == 2) mt_block_avx512(st); else if (isa == 1) mt_block_avx2(st); else mt_block_base(st);
@@ -155,7 +170,11 @@ void Mt::fill_words(uint32_t* out, size_t n) {
 inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t as_u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
+#if LS_TRNG_X86
 #define LS_FMA_TARGET __attribute__((target("fma")))      // fmaf as one instruction (through libm it is a call per operation)
+#else
+#define LS_FMA_TARGET
+#endif
 LS_FMA_TARGET inline float cephes_logf(float x, int variant) {
     const bool invalid = x <= 0.0f;
     x = std::fmax(x, as_f(0x00800000u));                    // cut off denormalized stuff
@@ -415,7 +434,8 @@ extern "C" {
 // torch.randn(n) (contiguous float32) / torch.randn_like of a [T][B][J][F]-memory-order view, from the state blob; see ls_hip.h
 int ls_trng_randn(uint8_t* state, size_t state_bytes, float* out, size_t n, int variant, int n_threads) {
     if (!state || state_bytes != kStateBytes || (!out && n) || variant < 0 || variant > 4) return LS_EINVAL;
-    if (variant > 0 && !__builtin_cpu_supports("fma")) return LS_EUNSUPPORTED;
+    if (variant > 0 && !have_fma()) return LS_EUNSUPPORTED;
+    try {
     Mt g;
     if (!g.load(state)) return LS_EINVAL;
     {
@@ -428,13 +448,15 @@ int ls_trng_randn(uint8_t* state, size_t state_bytes, float* out, size_t n, int 
     }
     g.store(state);
     return LS_OK;
+    } catch (...) { return LS_ENOMEM; }     // nothing (a failed allocation of a word buffer, a thread that could not start) crosses the C ABI
 }
 
 int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, int F, int T, int n_steps, int first_contiguous, float* eps,
                        float* noise, int variant, int n_threads) {
     if (variant < 0 || variant > 4) return LS_EINVAL;
-    if (variant > 0 && !__builtin_cpu_supports("fma")) return LS_EUNSUPPORTED;
+    if (variant > 0 && !have_fma()) return LS_EUNSUPPORTED;
     if (!state || state_bytes != kStateBytes || !eps || !noise || B < 1 || D < 1 || J < 1 || F < 1 || T < 1 || n_steps < 0) return LS_EINVAL;
+    try {
     Mt g;
     if (!g.load(state)) return LS_EINVAL;
     const size_t ne = (size_t)B * D, nx = (size_t)B * J * F * T;
@@ -458,6 +480,7 @@ int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, 
     }
     g.store(state);
     return LS_OK;
+    } catch (...) { return LS_ENOMEM; }
 }
 
 }  // extern "C"

@@ -431,10 +431,8 @@ class GaussianDiffusion:
         """p_sample_loop_progressive / ddim_sample_loop_progressive (gaussian_diffusion.py:673-743, 945-1014): the same draws in the same
         order as the reference's generator -- x_T, then per step what p_sample / ddim_sample draws -- one step-kernel launch per yield,
         tensors device-resident when the model is (no host synchronisation between yields)."""
-        self._reject(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
         if device is None:
             device = next(model.parameters()).device
-        assert isinstance(shape, (tuple, list))
         if noise is not None:
             img = noise
         else:
@@ -456,15 +454,33 @@ class GaussianDiffusion:
             yield out
             img = out["sample"]
 
+    def _progressive_args(self, model, shape, denoised_fn, cond_fn, model_kwargs, randomize_class, cond_fn_with_grad):
+        """What can be refused is refused when the generator is REQUESTED, not at its first ``next()`` (a generator body does not run
+        until then): unbuilt hooks, a shape that is not a 4-tuple of this model's (joints, feats, frames), missing conditioning.  The
+        draws stay in the generator, where the reference's are (gaussian_diffusion.py:700-743)."""
+        self._reject(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        if not isinstance(shape, (tuple, list)) or len(shape) != 4:
+            raise ValueError(f"shape must be (batch, njoints, nfeats, nframes), got {shape!r}")
+        shape = tuple(int(v) for v in shape)
+        inner = getattr(model, "model", model)
+        want = tuple(getattr(inner, k, None) for k in ("njoints", "nfeats", "nframes"))
+        if None not in want and shape[1:] != want:
+            raise ValueError(f"shape {shape} does not match the model's (njoints, nfeats, nframes) = {want}")
+        if model_kwargs is None or "y" not in model_kwargs:
+            raise ValueError("model_kwargs={'y': conditioning} is required (RAG.forward reads y['audio_input'], y['origin_x'], ...)")
+        return shape, model_kwargs
+
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
                                   randomize_class=False, cond_fn_with_grad=False, const_noise=False):
+        shape, model_kwargs = self._progressive_args(model, shape, denoised_fn, cond_fn, model_kwargs, randomize_class, cond_fn_with_grad)
         return self._progressive(_lib.LS_SAMPLER_DDPM, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
                                  skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, 0.0)
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                      model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
                                      randomize_class=False, cond_fn_with_grad=False, const_noise=False):
+        shape, model_kwargs = self._progressive_args(model, shape, denoised_fn, cond_fn, model_kwargs, randomize_class, cond_fn_with_grad)
         return self._progressive(_lib.LS_SAMPLER_DDIM, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
                                  skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, eta)
 

@@ -24,12 +24,14 @@ class UniformSampler:
         return self._weights
 
     def sample(self, batch_size, device):
-        """(timesteps, weights) -- ``np.random.choice`` exactly as resample.py:52-58, so ``np.random.seed`` reproduces
-        the reference's timestep stream."""
-        w = self.weights()
-        p = w / np.sum(w)
-        indices_np = np.random.choice(len(p), size=(batch_size,), p=p)
-        indices = th.from_numpy(indices_np).long().to(device)
-        weights_np = 1 / (len(p) * p[indices_np])
-        weights = th.from_numpy(weights_np).float().to(device)
-        return indices, weights
+        """(timesteps, importance weights) for one batch.  The contract with the reference (resample.py:52-58) is ONE call of
+        ``np.random.choice(T, size=(batch,), p=probabilities)`` per batch on numpy's global generator, so that ``np.random.seed``
+        replays the reference's timestep stream; the weight of a drawn step is 1 / (T * its probability) -- all ones for the
+        uniform sampler."""
+        prob = np.asarray(self.weights(), dtype=np.float64)
+        prob = prob / prob.sum()
+        n_steps = prob.shape[0]
+        drawn = np.random.choice(n_steps, size=(batch_size,), p=prob)
+        importance = np.reciprocal(n_steps * prob[drawn])
+        return (th.as_tensor(drawn, dtype=th.long, device=device),
+                th.as_tensor(importance, dtype=th.float32, device=device))

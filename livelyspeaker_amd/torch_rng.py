@@ -58,7 +58,9 @@ def _probe() -> int:
         return -1
     keep = th.get_rng_state()
     try:
-        th.manual_seed(0x5EED)
+        # the CPU generator only: th.manual_seed would also reseed every CUDA generator, i.e. silently reset the caller's device-side
+        # RNG streams the first time this mode is used in a process
+        th.default_generator.manual_seed(0x5EED)
         th.randn(3)                                     # leave a cached double sample behind: the hand-over is part of the contract
         s0 = th.get_rng_state()
         shape = dict(n=3, B=3, D=512, J=3, F=3, T=5)    # odd element counts: the cached sample crosses step boundaries

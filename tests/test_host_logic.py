@@ -444,3 +444,23 @@ def test_committed_traffic_profile_was_taken_on_the_shipped_step_kernel():
     now = hashlib.sha256(open(os.path.join(ROOT, "livelyspeaker_amd", "csrc", "ls_step_kernel.h"), "rb").read()).hexdigest()
     stale = [k for k, e in doc["entries"].items() if e["kernel_source_sha256"] != now]
     assert not stale, f"re-take profiles/k_step_traffic.json (tools/traffic_measure.sh on the GPU box): stale entries {stale}"
+
+
+def test_progressive_generators_refuse_bad_arguments_when_requested_not_at_first_next():
+    """A generator body runs at the first next(): the argument checks of p_sample_loop_progressive / ddim_sample_loop_progressive are made
+    by the call itself (unbuilt hooks, a shape that is not this model's, missing conditioning); the draws stay inside the generator."""
+    model, diff = create_model_and_diffusion(mk_args(steps=5), "")
+    cfgm = ClassifierFreeSampleModel(model)
+    y = {"dummy": torch.zeros(2)}
+    for fn in (diff.p_sample_loop_progressive, diff.ddim_sample_loop_progressive):
+        with pytest.raises(NotImplementedError):
+            fn(cfgm, (2, 9, 3, 34), cond_fn=lambda *a: None, model_kwargs={"y": y})
+        with pytest.raises(ValueError, match="njoints"):
+            fn(cfgm, (2, 9, 3, 30), model_kwargs={"y": y})
+        with pytest.raises(ValueError, match="shape must be"):
+            fn(cfgm, (2, 27, 34), model_kwargs={"y": y})
+        with pytest.raises(ValueError, match="model_kwargs"):
+            fn(cfgm, (2, 9, 3, 34), model_kwargs=None)
+        state = torch.get_rng_state()
+        gen = fn(cfgm, [2, 9, 3, 34], model_kwargs={"y": y}, device="cpu")          # accepted: nothing has run or been drawn yet
+        assert torch.equal(state, torch.get_rng_state()) and hasattr(gen, "__next__")
