@@ -761,7 +761,7 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 // Step-time models in ms, measured on MI355X (profiles/r05_throughput_vs_batch.md): the plan is the cheapest of
 //   all sample-split | all batch-level | all fused | all pass | full fused rounds + the remainder on sample-split, batch-level or pass.
 struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single; };
-constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.70f, 0.423f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.842f, 0.503f};
+constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.697f, 0.412f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.496f};
 // bf16x3 (opt-in precision) exists in the fused and the one-pass-per-workgroup kernels only; measured on MI355X (tools/bf16x3_time.py)
 constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.302f};
 float coop_ms(const PathCost& c, int n, int np, int gmax) {

@@ -52,7 +52,7 @@ typedef __attribute__((address_space(1))) unsigned* pass_gu32p;
 #define LS_PASS_PFD 2                       // bf16x3 channel mixing: weight fragments requested this many k blocks ahead
 #endif
 #ifndef LS_PASS_BPREF
-#define LS_PASS_BPREF 0                     // channel mixing: the LDS operands of k block q + 1 are requested while block q is multiplied
+#define LS_PASS_BPREF 1                     // channel mixing: the LDS operands of k block q + 1 are requested while block q is multiplied
 #endif
 
 // PREC = 1: bf16x3 split precision (opt-in, as in k_step): operands u = hi + lo as two bf16 planes, W.u ~= hi.hi + hi.lo + lo.hi on
@@ -561,12 +561,13 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             f4 An[4];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) An[c4] = wload4(wrs, lane * 16, woff(0, c4));
-            f4 Bn[2], Un[kRemMfma ? NRG : NRV];
+            // LDS operands: the two full tiles' fragments meet the first MFMA of the k block, so they are requested one block ahead
+            // (LS_PASS_BPREF; one wave per SIMD and workgroup: nobody else hides the LDS round trip); the ragged rows' are first used
+            // behind eight MFMAs and are read at the top of their own block
+            f4 Bn[2];
             auto ldb = [&](int q) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) Bn[t] = *(ldsp4)(ub0 + 16 * t * kUStride + 16 * q);
-#pragma unroll
-                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r) Un[r] = *(ldsp4)(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
             };
             if (LS_PASS_BPREF) ldb(0);
 #pragma unroll 2
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) Bv[t] = Bn[t];
 #pragma unroll
-                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r) Ur[r] = Un[r];
+                for (int r = 0; r < (kRemMfma ? NRG : NRV); ++r) Ur[r] = *(ldsp4)(ur + (kRemMfma ? 4 : 1) * r * kUStride + 16 * q);
                 // per k: [8 MFMAs][4 * NREM scalar FMAs], order pinned (k_step: the compiler's own order stalls on the FMAs' ds_reads)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
