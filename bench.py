@@ -19,6 +19,8 @@ besides the contract's keys:
   "single_pass"    the guidance-scale-1 workload (uncond pass legitimately skipped), own FLOP count -- never mixed into `value`
   "livelyspeaker"  BASELINE configs[2] as the reference runs it: SAG decode + ddim100 / skip 80 refine, own roofline
   "configs4_beat"  BASELINE configs[4]: BEAT at 34 frames (B=256) and the SYNTHETIC 150-frame variant (B=32), own rooflines
+  "mid_batches"    batches that do not fill the chip a whole number of times (128 / 160 / 384 clips): the engine's plan, own rooflines;
+                   BEAT B=256 in the reference's own RNG mode (host-RNG bound stated)
   "shard_check"    the config-4 premise on hardware: every rank re-generates ANOTHER rank's shard via sample_offset
   "split_precision", "train_step"   secondary legs
   "cpu_baseline"   torch-CPU port of the reference algorithm timed on this box's host cores (bounded sample)
@@ -426,7 +428,7 @@ def livelyspeaker_leg(cfg, model_sd, dev, B, fence, reps=3, world=1, rank=0, max
                          "call_frac_note": "k_step FLOPs of the 20 steps at the MFMA peak / whole-call wall time (SAG + prepare + loop + host)"}}
 
 
-def other_config_leg(dataset, B, dev, fence, steps=1000):
+def other_config_leg(dataset, B, dev, fence, steps=1000, noise="philox"):
     """One more BASELINE config measured in the same run, compactly: a fresh model of that dataset, one warm-up and one timed
     `p_sample_loop` call (1000-step DDPM, CFG 1.5, Philox noise), own FLOP count.  `beat150` is the SYNTHETIC 150-frame variant."""
     import torch
@@ -440,9 +442,11 @@ def other_config_leg(dataset, B, dev, fence, steps=1000):
     model.eval()
     model.cache_conditioning = False
     cfgm = ClassifierFreeSampleModel(model)
-    diffusion.noise_source = "philox"
+    diffusion.noise_source = noise
     y = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_cond(cfg, B, scale=1.5).items()}
     shape = (B, cfg.njoints, cfg.nfeats, cfg.nframes)
+    if noise == "torch_cpu":
+        torch.manual_seed(233)
     call = lambda: diffusion.p_sample_loop(cfgm, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
                                            progress=False, dump_steps=None, noise=None, const_noise=False)
     call()
@@ -460,15 +464,30 @@ def other_config_leg(dataset, B, dev, fence, steps=1000):
              3: "one-pass-per-workgroup step kernel (ls_pass_kernel.h: a workgroup per (clip, CFG pass), two per CU)"}
     kernels = names[tm["step_path"]] + (f" + {tm['tail_samples']} clips on the {names[tm['tail_path']].split(' (')[0]}" if tm["tail_samples"] else "") \
         + (f" + {tm['tail2_samples']} clips on the {names[tm['tail2_path']].split(' (')[0]}" if tm["tail2_samples"] else "")
+    seeds_extra = {}
+    if noise == "torch_cpu":
+        n_seg = int(diffusion.last_tape_segments)
+        words = 2 * B * 512 + B * cfg.jf * cfg.nframes
+        host = diffusion.last_host_rng_ms / steps
+        seeds_extra = {"identical_seeds": {"host_rng_ms_per_step": round(host, 3), "upload_ms_per_step": round(tm["tape_upload_ms"] / steps, 3),
+                                           "loop_ms_per_step": round(km, 4), "normals_per_step": words, "segments": n_seg,
+                                           "native_stream": bool(getattr(diffusion, "last_host_rng_native", False)),
+                                           "bound": ("host RNG" if host > 0.8 * km else "step kernel") + f": one sequential mt19937 stream of {words / 1e6:.2f} M "
+                                                    f"normals per step takes {host:.2f} ms on the host (the [T][B][J][F]-ordered randn_like is torch's "
+                                                    "per-element double Box-Muller: two 32-bit words per normal from ONE generator); the loop advanced at "
+                                                    f"{km:.2f} ms per step -- a segment is drawn while the previous one runs, so a step costs the slower of "
+                                                    "the host draws and the step kernel (the same workload on Philox noise: `configs4_beat`).  Faster needs "
+                                                    "mt19937 jump-ahead (several producers), not done"}}
     model.engine().close()
-    return {"workload": f"{dataset.upper()} RAG, batch {B} x {cfg.nframes} frames, {steps}-step DDPM, CFG 1.5, Philox noise"
+    return {"workload": f"{dataset.upper()} RAG, batch {B} x {cfg.nframes} frames, {steps}-step DDPM, CFG 1.5, "
+                        + ("noise_source='torch_cpu' (the reference's own draws in its order: 'identical seeds')" if noise == "torch_cpu" else "Philox noise")
                         + (" -- SYNTHETIC shape (150 frames: the reference cannot run it), perf-only, no parity claim vs the reference"
                            if dataset == "beat150" else ""),
             "value": round(B * cfg.nframes / el, 1), "unit": "pose-frames/s", "ms_per_call": round(el * 1e3, 2),
             "kernels": kernels + (" -- self-pinned: checked against this repository's oracle only" if dataset == "beat150" else ""),
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "step_ms": round(km, 4),
-                         "flop_per_sample_step": 2 * FLOP_PER_FORWARD[dataset]}}
+                         "flop_per_sample_step": 2 * FLOP_PER_FORWARD[dataset]}, **seeds_extra}
 
 
 def _self_launch(a):
@@ -737,7 +756,7 @@ def main():
             diffusion.sample_offset, diffusion.philox_seed = first, None
 
     extra = not a.no_extra_legs and a.precision == "fp32" and a.legs != "none"
-    legs = set(("single", "split", "lively", "beat", "train", "seeds", "small") if a.legs in ("all", "none") else a.legs.split(","))
+    legs = set(("single", "split", "lively", "beat", "train", "seeds", "small", "mid") if a.legs in ("all", "none") else a.legs.split(","))
 
     # Secondary object: guidance scale 1 (what the reference's callers run): the uncond pass is legitimately skipped
     single = None
@@ -874,6 +893,19 @@ def main():
             except Exception as e:
                 others[name] = {"error": repr(e)[:300]}
 
+    # Batches that are not a multiple of the chip (the reference's loaders end on ragged batches, scripts/test_RAG_ted.py:43-82): what the
+    # engine's plan makes of them -- the one-pass-per-workgroup kernel alone or behind full fused rounds -- and BEAT B = 256 in the
+    # reference's own RNG mode (2.7 M normals per step from one sequential host stream)
+    mid = None
+    if extra and a.dataset == "ted" and world == 1 and "mid" in legs:
+        mid = {}
+        for name, ds, bb, nz in (("ted_b128", "ted", 128, "philox"), ("ted_b384", "ted", 384, "philox"), ("ted_b160", "ted", 160, "philox"),
+                                 ("beat_b256_identical_seeds", "beat", 256, "torch_cpu")):
+            try:
+                mid[name] = other_config_leg(ds, bb, dev, fence, noise=nz)
+            except Exception as e:
+                mid[name] = {"error": repr(e)[:300]}
+
     # Secondary leg: one optimisation step of the denoiser, data-parallel over the ranks.
     train = None
     if extra and (a.train_leg or world == 1) and not a.no_train_leg and not strong and "train" in legs:
@@ -945,6 +977,8 @@ def main():
             rec["livelyspeaker"] = lively
         if others is not None:
             rec["configs4_beat"] = others
+        if mid is not None:
+            rec["mid_batches"] = mid
         if split is not None:
             rec["split_precision"] = split
         if train is not None:
