@@ -141,7 +141,8 @@ struct ls_handle {
     std::string graph_key;
 
     ls_timing timing{};
-    CallParams call_host{0, 0};
+    CallParams call_host{0, 0, 0, 0};
+    unsigned tag_base = 0;  // sample-split kernel: base of the current call's hand-off tags (CallParams::tag_base)
     int precision = 0;      // 0 exact fp32 MFMA, 1 bf16x3 split-precision channel mixing (ls_set_precision)
 #ifdef LS_DEBUG             // profiling variant of the library only (build_library(defines=['LS_DEBUG'])); never in the shipped .so
     DevBuf prof, wgt;       // wgt: [1024][2] start / end stamps of every workgroup of the last step launch
@@ -1081,7 +1082,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
         if (upload(h, h->wgt, zw.data(), zw.size() * sizeof(unsigned long long)) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
     }
 #endif
-    CallParams cp{0, 0};
+    CallParams cp{0, 0, 0, 0};
     if (upload(h, h->callp, &cp, sizeof cp) != LS_OK) { g_create_error = h->err; delete h; return LS_EHIP; }
     *out = h;
     return LS_OK;
@@ -1539,7 +1540,8 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->xtmp.ensure(nx)); HIPCHK(h, h->xio.ensure(nx));
-    h->call_host = CallParams{a->seed, a->sample_offset};
+    h->tag_base += 1u << 21;          // > 64 tags x the launches of any call: this call's hand-off tags are new even against granules a failed reset left behind
+    h->call_host = CallParams{a->seed, a->sample_offset, h->tag_base, 0u};
     HIPCHK(h, hipMemcpyAsync(h->callp.p, &h->call_host, sizeof(CallParams), hipMemcpyHostToDevice, st));
 
     // x_T (gaussian_diffusion.py:700-707 / :972-977)
@@ -1691,7 +1693,7 @@ int ls_philox_x_init(ls_handle* h, int batch, uint64_t seed, uint64_t sample_off
     const size_t nx = (size_t)batch * h->JF * h->T * sizeof(float);
     HIPCHK(h, h->xtmp.ensure(nx));
     HIPCHK(h, h->xio.ensure(nx));
-    h->call_host = CallParams{seed, sample_offset};
+    h->call_host = CallParams{seed, sample_offset, h->tag_base, 0u};
     HIPCHK(h, hipMemcpyAsync(h->callp.p, &h->call_host, sizeof(CallParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, launch_randn_fill(h->xtmp.f(), batch, h->JF, static_cast<const CallParams*>(h->callp.p), 0u, h->stream, h->T));
     HIPCHK(h, launch_from_internal(h->xtmp.f(), h->xio.f(), batch, h->JF, h->stream, h->T));

@@ -31,7 +31,7 @@
 //     stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, then the row statistics are published as 8-byte
 //     {tag, value} granules with relaxed agent-scope atomic stores -- the granules ARE the flags.  Consumers poll the granules with
 //     relaxed agent-scope loads (sc1: L1 bypassed) and read the payload with sc1 loads.  Tags are unique per launch and sync point
-//     (StepArgs::epoch + index); the granule words are zeroed by a memset node ahead of every call.  Every spin is bounded: on a
+//     (CallParams::tag_base of the call + StepArgs::epoch of the launch + index); the granule words are also zeroed ahead of every call.  Every spin is bounded: on a
 //     timeout the workgroup records it in StepArgs::cerr and carries on (the host then fails the call).
 //   * single-buffered payload is safe: a slice rewrites its rows of layer l+1 only after SYNC1(l+1), which every consumer reaches
 //     after its reads of layer l; the statistics alternate between two granule areas for the same reason.
@@ -319,6 +319,9 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
         mean0 = s0.x; rstd0 = s0.y; mean1 = s1.x; rstd1 = s1.y;
     };
 
+    // tags of this launch: the host's per-launch epoch + the call's base from device memory (the launch arguments are frozen in a replayed
+    // graph; the base is what makes a replay's tags differ from the previous call's)
+    const unsigned ep = a.epoch + (a.call ? a.call->tag_base : 0u);
     const wrsrc_t xrs = uniform_rsrc(xg);
     // The weight table's pointers once, into SGPR descriptors: the hand-off asm statements clobber "memory", so a dereference of a.W
     // inside the layer loop is re-loaded after each of them -- a dependent global load + s_waitcnt vmcnt(0) at the head of every phase.
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
         X0 += temb4;
         if (live1()) X1 += temb4;
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
-        ln_publish(0, a.epoch + 2 * l + 1, false);
+        ln_publish(0, ep + 2 * l + 1, false);
         // LayerNorm affine, token-mix weights and biases of this wave's row tiles (tile h, and the ragged tile 2 for half 1): requested
         // AFTER the partials are out (22 dword loads per wave ahead of them cost the chain ~1 k clocks of issue), in flight during the
         // exchange -- they depend on no activation.  wtok1_img[l][t][mq][lane][j] = Wt[16 t + (lane & 15)][4 (4 mq + j) + (lane >> 4)]
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             btb0 = p_btok[l * 80 + row0()];
             btb1 = p_btok[l * 80 + row1c()];
         }
-        ln_gather(0, a.epoch + 2 * l + 1, 2 + 8 * l + 5);
+        ln_gather(0, ep + 2 * l + 1, 2 + 8 * l + 5);
         stamp(2 + 8 * l);
         fresh();
         const float mu1_0 = mean0, mu1_1 = mean1;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             const f4 c0 = X0 - (f4){mu1_0, mu1_0, mu1_0, mu1_0}, c1 = X1 - (f4){mu1_1, mu1_1, mu1_1, mu1_1};
             st_sc1(c0, xrs, ((c * 4 + w) * kCoopRows * 16 + row0() * 16 + 4 * g) * 4);
             if (live1()) st_sc1(c1, xrs, ((c * 4 + w) * kCoopRows * 16 + (32 + s16) * 16 + 4 * g) * 4);
-            ln_publish(1, a.epoch + 2 * l + 2, true);                // LayerNorm-2 partials of the RAW rows
+            ln_publish(1, ep + 2 * l + 2, true);                // LayerNorm-2 partials of the RAW rows
             float* own = U + c * kCoopSliceFloats + w * (kCoopRows * 16);
             *reinterpret_cast<f4*>(&own[row0() * 16 + 4 * g]) = c0;
             if (live1()) *reinterpret_cast<f4*>(&own[(32 + s16) * 16 + 4 * g]) = c1;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
 #pragma unroll
             for (int k = 0; k < PF; ++k) An[k] = wload4(wrs, lane * 16, wsb + qof(k) * 2048);
             const unsigned long long* ga = gran + (size_t)kCoopRows * kCoopSlices * 2;         // area 1: row 0's mean granule = slice ready
-            const unsigned tag2 = a.epoch + 2 * l + 2;
+            const unsigned tag2 = ep + 2 * l + 2;
             lds_barrier();                                           // own slice visible to every wave
             // Pull the 7 other slices (9 chunks of 1 KiB each, dealt over the waves) into their LDS regions as soon as their rows are
             // published: lane s polls slice s.  The pulls fly while this slice's own k blocks are multiplied from LDS.
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     fresh();
     const int j16 = p * kCoopSlices + c;
     const int n16 = np * kCoopSlices;                                // workgroups of this sample
-    const unsigned tagF = a.epoch + 2 * a.layers + 1;
+    const unsigned tagF = ep + 2 * a.layers + 1;
     {
         // this slice's final rows -> LDS [S][64] (token-mix operand layout): every wave has to be past its reads of the partial sums
         lds_barrier();

@@ -21,6 +21,8 @@ enum SamplerKind { kDDPM = 0, kDDIM = 1, kNone = 2 };
 struct CallParams {
     unsigned long long seed;
     unsigned long long sample_offset;
+    unsigned tag_base;          // sample-split kernel: added to every hand-off tag of the call, advanced by the host per sampling call, so a
+    unsigned pad_;              // granule left by an EARLIER call can never pass for this call's (whatever the zeroing ahead of the loop did)
 };
 
 // Weight images in MFMA operand order (built by ls_api.cpp build_images); lives in device memory so

@@ -125,7 +125,7 @@ def test_the_two_paths_agree_and_auto_switches_with_the_batch():
     _, eng = _engine("ted", "auto")
     try:
         eng.set_schedule(orc.Schedule(4, ""))
-        for B, scale, want_path, want_single in ((6, 1.0, 2, 1), (6, 1.5, 2, 0), (80, 1.5, 1, 0), (120, 1.5, 3, 0), (300, 1.0, 3, 1), (256, 1.5, 0, 0)):
+        for B, scale, want_path, want_single in ((6, 1.0, 2, 1), (6, 1.5, 2, 0), (72, 1.5, 1, 0), (120, 1.5, 3, 0), (300, 1.0, 3, 1), (256, 1.5, 0, 0)):
             eng.prepare(synth.make_cond(cfg, B, scale=scale))
             out = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=5)
             t = eng.timing()
