@@ -78,6 +78,7 @@ struct ls_handle {
     Seg seg[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     bool plan_pair = false; // the plan assumed the single-pass form (every guidance scale 1)
     DevBuf wtok1_img;       // token-mix operand of one pass (sample-split kernel)
+    DevBuf wtail;           // [L][S][4] token-mix weights of the ragged output rows 32 .. 35 (one-pass-per-workgroup kernel)
     DevBuf wtok1_hi_img, wtok1_lo_img;   // the same as bf16 hi / lo planes (one-pass-per-workgroup kernel, bf16x3)
     DevBuf co_x, co_part, co_gran, co_flag, co_err;      // its exchange workspaces (one launch's worth), granules / flags, timeout word
     unsigned coop_launches = 0;                        // launches since the granule words were zeroed: epoch = 64 * ordinal
@@ -226,6 +227,7 @@ int build_fused_images(ls_handle* h) {
     std::vector<unsigned short> wwh((size_t)L * kNT * KS * 64 * 8), wwl((size_t)L * kNT * KS * 64 * 8);
     const int KS1 = (S + 31) / 32;
     std::vector<unsigned short> wt1h((size_t)L * 3 * KS1 * 64 * 8), wt1l((size_t)L * 3 * KS1 * 64 * 8);
+    std::vector<float> wtl((size_t)L * S * 4, 0.f);
     char key[160];
     for (int l = 0; l < L; ++l) {
         auto K = [&](const char* suffix) { snprintf(key, sizeof key, "backbone.mlps.%d.%s", l, suffix); return std::string(key); };
@@ -299,6 +301,10 @@ int build_fused_images(ls_handle* h) {
                         wwl[o] = f32_to_bf16(v - bf16_to_f32(wwh[o]));
                     }
         for (int r = 0; r < R; ++r) bt[(size_t)l * 80 + r] = (*b1)[r % S];
+        // wtail[l][k][i] = Wt[32 + i][k] (zero beyond the last row): the A operand of the ragged rows' 4x4x1 MFMAs (ls_pass_kernel.h)
+        for (int k = 0; k < S; ++k)
+            for (int i = 0; i < 4; ++i)
+                if (32 + i < S) wtl[((size_t)l * S + k) * 4 + i] = (*Wt)[(size_t)(32 + i) * S + k];
         // wtok1_hi / lo [l][t][ks][lane][e] = Wt[r = 16t + (lane&15)][r' = 32ks + 8(lane>>4) + e] of ONE pass as bf16 hi / lo planes (ls_pass_kernel.h)
         for (int t = 0; t < 3; ++t)
             for (int ks = 0; ks < KS1; ++ks)
@@ -371,6 +377,7 @@ int build_fused_images(ls_handle* h) {
     if ((rc = upload(h, h->wtok1_hi_img, wt1h.data(), wt1h.size() * sizeof(unsigned short))) != LS_OK) return rc;
     if ((rc = upload(h, h->wtok1_lo_img, wt1l.data(), wt1l.size() * sizeof(unsigned short))) != LS_OK) return rc;
     UP(wch_img, wch); UP(bch, bch); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
+    UP(wtail, wtl);
     UP(ww_img, ww); UP(wtok1_img, wt1); UP(btok_rows, bt); UP(winx_img, winx); UP(wout_img, wout); UP(wout_reg_img, woutr); UP(bout, bout);
 #undef UP
     DevWeights dw{};
@@ -381,6 +388,7 @@ int build_fused_images(ls_handle* h) {
     dw.ww_lo_img = static_cast<const unsigned short*>(h->ww_lo_img.p);
     dw.ln1a = h->ln1a.f(); dw.ln1b = h->ln1b.f(); dw.ln2a = h->ln2a.f(); dw.ln2b = h->ln2b.f();
     dw.ww_img = h->ww_img.f(); dw.wtok1_img = h->wtok1_img.f(); dw.btok_rows = h->btok_rows.f();
+    dw.wtail = h->wtail.f();
     dw.wtok1_hi_img = static_cast<const unsigned short*>(h->wtok1_hi_img.p); dw.wtok1_lo_img = static_cast<const unsigned short*>(h->wtok1_lo_img.p);
     dw.winx_img = h->winx_img.f(); dw.wout_img = h->wout_img.f(); dw.wout_reg_img = h->wout_reg_img.f(); dw.bout = h->bout.f();
     if ((rc = upload(h, h->devw, &dw, sizeof dw)) != LS_OK) return rc;
@@ -762,7 +770,7 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 // Step-time models in ms, measured on MI355X (profiles/r05_throughput_vs_batch.md): the plan is the cheapest of
 //   all sample-split | all batch-level | all fused | all pass | full fused rounds + the remainder on sample-split, batch-level or pass.
 struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single; };
-constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.697f, 0.412f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.496f};
+constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.682f, 0.404f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.496f};
 // bf16x3 (opt-in precision) exists in the fused and the one-pass-per-workgroup kernels only; measured on MI355X (tools/bf16x3_time.py)
 constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.302f};
 float coop_ms(const PathCost& c, int n, int np, int gmax) {
@@ -1101,7 +1109,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt, &h->wtok1_hi_img, &h->wtok1_lo_img};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt, &h->wtail, &h->wtok1_hi_img, &h->wtok1_lo_img};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();

@@ -40,6 +40,7 @@ struct DevWeights {
     const float* ln1a; const float* ln1b; const float* ln2a; const float* ln2b;   // [L][512]
     const float* ww_img;     // [L][5][MK][64]   block-diagonal token-mix operand
     const float* wtok1_img;  // [L][3][ceil(S/16)][64][4]   token-mix operand of ONE pass (sample-split kernel, ls_coop_kernel.h)
+    const float* wtail;      // [L][S][4]   Wt[32 + i][k]: the ragged output rows' token-mix weights (one-pass-per-workgroup kernel, fp32)
     const unsigned short* wtok1_hi_img;   // [L][3][ceil(S/32)][64][8]  the same as bf16 hi / lo planes (one-pass-per-workgroup kernel, bf16x3)
     const unsigned short* wtok1_lo_img;
     const float* btok_rows;  // [L][80]

@@ -48,6 +48,13 @@ typedef __attribute__((address_space(1))) unsigned* pass_gu32p;
 #ifndef LS_PASS_PRIO
 #define LS_PASS_PRIO 2
 #endif
+// fp32: rows 32 .. S-1 of the residual stream live DENSE -- lane = channel of a 64-channel half, one register per row (6 | 8 VGPRs) --
+// instead of as a third MFMA C/D tile of which 3 | 4 of 16 lanes are real (32 VGPRs, and a full tile's worth of vector instructions in
+// every LayerNorm / SiLU phase for them).  The launch is power-bound when two workgroups share a CU (docs/DESIGN_NOTES_r5.md), so the
+// instructions not issued are the gain.  bf16x3 keeps the tile form (its products for the ragged rows are padded MFMAs).
+#ifndef LS_PASS_DENSE
+#define LS_PASS_DENSE 1
+#endif
 #ifndef LS_PASS_PFD
 #define LS_PASS_PFD 2                       // bf16x3 channel mixing: weight fragments requested this many k blocks ahead
 #endif
@@ -66,7 +73,9 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     constexpr int OSTR = NOB * 16 + 4;
     constexpr int NT = kPassNT, CB = kPassCB, NW = kPassWaves;
     constexpr int NREM = S - 32;             // rows of the ragged third tile: 3 (TED) | 4 (BEAT)
-    constexpr bool kRemMfma = (NREM % 4 == 0);
+    constexpr bool kDense = LS_PASS_DENSE != 0 && PREC == 0 && (NREM % 4 != 0);      // BEAT's 4 ragged rows stay on v_mfma_f32_4x4x1 in the tile form (measured: the dense form's 4 VALU rows cost it 6 %)
+    constexpr int NTX = kDense ? 2 : NT;     // row tiles of the residual stream held in the MFMA C/D layout
+    constexpr bool kRemMfma = !kDense && (NREM % 4 == 0);
     constexpr int NRG = kRemMfma ? NREM / 4 : 1;
     constexpr int NRV = kRemMfma ? 1 : NREM;
     constexpr int MK = (S + 3) / 4;          // k steps of the token-mix GEMM
@@ -104,7 +113,8 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     auto valid_of = [&](int t) { return t < 2 ? true : (s16 < NREM); };
     auto rowc_of = [&](int t) { return t < 2 ? 16 * t + s16 : min(32 + s16, S - 1); };
 
-    f4 X[CB][NT];
+    f4 X[CB][NT];                                   // kDense: tile 2 exists only while embedding and for poseFinal
+    float XR[2][NREM];                              // kDense: rows 32 + r, channel 128 w + 64 h + lane
 
     auto stamp = [&](int idx) {
 #ifdef LS_DEBUG
@@ -214,16 +224,45 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) X[2 * pp + c2][t] = valid_of(t) ? acc[c2][t] : (f4){0.f, 0.f, 0.f, 0.f};   // pad rows stay zero
         }
+        if constexpr (kDense) {
+            // tile 2 -> the dense form, through this wave's own columns of the (now free) operand buffer
+            __syncthreads();                        // every wave has read the last x_t operand
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                if (s16 < NREM) *reinterpret_cast<f4*>(&U[(32 + s16) * kUStride + chw + 16 * cb]) = X[cb][2];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < NREM; ++r) XR[h][r] = U[(32 + r) * kUStride + 128 * w + 64 * h + lane];
+        }
     }
     stamp(1);
 
     // LN_spatial statistics over the 512 channels of each row (mlp_module.py:29-33): two passes over the lane's 32 channels, then Chan's
     // parallel-variance merge over the 4 lane groups (two cross-lane exchanges) and the 4 waves (LDS) -- one workgroup barrier per LayerNorm.
     float mean[NT], rstd[NT];
+    float meanR[NREM], rstdR[NREM];                   // kDense: the ragged rows' statistics (wave-uniform)
     auto ln_stats = [&]() {
         f2* pst = reinterpret_cast<f2*>(psum);            // [4 waves][48 rows] (mean, M2) of 128 channels
+        if constexpr (kDense) {
+            // a row = this wave's 128 channels over the 64 lanes x 2 halves; sums over the wave on the VALU (DPP within a row of 16 lanes,
+            // then the two lane-swap exchanges): every lane ends with the total, no trip through SGPRs
+            auto wsum = [&](float v) { return xor32_sum(xor16_sum(row16_sum(v))); };
+            float mr[NREM], qr[NREM];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+            for (int r = 0; r < NREM; ++r) mr[r] = wsum(XR[0][r] + XR[1][r]) * (1.0f / 128.0f);
+#pragma unroll
+            for (int r = 0; r < NREM; ++r) {
+                const float d0 = XR[0][r] - mr[r], d1 = XR[1][r] - mr[r];
+                qr[r] = wsum(fmaf(d0, d0, d1 * d1));
+            }
+#pragma unroll
+            for (int r = 0; r < NREM; ++r)
+                if (lane == 0) pst[w * 48 + 32 + r] = (f2){mr[r], qr[r]};
+        }
+#pragma unroll
+        for (int t = 0; t < NTX; ++t) {
             f4 sv = X[0][t];
 #pragma unroll
             for (int cb = 1; cb < CB; ++cb) sv += X[cb][t];
@@ -257,7 +296,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NTX; ++t) {
             f2 pw[NW];
             f2 acc2 = (f2){0.f, 0.f};
 #pragma unroll
@@ -272,18 +311,46 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             mean[t] = mt;
             rstd[t] = rsqrtf((acc2.y + 128.0f * dd) * (1.0f / kD) + 1e-5f);
         }
+        if constexpr (kDense) {
+#pragma unroll
+            for (int r = 0; r < NREM; ++r) {
+                f2 pw[NW];
+                f2 acc2 = (f2){0.f, 0.f};
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    pw[ww] = pst[ww * 48 + 32 + r];
+                    acc2 += pw[ww];
+                }
+                const float mt = acc2.x * (1.0f / NW);
+                float dd = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
+                meanR[r] = mt;
+                rstdR[r] = rsqrtf((acc2.y + 128.0f * dd) * (1.0f / kD) + 1e-5f);
+            }
+        }
     };
     // the normalised operand of this lane's channels -> LDS [row][520]; LN1 applies alpha / beta here, LN2's are folded into the
     // channel-mix weights on the host (W' = W diag(alpha), b' = b + W beta)
-    auto ln_store = [&](auto affine, const f4 (&alv)[CB], const f4 (&bev)[CB]) {
+    auto ln_store = [&](auto affine, const f4 (&alv)[CB], const f4 (&bev)[CB], const float (&alR)[2], const float (&beR)[2]) {
         constexpr bool alpha = decltype(affine)::value;
+        if constexpr (kDense) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < NREM; ++r) {
+                    float u = (XR[h][r] - meanR[r]) * rstdR[r];
+                    if (alpha) u = fmaf(u, alR[h], beR[h]);
+                    U[(32 + r) * kUStride + 128 * w + 64 * h + lane] = u;
+                }
+        }
         float nmr[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) nmr[t] = -mean[t] * rstd[t];
+        for (int t = 0; t < NTX; ++t) nmr[t] = -mean[t] * rstd[t];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NTX; ++t)
                 if (valid_of(t)) {
                     const f4 rs = (f4){rstd[t], rstd[t], rstd[t], rstd[t]}, nm = (f4){nmr[t], nmr[t], nmr[t], nmr[t]};
                     f4 u = __builtin_elementwise_fma(X[cb][t], rs, nm);
@@ -320,8 +387,16 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             for (int cb = 0; cb < CB; ++cb) {
                 const f4 e = *reinterpret_cast<const f4*>(te + 16 * cb);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NTX; ++t)
                     if (valid_of(t)) X[cb][t] += e;
+            }
+            if constexpr (kDense) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float e = a.temb[(size_t)b * a.temb_stride + 128 * w + 64 * h + lane];
+#pragma unroll
+                    for (int r = 0; r < NREM; ++r) XR[h][r] += e;
+                }
             }
         }
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
@@ -331,10 +406,18 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             alv[cb] = wload4(wrsrc(a.W->ln1a), chw * 4, (l * kD + 16 * cb) * 4);
             bev[cb] = wload4(wrsrc(a.W->ln1b), chw * 4, (l * kD + 16 * cb) * 4);
         }
+        float alR[2] = {1.f, 1.f}, beR[2] = {0.f, 0.f};
+        if constexpr (kDense) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                alR[h] = g1(a.W->ln1a)[l * kD + 128 * w + 64 * h + lane];
+                beR[h] = g1(a.W->ln1b)[l * kD + 128 * w + 64 * h + lane];
+            }
+        }
         ln_stats();
         stamp(2 + 8 * l);
         fresh();
-        ln_store(std::true_type{}, alv, bev);
+        ln_store(std::true_type{}, alv, bev, alR, beR);
         // no workgroup barrier: token mixing contracts over ROWS, wave w reads back only the 128 channel columns it has just written
         __builtin_amdgcn_wave_barrier();
         stamp(3 + 8 * l);
@@ -403,10 +486,34 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             f4 Bt[NT][MQ];
             float bt[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NTX; ++t) {
 #pragma unroll
                 for (int m = 0; m < MQ; ++m) Bt[t][m] = wload4(wrs, lane * 16, wsb + (t * MQ + m) * 1024);
                 bt[t] = g1(a.W->btok_rows)[l * 80 + rowc_of(t)];
+            }
+            if constexpr (kDense) {
+                // ragged OUTPUT rows on v_mfma_f32_4x4x1 (16 blocks of 4 rows x 4 channels, k = 1): A = Wt[32 + (lane & 3)][k] (the same
+                // in every block; wtail[l][k][4]), B = u[k][this lane's channel], and D lands exactly in the dense form (lane = channel,
+                // register = row).  2 S instructions of 16 clocks instead of 8 x MK padded 16x16x4 MFMAs of 32.
+                float wt[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) wt[k] = g1(a.W->wtail)[(l * S + k) * 4 + (lane & 3)];
+                f4 acc4[2][2];                                  // [half][k parity]: four independent accumulator chains
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { acc4[h][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc4[h][1] = acc4[h][0]; }
+                typedef const __attribute__((address_space(3))) float* ldsq;
+                ldsq ucol = (ldsq)(U + 128 * w + lane);
+#pragma unroll
+                for (int k = 0; k < S; ++k)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc4[h][k & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[k], ucol[k * kUStride + 64 * h], acc4[h][k & 1], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < NREM; ++r) {
+                    const float br = g1(a.W->btok_rows)[l * 80 + 32 + r];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) XR[h][r] = silu_acc(acc4[h][0][r] + acc4[h][1][r] + br, XR[h][r]);
+                }
             }
             typedef const __attribute__((address_space(3))) float* ldsp;
             ldsp up[MK];
@@ -419,13 +526,13 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 for (int m = 0; m < MK; ++m) av[m] = up[m][16 * cb];
                 f4 acc[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = (f4){bt[t], bt[t], bt[t], bt[t]};
+                for (int t = 0; t < NTX; ++t) acc[t] = (f4){bt[t], bt[t], bt[t], bt[t]};
 #pragma unroll
                 for (int m = 0; m < MK; ++m)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = MFMA(av[m], Bt[t][m >> 2][m & 3], acc[t]);
+                    for (int t = 0; t < NTX; ++t) acc[t] = MFMA(av[m], Bt[t][m >> 2][m & 3], acc[t]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NTX; ++t)
                     if (valid_of(t)) X[cb][t] = silu_acc4(acc[t], X[cb][t]);
             }
         }
@@ -434,7 +541,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
         ln_stats();            // its barrier also orders every wave's token-mix reads before the stores below
         stamp(5 + 8 * l);
-        ln_store(std::false_type{}, alv, bev);
+        ln_store(std::false_type{}, alv, bev, alR, beR);
         __syncthreads();
         stamp(6 + 8 * l);
         if (LS_PASS_PRIO == 2) {
@@ -610,6 +717,23 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             fresh();
+            if constexpr (kDense) {
+                // ragged rows: lane (g, s16) accumulated channel 16 c4 + s16 of every block c4 over its k subset; summed over the lane groups
+                // every lane holds the totals of all four blocks, and block g's is the one of this lane's dense channel 64 pp + lane
+                const float bcR = g1(a.W->bch)[l * kD + 128 * w + 64 * pp + lane];
+#pragma unroll
+                for (int r = 0; r < NREM; ++r) {
+                    float v[4];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) v[c4] = xor32_sum(xor16_sum(racc[c4][r]));
+                    const float sel = g == 0 ? v[0] : g == 1 ? v[1] : g == 2 ? v[2] : v[3];
+                    XR[pp][r] = silu_acc(sel + bcR, XR[pp][r]);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) X[4 * pp + c4][t] = silu_acc4(acc[c4][t], X[4 * pp + c4][t]);
+            } else {
             // ragged rows: sum the 4 k subsets of the lane groups, then [channel-lane][row] -> [row-lane][channel-reg] through a per-wave patch
             float* rem = REM + w * (4 * NREM * 16);
 #pragma unroll
@@ -643,6 +767,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            }
             if (pp == 0) stamp(7 + 8 * l);
         }
         }
@@ -658,6 +783,19 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     constexpr int OROWS = kOutFromRegs ? NW * S : S;
     static_assert(OROWS * OSTR <= S * kUStride, "OUT overlay must fit the operand buffer");
     float* OUT = U;
+    if constexpr (kDense && kOutFromRegs) {
+        // the ragged rows back into the tile form the product below takes its B operand in: through this wave's own columns of rows 32 ..
+        // of the operand buffer (beyond the OUT overlay)
+        static_assert(OROWS * OSTR <= 32 * kUStride, "the tile-2 patch must not meet the OUT overlay");
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < NREM; ++r) U[(32 + r) * kUStride + 128 * w + 64 * h + lane] = XR[h][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            X[cb][2] = s16 < NREM ? *reinterpret_cast<const f4*>(&U[(32 + s16) * kUStride + chw + 16 * cb]) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
     if constexpr (kOutFromRegs) {
         // Narrow output (TED): every wave contracts over ITS OWN 128 channels straight from the residual registers (a valid MFMA B
         // operand; wout_reg_img carries the matching k permutation), writes a [S][32] partial; the 4 partials are summed below.
@@ -686,10 +824,16 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 if (valid_of(t)) *reinterpret_cast<f4*>(&OUT[(w * S + row_of(t)) * OSTR + 16 * ob + 4 * g]) = acc[ob][t];
     } else {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NTX; ++t)
             if (valid_of(t))
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = X[cb][t];
+        if constexpr (kDense) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < NREM; ++r) U[(32 + r) * kUStride + 128 * w + 64 * h + lane] = XR[h][r];
+        }
         __syncthreads();
         f4 res[MAXU];
 #pragma unroll

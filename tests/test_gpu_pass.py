@@ -169,3 +169,46 @@ def test_bf16x3_on_the_pass_kernel_meets_the_parity_contract(ds, golden):
             assert d5 < 1e-3
     finally:
         eng.close()
+
+
+def test_replayed_graph_through_the_torch_mirror_stays_correct_on_the_pass_kernel():
+    """Regression: the arrival tickets used to be zeroed by a memset node at the head of the captured loop; REPLAYED under the torch mirror
+    (device-resident outputs) that node left garbage in the ticket words and every second sample's passes were combined in the wrong
+    order from the second call on.  Four calls through p_sample_loop (same Philox key, graph replay from the second) must all agree with
+    the fused kernel's."""
+    import torch
+    from types import SimpleNamespace
+    from livelyspeaker_amd.cfg_sampler import ClassifierFreeSampleModel
+    from livelyspeaker_amd.model_util import create_model_and_diffusion
+    cfg = synth.TED
+    dev = torch.device("cuda", 0)
+    B, steps = 128, 40
+    args = SimpleNamespace(mdm_condm='text', latent_dim=512, ff_size=1024, layers=8, cond_mask_prob=0.1, arch='trans_enc', emb_trans_dec=False,
+                           dataset='humanml', lang_model=None, mlpact='silu', diffusion_steps=steps, noise_schedule='cosine', sigma_small=True,
+                           lambda_vel=1.0, lambda_rcxyz=0.0, lambda_fc=0.0, njoints=cfg.njoints)
+    outs = {}
+    for path in ("fused", "pass"):
+        model, diffusion = create_model_and_diffusion(args, "", dataset="ted")
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}, strict=False)
+        model.to(dev)
+        model.eval()
+        model.step_path = path
+        cfgm = ClassifierFreeSampleModel(model)
+        diffusion.noise_source, diffusion.use_graph, diffusion.sample_offset = "philox", True, 0
+        y = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_cond(cfg, B, scale=1.5, seed=3).items()}
+        res = []
+        for i in range(4):
+            diffusion.philox_seed = 12345
+            o = diffusion.p_sample_loop(cfgm, (B, cfg.njoints, cfg.nfeats, cfg.nframes), clip_denoised=False, model_kwargs={"y": y},
+                                        skip_timesteps=0, init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
+            torch.cuda.synchronize()
+            res.append(o.clone())
+            if i:
+                assert model.engine().timing()["graph_replayed"] == 1
+        assert model.engine().timing()["step_path"] == (3 if path == "pass" else 0)
+        outs[path] = res
+        model.engine().close()
+    for i in range(4):
+        d = float((outs["fused"][i] - outs["pass"][i]).abs().max())
+        assert d < 5e-5, (i, d)
+        assert torch.equal(outs["pass"][i], outs["pass"][0])
