@@ -769,10 +769,12 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 //   batch-level   every row of the batch through 21 launches per step that fill the chip (ls_long.hip).
 // Step-time models in ms, measured on MI355X (profiles/r05_throughput_vs_batch.md): the plan is the cheapest of
 //   all sample-split | all batch-level | all fused | all pass | full fused rounds + the remainder on sample-split, batch-level or pass.
-struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single; };
-constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.682f, 0.404f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.496f};
+// pass_round: two workgroups per CU; pass_single: one per CU, alone on the chip; pass_after: one per CU behind full rounds (they start
+// as the faster workgroup of every CU finishes, inside the slower one's tail)
+struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single, pass_after; };
+constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.682f, 0.404f, 0.378f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.496f, 0.47f};
 // bf16x3 (opt-in precision) exists in the fused and the one-pass-per-workgroup kernels only; measured on MI355X (tools/bf16x3_time.py)
-constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.302f};
+constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.2005f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.302f, 0.302f};
 float coop_ms(const PathCost& c, int n, int np, int gmax) {
     float ms = 0.f;
     for (int g = n * np; g > 0; g -= gmax) ms += c.coop_base + c.coop_per_group * (g < gmax ? g : gmax);
@@ -781,7 +783,7 @@ float coop_ms(const PathCost& c, int n, int np, int gmax) {
 // one-pass-per-workgroup kernel: two workgroups per CU are resident (pass_round each); up to one per CU left over run alone on their CU
 float pass_ms(const PathCost& c, int n, int np, int n_cu) {
     const int wgs = n * np, full = wgs / (2 * n_cu), rem = wgs % (2 * n_cu);
-    return c.pass_round * full + (rem == 0 ? 0.f : rem <= n_cu ? c.pass_single : c.pass_round);
+    return c.pass_round * full + (rem == 0 ? 0.f : rem <= n_cu ? (full ? c.pass_after : c.pass_single) : c.pass_round);
 }
 void decide_path(ls_handle* h) {
     const long long before = plan_code(h);
@@ -832,6 +834,9 @@ void decide_path(ls_handle* h) {
             if (h->nseg > 0 && tail[i].path == 0 && h->seg[h->nseg - 1].path == 0) h->seg[h->nseg - 1].n += tail[i].n;      // one more fused round
             else h->seg[h->nseg++] = tail[i];
         }
+        // ... or the whole batch on the one-pass-per-workgroup kernel: its later workgroups start as slots free up, so 384 clips
+        // (768 workgroups) cost a round and a half, not two
+        if (head > 0 && r > 0 && cost(3, B) < c.fused_round * (head / round) + best) { h->nseg = 1; h->seg[0] = {3, 0, B}; }
     }
     h->use_long = h->nseg == 1 && h->seg[0].path == 1;
     h->use_coop = h->nseg == 1 && h->seg[0].path == 2;
