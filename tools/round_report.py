@@ -19,6 +19,9 @@ RUNS = [
                                   "threads, no process group: the collective-free launcher, not a scaling number)"),
     ("bench_two_ranks_one_gpu", "`--gpus 2 --ranks-share-device --batch 256 --legs lively` (self-launched; TWO RANKS ON ONE GPU, collectives over gloo: "
                                 "the N > 1 control flow, not a scaling number)"),
+    ("bench_eight_ranks_one_gpu", "`--gpus 8 --ranks-share-device --batch 64 --legs none` (self-launched; EIGHT RANKS ON ONE GPU over gloo, RCCL probed and refused: "
+                                  "the driver's N = 8 control flow on the one GPU there is, not a scaling number)"),
+    ("bench_threads_eight_handles", "`--gpus 8 --launcher threads --ranks-share-device --batch 64 --path pass` (one process, eight handles on one GPU, eight threads)"),
 ]
 
 
@@ -52,7 +55,7 @@ for name, cmd in RUNS:
 d = load("bench_default")
 if d:
     out += ["", "Secondary objects of the default line:", ""]
-    for k in ("single_pass", "identical_seeds_mode", "config1_shape", "livelyspeaker", "configs4_beat", "split_precision", "train_step", "cpu_baseline",
+    for k in ("single_pass", "identical_seeds_mode", "config1_shape", "livelyspeaker", "configs4_beat", "mid_batches", "split_precision", "train_step", "cpu_baseline",
               "shard_check", "parity_in_run"):
         if k in d:
             out.append(f"* `{k}`: `{json.dumps(d[k])}`")
@@ -77,6 +80,33 @@ out += ["", "## ms per diffusion step over the batch size, by kernel family and 
         "", "## Sample-split step kernel, BEAT B = 32 (`tools/coop_time.py beat 20 32 coop`): dispatch summary and PMC passes", "", cat("coop/kt.md")]
 for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
     out += ["", f"### PMC {c}", "", "\n".join(l for l in cat(f"coop/pmc_{c}.md").splitlines() if "k_coop" in l or l.startswith("| kernel") or l.startswith("|---"))]
+# round 5: the one-pass-per-workgroup kernel, one workgroup per CU (B = 128) and two (B = 256), fp32 and bf16x3, the fused kernel beside it
+def pmc_rows(d, pick):
+    rows = []
+    if not os.path.isdir(os.path.join(src, d)):
+        return rows
+    for f in sorted(os.listdir(os.path.join(src, d))):
+        if f.startswith("pmc_") and f.endswith(".md"):
+            for l in cat(f"{d}/{f}").splitlines():
+                if pick in l:
+                    rows.append(l)
+    return rows
+HDR = ["| kernel | workgroups (x,y,z) x threads | launches | avg us | min us | vgpr | lds B | counters (mean per launch) |", "|---|---|---|---|---|---|---|---|"]
+sec = []
+for d, what, pick in (("pass128", "`tools/coop_time.py ted 20 128 pass`: ONE workgroup per CU", "k_pass<35"), ("pass256", "`tools/coop_time.py ted 20 256 pass`: TWO workgroups per CU", "k_pass<35"),
+                      ("fused256", "`tools/coop_time.py ted 20 256 fused`: the fused kernel, same 256 clips", "k_step<35"),
+                      ("pass256_bf16x3", "`tools/bf16x3_time.py pass 256 256`: bf16x3, two workgroups per CU", "k_pass<"),
+                      ("fused256_bf16x3", "`tools/bf16x3_time.py fused 256 256`: bf16x3, the fused kernel", "k_step<")):
+    rows = pmc_rows(d, pick)
+    if rows:
+        sec += ["", f"### {what}", ""] + HDR + rows
+if sec:
+    out += ["", "## One-pass-per-workgroup step kernel (ls_pass_kernel.h): one PMC pass per counter, mean per launch summed over the chip"] + sec + [
+            "", "Reading: GRBM_GUI_ACTIVE / 8 / avg us = the shader clock the launch ran at (profiled passes run ~4 % slower than un-profiled ones);",
+            "SQ_VALU_MFMA_BUSY_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8) = matrix pipe busy per SIMD; (SQ_INSTS_VALU - SQ_INSTS_MFMA) / 1024 x 4 = issue cycles of the other vector instructions.",
+            "", "Workgroup placement and start / end offsets of CU neighbours (`tools/wg_place.py`, -DLS_DEBUG build), fp32 then bf16x3:", "", "```", cat("wg_place_pass_ted256.txt"), "",
+            cat("wg_place_pass_ted256_bf16x3.txt"), "```",
+            "", "## bf16x3 (opt-in) step time by kernel family and batch (`tools/bf16x3_time.py auto,fused,pass ...`)", "", "```", cat("bf16x3_time.txt"), "```"]
 KSTEP = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
          "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")
 rows = []
