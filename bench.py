@@ -95,6 +95,20 @@ def mk_args(cfg, steps):
                            lambda_rcxyz=0.0, lambda_fc=0.0, njoints=cfg.njoints)
 
 
+def step_kernel_label(tm):
+    """What the step loop ran on, from ls_timing (the engine plans per prepared batch: fused rounds, one-pass-per-workgroup, sample-split,
+    batch-level kernels, or up to three of them for a batch that does not fill the chip a whole number of times)."""
+    names = {0: "ls::k_step (fused CFG denoiser + sampler update, one workgroup per clip, 1 launch/step)",
+             1: "batch-level kernels (ls_long.hip, 21 launches/step)",
+             2: "ls::k_coop (sample-split: 16 workgroups per clip, 1 launch per 32 clips and step)",
+             3: "ls::k_pass (one workgroup per (clip, CFG pass), two per CU, 1 launch/step)"}
+    s = names.get(tm["step_path"], "?")
+    for n, p in ((tm.get("tail_samples", 0), tm.get("tail_path", 0)), (tm.get("tail2_samples", 0), tm.get("tail2_path", 0))):
+        if n:
+            s += f" + {n} clips on {names.get(p, '?').split(' (')[0]}"
+    return s
+
+
 def pmc_traffic(dataset, B):
     """HBM bytes per k_step launch from the committed rocprofv3 PMC passes -- only if they were taken on THIS kernel source
     (the file stores the hash of ls_step_kernel.h it was measured on); otherwise null rather than a stale constant."""
@@ -135,14 +149,15 @@ def measure_traffic(a, B):
             if r.returncode != 0 or not dbs:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-160:]!r}"
             cur = sqlite3.connect(dbs[0]).cursor()
-            ids = [did for name, did in cur.execute("select name, dispatch_id from kernels") if "k_step" in name]
+            # the step kernel(s) of the plan: fused (k_step), one-pass-per-workgroup (k_pass), sample-split (k_coop); summed per launch index
+            ids = [did for name, did in cur.execute("select name, dispatch_id from kernels") if any(k in name for k in ("k_step", "k_pass", "k_coop"))]
             per = {}
             for did, cname, val in cur.execute("select dispatch_id, counter_name, value from counters_collection"):
                 if cname == counter:
                     per[did] = per.get(did, 0.0) + val
             vals = [per[i] for i in ids if i in per]
             if not vals:
-                return None, f"no {counter} rows for ls::k_step in the PMC pass"
+                return None, f"no {counter} rows for the step kernels (ls::k_step / k_pass / k_coop) in the PMC pass"
             kib[counter], launches = sum(vals) / len(vals), len(vals)
         except Exception as e:
             return None, f"traffic pass unavailable: {e!r}"[:200]
@@ -150,7 +165,7 @@ def measure_traffic(a, B):
             shutil.rmtree(d, ignore_errors=True)
     return int(round((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)), (
         f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass, --kernel-trace only) over {launches} "
-        f"k_step launches of a child process running this workload; 2 x FETCH_SIZE ({kib['FETCH_SIZE']:.0f} KiB) + WRITE_SIZE "
+        f"step-kernel launches of a child process running this workload; 2 x FETCH_SIZE ({kib['FETCH_SIZE']:.0f} KiB) + WRITE_SIZE "
         f"({kib['WRITE_SIZE']:.0f} KiB)")
 
 
@@ -732,7 +747,8 @@ def main():
     eng = model.engine()
     elapsed, loop_ms, launches, prep_ms, first_out, first_seed, gathered = timed(a.steps)
     assert first_out is not None and bool(torch.isfinite(first_out).all()), "non-finite samples"
-    single_pass_main = bool(eng.timing()["single_pass"])
+    main_tm = eng.timing()                  # what the headline's step loop ran on (later legs re-plan the same engine)
+    single_pass_main = bool(main_tm["single_pass"])
 
     # the config-4 premise, on hardware: rank r re-generates the shard of rank (r+1) % world on ITS OWN GPU from the same Philox key
     # with sample_offset, and compares it with what that rank produced (strong mode: the gathered tensor; weak mode: a P2P-free
@@ -943,7 +959,7 @@ def main():
                        "parallelism": (f"global batch {total} sharded x{world}, all_gather of the result in the timed region" if strong
                                        else f"batch-sharded x{world}, no per-step collective"),
                        "hipgraph": bool(diffusion.use_graph)},
-            "roofline": {"bound": "mfma", "kernel": ("ls::k_step (fused CFG denoiser + sampler update, 1 launch/step)" if a.dataset != "beat150" else
+            "roofline": {"bound": "mfma", "kernel": (step_kernel_label(main_tm) if a.dataset != "beat150" else
                                                      "long-sequence step: 36 launches/step (GEMMs on ls::k_gemm_tr + LayerNorm / assemble / update kernels); "
                                                      "achieved = algorithmic FLOPs / mean step time"),
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
