@@ -227,6 +227,10 @@ int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; def
  * arithmetic every way, different summation order: results agree to ~1e-5, not bitwise.  Takes effect at the next ls_prepare;
  * ls_timing.step_path reports what ran. */
 int ls_set_path(ls_handle* h, int mode);
+/* The plan mode 0 makes for `batch` clips on a device of `n_cus` compute units, without a handle or a GPU (what ls_prepare decides, exposed
+ * for inspection and for the CPU test suite): out10 = {pieces, then (kernel family as in ls_timing.step_path, first clip, clips) for up to
+ * three pieces}; *ms (nullable) = the step-time model's estimate.  beat: 0 TED / 1 BEAT cost table; single_pass: every guidance scale is 1. */
+int ls_plan_query(int beat, int batch, int single_pass, int precision, int n_cus, int* out10, float* ms);
 int ls_set_schedule(ls_handle* h, const ls_schedule* s);
 int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */
 /* The same, enqueued on the handle's stream WITHOUT waiting: later calls on this handle are ordered behind it, so the caller may

@@ -103,7 +103,7 @@ class LsEvalConfig(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_trng_randn", "ls_trng_fill_steps", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_trng_randn", "ls_trng_fill_steps", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
@@ -181,6 +181,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_philox_x_init.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     lib.ls_set_precision.argtypes = [C.c_void_p, C.c_int]
     lib.ls_set_path.argtypes = [C.c_void_p, C.c_int]
+    lib.ls_plan_query.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     lib.ls_trng_randn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     lib.ls_trng_fill_steps.argtypes = [C.c_void_p, C.c_size_t] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.ls_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, c_i64p, c_i64p]
@@ -332,6 +333,18 @@ def _np32(a) -> np.ndarray:
     if hasattr(a, "detach"):
         a = a.detach().cpu().numpy()
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def plan_query(batch, dataset="ted", single_pass=False, precision="fp32", n_cus=256):
+    """The step plan `auto` makes for ``batch`` clips (no GPU needed): ([(family, first, count), ...], model ms per step); family as in
+    ``Engine.timing()['step_path']`` (0 fused, 1 batch-level, 2 sample-split, 3 one-pass-per-workgroup)."""
+    lib = load_library()
+    out = (C.c_int * 10)()
+    ms = C.c_float()
+    rc = lib.ls_plan_query(int(dataset != "ted"), int(batch), int(bool(single_pass)), {"fp32": 0, "bf16x3": 1}.get(precision, precision), int(n_cus), out, C.byref(ms))
+    if rc != 0:
+        raise EngineError(f"ls_plan_query failed ({rc})")
+    return [(out[1 + 3 * i], out[2 + 3 * i], out[3 + 3 * i]) for i in range(out[0])], float(ms.value)
 
 
 class Engine:

@@ -785,59 +785,69 @@ float pass_ms(const PathCost& c, int n, int np, int n_cu) {
     const int wgs = n * np, full = wgs / (2 * n_cu), rem = wgs % (2 * n_cu);
     return c.pass_round * full + (rem == 0 ? 0.f : rem <= n_cu ? (full ? c.pass_after : c.pass_single) : c.pass_round);
 }
+// The plan as a pure function of what it depends on (also behind ls_plan_query, which needs no GPU: tests/test_host_logic.py).
+struct PlanIn { bool ted, fused, have_long, pair; int B, precision, path_mode, n_cu, coop_groups_max, layers; };
+struct PlanOut { int nseg; Seg seg[3]; float ms; };
+PlanOut plan_steps(const PlanIn& in) {
+    PlanOut o{1, {{0, 0, in.B}, {0, 0, 0}, {0, 0, 0}}, 0.f};
+    if (!in.fused) { o.seg[0].path = 1; return o; }
+    if (in.path_mode == 1) return o;
+    if (in.path_mode == 4) { o.seg[0].path = 3; return o; }
+    if (in.precision != 0 && in.path_mode != 0) return o;
+    if (in.path_mode == 2) { o.seg[0].path = in.have_long ? 1 : 0; return o; }
+    if (in.path_mode == 3) { o.seg[0].path = 2; return o; }
+    if (in.B <= 0) return o;
+    const bool bf = in.precision != 0;
+    const PathCost& c = bf ? (in.ted ? kCostTedBf : kCostBeatBf) : (in.ted ? kCostTed : kCostBeat);
+    const int B = in.B, np = in.pair ? 1 : 2, round = 2 * in.n_cu / np, unit = in.n_cu / np;     // round: samples of one fused round; unit: samples that put ONE pass workgroup on every CU
+    const float thr = 256.0f / (float)in.n_cu;          // throughput-bound terms (measured on 256 CUs) on a smaller / larger device
+    const int gmax = in.coop_groups_max > 0 ? in.coop_groups_max : 1;
+    auto cost = [&](int path, int n) -> float {
+        switch (path) {
+        case 0: return c.fused_round * ((n + round - 1) / round);
+        case 1: return in.have_long && !bf ? c.long_base + c.long_per_sample * thr * n : 1e30f;
+        case 2: return bf || in.coop_groups_max < np || 2 * in.layers + 2 > (int)kCoopEpochStride ? 1e30f : coop_ms(c, n, np, gmax);
+        default: return pass_ms(c, n, np, in.n_cu);
+        }
+    };
+    // head: the full fused rounds; the remainder r on one family, or -- beyond one pass workgroup per CU -- `unit` samples on the
+    // one-pass-per-workgroup kernel and the rest on the sample-split / batch-level kernels (ties go to the earlier candidate)
+    const int head = B >= round ? B / round * round : 0, r = B - head;
+    float best = 0.f;
+    Seg tail[2] = {{0, 0, 0}, {0, 0, 0}};
+    int ntail = 0;
+    if (r > 0) {
+        best = 1e30f;
+        for (int path = 0; path < 4; ++path) {
+            const float t = cost(path, r);
+            if (t < best) { best = t; ntail = 1; tail[0] = {path, head, r}; }
+        }
+        if (r > unit && !bf)
+            for (int path = 1; path < 3; ++path) {
+                const float t = cost(3, unit) + cost(path, r - unit);
+                if (t < best) { best = t; ntail = 2; tail[0] = {3, head, unit}; tail[1] = {path, head + unit, r - unit}; }
+            }
+    }
+    o.nseg = 0;
+    if (head > 0) o.seg[o.nseg++] = {0, 0, head};
+    for (int i = 0; i < ntail; ++i) {
+        if (o.nseg > 0 && tail[i].path == 0 && o.seg[o.nseg - 1].path == 0) o.seg[o.nseg - 1].n += tail[i].n;      // one more fused round
+        else o.seg[o.nseg++] = tail[i];
+    }
+    o.ms = c.fused_round * (head / round) + best;
+    // ... or the whole batch on the one-pass-per-workgroup kernel: its later workgroups start as slots free up, so 384 clips
+    // (768 workgroups) cost a round and a half, not two
+    if (head > 0 && r > 0 && cost(3, B) < o.ms) { o.nseg = 1; o.seg[0] = {3, 0, B}; o.ms = cost(3, B); }
+    return o;
+}
+
 void decide_path(ls_handle* h) {
     const long long before = plan_code(h);
-    h->use_coop = false; h->use_long = false; h->use_pass = false;
-    h->nseg = 1; h->seg[0] = {0, 0, h->B};
-    const bool have_long = h->lw_wtp.p != nullptr;
     h->plan_pair = h->all_scale_one;
-    if (!h->fused) h->seg[0].path = 1;
-    else if (h->path_mode == 1) {}
-    else if (h->path_mode == 4) h->seg[0].path = 3;
-    else if (h->precision != 0 && h->path_mode != 0) {}
-    else if (h->path_mode == 2) h->seg[0].path = have_long ? 1 : 0;
-    else if (h->path_mode == 3) h->seg[0].path = 2;
-    else if (h->B > 0) {
-        const bool bf = h->precision != 0;
-        const PathCost& c = bf ? (h->var == kTED ? kCostTedBf : kCostBeatBf) : (h->var == kTED ? kCostTed : kCostBeat);
-        const int B = h->B, np = h->plan_pair ? 1 : 2, round = 2 * h->n_cu / np, unit = h->n_cu / np;     // round: samples of one fused round; unit: samples that put ONE pass workgroup on every CU
-        const float thr = 256.0f / (float)h->n_cu;          // throughput-bound terms (measured on 256 CUs) on a smaller / larger device
-        const int gmax = h->coop_groups_max > 0 ? h->coop_groups_max : 1;
-        auto cost = [&](int path, int n) -> float {
-            switch (path) {
-            case 0: return c.fused_round * ((n + round - 1) / round);
-            case 1: return have_long && !bf ? c.long_base + c.long_per_sample * thr * n : 1e30f;
-            case 2: return bf || h->coop_groups_max < np || 2 * h->cfg.layers + 2 > (int)kCoopEpochStride ? 1e30f : coop_ms(c, n, np, gmax);
-            default: return pass_ms(c, n, np, h->n_cu);
-            }
-        };
-        // head: the full fused rounds; the remainder r on one family, or -- beyond one pass workgroup per CU -- `unit` samples on the
-        // one-pass-per-workgroup kernel and the rest on the sample-split / batch-level kernels (ties go to the earlier candidate)
-        const int head = B >= round ? B / round * round : 0, r = B - head;
-        float best = 1e30f;
-        Seg tail[2] = {{0, 0, 0}, {0, 0, 0}};
-        int ntail = 0;
-        if (r > 0) {
-            for (int path = 0; path < 4; ++path) {
-                const float t = cost(path, r);
-                if (t < best) { best = t; ntail = 1; tail[0] = {path, head, r}; }
-            }
-            if (r > unit && !bf)
-                for (int path = 1; path < 3; ++path) {
-                    const float t = cost(3, unit) + cost(path, r - unit);
-                    if (t < best) { best = t; ntail = 2; tail[0] = {3, head, unit}; tail[1] = {path, head + unit, r - unit}; }
-                }
-        }
-        h->nseg = 0;
-        if (head > 0) h->seg[h->nseg++] = {0, 0, head};
-        for (int i = 0; i < ntail; ++i) {
-            if (h->nseg > 0 && tail[i].path == 0 && h->seg[h->nseg - 1].path == 0) h->seg[h->nseg - 1].n += tail[i].n;      // one more fused round
-            else h->seg[h->nseg++] = tail[i];
-        }
-        // ... or the whole batch on the one-pass-per-workgroup kernel: its later workgroups start as slots free up, so 384 clips
-        // (768 workgroups) cost a round and a half, not two
-        if (head > 0 && r > 0 && cost(3, B) < c.fused_round * (head / round) + best) { h->nseg = 1; h->seg[0] = {3, 0, B}; }
-    }
+    const PlanOut o = plan_steps(PlanIn{h->var == kTED, h->fused, h->lw_wtp.p != nullptr, h->plan_pair, h->B, h->precision, h->path_mode, h->n_cu,
+                                        h->coop_groups_max, h->cfg.layers});
+    h->nseg = o.nseg;
+    for (int i = 0; i < 3; ++i) h->seg[i] = o.seg[i];
     h->use_long = h->nseg == 1 && h->seg[0].path == 1;
     h->use_coop = h->nseg == 1 && h->seg[0].path == 2;
     h->use_pass = h->nseg == 1 && h->seg[0].path == 3;
@@ -1169,6 +1179,17 @@ int ls_set_precision(ls_handle* h, int mode) {
         decide_path(h);
         if (was != plan_code(h)) h->prepared = false;
     }
+    return LS_OK;
+}
+
+// The step plan `auto` would make (no handle, no GPU): out = {n pieces, then (path, first, count) per piece}, *ms = the model's step time.
+int ls_plan_query(int beat, int batch, int single_pass, int precision, int n_cus, int* out10, float* ms) {
+    if (!out10 || batch < 1 || n_cus < 8) return LS_EINVAL;
+    const int gmax = 2 * n_cus / 8 < kCoopMaxGroups ? 2 * n_cus / 8 : kCoopMaxGroups;
+    const PlanOut o = plan_steps(PlanIn{beat == 0, true, true, single_pass != 0, batch, precision, 0, n_cus, gmax, 8});
+    out10[0] = o.nseg;
+    for (int i = 0; i < 3; ++i) { out10[1 + 3 * i] = o.seg[i].path; out10[2 + 3 * i] = o.seg[i].first; out10[3 + 3 * i] = o.seg[i].n; }
+    if (ms) *ms = o.ms;
     return LS_OK;
 }
 

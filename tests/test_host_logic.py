@@ -464,3 +464,36 @@ def test_progressive_generators_refuse_bad_arguments_when_requested_not_at_first
         state = torch.get_rng_state()
         gen = fn(cfgm, [2, 9, 3, 34], model_kwargs={"y": y}, device="cpu")          # accepted: nothing has run or been drawn yet
         assert torch.equal(state, torch.get_rng_state()) and hasattr(gen, "__next__")
+
+
+def test_step_plans_cover_the_batch_and_follow_the_chip():
+    """ls_plan_query (no GPU): the pieces `auto` splits a batch into are contiguous and cover it, a fused piece comes first and holds whole
+    rounds of the chip, bf16x3 plans use the two families that have that mode, and the round / unit sizes follow the CU count."""
+    from livelyspeaker_amd import _lib as L
+    for ds in ("ted", "beat"):
+        for sp in (False, True):
+            for prec in ("fp32", "bf16x3"):
+                for n_cus in (256, 64, 304):
+                    for B in list(range(1, 70, 7)) + [96, 128, 129, 160, 255, 256, 257, 300, 352, 384, 416, 511, 512, 513, 1000, 4096]:
+                        segs, ms = L.plan_query(B, ds, sp, prec, n_cus)
+                        assert 1 <= len(segs) <= 3 and ms > 0, (ds, sp, prec, n_cus, B, segs)
+                        nxt = 0
+                        for i, (path, first, n) in enumerate(segs):
+                            assert first == nxt and n > 0 and path in (0, 1, 2, 3), (B, segs)
+                            nxt += n
+                            if path == 0:
+                                assert i == 0                                            # the fused kernel indexes clips from 0
+                                if len(segs) > 1:
+                                    assert n % (n_cus * (2 if sp else 1)) == 0, (B, segs)   # whole rounds in front of a remainder
+                            if prec == "bf16x3":
+                                assert path in (0, 3), (B, segs)
+                        assert nxt == B, (B, segs)
+    # the measured table's landmarks (TED, fp32, CFG, 256 CUs)
+    want = {4: [2], 32: [2], 64: [2], 128: [3], 160: [3, 2], 256: [0], 300: [0, 2], 384: [3], 416: [0, 3, 2], 512: [0], 4096: [0]}
+    for B, fam in want.items():
+        assert [p for p, _, _ in L.plan_query(B)[0]] == fam, (B, L.plan_query(B))
+    # model time never falls when clips are added by whole rounds, and a batch never costs more than the next multiple of the chip
+    for B in range(1, 513):
+        assert L.plan_query(B)[1] <= L.plan_query(-(-B // 256) * 256)[1] + 1e-6, B
+    with pytest.raises(L.EngineError):
+        L.plan_query(0)
