@@ -70,6 +70,7 @@ struct ls_handle {
     bool use_pass = false;  // the prepared batch runs the one-pass-per-workgroup kernel (ls_pass_kernel.h: two independent workgroups per CU)
     DevBuf pa_out, pa_cnt;  // its CFG hand-off: pass outputs [n][2][T][J*F], arrival tickets [n]
     int pass_n = 0;         // samples the hand-off buffers hold
+    int pass_waves = 0;     // 0: 8-wave workgroups when the grid fits the chip once, 4-wave otherwise; LS_PASS_WAVES = 4 | 8 forces one (-DLS_DEBUG builds)
     bool use_coop = false;  // the prepared batch runs the sample-split kernel (ls_coop_kernel.h: 16 workgroups per sample)
     // the step plan of the prepared batch (decide_path): up to three pieces, e.g. 416 clips = 256 on the fused kernel + 128 on the
     // one-pass-per-workgroup kernel (one workgroup per CU) + 32 on the sample-split kernel.  use_long / use_coop / use_pass: the whole batch
@@ -618,7 +619,14 @@ hipError_t run_pass(ls_handle* h, const StepArgs& s, int first, int n, bool pair
     StepArgs c = s;
     c.pf = h->pa_out.f(); c.pcnt = static_cast<unsigned*>(h->pa_cnt.p);
     c.b0 = first; c.npass = pair ? 1 : 2;
-    return launch_step_pass(h->var, h->precision == 1 ? 1 : 0, c, n, st);
+    // a grid that fits the chip once runs as 8-wave workgroups, one per CU (two waves per SIMD hide each other's round trips);
+    // beyond that, 4-wave workgroups, two per CU
+#ifdef LS_PASS_FORCE_WAVES
+    const int waves = LS_PASS_FORCE_WAVES;          // A/B builds (tools/ab_variants.py)
+#else
+    const int waves = h->pass_waves ? h->pass_waves : (n * c.npass <= h->n_cu ? 8 : 4);
+#endif
+    return launch_step_pass(h->var, h->precision == 1 ? 1 : 0, waves, c, n, st);
 }
 
 // the batch-level kernels over samples [first, first + n): the same step from separate kernels over all rows (both passes always; exact fp32 only)
@@ -772,9 +780,9 @@ hipError_t run_inpaint_update(ls_handle* h, const StepArgs& s, int i, bool noise
 // pass_round: two workgroups per CU; pass_single: one per CU, alone on the chip; pass_after: one per CU behind full rounds (they start
 // as the faster workgroup of every CU finishes, inside the slower one's tail)
 struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, fused_round, pass_round, pass_single, pass_after; };
-constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.682f, 0.404f, 0.378f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.496f, 0.47f};
+constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.682f, 0.363f, 0.378f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.437f, 0.47f};
 // bf16x3 (opt-in precision) exists in the fused and the one-pass-per-workgroup kernels only; measured on MI355X (tools/bf16x3_time.py)
-constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.2005f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.302f, 0.302f};
+constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.193f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.28f, 0.302f};
 float coop_ms(const PathCost& c, int n, int np, int gmax) {
     float ms = 0.f;
     for (int g = n * np; g > 0; g -= gmax) ms += c.coop_base + c.coop_per_group * (g < gmax ? g : gmax);
@@ -1057,6 +1065,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (const char* pr = getenv("LS_PROF")) { h->prof_on = true; h->prof_wg = atoi(pr); }
     if (const char* xm = getenv("LS_COOP_XMAP")) h->coop_xmap = atoi(xm);
     if (const char* gm = getenv("LS_COOP_GROUPS")) h->coop_groups_max = atoi(gm);
+    if (const char* pw = getenv("LS_PASS_WAVES")) h->pass_waves = atoi(pw) == 8 ? 8 : atoi(pw) == 4 ? 4 : 0;
 #endif
     h->var = var;
     h->JF = JF;

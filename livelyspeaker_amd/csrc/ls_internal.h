@@ -159,7 +159,7 @@ hipError_t launch_step_coop(Variant v, const StepArgs& a, int nsamples, hipStrea
 
 // one-pass-per-workgroup step kernel (ls_pass.hip): npass workgroups of 4 waves per sample, two workgroups per CU
 hipError_t init_pass_kernels();
-hipError_t launch_step_pass(Variant v, int prec, const StepArgs& a, int nsamples, hipStream_t st);
+hipError_t launch_step_pass(Variant v, int prec, int waves, const StepArgs& a, int nsamples, hipStream_t st);
 
 // prec: 0 = exact fp32 MFMA (default), 1 = bf16x3 split-precision channel mixing (opt-in, parity-gated at 1e-3)
 // pair: 0 = CFG (cond + uncond pass of one sample per workgroup), 1 = single pass (guidance scale 1: two samples per workgroup)

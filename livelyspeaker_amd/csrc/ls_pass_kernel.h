@@ -29,14 +29,15 @@
 
 namespace ls {
 
-constexpr int kPassThreads = 256;
-constexpr int kPassWaves = 4;
-constexpr int kPassCB = 8;                 // 16-channel blocks owned by one wave (4 waves * 8 * 16 = 512)
 constexpr int kPassNT = 3;                 // 16-row tiles of one pass (S = 35 | 36 -> 48)
 
-__host__ __device__ constexpr int pass_lds_floats(int S) {
-    // psum [4 waves][48 rows] (mean, M2) | U [S][520] | REM [4 waves][4 blocks][S - 32 rows][16]
-    return 2 * kPassWaves * 16 * kPassNT + S * kUStride + kPassWaves * 4 * (S - 32) * 16;
+// NW waves per workgroup.  4 (128 channels per wave, up to 256 VGPRs at two workgroups per CU): the form that SHARES a CU.  8 (64
+// channels per wave, as in k_step): for launches that put at most ONE workgroup on a CU -- two waves per SIMD of the same workgroup hide
+// each other's LDS / L2 round trips, which a lone 4-wave workgroup cannot (its SIMDs hold one wave each); its registers (up to 256 per
+// wave x 8 waves) leave no room for a second workgroup, so it is never used where two per CU are wanted.
+__host__ __device__ constexpr int pass_lds_floats(int S, int NW) {
+    // psum [NW waves][48 rows] (mean, M2) | U [S][520] | REM [NW waves][4 blocks][S - 32 rows][16]
+    return 2 * NW * 16 * kPassNT + S * kUStride + NW * 4 * (S - 32) * 16;
 }
 
 typedef unsigned pass_u4v __attribute__((ext_vector_type(4)));
@@ -65,13 +66,18 @@ typedef __attribute__((address_space(1))) unsigned* pass_gu32p;
 // PREC = 1: bf16x3 split precision (opt-in, as in k_step): operands u = hi + lo as two bf16 planes, W.u ~= hi.hi + hi.lo + lo.hi on
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  bf16 MFMAs and the fp32 VALU do not share lanes, and the CU's two workgroups are
 // independent, so one's LayerNorm / SiLU phases run beside the other's products.
-template <int S, int NPRE, int JF, int PREC = 0>
-__global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
+template <int S, int NPRE, int JF, int PREC = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void k_pass(const StepArgs a) {
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    constexpr int kPassThreads = 64 * NW;
+    constexpr int CB = 32 / NW;              // 16-channel blocks owned by one wave
+    constexpr int CHW = 16 * CB;             // channels owned by one wave: 128 | 64
+    constexpr int NH = CHW / 64;             // 64-channel halves of a wave's channels (the dense ragged rows: lane = channel of a half)
     constexpr int KXQ = (JF + 15) / 16;      // 16-wide k groups of the x_t part of input_mapping
     constexpr int KXP = KXQ * 16;
     constexpr int NOB = (JF + 15) / 16;      // 16-wide output blocks of poseFinal
     constexpr int OSTR = NOB * 16 + 4;
-    constexpr int NT = kPassNT, CB = kPassCB, NW = kPassWaves;
+    constexpr int NT = kPassNT;
     constexpr int NREM = S - 32;             // rows of the ragged third tile: 3 (TED) | 4 (BEAT)
     constexpr bool kDense = LS_PASS_DENSE != 0 && PREC == 0 && (NREM % 4 != 0);      // BEAT's 4 ragged rows stay on v_mfma_f32_4x4x1 in the tile form (measured: the dense form's 4 VALU rows cost it 6 %)
     constexpr int NTX = kDense ? 2 : NT;     // row tiles of the residual stream held in the MFMA C/D layout
@@ -101,20 +107,20 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
     const bool unc = p == 1;
     int s16 = lane & 15;
     int g = lane >> 4;
-    int chw = 128 * w + 4 * g;                      // + 16 cb + j = this lane's channels
+    int chw = CHW * w + 4 * g;                      // + 16 cb + j = this lane's channels
     // see k_step: laundering the lane id at phase boundaries keeps per-lane addresses phase-local, so the residual stream stays in registers
     auto fresh = [&]() {
         asm volatile("" : "+v"(lane));
         s16 = lane & 15;
         g = lane >> 4;
-        chw = 128 * w + 4 * g;
+        chw = CHW * w + 4 * g;
     };
     auto row_of = [&](int t) { return 16 * t + s16; };
     auto valid_of = [&](int t) { return t < 2 ? true : (s16 < NREM); };
     auto rowc_of = [&](int t) { return t < 2 ? 16 * t + s16 : min(32 + s16, S - 1); };
 
     f4 X[CB][NT];                                   // kDense: tile 2 exists only while embedding and for poseFinal
-    float XR[2][NREM];                              // kDense: rows 32 + r, channel 128 w + 64 h + lane
+    float XR[NH][NREM];                             // kDense: rows 32 + r, channel CHW w + 64 h + lane
 
     auto stamp = [&](int idx) {
 #ifdef LS_DEBUG
@@ -192,13 +198,14 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         // winx_img[8][2][KXQ][2][64][4]: 16-channel block 8 w + cb = (8-wave slice 2 w + (cb >> 2), pass (cb >> 1) & 1, c2 = cb & 1)
         const wrsrc_t wrs = wrsrc(a.W->winx_img);
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {                // two channel blocks at a time: 6 accumulators
+        for (int pp = 0; pp < CB / 2; ++pp) {           // two channel blocks at a time: 6 accumulators
             f4 acc[2][NT];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[c2][t] = X[2 * pp + c2][t];
-            const int wsb = ((2 * w + (pp >> 1)) * 2 + (pp & 1)) * KXQ * 2 * 1024;
+            const int gb0 = CB * w + 2 * pp;            // global 16-channel block = (8-wave slice gb >> 2, pass (gb >> 1) & 1, c2 = gb & 1)
+            const int wsb = ((gb0 >> 2) * 2 + ((gb0 >> 1) & 1)) * KXQ * 2 * 1024;
             f4 An[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) An[c2] = wload4(wrs, lane * 16, wsb + c2 * 1024);
@@ -232,9 +239,9 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 if (s16 < NREM) *reinterpret_cast<f4*>(&U[(32 + s16) * kUStride + chw + 16 * cb]) = X[cb][2];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int r = 0; r < NREM; ++r) XR[h][r] = U[(32 + r) * kUStride + 128 * w + 64 * h + lane];
+                for (int r = 0; r < NREM; ++r) XR[h][r] = U[(32 + r) * kUStride + CHW * w + 64 * h + lane];
         }
     }
     stamp(1);
@@ -251,11 +258,17 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             auto wsum = [&](float v) { return xor32_sum(xor16_sum(row16_sum(v))); };
             float mr[NREM], qr[NREM];
 #pragma unroll
-            for (int r = 0; r < NREM; ++r) mr[r] = wsum(XR[0][r] + XR[1][r]) * (1.0f / 128.0f);
+            for (int r = 0; r < NREM; ++r) {
+                float sr = XR[0][r];
+                if constexpr (NH == 2) sr += XR[NH - 1][r];
+                mr[r] = wsum(sr) * (1.0f / CHW);
+            }
 #pragma unroll
             for (int r = 0; r < NREM; ++r) {
-                const float d0 = XR[0][r] - mr[r], d1 = XR[1][r] - mr[r];
-                qr[r] = wsum(fmaf(d0, d0, d1 * d1));
+                const float d0 = XR[0][r] - mr[r];
+                float dq = d0 * d0;
+                if constexpr (NH == 2) { const float d1 = XR[NH - 1][r] - mr[r]; dq = fmaf(d1, d1, dq); }
+                qr[r] = wsum(dq);
             }
 #pragma unroll
             for (int r = 0; r < NREM; ++r)
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #pragma unroll
             for (int cb = 1; cb < CB; ++cb) sv += X[cb][t];
             const float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
-            float m = s * (1.0f / 32.0f);
+            float m = s * (1.0f / (4 * CB));
             const f4 mv = (f4){m, m, m, m};
             f4 qv = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -276,12 +289,12 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 qv = __builtin_elementwise_fma(d, d, qv);
             }
             float m2 = (qv[0] + qv[1]) + (qv[2] + qv[3]);
-            {   // the lane group 16 lanes away (32 + 32 values), then 32 lanes away (64 + 64)
+            {   // the lane group 16 lanes away (4 CB + 4 CB values), then 32 lanes away (8 CB + 8 CB)
                 float ma, mb, qa, qb;
                 xor16_pair(m, ma, mb);
                 xor16_pair(m2, qa, qb);
                 const float d = mb - ma;
-                m2 = (qa + qb) + d * d * 16.0f;
+                m2 = (qa + qb) + d * d * (2.0f * CB);
                 m = 0.5f * (ma + mb);
             }
             {
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 xor32_pair(m, ma, mb);
                 xor32_pair(m2, qa, qb);
                 const float d = mb - ma;
-                m2 = (qa + qb) + d * d * 32.0f;
+                m2 = (qa + qb) + d * d * (4.0f * CB);
                 m = 0.5f * (ma + mb);
             }
             if (g == 0) pst[w * 48 + 16 * t + s16] = (f2){m, m2};
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
             mean[t] = mt;
-            rstd[t] = rsqrtf((acc2.y + 128.0f * dd) * (1.0f / kD) + 1e-5f);
+            rstd[t] = rsqrtf((acc2.y + (float)CHW * dd) * (1.0f / kD) + 1e-5f);
         }
         if constexpr (kDense) {
 #pragma unroll
@@ -326,22 +339,22 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
                 meanR[r] = mt;
-                rstdR[r] = rsqrtf((acc2.y + 128.0f * dd) * (1.0f / kD) + 1e-5f);
+                rstdR[r] = rsqrtf((acc2.y + (float)CHW * dd) * (1.0f / kD) + 1e-5f);
             }
         }
     };
     // the normalised operand of this lane's channels -> LDS [row][520]; LN1 applies alpha / beta here, LN2's are folded into the
     // channel-mix weights on the host (W' = W diag(alpha), b' = b + W beta)
-    auto ln_store = [&](auto affine, const f4 (&alv)[CB], const f4 (&bev)[CB], const float (&alR)[2], const float (&beR)[2]) {
+    auto ln_store = [&](auto affine, const f4 (&alv)[CB], const f4 (&bev)[CB], const float (&alR)[NH], const float (&beR)[NH]) {
         constexpr bool alpha = decltype(affine)::value;
         if constexpr (kDense) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int r = 0; r < NREM; ++r) {
                     float u = (XR[h][r] - meanR[r]) * rstdR[r];
                     if (alpha) u = fmaf(u, alR[h], beR[h]);
-                    U[(32 + r) * kUStride + 128 * w + 64 * h + lane] = u;
+                    U[(32 + r) * kUStride + CHW * w + 64 * h + lane] = u;
                 }
         }
         float nmr[NT];
@@ -392,8 +405,8 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             }
             if constexpr (kDense) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float e = a.temb[(size_t)b * a.temb_stride + 128 * w + 64 * h + lane];
+                for (int h = 0; h < NH; ++h) {
+                    const float e = a.temb[(size_t)b * a.temb_stride + CHW * w + 64 * h + lane];
 #pragma unroll
                     for (int r = 0; r < NREM; ++r) XR[h][r] += e;
                 }
@@ -406,12 +419,14 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             alv[cb] = wload4(wrsrc(a.W->ln1a), chw * 4, (l * kD + 16 * cb) * 4);
             bev[cb] = wload4(wrsrc(a.W->ln1b), chw * 4, (l * kD + 16 * cb) * 4);
         }
-        float alR[2] = {1.f, 1.f}, beR[2] = {0.f, 0.f};
+        float alR[NH], beR[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { alR[h] = 1.f; beR[h] = 0.f; }
         if constexpr (kDense) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                alR[h] = g1(a.W->ln1a)[l * kD + 128 * w + 64 * h + lane];
-                beR[h] = g1(a.W->ln1b)[l * kD + 128 * w + 64 * h + lane];
+            for (int h = 0; h < NH; ++h) {
+                alR[h] = g1(a.W->ln1a)[l * kD + CHW * w + 64 * h + lane];
+                beR[h] = g1(a.W->ln1b)[l * kD + CHW * w + 64 * h + lane];
             }
         }
         ln_stats();
@@ -446,8 +461,8 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             int ro[KS][2];                                  // rows past the last one are clamped: their weights are 0 and the clamped row is finite
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                ro[ks][0] = min(32 * ks + 8 * g + (s16 >> 2), S - 1) * kUStride + 128 * w + 4 * (s16 & 3);
-                ro[ks][1] = min(32 * ks + 8 * g + 4 + (s16 >> 2), S - 1) * kUStride + 128 * w + 4 * (s16 & 3);
+                ro[ks][0] = min(32 * ks + 8 * g + (s16 >> 2), S - 1) * kUStride + CHW * w + 4 * (s16 & 3);
+                ro[ks][1] = min(32 * ks + 8 * g + 4 + (s16 >> 2), S - 1) * kUStride + CHW * w + 4 * (s16 & 3);
             }
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
@@ -498,27 +513,27 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 float wt[S];
 #pragma unroll
                 for (int k = 0; k < S; ++k) wt[k] = g1(a.W->wtail)[(l * S + k) * 4 + (lane & 3)];
-                f4 acc4[2][2];                                  // [half][k parity]: four independent accumulator chains
+                f4 acc4[NH][2];                                 // [half][k parity]: independent accumulator chains
 #pragma unroll
-                for (int h = 0; h < 2; ++h) { acc4[h][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc4[h][1] = acc4[h][0]; }
+                for (int h = 0; h < NH; ++h) { acc4[h][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc4[h][1] = acc4[h][0]; }
                 typedef const __attribute__((address_space(3))) float* ldsq;
-                ldsq ucol = (ldsq)(U + 128 * w + lane);
+                ldsq ucol = (ldsq)(U + CHW * w + lane);
 #pragma unroll
                 for (int k = 0; k < S; ++k)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < NH; ++h)
                         acc4[h][k & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[k], ucol[k * kUStride + 64 * h], acc4[h][k & 1], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < NREM; ++r) {
                     const float br = g1(a.W->btok_rows)[l * 80 + 32 + r];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) XR[h][r] = silu_acc(acc4[h][0][r] + acc4[h][1][r] + br, XR[h][r]);
+                    for (int h = 0; h < NH; ++h) XR[h][r] = silu_acc(acc4[h][0][r] + acc4[h][1][r] + br, XR[h][r]);
                 }
             }
             typedef const __attribute__((address_space(3))) float* ldsp;
             ldsp up[MK];
 #pragma unroll
-            for (int m = 0; m < MK; ++m) up[m] = (ldsp)(U + min(4 * m + g, S - 1) * kUStride + 128 * w + s16);   // clamped rows meet zero weights
+            for (int m = 0; m < MK; ++m) up[m] = (ldsp)(U + min(4 * m + g, S - 1) * kUStride + CHW * w + s16);   // clamped rows meet zero weights
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 float av[MK];
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             // split residuals are O(2^-16) relative); all three row tiles padded (bf16 MFMAs are cheap), two channel blocks at a time.
             // wch_hi / lo [L][8][2][16 q][2][64][8]: block 8 w + 2 pp + c2 = (8-wave slice 2 w + (pp >> 1), pass pp & 1, c2)
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
+            for (int pp = 0; pp < CB / 2; ++pp) {
                 fresh();
                 f4 acc[2][NT];
 #pragma unroll
@@ -562,7 +577,8 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                     for (int t = 0; t < NT; ++t) acc[c2][t] = bc;
                 }
                 const wrsrc_t wrh = wrsrc(a.W->wch_hi_img), wrl = wrsrc(a.W->wch_lo_img);
-                const int wsb = ((((l * 8 + 2 * w + (pp >> 1)) * 2 + (pp & 1)) * 16) * 2) * 1024;
+                const int gb0 = CB * w + 2 * pp;
+                const int wsb = ((((l * 8 + (gb0 >> 2)) * 2 + ((gb0 >> 1) & 1)) * 16) * 2) * 1024;
                 const __bf16* Uh = reinterpret_cast<const __bf16*>(U);
                 const __bf16* Ul = Uh + S * kUStride;
                 int rofs[NT];
@@ -635,12 +651,12 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         if (valid_of(t)) X[2 * pp + c2][t] = silu_acc4(acc[c2][t], X[2 * pp + c2][t]);
-                if (pp == 1) stamp(7 + 8 * l);
+                if (pp == CB / 4 - 1) stamp(7 + 8 * l);
             }
         } else {
         // Rows 32 .. S-1 on the VALU (TED) / v_mfma_f32_4x4x1 (BEAT) from the same A-operand registers, as in k_step.
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {                 // 4 channel blocks x 2 full tiles = 8 accumulators per half
+        for (int pp = 0; pp < CB / 4; ++pp) {            // 4 channel blocks x 2 full tiles = 8 accumulators per half
             fresh();
             f4 acc[4][2];
             float racc[4][NRV];
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             }
             // wch_img[L][8][2][32 q][2][64][4]: block 8 w + 4 pp + c4 = (8-wave slice 2 w + pp, pass c4 >> 1, c2 = c4 & 1)
             const wrsrc_t wrs = wrsrc(a.W->wch_img);
-            const int wsb = ((l * 8 + 2 * w + pp) * 2 * 32) * 2 * 1024;
+            const int wsb = ((l * 8 + ((CB * w) >> 2) + pp) * 2 * 32) * 2 * 1024;
             auto woff = [&](int q, int c4) { return wsb + ((((c4 >> 1) * 32 + q) * 2) + (c4 & 1)) * 1024; };
             typedef const __attribute__((address_space(3))) float* ldsp;
             typedef const __attribute__((address_space(3))) f4* ldsp4;
@@ -720,7 +736,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
             if constexpr (kDense) {
                 // ragged rows: lane (g, s16) accumulated channel 16 c4 + s16 of every block c4 over its k subset; summed over the lane groups
                 // every lane holds the totals of all four blocks, and block g's is the one of this lane's dense channel 64 pp + lane
-                const float bcR = g1(a.W->bch)[l * kD + 128 * w + 64 * pp + lane];
+                const float bcR = g1(a.W->bch)[l * kD + CHW * w + 64 * pp + lane];
 #pragma unroll
                 for (int r = 0; r < NREM; ++r) {
                     float v[4];
@@ -788,9 +804,9 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
         // of the operand buffer (beyond the OUT overlay)
         static_assert(OROWS * OSTR <= 32 * kUStride, "the tile-2 patch must not meet the OUT overlay");
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int r = 0; r < NREM; ++r) U[(32 + r) * kUStride + 128 * w + 64 * h + lane] = XR[h][r];
+            for (int r = 0; r < NREM; ++r) U[(32 + r) * kUStride + CHW * w + 64 * h + lane] = XR[h][r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -810,7 +826,7 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 // wout_reg_img[8][NOB][4][64][4]: 8-wave slice 2 w + (cb >> 2), block cb & 3
-                const f4 A = wload4(wrs, lane * 16, (((2 * w + (cb >> 2)) * NOB + ob) * 4 + (cb & 3)) * 1024);
+                const f4 A = wload4(wrs, lane * 16, ((((CB * w + cb) >> 2) * NOB + ob) * 4 + ((CB * w + cb) & 3)) * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -830,9 +846,9 @@ __global__ __launch_bounds__(kPassThreads, 2) void k_pass(const StepArgs a) {
                 for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f4*>(&U[row_of(t) * kUStride + chw + 16 * cb]) = X[cb][t];
         if constexpr (kDense) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int r = 0; r < NREM; ++r) U[(32 + r) * kUStride + 128 * w + 64 * h + lane] = XR[h][r];
+                for (int r = 0; r < NREM; ++r) U[(32 + r) * kUStride + CHW * w + 64 * h + lane] = XR[h][r];
         }
         __syncthreads();
         f4 res[MAXU];

@@ -489,7 +489,7 @@ def test_step_plans_cover_the_batch_and_follow_the_chip():
                                 assert path in (0, 3), (B, segs)
                         assert nxt == B, (B, segs)
     # the measured table's landmarks (TED, fp32, CFG, 256 CUs)
-    want = {4: [2], 32: [2], 64: [2], 128: [3], 160: [3, 2], 256: [0], 300: [0, 2], 384: [3], 416: [0, 3, 2], 512: [0], 4096: [0]}
+    want = {4: [2], 32: [2], 64: [2], 128: [3], 160: [3, 2], 256: [0], 300: [0, 2], 384: [0, 3], 416: [0, 3, 2], 512: [0], 4096: [0]}
     for B, fam in want.items():
         assert [p for p, _, _ in L.plan_query(B)[0]] == fam, (B, L.plan_query(B))
     # model time never falls when clips are added by whole rounds, and a batch never costs more than the next multiple of the chip
