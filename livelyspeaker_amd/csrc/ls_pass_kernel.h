@@ -1,9 +1,7 @@
 // One-pass-per-workgroup diffusion step for gfx950 (MI355X): one launch = one p_sample / ddim_sample step, like k_step
-// (ls_step_kernel.h), but a workgroup holds ONE CFG pass of one sample -- S = 35 | 36 rows, 4 waves, ~78 KB of LDS -- so that two
-// INDEPENDENT workgroups share a CU.  What that buys over k_step's one-sample-per-CU mapping:
-//   * granularity: 128 clips fill the chip (k_step: 256), and a batch of 256 k + r clips pays for r in half-CU units;
-//   * the two workgroups of a CU are not phase-locked by a common barrier: one's LayerNorm / SiLU phases run beside the other's MFMAs.
-// Same reference arithmetic as k_step:
+// (ls_step_kernel.h), but a workgroup holds ONE CFG pass of one sample -- S = 35 | 36 rows, ~78 KB of LDS.  What that buys over k_step's
+// one-sample-per-CU mapping is granularity: 128 clips put a workgroup on every CU (k_step: 256), and a batch of 256 k + r clips pays for
+// r in half-CU units.  Same reference arithmetic as k_step:
 //   ClassifierFreeSampleModel.forward   scripts/model/cfg_sampler.py:24-31   (two INDEPENDENT forwards: what makes the split legal)
 //   RAG.forward                         scripts/model/RAG.py:98-133
 //   TransMLP / MLPblock / LN_spatial    scripts/model/mlp_module.py:21-91
@@ -11,12 +9,17 @@
 //   p_mean_variance / p_sample / ddim_sample   scripts/diffusion/gaussian_diffusion.py:284-399, 507-558, 745-798
 //
 // Mapping:
-//   * workgroup = (sample b, pass p), blockIdx = b * npass + p; 256 threads.  Wave w owns channels [128 w, 128 w + 128) of all rows in the
-//     MFMA C/D layout (lane & 15 = row of the tile, 4 (lane >> 4) + reg = channel of the 16-channel block): 8 blocks x 3 row tiles
-//     = 96 VGPRs of residual stream, resident for the whole forward.  Rows 32 .. S-1 (3 | 4 of the third tile's 16) are multiplied on the
-//     VALU (TED) or by v_mfma_f32_4x4x1 (BEAT) in channel mixing, exactly as k_step treats its ragged tile.
-//   * the weight images are k_step's (ls_api.cpp build_fused_images): this wave's 128 channels are the 64-channel slices 2 w and 2 w + 1 of
-//     the 8-wave kernel, so no second copy of the weights exists.
+//   * workgroup = (sample b, pass p), blockIdx = b * npass + p.  Two forms of the one template (NW waves):
+//       NW = 8   64 channels per wave, as in k_step; ONE workgroup per CU (its registers leave no room for a second).  Two waves per SIMD
+//                hide each other's LDS / L2 round trips.  Used when the grid fits the chip once (ls_api.cpp run_pass).
+//       NW = 4   128 channels per wave, up to 256 VGPRs; TWO independent workgroups per CU, not phase-locked by a common barrier (wave
+//                priority keeps them level).  Used for grids beyond one workgroup per CU.
+//     Wave w owns channels [CHW w, CHW w + CHW) of all rows in the MFMA C/D layout (lane & 15 = row of the tile, 4 (lane >> 4) + reg = channel
+//     of the 16-channel block), resident in registers for the whole forward.  Rows 32 .. S-1 (3 | 4 of a third tile's 16) are multiplied on
+//     the VALU (TED) or by v_mfma_f32_4x4x1 (BEAT) in channel mixing, as k_step treats its ragged tile; TED fp32 also HOLDS them dense
+//     (LS_PASS_DENSE below).
+//   * the weight images are k_step's (ls_api.cpp build_fused_images): global 16-channel block gb = (8-wave slice gb >> 2, pass (gb >> 1) & 1,
+//     c2 = gb & 1), so no second copy of the weights exists (plus wtail / wtok1_hi / wtok1_lo: a few KB for the one-pass token mixing).
 //   * CFG combination: each pass writes its poseFinal output [T][J*F] write-through (sc1), every wave drains, barrier, one lane takes a
 //     ticket (relaxed agent-scope fetch_add on the sample's counter: zeroed by ls_prepare, and set back to zero by the second taker).
 //     The workgroup that draws the odd ticket is the LAST of its sample: it reads the other pass's output with sc1 loads, combines the
@@ -64,8 +67,7 @@ typedef __attribute__((address_space(1))) unsigned* pass_gu32p;
 #endif
 
 // PREC = 1: bf16x3 split precision (opt-in, as in k_step): operands u = hi + lo as two bf16 planes, W.u ~= hi.hi + hi.lo + lo.hi on
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  bf16 MFMAs and the fp32 VALU do not share lanes, and the CU's two workgroups are
-// independent, so one's LayerNorm / SiLU phases run beside the other's products.
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (two terms do not meet the contract: docs/DESIGN_NOTES_r5.md).
 template <int S, int NPRE, int JF, int PREC = 0, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 2) void k_pass(const StepArgs a) {
     static_assert(NW == 4 || NW == 8, "four or eight waves");
@@ -92,9 +94,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pass(const StepArgs a) {
     static_assert(S > 32 && S <= 36, "one pass = two full row tiles + a ragged one of at most 4 rows");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* psum = smem;                          // [4][48] (mean, M2) pairs of the LayerNorm merge
+    float* psum = smem;                          // [NW][48] (mean, M2) pairs of the LayerNorm merge
     float* U = smem + 2 * NW * 16 * NT;          // [S][520] fp32 operand
-    float* REM = U + S * kUStride;               // [4 waves][4][NREM][16] ragged-row patch
+    float* REM = U + S * kUStride;               // [NW waves][4][NREM][16] ragged-row patch (tile form only)
 
     const int tid = threadIdx.x;
     int lane = tid & 63;
