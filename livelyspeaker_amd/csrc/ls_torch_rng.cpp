@@ -25,6 +25,7 @@
 // every product and sum below rounds where it is written: no contraction by THIS compiler (the FMAs of the restated kernels are explicit)
 #pragma clang fp contract(off)
 
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -94,6 +95,10 @@ struct Mt {
     }
     // n words of the same stream in bulk.  `left - 1` words of the current block are still unread, at st[next ...]
     void fill_words(uint32_t* out, size_t n);
+    // Generator threads for long fills (null: none).  The stream is sequential, but the 624-word state recurrence alone runs ~4x faster than
+    // recurrence + tempering + the store of the words: on a long fill the calling thread only advances the STATE ("scout"), handing a
+    // snapshot of it to a generator thread every few hundred blocks, and the generators produce the words of their pieces in parallel.
+    class Pool* gen = nullptr;
     float uf() { return (float)(word() & ((1u << 24) - 1)) * (1.0f / (float)(1u << 24)); }                 // uniform_real<float>
     double ud() {                                                                                           // uniform_real<double>: random64
         const uint64_t hi = word(), lo = word();
@@ -147,8 +152,45 @@ inline int mt_isa() { return 0; }
 inline bool have_fma() { return false; }
 #endif
 
+void mt_blocks_to_words(uint32_t* st, uint32_t* out, size_t nblocks, int isa) {       // nblocks block updates of `st`, every block's 624 words tempered to out
+    for (size_t b = 0; b < nblocks; ++b, out += kN) {
+        if (isa == 2) { mt_block_avx512(st); mt_temper_avx512(st, out, kN); }
+        else if (isa == 1) { mt_block_avx2(st); mt_temper_avx2(st, out, kN); }
+        else { mt_block_base(st); mt_temper_base(st, out, kN); }
+    }
+}
+void pool_submit(class Pool* p, std::function<void()> job);
+void pool_wait(class Pool* p);
+int pool_threads(class Pool* p);
+constexpr size_t kParBlocks = 256;           // whole blocks from which a fill is dealt to the generator threads (160 K words)
+
 void Mt::fill_words(uint32_t* out, size_t n) {
     const int isa = mt_isa();
+    if (gen && n >= (kParBlocks + 2) * (size_t)kN) {
+        // head: the rest of the current block
+        if (left - 1 > 0) {
+            const size_t m = (size_t)(left - 1);
+            if (isa == 2) mt_temper_avx512(st + next, out, m); else if (isa == 1) mt_temper_avx2(st + next, out, m); else mt_temper_base(st + next, out, m);
+            next += (uint32_t)m; left -= (int)m; out += m; n -= m;
+        }
+        // middle: whole blocks, in pieces.  A piece's generator starts from a snapshot of the state in front of it; the scout (this thread)
+        // runs the recurrence alone over the piece to reach the next snapshot
+        const size_t nb = n / kN;
+        const int nt = pool_threads(gen) > 0 ? pool_threads(gen) : 1;
+        size_t per = (nb + (size_t)(4 * nt) - 1) / (size_t)(4 * nt);
+        if (per < 64) per = 64;
+        for (size_t b0 = 0; b0 < nb; b0 += per) {
+            const size_t cnt = b0 + per < nb ? per : nb - b0;
+            auto snap = std::make_shared<std::array<uint32_t, kN>>();
+            memcpy(snap->data(), st, sizeof st);
+            uint32_t* dst = out + b0 * kN;
+            pool_submit(gen, [snap, dst, cnt, isa] { mt_blocks_to_words(snap->data(), dst, cnt, isa); });
+            for (size_t b = 0; b < cnt; ++b) { if (isa == 2) mt_block_avx512(st); else if (isa == 1) mt_block_avx2(st); else mt_block_base(st); }
+        }
+        pool_wait(gen);
+        out += nb * kN; n -= nb * kN;
+        left = 1; next = kN;                 // the last block is used up, exactly as after reading it word by word
+    }
     while (n > 0) {
         if (left - 1 == 0) {                 // word(): --left == 0 -> next_state(), and the word it then reads leaves left at kN
             if (isa == 2) mt_block_avx512(st); else if (isa == 1) mt_block_avx2(st); else mt_block_base(st);
@@ -292,6 +334,12 @@ public:
         std::unique_lock<std::mutex> l(m_);
         done_.wait(l, [this] { return pending_ == 0; });
     }
+    void submit(std::function<void()> job) {            // one job; runs inline without workers
+        if (th_.empty()) { job(); return; }
+        { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(job)); ++pending_; }
+        cv_.notify_one();
+    }
+    int threads() const { return (int)th_.size(); }
 private:
     void work() {
         for (;;) {
@@ -314,6 +362,10 @@ private:
     size_t pending_ = 0;
     bool stop_ = false;
 };
+
+void pool_submit(Pool* p, std::function<void()> job) { p->submit(std::move(job)); }
+void pool_wait(Pool* p) { p->wait(); }
+int pool_threads(Pool* p) { return p->threads(); }
 
 inline float word_to_uf(uint32_t w) { return (float)(w & ((1u << 24) - 1)) * (1.0f / (float)(1u << 24)); }                 // uniform_real<float>
 inline double words_to_ud(uint32_t hi, uint32_t lo) {                                                                        // uniform_real<double>: random64
@@ -440,6 +492,8 @@ int ls_trng_randn(uint8_t* state, size_t state_bytes, float* out, size_t n, int 
     if (!g.load(state)) return LS_EINVAL;
     {
         Pool pool(n >= 65536 && n_threads > 1 ? n_threads : 0);
+        Pool gpool(n >= (kParBlocks + 2) * (size_t)kN && n_threads > 1 ? (n_threads < 12 ? n_threads / 2 : 6) : 0);      // word generators of long fills
+        g.gen = gpool.threads() ? &gpool : nullptr;
         static thread_local WordRing ring;
         ring.used = 0;
         if (n >= 16) draw_contig(g, pool, out, n, variant);
@@ -463,6 +517,8 @@ int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, 
     {
         // The calling thread walks the steps in the reference's draw order producing words; the workers transform behind it.
         Pool pool(n_threads > 1 ? n_threads : 0);
+        Pool gpool(n_threads > 1 ? (n_threads < 12 ? n_threads / 2 : 6) : 0);      // word generators of long fills (Mt::fill_words)
+        g.gen = gpool.threads() ? &gpool : nullptr;
         static thread_local WordRing ring;
         ring.used = 0;
         for (int k = 0; k < n_steps; ++k) {

@@ -36,7 +36,7 @@ def test_a_variant_reproduces_this_torch_build():
     assert v >= 0, "no restated variant reproduces torch's contiguous float normals on this machine (callers fall back to torch)"
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 31, 32, 33, 100, 2048, 4099, 1 << 17])
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 31, 32, 33, 100, 2048, 4099, 1 << 17, (1 << 21) + 16, 3000003])
 def test_randn_equals_torch_for_every_size_class(n):
     v = torch_rng.variant()
     assert v >= 0
@@ -87,6 +87,27 @@ def test_step_draws_at_a_size_that_is_dealt_to_the_worker_pool(threads, monkeypa
     torch_rng.fill_steps(eps, nz, False, v)
     assert torch.equal(eps, want_e) and torch.equal(nz, want_n)
     assert torch.equal(torch.randn(4, dtype=torch.float64), want_after)
+
+
+@pytest.mark.parametrize("threads", [2, 16])
+def test_long_fills_dealt_to_generator_threads_stay_the_same_stream(threads, monkeypatch):
+    """Fills of more than ~160 K words are produced by generator threads from state snapshots the calling thread takes while it runs the
+    recurrence alone ahead of them (csrc/ls_torch_rng.cpp, Mt::fill_words): BEAT-like steps (1.2 M words of memory-order draw each, odd
+    counts, a cached sample on entry), values and the generator state afterwards as torch's."""
+    v = torch_rng.variant()
+    assert v >= 0
+    monkeypatch.setattr(torch_rng, "n_threads", lambda: threads)
+    shape = dict(n=3, B=65, D=512, J=47, F=6, T=33)         # 604 890 elements per memory-order draw (odd pairs), contiguous draws of 33 280
+    torch.manual_seed(4321)
+    torch.randn(3)
+    s0 = torch.get_rng_state()
+    want_e, want_n = torch_rng._torch_steps(first_contiguous=True, **shape)
+    want_after = torch.randn(6, dtype=torch.float64)
+    torch.set_rng_state(s0)
+    eps, nz = torch.empty_like(want_e), torch.empty_like(want_n)
+    torch_rng.fill_steps(eps, nz, True, v)
+    assert torch.equal(eps, want_e) and torch.equal(nz, want_n)
+    assert torch.equal(torch.randn(6, dtype=torch.float64), want_after)
 
 
 def test_bad_arguments_are_rejected():
