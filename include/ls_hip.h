@@ -289,6 +289,13 @@ void* ls_stream(const ls_handle* h);
 int ls_trng_randn(uint8_t* state, size_t state_bytes, float* out, size_t n, int variant, int n_threads);
 int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, int F, int T, int n_steps, int first_contiguous,
                        float* eps, float* noise, int variant, int n_threads);
+/* The per-element double pairs whose samples are stored as floats are evaluated by a vectorised restatement and taken from it only when
+ * every double within its error margin rounds to the same float; the others go through libm as in torch (ls_torch_rng.cpp).
+ * ls_trng_stats: pairs evaluated / pairs sent back to libm so far in this process.  ls_trng_pairs_debug (tests): the vectorised
+ * evaluation alone over np pairs (4 np words) next to libm's doubles; isa 0 / 1 / 2 = base / AVX2 / AVX-512 clone, -1 = this machine's. */
+int ls_trng_stats(uint64_t* pairs, uint64_t* redone);
+int ls_trng_pairs_debug(const uint32_t* words, int np, int isa, double* fast_c, double* fast_s, float* zc, float* zs, uint8_t* redo,
+                        double* libm_c, double* libm_s);
 
 /* ---- SAG decoder ---------------------------------------------------------------
  * Decoder_TRANSFORMER (scripts/model/motionclip_module.py:98-183), called as SAG.decoder(batch) at

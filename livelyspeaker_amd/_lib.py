@@ -103,7 +103,7 @@ class LsEvalConfig(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_trng_randn", "ls_trng_fill_steps", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_trng_randn", "ls_trng_fill_steps", "ls_trng_stats", "ls_trng_pairs_debug", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
@@ -184,6 +184,8 @@ def load_library(build_if_missing: bool = True):
     lib.ls_plan_query.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     lib.ls_trng_randn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     lib.ls_trng_fill_steps.argtypes = [C.c_void_p, C.c_size_t] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.ls_trng_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.ls_trng_pairs_debug.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
     lib.ls_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, c_i64p, c_i64p]
     lib.ls_sag_create.argtypes = [C.POINTER(LsSagConfig), C.POINTER(C.c_void_p)]
     lib.ls_sag_destroy.argtypes = [C.c_void_p]

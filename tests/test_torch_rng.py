@@ -119,3 +119,50 @@ def test_bad_arguments_are_rejected():
     bad = st.clone()
     bad[12] = 0                                                                            # "not seeded"
     assert lib.ls_trng_randn(bad.data_ptr(), bad.numel(), out.data_ptr(), 32, 0, 1) < 0
+
+
+@pytest.mark.parametrize("isa", [0, 1, 2])
+def test_vectorised_double_pairs_stay_inside_their_margin_and_defer_to_libm_at_the_edge(isa):
+    """The per-element double path stores floats.  Its vectorised evaluation (ls_torch_rng.cpp, LS_FAST_PAIRS_BODY) is used for a sample
+    only when every double within 2^-44 r of it rounds to the same float; the contract behind that guard is |fast - libm| <= 2^-48 r.
+    Measured here against libm's own doubles over 2^20 random pairs + the corner words, per ISA clone: the error bound, that every
+    sample it keeps is libm's float, and that the degenerate pairs (r = 0: u2 = 0) are handed back."""
+    lib = _lib.load_library()
+    rng = np.random.default_rng(7 + isa)
+    npairs = 1 << 20
+    w = rng.integers(0, 1 << 32, size=4 * npairs, dtype=np.uint32)
+    w[0:4] = 0                                                # u1 = u2 = 0: r = 0
+    w[4:8] = 0xFFFFFFFF                                       # u1, u2 = 1 - 2^-53: theta next to 2 pi, the largest r
+    w[8:12] = [0, 1, 0, 1]                                    # the smallest non-zero uniforms
+    w[12:16] = [0x80000, 0, 0x1FFFFF, 0xFFFFFFFF]             # theta = pi / 2 ... (a zero of the cosine)
+    fc, fs, lc, ls = (np.empty(npairs) for _ in range(4))
+    zc, zs = np.empty(npairs, np.float32), np.empty(npairs, np.float32)
+    redo = np.empty(npairs, np.uint8)
+    rc = lib.ls_trng_pairs_debug(w.ctypes.data, npairs, isa, fc.ctypes.data, fs.ctypes.data, zc.ctypes.data, zs.ctypes.data, redo.ctypes.data,
+                                 lc.ctypes.data, ls.ctypes.data)
+    if rc == -5:                                              # LS_EUNSUPPORTED
+        pytest.skip("this machine lacks the ISA of that clone")
+    assert rc == 0
+    r = np.hypot(lc, ls)
+    live = r > 0
+    err = np.maximum(np.abs(fc - lc), np.abs(fs - ls))[live] / r[live]
+    print(f"isa {isa}: max |fast - libm| / r = 2^{np.log2(err.max()):.2f}, sent back to libm: {redo.mean():.2e}")
+    assert err.max() < 2.0 ** -48
+    assert redo[0] == 1 and redo[~live].all()
+    keep = redo == 0
+    assert np.array_equal(zc[keep], lc[keep].astype(np.float32)) and np.array_equal(zs[keep], ls[keep].astype(np.float32))
+    assert 0 < redo.mean() < 1e-3                             # the guard is exercised, and rare
+
+
+def test_pair_statistics_count_what_went_back_to_libm():
+    lib = _lib.load_library()
+    a, b, a2, b2 = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert lib.ls_trng_stats(C.byref(a), C.byref(b)) == 0
+    torch.manual_seed(5)
+    eps, nz = torch.empty(1, 2, 16, 16), torch.empty(1, 16, 250, 1, 34)       # the noise of a later step: the per-element double path
+    torch_rng.fill_steps(eps, nz, False, max(torch_rng.variant(), 0))
+    assert lib.ls_trng_stats(C.byref(a2), C.byref(b2)) == 0
+    assert a2.value - a.value >= 16 * 250 * 34 // 2 and 0 <= b2.value - b.value < 100
+    torch.manual_seed(5)
+    torch.randn(16, 1, 16), torch.randn(16, 1, 16)
+    assert torch.equal(nz[0], torch.randn_like(torch.empty(34, 16, 250, 1).permute(1, 2, 3, 0)))

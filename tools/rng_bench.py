@@ -7,7 +7,7 @@ from livelyspeaker_amd import torch_rng
 lib = _lib.load_library()
 v = torch_rng.variant()
 for (B, D, J, F, T, n), label in (((512, 512, 9, 3, 34, 12), "TED B=512"), ((256, 512, 47, 6, 34, 8), "BEAT B=256")):
-  for nt in (8, 16, 24, 32, 48, 64):
+  for nt in (int(a) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else "4,8,12,16,24,32,48".split(","))):
     torch.manual_seed(1)
     st = torch.get_rng_state().numpy().copy()
     eps = np.empty((n, 2, B, D), np.float32); nz = np.empty((n, B, J, F, T), np.float32)
