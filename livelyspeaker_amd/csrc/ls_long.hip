@@ -108,8 +108,12 @@ __global__ __launch_bounds__(256) void k_long_addemb_ln(float* __restrict__ x, c
 // Wt[16 mt + s16][16 q + 4 g ..+3], zero-padded to KPAD x KPAD on the host, 100 KB per layer shared by every workgroup) through a
 // buffer descriptor, the next k block's ten fragments in flight while the current one is multiplied.  D[token tile][channel tile]
 // on v_mfma_f32_16x16x4_f32.  Epilogue through LDS (round 3): SiLU(D + bt) goes back into the operand buffer as [token][channel];
-// then thread (row, 4 channels) adds it to x with float4 loads / stores (rounds 1-2: 40 scalar loads + 40 scalar stores per lane)
-// and reduces the new row's (mean, M2) over the slab -- the LayerNorm-2 partial the channel-mixing epilogue consumes.
+// then thread (row, 4 channels) adds it to its x values -- kept in registers since the staging (round 5; a second read of the slab cost
+// 1 % of the step) -- stores whole rows as float4 (rounds 1-2: 40 scalar loads + 40 scalar stores per lane) and reduces the new row's
+// (mean, M2) over the slab -- the LayerNorm-2 partial the channel-mixing epilogue consumes.
+// Round 5, measured and NOT kept (tools/ab_variants.py run beat150 32 / 256, ms per step): wave = two token tiles x all four channel tiles
+// (five waves; every Wt fragment fetched once per workgroup instead of four times, the LDS operand read four times instead) 0.706 / 4.97
+// against 0.683 / 4.62 for this mapping: the Wt stream from L2 was not what bounds it.
 template <int KPAD>
 __global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, const float* __restrict__ part1, float* __restrict__ part2,
                                                         const float* __restrict__ wimg, const float* __restrict__ bt,
@@ -130,9 +134,9 @@ __global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, c
     for (int mt = 0; mt < NMT; ++mt) An[mt] = wfrag(0, mt);             // in flight during the operand staging
     constexpr int NU = KPAD * 16 / 256;
     const int c4 = tid & 15;
+    f4 xv[NU];
     {   // operand slab: LN1 applied on the way in; loads first (clamped rows: branch-free), then the LDS writes
         const f4 al = *reinterpret_cast<const f4*>(alpha + c0 + 4 * c4), be = *reinterpret_cast<const f4*>(beta + c0 + 4 * c4);
-        f4 xv[NU];
         float pm[NU], pq[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -187,9 +191,6 @@ __global__ __launch_bounds__(256, 3) void k_long_tokmix(float* __restrict__ x, c
     __syncthreads();
     // thread (row, channels 4 c4 ..): x += SiLU(.), whole rows as float4; (mean, M2) of the new row over this slab's 64 channels
     {
-        f4 xv[NU];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) xv[j] = *reinterpret_cast<const f4*>(xs + (size_t)min((tid >> 4) + 16 * j, S - 1) * kD + c0 + 4 * c4);
         float* p2 = part2 + ((size_t)seq * S * 8 + blockIdx.y) * 2;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
