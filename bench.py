@@ -495,8 +495,10 @@ def other_config_leg(dataset, B, dev, fence, steps=1000, noise="philox"):
                                                     f"normals per step takes {host:.2f} ms on the host (the [T][B][J][F]-ordered randn_like is torch's "
                                                     "per-element double Box-Muller: two 32-bit words per normal from ONE generator); the loop advanced at "
                                                     f"{km:.2f} ms per step -- a segment is drawn while the previous one runs, so a step costs the slower of "
-                                                    "the host draws and the step kernel (the same workload on Philox noise: `configs4_beat`).  Faster needs "
-                                                    "mt19937 jump-ahead (several producers), not done"}}
+                                                    "the host draws and the step kernel (the same workload on Philox noise: `configs4_beat`).  The words of "
+                                                    "a long fill are already produced by generator threads behind a state-only scout (csrc/ls_torch_rng.cpp); "
+                                                    "what is left is the scout's own sequential state recurrence and the double-precision transforms, "
+                                                    "0.9 - 1.4 ms per step on the GPU hosts measured"}}
     model.engine().close()
     return {"workload": f"{dataset.upper()} RAG, batch {B} x {cfg.nframes} frames, {steps}-step DDPM, CFG 1.5, "
                         + ("noise_source='torch_cpu' (the reference's own draws in its order: 'identical seeds')" if noise == "torch_cpu" else "Philox noise")
