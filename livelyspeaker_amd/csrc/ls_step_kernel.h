@@ -30,6 +30,9 @@ namespace ls {
 // PAIR = 1: single-pass sampling for guidance scale 1 (out_u + 1 * (out_c - out_u) = out_c, cfg_sampler.py:31, and the callers
 // run guidance_param = 1: test_RAG_ted.py:183): the 2S rows hold the COND pass of TWO samples (2b, 2b+1) instead of the cond and
 // uncond passes of one -- the same block-diagonal token mixing, half the work per sample.
+// The training forward's activation stores (1.17 GB per launch at B = 512, read back only by the backward) are non-temporal: 2.06 -> 2.00 ms
+// of forward at B = 512 (round 5; with no stores at all, LS_TRAIN_ABL: 1.91).  The same on the backward's dA stores changed nothing.
+#define LS_TRAIN_ST(p, v) __builtin_nontemporal_store((v), (p))
 #ifndef LS_TRAIN_ABL
 #define LS_TRAIN_ABL 0          // timing-only A/B (tools): 1 = the training forward keeps no activations (its stores are skipped)
 #endif
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     f4 u = __builtin_elementwise_fma(X[cb][t], rs, nm);          // packed f32
                     if constexpr (TRAIN) {                // x-hat is what the backward needs (LayerNorm backward directly; the
                         const int gr = grow_of(t);        // weight gradients rebuild U = alpha * x-hat + beta from it)
-                        if (gr >= 0 && !LS_TRAIN_ABL) *reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb) = u;
+                        if (gr >= 0 && !LS_TRAIN_ABL) LS_TRAIN_ST(reinterpret_cast<f4*>(gout + (size_t)gr * kD + chw + 16 * cb), u);
                     }
                     if (alpha) u = __builtin_elementwise_fma(u, al, be);
                     if (PREC == 1 && alpha && !kTokTr) {
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                         if (gr >= 0 && !LS_TRAIN_ABL) {
                             float* dst = a.tr_a1 + ((size_t)l * a.tr_B * S + gr) * kD + chw;
 #pragma unroll
-                            for (int cb = 0; cb < kCB; ++cb) *reinterpret_cast<f4*>(dst + 16 * cb) = acc[cb];
+                            for (int cb = 0; cb < kCB; ++cb) LS_TRAIN_ST(reinterpret_cast<f4*>(dst + 16 * cb), acc[cb]);
                         }
                     }
 #pragma unroll
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                 for (int t = 0; t < kFullTiles; ++t) {
                     if constexpr (TRAIN) {                // pre-activation of the channel-mixing linear
                         const int gr = grow_of(t);
-                        if (gr >= 0 && !LS_TRAIN_ABL) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = acc[c2][t];
+                        if (gr >= 0 && !LS_TRAIN_ABL) LS_TRAIN_ST(reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb), acc[c2][t]);
                     }
                     X[cb][t] = silu_acc4(acc[c2][t], X[cb][t]);
                 }
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(512) void k_step(const StepArgs a) {
                     const f4 rv = *reinterpret_cast<const f4*>(&rem[(c2 * NREM + s16) * 16 + 4 * g]);
                     if constexpr (TRAIN) {
                         const int gr = grow_of(kFullTiles);
-                        if (gr >= 0 && !LS_TRAIN_ABL) *reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb) = rv + bc;
+                        if (gr >= 0 && !LS_TRAIN_ABL) LS_TRAIN_ST(reinterpret_cast<f4*>(a.tr_a2 + ((size_t)l * a.tr_B * S + gr) * kD + chw + 16 * cb), rv + bc);
                     }
                     X[cb][kFullTiles] = silu_acc4(rv + bc, X[cb][kFullTiles]);
                 }
