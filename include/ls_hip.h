@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LS_ABI_VERSION 4
+#define LS_ABI_VERSION 5
 
 enum {
     LS_OK = 0,
@@ -203,6 +203,7 @@ typedef struct ls_timing {
     int32_t tail2_path;
     int32_t n_cus;              /* compute units of the handle's device (hipDeviceProp.multiProcessorCount): what the plans and the
                                    sample-split kernel's residency are derived from */
+    int32_t coop_slices;        /* slice workgroups per (sample, pass) the sample-split piece of the last loop ran with: 8 | 4 | 2 (0: the plan had no such piece) */
 } ls_timing;
 
 int ls_abi_version(void);
@@ -223,7 +224,10 @@ int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; def
  * per step, and takes the small batches; 1: always one workgroup per sample; 2: the batch-level kernels of the long-sequence path
  * (21 launches per step; exact fp32, both CFG passes always evaluated); 3: always the sample-split kernel (exact fp32); 4: always the
  * one-pass-per-workgroup kernel (a workgroup of 4 waves per (sample, CFG pass), two independent workgroups per CU, the passes combined by
- * the later of the two: half-CU granularity, exact fp32).  Same
+ * the later of the two: half-CU granularity, exact fp32; grids of up to one workgroup per CU run as 8-wave workgroups, larger ones as
+ * 4-wave workgroups, two per CU); 5: the same kernel with the 4-wave / two-per-CU form at EVERY grid size (what mode 4 and the plans of
+ * a device with fewer CUs reach only beyond one workgroup per CU; this selector pins that form to the reference's fixtures); 6 / 7 / 8:
+ * the sample-split kernel with its slicing forced to 4 / 2 / 8 channel slices per (sample, CFG pass) (mode 3 chooses per piece).  Same
  * arithmetic every way, different summation order: results agree to ~1e-5, not bitwise.  Takes effect at the next ls_prepare;
  * ls_timing.step_path reports what ran. */
 int ls_set_path(ls_handle* h, int mode);
@@ -231,6 +235,9 @@ int ls_set_path(ls_handle* h, int mode);
  * for inspection and for the CPU test suite): out10 = {pieces, then (kernel family as in ls_timing.step_path, first clip, clips) for up to
  * three pieces}; *ms (nullable) = the step-time model's estimate.  beat: 0 TED / 1 BEAT cost table; single_pass: every guidance scale is 1. */
 int ls_plan_query(int beat, int batch, int single_pass, int precision, int n_cus, int* out10, float* ms);
+/* Slice workgroups per (sample, CFG pass) -- 8, 4 or 2 -- the sample-split kernel uses for a plan piece of `groups` (sample, pass) groups
+ * (clips x 2 under CFG, clips x 1 in the single-pass form) on a device of `n_cus` compute units; negative error code otherwise. */
+int ls_plan_coop_slices(int beat, int groups, int n_cus);
 int ls_set_schedule(ls_handle* h, const ls_schedule* s);
 int ls_prepare(ls_handle* h, const ls_cond* c);           /* once per sampling call */
 /* The same, enqueued on the handle's stream WITHOUT waiting: later calls on this handle are ordered behind it, so the caller may

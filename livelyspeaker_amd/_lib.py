@@ -79,7 +79,7 @@ class LsTiming(C.Structure):
     _fields_ = [("prepare_ms", C.c_float), ("loop_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_step_launches", C.c_int32), ("graph_replayed", C.c_int32), ("single_pass", C.c_int32),
                 ("tape_upload_ms", C.c_float), ("n_segments", C.c_int32), ("step_path", C.c_int32),
-                ("tail_samples", C.c_int32), ("tail_path", C.c_int32), ("tail2_samples", C.c_int32), ("tail2_path", C.c_int32), ("n_cus", C.c_int32)]
+                ("tail_samples", C.c_int32), ("tail_path", C.c_int32), ("tail2_samples", C.c_int32), ("tail2_path", C.c_int32), ("n_cus", C.c_int32), ("coop_slices", C.c_int32)]
 
 
 class LsTrainConfig(C.Structure):
@@ -103,7 +103,7 @@ class LsEvalConfig(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_trng_randn", "ls_trng_fill_steps", "ls_trng_stats", "ls_trng_pairs_debug", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_plan_coop_slices", "ls_trng_randn", "ls_trng_fill_steps", "ls_trng_stats", "ls_trng_pairs_debug", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
@@ -182,6 +182,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_set_precision.argtypes = [C.c_void_p, C.c_int]
     lib.ls_set_path.argtypes = [C.c_void_p, C.c_int]
     lib.ls_plan_query.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    lib.ls_plan_coop_slices.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.ls_trng_randn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     lib.ls_trng_fill_steps.argtypes = [C.c_void_p, C.c_size_t] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.ls_trng_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -228,7 +229,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_eval_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     lib.ls_eval_commit_weights.argtypes = [C.c_void_p]
     lib.ls_eval_features.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    if lib.ls_abi_version() != 4:
+    if lib.ls_abi_version() != 5:
         raise EngineError("libls_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -349,6 +350,15 @@ def plan_query(batch, dataset="ted", single_pass=False, precision="fp32", n_cus=
     return [(out[1 + 3 * i], out[2 + 3 * i], out[3 + 3 * i]) for i in range(out[0])], float(ms.value)
 
 
+def plan_coop_slices(groups, dataset="ted", n_cus=256):
+    """Slice workgroups per (sample, CFG pass) the sample-split kernel uses for ``groups`` (sample, pass) groups: 8, 4 or 2."""
+    lib = load_library()
+    rc = lib.ls_plan_coop_slices(int(dataset != "ted"), int(groups), int(n_cus))
+    if rc < 0:
+        raise EngineError(f"ls_plan_coop_slices failed ({rc})")
+    return rc
+
+
 class Engine:
     """One handle = one GPU. Thin, typed wrapper over the C-ABI; all arrays in/out are host numpy
     (torch CUDA tensors on the same device may be passed to ``sample``/``prepare`` via ``*_device``)."""
@@ -407,7 +417,7 @@ class Engine:
         (batch-level kernels, 21 launches per step), 'coop' (sample-split kernel), 'pass' (one workgroup per (sample, CFG pass), two per
         CU); applies from the next prepare().  None = 'auto'."""
         mode = "auto" if mode is None else mode
-        code = {"auto": 0, "fused": 1, "batch": 2, "coop": 3, "pass": 4}.get(mode, mode)
+        code = {"auto": 0, "fused": 1, "batch": 2, "coop": 3, "pass": 4, "pass4": 5, "coop4": 6, "coop2": 7, "coop8": 8}.get(mode, mode)
         self._check(self.lib.ls_set_path(self.h, int(code)), "ls_set_path")
         self.path = mode
 

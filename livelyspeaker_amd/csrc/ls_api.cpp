@@ -70,7 +70,8 @@ struct ls_handle {
     bool use_pass = false;  // the prepared batch runs the one-pass-per-workgroup kernel (ls_pass_kernel.h: two independent workgroups per CU)
     DevBuf pa_out, pa_cnt;  // its CFG hand-off: pass outputs [n][2][T][J*F], arrival tickets [n]
     int pass_n = 0;         // samples the hand-off buffers hold
-    int pass_waves = 0;     // 0: 8-wave workgroups when the grid fits the chip once, 4-wave otherwise; LS_PASS_WAVES = 4 | 8 forces one (-DLS_DEBUG builds)
+    int pass_waves = 0;     // 0: 8-wave workgroups when the grid fits the chip once, 4-wave otherwise; 4: ls_set_path(5) forces the 4-wave form
+    int pass_waves_env = 0; // LS_PASS_WAVES = 4 | 8 forces one (-DLS_DEBUG builds only)
     bool use_coop = false;  // the prepared batch runs the sample-split kernel (ls_coop_kernel.h: 16 workgroups per sample)
     // the step plan of the prepared batch (decide_path): up to three pieces, e.g. 416 clips = 256 on the fused kernel + 128 on the
     // one-pass-per-workgroup kernel (one workgroup per CU) + 32 on the sample-split kernel.  use_long / use_coop / use_pass: the whole batch
@@ -85,7 +86,8 @@ struct ls_handle {
     unsigned coop_launches = 0;                        // launches since the granule words were zeroed: epoch = 64 * ordinal
     unsigned coop_err_host = 0;
     int n_cu = 256;         // compute units of the device (hipDeviceProp.multiProcessorCount): residency of the sample-split kernel, round sizes of the plans
-    int coop_groups_max = kCoopMaxGroups, coop_groups = 0;   // (sample, pass) groups per launch: cap (two workgroups per CU, eight per group), and what the workspaces hold
+    int coop_groups_max = kCoopMaxGroups, coop_groups = 0;   // (sample, pass) groups per launch: cap of the 8-slice form (two workgroups per CU, eight per group), and what the workspaces hold
+    int coop_ncb = 0;       // slicing of the sample-split kernel: 0 = by the step-time model; 1 | 2 | 4 = 8 | 4 | 2 slice workgroups per (sample, pass) (ls_set_path 8 | 6 | 7)
     int coop_xmap = 0;      // blockIdx -> (group, slice) mapping of the sample-split kernel (speed only; LS_COOP_XMAP in -DLS_DEBUG builds)
     int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
@@ -597,10 +599,45 @@ int ensure_temb_table(ls_handle* h) {
     return LS_OK;
 }
 
-// the sample-split kernel over samples [first, first + n): 16 (CFG) or 8 (single pass) workgroups per sample, as many samples per
-// launch as are resident at once
+// (sample, pass) groups of the sample-split kernel resident at once, by slicing: ncb = 1 (8 slices of 64 channels): two workgroups per CU;
+// ncb = 2 / 4 (4 / 2 slices): one per CU (their registers).  The slices of a group wait for each other, so a launch never exceeds this.
+int coop_cap(int n_cu, int ncb) {
+    const int cap = (ncb == 1 ? 2 : 1) * n_cu / (8 / ncb);
+    return ncb == 1 && cap > kCoopMaxGroups ? kCoopMaxGroups : cap;
+}
+// Step time of the sample-split kernel in ms, measured on MI355X (profiles/r06_split_variants.md): per launch base + per (sample, pass)
+// group, for ncb = 1 | 2 | 4; [0] TED, [1] BEAT.  `g` groups cost the sum over the launches it takes.
+struct CoopCost { float base, per_group; };
+constexpr CoopCost kCoopCost[2][3] = {{{0.0875f, 0.00096f}, {0.1381f, 0.00041f}, {0.2299f, 0.0000992f}},
+                                      {{0.0963f, 0.00103f}, {0.1529f, 0.000327f}, {0.2628f, 0.0000833f}}};
+float coop_ms_ncb(bool ted, int ncb, int g, int n_cu) {
+    const CoopCost& c = kCoopCost[ted ? 0 : 1][ncb == 1 ? 0 : ncb == 2 ? 1 : 2];
+    const int cap = coop_cap(n_cu, ncb);
+    if (cap < 1) return 1e30f;
+    float ms = 0.f;
+    for (; g > 0; g -= cap) ms += c.base + c.per_group * (g < cap ? g : cap);
+    return ms;
+}
+// the slicing the model prefers for `g` groups (ties go to more slices: shorter chains per workgroup)
+int coop_pick_ncb(bool ted, int g, int n_cu) {
+    int best = 1;
+    float bm = coop_ms_ncb(ted, 1, g, n_cu);
+    for (int ncb = 2; ncb <= 4; ncb *= 2) {
+        const float m = coop_ms_ncb(ted, ncb, g, n_cu);
+        if (m < bm) { bm = m; best = ncb; }
+    }
+    return best;
+}
+
+// the sample-split kernel over samples [first, first + n): 8 / ncb workgroups per (sample, pass), as many samples per launch as are
+// resident at once
 hipError_t run_coop(ls_handle* h, const StepArgs& s, int first, int n, bool pair, hipStream_t st) {
-    const int np = pair ? 1 : 2, per = h->coop_groups / np;
+    const int np = pair ? 1 : 2;
+    const int ncb = h->coop_ncb ? h->coop_ncb : coop_pick_ncb(h->var == kTED, n * np, h->n_cu);
+    int cap = coop_cap(h->n_cu, ncb);
+    if (cap > h->coop_groups) cap = h->coop_groups;
+    const int per = cap / np;
+    if (per < 1) return hipErrorInvalidValue;
     for (int b0 = first; b0 < first + n; b0 += per) {
         StepArgs c = s;
         c.cx = h->co_x.f(); c.cpart = h->co_part.f();
@@ -608,7 +645,7 @@ hipError_t run_coop(ls_handle* h, const StepArgs& s, int first, int n, bool pair
         c.cerr = static_cast<unsigned*>(h->co_err.p);
         c.epoch = (++h->coop_launches) * kCoopEpochStride;      // tags of one launch: epoch + 1 .. epoch + 2 * layers + 1 < the stride (checked in decide_path / ls_set_path)
         c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap;
-        hipError_t e = launch_step_coop(h->var, c, first + n - b0 < per ? first + n - b0 : per, st);
+        hipError_t e = launch_step_coop(h->var, ncb, c, first + n - b0 < per ? first + n - b0 : per, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -624,7 +661,8 @@ hipError_t run_pass(ls_handle* h, const StepArgs& s, int first, int n, bool pair
 #ifdef LS_PASS_FORCE_WAVES
     const int waves = LS_PASS_FORCE_WAVES;          // A/B builds (tools/ab_variants.py)
 #else
-    const int waves = h->pass_waves ? h->pass_waves : (n * c.npass <= h->n_cu ? 8 : 4);
+    const int forced = h->pass_waves_env ? h->pass_waves_env : h->pass_waves;
+    const int waves = forced ? forced : (n * c.npass <= h->n_cu ? 8 : 4);
 #endif
     return launch_step_pass(h->var, h->precision == 1 ? 1 : 0, waves, c, n, st);
 }
@@ -783,18 +821,13 @@ struct PathCost { float coop_base, coop_per_group, long_base, long_per_sample, f
 constexpr PathCost kCostTed{0.0875f, 0.00096f, 0.175f, 0.0030f, 0.68f, 0.682f, 0.363f, 0.378f}, kCostBeat{0.0963f, 0.00103f, 0.166f, 0.0034f, 0.79f, 0.84f, 0.437f, 0.47f};
 // bf16x3 (opt-in precision) exists in the fused and the one-pass-per-workgroup kernels only; measured on MI355X (tools/bf16x3_time.py)
 constexpr PathCost kCostTedBf{1e30f, 1e30f, 1e30f, 1e30f, 0.289f, 0.321f, 0.193f, 0.2005f}, kCostBeatBf{1e30f, 1e30f, 1e30f, 1e30f, 0.391f, 0.462f, 0.28f, 0.302f};
-float coop_ms(const PathCost& c, int n, int np, int gmax) {
-    float ms = 0.f;
-    for (int g = n * np; g > 0; g -= gmax) ms += c.coop_base + c.coop_per_group * (g < gmax ? g : gmax);
-    return ms;
-}
 // one-pass-per-workgroup kernel: two workgroups per CU are resident (pass_round each); up to one per CU left over run alone on their CU
 float pass_ms(const PathCost& c, int n, int np, int n_cu) {
     const int wgs = n * np, full = wgs / (2 * n_cu), rem = wgs % (2 * n_cu);
     return c.pass_round * full + (rem == 0 ? 0.f : rem <= n_cu ? (full ? c.pass_after : c.pass_single) : c.pass_round);
 }
 // The plan as a pure function of what it depends on (also behind ls_plan_query, which needs no GPU: tests/test_host_logic.py).
-struct PlanIn { bool ted, fused, have_long, pair; int B, precision, path_mode, n_cu, coop_groups_max, layers; };
+struct PlanIn { bool ted, fused, have_long, pair; int B, precision, path_mode, n_cu, coop_groups_max, layers, coop_ncb; };
 struct PlanOut { int nseg; Seg seg[3]; float ms; };
 PlanOut plan_steps(const PlanIn& in) {
     PlanOut o{1, {{0, 0, in.B}, {0, 0, 0}, {0, 0, 0}}, 0.f};
@@ -809,12 +842,12 @@ PlanOut plan_steps(const PlanIn& in) {
     const PathCost& c = bf ? (in.ted ? kCostTedBf : kCostBeatBf) : (in.ted ? kCostTed : kCostBeat);
     const int B = in.B, np = in.pair ? 1 : 2, round = 2 * in.n_cu / np, unit = in.n_cu / np;     // round: samples of one fused round; unit: samples that put ONE pass workgroup on every CU
     const float thr = 256.0f / (float)in.n_cu;          // throughput-bound terms (measured on 256 CUs) on a smaller / larger device
-    const int gmax = in.coop_groups_max > 0 ? in.coop_groups_max : 1;
     auto cost = [&](int path, int n) -> float {
         switch (path) {
         case 0: return c.fused_round * ((n + round - 1) / round);
         case 1: return in.have_long && !bf ? c.long_base + c.long_per_sample * thr * n : 1e30f;
-        case 2: return bf || in.coop_groups_max < np || 2 * in.layers + 2 > (int)kCoopEpochStride ? 1e30f : coop_ms(c, n, np, gmax);
+        case 2: return bf || in.coop_groups_max < np || 2 * in.layers + 2 > (int)kCoopEpochStride ? 1e30f
+                       : coop_ms_ncb(in.ted, in.coop_ncb ? in.coop_ncb : coop_pick_ncb(in.ted, n * np, in.n_cu), n * np, in.n_cu);
         default: return pass_ms(c, n, np, in.n_cu);
         }
     };
@@ -853,7 +886,7 @@ void decide_path(ls_handle* h) {
     const long long before = plan_code(h);
     h->plan_pair = h->all_scale_one;
     const PlanOut o = plan_steps(PlanIn{h->var == kTED, h->fused, h->lw_wtp.p != nullptr, h->plan_pair, h->B, h->precision, h->path_mode, h->n_cu,
-                                        h->coop_groups_max, h->cfg.layers});
+                                        h->coop_groups_max, h->cfg.layers, h->coop_ncb});
     h->nseg = o.nseg;
     for (int i = 0; i < 3; ++i) h->seg[i] = o.seg[i];
     h->use_long = h->nseg == 1 && h->seg[0].path == 1;
@@ -869,6 +902,28 @@ hipError_t coop_reset(ls_handle* h, hipStream_t st) {
     if (e == hipSuccess) e = hipMemsetAsync(h->co_flag.p, 0, h->co_flag.bytes, st);
     h->coop_launches = 0;
     return e;
+}
+
+// A fresh range of hand-off tags for the call about to be enqueued (CallParams::tag_base, read by the sample-split kernel from device
+// memory): advanced past everything the PREVIOUS call can have used -- 64 tags per launch it made (a forced sample-split path at a large
+// batch makes many: 2048 clips x 1000 steps = 64 000 launches) -- and by at least 2^21, so that a granule an earlier call left behind can
+// never pass for this call's whatever the zeroing ahead of the loop did.  (32-bit tags wrap after >= 2048 calls; every granule word is
+// rewritten by every call that polls it, so a value that old no longer exists.)
+// Arrival tickets of the one-pass-per-workgroup kernel: handed back at zero by every step's second arriver, and re-zeroed here ahead of
+// every call by a plain stream memset (NOT a node of the captured loop: a replayed memset node was seen writing garbage,
+// docs/DESIGN_NOTES_r5.md), so a launch that died between its two arrivals cannot leave an odd ticket behind for the next call.
+hipError_t pass_reset(ls_handle* h, hipStream_t st) {
+    if (seg_n(h, 3) == 0 || !h->pa_cnt.p) return hipSuccess;
+    return hipMemsetAsync(h->pa_cnt.p, 0, h->pa_cnt.bytes, st);
+}
+
+int advance_tags(ls_handle* h, hipStream_t st) {
+    HIPCHK(h, pass_reset(h, st));
+    const unsigned long long span = ((unsigned long long)h->coop_launches + 2ull) * kCoopEpochStride;
+    h->tag_base += span > (1ull << 21) ? (unsigned)span : (1u << 21);
+    h->call_host.tag_base = h->tag_base;
+    HIPCHK(h, hipMemcpyAsync(h->callp.p, &h->call_host, sizeof(CallParams), hipMemcpyHostToDevice, st));
+    return LS_OK;
 }
 
 // after a stream synchronisation: did a hand-off spin of the sample-split kernel run out?  (Never observed; a result computed past a
@@ -888,6 +943,13 @@ void report_path(ls_handle* h, bool pair) {
     h->timing.tail_path = split ? h->seg[1].path : 0;
     h->timing.tail2_samples = split && h->nseg > 2 ? h->seg[2].n : 0;
     h->timing.tail2_path = split && h->nseg > 2 ? h->seg[2].path : 0;
+    h->timing.coop_slices = 0;
+    if (h->fused && (h->nseg == 1 || split))
+        for (int i = 0; i < h->nseg; ++i)
+            if (h->seg[i].path == 2) {
+                const int n = h->nseg == 1 ? h->B : h->seg[i].n, np = pair ? 1 : 2;
+                h->timing.coop_slices = 8 / (h->coop_ncb ? h->coop_ncb : coop_pick_ncb(h->var == kTED, n * np, h->n_cu));
+            }
 }
 
 // upload timing of a slot whose copy has been enqueued: wait for it (long done in steady state) and add it to the loop's total
@@ -940,6 +1002,7 @@ int sample_segment(ls_handle* h, const ls_sample_args* a) {
             HIPCHK(h, h->dump.ensure((size_t)a->n_dump * nx));
             if (old != h->dump.p) free_graph(h);
         }
+        if ((rc = advance_tags(h, st)) != LS_OK) return rc;
         HIPCHK(h, coop_reset(h, st));
         h->seg_next = 0; h->seg_index = 0; h->seg_skip = a->skip_timesteps; h->seg_sampler = a->sampler; h->seg_upload_ms = 0.f;
         h->slot_used[0] = h->slot_used[1] = false;
@@ -1065,7 +1128,8 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (const char* pr = getenv("LS_PROF")) { h->prof_on = true; h->prof_wg = atoi(pr); }
     if (const char* xm = getenv("LS_COOP_XMAP")) h->coop_xmap = atoi(xm);
     if (const char* gm = getenv("LS_COOP_GROUPS")) h->coop_groups_max = atoi(gm);
-    if (const char* pw = getenv("LS_PASS_WAVES")) h->pass_waves = atoi(pw) == 8 ? 8 : atoi(pw) == 4 ? 4 : 0;
+    if (const char* nc = getenv("LS_COOP_NCB")) h->coop_ncb = atoi(nc) == 2 ? 2 : atoi(nc) == 4 ? 4 : atoi(nc) == 1 ? 1 : 0;
+    if (const char* pw = getenv("LS_PASS_WAVES")) h->pass_waves_env = atoi(pw) == 8 ? 8 : atoi(pw) == 4 ? 4 : 0;
 #endif
     h->var = var;
     h->JF = JF;
@@ -1195,16 +1259,30 @@ int ls_set_precision(ls_handle* h, int mode) {
 int ls_plan_query(int beat, int batch, int single_pass, int precision, int n_cus, int* out10, float* ms) {
     if (!out10 || batch < 1 || n_cus < 8) return LS_EINVAL;
     const int gmax = 2 * n_cus / 8 < kCoopMaxGroups ? 2 * n_cus / 8 : kCoopMaxGroups;
-    const PlanOut o = plan_steps(PlanIn{beat == 0, true, true, single_pass != 0, batch, precision, 0, n_cus, gmax, 8});
+    const PlanOut o = plan_steps(PlanIn{beat == 0, true, true, single_pass != 0, batch, precision, 0, n_cus, gmax, 8, 0});
     out10[0] = o.nseg;
     for (int i = 0; i < 3; ++i) { out10[1 + 3 * i] = o.seg[i].path; out10[2 + 3 * i] = o.seg[i].first; out10[3 + 3 * i] = o.seg[i].n; }
     if (ms) *ms = o.ms;
     return LS_OK;
 }
 
+// Slice workgroups per (sample, pass) the sample-split kernel would use for a piece of `groups` (sample, pass) groups (mode 3's choice).
+int ls_plan_coop_slices(int beat, int groups, int n_cus) {
+    if (groups < 1 || n_cus < 8) return LS_EINVAL;
+    return 8 / coop_pick_ncb(beat == 0, groups, n_cus);
+}
+
 int ls_set_path(ls_handle* h, int mode) {
     if (!h) return LS_EINVAL;
-    if (mode < 0 || mode > 4) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel, 4 one workgroup per (sample, pass))", mode);
+    if (mode < 0 || mode > 8) return fail(h, LS_EINVAL, "ls_set_path: mode %d (0 auto, 1 one workgroup per sample, 2 batch-level kernels, 3 sample-split kernel, 4 one workgroup per (sample, pass), 5 the same in its 4-wave / two-per-CU form at every grid size, 6 / 7 / 8 the sample-split kernel with 4 / 2 / 8 slices per (sample, pass))", mode);
+    // modes 6 / 7 / 8 = mode 3 with the slicing forced (mode 3 picks it per piece from the step-time model): every slicing is pinned to the
+    // reference's fixtures through these selectors (tests/test_gpu_coop.py)
+    const int ncb = mode == 6 ? 2 : mode == 7 ? 4 : mode == 8 ? 1 : 0;
+    if (mode >= 6) mode = 3;
+    // mode 5 = mode 4 with the 4-wave form forced (mode 4 picks it only for grids beyond one workgroup per CU): the form the plans of a
+    // device with fewer CUs reach at small batches, pinned to the reference's fixtures at B = 4 / 5 through this selector (tests/test_gpu_pass.py)
+    const int waves = mode == 5 ? 4 : 0;
+    if (mode == 5) mode = 4;
     if (mode >= 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has neither the sample-split nor the one-pass-per-workgroup kernel", kT);
     if (mode == 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split kernel is exact fp32 only");
     if (mode == 3 && 2 * h->cfg.layers + 2 > (int)kCoopEpochStride)
@@ -1213,7 +1291,7 @@ int ls_set_path(ls_handle* h, int mode) {
         return fail(h, LS_EUNSUPPORTED, "the sample-split kernel needs the 16 workgroups of a sample resident at once (two per CU): %d CUs are too few", h->n_cu);
     if (mode == 2 && h->fused && h->lw_wtp.p == nullptr && h->committed) return fail(h, LS_EUNSUPPORTED, "batch-level kernels need S <= 160");
     if (mode == 1 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has no fused kernel", kT);
-    if (mode != h->path_mode) { h->path_mode = mode; h->prepared = false; free_graph(h); }      // takes effect at the next ls_prepare (workspaces)
+    if (mode != h->path_mode || waves != h->pass_waves || ncb != h->coop_ncb) { h->path_mode = mode; h->pass_waves = waves; h->coop_ncb = ncb; h->prepared = false; free_graph(h); }      // takes effect at the next ls_prepare (workspaces)
     return LS_OK;
 }
 
@@ -1335,7 +1413,10 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
     { const int keepB = h->B; h->B = B; decide_path(h); h->B = keepB; }
     if (seg_n(h, 2) > 0) {      // exchange workspaces of the sample-split kernel: one launch's worth of (sample, pass) groups
         const int nco = seg_n(h, 2);
-        const int groups = 2 * nco < h->coop_groups_max ? 2 * nco : h->coop_groups_max;
+        int gcap = h->coop_groups_max;                  // the most groups any slicing keeps resident (LS_COOP_GROUPS caps all of them in -DLS_DEBUG builds)
+        if (gcap == coop_cap(h->n_cu, 1))
+            for (int ncb = 2; ncb <= 4; ncb *= 2) if (coop_cap(h->n_cu, ncb) > gcap) gcap = coop_cap(h->n_cu, ncb);
+        const int groups = 2 * nco < gcap ? 2 * nco : gcap;
         const void* old[4] = {h->co_x.p, h->co_part.p, h->co_gran.p, h->co_flag.p};
         const size_t before = h->co_x.bytes;
         HIPCHK(h, h->co_x.ensure((size_t)groups * 36 * kD * sizeof(float)));
@@ -1426,6 +1507,7 @@ int ls_forward(ls_handle* h, const ls_forward_args* a) {
         HIPCHK(h, h->trace.ensure((size_t)B * (h->cfg.layers + 1) * h->R * kD * sizeof(float)));
         s.trace = h->trace.f();
     }
+    if ((rc = advance_tags(h, st)) != LS_OK) return rc;
     HIPCHK(h, coop_reset(h, st));
     HIPCHK(h, run_step(h, s, B, false, st));      // model(x, t, y) parity entry: both passes always
     float* outs[3] = {a->out_cond, a->out_uncond, a->out_cfg};
@@ -1480,6 +1562,7 @@ int ls_step(ls_handle* h, const ls_step_args* a) {
     HIPCHK(h, hipMemcpyAsync(h->eps.f(), a->eps_cond, (size_t)B * kD * sizeof(float), kind, st));
     HIPCHK(h, hipMemcpyAsync(h->eps.f() + (size_t)B * kD, a->eps_uncond, (size_t)B * kD * sizeof(float), kind, st));
     if ((rc = ingest(h, h->noise, a->noise, nx, od)) != LS_OK) return rc;
+    if ((rc = advance_tags(h, st)) != LS_OK) return rc;
     HIPCHK(h, coop_reset(h, st));
     StepArgs s;
     fill_common(h, s);
@@ -1583,9 +1666,8 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
     if ((rc = ensure_temb_table(h)) != LS_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     HIPCHK(h, h->xa.ensure(nx)); HIPCHK(h, h->xb.ensure(nx)); HIPCHK(h, h->xtmp.ensure(nx)); HIPCHK(h, h->xio.ensure(nx));
-    h->tag_base += 1u << 21;          // > 64 tags x the launches of any call: this call's hand-off tags are new even against granules a failed reset left behind
     h->call_host = CallParams{a->seed, a->sample_offset, h->tag_base, 0u};
-    HIPCHK(h, hipMemcpyAsync(h->callp.p, &h->call_host, sizeof(CallParams), hipMemcpyHostToDevice, st));
+    if ((rc = advance_tags(h, st)) != LS_OK) return rc;          // uploads call_host with this call's tag base
 
     // x_T (gaussian_diffusion.py:700-707 / :972-977)
     if (a->x_init) {

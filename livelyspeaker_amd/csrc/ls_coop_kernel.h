@@ -46,13 +46,26 @@ namespace ls {
 
 constexpr int kCoopThreads = 512;
 constexpr int kCoopWaves = 8;
-constexpr int kCoopSlices = 8;             // channel slices of 64
 constexpr int kCoopRows = 36;              // rows of one pass in the exchange buffers (S <= 36)
-constexpr int kCoopU1Stride = 80;          // LDS row stride of the token-mix operand [S][64]: = 16 mod 32, conflict-free column reads
 constexpr unsigned kCoopSpinLimit = 1u << 18;       // polls (~1-2 us each) before a hand-off wait gives up: waits are < 1 ms when the slices are resident
-constexpr int kCoopSliceFloats = 4 * kCoopRows * 16;   // one slice's rows in exchange order [4 k blocks][36 rows][16]: 9216 B
-// LDS: psum [4][48] f2 | stat [48] f2 | U [8 slices][4][36][16]
-constexpr int kCoopLdsFloats = 2 * 4 * 48 + 2 * 48 + kCoopSlices * kCoopSliceFloats;
+// LDS: psum [4][48] f2 | stat [48] f2 | U [32 k blocks of 16 channels][36 rows][16] (all 512 channels of one pass, whatever the slicing)
+constexpr int kCoopLdsFloats = 2 * 4 * 48 + 2 * 48 + 32 * kCoopRows * 16;
+// The slicing is a template parameter (round 6): NCB = 16-channel blocks per WAVE = 1 | 2 | 4, i.e. slices of 64 | 128 | 256 channels,
+// 8 | 4 | 2 slice workgroups per (sample, pass).  NCB = 1 is the round-4 kernel (two workgroups per CU: 32 clips fill the chip); with
+// NCB = 2 / 4 a workgroup holds twice / four times the registers (one workgroup per CU: 32 / 64 clips fill the chip), exchanges
+// 3/7 / 1/7 of the rows per group and layer, and -- with two slices -- multiplies its own half of k for ~18 k clocks while the other
+// half arrives, so the row hand-off leaves the chain altogether.
+template <int NCB> struct CoopGeom {
+    static_assert(NCB == 1 || NCB == 2 || NCB == 4, "16-channel blocks per wave");
+    static constexpr int NS = 8 / NCB;                     // slice workgroups of one (sample, pass)
+    static constexpr int KB = 4 * NCB;                     // 16-channel k blocks of a slice
+    static constexpr int CPS = 64 * NCB;                   // channels per slice
+    static constexpr int SLICEF = KB * kCoopRows * 16;     // one slice's rows in exchange order [KB k blocks][36 rows][16], floats
+    static constexpr int U1S = CPS + 16;                   // LDS row stride of the token-mix operand [S][CPS]: = 16 mod 32, conflict-free column reads
+    static constexpr int HB = KB / 2;                      // k blocks of one slice a wave half multiplies
+    static constexpr int PF = NCB == 1 ? 4 : 2;            // k blocks whose weight fragments are in flight (NCB fragments each)
+    static constexpr int MINW = NCB == 1 ? 4 : 2;          // waves per SIMD the register budget allows for (two | one workgroup per CU)
+};
 
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long* gu64p;
@@ -81,8 +94,10 @@ __device__ __forceinline__ void gran_store(unsigned long long* p, unsigned tag, 
     __hip_atomic_store((gu64p)p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int S, int NPRE, int JF>
-__global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
+template <int S, int NPRE, int JF, int NCB>
+__global__ __launch_bounds__(kCoopThreads, CoopGeom<NCB>::MINW) void k_coop(const StepArgs a) {
+    using G = CoopGeom<NCB>;
+    constexpr int NS = G::NS, KB = G::KB, CPS = G::CPS, SLICEF = G::SLICEF, U1S = G::U1S, HB = G::HB, PF = G::PF;
     constexpr int KXQ = (JF + 15) / 16;
     constexpr int KXP = KXQ * 16;
     constexpr int XSTR = KXP + 4;               // LDS row stride of the x_t staging
@@ -97,24 +112,26 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     constexpr int NQUAD = kT * (NOBP / 4);      // (frame, 4 output columns) quads of one sample
     static_assert(S > 32 && S <= kCoopRows, "one pass = two full row tiles + a ragged one");
     static_assert(NREM >= 1 && NREM <= 4, "ragged tile");
-    static_assert(S * XSTR <= kCoopSlices * kCoopSliceFloats, "x_t staging fits the operand buffer");
+    static_assert(S * XSTR <= NS * SLICEF, "x_t staging fits the operand buffer");
+    static_assert(S * U1S <= NS * SLICEF && NCB * (kCoopWaves * 256 + kCoopWaves * 64) <= NS * SLICEF, "overlays fit the operand buffer");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f2* pst = reinterpret_cast<f2*>(smem);                         // [4 channel blocks][48 rows] (mean, M2) over 16 channels
+    f2* pst = reinterpret_cast<f2*>(smem);                         // [4 waves of a half][48 rows] (mean, M2) over the wave's 16 NCB channels
     f2* stat = pst + 4 * 48;                                       // [48 rows] (mean, rstd) over all 512 channels
-    float* U = smem + 2 * 4 * 48 + 2 * 48;                         // [8 slices][4 k blocks][36 rows][16]; overlays: x_t staging, token-mix operand, partial sums
+    float* U = smem + 2 * 4 * 48 + 2 * 48;                         // [NS slices][KB k blocks][36 rows][16]; overlays: x_t staging, token-mix operand, partial sums
 
     const int tid = threadIdx.x;
     int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv & 3, h = wv >> 2;                              // 16-channel block, row half
+    const int w = wv & 3, h = wv >> 2;                              // channel blocks NCB w .. NCB w + NCB - 1 of the slice, row half
     const int bid = blockIdx.x;
     const int np = a.npass;
-    // blockIdx -> (group, slice).  xmap 0: slice = bid % 8, i.e. slice c of every group on XCD c (each XCD's L2 holds one eighth of the
-    // weights; every row hand-off crosses XCDs).  xmap 1: the 8 slices of a group on ONE XCD (measured 35 % slower: the granule polls of
-    // a group then queue on one L2).  Observed round-robin placement; a different placement changes only speed.
-    const int c = a.xmap ? ((bid >> 3) & 7) : (bid & 7);            // channel slice
-    const int pg = a.xmap ? ((bid >> 6) * 8 + (bid & 7)) : (bid >> 3);      // launch-local (sample, pass) group
+    // blockIdx -> (group, slice).  xmap 0: slice = bid % NS, i.e. slice c of every group on XCDs c, c + NS, ... (each XCD's L2 holds 1 / NS
+    // of the weights; every row hand-off crosses XCDs).  xmap 1 (NCB = 1 only): the 8 slices of a group on ONE XCD (measured 35 % slower:
+    // the granule polls of a group then queue on one L2).  Observed round-robin placement; a different placement changes only speed.
+    const bool xm = NCB == 1 && a.xmap;
+    const int c = xm ? ((bid >> 3) & 7) : (bid & (NS - 1));         // channel slice
+    const int pg = xm ? ((bid >> 6) * 8 + (bid & 7)) : (bid / NS);  // launch-local (sample, pass) group
     if (pg >= a.ngroups) return;                                    // xmap 1 rounds the grid up to whole sets of 8 groups
     const int p = np == 2 ? (pg & 1) : 0;
     const int bl = np == 2 ? (pg >> 1) : pg;                        // launch-local sample
@@ -122,20 +139,21 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     const bool unc = p == 1;
     int s16 = lane & 15;
     int g = lane >> 4;
-    int chw = 64 * c + 16 * w + 4 * g;                              // + j = this lane's channels
+    // 16-channel block cb of this wave, numbered over all 512 channels (the weight images' numbering: block = 4 * (k_step wave) + 2 * pass + c2)
+    auto gblk = [&](int cb) { return KB * c + NCB * w + cb; };
+    auto chw = [&](int cb) { return 16 * gblk(cb) + 4 * g; };       // + j = this lane's channels of block cb
     auto fresh = [&]() {
         asm volatile("" : "+v"(lane));
         s16 = lane & 15;
         g = lane >> 4;
-        chw = 64 * c + 16 * w + 4 * g;
     };
     // this lane's rows: r0 = 16 h + s16 (always a real row), r1 = 32 + s16 (half 1 only, the ragged rows)
     auto row0 = [&]() { return 16 * h + s16; };
     auto live1 = [&]() { return h == 1 && s16 < NREM; };
     auto row1c = [&]() { return min(32 + s16, S - 1); };
 
-    float* xg = a.cx + (size_t)pg * kCoopSlices * kCoopSliceFloats;     // centred rows of this (sample, pass), exchange order
-    unsigned long long* gran = a.cgran + (size_t)pg * 2 * kCoopRows * kCoopSlices * 2;   // [2 areas][36 rows][8 slices][2] granules
+    float* xg = a.cx + (size_t)pg * 32 * kCoopRows * 16;                // centred rows of this (sample, pass), exchange order
+    unsigned long long* gran = a.cgran + (size_t)pg * 2 * kCoopRows * NS * 2;   // [2 areas][36 rows][NS slices][2] granules
     unsigned spin_bad = 0;
     // phase stamps, -DLS_DEBUG builds only (tools/coop_profile.py): lane 0 of every wave of one workgroup records s_memtime
     auto stamp = [&](int idx) {
@@ -150,31 +168,34 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     // of the CU's other workgroup is the filler (measured: -3.5 % at 32 TED clips, nothing at 4).
     __builtin_amdgcn_s_setprio(3);
 
-    f4 X0, X1;                                                      // residual stream: rows r0 / r1 of this lane's 4 channels
+    f4 X0[NCB], X1[NCB];                                            // residual stream: rows r0 / r1 of this lane's 4 channels of each block
 
     // ================= embedding: InputProcess + input_mapping (RAG.py:110-114, 184-192) ==========
     {
         const unsigned long long goff = a.call ? a.call->sample_offset : 0ull;
-        auto base_row = [&](int tk) -> f4 {
-            if (tk >= NPRE) return *reinterpret_cast<const f4*>((unc ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + chw);
+        auto base_row = [&](int tk, int ch) -> f4 {
+            if (tk >= NPRE) return *reinterpret_cast<const f4*>((unc ? a.static_u : a.static_c) + ((size_t)b * kT + (tk - NPRE)) * kD + ch);
             if (tk == 0) {                                          // style token: reparameterize(mu, logvar)  (RAG.py:10-13, 116-120)
-                const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + chw);
-                const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + chw);
+                const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + ch);
+                const f4 sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + ch);
                 f4 e;
                 const float* ep = unc ? a.eps_u : a.eps_c;
                 if (ep) {
-                    e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + chw);
+                    e = *reinterpret_cast<const f4*>(ep + (size_t)b * kD + ch);
                 } else {
                     float z[4];
-                    philox_normal4(a.call, goff + (unsigned long long)b, a.step_id, unc ? 2u : 1u, (unsigned)(chw >> 2), z);
+                    philox_normal4(a.call, goff + (unsigned long long)b, a.step_id, unc ? 2u : 1u, (unsigned)(ch >> 2), z);
                     e = (f4){z[0], z[1], z[2], z[3]};
                 }
                 return mu + e * sd;
             }
-            return *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + chw);       // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
+            return *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);       // BEAT emotion token (scripts_beat/model/RAG.py:125-126)
         };
-        X0 = base_row(row0());
-        X1 = live1() ? base_row(row1c()) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            X0[cb] = base_row(row0(), chw(cb));
+            X1[cb] = live1() ? base_row(row1c(), chw(cb)) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
         // x_t of this sample -> LDS [S][KXP] (zero for prefix tokens and pad columns); loads first, then the writes, in blocks
         constexpr int NIT = (S * KXP + kCoopThreads - 1) / kCoopThreads;
         constexpr int CH = 11;
@@ -202,50 +223,86 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
         }
         lds_barrier();
         fresh();
-        f4 acc0 = X0, acc1 = X1;
-        // winx_img[8][2][KXQ][2][64][4] (ls_api.cpp build_fused_images): 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1)
-        const wrsrc_t wrs = wrsrc(a.W->winx_img);
-        const int wsb = ((c * 2 + (w >> 1)) * KXQ * 2 + (w & 1)) * 1024;
-        constexpr int EPF = KXQ < 4 ? KXQ : 4;                       // weight fragments in flight
-        f4 An[EPF];
+        f4 acc0[NCB], acc1[NCB];
 #pragma unroll
-        for (int k = 0; k < EPF; ++k) An[k] = wload4(wrs, lane * 16, wsb + k * 2048);
+        for (int cb = 0; cb < NCB; ++cb) { acc0[cb] = X0[cb]; acc1[cb] = X1[cb]; }
+        // winx_img[8][2][KXQ][2][64][4] (ls_api.cpp build_fused_images): 16-channel block gb = (wave gb >> 2, pass (gb >> 1) & 1, c2 = gb & 1)
+        const wrsrc_t wrs = wrsrc(a.W->winx_img);
+        auto wsb = [&](int cb) { const int gb = gblk(cb); return (((gb >> 2) * 2 + ((gb >> 1) & 1)) * KXQ * 2 + (gb & 1)) * 1024; };
+        constexpr int EPF0 = NCB == 1 ? 4 : 2;
+        constexpr int EPF = KXQ < EPF0 ? KXQ : EPF0;                 // k steps whose weight fragments are in flight
+        f4 An[EPF][NCB];
+#pragma unroll
+        for (int k = 0; k < EPF; ++k)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) An[k][cb] = wload4(wrs, lane * 16, wsb(cb) + k * 2048);
         const float* u0 = &U[row0() * XSTR + 4 * g];
         const float* u1 = &U[row1c() * XSTR + 4 * g];
 #pragma unroll EPF
         for (int q = 0; q < KXQ; ++q) {
-            const f4 A = An[0];
+            f4 A[NCB];
 #pragma unroll
-            for (int k = 0; k + 1 < EPF; ++k) An[k] = An[k + 1];
-            An[EPF - 1] = wload4(wrs, lane * 16, wsb + min(q + EPF, KXQ - 1) * 2048);
+            for (int cb = 0; cb < NCB; ++cb) {
+                A[cb] = An[0][cb];
+#pragma unroll
+                for (int k = 0; k + 1 < EPF; ++k) An[k][cb] = An[k + 1][cb];
+                An[EPF - 1][cb] = wload4(wrs, lane * 16, wsb(cb) + min(q + EPF, KXQ - 1) * 2048);
+            }
             const f4 B0 = *reinterpret_cast<const f4*>(u0 + 16 * q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc0 = MFMA(A[j], B0[j], acc0);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc0[cb] = MFMA(A[cb][j], B0[j], acc0[cb]);
             if (h) {
                 const f4 B1 = *reinterpret_cast<const f4*>(u1 + 16 * q);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc1 = MFMA(A[j], B1[j], acc1);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc1[cb] = MFMA(A[cb][j], B1[j], acc1[cb]);
             }
         }
-        X0 = acc0;
-        X1 = live1() ? acc1 : (f4){0.f, 0.f, 0.f, 0.f};             // pad rows stay zero
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            X0[cb] = acc0[cb];
+            X1[cb] = live1() ? acc1[cb] : (f4){0.f, 0.f, 0.f, 0.f};  // pad rows stay zero
+        }
     }
 
-    // LN_spatial statistics (mlp_module.py:29-33) of every row over all 512 channels, across the 8 slice workgroups:
-    // lane: two passes over its 4 channels; Chan's parallel-variance merge over the 4 lane groups (VALU swaps), the 4 channel blocks
-    // (LDS) and the 8 slices (granules through L2 / memory).
+    // LN_spatial statistics (mlp_module.py:29-33) of every row over all 512 channels, across the NS slice workgroups:
+    // lane: two passes over its 4 NCB channels; Chan's parallel-variance merge over the lane's blocks, the 4 lane groups (VALU swaps), the
+    // 4 waves of a half (LDS) and the NS slices (granules through L2 / memory).
     // ln_publish: this slice's (mean, M2) of every row -> granule area `area`.  `payload`: the caller has issued this workgroup's
     // write-through payload stores; they are drained before the granules -- which double as the payload's ready flags -- go out.
-    auto lane_part = [&](f4 v, float& m, float& m2) {
-        m = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
-        const f4 d4 = v - (f4){m, m, m, m};
-        m2 = (d4[0] * d4[0] + d4[1] * d4[1]) + (d4[2] * d4[2] + d4[3] * d4[3]);
+    auto lane_part = [&](const f4 (&X)[NCB], float& m, float& m2) {
+        float mm[NCB], qq[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const f4 v = X[cb];
+            mm[cb] = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
+            const f4 d4 = v - (f4){mm[cb], mm[cb], mm[cb], mm[cb]};
+            qq[cb] = (d4[0] * d4[0] + d4[1] * d4[1]) + (d4[2] * d4[2] + d4[3] * d4[3]);
+        }
+        // equal counts n merge as: mean = (ma + mb) / 2, M2 = qa + qb + (mb - ma)^2 n / 2
+        if constexpr (NCB >= 2) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb += 2) {
+                const float d = mm[cb + 1] - mm[cb];
+                qq[cb] = (qq[cb] + qq[cb + 1]) + d * d * 2.0f;
+                mm[cb] = 0.5f * (mm[cb] + mm[cb + 1]);
+            }
+        }
+        if constexpr (NCB >= 4) {
+            const float d = mm[2] - mm[0];
+            qq[0] = (qq[0] + qq[2]) + d * d * 4.0f;
+            mm[0] = 0.5f * (mm[0] + mm[2]);
+        }
+        m = mm[0]; m2 = qq[0];
         {
             float ma, mb, qa, qb;
             xor16_pair(m, ma, mb);
             xor16_pair(m2, qa, qb);
             const float d = mb - ma;
-            m2 = (qa + qb) + d * d * 2.0f;
+            m2 = (qa + qb) + d * d * (2.0f * NCB);
             m = 0.5f * (ma + mb);
         }
         {
@@ -253,7 +310,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             xor32_pair(m, ma, mb);
             xor32_pair(m2, qa, qb);
             const float d = mb - ma;
-            m2 = (qa + qb) + d * d * 4.0f;
+            m2 = (qa + qb) + d * d * (4.0f * NCB);
             m = 0.5f * (ma + mb);
         }
     };
@@ -273,7 +330,7 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
         }
         if (payload) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores
         lds_barrier();
-        if (tid < S) {                                                          // row tid: merge the 4 channel blocks, publish the slice's partial
+        if (tid < S) {                                                          // row tid: merge the 4 waves' blocks, publish the slice's partial
             f2 pw[4];
             float ms = 0.f, qs = 0.f;
 #pragma unroll
@@ -282,22 +339,22 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             float dd = 0.f;
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
-            unsigned long long* gp = gran + (size_t)area * kCoopRows * kCoopSlices * 2 + ((size_t)tid * kCoopSlices + c) * 2;
+            unsigned long long* gp = gran + (size_t)area * kCoopRows * NS * 2 + ((size_t)tid * NS + c) * 2;
             gran_store(gp, tag, mt);
-            gran_store(gp + 1, tag, qs + 16.0f * dd);
+            gran_store(gp + 1, tag, qs + (16.0f * NCB) * dd);
         }
     };
-    // ln_gather: wait for all 8 slices' partials of every row, merge -> stat[row] = (mean, rstd) and this lane's rows' values
+    // ln_gather: wait for all NS slices' partials of every row, merge -> stat[row] = (mean, rstd) and this lane's rows' values
     float mean0, rstd0, mean1, rstd1;
     auto ln_gather = [&](int area, unsigned tag, int stamp_at, bool drain = false) {
-        const unsigned long long* ga = gran + (size_t)area * kCoopRows * kCoopSlices * 2;
-        // thread (row = tid >> 3, slice = tid & 7); threads beyond the S rows re-read the last row
-        const int sl = tid & 7, r = min(tid >> 3, S - 1);
-        const bool live = (tid >> 3) < S;
-        const unsigned long long* g0 = ga + ((size_t)r * kCoopSlices + sl) * 2;
+        const unsigned long long* ga = gran + (size_t)area * kCoopRows * NS * 2;
+        // thread (row = tid / NS, slice = tid % NS); threads beyond the S rows re-read the last row
+        const int sl = tid & (NS - 1), r = min(tid / NS, S - 1);
+        const bool live = (tid / NS) < S;
+        const unsigned long long* g0 = ga + ((size_t)r * NS + sl) * 2;
         unsigned long long v0, v1;
         stamp(stamp_at);
-        if (wv * 8 < S) {                                            // waves whose rows exist poll (wave-uniform)
+        if (wv * (64 / NS) < S) {                                    // waves whose rows exist poll (wave-uniform)
             for (unsigned spins = 0;; ++spins) {
                 v0 = gran_load(g0); v1 = gran_load(g0 + 1);
                 const bool ok = (unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag;
@@ -307,10 +364,14 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             }
             const float pm = __uint_as_float((unsigned)v0), pq = __uint_as_float((unsigned)v1);
             float sm = pm;
-            sm = dpp_add<0xB1>(sm); sm = dpp_add<0x4E>(sm); sm = dpp_add<0x141>(sm);     // the 8 lanes of one row
-            const float mu = sm * 0.125f, d = pm - mu;
-            float q = fmaf(64.f * d, d, pq);
-            q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q); q = dpp_add<0x141>(q);
+            sm = dpp_add<0xB1>(sm);                                  // the NS lanes of one row
+            if constexpr (NS >= 4) sm = dpp_add<0x4E>(sm);
+            if constexpr (NS >= 8) sm = dpp_add<0x141>(sm);
+            const float mu = sm * (1.0f / NS), d = pm - mu;
+            float q = fmaf((float)CPS * d, d, pq);
+            q = dpp_add<0xB1>(q);
+            if constexpr (NS >= 4) q = dpp_add<0x4E>(q);
+            if constexpr (NS >= 8) q = dpp_add<0x141>(q);
             if (live && sl == 0) stat[r] = (f2){mu, rsqrtf(q * (1.0f / kD) + 1e-5f)};
         }
         if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the caller's LDS-DMA pulls have landed before anyone passes the barrier
@@ -328,21 +389,28 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     const wrsrc_t rs_ln1a = wrsrc(a.W->ln1a), rs_ln1b = wrsrc(a.W->ln1b), rs_wtok1 = wrsrc(a.W->wtok1_img), rs_bch = wrsrc(a.W->bch),
                   rs_wsum = wrsrc(a.W->wsum), rs_wch = wrsrc(a.W->wch_img), rs_wout = wrsrc(a.W->wout_reg_img);
     const gfp p_btok = g1(a.W->btok_rows), p_bout = g1(a.W->bout);
-    const f4 temb4 = *reinterpret_cast<const f4*>(a.temb + (size_t)b * a.temb_stride + chw);     // the same row at every block
+    f4 temb4[NCB];                                                   // the same row at every block
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) temb4[cb] = *reinterpret_cast<const f4*>(a.temb + (size_t)b * a.temb_stride + chw(cb));
     stamp(1);
 
     // ================= TransMLP: 8 x MLPblock (mlp_module.py:67-91) ================================
     for (int l = 0; l < a.layers; ++l) {
         fresh();
         // x = x + emb  (re-added at the input of EVERY block, mlp_module.py:68-69, 88-89)
-        X0 += temb4;
-        if (live1()) X1 += temb4;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            X0[cb] += temb4[cb];
+            if (live1()) X1[cb] += temb4[cb];
+        }
         // ---- block1: LN -> token-mixing Conv1d(S,S,1) -> SiLU -> residual -------------------------
         ln_publish(0, ep + 2 * l + 1, false);
         // LayerNorm affine, token-mix weights and biases of this wave's row tiles (tile h, and the ragged tile 2 for half 1): requested
         // AFTER the partials are out (22 dword loads per wave ahead of them cost the chain ~1 k clocks of issue), in flight during the
         // exchange -- they depend on no activation.  wtok1_img[l][t][mq][lane][j] = Wt[16 t + (lane & 15)][4 (4 mq + j) + (lane >> 4)]
-        const f4 al1 = wload4(rs_ln1a, chw * 4, l * kD * 4), be1 = wload4(rs_ln1b, chw * 4, l * kD * 4);
+        f4 al1[NCB], be1[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) { al1[cb] = wload4(rs_ln1a, chw(cb) * 4, l * kD * 4); be1[cb] = wload4(rs_ln1b, chw(cb) * 4, l * kD * 4); }
         f4 Bt0[MQ1], Bt1[MQ1];
         float btb0, btb1;
         {
@@ -359,146 +427,180 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
         stamp(2 + 8 * l);
         fresh();
         const float mu1_0 = mean0, mu1_1 = mean1;
-        {
-            const float nm = -mean0 * rstd0;
-            f4 u = __builtin_elementwise_fma(X0, (f4){rstd0, rstd0, rstd0, rstd0}, (f4){nm, nm, nm, nm});
-            u = __builtin_elementwise_fma(u, al1, be1);
-            *reinterpret_cast<f4*>(&U[row0() * kCoopU1Stride + 16 * w + 4 * g]) = u;
-        }
-        if (live1()) {
-            const float nm = -mean1 * rstd1;
-            f4 u = __builtin_elementwise_fma(X1, (f4){rstd1, rstd1, rstd1, rstd1}, (f4){nm, nm, nm, nm});
-            u = __builtin_elementwise_fma(u, al1, be1);
-            *reinterpret_cast<f4*>(&U[(32 + s16) * kCoopU1Stride + 16 * w + 4 * g]) = u;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            {
+                const float nm = -mean0 * rstd0;
+                f4 u = __builtin_elementwise_fma(X0[cb], (f4){rstd0, rstd0, rstd0, rstd0}, (f4){nm, nm, nm, nm});
+                u = __builtin_elementwise_fma(u, al1[cb], be1[cb]);
+                *reinterpret_cast<f4*>(&U[row0() * U1S + 16 * (NCB * w + cb) + 4 * g]) = u;
+            }
+            if (live1()) {
+                const float nm = -mean1 * rstd1;
+                f4 u = __builtin_elementwise_fma(X1[cb], (f4){rstd1, rstd1, rstd1, rstd1}, (f4){nm, nm, nm, nm});
+                u = __builtin_elementwise_fma(u, al1[cb], be1[cb]);
+                *reinterpret_cast<f4*>(&U[(32 + s16) * U1S + 16 * (NCB * w + cb) + 4 * g]) = u;
+            }
         }
         lds_barrier();                                             // token mixing contracts over ROWS: both halves' rows of these channels
         fresh();
         {
             // out[ch][r] = sum_r' u[r'][ch] * Wt[r][r'] + bt[r] as D[channel][row]: A = u^T from LDS, B = the Conv1d weights
-            f4 acc0 = (f4){btb0, btb0, btb0, btb0}, acc1 = (f4){btb1, btb1, btb1, btb1};
+            f4 acc0[NCB], acc1[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) { acc0[cb] = (f4){btb0, btb0, btb0, btb0}; acc1[cb] = (f4){btb1, btb1, btb1, btb1}; }
 #pragma unroll
             for (int m = 0; m < MK1; ++m) {
                 const int sr = (4 * m + 3 < S) ? 4 * m + g : min(4 * m + g, S - 1);   // clamped rows meet zero weights
-                const float av = U[sr * kCoopU1Stride + 16 * w + s16];
-                acc0 = MFMA(av, Bt0[m >> 2][m & 3], acc0);
-                if (h) acc1 = MFMA(av, Bt1[m >> 2][m & 3], acc1);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const float av = U[sr * U1S + 16 * (NCB * w + cb) + s16];
+                    acc0[cb] = MFMA(av, Bt0[m >> 2][m & 3], acc0[cb]);
+                    if (h) acc1[cb] = MFMA(av, Bt1[m >> 2][m & 3], acc1[cb]);
+                }
             }
-            X0 = silu_acc4(acc0, X0);
-            if (live1()) X1 = silu_acc4(acc1, X1);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                X0[cb] = silu_acc4(acc0[cb], X0[cb]);
+                if (live1()) X1[cb] = silu_acc4(acc1[cb], X1[cb]);
+            }
         }
         stamp(3 + 8 * l);
         fresh();
         // ---- block2: LN -> channel-mixing Linear(512,512) -> SiLU -> residual ---------------------
         // This slice's rows, centred on the LayerNorm-1 mean: (write-through) to the other slices, and into its own region of the operand
-        // buffer once every wave is past its token-mix reads of the overlay (the barrier inside ln_publish); k block w of the slice.
+        // buffer once every wave is past its token-mix reads of the overlay (the barrier inside ln_publish); k block NCB w + cb of the slice.
         {
-            const f4 c0 = X0 - (f4){mu1_0, mu1_0, mu1_0, mu1_0}, c1 = X1 - (f4){mu1_1, mu1_1, mu1_1, mu1_1};
-            st_sc1(c0, xrs, ((c * 4 + w) * kCoopRows * 16 + row0() * 16 + 4 * g) * 4);
-            if (live1()) st_sc1(c1, xrs, ((c * 4 + w) * kCoopRows * 16 + (32 + s16) * 16 + 4 * g) * 4);
+            f4 c0[NCB], c1[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                c0[cb] = X0[cb] - (f4){mu1_0, mu1_0, mu1_0, mu1_0};
+                c1[cb] = X1[cb] - (f4){mu1_1, mu1_1, mu1_1, mu1_1};
+                st_sc1(c0[cb], xrs, ((c * KB + NCB * w + cb) * kCoopRows * 16 + row0() * 16 + 4 * g) * 4);
+                if (live1()) st_sc1(c1[cb], xrs, ((c * KB + NCB * w + cb) * kCoopRows * 16 + (32 + s16) * 16 + 4 * g) * 4);
+            }
             ln_publish(1, ep + 2 * l + 2, true);                // LayerNorm-2 partials of the RAW rows
-            float* own = U + c * kCoopSliceFloats + w * (kCoopRows * 16);
-            *reinterpret_cast<f4*>(&own[row0() * 16 + 4 * g]) = c0;
-            if (live1()) *reinterpret_cast<f4*>(&own[(32 + s16) * 16 + 4 * g]) = c1;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float* own = U + c * SLICEF + (NCB * w + cb) * (kCoopRows * 16);
+                *reinterpret_cast<f4*>(&own[row0() * 16 + 4 * g]) = c0[cb];
+                if (live1()) *reinterpret_cast<f4*>(&own[(32 + s16) * 16 + 4 * g]) = c1[cb];
+            }
         }
         stamp(4 + 8 * l);
         fresh();
         {
-            const f4 bc = wload4(rs_bch, chw * 4, l * kD * 4), ws4 = wload4(rs_wsum, chw * 4, l * kD * 4);
-            f4 acc[2];
-            acc[0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
-            float racc[NRV];
-            f4 racc4 = (f4){0.f, 0.f, 0.f, 0.f};
+            f4 bc[NCB], ws4[NCB];
 #pragma unroll
-            for (int r = 0; r < NRV; ++r) racc[r] = 0.f;
-            // wch_img[L][8][2][32 q][2][64][4]: 16-channel block 4c + w = (wave c, pass w >> 1, c2 = w & 1); k block q = 4 s + q' of slice s.
-            // Half h multiplies k blocks q' = 2h, 2h + 1 of every slice, slices in ring order from its own.
+            for (int cb = 0; cb < NCB; ++cb) { bc[cb] = wload4(rs_bch, chw(cb) * 4, l * kD * 4); ws4[cb] = wload4(rs_wsum, chw(cb) * 4, l * kD * 4); }
+            f4 acc[NCB][2];
+            float racc[NCB][NRV];
+            f4 racc4[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                acc[cb][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[cb][1] = acc[cb][0]; racc4[cb] = acc[cb][0];
+#pragma unroll
+                for (int r = 0; r < NRV; ++r) racc[cb][r] = 0.f;
+            }
+            // wch_img[L][8][2][32 q][2][64][4]: 16-channel block gb = (wave gb >> 2, pass (gb >> 1) & 1, c2 = gb & 1); k block q = KB s + q' of slice s.
+            // Half h multiplies k blocks q' = HB h .. HB h + HB - 1 of every slice, slices in ring order from its own.
             const wrsrc_t wrs = rs_wch;
-            const int wsb = (((l * 8 + c) * 2 + (w >> 1)) * 32 * 2 + (w & 1)) * 1024;
-            auto qof = [&](int n) { return ((c + (n >> 1)) & 7) * 4 + 2 * h + (n & 1); };     // the n-th of this wave's 16 k blocks
-            constexpr int PF = 4;                                    // weight fragments in flight ahead of their use
-            f4 An[PF];
+            auto wsb = [&](int cb) { const int gb = gblk(cb); return (((l * 8 + (gb >> 2)) * 2 + ((gb >> 1) & 1)) * 32 * 2 + (gb & 1)) * 1024; };
+            auto qof = [&](int n) { return ((c + n / HB) & (NS - 1)) * KB + HB * h + (n % HB); };     // the n-th of this wave's 16 k blocks
+            constexpr int NKB = NS * HB;                             // = 16
+            f4 An[PF][NCB];                                          // weight fragments in flight ahead of their use
 #pragma unroll
-            for (int k = 0; k < PF; ++k) An[k] = wload4(wrs, lane * 16, wsb + qof(k) * 2048);
-            const unsigned long long* ga = gran + (size_t)kCoopRows * kCoopSlices * 2;         // area 1: row 0's mean granule = slice ready
+            for (int k = 0; k < PF; ++k)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) An[k][cb] = wload4(wrs, lane * 16, wsb(cb) + qof(k) * 2048);
+            const unsigned long long* ga = gran + (size_t)kCoopRows * NS * 2;         // area 1: row 0's mean granule = slice ready
             const unsigned tag2 = ep + 2 * l + 2;
             lds_barrier();                                           // own slice visible to every wave
-            // Pull the 7 other slices (9 chunks of 1 KiB each, dealt over the waves) into their LDS regions as soon as their rows are
+            // Pull the other slices (9 NCB chunks of 1 KiB each, dealt over the waves) into their LDS regions as soon as their rows are
             // published: lane s polls slice s.  The pulls fly while this slice's own k blocks are multiplied from LDS.
             {
                 for (unsigned spins = 0;; ++spins) {
-                    const bool ok = (unsigned)(gran_load(ga + (size_t)(lane & 7) * 2) >> 32) == tag2;
+                    const bool ok = (unsigned)(gran_load(ga + (size_t)(lane & (NS - 1)) * 2) >> 32) == tag2;
                     if (__all(ok)) break;
                     if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 stamp(70 + 2 * l);
+                constexpr int NCHUNK = SLICEF / 256;                 // 1 KiB chunks of a slice: 9 NCB
 #pragma unroll 1
-                for (int i = 1; i < kCoopSlices; ++i) {
-                    const int s = (c + i) & 7;
-                    dma_sc1(xrs, U + s * kCoopSliceFloats + wv * 256, lane * 16, (s * kCoopSliceFloats + wv * 256) * 4);
-                    if (wv == 0) dma_sc1(xrs, U + s * kCoopSliceFloats + 8 * 256, lane * 16, (s * kCoopSliceFloats + 8 * 256) * 4);
+                for (int i = 1; i < NS; ++i) {
+                    const int s = (c + i) & (NS - 1);
+#pragma unroll
+                    for (int ch0 = 0; ch0 < NCHUNK; ch0 += kCoopWaves) {
+                        const int ch = ch0 + wv;
+                        if (ch < NCHUNK) dma_sc1(xrs, U + s * SLICEF + ch * 256, lane * 16, (s * SLICEF + ch * 256) * 4);
+                    }
                 }
             }
             typedef const __attribute__((address_space(3))) f4* ldsp4;
-            // Two slices (= PF k blocks) per trip, so that fragment k of the trip lives in An[k] and is re-requested in place: a rolled
-            // one-slice loop rotates An[] through register moves, and a move of the newest fragment waits for it -- vmcnt(0) at the end of
+            // PF k blocks per trip, so that fragment k of the trip lives in An[k] and is re-requested in place: a rolled
+            // one-block loop rotates An[] through register moves, and a move of the newest fragment waits for it -- vmcnt(0) at the end of
             // every iteration, i.e. no prefetch across iterations at all.
-            static_assert(PF == 4 && kCoopSlices % 2 == 0, "the slice loop is unrolled by PF k blocks");
+            static_assert(NKB % PF == 0 && (PF % HB == 0 || HB % PF == 0), "the k-block loop is unrolled by PF");
 #pragma unroll 1
-            for (int ip = 0; ip < kCoopSlices / 2; ++ip)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int i = 2 * ip + hf;
-                const int s = (c + i) & 7;
-                if (i == 0) __builtin_amdgcn_s_setprio(0);
-                if (i == 1) {
-                    // LayerNorm-2 statistics while the pulls land (their granules came up with the ready flags); its barrier waits for
-                    // vmcnt(0) first: this wave's chunks have landed in LDS, and so have the other waves'
-                    __builtin_amdgcn_s_setprio(3);
-                    ln_gather(1, tag2, 2 + 8 * l + 6, true);
-                    stamp(71 + 2 * l);
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                const float* ub = U + s * kCoopSliceFloats + (2 * h * kCoopRows + s16) * 16 + 4 * g;
-                const float* ubr = U + s * kCoopSliceFloats + (2 * h * kCoopRows + 32 + (kRemMfma ? (lane & 3) : 0)) * 16 + 4 * g;
-                // operands of a k block are read while the previous block is multiplied
+            for (int trip = 0; trip < NKB / PF; ++trip) {
+                // operands of a k block are read while the previous block of the SAME slice is multiplied (never across the point where
+                // the other slices' rows are known to have landed)
                 f4 Bn[2], Un[kRemMfma ? 1 : NRV];
-                auto ldb = [&](int qq) {
+                auto ldb = [&](int n) {
+                    const int s = (c + n / HB) & (NS - 1), kb = HB * h + (n % HB);
+                    const float* ub = U + s * SLICEF + (kb * kCoopRows + s16) * 16 + 4 * g;
+                    const float* ubr = U + s * SLICEF + (kb * kCoopRows + 32 + (kRemMfma ? (lane & 3) : 0)) * 16 + 4 * g;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) Bn[t] = *(ldsp4)(ub + (qq * kCoopRows + 16 * t) * 16);
+                    for (int t = 0; t < 2; ++t) Bn[t] = *(ldsp4)(ub + 16 * t * 16);
 #pragma unroll
-                    for (int r = 0; r < (kRemMfma ? 1 : NRV); ++r) Un[r] = *(ldsp4)(ubr + (qq * kCoopRows + r) * 16);
+                    for (int r = 0; r < (kRemMfma ? 1 : NRV); ++r) Un[r] = *(ldsp4)(ubr + r * 16);
                 };
-                ldb(0);
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int n = 2 * i + qq;
-                    const f4 A = An[2 * hf + qq];
+                for (int u = 0; u < PF; ++u) {
+                    const int n = PF * trip + u;
+                    if (u == 0 && trip == 0) __builtin_amdgcn_s_setprio(0);
+                    if ((PF % HB == 0) ? (trip == 0 && u == HB) : (u == 0 && trip == HB / PF)) {
+                        // LayerNorm-2 statistics while the pulls land (their granules came up with the ready flags); its barrier waits for
+                        // vmcnt(0) first: this wave's chunks have landed in LDS, and so have the other waves'
+                        __builtin_amdgcn_s_setprio(3);
+                        ln_gather(1, tag2, 2 + 8 * l + 6, true);
+                        stamp(71 + 2 * l);
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    const bool head = u == 0 || (PF % HB == 0 && u % HB == 0);                   // first block of a slice (or of the trip)
+                    const bool more = u + 1 < PF && !(PF % HB == 0 && (u + 1) % HB == 0);       // the next block is of the same slice
+                    if (head) ldb(n);
                     f4 Bv[2], Ur[kRemMfma ? 1 : NRV];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) Bv[t] = Bn[t];
 #pragma unroll
                     for (int r = 0; r < (kRemMfma ? 1 : NRV); ++r) Ur[r] = Un[r];
-                    if (qq + 1 < 2) ldb(qq + 1);
+                    if (more) ldb(n + 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) acc[t] = MFMA(A[j], Bv[t][j], acc[t]);
+                        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) acc[cb][t] = MFMA(An[u][cb][j], Bv[t][j], acc[cb][t]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if constexpr (kRemMfma) {
-                            racc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(A[j], Ur[0][j], racc4, 0, 0, 0);
-                        } else {
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int r = 0; r < NRV; ++r) racc[r] = fmaf(A[j], Ur[r][j], racc[r]);
+                        for (int cb = 0; cb < NCB; ++cb) {
+                            if constexpr (kRemMfma) {
+                                racc4[cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(An[u][cb][j], Ur[0][j], racc4[cb], 0, 0, 0);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < NRV; ++r) racc[cb][r] = fmaf(An[u][cb][j], Ur[r][j], racc[cb][r]);
+                            }
                         }
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                     // re-requested in place AFTER its last use (requested before, the old and the new fragment are both live and the new one
                     // is copied into place at the back edge -- behind a wait for it)
-                    An[2 * hf + qq] = wload4(wrs, lane * 16, wsb + qof(min(n + PF, 15)) * 2048);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) An[u][cb] = wload4(wrs, lane * 16, wsb(cb) + qof(min(n + PF, NKB - 1)) * 2048);
                 }
             }
             stamp(5 + 8 * l);
@@ -508,36 +610,43 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             // after the barrier): wave (w, h) keeps row tile h and hands tile 1 - h to wave (w, 1 - h); the ragged rows' partials --
             // summed over the 4 k subsets of the lanes first, [channel-lane][row] -> [row-lane][channel-reg] -- all go to half 1.
             lds_barrier();
-            float* xch = U + wv * 256;                               // [8 waves][64 lanes][4]
-            float* rag = U + 8 * 256 + wv * 64;                      // [8 waves][4 rows][16 channels]
-            *reinterpret_cast<f4*>(&xch[lane * 4]) = h ? acc[0] : acc[1];
-            if constexpr (kRemMfma) {
-                f4 v = racc4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = xor32_sum(xor16_sum(v[i]));
-                if (g == 0) *reinterpret_cast<f4*>(&rag[(lane & 3) * 16 + 4 * (s16 >> 2)]) = v;
-            } else {
+            for (int cb = 0; cb < NCB; ++cb) {
+                float* xch = U + (cb * kCoopWaves + wv) * 256;                           // [NCB][8 waves][64 lanes][4]
+                float* rag = U + NCB * kCoopWaves * 256 + (cb * kCoopWaves + wv) * 64;   // [NCB][8 waves][4 rows][16 channels]
+                *reinterpret_cast<f4*>(&xch[lane * 4]) = h ? acc[cb][0] : acc[cb][1];
+                if constexpr (kRemMfma) {
+                    f4 v = racc4[cb];
 #pragma unroll
-                for (int r = 0; r < NRV; ++r) {
-                    const float v = xor32_sum(xor16_sum(racc[r]));
-                    if (g == 0) rag[r * 16 + s16] = v;
+                    for (int i = 0; i < 4; ++i) v[i] = xor32_sum(xor16_sum(v[i]));
+                    if (g == 0) *reinterpret_cast<f4*>(&rag[(lane & 3) * 16 + 4 * (s16 >> 2)]) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NRV; ++r) {
+                        const float v = xor32_sum(xor16_sum(racc[cb][r]));
+                        if (g == 0) rag[r * 16 + s16] = v;
+                    }
                 }
             }
             // LayerNorm 2 around the product: v = rstd2 * (acc - (mu2 - mu1) wsum) + b'
             lds_barrier();                                         // the partner's partials are in LDS
-            {
-                const f4 mine = h ? acc[1] : acc[0];
-                const f4 sum = mine + *reinterpret_cast<const f4*>(&U[(wv ^ 4) * 256 + lane * 4]);
-                const float dm = mean0 - mu1_0;
-                const f4 v = (sum - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd0, rstd0, rstd0, rstd0} + bc;
-                X0 = silu_acc4(v, X0);
-            }
-            if (live1()) {
-                const f4 rv = *reinterpret_cast<const f4*>(&rag[s16 * 16 + 4 * g]) +
-                              *reinterpret_cast<const f4*>(&U[8 * 256 + (wv ^ 4) * 64 + s16 * 16 + 4 * g]);
-                const float dm = mean1 - mu1_1;
-                const f4 v = (rv - (f4){dm, dm, dm, dm} * ws4) * (f4){rstd1, rstd1, rstd1, rstd1} + bc;
-                X1 = silu_acc4(v, X1);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float* rag = U + NCB * kCoopWaves * 256 + (cb * kCoopWaves + wv) * 64;
+                {
+                    const f4 mine = h ? acc[cb][1] : acc[cb][0];
+                    const f4 sum = mine + *reinterpret_cast<const f4*>(&U[(cb * kCoopWaves + (wv ^ 4)) * 256 + lane * 4]);
+                    const float dm = mean0 - mu1_0;
+                    const f4 v = (sum - (f4){dm, dm, dm, dm} * ws4[cb]) * (f4){rstd0, rstd0, rstd0, rstd0} + bc[cb];
+                    X0[cb] = silu_acc4(v, X0[cb]);
+                }
+                if (live1()) {
+                    const f4 rv = *reinterpret_cast<const f4*>(&rag[s16 * 16 + 4 * g]) +
+                                  *reinterpret_cast<const f4*>(&U[NCB * kCoopWaves * 256 + (cb * kCoopWaves + (wv ^ 4)) * 64 + s16 * 16 + 4 * g]);
+                    const float dm = mean1 - mu1_1;
+                    const f4 v = (rv - (f4){dm, dm, dm, dm} * ws4[cb]) * (f4){rstd1, rstd1, rstd1, rstd1} + bc[cb];
+                    X1[cb] = silu_acc4(v, X1[cb]);
+                }
             }
         }
         stamp(6 + 8 * l);
@@ -545,47 +654,57 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
 
     // ================= OutputProcess.poseFinal (RAG.py:205-211) + CFG + sampler update =============
     fresh();
-    const int j16 = p * kCoopSlices + c;
-    const int n16 = np * kCoopSlices;                                // workgroups of this sample
+    const int j16 = p * NS + c;
+    const int n16 = np * NS;                                         // workgroups of this sample
     const unsigned tagF = ep + 2 * a.layers + 1;
     {
-        // this slice's final rows -> LDS [S][64] (token-mix operand layout): every wave has to be past its reads of the partial sums
+        // this slice's final rows -> LDS [S][CPS] (token-mix operand layout): every wave has to be past its reads of the partial sums
         lds_barrier();
-        *reinterpret_cast<f4*>(&U[row0() * kCoopU1Stride + 16 * w + 4 * g]) = X0;
-        if (live1()) *reinterpret_cast<f4*>(&U[(32 + s16) * kCoopU1Stride + 16 * w + 4 * g]) = X1;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            *reinterpret_cast<f4*>(&U[row0() * U1S + 16 * (NCB * w + cb) + 4 * g]) = X0[cb];
+            if (live1()) *reinterpret_cast<f4*>(&U[(32 + s16) * U1S + 16 * (NCB * w + cb) + 4 * g]) = X1[cb];
+        }
         lds_barrier();
-        // partial poseFinal over this slice's 64 channels: unit (out block ob, row tile t) = 16 MFMAs; wout_reg_img[8][NOB][4][64][4]
-        // holds Wout[16 ob + (lane & 15)][64 c + 16 q' + 4 (lane >> 4) + j] (ls_api.cpp build_fused_images)
-        float* part = a.cpart + ((size_t)pg * kCoopSlices + c) * kCoopRows * NOBP;
+        // partial poseFinal over this slice's CPS channels: unit (out block ob, row tile t, 4 k blocks) = 16 MFMAs; wout_reg_img[8][NOB][4][64][4]
+        // holds Wout[16 ob + (lane & 15)][64 w8 + 16 q' + 4 (lane >> 4) + j] (ls_api.cpp build_fused_images); this slice: w8 = NCB c .. NCB c + NCB - 1
+        float* part = a.cpart + ((size_t)pg * NS + c) * kCoopRows * NOBP;
         const wrsrc_t prs = uniform_rsrc(part);
         const wrsrc_t wrs = rs_wout;
-        // out block ob = wv + 8 i: its four weight fragments once for the three row tiles, the next block's in flight meanwhile
+        // out block ob = wv + 8 i, 64 channels (one w8) at a time: four weight fragments for the three row tiles, the next four in flight meanwhile
         constexpr int MAXOB = (NOB + kCoopWaves - 1) / kCoopWaves;
+        auto woff = [&](int step) {                                  // step = i * NCB + kq
+            const int ob = min(wv + kCoopWaves * (step / NCB), NOB - 1), w8 = NCB * c + (step % NCB);
+            return (w8 * NOB + ob) * 4 * 1024;
+        };
         f4 An[4];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + min(wv, NOB - 1)) * 4 + qq) * 1024);
+        for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, woff(0) + qq * 1024);
 #pragma unroll 1
         for (int i = 0; i < MAXOB; ++i) {
             const int ob = wv + kCoopWaves * i;                      // wave-uniform
             if (ob >= NOB) break;
-            f4 A[4];
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) A[qq] = An[qq];
-            const int obn = min(ob + kCoopWaves, NOB - 1);
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, ((c * NOB + obn) * 4 + qq) * 1024);
             f4 o[NT1];
 #pragma unroll
             for (int t = 0; t < NT1; ++t) o[t] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                f4 Bv[NT1];
+            for (int kq = 0; kq < NCB; ++kq) {
+                f4 A[4];
 #pragma unroll
-                for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[min(16 * t + s16, S - 1) * kCoopU1Stride + 16 * qq + 4 * g]);
+                for (int qq = 0; qq < 4; ++qq) A[qq] = An[qq];
+                const int nxt = woff(i * NCB + kq + 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int qq = 0; qq < 4; ++qq) An[qq] = wload4(wrs, lane * 16, nxt + qq * 1024);
 #pragma unroll
-                    for (int t = 0; t < NT1; ++t) o[t] = MFMA(A[qq][j], Bv[t][j], o[t]);
+                for (int qq = 0; qq < 4; ++qq) {
+                    f4 Bv[NT1];
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) Bv[t] = *reinterpret_cast<const f4*>(&U[min(16 * t + s16, S - 1) * U1S + 16 * (4 * kq + qq) + 4 * g]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int t = 0; t < NT1; ++t) o[t] = MFMA(A[qq][j], Bv[t][j], o[t]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < NT1; ++t)
@@ -610,18 +729,18 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
     stamp(3 + 8 * a.layers);
     if (spin_bad && lane == 0) atomicOr(a.cerr, 1u);
 
-    // ====== sum of the 8 partials of each pass, CFG lerp (cfg_sampler.py:31), posterior / DDIM update (gaussian_diffusion.py:260-282,
+    // ====== sum of the NS partials of each pass, CFG lerp (cfg_sampler.py:31), posterior / DDIM update (gaussian_diffusion.py:260-282,
     //        507-558, 745-798): quad (frame f, columns 4 cq .. + 3), dealt over the sample's workgroups ======================
     {
         const int per = (NQUAD + n16 - 1) / n16;
         const float sc = (np == 2 && a.scale) ? a.scale[b] : 1.0f;
         const unsigned long long gidx = (a.call ? a.call->sample_offset : 0ull) + (unsigned long long)b;
         const size_t base = (size_t)b * kT * JF;
-        const wrsrc_t p0 = uniform_rsrc(a.cpart + (size_t)(bl * np) * kCoopSlices * kCoopRows * NOBP);
+        const wrsrc_t p0 = uniform_rsrc(a.cpart + (size_t)(bl * np) * NS * kCoopRows * NOBP);
         // Few quads per workgroup (TED: 17): one thread per output ELEMENT (a quad's four columns on four lanes: 4x the threads for the
         // Philox draws and the update; the same sums in the same order).  Many (BEAT: 77): one thread per quad -- measured 1 % faster
         // there at 32 clips, 2 % slower for TED.
-        constexpr bool kByElement = 4 * ((NQUAD + 15) / 16) <= 128;
+        constexpr bool kByElement = 4 * ((NQUAD + 2 * NS - 1) / (2 * NS)) <= 128 * NCB;
         if constexpr (kByElement) {
         for (int e = tid; e < 4 * per; e += kCoopThreads) {
             const int quad = j16 * per + (e >> 2), jj = e & 3;
@@ -630,22 +749,22 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             const int cc = 4 * cq + jj;
             if (cc >= JF) continue;
             const int off = ((NPRE + f) * NOBP + cc) * 4;
-            float pc[kCoopSlices], pu[kCoopSlices];
+            float pc[NS], pu[NS];
 #pragma unroll
-            for (int s = 0; s < kCoopSlices; ++s) pc[s] = ld_sc1_1(p0, off + s * kCoopRows * NOBP * 4);
+            for (int s = 0; s < NS; ++s) pc[s] = ld_sc1_1(p0, off + s * kCoopRows * NOBP * 4);
             if (np == 2) {
 #pragma unroll
-                for (int s = 0; s < kCoopSlices; ++s) pu[s] = ld_sc1_1(p0, off + (kCoopSlices + s) * kCoopRows * NOBP * 4);
+                for (int s = 0; s < NS; ++s) pu[s] = ld_sc1_1(p0, off + (NS + s) * kCoopRows * NOBP * 4);
             }
             const int idx = f * JF + cc;
             const float xt = a.sampler != kNone ? a.x_in[base + idx] : 0.f;
             float oc = pc[0], ou = 0.f;
 #pragma unroll
-            for (int s = 1; s < kCoopSlices; ++s) oc += pc[s];
+            for (int s = 1; s < NS; ++s) oc += pc[s];
             if (np == 2) {
                 ou = pu[0];
 #pragma unroll
-                for (int s = 1; s < kCoopSlices; ++s) ou += pu[s];
+                for (int s = 1; s < NS; ++s) ou += pu[s];
             }
             const float bo = p_bout[cc];
             oc += bo;
@@ -688,20 +807,20 @@ __global__ __launch_bounds__(kCoopThreads, 4) void k_coop(const StepArgs a) {
             if (quad >= NQUAD) break;
             const int f = quad / (NOBP / 4), cq = quad - f * (NOBP / 4);
             const int off = ((NPRE + f) * NOBP + 4 * cq) * 4;
-            f4 pc[kCoopSlices], pu[kCoopSlices];
+            f4 pc[NS], pu[NS];
 #pragma unroll
-            for (int s = 0; s < kCoopSlices; ++s) pc[s] = ld_sc1(p0, off + s * kCoopRows * NOBP * 4);
+            for (int s = 0; s < NS; ++s) pc[s] = ld_sc1(p0, off + s * kCoopRows * NOBP * 4);
             if (np == 2) {
 #pragma unroll
-                for (int s = 0; s < kCoopSlices; ++s) pu[s] = ld_sc1(p0, off + (kCoopSlices + s) * kCoopRows * NOBP * 4);
+                for (int s = 0; s < NS; ++s) pu[s] = ld_sc1(p0, off + (NS + s) * kCoopRows * NOBP * 4);
             }
             f4 oc4 = pc[0], ou4 = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 1; s < kCoopSlices; ++s) oc4 += pc[s];
+            for (int s = 1; s < NS; ++s) oc4 += pc[s];
             if (np == 2) {
                 ou4 = pu[0];
 #pragma unroll
-                for (int s = 1; s < kCoopSlices; ++s) ou4 += pu[s];
+                for (int s = 1; s < NS; ++s) ou4 += pu[s];
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {

@@ -96,9 +96,9 @@ struct StepArgs {
     int tr_B;
     float* trace;            // [B][L+1][2S][512] or null
     // ---- sample-split kernel (k_coop, ls_coop_kernel.h): exchange workspaces of ONE launch (kCoopMaxGroups (sample, pass) groups)
-    float* cx;               // [groups][8 slices][4 k blocks][36 rows][16] rows entering channel mixing, centred on the LayerNorm-1 mean
-    float* cpart;            // [groups][8 slices][36][J*F padded to 16s] partial poseFinal outputs of each slice
-    unsigned long long* cgran;   // [groups][2 areas][36 rows][8 slices][2] {tag, value} granules: (mean, M2) partials of the two LayerNorms
+    float* cx;               // [groups][32 k blocks of 16 channels][36 rows][16] rows entering channel mixing, centred on the LayerNorm-1 mean
+    float* cpart;            // [groups][NS slices][36][J*F padded to 16s] partial poseFinal outputs of each slice (NS = 8 | 4 | 2)
+    unsigned long long* cgran;   // [groups][2 areas][36 rows][NS slices][2] {tag, value} granules: (mean, M2) partials of the two LayerNorms
     unsigned long long* cflag;   // [samples][16] {tag, -} ready flags of the final rows
     unsigned* cerr;          // set non-zero by a workgroup whose bounded spin ran out
     unsigned epoch;          // tag base of this launch: unique among the launches since the granule words were last zeroed
@@ -155,7 +155,8 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st);
 constexpr int kCoopMaxGroups = 64;     // (sample, pass) groups of one launch: 512 workgroups = two per CU, all resident at once
 constexpr unsigned kCoopEpochStride = 64;   // hand-off tags per launch: 2 * layers + 1 of them are used, so layers <= 31 (the reference: 8)
 hipError_t init_coop_kernels();
-hipError_t launch_step_coop(Variant v, const StepArgs& a, int nsamples, hipStream_t st);
+// ncb = 1 | 2 | 4: 8 | 4 | 2 slice workgroups per (sample, pass) (16-channel blocks per wave)
+hipError_t launch_step_coop(Variant v, int ncb, const StepArgs& a, int nsamples, hipStream_t st);
 
 // one-pass-per-workgroup step kernel (ls_pass.hip): npass workgroups of 4 waves per sample, two workgroups per CU
 hipError_t init_pass_kernels();

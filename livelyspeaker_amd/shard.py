@@ -42,23 +42,27 @@ def use_group(group) -> None:
     _GROUP = group
 
 
+_ENV_NO_WATCHDOG = ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "NCCL_ASYNC_ERROR_HANDLING")
+
+
 def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_timeout_s: float = 120.0, timeout_min: float = 15.0) -> dict:
     """Bring up the process groups so that a broken RCCL cannot take the job down (the reference's ``dist_util.setup_dist`` is a
     stub, scripts/mdm_utils/dist_util.py:18-41, so there is nothing to mirror).  The DEFAULT group is gloo over TCP on the
     rendezvous the launcher gave us: it carries the control plane (barriers, agreement) and, if need be, the data on host copies.
-    An RCCL group over the same ranks is then created and PROBED (one all_reduce + one all_gather on ``device``, waited for with a
-    timeout in a helper thread); only if every rank's probe succeeded do the data collectives move onto it.  Returns a record for
-    the bench line: {collective_backend, rccl_ranks, rccl_error}."""
+    A THROW-AWAY RCCL group over the same ranks is then created and PROBED (one all_reduce + one all_gather on ``device``, waited for
+    with a timeout in a helper thread).  Only if every rank's probe succeeded is the probe group destroyed and the DATA group created:
+    a second RCCL group with the caller's ordinary timeout (``timeout_min``) and torch's default error handling, so a rank that dies
+    mid-collective later is torn down by the watchdog as usual instead of leaving the others waiting.  Returns a record for the bench
+    line: {collective_backend, rccl_ranks, rccl_error}.
+
+    Process-wide side effect, limited to the probe: ``TORCH_NCCL_ASYNC_ERROR_HANDLING`` / ``NCCL_ASYNC_ERROR_HANDLING`` are set to "0"
+    while the probe group is constructed (ProcessGroupNCCL reads them in its constructor) and put back to what they were -- unset
+    included -- before the data group is created and before this function returns.  If the probe thread had to be ABANDONED inside a
+    hung collective they stay at "0" (the abandoned group's watchdog must never end the process) and the run stays on gloo."""
     import os
     import threading
     from datetime import timedelta
     global _ABANDONED_PROBE
-    # A collective of the probe that hangs stays registered with ProcessGroupNCCL's watchdog; with torch's default error handling the
-    # watchdog aborts the WHOLE process when it times out -- minutes after the run has moved on over gloo.  The probe's verdict is
-    # taken here, by the join below, so the watchdog must not be able to end the process: no async error handling, and a group timeout
-    # far beyond the join's (the abandoned thread is dealt with by `finish`).
-    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-    os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(minutes=timeout_min))
     use_group(None)
     info = {"collective_backend": "gloo", "rccl_ranks": 0, "rccl_error": None}
@@ -67,6 +71,31 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
         return info
     ok, err = 1, None
     box = {}
+    # A collective of the probe that hangs stays registered with ProcessGroupNCCL's watchdog; with torch's default error handling the
+    # watchdog aborts the WHOLE process when it times out -- minutes after the run has moved on over gloo.  The probe's verdict is
+    # taken here, by the join below, so the PROBE group's watchdog must not be able to end the process: no async error handling and a
+    # group timeout far beyond the join's -- for that group only (the abandoned thread is dealt with by `finish`).
+    saved_env = {k: os.environ.get(k) for k in _ENV_NO_WATCHDOG}
+    for k in _ENV_NO_WATCHDOG:
+        os.environ[k] = "0"
+
+    def restore_env():
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def check_collectives(g):
+        t = torch.full((1024,), float(rank + 1), device=device)
+        dist.all_reduce(t, group=g)
+        out = torch.empty(world * 8, device=device)
+        dist.all_gather_into_tensor(out, torch.full((8,), float(rank), device=device), group=g)
+        if getattr(device, "type", "cpu") == "cuda":
+            torch.cuda.synchronize(device)
+        want = world * (world + 1) / 2
+        if float(t[0].item()) != want or [float(v) for v in out[::8].tolist()] != [float(r) for r in range(world)]:
+            raise RuntimeError(f"RCCL probe returned wrong values ({float(t[0].item())} != {want})")
 
     def probe():
         try:
@@ -74,14 +103,7 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
                 torch.cuda.set_device(device)       # the current device is per host thread: this helper thread starts on device 0
             g = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=timedelta(seconds=max(3600.0, 20.0 * probe_timeout_s)))
             box["group"] = g
-            t = torch.full((1024,), float(rank + 1), device=device)
-            dist.all_reduce(t, group=g)
-            out = torch.empty(world * 8, device=device)
-            dist.all_gather_into_tensor(out, torch.full((8,), float(rank), device=device), group=g)
-            torch.cuda.synchronize(device)
-            want = world * (world + 1) / 2
-            if float(t[0].item()) != want or [float(v) for v in out[::8].tolist()] != [float(r) for r in range(world)]:
-                raise RuntimeError(f"RCCL probe returned wrong values ({float(t[0].item())} != {want})")
+            check_collectives(g)
             box["ok"] = True
         except Exception as e:              # noqa: BLE001  (any failure means: stay on gloo)
             box["err"] = repr(e)[:300]
@@ -95,18 +117,38 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
         print(f"[shard] rank {rank}: {err}", file=sys.stderr, flush=True)
     elif not box.get("ok"):
         ok, err = 0, box.get("err", "RCCL probe failed")
+    if not _ABANDONED_PROBE:
+        restore_env()                       # (an abandoned probe group is still alive: its watchdog must stay harmless)
     agree = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(agree, op=dist.ReduceOp.MIN)            # over gloo: every rank takes the same decision
+    probe_up = bool(box.get("ok")) and not th.is_alive()
+    if probe_up:                                            # the probe group has served its purpose either way: give the communicator back
+        try:
+            dist.destroy_process_group(box["group"])
+        except Exception as e:                              # noqa: BLE001  (teardown of RCCL must not take the run down either)
+            err = (err or "") + f"; destroy_process_group(probe): {e!r}"[:120]
     if int(agree.item()) == 1:
-        use_group(box["group"])
-        info.update(collective_backend="nccl", rccl_ranks=world)
+        # the data group: ordinary timeout, default error handling (the env is back to the caller's), checked once before use
+        data_ok, data_err, group = 1, None, None
+        try:
+            group = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=timedelta(minutes=timeout_min))
+            check_collectives(group)
+        except Exception as e:                              # noqa: BLE001
+            data_ok, data_err = 0, f"RCCL data group failed after a good probe: {e!r}"[:300]
+        agree2 = torch.tensor([data_ok], dtype=torch.int32)
+        dist.all_reduce(agree2, op=dist.ReduceOp.MIN)
+        if int(agree2.item()) == 1:
+            use_group(group)
+            info.update(collective_backend="nccl", rccl_ranks=world)
+        else:
+            info["rccl_error"] = data_err or "RCCL data group failed on another rank"
+            if group is not None and data_ok:
+                try:
+                    dist.destroy_process_group(group)
+                except Exception as e:                      # noqa: BLE001
+                    info["rccl_error"] += f"; destroy_process_group: {e!r}"[:120]
     else:
         info["rccl_error"] = err or "RCCL probe failed on another rank"
-        if box.get("ok") and not th.is_alive():          # this rank's RCCL came up but another rank's did not: give the communicator back
-            try:
-                dist.destroy_process_group(box["group"])
-            except Exception as e:                      # noqa: BLE001  (teardown of a half-working RCCL must not take the run down either)
-                info["rccl_error"] += f"; destroy_process_group: {e!r}"[:120]
     info["rccl_probe_abandoned"] = _ABANDONED_PROBE
     return info
 
@@ -114,11 +156,19 @@ def init_groups(device, rank: int, world: int, *, want_rccl: bool = True, probe_
 def finish(code: int = 0) -> None:
     """Last call of a multi-rank program.  If an RCCL probe thread was abandoned, interpreter shutdown would wait on RCCL's teardown
     of a communicator that never finished coming up: flush what was printed and leave through ``os._exit`` -- deterministically, and
-    said so on stderr.  Otherwise: the ordinary ``destroy_process_group``."""
+    said so on stderr (``os._exit`` runs no atexit handlers: stdout, stderr and the root logger's handlers are flushed here, files the
+    caller opened are the caller's to flush and close first).  Otherwise: the ordinary ``destroy_process_group``."""
     import os
     if _ABANDONED_PROBE:
         print(f"[shard] leaving through os._exit({code}): an RCCL probe thread is still inside a collective", file=sys.stderr, flush=True)
+        import logging
+        for hd in list(logging.getLogger().handlers):       # os._exit skips atexit handlers and buffered writers other than these:
+            try:                                            # callers flush and close their OWN files before calling finish()
+                hd.flush()
+            except Exception:                               # noqa: BLE001
+                pass
         sys.stdout.flush()
+        sys.stderr.flush()
         os._exit(code)
     if _on():
         dist.destroy_process_group()

@@ -46,11 +46,17 @@ def _loop(eng, cfg, steps, resp, ddim, skip, use_init, dump=None, use_graph=True
                       two_pass_always=two_pass_always)
 
 
+# the slicings of the sample-split kernel (ls_set_path 8 | 6 | 7): 8 | 4 | 2 slice workgroups per (sample, CFG pass); "coop" lets the
+# step-time model choose per piece.  Every one is pinned to the reference's fixtures.
+FORMS = ["coop8", "coop4", "coop2"]
+
+
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("ds", ["ted", "beat"])
-def test_reference_fixtures_on_the_sample_split_kernel(ds, golden):
+def test_reference_fixtures_on_the_sample_split_kernel(ds, form, golden):
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
-    cfg, eng = _engine(ds)
+    cfg, eng = _engine(ds, form)
     g = golden[ds]
     try:
         # model(x, t, y) itself (G1): cond / uncond outputs at four timesteps
@@ -76,7 +82,7 @@ def test_reference_fixtures_on_the_sample_split_kernel(ds, golden):
         assert np.array_equal(out, _loop(eng, cfg, 50, "", False, 0, False))            # the cached graph, replayed
         # the LivelySpeaker refine schedule (G4)
         d4 = max_abs(_loop(eng, cfg, 1000, "ddim100", True, 80, True), g["G4_ddim100_skip80_final"])
-        print(f"{ds} [coop]: G3 {d3:.3e}  G4 skip80 {d4:.3e}")
+        print(f"{ds} [{form}]: G3 {d3:.3e}  G4 skip80 {d4:.3e}")
         assert d3 < TOL_LOOP and d4 < TOL_LOOP
         if ds == "ted":
             d5 = max_abs(_loop(eng, cfg, 1000, "", False, 0, False), g["G5_ddpm1000_final"])
@@ -87,18 +93,19 @@ def test_reference_fixtures_on_the_sample_split_kernel(ds, golden):
         eng.close()
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("ds", ["ted", "beat"])
-def test_round2_fixtures_scale1_and_beat_loops_on_the_sample_split_kernel(ds):
+def test_round2_fixtures_scale1_and_beat_loops_on_the_sample_split_kernel(ds, form):
     """G11: guidance scale 1 with an odd batch, both as the reference evaluates it (two passes) and in the single-pass form (8
     workgroups per sample); G12 / G13: BEAT 1000-step DDPM and full ddim100."""
     g = np.load(os.path.join(GOLDEN, f"{ds}_golden_r2.npz"))
-    cfg, eng = _engine(ds)
+    cfg, eng = _engine(ds, form)
     try:
         for two in (True, False):
             d1 = max_abs(_loop(eng, cfg, 50, "", False, 0, False, B=5, scale=1.0, two_pass_always=two), g["G11_scale1_ddpm50_B5_final"])
             assert eng.timing()["single_pass"] == (0 if two else 1)
             d2 = max_abs(_loop(eng, cfg, 1000, "ddim100", True, 80, True, B=5, scale=1.0, two_pass_always=two), g["G11_scale1_ddim100_skip80_B5_final"])
-            print(f"{ds}: G11 ddpm50 {d1:.3e}, ddim100/skip80 {d2:.3e} (two passes: {two})")
+            print(f"{ds} [{form}]: G11 ddpm50 {d1:.3e}, ddim100/skip80 {d2:.3e} (two passes: {two})")
             assert d1 < TOL_LOOP and d2 < TOL_LOOP
         if ds == "beat":
             for key, args in (("G12_ddpm1000_final", (1000, "", False, 0, False)), ("G13_ddim100_full_final", (1000, "ddim100", True, 0, False))):
@@ -110,17 +117,19 @@ def test_round2_fixtures_scale1_and_beat_loops_on_the_sample_split_kernel(ds):
         eng.close()
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("ds,B", [("ted", 9), ("ted", 40), ("ted", 77), ("beat", 32), ("beat", 70)])
-def test_sample_split_agrees_with_the_fused_kernel_across_launch_chunks(ds, B):
-    """One launch holds 32 samples (two passes) or 64 (single pass); larger batches run as several launches per step.  Every sample
-    must come out as the fused kernel computes it (to summation order) wherever it falls in the chunking."""
+def test_sample_split_agrees_with_the_fused_kernel_across_launch_chunks(ds, B, form):
+    """One launch holds what is resident at once (8 / 4 slices: 32 samples with two passes, 64 with one; 2 slices: 64 / 128); larger
+    batches run as several launches per step.  Every sample must come out as the fused kernel computes it (to summation order) wherever
+    it falls in the chunking."""
     cfg = synth.CONFIGS[ds]
     outs = {}
-    for path in ("fused", "coop"):
+    for path in ("fused", form):
         _, eng = _engine(ds, path)
         try:
-            outs[path] = _loop(eng, cfg, 12, "", False, 0, False, B=B)
-            if path == "coop":
+            outs["fused" if path == "fused" else "coop"] = _loop(eng, cfg, 12, "", False, 0, False, B=B)
+            if path != "fused":
                 assert eng.timing()["step_path"] == 2
                 outs["coop1"] = _loop(eng, cfg, 12, "", False, 0, False, B=B, scale=1.0)
                 assert eng.timing()["single_pass"] == 1
@@ -129,7 +138,7 @@ def test_sample_split_agrees_with_the_fused_kernel_across_launch_chunks(ds, B):
         finally:
             eng.close()
     d, d1 = max_abs(outs["fused"], outs["coop"]), max_abs(outs["fused1"], outs["coop1"])
-    print(f"{ds} B = {B}: fused vs sample-split, 12 steps: {d:.3e}; single pass {d1:.3e}")
+    print(f"{ds} B = {B} [{form}]: fused vs sample-split, 12 steps: {d:.3e}; single pass {d1:.3e}")
     assert 0 < d < 5e-5 and 0 < d1 < 5e-5
 
 

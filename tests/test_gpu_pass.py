@@ -21,11 +21,17 @@ def _engine(ds, path="pass"):
     return _engine_any(ds, path)
 
 
+# "pass": 8-wave workgroups at these batch sizes (the grid fits the chip once); "pass4" (ls_set_path 5): the 4-wave / two-per-CU form,
+# which `auto` and "pass" reach only beyond one workgroup per CU -- pinned to the same reference fixtures here
+FORMS = ["pass", "pass4"]
+
+
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("ds", ["ted", "beat"])
-def test_reference_fixtures_on_the_pass_kernel(ds, golden):
+def test_reference_fixtures_on_the_pass_kernel(ds, form, golden):
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
-    cfg, eng = _engine(ds)
+    cfg, eng = _engine(ds, form)
     g = golden[ds]
     try:
         x, eps, noise = _g1_inputs(cfg)
@@ -47,7 +53,7 @@ def test_reference_fixtures_on_the_pass_kernel(ds, golden):
         assert np.array_equal(out, _loop(eng, cfg, 50, "", False, 0, False, use_graph=False))      # hipGraph replay == plain launches
         assert np.array_equal(out, _loop(eng, cfg, 50, "", False, 0, False))
         d4 = max_abs(_loop(eng, cfg, 1000, "ddim100", True, 80, True), g["G4_ddim100_skip80_final"])
-        print(f"{ds} [pass]: G3 {d3:.3e}  G4 skip80 {d4:.3e}")
+        print(f"{ds} [{form}]: G3 {d3:.3e}  G4 skip80 {d4:.3e}")
         assert d3 < TOL_LOOP and d4 < TOL_LOOP
         if ds == "ted":
             d5 = max_abs(_loop(eng, cfg, 1000, "", False, 0, False), g["G5_ddpm1000_final"])
@@ -58,16 +64,17 @@ def test_reference_fixtures_on_the_pass_kernel(ds, golden):
         eng.close()
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("ds", ["ted", "beat"])
-def test_round2_fixtures_scale1_and_beat_loops_on_the_pass_kernel(ds):
+def test_round2_fixtures_scale1_and_beat_loops_on_the_pass_kernel(ds, form):
     g = np.load(os.path.join(GOLDEN, f"{ds}_golden_r2.npz"))
-    cfg, eng = _engine(ds)
+    cfg, eng = _engine(ds, form)
     try:
         for two in (True, False):
             d1 = max_abs(_loop(eng, cfg, 50, "", False, 0, False, B=5, scale=1.0, two_pass_always=two), g["G11_scale1_ddpm50_B5_final"])
             assert eng.timing()["single_pass"] == (0 if two else 1)
             d2 = max_abs(_loop(eng, cfg, 1000, "ddim100", True, 80, True, B=5, scale=1.0, two_pass_always=two), g["G11_scale1_ddim100_skip80_B5_final"])
-            print(f"{ds}: G11 ddpm50 {d1:.3e}, ddim100/skip80 {d2:.3e} (two passes: {two})")
+            print(f"{ds} [{form}]: G11 ddpm50 {d1:.3e}, ddim100/skip80 {d2:.3e} (two passes: {two})")
             assert d1 < TOL_LOOP and d2 < TOL_LOOP
         if ds == "beat":
             for key, args in (("G12_ddpm1000_final", (1000, "", False, 0, False)), ("G13_ddim100_full_final", (1000, "ddim100", True, 0, False))):
@@ -139,13 +146,14 @@ def test_pass_kernel_determinism_under_load_and_next_to_another_handle():
         other.close()
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("ds", ["ted", "beat"])
-def test_bf16x3_on_the_pass_kernel_meets_the_parity_contract(ds, golden):
+def test_bf16x3_on_the_pass_kernel_meets_the_parity_contract(ds, form, golden):
     """The opt-in split-precision arithmetic (three bf16 MFMAs per product) inside the one-pass-per-workgroup kernel, both forms:
     contract 1e-3 against the reference's fixtures (G1 forwards, G3 / G4 / G5 loops, G11 scale 1 single-pass)."""
     from livelyspeaker_amd import _lib
     from oracle import rag_oracle as orc
-    cfg, eng = _engine(ds)
+    cfg, eng = _engine(ds, form)
     g = golden[ds]
     g2 = np.load(os.path.join(GOLDEN, f"{ds}_golden_r2.npz"))
     try:
@@ -161,7 +169,7 @@ def test_bf16x3_on_the_pass_kernel_meets_the_parity_contract(ds, golden):
         d4 = max_abs(_loop(eng, cfg, 1000, "ddim100", True, 80, True), g["G4_ddim100_skip80_final"])
         d11 = max_abs(_loop(eng, cfg, 50, "", False, 0, False, B=5, scale=1.0), g2["G11_scale1_ddpm50_B5_final"])
         assert eng.timing()["single_pass"] == 1 and eng.timing()["step_path"] == 3
-        print(f"{ds} bf16x3 [pass]: forward {worst:.3e}  G3 {d3:.3e}  G4 skip80 {d4:.3e}  G11 {d11:.3e}")
+        print(f"{ds} bf16x3 [{form}]: forward {worst:.3e}  G3 {d3:.3e}  G4 skip80 {d4:.3e}  G11 {d11:.3e}")
         assert max(worst, d3, d4, d11) < 1e-3
         if ds == "ted":
             d5 = max_abs(_loop(eng, cfg, 1000, "", False, 0, False), g["G5_ddpm1000_final"])

@@ -104,6 +104,39 @@ def test_headline_workload_batch512_1000_steps_spot_check():
         eng.close()
 
 
+@pytest.mark.parametrize("ds,B", [("ted", 160), ("ted", 416), ("beat", 192), ("ted", 72)])
+def test_multi_piece_plans_replayed_through_the_oracle(ds, B):
+    """Ragged batches (the last iteration of the reference's loaders, scripts/test_RAG_ted.py:43-82) run on plans of several pieces --
+    full rounds on the fused kernel, a chip's worth on the one-pass-per-workgroup kernel, the rest on the sample-split kernel.  The first
+    and the last sample of EVERY piece of the plan `auto` makes are replayed alone through the CPU oracle on the restated Philox noise
+    (50-step DDPM, CFG 1.5: cfg_sampler.py:24-31, gaussian_diffusion.py:608-743), as the B = 512 check above does for the headline."""
+    from livelyspeaker_amd import _lib
+    from oracle import philox_oracle as po
+    cfg, eng = _engine(ds)
+    orc, oracle = _oracle(cfg)
+    try:
+        steps, seed, off = 50, 777 + B, 1000
+        y = synth.make_cond(cfg, B, scale=1.5)
+        sch = orc.Schedule(steps, "")
+        eng.set_schedule(sch)
+        eng.prepare(y)
+        got = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=off, use_graph=True)
+        assert np.isfinite(got).all()
+        tm = eng.timing()
+        pieces, _ = _lib.plan_query(B, dataset=ds, n_cus=tm["n_cus"])
+        assert sum(n for _, _, n in pieces) == B
+        assert tm["step_path"] == pieces[0][0] and tm["tail_samples"] == (pieces[1][2] if len(pieces) > 1 else 0)     # the plan that ran
+        pick = np.array(sorted({i for _, first, n in pieces for i in (first, first + n - 1)}))
+        eps, noise = po.step_tapes(seed, off + pick, steps, (cfg.njoints, cfg.nfeats, cfg.nframes))
+        x_T = po.x_init(seed, off + pick, cfg.njoints * cfg.nfeats, cfg.nframes, (cfg.njoints, cfg.nfeats))
+        want = orc.sample_loop(oracle, sch, {k: v[pick] for k, v in y.items()}, x_T, eps, noise)
+        per = np.abs(got[pick].astype(np.float64) - want).reshape(len(pick), -1).max(axis=1)
+        print(f"{ds} B={B}: plan {pieces}; samples {pick.tolist()}: max|hip - oracle| per sample {[float(f'{v:.2e}') for v in per]}")
+        assert per.max() < TOL_LOOP
+    finally:
+        eng.close()
+
+
 def test_beat_caller_batch_256_1000_steps_spot_check():
     """BASELINE configs[4] at the frame count the reference can run (34): BEAT, B=256, 1000-step DDPM, Philox noise."""
     from livelyspeaker_amd import _lib

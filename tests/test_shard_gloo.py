@@ -225,7 +225,11 @@ def _groups_worker(rank, world, port, want_rccl, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     try:
         from livelyspeaker_amd import shard
+        os.environ.pop("TORCH_NCCL_ASYNC_ERROR_HANDLING", None)
+        os.environ["NCCL_ASYNC_ERROR_HANDLING"] = "1"                    # the caller's own setting: must survive the probe
         info = shard.init_groups(torch.device("cpu"), rank, world, want_rccl=want_rccl, probe_timeout_s=60.0, timeout_min=2.0)
+        # the probe's "no watchdog" environment is scoped to the throw-away probe group: afterwards the process env is the caller's again
+        assert "TORCH_NCCL_ASYNC_ERROR_HANDLING" not in os.environ and os.environ["NCCL_ASYNC_ERROR_HANDLING"] == "1", dict(os.environ)
         t = torch.full((4,), float(rank + 1))
         shard.all_reduce_(t)                                             # the data collectives work on whatever group was chosen
         whole = shard.gather_samples(torch.full((2, 1, 1, 1), float(rank)), 2 * world)
