@@ -326,7 +326,10 @@ int ls_sag_commit_weights(ls_sag* h);
  * -> batch['output'] [B,J,F,T] */
 int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask,
                   float* out);
-float ls_sag_last_decode_ms(const ls_sag* h);   /* GPU time of the last ls_sag_decode (HIP events on the handle's stream) */
+/* The same, enqueued only (device pointers): returns without waiting for the GPU; `out` is complete once ls_sag_stream() has reached
+ * this point (order consumers with ls_stream_order).  Lets a caller that iterates batches decode batch n + 1 while batch n is refined. */
+int ls_sag_decode_async(ls_sag* h, int batch, const float* x, const float* z, const unsigned char* mask, float* out);
+float ls_sag_last_decode_ms(const ls_sag* h);   /* GPU time of the last decode (HIP events on the handle's stream); waits for an asynchronous one */
 void* ls_sag_stream(const ls_sag* h);
 
 /* ---- caller-side post-processing of sampled clips ---------------------------------

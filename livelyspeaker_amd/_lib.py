@@ -104,7 +104,7 @@ class LsEvalConfig(C.Structure):
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
            "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_plan_coop_slices", "ls_trng_randn", "ls_trng_fill_steps", "ls_trng_stats", "ls_trng_pairs_debug", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
-           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
+           "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_decode_async", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",
            "ls_train_adamw", "ls_train_read", "ls_train_get_moment", "ls_train_set_moment", "ls_train_get_step", "ls_train_set_step",
@@ -196,6 +196,7 @@ def load_library(build_if_missing: bool = True):
     lib.ls_sag_set_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_size_t]
     lib.ls_sag_commit_weights.argtypes = [C.c_void_p]
     lib.ls_sag_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ls_sag_decode_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ls_sag_last_decode_ms.argtypes = [C.c_void_p]
     lib.ls_sag_last_decode_ms.restype = C.c_float
     lib.ls_ted_post.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(LsPostConfig), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -321,6 +322,13 @@ class _Marshal:
             return t, C.c_void_p(t.data_ptr())
         n = np.empty(tuple(shape), np.float32)
         return n, n.ctypes.data_as(C.c_void_p)
+
+
+def stream_order(device_index: int, first, then) -> None:
+    """Work enqueued on stream ``then`` from now on waits for what stream ``first`` holds so far (an event; no host wait).  Streams are
+    raw handles: ``Engine._stream`` / ``SagEngine._stream`` or ``torch.cuda.current_stream().cuda_stream``."""
+    if load_library().ls_stream_order(int(device_index), C.c_void_p(first), C.c_void_p(then)) != 0:
+        raise EngineError("ls_stream_order failed")
 
 
 def _order_after_torch(device_index: int, stream) -> None:
@@ -653,7 +661,9 @@ class SagEngine:
     def last_decode_ms(self) -> float:
         return float(self.lib.ls_sag_last_decode_ms(self.h))
 
-    def decode(self, x, z, mask=None):
+    def decode(self, x, z, mask=None, wait=True):
+        """``wait=False`` (device tensors only): enqueue on the decoder's stream and return at once; the output tensor is complete once
+        that stream has reached this point -- ``order_after(self, other_engine)`` / ``stream_order`` puts a consumer behind it."""
         m = _Marshal(self.device, x, z, mask, stream=self._stream)
         B = int(x.shape[0])
         out, pout = m.out((B, self.J, self.F, self.T))
@@ -669,8 +679,16 @@ class SagEngine:
                 m.keep.append(a)
                 pmask = a.ctypes.data_as(C.c_void_p)
         m.ready()
+        if not wait:
+            if not m.on_device:
+                raise EngineError("decode(wait=False) needs device tensors")
+            self._check(self.lib.ls_sag_decode_async(self.h, B, m.f32(x, (B, self.J, self.F, self.T)), m.f32(z, (B, self.D)), pmask, pout),
+                        "ls_sag_decode_async")
+            self._async_inputs = m          # the marshalled inputs stay referenced until the next decode on this (in-order) stream
+            return out
         self._check(self.lib.ls_sag_decode(self.h, B, int(m.on_device), m.f32(x, (B, self.J, self.F, self.T)),
                                            m.f32(z, (B, self.D)), pmask, pout), "ls_sag_decode")
+        self._async_inputs = None
         return out
 
 

@@ -42,6 +42,7 @@ struct ls_sag {
     Buf wcross, bcross;      // cross-attention of ALL layers as one [L*D][D] matrix (see ls_sag_commit_weights)
     hipEvent_t ev[2] = {nullptr, nullptr};
     float last_ms = 0.f;
+    bool pending_ms = false;   // ls_sag_decode_async enqueued: last_ms is read from the events when asked for
 };
 
 namespace {
@@ -194,7 +195,7 @@ int ls_sag_commit_weights(ls_sag* h) {
     return LS_OK;
 }
 
-int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask, float* out) {
+static int sag_decode_impl(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask, float* out, bool wait) {
     if (!h || !x || !z || !out) return sfail(h, LS_EINVAL, "ls_sag_decode: null argument");
     if (!h->committed) return sfail(h, LS_ESTATE, "ls_sag_decode before ls_sag_commit_weights");
     if (batch < 1) return sfail(h, LS_EINVAL, "batch must be >= 1");
@@ -257,12 +258,33 @@ int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const flo
     SCHK(h, launch_sag_final(xcur, W("finallayer.weight"), W("finallayer.bias"), dmask, h->out.f(), B, JF, D, st));
     SCHK(h, hipEventRecord(h->ev[1], st));
     SCHK(h, hipMemcpyAsync(out, h->out.p, nx, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (!wait) { h->pending_ms = true; return LS_OK; }      // the caller orders consumers behind ls_sag_stream (ls_stream_order)
     SCHK(h, hipStreamSynchronize(st));
     SCHK(h, hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
+    h->pending_ms = false;
     return LS_OK;
 }
 
-float ls_sag_last_decode_ms(const ls_sag* h) { return h ? h->last_ms : -1.f; }
+int ls_sag_decode(ls_sag* h, int batch, int on_device, const float* x, const float* z, const unsigned char* mask, float* out) {
+    return sag_decode_impl(h, batch, on_device, x, z, mask, out, true);
+}
+
+// The same decode, enqueued only (device pointers): returns without waiting for the GPU, so a caller that iterates batches can decode
+// batch n + 1 on this handle's stream while batch n is refined on another handle's (scripts/test_LivelySpeaker_ted.py:57-113 runs them
+// back to back).  `out` is complete once ls_sag_stream() has reached this point: order its consumers with ls_stream_order.  The
+// handle's staging buffers are reused by the next decode on the same (in-order) stream.
+int ls_sag_decode_async(ls_sag* h, int batch, const float* x, const float* z, const unsigned char* mask, float* out) {
+    return sag_decode_impl(h, batch, 1, x, z, mask, out, false);
+}
+
+float ls_sag_last_decode_ms(const ls_sag* h) {
+    if (!h) return -1.f;
+    if (h->pending_ms) {           // an asynchronous decode: its span is read once it has finished (waits for it)
+        ls_sag* m = const_cast<ls_sag*>(h);
+        if (hipEventSynchronize(m->ev[1]) == hipSuccess && hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]) == hipSuccess) m->pending_ms = false;
+    }
+    return h->last_ms;
+}
 
 void* ls_sag_stream(const ls_sag* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
 

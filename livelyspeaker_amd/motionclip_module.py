@@ -64,12 +64,14 @@ class Decoder_TRANSFORMER(nn.Module):
             self._weights_dirty = False
         return self._engine
 
-    def forward(self, batch, use_text_emb=False):
+    def forward(self, batch, use_text_emb=False, wait=True):
+        """``wait=False`` (no counterpart in the reference): enqueue the decode on the decoder's own stream and return; the output is
+        ordered for a consumer by ``_lib.stream_order(device, decoder.engine()._stream, consumer_stream)`` (examples/livelyspeaker_ted.py)."""
         z, mask = batch["z"], batch["mask"]
         if use_text_emb:
             z = batch["clip_text_emb"]
         batch['final_z'] = z.clone()
-        out = self.engine().decode(batch["x"], z.float(), mask)
+        out = self.engine().decode(batch["x"], z.float(), mask, wait=wait)
         out = (out if isinstance(out, torch.Tensor) else torch.from_numpy(out)).to(batch["x"].device)
         batch["txt_output" if use_text_emb else "output"] = out
         return batch

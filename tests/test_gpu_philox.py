@@ -104,7 +104,8 @@ def test_headline_workload_batch512_1000_steps_spot_check():
         eng.close()
 
 
-@pytest.mark.parametrize("ds,B", [("ted", 160), ("ted", 416), ("beat", 192), ("ted", 72)])
+@pytest.mark.engine_path_auto
+@pytest.mark.parametrize("ds,B", [("ted", 160), ("ted", 416), ("beat", 192), ("ted", 72), ("ted", 48)])
 def test_multi_piece_plans_replayed_through_the_oracle(ds, B):
     """Ragged batches (the last iteration of the reference's loaders, scripts/test_RAG_ted.py:43-82) run on plans of several pieces --
     full rounds on the fused kernel, a chip's worth on the one-pass-per-workgroup kernel, the rest on the sample-split kernel.  The first
@@ -112,7 +113,9 @@ def test_multi_piece_plans_replayed_through_the_oracle(ds, B):
     (50-step DDPM, CFG 1.5: cfg_sampler.py:24-31, gaussian_diffusion.py:608-743), as the B = 512 check above does for the headline."""
     from livelyspeaker_amd import _lib
     from oracle import philox_oracle as po
-    cfg, eng = _engine(ds)
+    cfg = synth.CONFIGS[ds]
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path="auto")
+    eng.load_state_dict(synth.make_state_dict(cfg))
     orc, oracle = _oracle(cfg)
     try:
         steps, seed, off = 50, 777 + B, 1000

@@ -12,6 +12,35 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_pipelining_across_calls_is_bitwise_the_call_by_call_order():
+    """The loader loop of scripts/test_LivelySpeaker_ted.py:57-113 over five batches (a ragged last one), two ways: call by call (decode,
+    prepare, refine, wait -- per batch), and pipelined (decode + prepare of batch n + 1 enqueued on their own streams before batch n's
+    refinement is waited for, two model replicas alternating).  Same seed -> the same Philox keys in the same order -> identical bits."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import livelyspeaker_ted as ex
+    cfg, model, diffusion, sag_decoder, _ = ex.build()
+    _, model2, _, _, _ = ex.build()
+    sizes = [40, 40, 40, 40, 13]
+    ins = [ex.make_inputs(cfg, b, seed=n) for n, b in enumerate(sizes)]
+    batches, conds = [i[1] for i in ins], [i[2] for i in ins]
+    diffusion.noise_source = "philox"
+    torch.manual_seed(5)
+    serial = []
+    for n in range(len(sizes)):                                      # ex.infer without its per-call manual_seed
+        dec = sag_decoder(batches[n])["output"]
+        serial.append((dec, diffusion.ddim_sample_loop(model, (sizes[n], 9, 3, 34), clip_denoised=False, model_kwargs=conds[n],
+                                                       skip_timesteps=80, init_image=dec, progress=False, dump_steps=None, noise=None,
+                                                       const_noise=False)))
+    for rep in range(3):                                             # first run captures the replicas' graphs, later ones replay them
+        piped = ex.infer_pipelined([model, model2], diffusion, sag_decoder, batches, conds, seed=5)
+        torch.cuda.synchronize()
+        for n, ((d0, s0), (d1, s1)) in enumerate(zip(serial, piped)):
+            assert torch.equal(d0, d1), (rep, n, "decode")
+            assert torch.equal(s0, s1) and bool(torch.isfinite(s1).all()), (rep, n, float((s0 - s1).abs().max()))
+    assert not torch.equal(serial[0][1], serial[1][1])               # the batches differ (the check has teeth)
+
+
 def test_livelyspeaker_pipeline_matches_chained_oracles():
     import torch
     sys.path.insert(0, os.path.join(ROOT, "examples"))
