@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel phase profile of ls::k_coop (debug aid; -DLS_DEBUG build of the library, variants/debug.so: build it in the container
 with `python tools/phase_profile.py build`).  LS_PROF=<workgroup>: lane 0 of each wave of that workgroup records s_memtime at
-phase boundaries.  usage: python tools/coop_profile.py [ted|beat] [B]"""
+phase boundaries.  usage: python tools/coop_profile.py [ted|beat] [B] [coop|coop8|coop4|coop2]"""
 import os
 import sys
 
@@ -16,7 +16,8 @@ _lib.use_library(os.path.join(_build.ROOT, "variants", "debug.so"))
 ds = sys.argv[1] if len(sys.argv) > 1 else "ted"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 cfg = synth.CONFIGS[ds]
-eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path="coop")
+path = sys.argv[3] if len(sys.argv) > 3 else "coop"
+eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, path=path)
 eng.load_state_dict(synth.make_state_dict(cfg))
 eng.set_schedule(synth.schedule(8))
 eng.prepare(synth.make_cond(cfg, B))
@@ -27,7 +28,7 @@ eng.lib.ls_read(eng.h, b"prof", raw.ctypes.data_as(_lib.c_f32p), raw.size)
 st = raw.view(np.uint64).reshape(8, 96).astype(np.float64)[:4]
 L = 8
 E = 2 + 8 * L
-print(f"{ds} B={B} workgroup {os.environ['LS_PROF']}: total (wave mean) = {np.mean(st[:, E + 3] - st[:, 0]):.0f}  [s_memtime ticks]")
+print(f"{ds} B={B} {path} workgroup {os.environ['LS_PROF']}: total (wave mean) = {np.mean(st[:, E + 3] - st[:, 0]):.0f}  [s_memtime ticks]")
 print(f"  embed                      : {np.mean(st[:, 1] - st[:, 0]):9.0f}")
 names = ["temb + LN1 partials/publish", "SYNC1 wait + merge", "LN1 store + token mixing", "rows publish + LN2 partials", "ready-flag wait + pulls issued",
          "own k blocks", "LN2 gather + pulls landed", "remaining k blocks", "partial-sum swap + epilogue"]
