@@ -88,7 +88,10 @@ struct ls_handle {
     int n_cu = 256;         // compute units of the device (hipDeviceProp.multiProcessorCount): residency of the sample-split kernel, round sizes of the plans
     int coop_groups_max = kCoopMaxGroups, coop_groups = 0;   // (sample, pass) groups per launch: cap of the 8-slice form (two workgroups per CU, eight per group), and what the workspaces hold
     int coop_ncb = 0;       // slicing of the sample-split kernel: 0 = by the step-time model; 1 | 2 | 4 = 8 | 4 | 2 slice workgroups per (sample, pass) (ls_set_path 8 | 6 | 7)
-    int coop_xmap = 0;      // blockIdx -> (group, slice) mapping of the sample-split kernel (speed only; LS_COOP_XMAP in -DLS_DEBUG builds)
+#ifndef LS_COOP_XMAP_DEFAULT
+#define LS_COOP_XMAP_DEFAULT -1
+#endif
+    int coop_xmap = LS_COOP_XMAP_DEFAULT;      // -1: by grid size (run_coop); otherwise the blockIdx -> (group, slice) mapping of the sample-split kernel (speed only; LS_COOP_XMAP in -DLS_DEBUG builds)
     int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
     DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_wcf, lw_bcf, lw_wsum, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
@@ -608,16 +611,23 @@ int coop_cap(int n_cu, int ncb) {
 // Step time of the sample-split kernel in ms, measured on MI355X (profiles/r06_split_variants.md): per launch base + per (sample, pass)
 // group, for ncb = 1 | 2 | 4; [0] TED, [1] BEAT.  `g` groups cost the sum over the launches it takes.
 struct CoopCost { float base, per_group; };
-constexpr CoopCost kCoopCost[2][3] = {{{0.0875f, 0.00096f}, {0.1381f, 0.00041f}, {0.2299f, 0.0000992f}},
-                                      {{0.0963f, 0.00103f}, {0.1529f, 0.000327f}, {0.2628f, 0.0000833f}}};
+// [dataset][ncb 1 with up to one workgroup per CU (the slices of a group on one XCD) | ncb 1 two per CU | ncb 2 | ncb 4]
+constexpr CoopCost kCoopCost[2][4] = {{{0.0909f, 0.000213f}, {0.0875f, 0.00096f}, {0.1397f, 0.0000958f}, {0.2297f, 0.00000625f}},
+                                      {{0.0987f, 0.00028f}, {0.0963f, 0.00103f}, {0.1511f, 0.000156f}, {0.2610f, 0.0000115f}}};
 float coop_ms_ncb(bool ted, int ncb, int g, int n_cu) {
-    const CoopCost& c = kCoopCost[ted ? 0 : 1][ncb == 1 ? 0 : ncb == 2 ? 1 : 2];
     const int cap = coop_cap(n_cu, ncb);
     if (cap < 1) return 1e30f;
     float ms = 0.f;
-    for (; g > 0; g -= cap) ms += c.base + c.per_group * (g < cap ? g : cap);
+    for (; g > 0; g -= cap) {
+        const int gl = g < cap ? g : cap;
+        const CoopCost& c = kCoopCost[ted ? 0 : 1][ncb == 1 ? (gl * 8 <= n_cu ? 0 : 1) : ncb == 2 ? 2 : 3];
+        ms += c.base + c.per_group * gl;
+    }
     return ms;
 }
+// blockIdx -> (group, slice) mapping of a launch (speed only): a grid of up to one workgroup per CU keeps the slices of a group on one
+// XCD (hand-offs through one L2: 13-16 % at 16 clips on 8 slices, 5-10 % on 4 / 2 slices), two per CU splits them 4 + 4 over two XCDs
+int coop_xmap_for(int n_cu, int ncb, int groups) { return ncb != 1 || groups * 8 <= n_cu ? 1 : 2; }
 // the slicing the model prefers for `g` groups (ties go to more slices: shorter chains per workgroup)
 int coop_pick_ncb(bool ted, int g, int n_cu) {
     int best = 1;
@@ -644,8 +654,9 @@ hipError_t run_coop(ls_handle* h, const StepArgs& s, int first, int n, bool pair
         c.cgran = static_cast<unsigned long long*>(h->co_gran.p); c.cflag = static_cast<unsigned long long*>(h->co_flag.p);
         c.cerr = static_cast<unsigned*>(h->co_err.p);
         c.epoch = (++h->coop_launches) * kCoopEpochStride;      // tags of one launch: epoch + 1 .. epoch + 2 * layers + 1 < the stride (checked in decide_path / ls_set_path)
-        c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap;
-        hipError_t e = launch_step_coop(h->var, ncb, c, first + n - b0 < per ? first + n - b0 : per, st);
+        const int ns = first + n - b0 < per ? first + n - b0 : per;
+        c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap >= 0 ? h->coop_xmap : coop_xmap_for(h->n_cu, ncb, ns * np);
+        hipError_t e = launch_step_coop(h->var, ncb, c, ns, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -25,7 +25,8 @@ hipError_t launch_step_coop(Variant v, int ncb, const StepArgs& a, int nsamples,
     StepArgs c = a;
     c.ngroups = nsamples * a.npass;
     const int ns = 8 / ncb;
-    const dim3 grid((ncb == 1 && a.xmap ? (c.ngroups + 7) / 8 * 8 : c.ngroups) * ns), block(kCoopThreads);
+    if (ncb != 1 && c.xmap == 2) c.xmap = 0;
+    const dim3 grid((c.xmap ? (c.ngroups + 7) / 8 * 8 : c.ngroups) * ns), block(kCoopThreads);      // xmap 1 / 2 deal whole sets of 8 groups over the XCDs
     const size_t lds = coop_lds_bytes();
     if (v == kTED) {
         if (ncb == 1) hipLaunchKernelGGL((k_coop<35, 1, 27, 1>), grid, block, lds, st, c);

@@ -126,12 +126,14 @@ __global__ __launch_bounds__(kCoopThreads, CoopGeom<NCB>::MINW) void k_coop(cons
     const int w = wv & 3, h = wv >> 2;                              // channel blocks NCB w .. NCB w + NCB - 1 of the slice, row half
     const int bid = blockIdx.x;
     const int np = a.npass;
-    // blockIdx -> (group, slice).  xmap 0: slice = bid % NS, i.e. slice c of every group on XCDs c, c + NS, ... (each XCD's L2 holds 1 / NS
-    // of the weights; every row hand-off crosses XCDs).  xmap 1 (NCB = 1 only): the 8 slices of a group on ONE XCD (measured 35 % slower:
-    // the granule polls of a group then queue on one L2).  Observed round-robin placement; a different placement changes only speed.
-    const bool xm = NCB == 1 && a.xmap;
-    const int c = xm ? ((bid >> 3) & 7) : (bid & (NS - 1));         // channel slice
-    const int pg = xm ? ((bid >> 6) * 8 + (bid & 7)) : (bid / NS);  // launch-local (sample, pass) group
+    // blockIdx -> (group, slice), for speed only (observed round-robin placement: block b runs on XCD b % 8; every hand-off is
+    // placement-independent).  xmap 0: slice = bid % NS, i.e. slice c of every group on XCDs c, c + NS, ... (each XCD's L2 holds 1 / NS of
+    // the weights; every row hand-off crosses XCDs).  xmap 1: the NS slices of a group on ONE XCD (cheaper hand-offs, every L2 sees all the
+    // weights).  xmap 2 (8 slices): slices 0-3 of a group on one XCD, 4-7 on its neighbour.  Measured (profiles/r06_split_variants.md):
+    // with one workgroup per CU xmap 1 wins by 13-16 %, with two per CU xmap 2 by 0-4 % -- the host picks by grid size.
+    const bool xm = a.xmap == 1, xm2 = NCB == 1 && a.xmap == 2;
+    const int c = xm ? ((bid >> 3) & (NS - 1)) : xm2 ? ((bid & 1) * 4 + ((bid >> 3) & 3)) : (bid & (NS - 1));            // channel slice
+    const int pg = xm ? ((bid >> 3) / NS * 8 + (bid & 7)) : xm2 ? ((bid >> 5) * 4 + ((bid & 7) >> 1)) : (bid / NS);      // launch-local (sample, pass) group
     if (pg >= a.ngroups) return;                                    // xmap 1 rounds the grid up to whole sets of 8 groups
     const int p = np == 2 ? (pg & 1) : 0;
     const int bl = np == 2 ? (pg >> 1) : pg;                        // launch-local sample

@@ -492,11 +492,12 @@ def test_step_plans_cover_the_batch_and_follow_the_chip():
     want = {4: [2], 32: [2], 64: [2], 128: [3], 160: [3, 2], 256: [0], 300: [0, 2], 384: [0, 3], 416: [0, 3, 2], 512: [0], 4096: [0]}
     for B, fam in want.items():
         assert [p for p, _, _ in L.plan_query(B)[0]] == fam, (B, L.plan_query(B))
-    # the sample-split kernel's slicing: 8 slices of 64 channels while two launches' worth of workgroups fit (<= 32 clips under CFG), two
-    # slices of 256 channels (one workgroup per CU, 64 clips per launch) from there to where the one-pass-per-workgroup kernel takes over
+    # the sample-split kernel's slicing: 8 slices of 64 channels up to 30 clips under CFG, 4 slices of 128 channels (one workgroup per CU, the
+    # slices of a group on one XCD) at 32, two slices of 256 channels (64 clips per launch) from there to where the one-pass-per-workgroup
+    # kernel takes over
     for ds in ("ted", "beat"):
-        assert [L.plan_coop_slices(2 * b, ds) for b in (1, 4, 16, 32, 40, 48, 64)] == [8, 8, 8, 8, 2, 2, 2], ds
-        assert L.plan_coop_slices(64, ds) == 8 and L.plan_coop_slices(80, ds) == 2        # single-pass form: groups = clips
+        assert [L.plan_coop_slices(2 * b, ds) for b in (1, 4, 16, 28, 32, 40, 48, 64)] == [8, 8, 8, 8, 4, 2, 2, 2], ds
+        assert L.plan_coop_slices(32, ds) == 8 and L.plan_coop_slices(64, ds) == 4 and L.plan_coop_slices(80, ds) == 2     # single-pass form: groups = clips
     assert [p for p, _, _ in L.plan_query(48)[0]] == [2] and [p for p, _, _ in L.plan_query(72)[0]] == [3]
     # model time never falls when clips are added by whole rounds, and a batch never costs more than the next multiple of the chip
     for B in range(1, 513):
