@@ -614,48 +614,66 @@ struct CoopCost { float base, per_group; };
 // [dataset][ncb 1 with up to one workgroup per CU (the slices of a group on one XCD) | ncb 1 two per CU | ncb 2 | ncb 4]
 constexpr CoopCost kCoopCost[2][4] = {{{0.0909f, 0.000213f}, {0.0875f, 0.00096f}, {0.1397f, 0.0000958f}, {0.2297f, 0.00000625f}},
                                       {{0.0987f, 0.00028f}, {0.0963f, 0.00103f}, {0.1511f, 0.000156f}, {0.2610f, 0.0000115f}}};
+// one launch of `gl` groups
+float coop_launch_ms(bool ted, int ncb, int gl, int n_cu) {
+    const CoopCost& c = kCoopCost[ted ? 0 : 1][ncb == 1 ? (gl * 8 <= n_cu ? 0 : 1) : ncb == 2 ? 2 : 3];
+    return c.base + c.per_group * gl;
+}
+// `g` groups in launches of ONE slicing
 float coop_ms_ncb(bool ted, int ncb, int g, int n_cu) {
     const int cap = coop_cap(n_cu, ncb);
     if (cap < 1) return 1e30f;
     float ms = 0.f;
-    for (; g > 0; g -= cap) {
-        const int gl = g < cap ? g : cap;
-        const CoopCost& c = kCoopCost[ted ? 0 : 1][ncb == 1 ? (gl * 8 <= n_cu ? 0 : 1) : ncb == 2 ? 2 : 3];
-        ms += c.base + c.per_group * gl;
-    }
+    for (; g > 0; g -= cap) ms += coop_launch_ms(ted, ncb, g < cap ? g : cap, n_cu);
     return ms;
+}
+// `g` groups in the cheapest SEQUENCE of launches, each with its own slicing (80 clips = 64 on two slices + 16 on eight): the model time and
+// the slicing of the first launch.  Launches hold whole samples (`np` groups each); ties go to more slices (shorter chains per workgroup).
+struct CoopBest { float ms; int ncb; };
+CoopBest coop_best(bool ted, int g, int n_cu, int np) {
+    if (g < 1) return {0.f, 1};
+    std::vector<float> cost((size_t)g + 1, 0.f);
+    int first = 1;
+    for (int k = np; k <= g; k += np) {
+        float bm = 1e30f;
+        int bn = 1;
+        for (int ncb = 1; ncb <= 4; ncb *= 2) {
+            const int cap = coop_cap(n_cu, ncb) / np * np;
+            if (cap < np) continue;
+            const int gl = k < cap ? k : cap;
+            const float m = coop_launch_ms(ted, ncb, gl, n_cu) + cost[(size_t)(k - gl)];
+            if (m < bm) { bm = m; bn = ncb; }
+        }
+        cost[(size_t)k] = bm;
+        if (k == g) first = bn;
+    }
+    return {cost[(size_t)g], first};
 }
 // blockIdx -> (group, slice) mapping of a launch (speed only): a grid of up to one workgroup per CU keeps the slices of a group on one
 // XCD (hand-offs through one L2: 13-16 % at 16 clips on 8 slices, 5-10 % on 4 / 2 slices), two per CU splits them 4 + 4 over two XCDs
 int coop_xmap_for(int n_cu, int ncb, int groups) { return ncb != 1 || groups * 8 <= n_cu ? 1 : 2; }
-// the slicing the model prefers for `g` groups (ties go to more slices: shorter chains per workgroup)
-int coop_pick_ncb(bool ted, int g, int n_cu) {
-    int best = 1;
-    float bm = coop_ms_ncb(ted, 1, g, n_cu);
-    for (int ncb = 2; ncb <= 4; ncb *= 2) {
-        const float m = coop_ms_ncb(ted, ncb, g, n_cu);
-        if (m < bm) { bm = m; best = ncb; }
-    }
-    return best;
-}
+// the slicing of the first launch of `g` groups
+int coop_pick_ncb(bool ted, int g, int n_cu, int np) { return coop_best(ted, g, n_cu, np).ncb; }
 
 // the sample-split kernel over samples [first, first + n): 8 / ncb workgroups per (sample, pass), as many samples per launch as are
 // resident at once
 hipError_t run_coop(ls_handle* h, const StepArgs& s, int first, int n, bool pair, hipStream_t st) {
     const int np = pair ? 1 : 2;
-    const int ncb = h->coop_ncb ? h->coop_ncb : coop_pick_ncb(h->var == kTED, n * np, h->n_cu);
-    int cap = coop_cap(h->n_cu, ncb);
-    if (cap > h->coop_groups) cap = h->coop_groups;
-    const int per = cap / np;
-    if (per < 1) return hipErrorInvalidValue;
-    for (int b0 = first; b0 < first + n; b0 += per) {
+    for (int b0 = first; b0 < first + n;) {
+        const int left = first + n - b0;
+        const int ncb = h->coop_ncb ? h->coop_ncb : coop_pick_ncb(h->var == kTED, left * np, h->n_cu, np);     // per launch: the rest of the piece re-planned
+        int cap = coop_cap(h->n_cu, ncb);
+        if (cap > h->coop_groups) cap = h->coop_groups;
+        const int per = cap / np;
+        if (per < 1) return hipErrorInvalidValue;
         StepArgs c = s;
         c.cx = h->co_x.f(); c.cpart = h->co_part.f();
         c.cgran = static_cast<unsigned long long*>(h->co_gran.p); c.cflag = static_cast<unsigned long long*>(h->co_flag.p);
         c.cerr = static_cast<unsigned*>(h->co_err.p);
         c.epoch = (++h->coop_launches) * kCoopEpochStride;      // tags of one launch: epoch + 1 .. epoch + 2 * layers + 1 < the stride (checked in decide_path / ls_set_path)
-        const int ns = first + n - b0 < per ? first + n - b0 : per;
+        const int ns = left < per ? left : per;
         c.b0 = b0; c.npass = np; c.xmap = h->coop_xmap >= 0 ? h->coop_xmap : coop_xmap_for(h->n_cu, ncb, ns * np);
+        b0 += ns;
         hipError_t e = launch_step_coop(h->var, ncb, c, ns, st);
         if (e != hipSuccess) return e;
     }
@@ -858,7 +876,7 @@ PlanOut plan_steps(const PlanIn& in) {
         case 0: return c.fused_round * ((n + round - 1) / round);
         case 1: return in.have_long && !bf ? c.long_base + c.long_per_sample * thr * n : 1e30f;
         case 2: return bf || in.coop_groups_max < np || 2 * in.layers + 2 > (int)kCoopEpochStride ? 1e30f
-                       : coop_ms_ncb(in.ted, in.coop_ncb ? in.coop_ncb : coop_pick_ncb(in.ted, n * np, in.n_cu), n * np, in.n_cu);
+                       : in.coop_ncb ? coop_ms_ncb(in.ted, in.coop_ncb, n * np, in.n_cu) : coop_best(in.ted, n * np, in.n_cu, np).ms;
         default: return pass_ms(c, n, np, in.n_cu);
         }
     };
@@ -959,7 +977,7 @@ void report_path(ls_handle* h, bool pair) {
         for (int i = 0; i < h->nseg; ++i)
             if (h->seg[i].path == 2) {
                 const int n = h->nseg == 1 ? h->B : h->seg[i].n, np = pair ? 1 : 2;
-                h->timing.coop_slices = 8 / (h->coop_ncb ? h->coop_ncb : coop_pick_ncb(h->var == kTED, n * np, h->n_cu));
+                h->timing.coop_slices = 8 / (h->coop_ncb ? h->coop_ncb : coop_pick_ncb(h->var == kTED, n * np, h->n_cu, np));      // of the first launch
             }
 }
 
@@ -1280,7 +1298,7 @@ int ls_plan_query(int beat, int batch, int single_pass, int precision, int n_cus
 // Slice workgroups per (sample, pass) the sample-split kernel would use for a piece of `groups` (sample, pass) groups (mode 3's choice).
 int ls_plan_coop_slices(int beat, int groups, int n_cus) {
     if (groups < 1 || n_cus < 8) return LS_EINVAL;
-    return 8 / coop_pick_ncb(beat == 0, groups, n_cus);
+    return 8 / coop_pick_ncb(beat == 0, groups, n_cus, 1);
 }
 
 int ls_set_path(ls_handle* h, int mode) {

@@ -105,7 +105,7 @@ def test_headline_workload_batch512_1000_steps_spot_check():
 
 
 @pytest.mark.engine_path_auto
-@pytest.mark.parametrize("ds,B", [("ted", 160), ("ted", 416), ("beat", 192), ("ted", 72), ("ted", 48)])
+@pytest.mark.parametrize("ds,B", [("ted", 160), ("ted", 416), ("beat", 192), ("ted", 72), ("ted", 48), ("beat", 88)])
 def test_multi_piece_plans_replayed_through_the_oracle(ds, B):
     """Ragged batches (the last iteration of the reference's loaders, scripts/test_RAG_ted.py:43-82) run on plans of several pieces --
     full rounds on the fused kernel, a chip's worth on the one-pass-per-workgroup kernel, the rest on the sample-split kernel.  The first
