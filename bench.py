@@ -19,7 +19,7 @@ besides the contract's keys:
   "single_pass"    the guidance-scale-1 workload (uncond pass legitimately skipped), own FLOP count -- never mixed into `value`
   "livelyspeaker"  BASELINE configs[2] as the reference runs it: SAG decode + ddim100 / skip 80 refine, own roofline
   "configs4_beat"  BASELINE configs[4]: BEAT at 34 frames (B=256) and the SYNTHETIC 150-frame variant (B=32), own rooflines
-  "mid_batches"    batches that do not fill the chip a whole number of times (128 / 160 / 384 clips): the engine's plan, own rooflines;
+  "mid_batches"    batches that do not fill the chip a whole number of times (64 / 80 / 128 / 160 / 384 clips): the engine's plan, own rooflines;
                    BEAT B=256 in the reference's own RNG mode (host-RNG bound stated)
   "shard_check"    the config-4 premise on hardware: every rank re-generates ANOTHER rank's shard via sample_offset
   "split_precision", "train_step"   secondary legs
@@ -100,8 +100,9 @@ def step_kernel_label(tm):
     batch-level kernels, or up to three of them for a batch that does not fill the chip a whole number of times)."""
     names = {0: "ls::k_step (fused CFG denoiser + sampler update, one workgroup per clip, 1 launch/step)",
              1: "batch-level kernels (ls_long.hip, 21 launches/step)",
-             2: "ls::k_coop (sample-split: 16 workgroups per clip, 1 launch per 32 clips and step)",
+             2: "ls::k_coop (sample-split: {s} slice workgroups per (clip, CFG pass), 1 launch per step and resident set)",
              3: "ls::k_pass (one workgroup per (clip, CFG pass), two per CU, 1 launch/step)"}
+    names[2] = names[2].format(s=tm.get("coop_slices") or "8 / 4 / 2")
     s = names.get(tm["step_path"], "?")
     for n, p in ((tm.get("tail_samples", 0), tm.get("tail_path", 0)), (tm.get("tail2_samples", 0), tm.get("tail2_path", 0))):
         if n:
@@ -544,7 +545,7 @@ def other_config_leg(dataset, B, dev, fence, steps=1000, noise="philox"):
     km = tm["loop_ms"] / max(tm["n_step_launches"], 1)
     ach = 2 * FLOP_PER_FORWARD[dataset] * B / (km * 1e-3) / 1e12
     names = {0: "fused step kernel (one workgroup per clip)", 1: "batch-level kernels (ls_long.hip, 21 launches per step)",
-             2: "sample-split step kernel (ls_coop_kernel.h: 16 workgroups per clip, one launch per step)",
+             2: f"sample-split step kernel (ls_coop_kernel.h: {tm.get('coop_slices') or '8 / 4 / 2'} slice workgroups per (clip, CFG pass) in its first launch; one launch per step and resident set)",
              3: "one-pass-per-workgroup step kernel (ls_pass_kernel.h: a workgroup per (clip, CFG pass), two per CU)"}
     kernels = names[tm["step_path"]] + (f" + {tm['tail_samples']} clips on the {names[tm['tail_path']].split(' (')[0]}" if tm["tail_samples"] else "") \
         + (f" + {tm['tail2_samples']} clips on the {names[tm['tail2_path']].split(' (')[0]}" if tm["tail2_samples"] else "")
@@ -842,6 +843,20 @@ def main():
                            "collective_backend": backend}
             diffusion.sample_offset, diffusion.philox_seed = first, None
 
+    # diagnostics of a multi-rank run, so that the first run on N real GPUs can be read from its one line: every rank's device, CU count,
+    # kernel plan and own timings (collected over the gloo control plane), and what the result gather costs on the data group
+    rank_recs = gather_rec = None
+    if use_dist:
+        try:
+            prop = torch.cuda.get_device_properties(dev)
+            rank_recs = shard.rank_reports({"device": f"cuda:{local}", "name": prop.name, "n_cus": int(main_tm["n_cus"]), "batch": B,
+                                            "step_kernel": step_kernel_label(main_tm), "loop_ms_per_call": round(loop_ms / a.steps, 3),
+                                            "prepare_ms_per_call": round(prep_ms / a.steps, 3), "collective_backend": shard.backend(),
+                                            "rccl_error": (groups or {}).get("rccl_error")})
+            gather_rec = shard.timed_gather(first_out, total)
+        except Exception as e:          # noqa: BLE001  (symmetric on every rank)
+            rank_recs, gather_rec = [{"error": repr(e)[:300]}], None
+
     extra = not a.no_extra_legs and a.precision == "fp32" and a.legs != "none"
     legs = set(("single", "split", "lively", "beat", "train", "seeds", "small", "mid") if a.legs in ("all", "none") else a.legs.split(","))
 
@@ -986,7 +1001,8 @@ def main():
     mid = None
     if extra and a.dataset == "ted" and world == 1 and "mid" in legs:
         mid = {}
-        for name, ds, bb, nz in (("ted_b128", "ted", 128, "philox"), ("ted_b384", "ted", 384, "philox"), ("ted_b160", "ted", 160, "philox"),
+        for name, ds, bb, nz in (("ted_b64", "ted", 64, "philox"), ("ted_b80", "ted", 80, "philox"),
+                                 ("ted_b128", "ted", 128, "philox"), ("ted_b384", "ted", 384, "philox"), ("ted_b160", "ted", 160, "philox"),
                                  ("beat_b256_identical_seeds", "beat", 256, "torch_cpu")):
             try:
                 mid[name] = other_config_leg(ds, bb, dev, fence, noise=nz)
@@ -1040,6 +1056,9 @@ def main():
                          "kernel_ms": round(kernel_ms, 4), "flop_per_launch": flop_launch,
                          "prepare_ms_per_call": round(prep_ms / a.steps, 3)},
         }
+        if rank_recs is not None:
+            rec["ranks"] = rank_recs
+            rec["gather"] = gather_rec
         if shard_check is not None:
             rec["shard_check"] = shard_check
             rec["rccl_ranks"] = shard_check["rccl_ranks"]

@@ -263,6 +263,38 @@ def gather_samples(local: torch.Tensor, total: int) -> torch.Tensor:
     return torch.cat([out[r * pad: r * pad + c] for r, c in enumerate(counts)], dim=0)
 
 
+def rank_reports(mine: dict) -> list:
+    """Every rank's small diagnostic record (device, compute units, kernel plan, its own wall time ...) collected on every rank, in rank
+    order -- over the gloo control-plane group, so it works whatever became of RCCL.  One rank: ``[mine]``.  Collective."""
+    if not _on():
+        return [dict(mine, rank=0)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, dict(mine, rank=dist.get_rank()))
+    return out
+
+
+def timed_gather(local: torch.Tensor, total: int, reps: int = 3) -> dict:
+    """Wall time of the result gather alone (barrier -> ``gather_samples`` -> device synchronised), best of ``reps``, MAX over ranks: the
+    only collective of a sampling call, so the first multi-GPU line says what it costs.  Collective."""
+    import time
+    best = float("inf")
+    for _ in range(reps):
+        if _on():
+            dist.barrier()
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        t0 = time.perf_counter()
+        whole = gather_samples(local, total)
+        if whole.is_cuda:
+            torch.cuda.synchronize(whole.device)
+        best = min(best, time.perf_counter() - t0)
+    t = torch.tensor([best], dtype=torch.float64, device=local.device)
+    if _on():
+        all_reduce_(t, dist.ReduceOp.MAX)
+    return {"ms": round(float(t.item()) * 1e3, 3), "bytes_per_rank": int(local.numel() * local.element_size()), "total_samples": int(total),
+            "collective_backend": backend(), "what": "all_gather of the per-rank results into the global batch (gather_samples), max over ranks"}
+
+
 def sample_sharded(sample_fn, model, global_shape, y_global: dict, diffusion=None, **kwargs) -> torch.Tensor:
     """Run ``sample_fn`` (``diffusion.p_sample_loop`` / ``ddim_sample_loop``) on this rank's contiguous
     shard of the batch and return the gathered global result.  ``diffusion.sample_offset`` is set so the

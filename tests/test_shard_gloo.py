@@ -302,7 +302,10 @@ def _world8_worker(rank, world, port, q):
         mine = gen(first, count, rank)
         whole = shard.gather_samples(mine, total)
         chk = shard.cross_check(gen, mine, total)
-        q.put((rank, (info, t.tolist(), whole[:, 0, 0, 0].tolist(), (first, count), chk)))
+        # what bench.py --gpus 8 adds to its line so that the first run on eight real GPUs is diagnosable from it alone
+        reps = shard.rank_reports({"device": f"cpu:{rank}", "n_cus": 256 - rank, "collective_backend": shard.backend(), "elapsed_s": 0.5 + rank})
+        tg = shard.timed_gather(mine, total, reps=2)
+        q.put((rank, (info, t.tolist(), whole[:, 0, 0, 0].tolist(), (first, count), chk, reps, tg)))
         shard.finish(0)
     except Exception as e:
         import traceback
@@ -326,8 +329,13 @@ def test_world8_bring_up_ragged_gather_and_cross_check():
     covered = []
     for r in range(world):
         assert not isinstance(res[r], Exception), res[r]
-        info, red, whole, (first, count), chk = res[r]
+        info, red, whole, (first, count), chk, reps, tg = res[r]
         assert info["collective_backend"] == "gloo" and info["rccl_ranks"] == 0 and not info["rccl_probe_abandoned"], info
+        # the N = 8 line's diagnostics: one record per rank, in rank order, each with its device's CU count and the backend it ended up on;
+        # the gather's own time, byte count and backend
+        assert [x["rank"] for x in reps] == list(range(8)) and [x["n_cus"] for x in reps] == [256 - k for k in range(8)], reps
+        assert all(x["collective_backend"] == "gloo" and x["device"] == f"cpu:{x['rank']}" for x in reps)
+        assert tg["ms"] > 0 and tg["collective_backend"] == "gloo" and tg["total_samples"] == total and tg["bytes_per_rank"] == count * 6 * 4, tg
         assert red == [36.0] * 4 and whole == want                         # every rank holds the whole batch in global order
         assert chk["ranks"] == 8 and chk["bitwise_equal"] and chk["checksum_recomputed"] == chk["checksum_sharded"], chk
         covered += list(range(first, first + count))
