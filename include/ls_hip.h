@@ -301,6 +301,12 @@ int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, 
  * ls_trng_stats: pairs evaluated / pairs sent back to libm so far in this process.  ls_trng_pairs_debug (tests): the vectorised
  * evaluation alone over np pairs (4 np words) next to libm's doubles; isa 0 / 1 / 2 = base / AVX2 / AVX-512 clone, -1 = this machine's. */
 int ls_trng_stats(uint64_t* pairs, uint64_t* redone);
+/* Long fills of the native stream start their generator threads from JUMPED mt19937 states (csrc/ls_mt_jump.h: t^J modulo the
+ * characteristic polynomial, applied as an XOR of ~10 k windows of a 33-block expansion of the state) instead of behind one thread that
+ * walks the whole stream.  ls_trng_set_jump(0) restores the sequential scout (returns the previous setting); ls_trng_jump_check compares
+ * the two ways of reaching the state `words` (a multiple of 624) further on: 0 = identical. */
+int ls_trng_set_jump(int on);
+int ls_trng_jump_check(uint32_t seed, uint64_t words, int* support);
 int ls_trng_pairs_debug(const uint32_t* words, int np, int isa, double* fast_c, double* fast_s, float* zc, float* zs, uint8_t* redo,
                         double* libm_c, double* libm_s);
 

@@ -103,7 +103,7 @@ class LsEvalConfig(C.Structure):
 
 EXPORTS = ("ls_abi_version", "ls_create", "ls_destroy", "ls_last_error", "ls_set_weight", "ls_commit_weights",
            "ls_set_schedule", "ls_prepare", "ls_prepare_async", "ls_sample", "ls_forward", "ls_step", "ls_q_sample", "ls_read",
-           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_plan_coop_slices", "ls_trng_randn", "ls_trng_fill_steps", "ls_trng_stats", "ls_trng_pairs_debug", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
+           "ls_get_timing", "ls_synchronize", "ls_stream_order", "ls_stream", "ls_sag_stream", "ls_train_stream", "ls_eval_stream", "ls_philox_x_init", "ls_shard_range", "ls_set_precision", "ls_set_path", "ls_plan_query", "ls_plan_coop_slices", "ls_trng_randn", "ls_trng_fill_steps", "ls_trng_stats", "ls_trng_set_jump", "ls_trng_jump_check", "ls_trng_pairs_debug", "ls_sag_create", "ls_sag_destroy", "ls_sag_last_error",
            "ls_sag_set_weight", "ls_sag_commit_weights", "ls_sag_decode", "ls_sag_decode_async", "ls_sag_last_decode_ms", "ls_ted_post", "ls_beat_post",
            "ls_train_create", "ls_train_destroy", "ls_train_last_error", "ls_train_set_schedule", "ls_train_param_count",
            "ls_train_flat_size", "ls_train_param_info", "ls_train_set_weight", "ls_train_get_weight", "ls_train_forward_backward",

@@ -38,6 +38,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include "ls_mt_jump.h"
 #if defined(__x86_64__)
 #include <immintrin.h>
 #define LS_CPU_PAUSE _mm_pause();
@@ -218,8 +219,16 @@ inline void words_ready(const Mt::Pending& p) {
     }
     LS_TA(g_ns_spin)
 }
+// ls_trng_set_jump: generator threads of a long fill start from JUMPED states (ls_mt_jump.h) instead of behind the sequential scout.
+// Off by default -- measured on the GPU hosts (round 6, tools/rng_jump_ab.py, tools/seeds_time.py): the scout costs 0.2 ms per step at
+// BEAT B = 256 there, not the 1.35 ms round 5 attributed to it; what a step's draws cost is the double-precision transforms (15.7 thread-ms)
+// and, per call, starting and draining the pipeline, so the jump moves nothing in the loop (0.60-1.4 ms per step against 0.68-0.90, run to
+// run) while persistent pools and 12-step segments brought the mode to the step kernel's own rate.  Kept: bitwise-tested, and the right
+// tool on a host whose single-thread recurrence is the bound.
+std::atomic<int> g_use_jump{0};
 Mt::Pending Mt::fill_words(uint32_t* out, size_t n) {
     const int isa = mt_isa();
+    const size_t n_entry = n;
     Pending pend;
     if (gen && n >= (kParBlocks + 2) * (size_t)kN) {
         // head: the rest of the current block
@@ -228,10 +237,58 @@ Mt::Pending Mt::fill_words(uint32_t* out, size_t n) {
             if (isa == 2) mt_temper_avx512(st + next, out, m); else if (isa == 1) mt_temper_avx2(st + next, out, m); else mt_temper_base(st + next, out, m);
             next += (uint32_t)m; left -= (int)m; out += m; n -= m;
         }
-        // middle: whole blocks, in pieces.  A piece's generator starts from a snapshot of the state in front of it; the scout (this thread)
-        // runs the recurrence alone over the piece to reach the next snapshot
+        // middle: whole blocks, in pieces.  A piece's generator starts from the state in front of it.
         const size_t nb = n / kN;
         const int nt = pool_threads(gen) > 0 ? pool_threads(gen) : 1;
+        // (a) jump-ahead (ls_mt_jump.h): one piece per generator thread, each thread computes its own starting state from a shared
+        // 33-block expansion of the current state and a precomputed jump polynomial (~0.1 ms), then produces its words; this thread only
+        // jumps to the last whole piece and walks the remainder (< one piece) to leave the state where the fill ends.  The piece length
+        // depends on the fill's size alone (not on where the stream stands inside a block), so a loop's fills reuse their polynomials.
+        size_t jper = (n_entry / kN + (size_t)nt - 1) / (size_t)nt;
+        if (jper < 64) jper = 64;
+        bool jumped = false;
+        if (g_use_jump.load(std::memory_order_relaxed) && nb >= 2 * jper && mtjump::field().ok) {
+            size_t pfull = nb / jper, rem = nb % jper;
+            if (rem == 0) { --pfull; rem = jper; }      // the state left behind comes out of real block updates (word 0's low bits are not part of a jumped state)
+            const unsigned long long L = (unsigned long long)jper * kN;
+            std::vector<std::shared_ptr<const mtjump::Support>> sup(pfull + 1);
+            bool have = true;
+            for (size_t p = 1; p <= pfull; ++p) have = have && (sup[p] = mtjump::jump_support(L, (int)p)) != nullptr;
+            if (have) {
+                LS_T0
+                auto X = std::make_shared<std::vector<uint32_t>>((size_t)mtjump::kXWords);
+                mtjump::expand(st, X->data());
+                pend = std::make_shared<std::atomic<int>>((int)(pfull + 1));
+                for (size_t p = 0; p < pfull; ++p) {
+                    uint32_t* dst = out + p * jper * kN;
+                    auto sp = sup[p];
+                    const size_t cnt = jper;
+                    pool_submit(gen, [X, sp, dst, cnt, isa, pend] {
+                        LS_T0
+                        alignas(64) uint32_t s0[kN];
+                        if (sp) mtjump::apply(X->data(), *sp, s0, isa); else memcpy(s0, X->data(), sizeof s0);
+                        mt_blocks_to_words(s0, dst, cnt, isa);
+                        pend->fetch_sub(1, std::memory_order_acq_rel);
+                        LS_TA(g_ns_gen)
+                    });
+                }
+                alignas(64) uint32_t s1[kN];
+                mtjump::apply(X->data(), *sup[pfull], s1, isa);
+                {
+                    auto snap = std::make_shared<std::array<uint32_t, kN>>();
+                    memcpy(snap->data(), s1, sizeof s1);
+                    uint32_t* dst = out + pfull * jper * kN;
+                    const size_t cnt = rem;
+                    pool_submit(gen, [snap, dst, cnt, isa, pend] { LS_T0 mt_blocks_to_words(snap->data(), dst, cnt, isa); pend->fetch_sub(1, std::memory_order_acq_rel); LS_TA(g_ns_gen) });
+                }
+                for (size_t b = 0; b < rem; ++b) { if (isa == 2) mt_block_avx512(s1); else if (isa == 1) mt_block_avx2(s1); else mt_block_base(s1); }
+                memcpy(st, s1, sizeof s1);
+                jumped = true;
+                LS_T1(g_t_scout)
+            }
+        }
+        // (b) the scout (this thread) runs the recurrence alone over each piece to reach the next snapshot
+        if (!jumped) {
         size_t per = (nb + (size_t)(4 * nt) - 1) / (size_t)(4 * nt);
         if (per < 64) per = 64;
         pend = std::make_shared<std::atomic<int>>((int)((nb + per - 1) / per));
@@ -245,6 +302,7 @@ Mt::Pending Mt::fill_words(uint32_t* out, size_t n) {
             for (size_t b = 0; b < cnt; ++b) { if (isa == 2) mt_block_avx512(st); else if (isa == 1) mt_block_avx2(st); else mt_block_base(st); }
         }
         LS_T1(g_t_scout) }
+        }
         out += nb * kN; n -= nb * kN;
         left = 1; next = kN;                 // the last block is used up, exactly as after reading it word by word
     }
@@ -435,7 +493,9 @@ public:
         cv_.notify_one();
     }
     int threads() const { return (int)th_.size(); }
+    bool take_failure() { return failed_.exchange(false); }
 private:
+    std::atomic<bool> failed_{false};
     struct Batch {
         std::function<void(size_t, size_t)> fn;
         size_t n = 0, chunk = 1, njobs = 0;
@@ -454,7 +514,11 @@ private:
                 const size_t i = b->next.fetch_add(1, std::memory_order_relaxed);
                 if (i >= b->njobs) break;
                 const size_t a = i * b->chunk;
-                b->fn(a, a + b->chunk < b->n ? a + b->chunk : b->n);
+                try {
+                    b->fn(a, a + b->chunk < b->n ? a + b->chunk : b->n);
+                } catch (...) {                          // (a failed allocation inside a job: recorded, the batch still retires, the entry point reports it)
+                    failed_.store(true, std::memory_order_relaxed);
+                }
                 if (b->finished.fetch_add(1, std::memory_order_acq_rel) + 1 == b->njobs) {
                     std::lock_guard<std::mutex> l(m_);
                     if (--pending_ == 0) done_.notify_all();
@@ -473,6 +537,31 @@ private:
     size_t pending_ = 0;                                  // batches not finished yet
     bool stop_ = false;
 };
+
+// The two pools of a draw call, kept between calls: a sampling loop in the identical-seeds mode calls ls_trng_fill_steps once per segment of
+// a few steps, and starting ~30 threads per call cost more than the draws of a short segment.  One caller at a time owns them (the stream
+// is sequential anyway); a concurrent caller gets pools of its own for the call.
+struct PoolPair {
+    std::unique_ptr<Pool> own_x, own_g;
+    Pool* x = nullptr;
+    Pool* g = nullptr;
+    std::unique_lock<std::mutex> lock;
+};
+PoolPair acquire_pools(int nx, int ng) {
+    static std::mutex mu;
+    static std::unique_ptr<Pool> keep_x, keep_g;
+    PoolPair pp;
+    pp.lock = std::unique_lock<std::mutex>(mu, std::try_to_lock);
+    if (pp.lock.owns_lock()) {
+        if (!keep_x || keep_x->threads() != nx) keep_x.reset(new Pool(nx));
+        if (!keep_g || keep_g->threads() != ng) keep_g.reset(new Pool(ng));
+        pp.x = keep_x.get(); pp.g = keep_g.get();
+    } else {
+        pp.own_x.reset(new Pool(nx)); pp.own_g.reset(new Pool(ng));
+        pp.x = pp.own_x.get(); pp.g = pp.own_g.get();
+    }
+    return pp;
+}
 
 void pool_submit(Pool* p, std::function<void()> job) { p->submit(std::move(job)); }
 void pool_wait(Pool* p) { p->wait(); }
@@ -713,14 +802,18 @@ int ls_trng_randn(uint8_t* state, size_t state_bytes, float* out, size_t n, int 
     Mt g;
     if (!g.load(state)) return LS_EINVAL;
     {
-        Pool pool(n >= 65536 && n_threads > 1 ? n_threads : 0);
-        Pool gpool(n >= (kParBlocks + 2) * (size_t)kN && n_threads > 1 ? (n_threads < 12 ? n_threads / 2 : 6) : 0);      // word generators of long fills
+        PoolPair pp = acquire_pools(n >= 65536 && n_threads > 1 ? n_threads : 0,
+                                    n >= (kParBlocks + 2) * (size_t)kN && n_threads > 1 ? (n_threads < 12 ? n_threads / 2 : 6) : 0);      // word generators of long fills
+        Pool& pool = *pp.x;
+        Pool& gpool = *pp.g;
         g.gen = gpool.threads() ? &gpool : nullptr;
         static thread_local WordRing ring;
         ring.used = 0;
         if (n >= 16) draw_contig(g, pool, out, n, variant);
         else draw_serial(g, pool, ring, out, n, SerialShape{1, 1, 1, (int)n, false});
         pool.wait();
+        gpool.wait();
+        if (pool.take_failure() | gpool.take_failure()) return LS_ENOMEM;
     }
     g.store(state);
     return LS_OK;
@@ -741,8 +834,12 @@ int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, 
 #ifdef LS_TRNG_TIMING
         const double t_begin = now_s();
 #endif
-        Pool pool(n_threads > 1 ? n_threads : 0);
-        Pool gpool(n_threads > 1 ? (n_threads < 12 ? n_threads / 2 : 6) : 0);      // word generators of long fills (Mt::fill_words)
+        // word generators of long fills (Mt::fill_words): behind the scout six keep up with it; with jump-ahead nobody walks the stream and
+        // the generators are the producers, so more of them shorten a fill.  (Generator + transform threads <= 2 n_threads.)
+        PoolPair pp = acquire_pools(n_threads > 1 ? n_threads : 0,
+                                    n_threads > 1 ? (n_threads < 12 ? n_threads / 2 : (g_use_jump.load(std::memory_order_relaxed) ? 12 : 6)) : 0);
+        Pool& pool = *pp.x;
+        Pool& gpool = *pp.g;
         g.gen = gpool.threads() ? &gpool : nullptr;
         static thread_local WordRing ring;
         ring.used = 0;
@@ -757,7 +854,8 @@ int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, 
             if (first_c && nx >= 16) draw_contig(g, pool, nz, nx, variant);
             else draw_serial(g, pool, ring, nz, nx, SerialShape{B, J, F, T, !first_c});             // a contiguous x of < 16 elements: serial, in order
         }
-        { LS_T0 pool.wait(); LS_T1(g_t_finalwait) }
+        { LS_T0 pool.wait(); gpool.wait(); LS_T1(g_t_finalwait) }
+        if (pool.take_failure() | gpool.take_failure()) return LS_ENOMEM;
 #ifdef LS_TRNG_TIMING
         fprintf(stderr, "trng timing (s): total %.4f scout %.4f genwait %.4f serial %.4f ringwait %.4f submit %.4f finalwait %.4f steps %d\n", now_s() - t_begin, g_t_scout, g_t_genwait, g_t_serial, g_t_ringwait, g_t_submit, g_t_finalwait, n_steps);
         fprintf(stderr, "   thread-ms: gen %.3f spin %.3f xform %.3f\n", g_ns_gen.exchange(0) * 1e-6, g_ns_spin.exchange(0) * 1e-6, g_ns_xform.exchange(0) * 1e-6);
@@ -771,6 +869,34 @@ int ls_trng_fill_steps(uint8_t* state, size_t state_bytes, int B, int D, int J, 
 }
 
 // how many double pairs were evaluated, and how many of them went back to libm (process-wide; tests and tools)
+// The mt19937 jump-ahead of long fills (ls_mt_jump.h): on (default) / off = round 5's sequential scout; returns the previous setting.
+int ls_trng_set_jump(int on) { return g_use_jump.exchange(on ? 1 : 0); }
+
+// Self-check of the jump-ahead: the state `words` (a multiple of 624) further on from init_genrand(seed), by the jump polynomial and by
+// running the recurrence; 0 = identical in every bit that is part of the state (word 0's top bit, words 1 .. 623), 1 = different,
+// negative = the characteristic polynomial could not be built.  *support = number of windows the jump XORs.
+int ls_trng_jump_check(uint32_t seed, uint64_t words, int* support) {
+    if (words == 0 || words % kN) return LS_EINVAL;
+    const mtjump::Field& f = mtjump::field();
+    if (!f.ok) return LS_EUNSUPPORTED;
+    uint32_t st[kN], ref[kN], got[kN];
+    st[0] = seed;
+    for (int j = 1; j < kN; ++j) st[j] = 1812433253u * (st[j - 1] ^ (st[j - 1] >> 30)) + (uint32_t)j;
+    memcpy(ref, st, sizeof st);
+    for (uint64_t b = 0; b < words / kN; ++b) mt_block_base(ref);
+    auto sup = mtjump::jump_support(words, 1);
+    if (!sup) return LS_EUNSUPPORTED;
+    if (support) *support = (int)sup->size();
+    std::vector<uint32_t> X((size_t)mtjump::kXWords);
+    mtjump::expand(st, X.data());
+    for (int isa = 0; isa <= mt_isa(); ++isa) {
+        mtjump::apply(X.data(), *sup, got, isa);
+        if ((got[0] ^ ref[0]) & 0x80000000u) return 1;
+        if (memcmp(got + 1, ref + 1, (kN - 1) * sizeof(uint32_t)) != 0) return 1;
+    }
+    return 0;
+}
+
 int ls_trng_stats(uint64_t* pairs, uint64_t* redone) {
     if (!pairs || !redone) return LS_EINVAL;
     *pairs = g_pairs.load(std::memory_order_relaxed);

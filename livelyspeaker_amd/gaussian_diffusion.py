@@ -101,8 +101,10 @@ class GaussianDiffusion:
     #: runs ONE pass (out_u + 1 * (out_c - out_u) = out_c up to one fp32 rounding -- the two settings agree to ~1e-5, not bitwise)
     two_pass_always = False
     #: torch_cpu mode: host noise tapes larger than this many bytes are drawn and uploaded in K-step segments (page-locked
-    #: double buffer, upload of segment i+1 under the steps of segment i) instead of one [n_exec, ...] piece
-    tape_segment_bytes = 96 << 20
+    #: double buffer, upload of segment i+1 under the steps of segment i) instead of one [n_exec, ...] piece.  256 MB (two 128 MB slots:
+    #: 12 steps at BEAT B = 256, 23 at TED B = 512): every draw call starts and drains the native stream's pipeline, and at 4-step
+    #: segments (96 MB, rounds 4-5) that was a third of the BEAT step's host time (round 6: 1.0 -> 0.7 ms per step)
+    tape_segment_bytes = 256 << 20
     #: torch_cpu mode: make the per-step draws natively from torch's generator state (same values, same final generator state) when the
     #: native restatement reproduces this torch build; False = always call torch's generator
     native_host_rng = True

@@ -21,7 +21,12 @@ _VARIANT = None         # None: not probed yet; -1: no variant reproduces this t
 
 
 def n_threads() -> int:
-    return max(1, min(16, (os.cpu_count() or 1)))      # measured on the 256-core GPU host: 16 workers behind the one word producer are the sweet spot
+    """Transform workers of a draw call (the word generators of long fills come on top: 6 behind the sequential scout, 12 with jump-ahead).
+    LS_TRNG_THREADS overrides (tools / A-B runs)."""
+    env = os.environ.get("LS_TRNG_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(16, (os.cpu_count() or 1)))      # measured on the 256-thread GPU hosts, rounds 4 and 6: 16 workers; 24 / 32 are slower inside the sampling loop
 
 
 def fill_steps(eps: th.Tensor, noise: th.Tensor, first_contiguous: bool, variant_: int) -> None:
@@ -33,6 +38,8 @@ def fill_steps(eps: th.Tensor, noise: th.Tensor, first_contiguous: bool, variant
     assert two == 2 and noise.shape[0] == n and noise.shape[1] == B
     _, _, J, F, T = noise.shape
     lib = _lib.load_library()
+    if os.environ.get("LS_TRNG_JUMP") is not None:      # A/B switch: 0 = the sequential scout (default), 1 = mt19937 jump-ahead (csrc/ls_mt_jump.h)
+        lib.ls_trng_set_jump(int(os.environ["LS_TRNG_JUMP"]))
     st = th.get_rng_state()
     rc = lib.ls_trng_fill_steps(st.data_ptr(), st.numel(), B, D, J, F, T, n, int(bool(first_contiguous)), eps.data_ptr(), noise.data_ptr(),
                                 int(variant_), n_threads())

@@ -166,3 +166,51 @@ def test_pair_statistics_count_what_went_back_to_libm():
     torch.manual_seed(5)
     torch.randn(16, 1, 16), torch.randn(16, 1, 16)
     assert torch.equal(nz[0], torch.randn_like(torch.empty(34, 16, 250, 1).permute(1, 2, 3, 0)))
+
+
+def test_jump_ahead_reaches_the_same_state_as_the_recurrence():
+    """ls_mt_jump.h: t^J modulo the characteristic polynomial (Berlekamp-Massey, degree 19937) applied as an XOR of windows of a 33-block
+    expansion of the state == J steps of the recurrence, for piece lengths from one block to 10^5 blocks, every ISA clone."""
+    import ctypes as C
+    lib = _lib.load_library()
+    lib.ls_trng_jump_check.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_int)]
+    for seed, blocks in ((5489, 1), (5489, 33), (1, 64), (233, 525), (7, 8400), (99, 100003)):
+        n = C.c_int()
+        assert lib.ls_trng_jump_check(seed, 624 * blocks, C.byref(n)) == 0, (seed, blocks)
+        assert (n.value == 1) if blocks < 32 else (n.value > 100 if blocks < 500 else 8000 < n.value < 12000), (blocks, n.value)      # t^J itself below the degree, ~half of the 19937 coefficients far above it
+    assert lib.ls_trng_jump_check(1, 100, None) < 0                                                 # not a whole number of blocks
+
+
+@pytest.mark.parametrize("B,J,F", [(256, 47, 6), (512, 9, 3)])
+def test_long_fills_are_identical_with_and_without_jump_ahead(B, J, F):
+    """The per-step draws of a sampling loop (BEAT B = 256: 4.9 M words per noise tensor; TED B = 512) with the generator threads started
+    from jumped states vs behind the sequential scout: every float and the generator state handed back, bit for bit -- and torch's own."""
+    import ctypes as C
+    lib = _lib.load_library()
+    v = torch_rng.variant()
+    if v < 0:
+        pytest.skip("the native stream does not reproduce torch on this machine")
+    D, T, n = 512, 34, 3
+    outs = []
+    was = lib.ls_trng_set_jump(1)
+    try:
+        for on in (1, 0):
+            lib.ls_trng_set_jump(on)
+            torch.manual_seed(77)
+            st = torch.get_rng_state().numpy().copy()
+            eps, nz = np.empty((n, 2, B, D), np.float32), np.empty((n, B, J, F, T), np.float32)
+            rc = lib.ls_trng_fill_steps(st.ctypes.data_as(C.POINTER(C.c_uint8)), st.size, B, D, J, F, T, n, 0, eps.ctypes.data_as(_lib.c_f32p),
+                                        nz.ctypes.data_as(_lib.c_f32p), v, 8)
+            assert rc == 0
+            outs.append((eps, nz, st))
+    finally:
+        lib.ls_trng_set_jump(was)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    # torch itself, first step: randn(B,1,D) x 2, then randn_like of the [T][B][J][F]-ordered view
+    torch.manual_seed(77)
+    e0, e1 = torch.randn(B, 1, D), torch.randn(B, 1, D)
+    x = torch.empty(T, B, J, F).permute(1, 2, 3, 0)
+    z = torch.randn_like(x)
+    assert np.array_equal(outs[0][0][0, 0], e0.numpy().reshape(B, D)) and np.array_equal(outs[0][0][0, 1], e1.numpy().reshape(B, D))
+    assert np.array_equal(outs[0][1][0], z.numpy())
