@@ -12,14 +12,15 @@ python bench.py --dataset beat150 --batch 256 --no-extra-legs --no-cpu-baseline 
 python bench.py --respacing ddim100 --no-extra-legs --no-cpu-baseline --steps 5 > "$out/bench_ddim100_full.json" 2> "$out/bench_ddim100_full.err"; echo "ddim100 rc=$?"
 python bench.py --batch 4 --diffusion-steps 50 --no-extra-legs --no-cpu-baseline --steps 20 > "$out/bench_config1_shape.json" 2> "$out/bench_config1.err"; echo "config1 rc=$?"
 python bench.py --gpus 2 --ranks-share-device --batch 256 --legs lively --no-cpu-baseline --steps 2 > "$out/bench_two_ranks_one_gpu.json" 2> "$out/bench_two_ranks_one_gpu.err"; echo "2 ranks / 1 GPU rc=$?"
-python tools/coop_time.py ted 30 4,16,32,64,80,96,112,128,144,160,176,192,224,256,288,320,352,384,416,448,480,512 coop,batch,pass,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_ted.txt"
-python tools/coop_time.py beat 30 4,32,64,96,128,160,192,256 coop,batch,pass,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_beat.txt"
+python tools/coop_time.py ted 30 4,8,16,24,32,40,48,64,72,80,88,96,112,128,144,160,176,192,224,256,288,320,352,384,416,448,480,512 coop8,coop4,coop2,batch,pass,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_ted.txt"
+python tools/coop_time.py beat 30 4,16,32,48,64,80,96,128,160,192,256 coop8,coop4,coop2,batch,pass,fused,auto 2>&1 | grep -v amdgpu.ids > "$out/tvb_beat.txt"
 python tools/bf16x3_time.py auto,fused,pass 64,128,256,384,512 32,128,256 2>&1 | grep -v amdgpu.ids > "$out/bf16x3_time.txt"
 python bench.py --gpus 8 --ranks-share-device --batch 64 --legs none --no-cpu-baseline --steps 2 --warmup 1 > "$out/bench_eight_ranks_one_gpu.json" 2> "$out/bench_eight_ranks.err"; echo "8 ranks / 1 GPU rc=$?"
 python bench.py --gpus 8 --launcher threads --ranks-share-device --batch 64 --path pass --steps 2 --warmup 1 > "$out/bench_threads_eight_handles.json" 2> "$out/bench_threads8.err"; echo "threads launcher x8 rc=$?"
 python bench.py --gpus 2 --launcher threads --ranks-share-device --batch 256 --steps 2 > "$out/bench_threads_two_handles.json" 2> "$out/bench_threads.err"; echo "threads launcher rc=$?"
 tools/prof_call.sh "$out/kstep" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" -- python tools/coop_time.py ted 20 512 fused
 tools/prof_call.sh "$out/coop" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU FETCH_SIZE WRITE_SIZE" -- python tools/coop_time.py beat 20 32 coop
+tools/prof_call.sh "$out/coop2_ted64" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU FETCH_SIZE WRITE_SIZE" -- python tools/coop_time.py ted 20 64 coop
 # the one-pass-per-workgroup kernel: one workgroup per CU (B = 128) and two (B = 256); GRBM_GUI_ACTIVE / 8 / kernel time = the clock the chip held
 tools/prof_call.sh "$out/pass128" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY FETCH_SIZE WRITE_SIZE" -- python tools/coop_time.py ted 20 128 pass
 tools/prof_call.sh "$out/pass256" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY FETCH_SIZE WRITE_SIZE" -- python tools/coop_time.py ted 20 256 pass

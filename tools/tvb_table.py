@@ -6,10 +6,10 @@ import re
 import sys
 
 src, dst, title = sys.argv[1], sys.argv[2], sys.argv[3]
-FAM = {"coop": "sample-split", "batch": "batch-level", "pass": "one-pass-per-workgroup", "fused": "fused"}
+FAM = {"coop8": "sample-split x8", "coop4": "sample-split x4", "coop2": "sample-split x2", "coop": "sample-split", "batch": "batch-level", "pass": "one-pass-per-workgroup", "fused": "fused"}
 NAMES = {0: "fused", 1: "batch-level", 2: "sample-split", 3: "one-pass-per-workgroup"}
 out = [f"# {title}: step time vs batch, by kernel family (MI355X, 30-step DDPM, CFG 1.5, Philox noise, hipGraph replay)", "",
-       "`python tools/coop_time.py <ds> 30 <batches> coop,batch,pass,fused,auto` in the round's final measurement set (one box, one run; ms per step | pose-frames/s",
+       "`python tools/coop_time.py <ds> 30 <batches> coop8,coop4,coop2,batch,pass,fused,auto` (sample-split with 8 / 4 / 2 slice workgroups per (clip, CFG pass)) in the round's final measurement set (one box, one run; ms per step | pose-frames/s",
        "extrapolated to a 1000-step call = B * 34 / ms).  `auto` = the plan `plan_steps` (ls_api.cpp) makes from its step-time model; the last column",
        "says which pieces it ran: family, then `+ n clips on family` for the second / third piece.  one-pass-per-workgroup = `k_pass`: 8-wave",
        "workgroups, one per CU, while the grid fits the chip once (B <= 128), 4-wave workgroups, two per CU, beyond.", ""]
@@ -22,14 +22,15 @@ for ds, fname in (("TED (S = 35, J*F = 27)", "tvb_ted.txt"), ("BEAT (S = 36, J*F
         m = re.match(r"(\w+)\s+B=\s*(\d+)\s+([\d.]+) ms/step\s+(\d+) frames/s\s+path=(\d)(.*)", line)
         if m:
             rows.setdefault(int(m.group(2)), {})[m.group(1)] = (float(m.group(3)), int(m.group(4)), int(m.group(5)), m.group(6).strip())
-    out += [f"## {ds}", "", "| B | " + " | ".join(f"{FAM[f]} ms | frames/s" for f in FAM) + " | best family | `auto` ms | frames/s | what `auto` ran |",
-            "|---|" + "---|" * (2 * len(FAM) + 4)]
+    fams = [f for f in FAM if any(f in r for r in rows.values())]
+    out += [f"## {ds}", "", "| B | " + " | ".join(f"{FAM[f]} ms | frames/s" for f in fams) + " | best family | `auto` ms | frames/s | what `auto` ran |",
+            "|---|" + "---|" * (2 * len(fams) + 4)]
     for B in sorted(rows):
         r = rows[B]
         cells = []
-        for f in FAM:
+        for f in fams:
             cells += [f"{r[f][0]:.4f}", str(r[f][1])] if f in r else ["", ""]
-        best = min((f for f in FAM if f in r), key=lambda f: r[f][0], default=None)
+        best = min((f for f in fams if f in r), key=lambda f: r[f][0], default=None)
         a = r.get("auto")
         what = ""
         if a:
