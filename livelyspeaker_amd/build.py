@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libls_hip.so")
-SOURCES = ["ls_api.cpp", "ls_torch_rng.cpp", "ls_sag_api.cpp", "ls_step.hip", "ls_step_beat.hip", "ls_coop.hip", "ls_pass.hip", "ls_long.hip", "ls_prepare.hip", "ls_sag.hip", "ls_post.hip", "ls_conv.hip", "ls_train_api.cpp", "ls_gemm.hip", "ls_train_kernels.hip", "ls_train_bwd.hip", "ls_eval.hip"]
+SOURCES = ["ls_api.cpp", "ls_torch_rng.cpp", "ls_sag_api.cpp", "ls_step.hip", "ls_step_beat.hip", "ls_coop.hip", "ls_pass.hip", "ls_mix.hip", "ls_long.hip", "ls_prepare.hip", "ls_sag.hip", "ls_post.hip", "ls_conv.hip", "ls_train_api.cpp", "ls_gemm.hip", "ls_train_kernels.hip", "ls_train_bwd.hip", "ls_eval.hip"]
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "ls_hip.h")]
 STAMP = LIB + ".srchash"          # hash of the sources the library was built from (travels with it; git-ignored)
 

@@ -95,6 +95,8 @@ struct ls_handle {
     int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
     DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_wcf, lw_bcf, lw_wsum, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
+    DevBuf mx_wtok, mx_wch, mx_xg, mx_gran;             // long-sequence mixer kernel (ls_mix_kernel.h): operand images, exchange workspace, granules
+    int mix_cap = 0;                                    // (sample, pass) groups per mixer launch; 0: the model has no such kernel (or ls_set_path(2) asked for the batch-level kernels)
     DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_part1, lx_part2, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -542,6 +544,28 @@ int build_long_weights(ls_handle* h) {
         h->lw_wtp.release();
     }
     UP(lw_wt, wt); UP(lw_bt, bt); UP(lw_wc, wc); UP(lw_bc, bc); UP(ln1a, l1a); UP(ln1b, l1b); UP(ln2a, l2a); UP(ln2b, l2b);
+    if (!h->fused && mix_supports(S)) {
+        // operand images of the one-launch mixer (ls_mix_kernel.h).  wtok[l][q][mt][lane][e] = Wt[16 mt + s16][16 q + 4 e + g] (zero beyond S):
+        // the four lane groups of an MFMA k step read four CONSECUTIVE rows of the LDS operand; wch[l][gb][q][lane][j] = W'[16 gb + s16][16 q + 4 g + j]
+        std::vector<float> wtk((size_t)L * 100 * 256, 0.f), wch((size_t)L * D * D);
+        for (int l = 0; l < L; ++l) {
+            for (int q = 0; q < 10; ++q)
+                for (int mt = 0; mt < 10; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 16 * mt + (lane & 15), k = 16 * q + 4 * e + (lane >> 4);
+                            if (r < S && k < S) wtk[(size_t)l * 25600 + (((size_t)q * 10 + mt) * 64 + lane) * 4 + e] = wt[((size_t)l * S + r) * S + k];
+                        }
+            for (int gb = 0; gb < 32; ++gb)
+                for (int q = 0; q < 32; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int n = 16 * gb + (lane & 15), k = 16 * q + 4 * (lane >> 4) + j;
+                            wch[(size_t)l * D * D + (((size_t)gb * 32 + q) * 64 + lane) * 4 + j] = wc[((size_t)l * D + n) * D + k] * l2a[(size_t)l * D + k];
+                        }
+        }
+        UP(mx_wtok, wtk); UP(mx_wch, wch);
+    }
     if (S <= 160) {     // fused form: LayerNorm 2 folded around the channel-mixing product (ls_long.hip): W' = W diag(alpha2), bias' = b + W beta2,
                         // wsum[n] = sum_k W'[n][k] (the row's mean enters the epilogue as  - mean * wsum)
         std::vector<float> wcf((size_t)L * D * D), bcf((size_t)L * D), wsum((size_t)L * D);
@@ -710,6 +734,12 @@ hipError_t run_long(ls_handle* h, const StepArgs& s, int first, int n, hipStream
     a.winx = h->lw_winx.f(); a.ln1a = h->ln1a.f(); a.ln1b = h->ln1b.f(); a.ln2a = h->ln2a.f(); a.ln2b = h->ln2b.f();
     a.wt = h->lw_wt.f(); a.wtp = h->lw_wtp.f(); a.part1 = h->lx_part1.f(); a.part2 = h->lx_part2.f(); a.wcf = h->lw_wcf.f(); a.bcf = h->lw_bcf.f(); a.wsum = h->lw_wsum.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
     a.xproj = h->lx_proj.f(); a.xpad = h->lx_xpad.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
+    if (h->mix_cap > 0 && first == 0 && n == h->B && s.temb_stride == 0) {     // the one-launch mixer: whole prepared batch, uniform timestep (sampling)
+        a.mix_cap = h->mix_cap; a.mix_wtok = h->mx_wtok.f(); a.mix_wch = h->mx_wch.f(); a.mix_xg = h->mx_xg.f();
+        a.mix_gran = static_cast<unsigned long long*>(h->mx_gran.p); a.mix_err = static_cast<unsigned*>(h->co_err.p);
+        a.mix_epoch0 = (h->coop_launches + 1) * kCoopEpochStride;
+        h->coop_launches += (unsigned)((2 * n + h->mix_cap - 1) / h->mix_cap);
+    }
     a.sampler = s.sampler; a.t_nonzero = s.t_nonzero; a.clip_denoised = s.clip_denoised;
     a.c0 = s.c0; a.c1 = s.c1; a.c2 = s.c2; a.c3 = s.c3; a.c4 = s.c4;
     return launch_step_long(a, st);
@@ -926,6 +956,10 @@ void decide_path(ls_handle* h) {
 
 // zero the granule / flag words of the sample-split kernel (stream-ordered: a memset node when captured) and restart the epochs
 hipError_t coop_reset(ls_handle* h, hipStream_t st) {
+    if (h->mix_cap > 0 && h->mx_gran.p) {
+        h->coop_launches = 0;
+        return hipMemsetAsync(h->mx_gran.p, 0, h->mx_gran.bytes, st);
+    }
     if (seg_n(h, 2) == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(h->co_gran.p, 0, h->co_gran.bytes, st);
     if (e == hipSuccess) e = hipMemsetAsync(h->co_flag.p, 0, h->co_flag.bytes, st);
@@ -958,7 +992,7 @@ int advance_tags(ls_handle* h, hipStream_t st) {
 // after a stream synchronisation: did a hand-off spin of the sample-split kernel run out?  (Never observed; a result computed past a
 // timeout is garbage, so the call fails loudly.)
 int coop_check(ls_handle* h) {
-    if (seg_n(h, 2) == 0) return LS_OK;
+    if (seg_n(h, 2) == 0 && h->mix_cap == 0) return LS_OK;
     unsigned v = 0;
     HIPCHK(h, hipMemcpy(&v, h->co_err.p, sizeof v, hipMemcpyDeviceToHost));
     if (!v) return LS_OK;
@@ -1192,6 +1226,12 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     }
     e = init_step_kernels();
     if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "hipFuncSetAttribute(step kernel LDS): %s", hipGetErrorString(e)); }
+    if (!h->fused && mix_supports(cfg->nframes + cfg->n_prefix_tokens)) {
+        e = init_mix_kernels();
+        if (e == hipSuccess) e = h->co_err.ensure(sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemsetAsync(h->co_err.p, 0, sizeof(unsigned), h->stream);
+        if (e != hipSuccess) { delete h; return fail(nullptr, LS_EHIP, "long-sequence mixer kernel setup: %s", hipGetErrorString(e)); }
+    }
     if (h->fused) {         // sample-split kernel: LDS opt-in and one launch's worth of exchange workspaces (independent of the batch)
         e = init_coop_kernels();
         if (e == hipSuccess) e = init_pass_kernels();
@@ -1226,7 +1266,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt, &h->wtail, &h->wtok1_hi_img, &h->wtok1_lo_img};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->mx_wtok, &h->mx_wch, &h->mx_xg, &h->mx_gran, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt, &h->wtail, &h->wtok1_hi_img, &h->wtok1_lo_img};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -1484,6 +1524,24 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
               HIPCHK(h, hipMemsetAsync(h->lx_part1.p, 0, h->lx_part1.bytes, st)); HIPCHK(h, hipMemsetAsync(h->lx_part2.p, 0, h->lx_part2.bytes, st));
               free_graph(h); } }
         if (old[0] != h->lx_proj.p || old[1] != h->lx_X.p || old[2] != h->lx_U.p || old[3] != h->lx_OUT.p || old[4] != h->lx_xpad.p) free_graph(h);
+        // the one-launch mixer (a model whose token count it supports, unless ls_set_path(2) asked for the batch-level kernels): as many
+        // (sample, pass) groups per launch as fit the chip with four workgroups each, a multiple of eight (the grid is dealt in sets of eight groups)
+        const int was_cap = h->mix_cap;
+        h->mix_cap = 0;
+        if (!h->fused && h->mx_wch.p && h->path_mode != 2 && 2 * h->cfg.layers + 2 <= (int)kCoopEpochStride) {
+            int cap = h->n_cu / kMixSlices / 8 * 8;
+            const int need = (int)((2 * nlo + 7) / 8 * 8);
+            if (cap > need) cap = need;
+            if (cap >= 8) {
+                const void* o[2] = {h->mx_xg.p, h->mx_gran.p};
+                HIPCHK(h, h->mx_xg.ensure((size_t)cap * 32 * kMixRows * 16 * sizeof(float)));
+                HIPCHK(h, h->mx_gran.ensure((size_t)cap * 2 * kMixRows * kMixSlices * 2 * sizeof(unsigned long long)));
+                if (o[0] != h->mx_xg.p) HIPCHK(h, hipMemsetAsync(h->mx_xg.p, 0, h->mx_xg.bytes, st));       // rows a pass never writes are pulled into LDS (finite, never used)
+                if (o[0] != h->mx_xg.p || o[1] != h->mx_gran.p) free_graph(h);
+                h->mix_cap = cap;
+            }
+        }
+        if (was_cap != h->mix_cap) free_graph(h);
     }
     HIPCHK(h, hipEventRecord(h->ev[5], st));
     if (wait) {

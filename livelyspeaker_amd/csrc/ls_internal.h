@@ -146,10 +146,40 @@ struct LongStepArgs {
     float* xpad;                           // [B*T rounded up to 128][JFP]  x_t with zero pad columns / rows (operand of the projection)
     float* X; float* U;                    // [2*B*S][512]
     float* OUT;                            // [2*B*S][ldo]
+    // the eight blocks in one launch per resident set of groups (ls_mix_kernel.h) instead of sixteen batch-level launches: when mix_cap > 0
+    const float* mix_wtok; const float* mix_wch;   // per-lane operand images (MixArgs)
+    float* mix_xg; unsigned long long* mix_gran; unsigned* mix_err;
+    unsigned mix_epoch0;                   // tag base of this step's first mixer launch (one kCoopEpochStride per launch)
+    int mix_cap;                           // (sample, pass) groups per launch (4 workgroups each, all resident); 0 = batch-level kernels
     int sampler, t_nonzero, clip_denoised;
     float c0, c1, c2, c3, c4;
 };
 hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st);
+
+constexpr int kMixSlices = 4;               // slice workgroups of a (sample, pass) group
+constexpr int kMixRows = 160;               // padded rows (ten 16-row tiles)
+// long-sequence mixer kernel (ls_mix.hip): the eight MLPblocks of up to 160 tokens in one launch, four slice workgroups per (sample, pass)
+struct MixArgs {
+    const float* x_in;          // [groups][S][512] token sequences entering block 0 (group = launch-local (pass, sample) index g0 + ...)
+    float* x_out;               // same layout, after block L - 1
+    const float* temb;          // [512] timestep embedding row (the timestep is uniform over the batch in sampling)
+    const float* ln1a; const float* ln1b;     // [L][512]
+    const float* wtok_img;      // [L][10 q][10 mt][64][4]: Wt[16 mt + s16][16 q + 4 e + g], zero beyond S
+    const float* btok;          // [L][S]
+    const float* wch_img;       // [L][32 gb][32 q][64][4]: W'[16 gb + s16][16 q + 4 g + j], W' = W diag(alpha2)
+    const float* bch; const float* wsum;      // [L][512] folded bias, row sums of W'
+    float* xg;                  // [groups][32 k blocks][160][16] exchange: rows entering channel mixing, centred on the LayerNorm-1 mean
+    unsigned long long* gran;   // [groups][2 areas][160 rows][4 slices][2] {tag, value} granules
+    unsigned* err;              // set non-zero by a workgroup whose bounded spin ran out
+    const CallParams* call;
+    unsigned epoch;             // tag base of this launch
+    int ngroups, layers;
+    long long group_stride;     // floats between groups in x_in / x_out (S * 512)
+};
+
+bool mix_supports(int S);
+hipError_t init_mix_kernels();
+hipError_t launch_mix(int S, const MixArgs& a, hipStream_t st);
 
 // sample-split step kernel for small batches (ls_coop.hip): 16 workgroups per sample (2 passes x 8 channel slices of 4 waves)
 constexpr int kCoopMaxGroups = 64;     // (sample, pass) groups of one launch: 512 workgroups = two per CU, all resident at once

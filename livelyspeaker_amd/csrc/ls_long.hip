@@ -258,12 +258,26 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     // fused token mixing needs S <= 160 (accumulators for ten token tiles, the operand slab in LDS); longer sequences take the batched-GEMM form.
     // Token axis padded to 48 (the reference's 35 / 36 tokens: three tiles) or 160; a.tokpad says which image a.wtp holds.
     const int kTokPad = a.tokpad;
-    const bool fused_tok = a.wtp != nullptr && a.S <= kTokPad && (kTokPad == 48 || kTokPad == 160);
+    const bool use_mix = a.mix_cap > 0;
+    const bool fused_tok = !use_mix && a.wtp != nullptr && a.S <= kTokPad && (kTokPad == 48 || kTokPad == 160);
     hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a, fused_tok ? 1 : 0);
+    if (use_mix) {
+        // the eight blocks: one launch per resident set of (pass, sample) groups, in place on X (a workgroup reads and writes its own rows x channels only)
+        const int groups = 2 * a.B;
+        unsigned epoch = a.mix_epoch0;
+        for (int g0 = 0; g0 < groups; g0 += a.mix_cap, epoch += kCoopEpochStride) {
+            MixArgs m{};
+            m.x_in = a.X + (size_t)g0 * a.S * D; m.x_out = a.X + (size_t)g0 * a.S * D;
+            m.temb = a.temb; m.ln1a = a.ln1a; m.ln1b = a.ln1b; m.wtok_img = a.mix_wtok; m.btok = a.bt; m.wch_img = a.mix_wch; m.bch = a.bcf; m.wsum = a.wsum;
+            m.xg = a.mix_xg; m.gran = a.mix_gran; m.err = a.mix_err; m.call = a.call; m.epoch = epoch;
+            m.ngroups = groups - g0 < a.mix_cap ? groups - g0 : a.mix_cap; m.layers = a.layers; m.group_stride = (long long)a.S * D;
+            if ((e = launch_mix(a.S, m, st)) != hipSuccess) return e;
+        }
+    }
     float* Xc = a.X;                 // current activations; the fused form ping-pongs between X and U (an even number of layers ends in X)
     float* Xo = a.U;
     const int mrows = (rows + 127) / 128 * 128;         // whole GEMM tiles: the pad rows exist in the buffers and are never read back
-    for (int l = 0; l < a.layers; ++l) {
+    for (int l = 0; l < (use_mix ? 0 : a.layers); ++l) {
         if (fused_tok) {
             if (kTokPad == 48)
                 hipLaunchKernelGGL((k_long_tokmix<48>), dim3(2 * a.B, 8), dim3(256), 0, st, Xc, a.part1, a.part2, a.wtp + (size_t)l * 48 * 48,
@@ -299,7 +313,7 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
         if ((e = launch_layernorm512(a.X, nullptr, 0, a.ln2a + (size_t)l * D, a.ln2b + (size_t)l * D, a.U, rows, st)) != hipSuccess) return e;
         if ((e = launch_gemm_nt(a.U, D, a.wc + (size_t)l * D * D, D, a.bc + (size_t)l * D, a.X, D, a.X, D, rows, D, D, 1, st)) != hipSuccess) return e;
     }
-    if (fused_tok && Xc != a.X) return hipErrorInvalidValue;              // odd layer counts would end in the other buffer
+    if (!use_mix && fused_tok && Xc != a.X) return hipErrorInvalidValue;              // odd layer counts would end in the other buffer
     // poseFinal over whole 128-row tiles as well (N = JF padded to 128s with zero weight rows): 280 rows (4 clips) as they are would
     // take the GEMM's general staging path, 64 us instead of 8
     if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, mrows, a.ldo, D, 0, st)) != hipSuccess) return e;

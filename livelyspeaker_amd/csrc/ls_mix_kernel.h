@@ -1,0 +1,338 @@
+// The eight MLPblocks of a LONG sequence (up to 160 tokens: BASELINE configs[4] "as worded", 150 frames + 2 prefix tokens) in ONE launch,
+// sample-split like ls_coop_kernel.h: a (sample, CFG pass) group is spread over FOUR workgroups of 128 channels, one per CU, which exchange
+// LayerNorm partials and rows inside the launch.  Replaces sixteen launches per step of the batch-level path (ls_long.hip: a token-mixing
+// kernel + a channel-mixing GEMM per layer); the input projection / assembly in front and poseFinal / the sampler update behind stay the
+// batch-level kernels they were.  Same reference arithmetic:
+//   TransMLP / MLPblock / LN_spatial    scripts/model/mlp_module.py:21-91   (per-sample independence, :67-91, is what makes the split legal)
+// (the reference itself cannot run this shape: token mixing fixes S, scripts_beat/model/RAG.py:56 -- synthetic, self-pinned to oracle/).
+//
+// Mapping:
+//   * workgroup = (group, slice c of 128 channels), 8 waves.  Wave (w, h): channel blocks 2 w, 2 w + 1 of the slice (32 channels, MFMA C/D
+//     layout: lane (s16, g) holds channels 4 g .. 4 g + 3 of a block for row s16 of a tile), row tiles 5 h .. 5 h + 4 of the ten -- for
+//     EVERYTHING: residual stream, LayerNorms, token mixing, channel mixing (no split of k between the halves, no partial-sum swap).
+//   * token mixing  D[channel][row] = sum_r' u[r'][channel] Wt[row][r']: the operand u = LN1(x) of the slice's own channels, all rows, in LDS
+//     [160][144]; the Conv1d weights stream from an L2-resident per-lane image, one 16-row k block ahead.
+//   * channel mixing contracts over all 512 channels = 32 k blocks of 16, but 160 rows x 512 channels do not fit LDS: the k blocks pass
+//     through an 8-slot LDS ring [slot][160 rows][16].  The slice's own eight blocks are written into the ring from registers; the other
+//     24 are pulled global -> LDS by LDS-DMA from the exchange buffer, one block per iteration into the slot freed one iteration earlier
+//     (seven blocks = ~15 k clocks ahead of their use).  One workgroup barrier per k block: it says both "block n has landed for every wave"
+//     and "everyone is done with block n - 1".  VMEM returns in issue order on gfx950, so the weight fragments are requested FIVE blocks
+//     ahead: a wait for a fragment then only covers pulls that are at least five iterations old.  LayerNorm 2 is folded around the product
+//      with the rows centred on the LayerNorm-1 mean.
+//   * hand-offs: the protocol of ls_coop_kernel.h (write-through payload, every wave drains, barrier, {tag, value} granules that double as
+//     ready flags, bounded spins, tags unique per launch / sync point / call).  The four slices of a group sit on ONE XCD when the grid is
+//     dealt round-robin (blockIdx = (group / 8 * 4 + slice) * 8 + group % 8) -- speed only.
+#pragma once
+#include "ls_coop_kernel.h"
+
+#ifndef LS_MIX_ABL
+#define LS_MIX_ABL 0            // A/B builds only (tools/ab_variants.py): 1 no channel-mix MFMAs, 2 no token-mix MFMAs, 4 no ring refills, 8 no k-block loop -- wrong results
+#endif
+
+namespace ls {
+
+constexpr int kMixThreads = 512;
+constexpr int kMixUS = 144;                 // LDS row stride of the token-mix operand [160][128]: = 16 mod 32 (the four lane groups read four consecutive rows), 16-byte aligned rows
+constexpr int kMixSlots = 8;                // ring slots of [160][16] floats
+constexpr int kMixPFW = 5;                  // k blocks the weight fragments are requested ahead
+// LDS: pst [4][160] f2 | stat [160] f2 | U: max(token-mix operand 160 x 144, ring 8 x 160 x 16)
+constexpr int kMixLdsFloats = 2 * 4 * kMixRows + 2 * kMixRows + kMixRows * kMixUS;
+static_assert(kMixSlots * kMixRows * 16 <= kMixRows * kMixUS, "the ring overlays the token-mix operand");
+
+template <int S>
+__global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
+    constexpr int NT = (S + 15) / 16, TH = NT / 2, NS = kMixSlices, NCB = 2, KB = 8, RP = kMixRows, US = kMixUS;
+    static_assert(NT == 10 && NT * 16 == RP, "ten row tiles (S in 145 .. 160)");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f2* pst = reinterpret_cast<f2*>(smem);                 // [4 waves of a half... both halves own disjoint rows][160] (mean, M2) over the wave's 32 channels
+    f2* stat = pst + 4 * RP;                               // [160] (mean, rstd) over all 512 channels
+    float* U = smem + 2 * 4 * RP + 2 * RP;                 // token-mix operand [160][144] | ring [8][160][16]
+
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 3, h = wv >> 2;
+    const int bid = blockIdx.x;
+    const int c = (bid >> 3) & (NS - 1);                   // slice
+    const int pg = (bid >> 3) / NS * 8 + (bid & 7);        // launch-local group: its four slices share bid % 8, i.e. one XCD under round-robin placement
+    if (pg >= a.ngroups) return;
+    int s16 = lane & 15, g = lane >> 4;
+    auto fresh = [&]() { asm volatile("" : "+v"(lane)); s16 = lane & 15; g = lane >> 4; };
+    auto gblk = [&](int cb) { return KB * c + NCB * w + cb; };                // 16-channel block over all 512 channels
+    auto chw = [&](int cb) { return 16 * gblk(cb) + 4 * g; };
+    auto rowi = [&](int i) { return 16 * (TH * h + i) + s16; };               // this lane's row of its i-th tile
+    auto live = [&](int i) { return rowi(i) < S; };
+
+    const float* xin = a.x_in + (size_t)pg * a.group_stride;
+    float* xout = a.x_out + (size_t)pg * a.group_stride;
+    float* xg = a.xg + (size_t)pg * 32 * RP * 16;
+    unsigned long long* gran = a.gran + (size_t)pg * 2 * RP * NS * 2;
+    const wrsrc_t xrs = uniform_rsrc(xg);
+    const unsigned ep = a.epoch + (a.call ? a.call->tag_base : 0u);
+    unsigned spin_bad = 0;
+    const wrsrc_t rs_ln1a = wrsrc(a.ln1a), rs_ln1b = wrsrc(a.ln1b), rs_wtok = wrsrc(a.wtok_img), rs_wch = wrsrc(a.wch_img), rs_bch = wrsrc(a.bch),
+                  rs_wsum = wrsrc(a.wsum);
+    const gfp p_btok = g1(a.btok);
+
+    f4 X[NCB][TH];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+            X[cb][i] = live(i) ? *reinterpret_cast<const f4*>(xin + (size_t)rowi(i) * kD + chw(cb)) : (f4){0.f, 0.f, 0.f, 0.f};
+    f4 temb4[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) temb4[cb] = *reinterpret_cast<const f4*>(a.temb + chw(cb));
+
+    // (mean, M2) of the lane's 8 channels of one row, merged over the 4 lane groups: the wave's 32 channels
+    auto lane_part = [&](f4 v0, f4 v1, float& m, float& m2) {
+        const float ma0 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) * 0.25f, mb0 = ((v1[0] + v1[1]) + (v1[2] + v1[3])) * 0.25f;
+        const f4 d0 = v0 - (f4){ma0, ma0, ma0, ma0}, d1 = v1 - (f4){mb0, mb0, mb0, mb0};
+        const float qa0 = (d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3]);
+        const float qb0 = (d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]);
+        const float dd = mb0 - ma0;
+        m2 = (qa0 + qb0) + dd * dd * 2.0f;                   // equal counts n: M2 = qa + qb + d^2 n / 2
+        m = 0.5f * (ma0 + mb0);
+        {
+            float ma, mb, qa, qb;
+            xor16_pair(m, ma, mb); xor16_pair(m2, qa, qb);
+            const float d = mb - ma;
+            m2 = (qa + qb) + d * d * 4.0f;
+            m = 0.5f * (ma + mb);
+        }
+        {
+            float ma, mb, qa, qb;
+            xor32_pair(m, ma, mb); xor32_pair(m2, qa, qb);
+            const float d = mb - ma;
+            m2 = (qa + qb) + d * d * 8.0f;
+            m = 0.5f * (ma + mb);
+        }
+    };
+    // this slice's (mean, M2) of every row -> granule area `area`; `payload`: write-through stores of this workgroup are drained first
+    auto ln_publish = [&](int area, unsigned tag, bool payload) {
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            float m, m2;
+            lane_part(X[0][i], X[1][i], m, m2);
+            if (g == 0) pst[w * RP + rowi(i)] = (f2){m, m2};
+        }
+        if (payload) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (tid < S) {
+            f2 pw[4];
+            float ms = 0.f, qs = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) { pw[ww] = pst[ww * RP + tid]; ms += pw[ww].x; qs += pw[ww].y; }
+            const float mt = ms * 0.25f;
+            float dd = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
+            unsigned long long* gp = gran + (size_t)area * RP * NS * 2 + ((size_t)tid * NS + c) * 2;
+            gran_store(gp, tag, mt);
+            gran_store(gp + 1, tag, qs + 32.0f * dd);
+        }
+    };
+    // all slices' partials of every row -> stat[row] = (mean, rstd); pad rows get (0, 0)
+    auto ln_gather = [&](int area, unsigned tag) {
+        const unsigned long long* ga = gran + (size_t)area * RP * NS * 2;
+#pragma unroll 1
+        for (int r0 = 0; r0 < RP; r0 += kMixThreads / NS) {
+            const int sl = tid & (NS - 1), rr = r0 + tid / NS, r = min(rr, S - 1);
+            if (r0 + (wv * 64) / NS < S) {                   // waves whose rows exist poll (wave-uniform)
+                const unsigned long long* g0 = ga + ((size_t)r * NS + sl) * 2;
+                unsigned long long v0, v1;
+                for (unsigned spins = 0;; ++spins) {
+                    v0 = gran_load(g0); v1 = gran_load(g0 + 1);
+                    const bool ok = (unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag;
+                    if (__all(ok)) break;
+                    if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const float pm = __uint_as_float((unsigned)v0), pq = __uint_as_float((unsigned)v1);
+                float sm = pm;
+                sm = dpp_add<0xB1>(sm); sm = dpp_add<0x4E>(sm);
+                const float mu = sm * 0.25f, d = pm - mu;
+                float q = fmaf(128.0f * d, d, pq);
+                q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q);
+                if (sl == 0 && rr < RP) stat[rr] = rr < S ? (f2){mu, rsqrtf(q * (1.0f / kD) + 1e-5f)} : (f2){0.f, 0.f};
+            } else if (sl == 0 && rr < RP) {
+                stat[rr] = (f2){0.f, 0.f};
+            }
+        }
+        lds_barrier();
+    };
+
+    for (int l = 0; l < a.layers; ++l) {
+        fresh();
+        // x = x + emb  (mlp_module.py:68-69)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int i = 0; i < TH; ++i) if (live(i)) X[cb][i] += temb4[cb];
+        // ---- block1: LN -> token mixing -> SiLU -> residual ---------------------------------------
+        ln_publish(0, ep + 2 * l + 1, false);
+        f4 al1[NCB], be1[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) { al1[cb] = wload4(rs_ln1a, chw(cb) * 4, l * kD * 4); be1[cb] = wload4(rs_ln1b, chw(cb) * 4, l * kD * 4); }
+        float btb[TH];
+#pragma unroll
+        for (int i = 0; i < TH; ++i) btb[i] = p_btok[l * S + min(rowi(i), S - 1)];
+        // token-mix weights of the first k block, in flight during the exchange: wtok_img[l][q][mt][lane][e]
+        const int tsb = l * NT * NT * 1024;
+        f4 Bn[TH];
+#pragma unroll
+        for (int i = 0; i < TH; ++i) Bn[i] = wload4(rs_wtok, lane * 16, tsb + (0 * NT + TH * h + i) * 1024);
+        ln_gather(0, ep + 2 * l + 1);
+        fresh();
+        float mu1[TH];
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            const f2 st = stat[rowi(i)];
+            mu1[i] = st.x;
+            const float nm = -st.x * st.y;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                f4 u = __builtin_elementwise_fma(X[cb][i], (f4){st.y, st.y, st.y, st.y}, (f4){nm, nm, nm, nm});
+                u = __builtin_elementwise_fma(u, al1[cb], be1[cb]);
+                *reinterpret_cast<f4*>(&U[rowi(i) * US + 16 * (NCB * w + cb) + 4 * g]) = u;     // pad rows: beta (finite; they meet zero weights)
+            }
+        }
+        lds_barrier();
+        fresh();
+        {
+            f4 acc[NCB][TH];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < TH; ++i) acc[cb][i] = (f4){btb[i], btb[i], btb[i], btb[i]};
+#pragma unroll 1
+            for (int q = 0; q < NT; ++q) {
+                f4 Bv[TH];
+#pragma unroll
+                for (int i = 0; i < TH; ++i) Bv[i] = Bn[i];
+                const int qn = min(q + 1, NT - 1);
+#pragma unroll
+                for (int i = 0; i < TH; ++i) Bn[i] = wload4(rs_wtok, lane * 16, tsb + (qn * NT + TH * h + i) * 1024);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float av[NCB];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) av[cb] = U[(16 * q + 4 * e + g) * US + 16 * (NCB * w + cb) + s16];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int i = 0; i < TH; ++i) { if (!(LS_MIX_ABL & 2)) acc[cb][i] = MFMA(av[cb], Bv[i][e], acc[cb][i]); else acc[cb][i][e] += av[cb] * Bv[i][e]; }
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < TH; ++i) if (live(i)) X[cb][i] = silu_acc4(acc[cb][i], X[cb][i]);
+        }
+        fresh();
+        // ---- block2: LN -> channel mixing -> SiLU -> residual -------------------------------------
+        const unsigned tag2 = ep + 2 * l + 2;
+        {
+            // centred rows: write-through to the other slices (exchange order [k block][row][16]); the LDS copy goes into the ring once every wave
+            // is past its token-mix reads of the overlay (the barrier inside ln_publish)
+            f4 cen[NCB][TH];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < TH; ++i) {
+                    cen[cb][i] = live(i) ? X[cb][i] - (f4){mu1[i], mu1[i], mu1[i], mu1[i]} : (f4){0.f, 0.f, 0.f, 0.f};
+                    st_sc1(cen[cb][i], xrs, ((gblk(cb) * RP + rowi(i)) * 16 + 4 * g) * 4);
+                }
+            ln_publish(1, tag2, true);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < TH; ++i) *reinterpret_cast<f4*>(&U[((NCB * w + cb) * RP + rowi(i)) * 16 + 4 * g]) = cen[cb][i];     // slot = local k block
+        }
+        fresh();
+        {
+            f4 bc[NCB], ws4[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) { bc[cb] = wload4(rs_bch, chw(cb) * 4, l * kD * 4); ws4[cb] = wload4(rs_wsum, chw(cb) * 4, l * kD * 4); }
+            f4 acc[NCB][TH];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < TH; ++i) acc[cb][i] = (f4){0.f, 0.f, 0.f, 0.f};
+            // k block n of this wave's order: the slice's own eight first, then the other slices in ring order
+            auto qof = [&](int n) { return ((c + (n >> 3)) & (NS - 1)) * KB + (n & 7); };
+            auto wsb = [&](int cb) { return (l * 32 + gblk(cb)) * 32 * 1024; };
+            constexpr int PFW = kMixPFW;
+            f4 An[PFW][NCB];
+#pragma unroll
+            for (int k = 0; k < PFW; ++k)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) An[k][cb] = wload4(rs_wch, lane * 16, wsb(cb) + qof(k) * 1024);
+            const unsigned long long* ga = gran + (size_t)RP * NS * 2;          // area 1: row 0's mean granule of slice s = its rows are published
+            // one ring refill: k block n -> slot n % 8; ten 1 KiB chunks, wave wv takes chunk wv and chunk 8 + (wv & 1) (the doubled pulls of
+            // chunks 8 and 9 write the same bytes: every wave issues exactly two)
+            auto refill = [&](int n) {
+                const int q = qof(n), slot = n & (kMixSlots - 1);
+                dma_sc1(xrs, U + slot * RP * 16 + wv * 256, lane * 16, (q * RP * 16 + wv * 256) * 4);
+                dma_sc1(xrs, U + slot * RP * 16 + (8 + (wv & 1)) * 256, lane * 16, (q * RP * 16 + (8 + (wv & 1)) * 256) * 4);
+            };
+            typedef const __attribute__((address_space(3))) f4* ldsp4;
+#pragma unroll 1
+            for (int t5 = 0; t5 < 32 / PFW + 1; ++t5)
+#pragma unroll
+            for (int u = 0; u < PFW; ++u) {
+                const int n = PFW * t5 + u;
+                if (n >= 32 || (LS_MIX_ABL & 8)) break;
+                // block n has landed for every wave / everyone is done with block n - 1
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                lds_barrier();
+                if (n == 4) {
+                    // the other slices' rows: wait for their ready flags once (long up: four own blocks have been multiplied), then fill the four free slots
+                    for (unsigned spins = 0;; ++spins) {
+                        const bool ok = (unsigned)(gran_load(ga + (size_t)(lane & (NS - 1)) * 2) >> 32) == tag2;
+                        if (__all(ok)) break;
+                        if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!(LS_MIX_ABL & 4)) { refill(8); refill(9); refill(10); refill(11); }
+                } else if (n > 4 && n + 7 < 32) {
+                    if (!(LS_MIX_ABL & 4)) refill(n + 7);
+                }
+                if (n == 6) ln_gather(1, tag2);                                 // LayerNorm-2 statistics (their granules came up with the ready flags)
+                const float* ub = U + (n & (kMixSlots - 1)) * RP * 16 + 4 * g;
+                f4 Bv[TH];
+#pragma unroll
+                for (int i = 0; i < TH; ++i) Bv[i] = *(ldsp4)(ub + rowi(i) * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int i = 0; i < TH; ++i) { if (!(LS_MIX_ABL & 1)) acc[cb][i] = MFMA(An[u][cb][j], Bv[i][j], acc[cb][i]); else acc[cb][i][j] += An[u][cb][j] * Bv[i][j]; }
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) An[u][cb] = wload4(rs_wch, lane * 16, wsb(cb) + qof(min(n + PFW, 31)) * 1024);
+            }
+            fresh();
+            // LayerNorm 2 around the product: v = rstd2 * (acc - (mu2 - mu1) wsum) + b'
+#pragma unroll
+            for (int i = 0; i < TH; ++i) {
+                const f2 st = stat[rowi(i)];
+                const float dm = st.x - mu1[i];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const f4 v = (acc[cb][i] - (f4){dm, dm, dm, dm} * ws4[cb]) * (f4){st.y, st.y, st.y, st.y} + bc[cb];
+                    if (live(i)) X[cb][i] = silu_acc4(v, X[cb][i]);
+                }
+            }
+            lds_barrier();              // every wave is past its reads of the ring and of stat before the next layer writes them
+        }
+    }
+    if (spin_bad && lane == 0) atomicOr(a.err, 1u);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+            if (live(i)) *reinterpret_cast<f4*>(xout + (size_t)rowi(i) * kD + chw(cb)) = X[cb][i];
+}
+
+}  // namespace ls

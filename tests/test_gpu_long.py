@@ -131,3 +131,41 @@ def test_long_single_steps_vs_oracle(long_ctx):
         w0 = oracle.cfg_forward(x, np.full((B,), sch.timestep_map[idx]), y, eps[0], eps[1])
         want = orc.p_sample_update(sch, x, w0, idx, noise) if name == "p" else orc.ddim_update(sch, x, w0, idx, noise)
         assert max_abs(x0, w0) < TOL and max_abs(out, want) < TOL, name
+
+
+@pytest.mark.parametrize("B", [3, 8, 32, 40])
+def test_one_launch_mixer_agrees_with_the_batch_level_kernels_and_the_oracle(B):
+    """The eight blocks of the 150-frame model in ONE launch (csrc/ls_mix_kernel.h: four slice workgroups per (sample, pass), k blocks through
+    an LDS ring) against the sixteen batch-level launches it replaces (ls_set_path 2) -- same arithmetic, another summation order -- and, for
+    the first and the last sample, against the CPU oracle on the restated Philox noise.  40 clips = 80 groups: two mixer launches per step."""
+    from livelyspeaker_amd import _lib
+    from oracle import philox_oracle as po
+    from oracle import rag_oracle as orc
+    cfg = synth.BEAT150
+    sd = synth.make_state_dict(cfg)
+    steps, seed, off = 6, 4242 + B, 100
+    y = synth.make_cond(cfg, B)
+    sch = orc.Schedule(steps, "")
+    outs = {}
+    for path in ("auto", "batch"):
+        eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, nframes=cfg.nframes)
+        try:
+            eng.load_state_dict(sd)
+            if path == "batch":
+                eng.set_path("batch")
+            eng.set_schedule(sch)
+            eng.prepare(y)
+            outs[path] = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=off)
+            assert np.array_equal(outs[path], eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=off))       # graph replay, deterministic
+        finally:
+            eng.close()
+    d = max_abs(outs["auto"], outs["batch"])
+    assert np.isfinite(outs["auto"]).all() and 0 < d < 1e-4, d
+    pick = np.array([0, B - 1])
+    oracle = orc.RagOracle(sd, cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, nframes=cfg.nframes)
+    eps, noise = po.step_tapes(seed, off + pick, steps, (cfg.njoints, cfg.nfeats, cfg.nframes))
+    x_T = po.x_init(seed, off + pick, cfg.njoints * cfg.nfeats, cfg.nframes, (cfg.njoints, cfg.nfeats))
+    want = orc.sample_loop(oracle, sch, {k: v[pick] for k, v in y.items()}, x_T, eps, noise)
+    do = max_abs(outs["auto"][pick], want)
+    print(f"150 frames, B = {B}: one-launch mixer vs batch-level kernels {d:.3e}, vs oracle {do:.3e}")
+    assert do < TOL
