@@ -203,7 +203,8 @@ typedef struct ls_timing {
     int32_t tail2_path;
     int32_t n_cus;              /* compute units of the handle's device (hipDeviceProp.multiProcessorCount): what the plans and the
                                    sample-split kernel's residency are derived from */
-    int32_t coop_slices;        /* slice workgroups per (sample, pass) the sample-split piece of the last loop ran with: 8 | 4 | 2 (0: the plan had no such piece) */
+    int32_t coop_slices;        /* slice workgroups per (sample, pass) the sample-split piece of the last loop ran with: 8 | 4 | 2 (0: the plan had no such piece);
+                                   a long-sequence model (nframes != 34, step_path 1): 4 = its eight blocks ran in the one-launch mixer kernel, 0 = as batch-level launches */
 } ls_timing;
 
 int ls_abi_version(void);

@@ -730,6 +730,10 @@ hipError_t run_long(ls_handle* h, const StepArgs& s, int first, int n, hipStream
     a.x_in = s.x_in + ox; a.x_out = sh(s.x_out, ox); a.x0_out = sh(s.x0_out, ox); a.fwd_c = sh(s.fwd_c, ox); a.fwd_u = sh(s.fwd_u, ox);
     a.static_c = s.static_c + os; a.static_u = s.static_u + os; a.z_mu = s.z_mu + od; a.z_std = s.z_std + od; a.emo_tok = sh(s.emo_tok, od); a.scale = sh(s.scale, (size_t)first);
     a.temb = s.temb;
+    a.xpad_ready = s.xpad_ready && first == 0 && n == h->B;
+#ifdef LS_DEBUG
+    a.prof = s.prof; a.prof_wg = s.prof_wg;
+#endif
     a.eps_c = sh(s.eps_c, od); a.eps_u = sh(s.eps_u, od); a.noise = sh(s.noise, s.const_noise ? (size_t)0 : ox); a.const_noise = s.const_noise; a.call = s.call; a.step_id = s.step_id;
     a.winx = h->lw_winx.f(); a.ln1a = h->ln1a.f(); a.ln1b = h->ln1b.f(); a.ln2a = h->ln2a.f(); a.ln2b = h->ln2b.f();
     a.wt = h->lw_wt.f(); a.wtp = h->lw_wtp.f(); a.part1 = h->lx_part1.f(); a.part2 = h->lx_part2.f(); a.wcf = h->lw_wcf.f(); a.bcf = h->lw_bcf.f(); a.wsum = h->lw_wsum.f(); a.bt = h->lw_bt.f(); a.wc = h->lw_wc.f(); a.bc = h->lw_bc.f(); a.wout = h->lw_wout.f(); a.bout = h->bout.f();
@@ -1006,7 +1010,7 @@ void report_path(ls_handle* h, bool pair) {
     h->timing.tail_path = split ? h->seg[1].path : 0;
     h->timing.tail2_samples = split && h->nseg > 2 ? h->seg[2].n : 0;
     h->timing.tail2_path = split && h->nseg > 2 ? h->seg[2].path : 0;
-    h->timing.coop_slices = 0;
+    h->timing.coop_slices = !h->fused && h->mix_cap > 0 ? kMixSlices : 0;      // a long-sequence model: 4 = the one-launch mixer ran the blocks (step_path stays 1)
     if (h->fused && (h->nseg == 1 || split))
         for (int i = 0; i < h->nseg; ++i)
             if (h->seg[i].path == 2) {
@@ -1352,6 +1356,11 @@ int ls_set_path(ls_handle* h, int mode) {
     // device with fewer CUs reach at small batches, pinned to the reference's fixtures at B = 4 / 5 through this selector (tests/test_gpu_pass.py)
     const int waves = mode == 5 ? 4 : 0;
     if (mode == 5) mode = 4;
+    if (mode == 3 && !h->fused && ncb == 0 && mix_supports(h->S)) {
+        // a long-sequence model: mode 3 = its sample-split form, the one-launch mixer (ls_mix_kernel.h), at every batch size
+        if (mode != h->path_mode) { h->path_mode = mode; h->prepared = false; free_graph(h); }
+        return LS_OK;
+    }
     if (mode >= 3 && !h->fused) return fail(h, LS_EUNSUPPORTED, "nframes != %d has neither the sample-split nor the one-pass-per-workgroup kernel", kT);
     if (mode == 3 && h->precision != 0) return fail(h, LS_EUNSUPPORTED, "the sample-split kernel is exact fp32 only");
     if (mode == 3 && 2 * h->cfg.layers + 2 > (int)kCoopEpochStride)
@@ -1528,14 +1537,22 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
         // (sample, pass) groups per launch as fit the chip with four workgroups each, a multiple of eight (the grid is dealt in sets of eight groups)
         const int was_cap = h->mix_cap;
         h->mix_cap = 0;
-        if (!h->fused && h->mx_wch.p && h->path_mode != 2 && 2 * h->cfg.layers + 2 <= (int)kCoopEpochStride) {
+        // Measured on MI355X (profiles/r06_mixer_150_frames.md): a mixer launch costs ~0.50 ms however few of its 64 groups are used, the
+        // batch-level kernels 0.25 ms + ~13-17 us per clip: `auto` (mode 0) takes the mixer when every launch is at least 7/8 full and the batch
+        // is at most three launches (28-32, 60-64, 92-96 clips under CFG); ls_set_path(3) forces it, (2) forces the batch-level kernels.
+        bool want_mix = !h->fused && h->mx_wch.p && h->path_mode != 2 && 2 * h->cfg.layers + 2 <= (int)kCoopEpochStride;
+        if (want_mix && h->path_mode == 0) {
+            const int full = h->n_cu / kMixSlices / 8 * 8, groups = (int)(2 * nlo), last = groups % full;
+            want_mix = full >= 8 && groups <= 3 * full && groups >= full * 7 / 8 && (last == 0 || last >= full * 7 / 8);
+        }
+        if (want_mix) {
             int cap = h->n_cu / kMixSlices / 8 * 8;
             const int need = (int)((2 * nlo + 7) / 8 * 8);
             if (cap > need) cap = need;
             if (cap >= 8) {
                 const void* o[2] = {h->mx_xg.p, h->mx_gran.p};
                 HIPCHK(h, h->mx_xg.ensure((size_t)cap * 32 * kMixRows * 16 * sizeof(float)));
-                HIPCHK(h, h->mx_gran.ensure((size_t)cap * 2 * kMixRows * kMixSlices * 2 * sizeof(unsigned long long)));
+                HIPCHK(h, h->mx_gran.ensure((size_t)cap * (2 * kMixRows + 1) * kMixSlices * 2 * sizeof(unsigned long long)));
                 if (o[0] != h->mx_xg.p) HIPCHK(h, hipMemsetAsync(h->mx_xg.p, 0, h->mx_xg.bytes, st));       // rows a pass never writes are pulled into LDS (finite, never used)
                 if (o[0] != h->mx_xg.p || o[1] != h->mx_gran.p) free_graph(h);
                 h->mix_cap = cap;
@@ -1839,6 +1856,7 @@ int ls_sample(ls_handle* h, const ls_sample_args* a) {
                 continue;
             }
             if (dump_at) s.x0_out = dump_at;
+            s.xpad_ready = k > 0;                      // long-sequence path: the previous step's update kernel wrote this step's padded x_t
             HIPCHK(h, run_step(h, s, B, pair, st));
         }
         return LS_OK;

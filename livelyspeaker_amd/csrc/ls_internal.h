@@ -109,6 +109,7 @@ struct StepArgs {
     // ---- one-pass-per-workgroup kernel (k_pass, ls_pass_kernel.h): b0 / npass as above, plus the CFG hand-off of ONE launch
     float* pf;               // [samples][2 passes][T][J*F] poseFinal output of each pass (write-through)
     unsigned* pcnt;          // [samples] arrival tickets: zeroed by ls_prepare, back at zero after every step
+    int xpad_ready;          // batch-level / long-sequence path: the previous step of this loop left x_in's padded copy behind (k_long_update), no k_long_padx needed
 #ifdef LS_DEBUG
     // Profiling builds only (tools/phase_profile.py, tools/ab_variants.py compile their own -DLS_DEBUG variant of the library):
     // the shipped library has neither the fields nor the code that reads them, so no environment variable can change its results.
@@ -151,6 +152,10 @@ struct LongStepArgs {
     float* mix_xg; unsigned long long* mix_gran; unsigned* mix_err;
     unsigned mix_epoch0;                   // tag base of this step's first mixer launch (one kCoopEpochStride per launch)
     int mix_cap;                           // (sample, pass) groups per launch (4 workgroups each, all resident); 0 = batch-level kernels
+#ifdef LS_DEBUG
+    unsigned long long* prof; int prof_wg;
+#endif
+    int xpad_ready;                        // xpad already holds x_in (written by the previous step's k_long_update): skip k_long_padx
     int sampler, t_nonzero, clip_denoised;
     float c0, c1, c2, c3, c4;
 };
@@ -169,12 +174,20 @@ struct MixArgs {
     const float* wch_img;       // [L][32 gb][32 q][64][4]: W'[16 gb + s16][16 q + 4 g + j], W' = W diag(alpha2)
     const float* bch; const float* wsum;      // [L][512] folded bias, row sums of W'
     float* xg;                  // [groups][32 k blocks][160][16] exchange: rows entering channel mixing, centred on the LayerNorm-1 mean
-    unsigned long long* gran;   // [groups][2 areas][160 rows][4 slices][2] {tag, value} granules
+    unsigned long long* gran;   // [groups]([2 areas][160 rows] + 1)[4 slices][2] {tag, value} granules: LayerNorm partials, rows-ready flags
     unsigned* err;              // set non-zero by a workgroup whose bounded spin ran out
     const CallParams* call;
     unsigned epoch;             // tag base of this launch
     int ngroups, layers;
     long long group_stride;     // floats between groups in x_in / x_out (S * 512)
+    // assembly inside the kernel (xproj != null; x_in is then unused): what k_long_assemble read
+    const float* xproj;         // [B * T][512] x_t columns of input_mapping
+    const float* static_c; const float* static_u; const float* z_mu; const float* z_std; const float* emo_tok; const float* eps_c; const float* eps_u;
+#ifdef LS_DEBUG
+    unsigned long long* prof; int prof_wg;      // phase stamps of one workgroup (tools/mix_profile.py)
+#endif
+    int g0, B, b0, npre;        // first group of this launch (group = pass * B + sample), batch, index of sample 0 in the prepared batch (Philox), prefix tokens
+    unsigned step_id;
 };
 
 bool mix_supports(int S);

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void k_long_update(const LongStepArgs a) {
             if (a.t_nonzero) xn += a.c4 * nz;
         }
         a.x_out[base + idx] = xn;
+        a.xpad[((size_t)b * a.T + f) * a.JFP + c] = xn;          // the next step's x_t in the projection's padded layout (pad columns / rows stay zero)
     }
 }
 
@@ -253,14 +254,14 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     // aligned), which sent this product down the GEMM's general staging path (32 TFLOP/s); k_long_padx copies them into rows of JFP
     // (zero pad columns, zero pad rows up to a whole 128-row tile) and the product is a full-tile one over K = JFP.
     const int mpad = (a.B * a.T + 127) / 128 * 128;
-    hipLaunchKernelGGL(k_long_padx, dim3(mpad), dim3(128), 0, st, a.x_in, a.xpad, a.B * a.T, a.JF, a.JFP);
+    if (!a.xpad_ready) hipLaunchKernelGGL(k_long_padx, dim3(mpad), dim3(128), 0, st, a.x_in, a.xpad, a.B * a.T, a.JF, a.JFP);
     if ((e = launch_gemm_nt(a.xpad, a.JFP, a.winx, a.JFP, nullptr, nullptr, 0, a.xproj, D, mpad, D, a.JFP, 0, st)) != hipSuccess) return e;
     // fused token mixing needs S <= 160 (accumulators for ten token tiles, the operand slab in LDS); longer sequences take the batched-GEMM form.
     // Token axis padded to 48 (the reference's 35 / 36 tokens: three tiles) or 160; a.tokpad says which image a.wtp holds.
     const int kTokPad = a.tokpad;
     const bool use_mix = a.mix_cap > 0;
     const bool fused_tok = !use_mix && a.wtp != nullptr && a.S <= kTokPad && (kTokPad == 48 || kTokPad == 160);
-    hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a, fused_tok ? 1 : 0);
+    if (!use_mix) hipLaunchKernelGGL(k_long_assemble, dim3(rows), dim3(128), 0, st, a, fused_tok ? 1 : 0);
     if (use_mix) {
         // the eight blocks: one launch per resident set of (pass, sample) groups, in place on X (a workgroup reads and writes its own rows x channels only)
         const int groups = 2 * a.B;
@@ -268,6 +269,11 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
         for (int g0 = 0; g0 < groups; g0 += a.mix_cap, epoch += kCoopEpochStride) {
             MixArgs m{};
             m.x_in = a.X + (size_t)g0 * a.S * D; m.x_out = a.X + (size_t)g0 * a.S * D;
+            m.xproj = a.xproj; m.static_c = a.static_c; m.static_u = a.static_u; m.z_mu = a.z_mu; m.z_std = a.z_std; m.emo_tok = a.emo_tok;
+#ifdef LS_DEBUG
+            m.prof = a.prof; m.prof_wg = a.prof_wg;
+#endif
+            m.eps_c = a.eps_c; m.eps_u = a.eps_u; m.g0 = g0; m.B = a.B; m.b0 = a.b0; m.npre = a.npre; m.step_id = a.step_id;
             m.temb = a.temb; m.ln1a = a.ln1a; m.ln1b = a.ln1b; m.wtok_img = a.mix_wtok; m.btok = a.bt; m.wch_img = a.mix_wch; m.bch = a.bcf; m.wsum = a.wsum;
             m.xg = a.mix_xg; m.gran = a.mix_gran; m.err = a.mix_err; m.call = a.call; m.epoch = epoch;
             m.ngroups = groups - g0 < a.mix_cap ? groups - g0 : a.mix_cap; m.layers = a.layers; m.group_stride = (long long)a.S * D;

@@ -34,7 +34,7 @@ namespace ls {
 constexpr int kMixThreads = 512;
 constexpr int kMixUS = 144;                 // LDS row stride of the token-mix operand [160][128]: = 16 mod 32 (the four lane groups read four consecutive rows), 16-byte aligned rows
 constexpr int kMixSlots = 8;                // ring slots of [160][16] floats
-constexpr int kMixPFW = 5;                  // k blocks the weight fragments are requested ahead
+constexpr int kMixPFW = 4;                  // k blocks the weight fragments are requested ahead
 // LDS: pst [4][160] f2 | stat [160] f2 | U: max(token-mix operand 160 x 144, ring 8 x 160 x 16)
 constexpr int kMixLdsFloats = 2 * 4 * kMixRows + 2 * kMixRows + kMixRows * kMixUS;
 static_assert(kMixSlots * kMixRows * 16 <= kMixRows * kMixUS, "the ring overlays the token-mix operand");
@@ -66,20 +66,60 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
     const float* xin = a.x_in + (size_t)pg * a.group_stride;
     float* xout = a.x_out + (size_t)pg * a.group_stride;
     float* xg = a.xg + (size_t)pg * 32 * RP * 16;
-    unsigned long long* gran = a.gran + (size_t)pg * 2 * RP * NS * 2;
+    unsigned long long* gran = a.gran + (size_t)pg * (2 * RP + 1) * NS * 2;       // [2 areas][160 rows][4 slices][2] statistics granules + [4 slices][2] rows-ready flags
     const wrsrc_t xrs = uniform_rsrc(xg);
     const unsigned ep = a.epoch + (a.call ? a.call->tag_base : 0u);
     unsigned spin_bad = 0;
+    auto stamp = [&](int idx) {
+#ifdef LS_DEBUG
+        if (a.prof && bid == a.prof_wg && lane == 0 && idx < kProfPoints) a.prof[wv * kProfPoints + idx] = __builtin_amdgcn_s_memtime();
+#else
+        (void)idx;
+#endif
+    };
+    stamp(0);
     const wrsrc_t rs_ln1a = wrsrc(a.ln1a), rs_ln1b = wrsrc(a.ln1b), rs_wtok = wrsrc(a.wtok_img), rs_wch = wrsrc(a.wch_img), rs_bch = wrsrc(a.bch),
                   rs_wsum = wrsrc(a.wsum);
     const gfp p_btok = g1(a.btok);
 
+    // The token sequence entering block 0: either assembled rows from x_in, or (a.xproj != null) assembled HERE as k_long_assemble did --
+    // frame rows = x_t projection + static_{c|u}, row 0 = style token mu + eps * std (reparameterize, RAG.py:10-13, 116-120), row 1 = emotion token
     f4 X[NCB][TH];
+    if (a.xproj) {
+        const int grp = a.g0 + pg, p = grp / a.B, b = grp - p * a.B;            // group = pass * B + sample
+        const float* stc = p ? a.static_u : a.static_c;
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int i = 0; i < TH; ++i)
-            X[cb][i] = live(i) ? *reinterpret_cast<const f4*>(xin + (size_t)rowi(i) * kD + chw(cb)) : (f4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < TH; ++i) {
+                const int r = rowi(i), ch = chw(cb);
+                f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+                if (r < S && r >= a.npre) {
+                    const size_t fr = ((size_t)b * (S - a.npre) + (r - a.npre)) * kD + ch;
+                    v = *reinterpret_cast<const f4*>(a.xproj + fr) + *reinterpret_cast<const f4*>(stc + fr);
+                } else if (r == 0) {
+                    const f4 mu = *reinterpret_cast<const f4*>(a.z_mu + (size_t)b * kD + ch), sd = *reinterpret_cast<const f4*>(a.z_std + (size_t)b * kD + ch);
+                    f4 e;
+                    const float* epp = p ? a.eps_u : a.eps_c;
+                    if (epp) e = *reinterpret_cast<const f4*>(epp + (size_t)b * kD + ch);
+                    else {
+                        float z[4];
+                        philox_normal4(a.call, a.call->sample_offset + (unsigned long long)(a.b0 + b), a.step_id, 1u + (unsigned)p, (unsigned)(ch >> 2), z);
+                        e = (f4){z[0], z[1], z[2], z[3]};
+                    }
+                    v = mu + e * sd;
+                } else if (r < a.npre) {
+                    v = *reinterpret_cast<const f4*>(a.emo_tok + (size_t)b * kD + ch);
+                }
+                X[cb][i] = v;
+            }
+    } else {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int i = 0; i < TH; ++i)
+                X[cb][i] = live(i) ? *reinterpret_cast<const f4*>(xin + (size_t)rowi(i) * kD + chw(cb)) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
     f4 temb4[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) temb4[cb] = *reinterpret_cast<const f4*>(a.temb + chw(cb));
@@ -135,33 +175,37 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
     // all slices' partials of every row -> stat[row] = (mean, rstd); pad rows get (0, 0)
     auto ln_gather = [&](int area, unsigned tag) {
         const unsigned long long* ga = gran + (size_t)area * RP * NS * 2;
-#pragma unroll 1
-        for (int r0 = 0; r0 < RP; r0 += kMixThreads / NS) {
-            const int sl = tid & (NS - 1), rr = r0 + tid / NS, r = min(rr, S - 1);
-            if (r0 + (wv * 64) / NS < S) {                   // waves whose rows exist poll (wave-uniform)
-                const unsigned long long* g0 = ga + ((size_t)r * NS + sl) * 2;
-                unsigned long long v0, v1;
-                for (unsigned spins = 0;; ++spins) {
-                    v0 = gran_load(g0); v1 = gran_load(g0 + 1);
-                    const bool ok = (unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag;
-                    if (__all(ok)) break;
-                    if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                const float pm = __uint_as_float((unsigned)v0), pq = __uint_as_float((unsigned)v1);
-                float sm = pm;
-                sm = dpp_add<0xB1>(sm); sm = dpp_add<0x4E>(sm);
-                const float mu = sm * 0.25f, d = pm - mu;
-                float q = fmaf(128.0f * d, d, pq);
-                q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q);
-                if (sl == 0 && rr < RP) stat[rr] = rr < S ? (f2){mu, rsqrtf(q * (1.0f / kD) + 1e-5f)} : (f2){0.f, 0.f};
-            } else if (sl == 0 && rr < RP) {
-                stat[rr] = (f2){0.f, 0.f};
-            }
+        // thread (row = tid / 4, slice = tid % 4) covers rows 0 .. 127; the first two waves take rows 128 .. 159 as well, in the SAME poll
+        // (both rows' granules are requested before either is looked at: one round trip per gather)
+        const int sl = tid & (NS - 1), ra = tid / NS, rb = kMixThreads / NS + tid / NS;
+        const bool two = wv < 2;                              // wave-uniform
+        const unsigned long long* g0 = ga + ((size_t)min(ra, S - 1) * NS + sl) * 2;
+        const unsigned long long* g1 = ga + ((size_t)min(rb, S - 1) * NS + sl) * 2;
+        unsigned long long v0, v1, w0 = 0, w1 = 0;
+        for (unsigned spins = 0;; ++spins) {
+            v0 = gran_load(g0); v1 = gran_load(g0 + 1);
+            if (two) { w0 = gran_load(g1); w1 = gran_load(g1 + 1); }
+            bool ok = (unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag;
+            if (two) ok = ok && (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag;
+            if (__all(ok)) break;
+            if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
+        auto merge = [&](unsigned long long x0, unsigned long long x1, int rr) {
+            const float pm = __uint_as_float((unsigned)x0), pq = __uint_as_float((unsigned)x1);
+            float sm = pm;
+            sm = dpp_add<0xB1>(sm); sm = dpp_add<0x4E>(sm);
+            const float mu = sm * 0.25f, d = pm - mu;
+            float q = fmaf(128.0f * d, d, pq);
+            q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q);
+            if (sl == 0) stat[rr] = rr < S ? (f2){mu, rsqrtf(q * (1.0f / kD) + 1e-5f)} : (f2){0.f, 0.f};
+        };
+        merge(v0, v1, ra);
+        if (two) merge(w0, w1, rb);
         lds_barrier();
     };
 
+    stamp(1);
     for (int l = 0; l < a.layers; ++l) {
         fresh();
         // x = x + emb  (mlp_module.py:68-69)
@@ -182,7 +226,9 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
         f4 Bn[TH];
 #pragma unroll
         for (int i = 0; i < TH; ++i) Bn[i] = wload4(rs_wtok, lane * 16, tsb + (0 * NT + TH * h + i) * 1024);
+        stamp(2 + 10 * l);                                   // LN1 partials published, weights requested
         ln_gather(0, ep + 2 * l + 1);
+        stamp(3 + 10 * l);                                   // LN1 statistics gathered
         fresh();
         float mu1[TH];
 #pragma unroll
@@ -198,6 +244,7 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
             }
         }
         lds_barrier();
+        stamp(4 + 10 * l);                                   // LN1 applied, operand in LDS
         fresh();
         {
             f4 acc[NCB][TH];
@@ -229,6 +276,7 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
 #pragma unroll
                 for (int i = 0; i < TH; ++i) if (live(i)) X[cb][i] = silu_acc4(acc[cb][i], X[cb][i]);
         }
+        stamp(5 + 10 * l);                                   // token mixing done
         fresh();
         // ---- block2: LN -> channel mixing -> SiLU -> residual -------------------------------------
         const unsigned tag2 = ep + 2 * l + 2;
@@ -243,12 +291,14 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
                     cen[cb][i] = live(i) ? X[cb][i] - (f4){mu1[i], mu1[i], mu1[i], mu1[i]} : (f4){0.f, 0.f, 0.f, 0.f};
                     st_sc1(cen[cb][i], xrs, ((gblk(cb) * RP + rowi(i)) * 16 + 4 * g) * 4);
                 }
-            ln_publish(1, tag2, true);
+            ln_publish(1, tag2, false);       // LayerNorm-2 partials: they need no payload.  The rows are NOT waited for here: 80 KB of write-through stores
+                                              // take ~5 k clocks to drain -- the ready flag goes up from inside the product (k block 2), behind the waits that are there anyway
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int i = 0; i < TH; ++i) *reinterpret_cast<f4*>(&U[((NCB * w + cb) * RP + rowi(i)) * 16 + 4 * g]) = cen[cb][i];     // slot = local k block
         }
+        stamp(6 + 10 * l);                                   // rows published, ring holds the own slice
         fresh();
         {
             f4 bc[NCB], ws4[NCB];
@@ -268,7 +318,7 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
             for (int k = 0; k < PFW; ++k)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) An[k][cb] = wload4(rs_wch, lane * 16, wsb(cb) + qof(k) * 1024);
-            const unsigned long long* ga = gran + (size_t)RP * NS * 2;          // area 1: row 0's mean granule of slice s = its rows are published
+            unsigned long long* rdy = gran + (size_t)2 * RP * NS * 2;           // [4 slices][2] rows-ready flags
             // one ring refill: k block n -> slot n % 8; ten 1 KiB chunks, wave wv takes chunk wv and chunk 8 + (wv & 1) (the doubled pulls of
             // chunks 8 and 9 write the same bytes: every wave issues exactly two)
             auto refill = [&](int n) {
@@ -277,41 +327,61 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
                 dma_sc1(xrs, U + slot * RP * 16 + (8 + (wv & 1)) * 256, lane * 16, (q * RP * 16 + (8 + (wv & 1)) * 256) * 4);
             };
             typedef const __attribute__((address_space(3))) f4* ldsp4;
+            // Two k blocks per workgroup barrier (sixteen barriers per layer): the barrier of pair pr says "blocks 2 pr and 2 pr + 1 have landed
+            // for every wave" (each wave has waited for all but its last 16 memory operations: every pull older than two pairs) and "everyone is
+            // done with pair pr - 1", whose two slots are refilled with blocks 2 pr + 6 and 2 pr + 7.  The second block's LDS operands are read
+            // while the first is multiplied.
+            static_assert(PFW == 4, "two pairs of weight fragments in flight");
 #pragma unroll 1
-            for (int t5 = 0; t5 < 32 / PFW + 1; ++t5)
+            for (int t4 = 0; t4 < 8; ++t4)
 #pragma unroll
-            for (int u = 0; u < PFW; ++u) {
-                const int n = PFW * t5 + u;
-                if (n >= 32 || (LS_MIX_ABL & 8)) break;
-                // block n has landed for every wave / everyone is done with block n - 1
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const int pr = 2 * t4 + u2;
+                if (LS_MIX_ABL & 8) break;
+                if (pr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row stores (issued ahead of every load still in flight) have drained ...
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 lds_barrier();
-                if (n == 4) {
+                if (pr == 1 && tid == 0) gran_store(rdy + (size_t)c * 2, tag2, 0.f);        // ... and so have every other wave's: the slice's rows are published
+                if (pr == 2) {
                     // the other slices' rows: wait for their ready flags once (long up: four own blocks have been multiplied), then fill the four free slots
                     for (unsigned spins = 0;; ++spins) {
-                        const bool ok = (unsigned)(gran_load(ga + (size_t)(lane & (NS - 1)) * 2) >> 32) == tag2;
+                        const bool ok = (unsigned)(gran_load(rdy + (size_t)(lane & (NS - 1)) * 2) >> 32) == tag2;
                         if (__all(ok)) break;
                         if (spin_bad || spins > kCoopSpinLimit) { spin_bad = 1; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (!(LS_MIX_ABL & 4)) { refill(8); refill(9); refill(10); refill(11); }
-                } else if (n > 4 && n + 7 < 32) {
-                    if (!(LS_MIX_ABL & 4)) refill(n + 7);
+                    stamp(7 + 10 * l);                                           // four own blocks multiplied, first refills issued
+                } else if (pr > 2 && 2 * pr + 7 < 32) {
+                    if (!(LS_MIX_ABL & 4)) { refill(2 * pr + 6); refill(2 * pr + 7); }
                 }
-                if (n == 6) ln_gather(1, tag2);                                 // LayerNorm-2 statistics (their granules came up with the ready flags)
-                const float* ub = U + (n & (kMixSlots - 1)) * RP * 16 + 4 * g;
-                f4 Bv[TH];
+                if (pr == 3) ln_gather(1, tag2);                                 // LayerNorm-2 statistics (published ahead of the product)
+                if (pr == 4) stamp(8 + 10 * l);                                  // own half done
+                f4 Bv[TH], Bw[TH];
+                {
+                    const float* ub = U + ((2 * pr) & (kMixSlots - 1)) * RP * 16 + 4 * g;
 #pragma unroll
-                for (int i = 0; i < TH; ++i) Bv[i] = *(ldsp4)(ub + rowi(i) * 16);
+                    for (int i = 0; i < TH; ++i) Bv[i] = *(ldsp4)(ub + rowi(i) * 16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int i = 0; i < TH; ++i) Bw[i] = *(ldsp4)(ub + RP * 16 + rowi(i) * 16);
+                }
 #pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb)
+                for (int v = 0; v < 2; ++v) {
+                    const int n = 2 * pr + v, u = 2 * u2 + v;
 #pragma unroll
-                        for (int i = 0; i < TH; ++i) { if (!(LS_MIX_ABL & 1)) acc[cb][i] = MFMA(An[u][cb][j], Bv[i][j], acc[cb][i]); else acc[cb][i][j] += An[u][cb][j] * Bv[i][j]; }
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) An[u][cb] = wload4(rs_wch, lane * 16, wsb(cb) + qof(min(n + PFW, 31)) * 1024);
+                        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                            for (int i = 0; i < TH; ++i) {
+                                const float bval = v ? Bw[i][j] : Bv[i][j];
+                                if (!(LS_MIX_ABL & 1)) acc[cb][i] = MFMA(An[u][cb][j], bval, acc[cb][i]); else acc[cb][i][j] += An[u][cb][j] * bval;
+                            }
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) An[u][cb] = wload4(rs_wch, lane * 16, wsb(cb) + qof(min(n + PFW, 31)) * 1024);
+                }
             }
+            stamp(9 + 10 * l);                               // product done
             fresh();
             // LayerNorm 2 around the product: v = rstd2 * (acc - (mu2 - mu1) wsum) + b'
 #pragma unroll
@@ -326,6 +396,7 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
             }
             lds_barrier();              // every wave is past its reads of the ring and of stat before the next layer writes them
         }
+        stamp(11 + 10 * l);                                  // epilogue done (= stamp 1 of the next layer)
     }
     if (spin_bad && lane == 0) atomicOr(a.err, 1u);
 #pragma unroll

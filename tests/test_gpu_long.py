@@ -151,8 +151,7 @@ def test_one_launch_mixer_agrees_with_the_batch_level_kernels_and_the_oracle(B):
         eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, nframes=cfg.nframes)
         try:
             eng.load_state_dict(sd)
-            if path == "batch":
-                eng.set_path("batch")
+            eng.set_path("batch" if path == "batch" else "coop")      # "coop" on a long-sequence model = the one-launch mixer at any batch size (`auto` takes it from 28 clips)
             eng.set_schedule(sch)
             eng.prepare(y)
             outs[path] = eng.sample(sampler=_lib.LS_SAMPLER_DDPM, philox_seed=seed, sample_offset=off)
