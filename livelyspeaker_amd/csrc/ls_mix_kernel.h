@@ -1,8 +1,8 @@
 // The eight MLPblocks of a LONG sequence (up to 160 tokens: BASELINE configs[4] "as worded", 150 frames + 2 prefix tokens) in ONE launch,
 // sample-split like ls_coop_kernel.h: a (sample, CFG pass) group is spread over FOUR workgroups of 128 channels, one per CU, which exchange
 // LayerNorm partials and rows inside the launch.  Replaces sixteen launches per step of the batch-level path (ls_long.hip: a token-mixing
-// kernel + a channel-mixing GEMM per layer); the input projection / assembly in front and poseFinal / the sampler update behind stay the
-// batch-level kernels they were.  Same reference arithmetic:
+// kernel + a channel-mixing GEMM per layer) and the assembly launch (the token sequence is put together in the kernel's load); the x_t
+// projection GEMM in front and the poseFinal GEMM / sampler update behind stay batch-level launches: 4 per step.  Same reference arithmetic:
 //   TransMLP / MLPblock / LN_spatial    scripts/model/mlp_module.py:21-91   (per-sample independence, :67-91, is what makes the split legal)
 // (the reference itself cannot run this shape: token mixing fixes S, scripts_beat/model/RAG.py:56 -- synthetic, self-pinned to oracle/).
 //
@@ -14,11 +14,13 @@
 //     [160][144]; the Conv1d weights stream from an L2-resident per-lane image, one 16-row k block ahead.
 //   * channel mixing contracts over all 512 channels = 32 k blocks of 16, but 160 rows x 512 channels do not fit LDS: the k blocks pass
 //     through an 8-slot LDS ring [slot][160 rows][16].  The slice's own eight blocks are written into the ring from registers; the other
-//     24 are pulled global -> LDS by LDS-DMA from the exchange buffer, one block per iteration into the slot freed one iteration earlier
-//     (seven blocks = ~15 k clocks ahead of their use).  One workgroup barrier per k block: it says both "block n has landed for every wave"
-//     and "everyone is done with block n - 1".  VMEM returns in issue order on gfx950, so the weight fragments are requested FIVE blocks
-//     ahead: a wait for a fragment then only covers pulls that are at least five iterations old.  LayerNorm 2 is folded around the product
-//      with the rows centred on the LayerNorm-1 mean.
+//     24 are pulled global -> LDS by LDS-DMA from the exchange buffer, two blocks per pair of iterations into the two slots freed by the
+//     previous pair (six blocks = ~17 k clocks ahead of their use).  One workgroup barrier per PAIR of k blocks: it says both "blocks 2 pr,
+//     2 pr + 1 have landed for every wave" (every wave has waited for all but its last 16 memory operations) and "everyone is done with pair
+//     pr - 1".  VMEM returns in issue order on gfx950, so a wait for a weight fragment also waits for every pull issued before it: the
+//     fragments are requested four blocks ahead, behind pulls that are then at least two pairs old.  LayerNorm 2 is folded around the product
+//      with the rows centred on the LayerNorm-1 mean.  The rows are stored write-through and NOT waited for: the ready
+//     flag goes up from inside the product (pair 1), the other slices' flags are looked at in pair 2.
 //   * hand-offs: the protocol of ls_coop_kernel.h (write-through payload, every wave drains, barrier, {tag, value} granules that double as
 //     ready flags, bounded spins, tags unique per launch / sync point / call).  The four slices of a group sit on ONE XCD when the grid is
 //     dealt round-robin (blockIdx = (group / 8 * 4 + slice) * 8 + group % 8) -- speed only.
