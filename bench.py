@@ -545,8 +545,8 @@ def other_config_leg(dataset, B, dev, fence, steps=1000, noise="philox"):
     km = tm["loop_ms"] / max(tm["n_step_launches"], 1)
     ach = 2 * FLOP_PER_FORWARD[dataset] * B / (km * 1e-3) / 1e12
     names = {0: "fused step kernel (one workgroup per clip)",
-             1: ("x_t projection GEMM + one-launch mixer (ls_mix_kernel.h: the eight blocks, four slice workgroups per (clip, CFG pass), one launch per 32 clips) + "
-                 "poseFinal GEMM + update kernel: 4 launches per step" if (dataset == "beat150" and tm.get("coop_slices") == 4) else
+             1: ("x_t projection GEMM + one-launch mixer (ls_mix_kernel.h: the eight blocks, four slice workgroups per (clip, CFG pass), one launch per 32 clips, poseFinal in its tail as per-slice partial products) + "
+                 "update kernel: 3 launches per step" if (dataset == "beat150" and tm.get("coop_slices") == 4) else
                  "batch-level kernels (ls_long.hip, 21 launches per step)"),
              2: f"sample-split step kernel (ls_coop_kernel.h: {tm.get('coop_slices') or '8 / 4 / 2'} slice workgroups per (clip, CFG pass) in its first launch; one launch per step and resident set)",
              3: "one-pass-per-workgroup step kernel (ls_pass_kernel.h: a workgroup per (clip, CFG pass), two per CU)"}
@@ -1050,8 +1050,8 @@ def main():
                                        else f"batch-sharded x{world}, no per-step collective"),
                        "hipgraph": bool(diffusion.use_graph)},
             "roofline": {"bound": "mfma", "kernel": (step_kernel_label(main_tm) if a.dataset != "beat150" else
-                                                     ("long-sequence step, 4 launches: x_t projection GEMM, ls::k_mix (the eight blocks in one launch per 32 clips, four "
-                                                      "slice workgroups per (clip, CFG pass)), poseFinal GEMM, update; achieved = algorithmic FLOPs / mean step time"
+                                                     ("long-sequence step, 3 launches: x_t projection GEMM, ls::k_mix (the eight blocks + poseFinal in one launch per 32 clips, four "
+                                                      "slice workgroups per (clip, CFG pass)), update; achieved = algorithmic FLOPs / mean step time"
                                                       if main_tm.get("coop_slices") == 4 else
                                                       "long-sequence step: 21 launches/step (batch-level kernels: GEMMs on ls::k_gemm_tr + fused token-mixing / LayerNorm-partial "
                                                       "kernels); achieved = algorithmic FLOPs / mean step time")),

@@ -88,6 +88,9 @@ struct ls_handle {
     int n_cu = 256;         // compute units of the device (hipDeviceProp.multiProcessorCount): residency of the sample-split kernel, round sizes of the plans
     int coop_groups_max = kCoopMaxGroups, coop_groups = 0;   // (sample, pass) groups per launch: cap of the 8-slice form (two workgroups per CU, eight per group), and what the workspaces hold
     int coop_ncb = 0;       // slicing of the sample-split kernel: 0 = by the step-time model; 1 | 2 | 4 = 8 | 4 | 2 slice workgroups per (sample, pass) (ls_set_path 8 | 6 | 7)
+#ifndef LS_MIX_POSE_DEFAULT
+#define LS_MIX_POSE_DEFAULT 1
+#endif
 #ifndef LS_COOP_XMAP_DEFAULT
 #define LS_COOP_XMAP_DEFAULT -1
 #endif
@@ -95,7 +98,9 @@ struct ls_handle {
     int tokpad = 160;       // token axis of lw_wtp
     int JFP = 0;            // JF padded to a multiple of 32 (long path: K of the x_t projection)
     DevBuf lw_wt, lw_wtp, lw_bt, lw_wc, lw_bc, lw_wcf, lw_bcf, lw_wsum, lw_winx, lw_wout;     // long path: row-major weights (wtp: Wt zero-padded to 160 x 160 in k_long_tokmix's per-lane fragment order)
-    DevBuf mx_wtok, mx_wch, mx_xg, mx_gran;             // long-sequence mixer kernel (ls_mix_kernel.h): operand images, exchange workspace, granules
+    DevBuf mx_wtok, mx_wch, mx_wpose, mx_pout, mx_xg, mx_gran;             // long-sequence mixer kernel (ls_mix_kernel.h): operand images, exchange workspace, granules
+    bool mix_pose = LS_MIX_POSE_DEFAULT;                            // env LS_MIX_POSE=0: poseFinal as a GEMM behind the mixer (A/B runs)
+    int mx_npt = 0;                                     // 16-column tiles of poseFinal inside the mixer; 0: poseFinal stays a GEMM
     int mix_cap = 0;                                    // (sample, pass) groups per mixer launch; 0: the model has no such kernel (or ls_set_path(2) asked for the batch-level kernels)
     DevBuf lx_proj, lx_X, lx_U, lx_OUT, lx_part1, lx_part2, lx_xpad;   // long path: workspaces (xpad: x_t rows padded to whole GEMM tiles)
     int convL[5] = {0, 0, 0, 0, 0};
@@ -590,6 +595,21 @@ int build_long_weights(ls_handle* h) {
     std::vector<float> woutp((size_t)JFN * D, 0.f);
     memcpy(woutp.data(), Wout->data(), (size_t)JF * D * sizeof(float));
     UP(lw_winx, winx); UP(lw_wout, woutp); UP(bout, *bo);
+    h->mx_npt = 0;
+    if (!h->fused && mix_supports(S) && (JF + 15) / 16 <= 20) {
+        // poseFinal inside the mixer: wpose[nb][q][lane][j] = Wout[16 nb + s16][16 q + 4 g + j], zero rows beyond JF
+        const int npt = (JF + 15) / 16;
+        std::vector<float> wp((size_t)npt * 32 * 256, 0.f);
+        for (int nb = 0; nb < npt; ++nb)
+            for (int q = 0; q < 32; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = 16 * nb + (lane & 15), k = 16 * q + 4 * (lane >> 4) + j;
+                        if (n < JF) wp[(((size_t)nb * 32 + q) * 64 + lane) * 4 + j] = (*Wout)[(size_t)n * D + k];
+                    }
+        UP(mx_wpose, wp);
+        h->mx_npt = npt;
+    }
 #undef UP
     return LS_OK;
 }
@@ -740,6 +760,7 @@ hipError_t run_long(ls_handle* h, const StepArgs& s, int first, int n, hipStream
     a.xproj = h->lx_proj.f(); a.xpad = h->lx_xpad.f(); a.X = h->lx_X.f(); a.U = h->lx_U.f(); a.OUT = h->lx_OUT.f();
     if (h->mix_cap > 0 && first == 0 && n == h->B && s.temb_stride == 0) {     // the one-launch mixer: whole prepared batch, uniform timestep (sampling)
         a.mix_cap = h->mix_cap; a.mix_wtok = h->mx_wtok.f(); a.mix_wch = h->mx_wch.f(); a.mix_xg = h->mx_xg.f();
+        if (h->mx_npt > 0 && h->mx_pout.p && h->mix_pose) { a.mix_wpose = h->mx_wpose.f(); a.mix_pout = h->mx_pout.f(); a.mix_npt = h->mx_npt; }
         a.mix_gran = static_cast<unsigned long long*>(h->mx_gran.p); a.mix_err = static_cast<unsigned*>(h->co_err.p);
         a.mix_epoch0 = (h->coop_launches + 1) * kCoopEpochStride;
         h->coop_launches += (unsigned)((2 * n + h->mix_cap - 1) / h->mix_cap);
@@ -1194,6 +1215,7 @@ int ls_create(const ls_config* cfg, ls_handle** out) {
     if (const char* ab = getenv("LS_ABLATE")) h->ablate = atoi(ab);
     if (const char* pr = getenv("LS_PROF")) { h->prof_on = true; h->prof_wg = atoi(pr); }
     if (const char* xm = getenv("LS_COOP_XMAP")) h->coop_xmap = atoi(xm);
+    if (const char* mp = getenv("LS_MIX_POSE")) h->mix_pose = atoi(mp) != 0;
     if (const char* gm = getenv("LS_COOP_GROUPS")) h->coop_groups_max = atoi(gm);
     if (const char* nc = getenv("LS_COOP_NCB")) h->coop_ncb = atoi(nc) == 2 ? 2 : atoi(nc) == 4 ? 4 : atoi(nc) == 1 ? 1 : 0;
     if (const char* pw = getenv("LS_PASS_WAVES")) h->pass_waves_env = atoi(pw) == 8 ? 8 : atoi(pw) == 4 ? 4 : 0;
@@ -1270,7 +1292,7 @@ void ls_destroy(ls_handle* h) {
                      &h->z_logvar, &h->z_std, &h->emo_tok, &h->audio_feat, &h->spart, &h->xa, &h->xb, &h->xtmp, &h->xio, &h->fwd_c,
                      &h->fwd_u, &h->fwd_cfg, &h->eps, &h->noise, &h->tfwd, &h->tfwd_tmp, &h->tidx, &h->dump, &h->trace,
                      &h->callp, &h->eps_tape, &h->noise_tape, &h->lw_wt, &h->lw_wtp, &h->lx_part1, &h->lx_part2, &h->lw_bt, &h->lw_wc, &h->lw_bc, &h->lw_wcf, &h->lw_bcf, &h->lw_wsum, &h->lw_winx, &h->lw_wout,
-                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->mx_wtok, &h->mx_wch, &h->mx_xg, &h->mx_gran, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt, &h->wtail, &h->wtok1_hi_img, &h->wtok1_lo_img};
+                     &h->lx_proj, &h->lx_X, &h->lx_U, &h->lx_OUT, &h->lx_xpad, &h->mx_wtok, &h->mx_wch, &h->mx_wpose, &h->mx_pout, &h->mx_xg, &h->mx_gran, &h->wtok1_img, &h->co_x, &h->co_part, &h->co_gran, &h->co_flag, &h->co_err, &h->pa_out, &h->pa_cnt, &h->wtail, &h->wtok1_hi_img, &h->wtok1_lo_img};
     for (DevBuf* d : all) d->release();
 #ifdef LS_DEBUG
     h->prof.release();
@@ -1554,6 +1576,11 @@ static int prepare_impl(ls_handle* h, const ls_cond* c, bool wait) {
                 HIPCHK(h, h->mx_xg.ensure((size_t)cap * 32 * kMixRows * 16 * sizeof(float)));
                 HIPCHK(h, h->mx_gran.ensure((size_t)cap * (2 * kMixRows + 1) * kMixSlices * 2 * sizeof(unsigned long long)));
                 if (o[0] != h->mx_xg.p) HIPCHK(h, hipMemsetAsync(h->mx_xg.p, 0, h->mx_xg.bytes, st));       // rows a pass never writes are pulled into LDS (finite, never used)
+                if (h->mx_npt > 0) {      // partial poseFinal products of the whole batch: [2 B][4 slices][S][16 npt]
+                    const void* op = h->mx_pout.p;
+                    HIPCHK(h, h->mx_pout.ensure((size_t)2 * nlo * kMixSlices * h->S * 16 * h->mx_npt * sizeof(float)));
+                    if (op != h->mx_pout.p) free_graph(h);
+                }
                 if (o[0] != h->mx_xg.p || o[1] != h->mx_gran.p) free_graph(h);
                 h->mix_cap = cap;
             }

@@ -149,6 +149,7 @@ struct LongStepArgs {
     float* OUT;                            // [2*B*S][ldo]
     // the eight blocks in one launch per resident set of groups (ls_mix_kernel.h) instead of sixteen batch-level launches: when mix_cap > 0
     const float* mix_wtok; const float* mix_wch;   // per-lane operand images (MixArgs)
+    const float* mix_wpose; float* mix_pout; int mix_npt;     // poseFinal inside the mixer (mix_pout != null): partial products per slice, summed by k_long_update
     float* mix_xg; unsigned long long* mix_gran; unsigned* mix_err;
     unsigned mix_epoch0;                   // tag base of this step's first mixer launch (one kCoopEpochStride per launch)
     int mix_cap;                           // (sample, pass) groups per launch (4 workgroups each, all resident); 0 = batch-level kernels
@@ -181,6 +182,11 @@ struct MixArgs {
     int ngroups, layers;
     long long group_stride;     // floats between groups in x_in / x_out (S * 512)
     // assembly inside the kernel (xproj != null; x_in is then unused): what k_long_assemble read
+    // poseFinal inside the kernel (pout != null; x_out is then not written): every slice multiplies its own 128 channels into all output columns,
+    // the four partial products are summed (in slice order) by the update kernel
+    const float* wpose_img;     // [npt column tiles][32 q][64][4]: Wout[16 nb + s16][16 q + 4 g + j], zero rows beyond JF
+    float* pout;                // [all groups of the batch][4 slices][S][16 npt] partial poseFinal products (no bias)
+    int npt;                    // 16-column tiles of the output (JF = 282: 18); at most 20 (five per wave)
     const float* xproj;         // [B * T][512] x_t columns of input_mapping
     const float* static_c; const float* static_u; const float* z_mu; const float* z_std; const float* emo_tok; const float* eps_c; const float* eps_u;
 #ifdef LS_DEBUG

@@ -218,8 +218,19 @@ __global__ __launch_bounds__(256) void k_long_update(const LongStepArgs a) {
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < TJ; idx += gridDim.x * 256) {
         const int f = idx / a.JF, c = idx - f * a.JF;
         const float bo = a.bout[c];
-        const float oc = a.OUT[((size_t)(0 * a.B + b) * a.S + a.npre + f) * a.ldo + c] + bo;
-        const float ou = a.OUT[((size_t)(1 * a.B + b) * a.S + a.npre + f) * a.ldo + c] + bo;
+        float oc, ou;
+        if (a.mix_pout) {
+            // poseFinal ran inside the mixer: four partial products per (pass, sample), one per 128-channel slice, summed in slice order
+            const int ldp = 16 * a.mix_npt;
+            const size_t ss = (size_t)a.S * ldp, o = (size_t)(a.npre + f) * ldp + c;
+            const float* pc = a.mix_pout + (size_t)(0 * a.B + b) * kMixSlices * ss + o;
+            const float* pu = a.mix_pout + (size_t)(1 * a.B + b) * kMixSlices * ss + o;
+            oc = ((pc[0] + pc[ss]) + (pc[2 * ss] + pc[3 * ss])) + bo;
+            ou = ((pu[0] + pu[ss]) + (pu[2 * ss] + pu[3 * ss])) + bo;
+        } else {
+            oc = a.OUT[((size_t)(0 * a.B + b) * a.S + a.npre + f) * a.ldo + c] + bo;
+            ou = a.OUT[((size_t)(1 * a.B + b) * a.S + a.npre + f) * a.ldo + c] + bo;
+        }
         const size_t base = (size_t)b * TJ;
         if (a.fwd_c) a.fwd_c[base + idx] = oc;
         if (a.fwd_u) a.fwd_u[base + idx] = ou;
@@ -275,6 +286,7 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
 #endif
             m.eps_c = a.eps_c; m.eps_u = a.eps_u; m.g0 = g0; m.B = a.B; m.b0 = a.b0; m.npre = a.npre; m.step_id = a.step_id;
             m.temb = a.temb; m.ln1a = a.ln1a; m.ln1b = a.ln1b; m.wtok_img = a.mix_wtok; m.btok = a.bt; m.wch_img = a.mix_wch; m.bch = a.bcf; m.wsum = a.wsum;
+            m.wpose_img = a.mix_wpose; m.pout = a.mix_pout; m.npt = a.mix_npt;
             m.xg = a.mix_xg; m.gran = a.mix_gran; m.err = a.mix_err; m.call = a.call; m.epoch = epoch;
             m.ngroups = groups - g0 < a.mix_cap ? groups - g0 : a.mix_cap; m.layers = a.layers; m.group_stride = (long long)a.S * D;
             if ((e = launch_mix(a.S, m, st)) != hipSuccess) return e;
@@ -322,7 +334,7 @@ hipError_t launch_step_long(const LongStepArgs& a, hipStream_t st) {
     if (!use_mix && fused_tok && Xc != a.X) return hipErrorInvalidValue;              // odd layer counts would end in the other buffer
     // poseFinal over whole 128-row tiles as well (N = JF padded to 128s with zero weight rows): 280 rows (4 clips) as they are would
     // take the GEMM's general staging path, 64 us instead of 8
-    if ((e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, mrows, a.ldo, D, 0, st)) != hipSuccess) return e;
+    if (!(use_mix && a.mix_pout) && (e = launch_gemm_nt(a.X, D, a.wout, D, nullptr, nullptr, 0, a.OUT, a.ldo, mrows, a.ldo, D, 0, st)) != hipSuccess) return e;
     const int TJ = a.T * a.JF;
     hipLaunchKernelGGL(k_long_update, dim3((TJ + 1023) / 1024, a.B), dim3(256), 0, st, a);
     return hipGetLastError();

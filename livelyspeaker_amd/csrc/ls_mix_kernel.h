@@ -1,8 +1,11 @@
 // The eight MLPblocks of a LONG sequence (up to 160 tokens: BASELINE configs[4] "as worded", 150 frames + 2 prefix tokens) in ONE launch,
 // sample-split like ls_coop_kernel.h: a (sample, CFG pass) group is spread over FOUR workgroups of 128 channels, one per CU, which exchange
 // LayerNorm partials and rows inside the launch.  Replaces sixteen launches per step of the batch-level path (ls_long.hip: a token-mixing
-// kernel + a channel-mixing GEMM per layer) and the assembly launch (the token sequence is put together in the kernel's load); the x_t
-// projection GEMM in front and the poseFinal GEMM / sampler update behind stay batch-level launches: 4 per step.  Same reference arithmetic:
+// kernel + a channel-mixing GEMM per layer), the assembly launch (the token sequence is put together in the kernel's load) and the poseFinal
+// GEMM (every slice multiplies its 128 channels into all output columns in the kernel's tail; the update kernel sums the four partial
+// products in slice order); the x_t projection GEMM in front and the sampler update behind stay launches of their own: 3 per step.  (Folding the
+// x_t projection in as well would compute it once per CFG pass -- twice the matrix work of the GEMM it replaces -- and was not built.)
+// Same reference arithmetic:
 //   TransMLP / MLPblock / LN_spatial    scripts/model/mlp_module.py:21-91   (per-sample independence, :67-91, is what makes the split legal)
 // (the reference itself cannot run this shape: token mixing fixes S, scripts_beat/model/RAG.py:56 -- synthetic, self-pinned to oracle/).
 //
@@ -28,7 +31,7 @@
 #include "ls_coop_kernel.h"
 
 #ifndef LS_MIX_ABL
-#define LS_MIX_ABL 0            // A/B builds only (tools/ab_variants.py): 1 no channel-mix MFMAs, 2 no token-mix MFMAs, 4 no ring refills, 8 no k-block loop -- wrong results
+#define LS_MIX_ABL 0            // A/B builds only (tools/ab_variants.py): 1 no channel-mix MFMAs, 2 no token-mix MFMAs, 4 no ring refills, 8 no k-block loop, 16 no barriers in it -- wrong results
 #endif
 
 namespace ls {
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
                 if (LS_MIX_ABL & 8) break;
                 if (pr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row stores (issued ahead of every load still in flight) have drained ...
                 else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                lds_barrier();
+                if (!(LS_MIX_ABL & 16)) lds_barrier();
                 if (pr == 1 && tid == 0) gran_store(rdy + (size_t)c * 2, tag2, 0.f);        // ... and so have every other wave's: the slice's rows are published
                 if (pr == 2) {
                     // the other slices' rows: wait for their ready flags once (long up: four own blocks have been multiplied), then fill the four free slots
@@ -401,11 +404,69 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
         stamp(11 + 10 * l);                                  // epilogue done (= stamp 1 of the next layer)
     }
     if (spin_bad && lane == 0) atomicOr(a.err, 1u);
+    if (!a.pout) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int i = 0; i < TH; ++i)
+                if (live(i)) *reinterpret_cast<f4*>(xout + (size_t)rowi(i) * kD + chw(cb)) = X[cb][i];
+        return;
+    }
+    // ---- poseFinal (OutputProcess, scripts/model/RAG.py poseFinal Linear) on this slice's 128 channels: a partial product over k = the slice's eight
+    // 16-channel blocks into ALL output columns; the update kernel sums the four slices' partials in slice order and adds the bias.  The rows go through
+    // the ring slots as in channel mixing (slot = local k block; the end-of-layer barrier has passed), the weights stream from a per-lane image.
+    // Wave (w, h): column tiles w, w + 4, ... (five at most), row tiles 5 h .. 5 h + 4.
+    fresh();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int i = 0; i < TH; ++i)
-            if (live(i)) *reinterpret_cast<f4*>(xout + (size_t)rowi(i) * kD + chw(cb)) = X[cb][i];
+            *reinterpret_cast<f4*>(&U[((NCB * w + cb) * RP + rowi(i)) * 16 + 4 * g]) = live(i) ? X[cb][i] : (f4){0.f, 0.f, 0.f, 0.f};
+    constexpr int PT = 5;
+    const wrsrc_t rs_wp = wrsrc(a.wpose_img);
+    auto wpb = [&](int t, int ql) { return ((w + 4 * t) * 32 + KB * c + ql) * 1024; };
+    const int nt_w = (a.npt - w + 3) / 4;                   // column tiles of this wave (wave-uniform)
+    f4 Pn[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) Pn[t] = t < nt_w ? wload4(rs_wp, lane * 16, wpb(t, 0)) : (f4){0.f, 0.f, 0.f, 0.f};
+    f4 pacc[PT][TH];
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int i = 0; i < TH; ++i) pacc[t][i] = (f4){0.f, 0.f, 0.f, 0.f};
+    lds_barrier();
+    typedef const __attribute__((address_space(3))) f4* ldsq4;
+#pragma unroll 1
+    for (int ql = 0; ql < KB; ++ql) {
+        f4 Pv[PT], Bv[TH];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) Pv[t] = Pn[t];
+        const int qn = min(ql + 1, KB - 1);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) if (t < nt_w) Pn[t] = wload4(rs_wp, lane * 16, wpb(t, qn));
+#pragma unroll
+        for (int i = 0; i < TH; ++i) Bv[i] = *(ldsq4)(U + ql * RP * 16 + 4 * g + rowi(i) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+                if (t < nt_w) {
+#pragma unroll
+                    for (int i = 0; i < TH; ++i) pacc[t][i] = MFMA(Pv[t][j], Bv[i][j], pacc[t][i]);
+                }
+    }
+    fresh();
+    {
+        const int ldp = 16 * a.npt;
+        float* po = a.pout + ((size_t)(a.g0 + pg) * NS + c) * S * ldp;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+            if (t < nt_w) {
+#pragma unroll
+                for (int i = 0; i < TH; ++i)
+                    if (live(i)) *reinterpret_cast<f4*>(po + (size_t)rowi(i) * ldp + 16 * (w + 4 * t) + 4 * g) = pacc[t][i];
+            }
+    }
 }
 
 }  // namespace ls
