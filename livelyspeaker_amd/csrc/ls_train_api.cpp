@@ -44,6 +44,9 @@ struct Buf {
 struct Param { std::string key; int64_t off, n; };
 
 const int kCin[4] = {1, 32, 64, 128}, kCout[4] = {32, 64, 128, 256}, kStride[4] = {5, 6, 6, 6}, kPad[4] = {1600, 0, 0, 0}, kKey[4] = {0, 3, 6, 9};
+#ifndef LS_TRAIN_FORK_DEFAULT
+#define LS_TRAIN_FORK_DEFAULT 1      // A/B builds: 0 = the whole backward on one stream
+#endif
 constexpr int kSpk = 256, kAud = 256, kNW = 1024;   // kD, kPeRows come from ls_internal.h; kNW: waves of the row-loop kernels
 
 }  // namespace
@@ -54,6 +57,12 @@ struct ls_trainer {
     int convL[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // The backward forks behind the mixer's data gradient: the mixer's parameter gradients (the batched 512 x 512 weight-gradient product,
+    // token-mixing weights, LayerNorm / bias reductions, timestep embedder) run on `side` while the input stage and the WavEncoder backward run
+    // on `stream`; the two meet again before the step's closing event.  The side branch has its own split-K and reduction workspaces.
+    hipStream_t side = nullptr;
+    hipEvent_t evs[2] = {nullptr, nullptr};
+    bool fork = LS_TRAIN_FORK_DEFAULT != 0;
     // this step's batch: the caller's device tensors in place, or the handle's copies of host inputs (ls_train_forward_backward
     // synchronises before it returns, so nothing is read after the call)
     const float *audio_in = nullptr, *in_x = nullptr, *in_noise = nullptr, *in_origin = nullptr, *in_drop = nullptr, *in_eps = nullptr;
@@ -77,7 +86,7 @@ struct ls_trainer {
     Buf X1, A1, X2, A2, S1, S2, dA2, dA1, colpart, dembp;      // [L][B*S][512] (S1/S2: [L][B*S][2]) written by the fused training forward; X1 / X2 hold x-hat
     Buf twch, tbch, tww, tbtok, tl1a, tl1b, tl2a, tl2b, tdevw, twchT, twwT;    // mixer weight images + the DevWeights block k_step reads
     TrainImgArgs img_args{};
-    Buf out, dout, lossp, kldp, terms, G, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, dAt, col, dc[3], wmom, ws;
+    Buf out, dout, lossp, kldp, terms, G, part, pw, pb, demb, dmu, dlv, dzc, dhid, dAf, dAt, col, dc[3], wmom, ws, part2, ws2;
     size_t ws_floats = 0;
     int B = 0;
     bool have_forward = false;
@@ -218,6 +227,7 @@ int ensure_batch(ls_trainer* h, int B) {
     HIPCHK(h, E(h->col, colmax));
     h->ws_floats = (size_t)48 << 20;
     HIPCHK(h, E(h->ws, h->ws_floats));
+    if (h->fork) { HIPCHK(h, E(h->ws2, h->ws_floats)); HIPCHK(h, h->part2.ensure(h->part.bytes)); }
     h->capB = B;
     return LS_OK;
 }
@@ -349,6 +359,14 @@ static int train_backward_mixer(ls_trainer* h, const TrainDims& d, float* grad) 
         a.B = B; a.layers = d.L;
         HIPCHK(h, launch_mixer_bwd(d.NPRE == 2 ? kBEAT : kTED, a, st));
     }
+    return LS_OK;
+}
+
+// parameter gradients of the 8 MLPblocks from what k_mixer_bwd left (dA2 / dA1, partial column sums, d emb partials); independent of the
+// input stage and of the WavEncoder backward: runs on whichever stream h->stream is at the time (the side branch of the fork)
+static int train_backward_mixer_params(ls_trainer* h, const TrainDims& d, float* grad) {
+    TRAIN_LOCALS(h, d);
+    const int nwg = (B + 1) / 2;
     // per-workgroup partial column sums -> bias / LayerNorm-parameter gradients of ALL layers, one launch per family
     // (alpha and beta are adjacent both in colpart and in the flat layout; the per-layer stride of the flat layout is constant)
     const long long cps = (long long)d.L * 5 * kD, ls = h->img_args.lstride;
@@ -399,6 +417,12 @@ static int train_backward_inputs(ls_trainer* h, const TrainDims& d, float* grad)
         HIPCHK(h, gemm_run(h, a, true, true));
         HIPCHK(h, launch_scale_rows(h->dAf.f(), h->in_drop, B, T * kAud, st));
     }
+    return LS_OK;
+}
+
+// TimestepEmbedder backward from d emb (reduced by train_backward_mixer_params: same stream, behind it)
+static int train_backward_temb(ls_trainer* h, const TrainDims& d, float* grad) {
+    TRAIN_LOCALS(h, d);
     // TimestepEmbedder
     {
         const char* w0 = "backbone.embed_timestep.time_embed.0.weight";
@@ -507,6 +531,8 @@ int ls_train_create(const ls_train_config* cfg, ls_trainer** out) {
     if ((e = hipSetDevice(m.device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (auto& ev : h->evs) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (Buf* b : {&h->P, &h->M, &h->V}) {
         if ((e = b->ensure((size_t)h->flat * 4)) != hipSuccess) return bail("hipMalloc(params)", e);
         if ((e = hipMemsetAsync(b->p, 0, (size_t)h->flat * 4, h->stream)) != hipSuccess) return bail("hipMemset", e);
@@ -563,7 +589,7 @@ void ls_train_destroy(ls_trainer* h) {
     std::vector<Buf*> all = {&h->P, &h->M, &h->V, &h->pe, &h->x_start, &h->noise, &h->drop, &h->eps, &h->audio, &h->origin_x, &h->vid, &h->emo, &h->hostpack, &h->wpad, &h->waT,
                              &h->ca, &h->cb, &h->tidx, &h->feat, &h->x_t, &h->zc, &h->mu, &h->lv, &h->pe_rows, &h->pre1, &h->hid, &h->emb, &h->xcur,
                              &h->out, &h->dout, &h->lossp, &h->kldp, &h->terms, &h->G, &h->part, &h->pw, &h->pb, &h->demb, &h->dmu,
-                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->dAt, &h->col, &h->wmom, &h->ws};
+                             &h->dlv, &h->dzc, &h->dhid, &h->dAf, &h->dAt, &h->col, &h->wmom, &h->ws, &h->part2, &h->ws2};
     for (int i = 0; i < 4; ++i) { all.push_back(&h->c[i]); all.push_back(&h->img[i]); all.push_back(&h->dimg[i]); }
     for (int i = 0; i < 3; ++i) { all.push_back(&h->st[i]); all.push_back(&h->dc[i]); }
     for (Buf* b : {&h->X1, &h->A1, &h->X2, &h->A2, &h->S1, &h->S2, &h->twch, &h->tbch, &h->tww, &h->tbtok, &h->tl1a, &h->tl1b, &h->tl2a,
@@ -571,6 +597,8 @@ void ls_train_destroy(ls_trainer* h) {
         all.push_back(b);
     for (Buf* b : all) b->release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : h->evs) if (ev) (void)hipEventDestroy(ev);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -697,8 +725,22 @@ int ls_train_forward_backward(ls_trainer* h, const ls_train_batch* tb, float* gr
 
     if ((rc = train_forward(h, d)) != LS_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[1], st));
-    if ((rc = train_backward_mixer(h, d, grad)) != LS_OK || (rc = train_backward_inputs(h, d, grad)) != LS_OK ||
-        (rc = train_backward_audio(h, d, grad)) != LS_OK)
+    if ((rc = train_backward_mixer(h, d, grad)) != LS_OK) return rc;
+    if (h->fork) {
+        HIPCHK(h, hipEventRecord(h->evs[0], st));
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->evs[0], 0));
+        {   // the helpers launch on h->stream with h->ws / h->part: the side branch borrows the names for its launches
+            std::swap(h->stream, h->side); std::swap(h->ws, h->ws2); std::swap(h->part, h->part2);
+            rc = train_backward_mixer_params(h, d, grad);
+            if (rc == LS_OK) rc = train_backward_temb(h, d, grad);
+            std::swap(h->stream, h->side); std::swap(h->ws, h->ws2); std::swap(h->part, h->part2);
+            if (rc != LS_OK) return rc;
+        }
+        HIPCHK(h, hipEventRecord(h->evs[1], h->side));
+        if ((rc = train_backward_inputs(h, d, grad)) != LS_OK || (rc = train_backward_audio(h, d, grad)) != LS_OK) return rc;
+        HIPCHK(h, hipStreamWaitEvent(st, h->evs[1], 0));
+    } else if ((rc = train_backward_mixer_params(h, d, grad)) != LS_OK || (rc = train_backward_inputs(h, d, grad)) != LS_OK ||
+               (rc = train_backward_temb(h, d, grad)) != LS_OK || (rc = train_backward_audio(h, d, grad)) != LS_OK)
         return rc;
     HIPCHK(h, hipEventRecord(h->ev[2], st));
     float tv[8] = {0};
