@@ -34,6 +34,10 @@
 #define LS_MIX_ABL 0            // A/B builds only (tools/ab_variants.py): 1 no channel-mix MFMAs, 2 no token-mix MFMAs, 4 no ring refills, 8 no k-block loop, 16 no barriers in it -- wrong results
 #endif
 
+#ifndef LS_MIX_LNSUM
+#define LS_MIX_LNSUM 1          // LayerNorm partials as centred sums (sum, sum of squares around the row's previous mean) instead of (mean, M2) Chan merges
+#endif
+
 namespace ls {
 
 constexpr int kMixThreads = 512;
@@ -153,28 +157,55 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
             m = 0.5f * (ma + mb);
         }
     };
-    // this slice's (mean, M2) of every row -> granule area `area`; `payload`: write-through stores of this workgroup are drained first
-    auto ln_publish = [&](int area, unsigned tag, bool payload) {
+    // The same statistic as plain sums around a per-row centre c: (sum (x - c), sum (x - c)^2) over the wave's 32 channels.  c = the mean the
+    // row had at the previous LayerNorm (stat[row].x: LayerNorm 2 is centred on the LayerNorm-1 mean like the rows it normalises, LayerNorm 1
+    // on the previous block's LayerNorm-2 mean, block 0 on zero), so the variance E[d^2] - E[d]^2 has no cancellation to speak of; less than half
+    // of the Chan form's vector instructions, and sums merge by addition (four waves, four slices).  -0.55 % of the step at 32 clips.
+    auto lane_sums = [&](f4 v0, f4 v1, float cc, float& sm, float& sq) {
+        const f4 c4 = (f4){cc, cc, cc, cc};
+        const f4 d0 = v0 - c4, d1 = v1 - c4;
+        const f4 t = d0 + d1;
+        const f4 qq = __builtin_elementwise_fma(d1, d1, d0 * d0);
+        sm = (t[0] + t[1]) + (t[2] + t[3]);
+        sq = (qq[0] + qq[1]) + (qq[2] + qq[3]);
+        float x0, x1;
+        xor16_pair(sm, x0, x1); sm = x0 + x1;
+        xor16_pair(sq, x0, x1); sq = x0 + x1;
+        xor32_pair(sm, x0, x1); sm = x0 + x1;
+        xor32_pair(sq, x0, x1); sq = x0 + x1;
+    };
+    // this slice's partial statistics of every row -> granule area `area`; `payload`: write-through stores of this workgroup are drained first
+    // `cen`: the rows already centred on stat[row].x (the caller has them in registers), or null
+    auto ln_publish = [&](int area, unsigned tag, bool payload, const f4 (*cen)[TH]) {
 #pragma unroll
         for (int i = 0; i < TH; ++i) {
             float m, m2;
-            lane_part(X[0][i], X[1][i], m, m2);
+            if (LS_MIX_LNSUM && cen) lane_sums(cen[0][i], cen[1][i], 0.f, m, m2);
+            else if (LS_MIX_LNSUM) lane_sums(X[0][i], X[1][i], stat[rowi(i)].x, m, m2);
+            else lane_part(X[0][i], X[1][i], m, m2);
             if (g == 0) pst[w * RP + rowi(i)] = (f2){m, m2};
         }
         if (payload) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         if (tid < S) {
             f2 pw[4];
-            float ms = 0.f, qs = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) { pw[ww] = pst[ww * RP + tid]; ms += pw[ww].x; qs += pw[ww].y; }
-            const float mt = ms * 0.25f;
-            float dd = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
+            for (int ww = 0; ww < 4; ++ww) pw[ww] = pst[ww * RP + tid];
             unsigned long long* gp = gran + (size_t)area * RP * NS * 2 + ((size_t)tid * NS + c) * 2;
-            gran_store(gp, tag, mt);
-            gran_store(gp + 1, tag, qs + 32.0f * dd);
+            if (LS_MIX_LNSUM) {
+                gran_store(gp, tag, (pw[0].x + pw[1].x) + (pw[2].x + pw[3].x));
+                gran_store(gp + 1, tag, (pw[0].y + pw[1].y) + (pw[2].y + pw[3].y));
+            } else {
+                float ms = 0.f, qs = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) { ms += pw[ww].x; qs += pw[ww].y; }
+                const float mt = ms * 0.25f;
+                float dd = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) { const float d = pw[ww].x - mt; dd = fmaf(d, d, dd); }
+                gran_store(gp, tag, mt);
+                gran_store(gp + 1, tag, qs + 32.0f * dd);
+            }
         }
     };
     // all slices' partials of every row -> stat[row] = (mean, rstd); pad rows get (0, 0)
@@ -200,6 +231,15 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
             const float pm = __uint_as_float((unsigned)x0), pq = __uint_as_float((unsigned)x1);
             float sm = pm;
             sm = dpp_add<0xB1>(sm); sm = dpp_add<0x4E>(sm);
+            if (LS_MIX_LNSUM) {
+                float q = pq;
+                q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q);
+                if (sl == 0) {
+                    const float dm = sm * (1.0f / kD), var = fmaxf(fmaf(-dm, dm, q * (1.0f / kD)), 0.f);
+                    stat[rr] = rr < S ? (f2){stat[rr].x + dm, rsqrtf(var + 1e-5f)} : (f2){0.f, 0.f};        // the sums were taken around the old stat[rr].x
+                }
+                return;
+            }
             const float mu = sm * 0.25f, d = pm - mu;
             float q = fmaf(128.0f * d, d, pq);
             q = dpp_add<0xB1>(q); q = dpp_add<0x4E>(q);
@@ -210,6 +250,10 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
         lds_barrier();
     };
 
+    if (LS_MIX_LNSUM) {            // centre of block 0's LayerNorm 1: zero
+        if (tid < RP) stat[tid] = (f2){0.f, 0.f};
+        lds_barrier();
+    }
     stamp(1);
     for (int l = 0; l < a.layers; ++l) {
         fresh();
@@ -219,7 +263,7 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
 #pragma unroll
             for (int i = 0; i < TH; ++i) if (live(i)) X[cb][i] += temb4[cb];
         // ---- block1: LN -> token mixing -> SiLU -> residual ---------------------------------------
-        ln_publish(0, ep + 2 * l + 1, false);
+        ln_publish(0, ep + 2 * l + 1, false, nullptr);
         f4 al1[NCB], be1[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) { al1[cb] = wload4(rs_ln1a, chw(cb) * 4, l * kD * 4); be1[cb] = wload4(rs_ln1b, chw(cb) * 4, l * kD * 4); }
@@ -296,7 +340,7 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
                     cen[cb][i] = live(i) ? X[cb][i] - (f4){mu1[i], mu1[i], mu1[i], mu1[i]} : (f4){0.f, 0.f, 0.f, 0.f};
                     st_sc1(cen[cb][i], xrs, ((gblk(cb) * RP + rowi(i)) * 16 + 4 * g) * 4);
                 }
-            ln_publish(1, tag2, false);       // LayerNorm-2 partials: they need no payload.  The rows are NOT waited for here: 80 KB of write-through stores
+            ln_publish(1, tag2, false, cen);  // LayerNorm-2 partials: they need no payload.  The rows are NOT waited for here: 80 KB of write-through stores
                                               // take ~5 k clocks to drain -- the ready flag goes up from inside the product (k block 2), behind the waits that are there anyway
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
@@ -415,7 +459,8 @@ __global__ __launch_bounds__(kMixThreads, 2) void k_mix(const MixArgs a) {
     // ---- poseFinal (OutputProcess, scripts/model/RAG.py poseFinal Linear) on this slice's 128 channels: a partial product over k = the slice's eight
     // 16-channel blocks into ALL output columns; the update kernel sums the four slices' partials in slice order and adds the bias.  The rows go through
     // the ring slots as in channel mixing (slot = local k block; the end-of-layer barrier has passed), the weights stream from a per-lane image.
-    // Wave (w, h): column tiles w, w + 4, ... (five at most), row tiles 5 h .. 5 h + 4.
+    // Wave (w, h): column tiles w, w + 4, ... (five at most), row tiles 5 h .. 5 h + 4.  (Dealing the 18 x 10 (column, row) tiles evenly -- 23 / 22 per
+    // wave instead of 25 / 20 -- through a per-tile predicate measured 0.8 % SLOWER: a scalar branch per MFMA costs more than the imbalance.)
     fresh();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
