@@ -39,6 +39,8 @@ rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python bench.py --steps 1
 python profiles/summarize_rocprof.py "$(ls $out/kt/*.db | head -1)" "kernel trace of bench.py --steps 1 --warmup 1 (headline workload)" "$out/kt_bench.json" > "$out/kt_bench.md"
 python profiles/dispatch_summary.py "$(ls $out/kt/*.db | head -1)" "ls::" > "$out/kt_dispatch.md"
 tools/prof_call.sh "$out/lively" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE" -- python examples/livelyspeaker_ted.py 512
+for b in 4 8 16 32 40 64 96 128; do python tools/mix_time.py $b 30 coop; python tools/mix_time.py $b 30 batch; done 2>&1 | grep -v amdgpu.ids > "$out/mix_time.txt"
+tools/prof_call.sh "$out/mixer" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS FETCH_SIZE WRITE_SIZE" -- python tools/mix_time.py 32 20 coop
 tools/prof_call.sh "$out/long" "" -- python bench.py --dataset beat150 --batch 32 --no-extra-legs --no-cpu-baseline --no-parity --no-traffic-pass --steps 1 --warmup 1 --diffusion-steps 20
 tools/prof_call.sh "$out/long256" "" -- python bench.py --dataset beat150 --batch 256 --no-extra-legs --no-cpu-baseline --no-parity --no-traffic-pass --steps 1 --warmup 1 --diffusion-steps 20
 tools/prof_call.sh "$out/train" "" -- python tools/train_perf.py ted 512 4
