@@ -531,7 +531,13 @@ int ls_train_create(const ls_train_config* cfg, ls_trainer** out) {
     if ((e = hipSetDevice(m.device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (auto& ev : h->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    {   // the side branch at the HIGHEST stream priority: a stream of another priority gets a hardware queue of its own (streams of one
+        // priority share a small pool of queues, and two that land on the same queue run their kernels in order: in a process with a
+        // dozen other streams -- bench.py -- the fork bought nothing until this), and its short kernels go ahead of the long conv launches
+        int lo = 0, hi = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&lo, &hi)) != hipSuccess) return bail("hipDeviceGetStreamPriorityRange", e);
+        if ((e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi)) != hipSuccess) return bail("hipStreamCreateWithPriority", e);
+    }
     for (auto& ev : h->evs) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (Buf* b : {&h->P, &h->M, &h->V}) {
         if ((e = b->ensure((size_t)h->flat * 4)) != hipSuccess) return bail("hipMalloc(params)", e);
