@@ -168,3 +168,53 @@ def test_one_launch_mixer_agrees_with_the_batch_level_kernels_and_the_oracle(B):
     do = max_abs(outs["auto"][pick], want)
     print(f"150 frames, B = {B}: one-launch mixer vs batch-level kernels {d:.3e}, vs oracle {do:.3e}")
     assert do < TOL
+
+
+def test_mixer_forced_on_the_step_by_step_surface(long_ctx):
+    """An engine with the one-launch mixer forced (`coop` on a long-sequence model) on the rest of the sampler's surface: the CFG forward and
+    single p_sample / ddim_sample steps (per-sample timesteps: these keep the batch-level kernels, whatever the mode), then a taped DDIM loop with
+    skipped timesteps and an init image ON the mixer (host-drawn style eps and step noise, poseFinal's per-slice partial products summed by the
+    update kernel); graph replay == plain launches."""
+    from livelyspeaker_amd import _lib
+    cfg, orc, oracle, L = (long_ctx[k] for k in ("cfg", "orc", "oracle", "L"))
+    eng = _lib.Engine(cfg.njoints, cfg.nfeats, cfg.n_prefix_tokens, cfg.audio_len, n_emotions=cfg.n_emotions, nframes=cfg.nframes)
+    try:
+        eng.load_state_dict(synth.make_state_dict(cfg))
+        eng.set_path("coop")
+        B = 3
+        y = synth.make_cond(cfg, B)
+        g = np.random.Generator(np.random.PCG64(91))
+        x = g.standard_normal((B, cfg.njoints, cfg.nfeats, cfg.nframes)).astype(np.float32)
+        eps = g.standard_normal((2, B, 512)).astype(np.float32)
+        noise = g.standard_normal(x.shape).astype(np.float32)
+        oracle.prepare(y)
+        eng.set_schedule(orc.Schedule(50, ""))
+        eng.prepare(y)
+        oc, ou, og = eng.forward(x, np.full((B,), 17), eps[0], eps[1])
+        wc, wu = oracle.forward(x, np.full((B,), 17), y, False, eps[0]), oracle.forward(x, np.full((B,), 17), y, True, eps[1])
+        d = max(max_abs(oc, wc), max_abs(ou, wu), max_abs(og, wu + 1.5 * (wc - wu)))
+        print(f"150-frame forward on a mixer-forced engine: max|hip - oracle| = {d:.3e}")
+        assert d < TOL
+        for name, resp, sampler, idx in (("p", "", L.LS_SAMPLER_DDPM, 40), ("ddim", "ddim100", L.LS_SAMPLER_DDIM, 0)):
+            sch = orc.Schedule(1000 if resp else 50, resp)
+            eng.set_schedule(sch)
+            eng.prepare(y)
+            out, x0 = eng.step(sampler, idx, x, eps[0], eps[1], noise)
+            w0 = oracle.cfg_forward(x, np.full((B,), sch.timestep_map[idx]), y, eps[0], eps[1])
+            want = orc.p_sample_update(sch, x, w0, idx, noise) if name == "p" else orc.ddim_update(sch, x, w0, idx, noise)
+            assert max_abs(x0, w0) < TOL and max_abs(out, want) < TOL, name
+        sch = orc.Schedule(1000, "ddim100")
+        skip = 94
+        eng.set_schedule(sch)
+        eng.prepare(y)
+        tape = synth.NoiseTape(cfg, B, sch.num_timesteps - skip)
+        init = synth.make_init_image(cfg, B)
+        got = eng.sample(sampler=L.LS_SAMPLER_DDIM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise, skip_timesteps=skip, init_image=init)
+        assert eng.timing()["coop_slices"] == 4
+        want = orc.sample_loop(oracle, sch, y, tape.x_init, tape.eps, tape.noise, ddim=True, skip_timesteps=skip, init_image=init)
+        assert max_abs(got, want) < TOL
+        again = eng.sample(sampler=L.LS_SAMPLER_DDIM, x_init=tape.x_init, eps_tape=tape.eps, noise_tape=tape.noise, skip_timesteps=skip, init_image=init,
+                           use_graph=False)
+        assert np.array_equal(got, again)
+    finally:
+        eng.close()
