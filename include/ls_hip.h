@@ -230,7 +230,12 @@ int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; def
  * a device with fewer CUs reach only beyond one workgroup per CU; this selector pins that form to the reference's fixtures); 6 / 7 / 8:
  * the sample-split kernel with its slicing forced to 4 / 2 / 8 channel slices per (sample, CFG pass) (mode 3 chooses per piece).  Same
  * arithmetic every way, different summation order: results agree to ~1e-5, not bitwise.  Takes effect at the next ls_prepare;
- * ls_timing.step_path reports what ran. */
+ * ls_timing.step_path reports what ran.
+ * A long-sequence model (nframes != 34) always runs on the batch-level kernels, except that with 145..160 tokens the eight blocks and
+ * poseFinal of a SAMPLING loop run in one launch of the sample-split mixer (ls_timing.coop_slices == 4; 3 launches per step instead of
+ * 21) where every launch is at least 7/8 full: 28-32 / 60-64 / 92-96 clips on 256 compute units.  There mode 2 forces the batch-level
+ * kernels and mode 3 the mixer at every batch size; the other modes mean 0.  Steps with per-sample timesteps (ls_step, ls_forward) keep
+ * the batch-level kernels. */
 int ls_set_path(ls_handle* h, int mode);
 /* The plan mode 0 makes for `batch` clips on a device of `n_cus` compute units, without a handle or a GPU (what ls_prepare decides, exposed
  * for inspection and for the CPU test suite): out10 = {pieces, then (kernel family as in ls_timing.step_path, first clip, clips) for up to
