@@ -234,7 +234,7 @@ int ls_set_precision(ls_handle* h, int mode);             /* LS_PRECISION_*; def
  * A long-sequence model (nframes != 34) always runs on the batch-level kernels, except that with 145..160 tokens the eight blocks and
  * poseFinal of a SAMPLING loop run in one launch of the sample-split mixer (ls_timing.coop_slices == 4; 3 launches per step instead of
  * 21) where every launch is at least 7/8 full: 28-32 / 60-64 / 92-96 clips on 256 compute units.  There mode 2 forces the batch-level
- * kernels and mode 3 the mixer at every batch size; the other modes mean 0.  Steps with per-sample timesteps (ls_step, ls_forward) keep
+ * kernels and mode 3 the mixer at every batch size; the other modes return LS_EUNSUPPORTED.  Steps with per-sample timesteps (ls_step, ls_forward) keep
  * the batch-level kernels. */
 int ls_set_path(ls_handle* h, int mode);
 /* The plan mode 0 makes for `batch` clips on a device of `n_cus` compute units, without a handle or a GPU (what ls_prepare decides, exposed
