@@ -423,7 +423,10 @@ class Engine:
     def set_path(self, mode):
         """'auto' (default: the sample-split kernel for small batches, one workgroup per sample otherwise), 'fused', 'batch'
         (batch-level kernels, 21 launches per step), 'coop' (sample-split kernel), 'pass' (one workgroup per (sample, CFG pass), two per
-        CU); applies from the next prepare().  None = 'auto'."""
+        CU), 'pass4' (its 4-wave form at every grid size), 'coop8' / 'coop4' / 'coop2' (the sample-split kernel with that many channel
+        slices per (sample, CFG pass)); applies from the next prepare().  None = 'auto'.  On a long-sequence model (145-160 tokens) 'auto'
+        runs the sampling loop on the one-launch mixer where every launch is at least 7/8 full, 'batch' forces the batch-level kernels and
+        'coop' the mixer at every batch size; the other modes raise (ls_set_path in include/ls_hip.h)."""
         mode = "auto" if mode is None else mode
         code = {"auto": 0, "fused": 1, "batch": 2, "coop": 3, "pass": 4, "pass4": 5, "coop4": 6, "coop2": 7, "coop8": 8}.get(mode, mode)
         self._check(self.lib.ls_set_path(self.h, int(code)), "ls_set_path")
